@@ -1,0 +1,111 @@
+/* oracle.h — CPU (float64) restatement of the SMPLSim env-step hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under smplsim_amd/ may include, link or load
+ * this; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
+ *
+ * PARITY STATUS: "parity unpinned" for the physics (mj_step): MuJoCo is a third-party
+ * dependency of the reference (pyproject.toml:21 `mujoco>=3`), its source is not in
+ * /root/reference and no wheel exists in the build container, and the reference holds no
+ * golden vectors for it.  The physics below restates MuJoCo's documented
+ * pipeline; the pure-NumPy parts of the path (Stable-PD solve, observations, rewards,
+ * quaternion helpers) ARE pinned against the reference's own code via tests/golden/.
+ */
+#ifndef SMPLSIM_ORACLE_H
+#define SMPLSIM_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OM_MAXB 64
+#define OM_MAXV (6 + 3 * (OM_MAXB - 1))
+#define OM_GEOM_BOX 0
+#define OM_GEOM_CAPSULE 1
+
+/* Primitive (uncompiled) model description: what the MJCF text says. */
+typedef struct {
+  int nbody;
+  const int32_t *parent;      /* [nbody], -1 root */
+  const double *body_pos;     /* [nbody,3] */
+  const int32_t *geom_type;   /* [nbody] */
+  const double *geom_params;  /* [nbody,10]: box: pos3 half3 quat4 ; capsule: from3 to3 radius 0 0 0 */
+  const double *density;      /* [nbody] */
+  const double *armature;     /* [nv] */
+  const double *range_deg;    /* [nv,2] */
+  const int32_t *limited;     /* [nv] */
+  int nu;
+  const int32_t *act_dof;     /* [nu] */
+  const double *kp, *kd, *torque_lim, *act_scale, *act_offset; /* [nu] */
+  const int32_t *legal_contact; /* [nbody] bodies allowed to touch the floor (contact_bodies) */
+  double timestep, gravity, solref[2], solimp[5], margin, mu, impratio;
+} om_desc;
+
+typedef struct om_model om_model;
+typedef struct om_data om_data;
+typedef struct om_env om_env;
+
+om_model *om_model_create(const om_desc *d);
+void om_model_destroy(om_model *m);
+/* compiled constants, for checking the product's compiler: field ids below */
+enum { OM_M_MASS = 0, OM_M_IPOS, OM_M_IQUAT, OM_M_INERTIA, OM_M_GPOS, OM_M_GQUAT, OM_M_GSIZE,
+       OM_M_BODY_INVW, OM_M_DOF_INVW, OM_M_RANGE };
+int om_model_get(const om_model *m, int field, double *out);
+
+om_data *om_data_create(const om_model *m);
+void om_data_destroy(om_data *d);
+enum { OM_D_QPOS = 0, OM_D_QVEL, OM_D_QACC, OM_D_WARM, OM_D_CTRL, OM_D_M, OM_D_BIAS, OM_D_XPOS, OM_D_XQUAT,
+       OM_D_LINVEL, OM_D_ANGVEL, OM_D_TOUCH, OM_D_NCON, OM_D_CON_POS, OM_D_CON_DIST, OM_D_CON_BODY,
+       OM_D_QACC_SMOOTH, OM_D_NEFC, OM_D_EFC_FORCE, OM_D_SOLVER_ITER, OM_D_ENERGY, OM_D_XIPOS,
+       OM_D_QFRC_CONSTRAINT, OM_D_CON_FRAME };
+int om_get(const om_model *m, const om_data *d, int field, double *out);
+int om_set(const om_model *m, om_data *d, int field, const double *in);
+
+void om_kinematics(const om_model *m, om_data *d);            /* mj_kinematics */
+void om_forward(const om_model *m, om_data *d);               /* mj_forward    */
+void om_step(const om_model *m, om_data *d);                  /* mj_step       */
+/* StablePDController.control (reference controllers.py:116-190) on the data's (stale) M, bias */
+void om_spd_torque(const om_model *m, const om_data *d, const double *action, double *tau);
+/* other controllers selectable by control_mode: 1 = pd (controllers.py:335-346), 2 = torque (:45-46) */
+void om_ctrl_torque(const om_model *m, const om_data *d, int control_mode, double power_scale,
+                    const double *action, double *tau);
+
+/* ---- env layer (reference humanoid_env.py / humanoid_task.py / tasks) ---- */
+enum { OM_TASK_BASE = 0, OM_TASK_SPEED = 1, OM_TASK_GETUP = 2 };
+enum { OM_INIT_DEFAULT = 0, OM_INIT_FALL = 1 };
+typedef struct {
+  int task, state_init, self_obs_v, control_mode /*0 uhc_pd,1 pd,2 torque*/;
+  int episode_length, control_freq_inv, root_height_obs;
+  double power_scale;
+  double tar_speed_min, tar_speed_max; int speed_change_min, speed_change_max;
+  double tar_height_min, tar_height_max; int height_change_min, height_change_max, recovery_steps;
+} om_env_cfg;
+
+om_env *om_env_create(const om_model *m, const om_env_cfg *cfg);
+void om_env_destroy(om_env *e);
+int om_env_obs_size(const om_env *e);
+om_data *om_env_data(om_env *e);
+/* fall_actions: [3,nu] uniform(0,1) draws (used when state_init == Fall), task_rand: [2] uniform(0,1) */
+void om_env_reset(om_env *e, const double *fall_actions, const double *task_rand, float *obs);
+void om_env_step(om_env *e, const double *action, const double *task_rand, float *obs, double *reward,
+                 int *terminated, int *truncated);
+void om_env_obs(om_env *e, float *obs);   /* compute_observations() on the current state */
+void om_quat_op(int op, const double *a, const double *b, double *out);
+/* task scalars: [cur_t, tar_speed|tar_height, change_steps, recovery_counter, prev_root_pos xyz] */
+void om_env_get_task(const om_env *e, double *out7);
+void om_env_set_task(om_env *e, const double *in7);
+
+/* obs functions alone (pinned against the reference's numpy code) */
+void om_obs_v1(int nbody, const double *qpos, const double *qvel, const double *xpos, const double *xquat,
+               int root_height_obs, float *obs);
+void om_obs_v2(int nbody, const double *xpos, const double *xquat, const double *linvel, const double *angvel,
+               int root_height_obs, float *obs);
+
+/* batched rollout on `nthreads` host threads, for the cpu_baseline timing: every env gets the
+ * same action stream layout actions[step][env][nu]; returns total env-steps done */
+long om_batch_rollout(om_env **envs, int nenv, int nsteps, const double *actions, int nthreads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

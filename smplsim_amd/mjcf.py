@@ -1,0 +1,348 @@
+"""MJCF-subset model compiler (host side, numpy f64).
+
+Replaces, for the SMPL-family humanoids the reference generates, what
+`mujoco.MjModel.from_xml_string` does at reference smpl_sim/envs/base_env.py:139-142:
+MJCF text -> flat model constants.  Only the subset of MJCF those models use is
+accepted: one free-jointed root body, every other body carrying
+exactly three hinges about its local x, y, z axes at the body origin, one box or
+capsule geom per body, a floor plane, unit-gear motors, `<default>` joint/geom
+classes without nesting.  Anything else raises `MjcfError` — the stepper's kernels
+are specialised to that structure.
+
+MuJoCo compile semantics restated here (MuJoCo >= 3 documentation; MuJoCo itself is
+not a dependency of this repo and not installed in the build container):
+  * angles are degrees (compiler default), coordinate="local";
+  * `<freejoint>` ignores `<default><joint>`: armature 0, unlimited;
+  * no `<inertial>` => body mass/inertia from its geom: mass = density * volume,
+    inertial frame = geom frame (capsule z axis along `fromto`);
+  * capsule `fromto`: geom pos = midpoint, quat = minimal rotation of +z onto
+    (to - from), size = (radius, half length);
+  * `body_invweight0[b]` = (mean diag of Jp M^-1 Jp^T, mean diag of Jr M^-1 Jr^T) with
+    the body-COM Jacobian at qpos0; `dof_invweight0` = diag(M^-1), averaged over each
+    free-joint triplet.
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+import xml.etree.ElementTree as ET
+from typing import List, Optional
+
+import numpy as np
+
+GEOM_BOX = 0
+GEOM_CAPSULE = 1
+
+
+class MjcfError(ValueError):
+    pass
+
+
+@dataclasses.dataclass
+class ModelConst:
+    """Flat constants of one SMPL-family humanoid (all float64 / int32 numpy arrays).
+
+    Body index 0 is the root (MuJoCo body id 1; the world body is implicit).
+    Dof layout (MuJoCo `qvel`): 0-2 root linear velocity (world), 3-5 root angular
+    velocity (root frame), then 3 hinge rates per body in body order.
+    `qpos`: 0-2 root position, 3-6 root quaternion wxyz, then the hinge angles.
+    """
+    nbody: int
+    nq: int
+    nv: int
+    nu: int
+    body_names: List[str]
+    body_parent: np.ndarray        # [nbody] int32, -1 for the root
+    body_pos: np.ndarray           # [nbody,3] offset in parent frame (root: initial world position)
+    body_mass: np.ndarray          # [nbody]
+    body_ipos: np.ndarray          # [nbody,3] COM in body frame
+    body_iquat: np.ndarray         # [nbody,4] inertial frame orientation (wxyz)
+    body_inertia: np.ndarray       # [nbody,3] principal moments in the inertial frame
+    geom_type: np.ndarray          # [nbody] int32 GEOM_BOX / GEOM_CAPSULE
+    geom_size: np.ndarray          # [nbody,3] box half sizes | (radius, half length, 0)
+    geom_pos: np.ndarray           # [nbody,3] geom centre in body frame
+    geom_quat: np.ndarray          # [nbody,4] geom orientation in body frame (wxyz)
+    geom_names: List[str]
+    dof_armature: np.ndarray       # [nv]
+    jnt_range: np.ndarray          # [nv,2] radians (root dofs: -inf, +inf)
+    jnt_limited: np.ndarray        # [nv] bool
+    joint_names: List[str]         # hinge joint names in dof order (len nv-6)
+    actuator_names: List[str]
+    actuator_dof: np.ndarray       # [nu] int32 dof index driven by each motor
+    actuator_gear: np.ndarray      # [nu]
+    body_invweight0: np.ndarray    # [nbody,2]
+    dof_invweight0: np.ndarray     # [nv]
+    qpos0: np.ndarray              # [nq]
+    excludes: List[tuple]
+    has_vel_sensors: bool
+    # options (MuJoCo defaults unless the env overrides; timestep is set by the env,
+    # reference base_env.py:142)
+    timestep: float = 0.002
+    gravity: float = -9.81
+    solref: tuple = (0.02, 1.0)
+    solimp: tuple = (0.9, 0.95, 0.001, 0.5, 2.0)
+    geom_margin: float = 0.001
+    friction: float = 1.0
+    impratio: float = 1.0
+
+    @property
+    def total_mass(self) -> float:
+        return float(self.body_mass.sum())
+
+
+def _floats(s, n=None):
+    v = np.array([float(x) for x in s.split()], dtype=np.float64)
+    if n is not None and v.shape[0] != n:
+        raise MjcfError(f"expected {n} numbers, got {s!r}")
+    return v
+
+
+def quat_to_mat(q):
+    w, x, y, z = q
+    return np.array([
+        [1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+        [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+        [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)],
+    ])
+
+
+def z_to_quat(vec):
+    """Minimal rotation taking +z onto `vec` (MuJoCo's fromto convention), wxyz."""
+    v = np.asarray(vec, dtype=np.float64)
+    v = v / np.linalg.norm(v)
+    axis = np.cross([0.0, 0.0, 1.0], v)
+    s = np.linalg.norm(axis)
+    if s < 1e-10:
+        axis = np.array([1.0, 0.0, 0.0])
+    else:
+        axis = axis / s
+    ang = math.atan2(s, v[2])
+    return np.concatenate([[math.cos(ang / 2)], axis * math.sin(ang / 2)])
+
+
+def geom_mass_inertia(gtype, size, density):
+    """mass and principal inertia (in the geom frame) of a uniform-density primitive."""
+    if gtype == GEOM_BOX:
+        a, b, c = size
+        m = density * 8.0 * a * b * c
+        return m, np.array([m / 3 * (b * b + c * c), m / 3 * (a * a + c * c), m / 3 * (a * a + b * b)])
+    if gtype == GEOM_CAPSULE:
+        r, hl = size[0], size[1]
+        h = 2.0 * hl
+        m_c = density * math.pi * r * r * h
+        m_s = density * 4.0 / 3.0 * math.pi * r ** 3
+        i_perp = m_c * (3 * r * r + h * h) / 12 + 0.4 * m_s * r * r + m_s * h * (3 * r + 2 * h) / 8
+        i_par = m_c * r * r / 2 + 0.4 * m_s * r * r
+        return m_c + m_s, np.array([i_perp, i_perp, i_par])
+    raise MjcfError(f"unsupported geom type {gtype}")
+
+
+def compile_mjcf(xml: str) -> ModelConst:
+    try:
+        root = ET.fromstring(xml)
+    except ET.ParseError as e:  # same failure class as MuJoCo's XML error
+        raise MjcfError(f"XML parse error: {e}") from e
+    if root.tag != "mujoco":
+        raise MjcfError("root element must be <mujoco>")
+    comp = root.find("compiler")
+    if comp is not None:
+        if comp.get("coordinate", "local") != "local":
+            raise MjcfError("only coordinate='local' is supported")
+        if comp.get("angle", "degree") != "degree":
+            raise MjcfError("only angle='degree' (the compiler default) is supported")
+    if root.find("option") is not None and len(root.find("option").attrib):
+        raise MjcfError("<option> overrides are not supported (the env sets opt.timestep itself)")
+
+    djoint, dgeom = {}, {}
+    dflt = root.find("default")
+    if dflt is not None:
+        if dflt.find("default") is not None:
+            raise MjcfError("nested default classes are not supported")
+        if dflt.find("joint") is not None:
+            djoint = dict(dflt.find("joint").attrib)
+        if dflt.find("geom") is not None:
+            dgeom = dict(dflt.find("geom").attrib)
+
+    wb = root.find("worldbody")
+    if wb is None:
+        raise MjcfError("missing <worldbody>")
+    planes = [g for g in wb.findall("geom") if g.get("type") == "plane"]
+    if len(planes) != 1:
+        raise MjcfError("exactly one floor plane geom is required in <worldbody>")
+    fl = planes[0]
+    if np.abs(_floats(fl.get("pos", "0 0 0"), 3)).max() != 0 or fl.get("quat") or fl.get("zaxis"):
+        raise MjcfError("floor plane must be z=0 with identity orientation")
+    top = wb.findall("body")
+    if len(top) != 1:
+        raise MjcfError("exactly one root body is required")
+
+    names, parent, pos = [], [], []
+    mass, ipos, iquat, inertia = [], [], [], []
+    gtype, gsize, gpos, gquat, gnames, gmargin, gfric = [], [], [], [], [], [], []
+    armature, jrange, jlimited, jnames = [], [], [], []
+
+    def add_body(b, par):
+        idx = len(names)
+        names.append(b.get("name"))
+        parent.append(par)
+        pos.append(_floats(b.get("pos", "0 0 0"), 3))
+        if b.get("quat") is not None and not np.allclose(_floats(b.get("quat"), 4), [1, 0, 0, 0]):
+            raise MjcfError(f"body {b.get('name')}: non-identity body quat is not supported")
+        if b.find("inertial") is not None:
+            raise MjcfError("explicit <inertial> is not supported (inertia comes from the geom)")
+        free = b.find("freejoint")
+        joints = b.findall("joint")
+        if par < 0:
+            if free is None or joints:
+                raise MjcfError("the root body must carry exactly one <freejoint>")
+            armature.extend([0.0] * 6)
+            jrange.extend([[-np.inf, np.inf]] * 6)
+            jlimited.extend([False] * 6)
+        else:
+            if free is not None or len(joints) != 3:
+                raise MjcfError(f"body {b.get('name')}: expected exactly 3 hinge joints")
+            for k, j in enumerate(joints):
+                a = {**djoint, **j.attrib}
+                if a.get("type", "hinge") != "hinge":
+                    raise MjcfError(f"joint {a.get('name')}: only hinge joints are supported")
+                if np.abs(_floats(a.get("pos", "0 0 0"), 3)).max() != 0:
+                    raise MjcfError(f"joint {a.get('name')}: joint anchor must be the body origin")
+                ax = _floats(a.get("axis", "0 0 1"), 3)
+                want = np.eye(3)[k]
+                if not np.array_equal(ax, want):
+                    raise MjcfError(f"joint {a.get('name')}: hinge axes must be x, y, z in this order")
+                if float(a.get("damping", 0)) != 0 or float(a.get("stiffness", 0)) != 0 \
+                        or float(a.get("frictionloss", 0)) != 0:
+                    raise MjcfError(f"joint {a.get('name')}: passive damping/stiffness/frictionloss not supported")
+                armature.append(float(a.get("armature", 0)))
+                lim = a.get("limited", "auto")
+                has_range = a.get("range") is not None
+                limited = (lim == "true") or (lim == "auto" and has_range)
+                rng = np.deg2rad(_floats(a["range"], 2)) if has_range else np.array([0.0, 0.0])
+                jrange.append(list(rng))
+                jlimited.append(bool(limited))
+                jnames.append(a.get("name"))
+        geoms = b.findall("geom")
+        if len(geoms) != 1:
+            raise MjcfError(f"body {b.get('name')}: exactly one geom per body is supported")
+        g = {**dgeom, **geoms[0].attrib}
+        if g.get("type") == "box":
+            t = GEOM_BOX
+            size = _floats(g["size"], 3)
+            p = _floats(g.get("pos", "0 0 0"), 3)
+            q = _floats(g.get("quat", "1 0 0 0"), 4)
+            q = q / np.linalg.norm(q)
+        elif g.get("type") == "capsule":
+            t = GEOM_CAPSULE
+            if g.get("fromto") is None:
+                raise MjcfError("capsules must be given by fromto")
+            ft = _floats(g["fromto"], 6)
+            r = _floats(g["size"])[0]
+            vec = ft[3:] - ft[:3]
+            size = np.array([r, 0.5 * np.linalg.norm(vec), 0.0])
+            p = 0.5 * (ft[:3] + ft[3:])
+            q = z_to_quat(vec)
+        else:
+            raise MjcfError(f"geom type {g.get('type')!r} is not supported")
+        if int(g.get("condim", 3)) != 3:
+            raise MjcfError("only condim=3 is supported")
+        m, inert = geom_mass_inertia(t, size, float(g.get("density", 1000)))
+        gtype.append(t); gsize.append(size); gpos.append(p); gquat.append(q)
+        gnames.append(g.get("name")); gmargin.append(float(g.get("margin", 0)))
+        gfric.append(_floats(g.get("friction", "1 0.005 0.0001"))[0])
+        mass.append(m); ipos.append(p); iquat.append(q); inertia.append(inert)
+        for c in b.findall("body"):
+            add_body(c, idx)
+
+    add_body(top[0], -1)
+    nbody = len(names)
+    nv = 6 + 3 * (nbody - 1)
+    nq = nv + 1
+
+    # floor mixes with each geom: margin = max, friction = max (MuJoCo contact parameter mixing)
+    fl_attr = {**dgeom, **fl.attrib}
+    margin = max(max(gmargin), float(fl_attr.get("margin", 0)))
+    mu = max(max(gfric), _floats(fl_attr.get("friction", "1 0.005 0.0001"))[0])
+    if len(set(gmargin)) != 1 or len(set(gfric)) != 1:
+        raise MjcfError("per-geom margin/friction variation is not supported")
+
+    act = root.find("actuator")
+    anames, adof, agear = [], [], []
+    if act is not None:
+        for m_ in act:
+            if m_.tag != "motor":
+                raise MjcfError("only <motor> actuators are supported")
+            if m_.get("ctrlrange") or m_.get("ctrllimited") == "true" or m_.get("forcerange"):
+                raise MjcfError("actuator ctrl/force ranges are not supported")
+            jn = m_.get("joint")
+            if jn not in jnames:
+                raise MjcfError(f"motor {m_.get('name')}: unknown joint {jn}")
+            anames.append(m_.get("name")); adof.append(6 + jnames.index(jn)); agear.append(float(m_.get("gear", "1").split()[0]))
+    con = root.find("contact")
+    excludes = [(e.get("body1"), e.get("body2")) for e in con.findall("exclude")] if con is not None else []
+    sen = root.find("sensor")
+    has_sens = sen is not None and len(sen.findall("framelinvel")) == nbody and len(sen.findall("frameangvel")) == nbody
+
+    qpos0 = np.zeros(nq)
+    qpos0[:3] = pos[0]
+    qpos0[3] = 1.0
+    mc = ModelConst(
+        nbody=nbody, nq=nq, nv=nv, nu=len(anames), body_names=names,
+        body_parent=np.array(parent, dtype=np.int32), body_pos=np.array(pos),
+        body_mass=np.array(mass), body_ipos=np.array(ipos), body_iquat=np.array(iquat),
+        body_inertia=np.array(inertia), geom_type=np.array(gtype, dtype=np.int32),
+        geom_size=np.array(gsize), geom_pos=np.array(gpos), geom_quat=np.array(gquat), geom_names=gnames,
+        dof_armature=np.array(armature), jnt_range=np.array(jrange), jnt_limited=np.array(jlimited),
+        joint_names=jnames, actuator_names=anames, actuator_dof=np.array(adof, dtype=np.int32),
+        actuator_gear=np.array(agear), body_invweight0=np.zeros((nbody, 2)), dof_invweight0=np.zeros(nv),
+        qpos0=qpos0, excludes=excludes, has_vel_sensors=bool(has_sens),
+        geom_margin=margin, friction=mu,
+    )
+    _set_invweight0(mc)
+    return mc
+
+
+def body_com_jacobians_qpos0(mc: ModelConst):
+    """Dense 6 x nv Jacobians (linear over angular) of every body COM at qpos0, and world COMs."""
+    nb, nv = mc.nbody, mc.nv
+    xpos = np.zeros((nb, 3))
+    for b in range(nb):
+        p = mc.body_parent[b]
+        xpos[b] = mc.body_pos[b] + (xpos[p] if p >= 0 else 0.0)   # all frames are identity at qpos0
+    com = xpos + mc.body_ipos
+    J = np.zeros((nb, 6, nv))
+    eye = np.eye(3)
+    for b in range(nb):
+        J[b, 0:3, 0:3] = eye
+        a = b
+        while a >= 0:
+            base = 3 if a == 0 else 6 + 3 * (a - 1)
+            for k in range(3):
+                J[b, 3:6, base + k] = eye[k]
+                J[b, 0:3, base + k] = np.cross(eye[k], com[b] - xpos[a])
+            a = mc.body_parent[a]
+    return J, com
+
+
+def mass_matrix_qpos0(mc: ModelConst):
+    J, _ = body_com_jacobians_qpos0(mc)
+    M = np.diag(mc.dof_armature.copy())
+    for b in range(mc.nbody):
+        R = quat_to_mat(mc.body_iquat[b])
+        Iw = R @ np.diag(mc.body_inertia[b]) @ R.T
+        M += mc.body_mass[b] * J[b, 0:3].T @ J[b, 0:3] + J[b, 3:6].T @ Iw @ J[b, 3:6]
+    return M
+
+
+def _set_invweight0(mc: ModelConst):
+    M = mass_matrix_qpos0(mc)
+    Minv = np.linalg.inv(M)
+    J, _ = body_com_jacobians_qpos0(mc)
+    for b in range(mc.nbody):
+        A = J[b] @ Minv @ J[b].T
+        mc.body_invweight0[b, 0] = np.trace(A[0:3, 0:3]) / 3
+        mc.body_invweight0[b, 1] = np.trace(A[3:6, 3:6]) / 3
+    d = np.diag(Minv).copy()
+    d[0:3] = d[0:3].mean()
+    d[3:6] = d[3:6].mean()
+    mc.dof_invweight0[:] = d
