@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/sec of the fused SMPL env step on N MI355X (BASELINE.json metric).
+
+Workload (BASELINE config 2): 4096 SMPL humanoids per GPU, flat ground, Stable-PD with fresh
+uniform(-1,1) actions every control step, obs v1 + reward + reset flags computed in the step
+launch, device-side autoreset.  One "step" = one control step of every env on every rank
+(15 mj_steps each).  Weak scaling: independent shards, no collective in the data path.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ENVS_PER_GPU = 4096
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def algorithmic_bytes(nq, nv, nu, nobs):
+    # read qpos,qvel,action + write qpos,qvel,obs,reward + 2 flag bytes
+    return 4 * (2 * nq + 2 * nv + nu + nobs + 1) + 2
+
+
+def cpu_baseline(seconds=12.0):
+    """The CPU oracle (float64 C restatement; 'port', NOT MuJoCo — MuJoCo is not installable here) on the
+    host cores, same workload shape, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import oracle_model
+    from oracle import oracle as O
+    cores = len(os.sched_getaffinity(0))
+    om = oracle_model()
+    nenv = cores * 4
+    envs = [O.OracleEnv(om) for _ in range(nenv)]
+    for e in envs:
+        e.reset()
+    rs = np.random.default_rng(1234)
+    steps = 8
+    acts = rs.uniform(-1, 1, (steps, nenv, 69))
+    t0 = time.perf_counter()
+    done = O.batch_rollout(envs, acts, cores)
+    dt = time.perf_counter() - t0
+    rate = done / dt
+    # scale the sample to ~`seconds` of CPU work
+    steps2 = max(steps, int(steps * seconds / max(dt, 1e-3)))
+    steps2 = min(steps2, 400)
+    acts = rs.uniform(-1, 1, (steps2, nenv, 69))
+    t0 = time.perf_counter()
+    done = O.batch_rollout(envs, acts, cores)
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{nenv} envs x {steps2} control steps, uniform(-1,1) actions, float64 C oracle "
+                      f"(oracle/oracle.c), one env per thread-slice over {cores} threads, {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from smplsim_amd.batch import SMPLSimVecEnv
+    N = args.envs_per_gpu
+    env = SMPLSimVecEnv(N, device=local_rank, task="HumanoidEnv", state_init="Default", self_obs_v=1,
+                        autoreset=True, seed=1234 + rank)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    env.reset()
+
+    def one_step():
+        a = torch.rand(N, env.nu, generator=g, device=dev) * 2 - 1
+        env.step(a)
+
+    for _ in range(args.warmup):
+        one_step()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # per-launch duration of the dominant kernel (the fused step), HIP events on the launch stream
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    import ctypes as C
+    from smplsim_amd.batch import _check, _ptr, lib
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        a = torch.rand(N, env.nu, generator=g, device=dev) * 2 - 1
+        ev0[i].record()
+        _check(lib().ss_step(env.handle, _ptr(a), None, _ptr(env.obs_buf), _ptr(env.rew_buf), _ptr(env.terminated),
+                             _ptr(env.truncated), env._stream()))
+        ev1[i].record()
+        torch.bitwise_or(env.terminated, env.truncated, out=env.reset_buf)
+        _check(lib().ss_reset(env.handle, _ptr(env.reset_buf), None, None, _ptr(env.obs_buf), env._stream()))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    finite = bool(torch.isfinite(env.obs_buf).all().item())
+    nwarn = int(env.nwarn.sum().item())
+    iters = float(env.solver_iters.float().mean().item())
+
+    if rank == 0:
+        total_envs = N * world
+        value = total_envs * args.steps / elapsed
+        bstep = algorithmic_bytes(env.nq, env.nv, env.nu, env.obs_size)
+        ach = N * bstep / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "env-steps/sec (whole node), 4096-env SMPL rollout", "value": value, "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE config 2: {N} SMPL humanoids per GPU (24 bodies, nv=75), flat ground, "
+                                   "Stable-PD, fresh uniform(-1,1) actions per control step, 15 mj_steps @450 Hz per "
+                                   "step, obs v1 (289 f32) + reward + reset flags fused, device-side autoreset",
+                       "envs_per_gpu": N, "parallelism": f"independent shards x{world} (no collective)",
+                       "launch": env.launch_info(), "mean_newton_iters_per_step": iters, "autoresets_total": nwarn,
+                       "obs_finite": finite},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "ss_env_kernel<2,2> (MODE_STEP)", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_env_step": bstep,
+                         "note": "path is LDS-latency/VALU bound, not HBM bound (DESIGN.md §roofline)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

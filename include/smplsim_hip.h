@@ -1,0 +1,140 @@
+/* smplsim_hip.h — C ABI of libsmplsim_hip.so, the MI355X (gfx950) batched SMPL-humanoid env stepper.
+ *
+ * The reference (ZhengyiLuo/SMPLSim) has no FFI of its own on this path: `HumanoidEnv.step()`
+ * calls the MuJoCo C API through its Python bindings and SciPy/LAPACK
+ * (reference smpl_sim/envs/humanoid_env.py:439-469, smpl_sim/envs/controllers.py:116-190).
+ * Each entry point below names the reference call(s) it replaces.  Conventions follow
+ * plain pointers and sizes, no torch types; every function returns 0 on
+ * success or a negative ss_status and records a message retrievable with ss_last_error();
+ * all device work is enqueued on the caller's hipStream_t (passed as void*) and is
+ * asynchronous w.r.t. the host; the caller owns every state/IO buffer (device pointers
+ * taken from PyTorch-ROCm tensors), the library owns only the model tables.
+ *
+ * State layout (struct-of-arrays by field, env-major rows, float32): one wavefront steps one
+ * env, so each row `field[env, :]` is a contiguous segment read/written with coalesced loads.
+ */
+#ifndef SMPLSIM_HIP_H
+#define SMPLSIM_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  SS_OK = 0,
+  SS_ERR_INVALID = -1,      /* bad argument / unsupported model */
+  SS_ERR_HIP = -2,          /* a HIP runtime call failed */
+  SS_ERR_NOMEM = -3,
+  SS_ERR_LDS = -4           /* model does not fit the 160 KiB LDS budget */
+} ss_status;
+
+enum { SS_GEOM_BOX = 0, SS_GEOM_CAPSULE = 1 };
+enum { SS_TASK_BASE = 0, SS_TASK_SPEED = 1, SS_TASK_GETUP = 2 };      /* reference tasks/humanoid_{speed,getup}.py */
+enum { SS_INIT_DEFAULT = 0, SS_INIT_FALL = 1 };                        /* HumanoidEnv.StateInit, humanoid_env.py:141-146 */
+enum { SS_CTRL_UHC_PD = 0, SS_CTRL_PD = 1, SS_CTRL_TORQUE = 2 };       /* control_mode, humanoid_env.py:312-323 */
+
+/* Compiled model constants (host pointers, float64; produced by smplsim_amd.mjcf.compile_mjcf).
+ * Replaces the mjModel built by mujoco.MjModel.from_xml_string (reference base_env.py:139-142)
+ * plus the per-actuator tables of HumanoidEnv.build_pd_action_scale (humanoid_env.py:325-370). */
+typedef struct {
+  int32_t nbody;                 /* bodies without the world body; nv = 6 + 3*(nbody-1), nq = nv+1 */
+  const int32_t *body_parent;    /* [nbody] (-1 root), parents precede children */
+  const double *body_pos;        /* [nbody,3] */
+  const double *body_mass;       /* [nbody] */
+  const double *body_ipos;       /* [nbody,3] */
+  const double *body_iquat;      /* [nbody,4] wxyz */
+  const double *body_inertia;    /* [nbody,3] principal */
+  const int32_t *geom_type;      /* [nbody] */
+  const double *geom_size;       /* [nbody,3] */
+  const double *geom_pos;        /* [nbody,3] */
+  const double *geom_quat;       /* [nbody,4] */
+  const double *dof_armature;    /* [nv] */
+  const double *jnt_range;       /* [nv,2] radians */
+  const uint8_t *jnt_limited;    /* [nv] */
+  const double *body_invweight0; /* [nbody,2] */
+  const double *dof_invweight0;  /* [nv] */
+  const double *qpos0;           /* [nq] */
+  int32_t nu;
+  const int32_t *actuator_dof;   /* [nu] */
+  const double *kp, *kd, *torque_lim, *act_scale, *act_offset;   /* [nu] */
+  const uint8_t *legal_contact;  /* [nbody] bodies allowed to touch the floor (cfg.env.contact_bodies) */
+  double timestep, gravity, solref[2], solimp[5], margin, friction, impratio;
+} ss_model_desc;
+
+/* Environment configuration (reference smpl_sim/data/cfg/env/*.yaml keys). */
+typedef struct {
+  int32_t task, state_init, self_obs_v, control_mode;
+  int32_t episode_length, control_freq_inv, root_height_obs;
+  float power_scale;
+  float tar_speed_min, tar_speed_max; int32_t speed_change_min, speed_change_max;
+  float tar_height_min, tar_height_max; int32_t height_change_min, height_change_max, recovery_steps;
+  int32_t newton_iters;          /* max Newton iterations of the constraint solve per substep (default 8) */
+} ss_env_cfg;
+
+/* Device buffers of one shard of environments (all caller-owned, float32 unless noted). */
+typedef struct {
+  int32_t num_envs;
+  float *qpos;        /* [N,nq]  mjData.qpos */
+  float *qvel;        /* [N,nv]  mjData.qvel */
+  float *qpos_prev;   /* [N,nq]  state at which the last mj_forward ran (source of the stale qM, qfrc_bias */
+  float *qvel_prev;   /* [N,nv]   that StablePDController reads; SURVEY.md §3.2 "staleness subtlety") */
+  float *qacc_warm;   /* [N,nv]  mjData.qacc_warmstart */
+  float *body_vel;    /* [N,nbody,6] world lin(3)+ang(3) velocity of every body frame at the last forward
+                                   (the framelinvel/frameangvel sensors, humanoid_env.py:539-544) */
+  int32_t *touch;     /* [N,2]   bit b of the 64-bit mask set: body b touched the floor at the last forward (mjData.contact) */
+  int32_t *cur_t;     /* [N]     BaseEnv.cur_t */
+  float *task;        /* [N,4]   tar_speed|tar_height, change_steps, recovery_counter, unused */
+  int32_t *nwarn;     /* [N]     count of MuJoCo-style autoresets (mj_checkPos/Vel/Acc) */
+  int32_t *solver_iters; /* [N]  Newton iterations spent in the last step (diagnostic) */
+} ss_state;
+
+typedef struct ss_model ss_model;
+typedef struct ss_batch ss_batch;
+
+/* mujoco.MjModel.from_xml_string + setup_humanoid_properties + setup_controller */
+int ss_model_create(const ss_model_desc *desc, int device_id, ss_model **out);
+void ss_model_destroy(ss_model *m);
+/* nq, nv, nu, nbody, obs size for (self_obs_v, task, root_height_obs) — humanoid_env.py:293-299 */
+int ss_model_dims(const ss_model *m, int32_t *nq, int32_t *nv, int32_t *nu, int32_t *nbody);
+int ss_obs_size(const ss_model *m, const ss_env_cfg *cfg);
+
+/* mujoco.MjData(model) for N envs: binds caller-owned state buffers */
+int ss_batch_create(const ss_model *m, const ss_env_cfg *cfg, const ss_state *state, ss_batch **out);
+void ss_batch_destroy(ss_batch *b);
+
+/* HumanoidEnv.reset()/HumanoidTask.reset() (humanoid_env.py:471-512, humanoid_task.py:6-9) for the envs
+ * whose mask byte is non-zero (mask NULL = all).  fall_actions [N,3,nu] uniform(0,1) draws consumed by
+ * StateInit.Fall (may be NULL for Default); task_rand [N,2] uniform(0,1) draws for target resampling
+ * (may be NULL for the base task).  obs [N,obs_size] is written for the reset envs only. */
+int ss_reset(ss_batch *b, const uint8_t *mask, const float *fall_actions, const float *task_rand,
+             float *obs, void *stream);
+
+/* BaseEnv.step(): control_freq_inv x (controller + mj_step) + observation + reward + reset flags, one
+ * launch (humanoid_env.py:439-469; controllers.py:116-190; tasks compute_reward/compute_reset).
+ * actions [N,nu]; obs [N,obs_size]; reward [N]; terminated, truncated [N] bytes. */
+int ss_step(ss_batch *b, const float *actions, const float *task_rand, float *obs, float *reward,
+            uint8_t *terminated, uint8_t *truncated, void *stream);
+
+/* n x (controller + mj_step) without the env epilogue — substep-granular parity/debugging */
+int ss_substep(ss_batch *b, const float *actions, int n_substeps, void *stream);
+
+/* mj_kinematics readback: xpos [N,nbody,3], xquat-equivalent rotation matrices xmat [N,nbody,9] */
+int ss_kinematics(ss_batch *b, float *xpos, float *xmat, void *stream);
+
+/* Diagnostics for parity triage: one mj_forward at (qpos, qvel) with raw joint torques [N,nu] (NULL = 0);
+ * writes the tree-sparse mass-matrix entries [N,ne] (mj_fullM's data before scattering), qfrc_bias [N,nv]
+ * and the constrained qacc [N,nv].  ss_debug_decode returns for every sparse entry (row_dof << 16 | col_dof). */
+int ss_debug_forward(ss_batch *b, const float *torques, float *M_entries, float *bias, float *qacc, void *stream);
+int ss_debug_decode(const ss_model *m, int32_t *out, int32_t *ne);
+
+/* launch geometry actually used (envs per workgroup, LDS bytes per workgroup) */
+int ss_launch_info(const ss_batch *b, int32_t *envs_per_wg, int32_t *lds_bytes, int32_t *kernel_regs);
+
+const char *ss_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

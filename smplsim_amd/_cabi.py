@@ -1,0 +1,113 @@
+"""ctypes declarations of the C ABI in include/smplsim_hip.h (structs + prototypes).
+
+Pure declarations: `bind(cdll)` attaches argtypes/restypes to an already-loaded library.
+The product loads libsmplsim_hip.so through smplsim_amd/_lib.py; tests bind the same
+declarations onto the wavefront-emulator build of the kernel source.
+"""
+import ctypes as C
+
+import numpy as np
+
+TASK_BASE, TASK_SPEED, TASK_GETUP = 0, 1, 2
+INIT_DEFAULT, INIT_FALL = 0, 1
+CTRL_UHC_PD, CTRL_PD, CTRL_TORQUE = 0, 1, 2
+TASKS = {"HumanoidEnv": TASK_BASE, "HumanoidSpeed": TASK_SPEED, "HumanoidGetup": TASK_GETUP}
+CONTROL_MODES = {"uhc_pd": CTRL_UHC_PD, "pd": CTRL_PD, "torque": CTRL_TORQUE}
+STATE_INITS = {"Default": INIT_DEFAULT, "Fall": INIT_FALL}
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [
+        ("nbody", C.c_int32), ("body_parent", C.c_void_p), ("body_pos", C.c_void_p), ("body_mass", C.c_void_p),
+        ("body_ipos", C.c_void_p), ("body_iquat", C.c_void_p), ("body_inertia", C.c_void_p),
+        ("geom_type", C.c_void_p), ("geom_size", C.c_void_p), ("geom_pos", C.c_void_p), ("geom_quat", C.c_void_p),
+        ("dof_armature", C.c_void_p), ("jnt_range", C.c_void_p), ("jnt_limited", C.c_void_p),
+        ("body_invweight0", C.c_void_p), ("dof_invweight0", C.c_void_p), ("qpos0", C.c_void_p),
+        ("nu", C.c_int32), ("actuator_dof", C.c_void_p), ("kp", C.c_void_p), ("kd", C.c_void_p),
+        ("torque_lim", C.c_void_p), ("act_scale", C.c_void_p), ("act_offset", C.c_void_p),
+        ("legal_contact", C.c_void_p),
+        ("timestep", C.c_double), ("gravity", C.c_double), ("solref", C.c_double * 2), ("solimp", C.c_double * 5),
+        ("margin", C.c_double), ("friction", C.c_double), ("impratio", C.c_double),
+    ]
+
+
+class EnvCfg(C.Structure):
+    _fields_ = [
+        ("task", C.c_int32), ("state_init", C.c_int32), ("self_obs_v", C.c_int32), ("control_mode", C.c_int32),
+        ("episode_length", C.c_int32), ("control_freq_inv", C.c_int32), ("root_height_obs", C.c_int32),
+        ("power_scale", C.c_float),
+        ("tar_speed_min", C.c_float), ("tar_speed_max", C.c_float), ("speed_change_min", C.c_int32),
+        ("speed_change_max", C.c_int32),
+        ("tar_height_min", C.c_float), ("tar_height_max", C.c_float), ("height_change_min", C.c_int32),
+        ("height_change_max", C.c_int32), ("recovery_steps", C.c_int32), ("newton_iters", C.c_int32),
+    ]
+
+
+class State(C.Structure):
+    _fields_ = [
+        ("num_envs", C.c_int32), ("qpos", C.c_void_p), ("qvel", C.c_void_p), ("qpos_prev", C.c_void_p),
+        ("qvel_prev", C.c_void_p), ("qacc_warm", C.c_void_p), ("body_vel", C.c_void_p), ("touch", C.c_void_p),
+        ("cur_t", C.c_void_p), ("task", C.c_void_p), ("nwarn", C.c_void_p), ("solver_iters", C.c_void_p),
+    ]
+
+
+def bind(lib):
+    vp = C.c_void_p
+    lib.ss_model_create.argtypes = [C.POINTER(ModelDesc), C.c_int, C.POINTER(vp)]
+    lib.ss_model_destroy.argtypes = [vp]; lib.ss_model_destroy.restype = None
+    lib.ss_model_dims.argtypes = [vp] + [C.POINTER(C.c_int32)] * 4
+    lib.ss_obs_size.argtypes = [vp, C.POINTER(EnvCfg)]
+    lib.ss_batch_create.argtypes = [vp, C.POINTER(EnvCfg), C.POINTER(State), C.POINTER(vp)]
+    lib.ss_batch_destroy.argtypes = [vp]; lib.ss_batch_destroy.restype = None
+    lib.ss_reset.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.ss_step.argtypes = [vp] * 8
+    lib.ss_substep.argtypes = [vp, vp, C.c_int, vp]
+    lib.ss_kinematics.argtypes = [vp, vp, vp, vp]
+    lib.ss_debug_forward.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.ss_debug_decode.argtypes = [vp, vp, C.POINTER(C.c_int32)]
+    lib.ss_launch_info.argtypes = [vp] + [C.POINTER(C.c_int32)] * 3
+    lib.ss_last_error.argtypes = []; lib.ss_last_error.restype = C.c_char_p
+    return lib
+
+
+EXPORTS = ["ss_model_create", "ss_model_destroy", "ss_model_dims", "ss_obs_size", "ss_batch_create",
+           "ss_batch_destroy", "ss_reset", "ss_step", "ss_substep", "ss_kinematics", "ss_debug_forward",
+           "ss_debug_decode", "ss_launch_info", "ss_last_error"]
+
+
+def make_model_desc(mc, kp, kd, torque_lim, act_scale, act_offset, legal_bodies=(), timestep=1.0 / 450):
+    """ModelConst (smplsim_amd.mjcf) + actuator tables -> (ModelDesc, keepalive list)."""
+    keep = []
+
+    def arr(x, dt):
+        a = np.ascontiguousarray(x, dtype=dt)
+        keep.append(a)
+        return a.ctypes.data_as(C.c_void_p)
+
+    d = ModelDesc()
+    d.nbody = mc.nbody
+    d.body_parent = arr(mc.body_parent, np.int32)
+    for name in ("body_pos", "body_mass", "body_ipos", "body_iquat", "body_inertia", "geom_size", "geom_pos",
+                 "geom_quat", "dof_armature", "jnt_range", "body_invweight0", "dof_invweight0", "qpos0"):
+        setattr(d, name, arr(getattr(mc, name), np.float64))
+    d.geom_type = arr(mc.geom_type, np.int32)
+    d.jnt_limited = arr(mc.jnt_limited, np.uint8)
+    d.nu = mc.nu
+    d.actuator_dof = arr(mc.actuator_dof, np.int32)
+    d.kp, d.kd, d.torque_lim = arr(kp, np.float64), arr(kd, np.float64), arr(torque_lim, np.float64)
+    d.act_scale, d.act_offset = arr(act_scale, np.float64), arr(act_offset, np.float64)
+    d.legal_contact = arr([int(n in legal_bodies) for n in mc.body_names], np.uint8)
+    d.timestep, d.gravity = timestep, mc.gravity
+    d.solref = (C.c_double * 2)(*mc.solref)
+    d.solimp = (C.c_double * 5)(*mc.solimp)
+    d.margin, d.friction, d.impratio = mc.geom_margin, mc.friction, mc.impratio
+    return d, keep
+
+
+def make_env_cfg(task=TASK_BASE, state_init=INIT_DEFAULT, self_obs_v=1, control_mode=CTRL_UHC_PD,
+                 episode_length=300, control_freq_inv=15, root_height_obs=True, power_scale=1.0,
+                 tar_speed=(0.0, 5.0), speed_change=(100, 200), tar_height=(0.5, 1.2), height_change=(100, 200),
+                 recovery_steps=60, newton_iters=8):
+    return EnvCfg(task, state_init, self_obs_v, control_mode, episode_length, control_freq_inv, int(root_height_obs),
+                  power_scale, tar_speed[0], tar_speed[1], speed_change[0], speed_change[1], tar_height[0],
+                  tar_height[1], height_change[0], height_change[1], recovery_steps, newton_iters)

@@ -1,0 +1,201 @@
+"""Batched env on one GPU shard: torch tensors in, torch tensors out, one HIP launch per step.
+
+Mirrors the tensor surface of the reference's Isaac path (`GymVectEnv`, reference
+smpl_sim/envs/nv/gymwrapper.py:7-65: step(actions[N,nu]) -> obs[N,D], rew[N], terminated[N],
+truncated[N], info with autoreset) on top of the MuJoCo-semantics stepper, keeping MuJoCo's
+wxyz / qpos / qvel packing.  PyTorch is only the owner of device memory and
+streams here; all arithmetic happens in libsmplsim_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _cabi
+from ._lib import lib
+from .gains import build_pd_tables
+from .mjcf import compile_mjcf
+from .mjcf_writer import default_xml_str
+
+DEFAULT_CONTACT_BODIES = ("R_Ankle", "L_Ankle", "R_Toe", "L_Toe")
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError(f"libsmplsim_hip error {rc}: {lib().ss_last_error().decode()}")
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class ShardModel:
+    """Compiled model + device tables (ss_model) for one device."""
+
+    def __init__(self, xml=None, humanoid="smpl_humanoid", device=0, contact_bodies=DEFAULT_CONTACT_BODIES,
+                 control_mode="uhc_pd", clip_actions=True, pdp_scale=1.0, pdd_scale=1.0, sim_timestep_inv=450):
+        self.xml = xml if xml is not None else default_xml_str(humanoid)
+        self.mc = compile_mjcf(self.xml)
+        rng = {n: self.mc.jnt_range[6 + i] for i, n in enumerate(self.mc.joint_names)}
+        self.tables = build_pd_tables(self.mc.actuator_names, lambda n: rng[n], clip_actions=clip_actions,
+                                      control_mode=control_mode, pdp_scale=pdp_scale, pdd_scale=pdd_scale)
+        self.device = int(device)
+        desc, self._keep = _cabi.make_model_desc(self.mc, *self.tables, legal_bodies=tuple(contact_bodies),
+                                                 timestep=1.0 / sim_timestep_inv)
+        self.handle = C.c_void_p()
+        _check(lib().ss_model_create(C.byref(desc), self.device, C.byref(self.handle)))
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h:
+            try:
+                lib().ss_model_destroy(h)
+            except Exception:
+                pass
+
+
+class SMPLSimVecEnv:
+    """N environments on one GPU.  All tensors live on `cuda:<device>` and are updated in place."""
+
+    def __init__(self, num_envs, model=None, device=0, task="HumanoidEnv", state_init="Default", self_obs_v=1,
+                 control_mode="uhc_pd", episode_length=300, control_freq_inv=15, root_height_obs=True,
+                 power_scale=1.0, tar_speed=(0.0, 5.0), speed_change=(100, 200), tar_height=(0.5, 1.2),
+                 height_change=(100, 200), recovery_steps=60, newton_iters=8, autoreset=True, seed=0, **model_kw):
+        if not torch.cuda.is_available():
+            raise RuntimeError("SMPLSimVecEnv needs a ROCm GPU (MI355X); there is no CPU fallback")
+        self.model = model if model is not None else ShardModel(device=device, control_mode=control_mode, **model_kw)
+        mc = self.model.mc
+        self.num_envs, self.device = int(num_envs), torch.device("cuda", self.model.device)
+        self.nq, self.nv, self.nu, self.nbody = mc.nq, mc.nv, mc.nu, mc.nbody
+        self.task_id = _cabi.TASKS[task] if isinstance(task, str) else int(task)
+        self.state_init = _cabi.STATE_INITS[state_init] if isinstance(state_init, str) else int(state_init)
+        self.cfg = _cabi.make_env_cfg(
+            task=self.task_id, state_init=self.state_init, self_obs_v=self_obs_v,
+            control_mode=_cabi.CONTROL_MODES[control_mode], episode_length=episode_length,
+            control_freq_inv=control_freq_inv, root_height_obs=root_height_obs, power_scale=power_scale,
+            tar_speed=tar_speed, speed_change=speed_change, tar_height=tar_height, height_change=height_change,
+            recovery_steps=recovery_steps, newton_iters=newton_iters)
+        N, dev = self.num_envs, self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.qpos = torch.zeros(N, self.nq, **f32); self.qvel = torch.zeros(N, self.nv, **f32)
+        self.qpos_prev = torch.zeros(N, self.nq, **f32); self.qvel_prev = torch.zeros(N, self.nv, **f32)
+        self.qacc_warm = torch.zeros(N, self.nv, **f32); self.body_vel = torch.zeros(N, self.nbody, 6, **f32)
+        self.touch = torch.zeros(N, 2, **i32); self.cur_t = torch.zeros(N, **i32)
+        self.task_state = torch.zeros(N, 4, **f32); self.nwarn = torch.zeros(N, **i32)
+        self.solver_iters = torch.zeros(N, **i32)
+        self.qpos[:, 3] = 1; self.qpos_prev[:, 3] = 1
+        st = _cabi.State(N, *[_ptr(t) for t in (self.qpos, self.qvel, self.qpos_prev, self.qvel_prev, self.qacc_warm,
+                                               self.body_vel, self.touch, self.cur_t, self.task_state, self.nwarn,
+                                               self.solver_iters)])
+        self.handle = C.c_void_p()
+        _check(lib().ss_batch_create(self.model.handle, C.byref(self.cfg), C.byref(st), C.byref(self.handle)))
+        self.obs_size = lib().ss_obs_size(self.model.handle, C.byref(self.cfg))
+        self.obs_buf = torch.zeros(N, self.obs_size, **f32)
+        self.rew_buf = torch.zeros(N, **f32)
+        self.terminated = torch.zeros(N, dtype=torch.uint8, device=dev)
+        self.truncated = torch.zeros(N, dtype=torch.uint8, device=dev)
+        self.reset_buf = torch.zeros(N, dtype=torch.uint8, device=dev)
+        self.autoreset = autoreset
+        self.gen = torch.Generator(device=dev)
+        self.gen.manual_seed(int(seed))
+        self.action_size = self.nu
+        self.actuator_names = list(mc.actuator_names)
+        self._keep = self._keep2 = None
+
+    # ---- random inputs the reference draws from np.random inside the env (targets, Fall actions)
+    def _task_rand(self):
+        if self.task_id == _cabi.TASK_BASE:
+            return None
+        return torch.rand(self.num_envs, 2, generator=self.gen, device=self.device)
+
+    def _fall_actions(self):
+        if self.state_init != _cabi.INIT_FALL:
+            return None
+        return torch.rand(self.num_envs, 3, self.nu, generator=self.gen, device=self.device)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def reset(self, mask=None, fall_actions=None, task_rand=None):
+        """Reset all envs (mask None) or those with mask != 0.  Returns (obs, info)."""
+        fa = fall_actions if fall_actions is not None else self._fall_actions()
+        tr = task_rand if task_rand is not None else self._task_rand()
+        m = None if mask is None else mask.to(torch.uint8).contiguous()
+        self._keep = (fa, tr, m)
+        _check(lib().ss_reset(self.handle, _ptr(m), _ptr(fa), _ptr(tr), _ptr(self.obs_buf), self._stream()))
+        return self.obs_buf, {"critic_state": self.obs_buf}
+
+    def step(self, actions, task_rand=None):
+        actions = actions.to(torch.float32).contiguous()
+        assert actions.shape == (self.num_envs, self.nu) and actions.device == self.device
+        tr = task_rand if task_rand is not None else self._task_rand()
+        self._keep = (actions, tr)
+        _check(lib().ss_step(self.handle, _ptr(actions), _ptr(tr), _ptr(self.obs_buf), _ptr(self.rew_buf),
+                             _ptr(self.terminated), _ptr(self.truncated), self._stream()))
+        info = {}
+        if self.autoreset:
+            # autoreset of finished envs: device-side mask, no host sync (GymVectEnv semantics,
+            # reference nv/gymwrapper.py:53-60; the pre-reset observation is kept for the learner)
+            torch.bitwise_or(self.terminated, self.truncated, out=self.reset_buf)
+            info["final_observation"] = self.obs_buf.clone()
+            fa, tr2 = self._fall_actions(), self._task_rand()
+            self._keep2 = (fa, tr2)
+            _check(lib().ss_reset(self.handle, _ptr(self.reset_buf), _ptr(fa), _ptr(tr2), _ptr(self.obs_buf),
+                                  self._stream()))
+        info["critic_state"] = self.obs_buf
+        return self.obs_buf, self.rew_buf, self.terminated.bool(), self.truncated.bool(), info
+
+    def substep(self, actions, n):
+        actions = actions.to(torch.float32).contiguous()
+        self._keep = (actions,)
+        _check(lib().ss_substep(self.handle, _ptr(actions), int(n), self._stream()))
+
+    def kinematics(self):
+        xpos = torch.zeros(self.num_envs, self.nbody, 3, device=self.device)
+        xmat = torch.zeros(self.num_envs, self.nbody, 9, device=self.device)
+        _check(lib().ss_kinematics(self.handle, _ptr(xpos), _ptr(xmat), self._stream()))
+        return xpos, xmat
+
+    def debug_forward(self, torques=None):
+        """(decode, M entries, qfrc_bias, qacc) of one mj_forward at the current state (parity triage)."""
+        ne = C.c_int32()
+        _check(lib().ss_debug_decode(self.model.handle, None, C.byref(ne)))
+        dec = np.zeros(ne.value, np.int32)
+        _check(lib().ss_debug_decode(self.model.handle, dec.ctypes.data_as(C.c_void_p), C.byref(ne)))
+        Me = torch.zeros(self.num_envs, ne.value, device=self.device)
+        bias = torch.zeros(self.num_envs, self.nv, device=self.device)
+        qacc = torch.zeros(self.num_envs, self.nv, device=self.device)
+        tq = None if torques is None else torques.to(torch.float32).contiguous()
+        _check(lib().ss_debug_forward(self.handle, _ptr(tq), _ptr(Me), _ptr(bias), _ptr(qacc), self._stream()))
+        return dec, Me, bias, qacc
+
+    def set_state(self, qpos, qvel, qpos_prev=None, qvel_prev=None, warm=None):
+        """Teacher forcing / checkpoint restore.  *_prev default to the state itself (== after mj_forward)."""
+        def as_t(x):
+            if torch.is_tensor(x):
+                return x.to(self.device, torch.float32)
+            return torch.as_tensor(np.asarray(x), dtype=torch.float32, device=self.device)
+        self.qpos.copy_(as_t(qpos)); self.qvel.copy_(as_t(qvel))
+        self.qpos_prev.copy_(as_t(qpos if qpos_prev is None else qpos_prev))
+        self.qvel_prev.copy_(as_t(qvel if qvel_prev is None else qvel_prev))
+        if warm is not None:
+            self.qacc_warm.copy_(as_t(warm))
+
+    def launch_info(self):
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        _check(lib().ss_launch_info(self.handle, C.byref(a), C.byref(b), C.byref(c)))
+        return {"envs_per_workgroup": a.value, "lds_bytes": b.value, "vgprs": c.value}
+
+    def close(self):
+        h = getattr(self, "handle", None)
+        if h:
+            torch.cuda.synchronize(self.device)
+            lib().ss_batch_destroy(h)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

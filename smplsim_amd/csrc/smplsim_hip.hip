@@ -1,0 +1,92 @@
+// smplsim_hip.hip — gfx950 (MI355X) build of the wavefront env stepper + the C ABI (include/smplsim_hip.h).
+//
+// Launch geometry: one workgroup = E wavefronts = E environments (E <= 8, chosen so that the shared
+// index tables + E per-env LDS blocks fit the CU's 160 KiB LDS); no workgroup barrier after the
+// table copy — the wavefronts of a workgroup never talk to each other.  4096 envs = 512 workgroups
+// of 512 threads = two resident rounds over the chip's 256 CUs.
+#include <hip/hip_runtime.h>
+
+#include "ss_api.h"
+#include "ss_kernel.h"
+
+namespace {
+
+struct WaveGpu {
+  int ln;
+  __device__ __forceinline__ int lane() const { return ln; }
+  // wave-level LDS hand-off: LDS ops of one wavefront execute in order; the asm statement is the
+  // compiler barrier and drains outstanding LDS traffic before any lane continues
+  __device__ __forceinline__ void sync() const {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+  __device__ __forceinline__ float sum(float v) const {
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+  }
+  __device__ __forceinline__ unsigned long long ballot(int p) const { return __ballot(p); }
+  __device__ __forceinline__ bool any(int p) const { return __any(p) != 0; }
+  __device__ __forceinline__ unsigned long long bor(unsigned long long v) const {
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    for (int m = 32; m >= 1; m >>= 1) { lo |= (unsigned)__shfl_xor((int)lo, m, 64); hi |= (unsigned)__shfl_xor((int)hi, m, 64); }
+    return ((unsigned long long)hi << 32) | lo;
+  }
+  __device__ __forceinline__ void atomic_add(float *p, float v) const {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  }
+};
+
+template <int DOFP, int CANDP>
+__global__ void __launch_bounds__(512) ss_env_kernel(const ss::KArgs k) {
+  extern __shared__ __align__(16) uint32_t lds[];
+  for (int i = threadIdx.x; i < k.h.shared_words; i += blockDim.x) lds[i] = k.shared_g[i];
+  __syncthreads();
+  const int wave = threadIdx.x >> 6;
+  const int env = blockIdx.x * (blockDim.x >> 6) + wave;
+  if (env >= k.st.num_envs) return;
+  float *L = reinterpret_cast<float *>(lds + ((k.h.shared_words + 3) & ~3)) + (size_t)wave * k.h.env_floats;
+  WaveGpu w{(int)(threadIdx.x & 63)};
+  ss::run_env<WaveGpu, DOFP, CANDP>(&w, &k, lds, L, env);
+}
+
+typedef void (*kern_t)(const ss::KArgs);
+kern_t pick_kernel(int dofp, int candp) {
+  if (dofp == 2 && candp == 2) return ss_env_kernel<2, 2>;
+  if (dofp == 3 && candp == 3) return ss_env_kernel<3, 3>;
+  if (dofp == 3 && candp == 2) return ss_env_kernel<3, 2>;
+  if (dofp == 2 && candp == 3) return ss_env_kernel<2, 3>;
+  if (dofp == 1 && candp == 1) return ss_env_kernel<1, 1>;
+  return nullptr;
+}
+
+struct HipBackend {
+  static void *alloc(size_t n) { void *p = nullptr; return hipMalloc(&p, n) == hipSuccess ? p : nullptr; }
+  static void free_(void *p) { if (p) (void)hipFree(p); }
+  static bool upload(void *dst, const void *src, size_t n) { return hipMemcpy(dst, src, n, hipMemcpyHostToDevice) == hipSuccess; }
+  static bool set_device(int d) { return hipSetDevice(d) == hipSuccess; }
+  static int lds_capacity() { return 160 * 1024; }
+  static int &regs_ref() { static int r = 0; return r; }
+  static int kernel_regs() { return regs_ref(); }
+  static const char *launch(const ss::KArgs &k, int nenv, int envs_per_wg, size_t lds_bytes, void *stream) {
+    const int dofp = (k.h.nv + 63) / 64, candp = (k.h.ncand + 63) / 64;
+    kern_t kern = pick_kernel(dofp, candp);
+    if (!kern) return "no kernel variant for this model size";
+    static thread_local kern_t configured = nullptr;
+    static thread_local size_t configured_lds = 0;
+    if (configured != kern || configured_lds < lds_bytes) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      if (e != hipSuccess) return hipGetErrorString(e);
+      hipFuncAttributes fa;
+      if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern)) == hipSuccess) regs_ref() = fa.numRegs;
+      configured = kern; configured_lds = lds_bytes;
+    }
+    dim3 grid((nenv + envs_per_wg - 1) / envs_per_wg), block(64 * envs_per_wg);
+    hipLaunchKernelGGL(kern, grid, block, lds_bytes, (hipStream_t)stream, k);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? nullptr : hipGetErrorString(e);
+  }
+};
+
+}  // namespace
+
+SS_DEFINE_C_API(HipBackend)

@@ -1,0 +1,167 @@
+// ss_api.h — host side of the C ABI (include/smplsim_hip.h), written once and instantiated with a
+// backend: the HIP backend in smplsim_hip.hip (the product) and the wavefront-emulator backend in
+// tests/wave_emu/emu.cpp (unit-test infrastructure).  A backend provides:
+//   static void *alloc(size_t);  static void free_(void *);  static bool upload(void *dst, const void *src, size_t);
+//   static int lds_capacity();   static const char *launch(const ss::KArgs &, int nenv, int envs_per_wg, size_t lds_bytes, void *stream);
+//   static bool set_device(int);
+#pragma once
+#include <new>
+#include <string>
+
+#include "ss_tables.h"
+
+namespace ss {
+inline std::string &last_error() { static thread_local std::string e; return e; }
+}  // namespace ss
+
+struct ss_model {
+  ss::HostModel hm;
+  int device = 0;
+  uint32_t *d_shared = nullptr;
+  float *d_bodyc = nullptr, *d_candc = nullptr;
+  int32_t *d_candb = nullptr;
+};
+struct ss_batch {
+  const ss_model *m = nullptr;
+  ss_env_cfg cfg{};
+  ss_state st{};
+  int envs_per_wg = 1;
+  size_t lds_bytes = 0;
+  int obs_size = 0;
+};
+
+template <class BE>
+struct ss_api {
+  static int fail(int code, const std::string &msg) { ss::last_error() = msg; return code; }
+
+  static int model_create(const ss_model_desc *d, int device, ss_model **out) {
+    if (!d || !out) return fail(SS_ERR_INVALID, "null argument");
+    ss_model *m = new (std::nothrow) ss_model();
+    if (!m) return fail(SS_ERR_NOMEM, "out of host memory");
+    if (!ss::build_host_model(*d, m->hm)) { std::string e = m->hm.error; delete m; return fail(SS_ERR_INVALID, e); }
+    m->device = device;
+    if (!BE::set_device(device)) { delete m; return fail(SS_ERR_HIP, "cannot select device"); }
+    auto up = [&](const void *src, size_t bytes) -> void * {
+      void *p = BE::alloc(bytes ? bytes : 4);
+      if (p && bytes && !BE::upload(p, src, bytes)) { BE::free_(p); p = nullptr; }
+      return p;
+    };
+    m->d_shared = (uint32_t *)up(m->hm.shared.data(), m->hm.shared.size() * 4);
+    m->d_bodyc = (float *)up(m->hm.bodyc.data(), m->hm.bodyc.size() * 4);
+    m->d_candc = (float *)up(m->hm.candc.data(), m->hm.candc.size() * 4);
+    m->d_candb = (int32_t *)up(m->hm.candb.data(), m->hm.candb.size() * 4);
+    if (!m->d_shared || !m->d_bodyc || !m->d_candc || !m->d_candb) { model_destroy(m); return fail(SS_ERR_HIP, "device table upload failed"); }
+    *out = m;
+    return SS_OK;
+  }
+  static void model_destroy(ss_model *m) {
+    if (!m) return;
+    BE::free_(m->d_shared); BE::free_(m->d_bodyc); BE::free_(m->d_candc); BE::free_(m->d_candb);
+    delete m;
+  }
+  static int batch_create(const ss_model *m, const ss_env_cfg *cfg, const ss_state *st, ss_batch **out) {
+    if (!m || !cfg || !st || !out) return fail(SS_ERR_INVALID, "null argument");
+    if (st->num_envs < 1) return fail(SS_ERR_INVALID, "num_envs must be positive");
+    if (!st->qpos || !st->qvel || !st->qpos_prev || !st->qvel_prev || !st->qacc_warm || !st->body_vel || !st->touch ||
+        !st->cur_t || !st->task || !st->nwarn || !st->solver_iters)
+      return fail(SS_ERR_INVALID, "every ss_state buffer must be provided");
+    if (cfg->self_obs_v != 1 && cfg->self_obs_v != 2) return fail(SS_ERR_INVALID, "self_obs_v must be 1 or 2");
+    if (cfg->control_freq_inv < 1) return fail(SS_ERR_INVALID, "control_freq_inv must be >= 1");
+    const ss::Hdr &h = m->hm.h;
+    const int dofp = (h.nv + 63) / 64, candp = (h.ncand + 63) / 64;
+    if (dofp > 3 || candp > 3) return fail(SS_ERR_INVALID, "model too large for the compiled kernel variants");
+    ss_batch *b = new (std::nothrow) ss_batch();
+    if (!b) return fail(SS_ERR_NOMEM, "out of host memory");
+    b->m = m; b->cfg = *cfg; b->st = *st;
+    if (b->cfg.newton_iters <= 0) b->cfg.newton_iters = 8;
+    b->obs_size = ss::obs_size(h, *cfg);
+    size_t shared_b = (size_t)((h.shared_words + 3) & ~3) * 4, env_b = (size_t)h.env_floats * 4;
+    int cap = BE::lds_capacity();
+    int e = (int)((cap - (long)shared_b) / (long)env_b);
+    if (e < 1) { delete b; return fail(SS_ERR_LDS, "model does not fit in LDS"); }
+    if (e > 8) e = 8;
+    b->envs_per_wg = e;
+    b->lds_bytes = shared_b + (size_t)e * env_b;
+    *out = b;
+    return SS_OK;
+  }
+  static ss::KArgs base_args(const ss_batch *b, int mode) {
+    ss::KArgs k{};
+    const ss_model *m = b->m;
+    k.h = m->hm.h; k.cfg = b->cfg; k.st = b->st;
+    k.shared_g = m->d_shared; k.bodyc = m->d_bodyc; k.candc = m->d_candc; k.candb = m->d_candb;
+    k.illegal_mask = m->hm.illegal_mask;
+    k.mode = mode; k.nsub = b->cfg.control_freq_inv; k.obs_size = b->obs_size;
+    return k;
+  }
+  static int run(const ss_batch *b, const ss::KArgs &k, void *stream) {
+    if (!BE::set_device(b->m->device)) return fail(SS_ERR_HIP, "cannot select device");
+    const char *err = BE::launch(k, b->st.num_envs, b->envs_per_wg, b->lds_bytes, stream);
+    if (err) return fail(SS_ERR_HIP, err);
+    return SS_OK;
+  }
+  static int reset(ss_batch *b, const uint8_t *mask, const float *fall_actions, const float *task_rand, float *obs, void *stream) {
+    if (!b || !obs) return fail(SS_ERR_INVALID, "null argument");
+    if (b->cfg.state_init == SS_INIT_FALL && !fall_actions) return fail(SS_ERR_INVALID, "StateInit.Fall needs fall_actions");
+    ss::KArgs k = base_args(b, ss::MODE_RESET);
+    k.mask = mask; k.fall_actions = fall_actions; k.task_rand = task_rand; k.obs = obs;
+    return run(b, k, stream);
+  }
+  static int step(ss_batch *b, const float *actions, const float *task_rand, float *obs, float *reward, uint8_t *term,
+                  uint8_t *trunc, void *stream) {
+    if (!b || !actions || !obs || !reward || !term || !trunc) return fail(SS_ERR_INVALID, "null argument");
+    ss::KArgs k = base_args(b, ss::MODE_STEP);
+    k.actions = actions; k.task_rand = task_rand; k.obs = obs; k.reward = reward; k.terminated = term; k.truncated = trunc;
+    return run(b, k, stream);
+  }
+  static int substep(ss_batch *b, const float *actions, int n, void *stream) {
+    if (!b || !actions || n < 1) return fail(SS_ERR_INVALID, "bad argument");
+    ss::KArgs k = base_args(b, ss::MODE_SUBSTEP);
+    k.actions = actions; k.nsub = n;
+    return run(b, k, stream);
+  }
+  static int kinematics(ss_batch *b, float *xpos, float *xmat, void *stream) {
+    if (!b || !xpos || !xmat) return fail(SS_ERR_INVALID, "null argument");
+    ss::KArgs k = base_args(b, ss::MODE_KINEMATICS);
+    k.out0 = xpos; k.out1 = xmat;
+    return run(b, k, stream);
+  }
+  static int debug_forward(ss_batch *b, const float *torques, float *M_entries, float *bias, float *qacc, void *stream) {
+    if (!b || !M_entries || !bias || !qacc) return fail(SS_ERR_INVALID, "null argument");
+    ss::KArgs k = base_args(b, ss::MODE_DEBUG_FORWARD);
+    k.actions = torques; k.out0 = M_entries; k.out1 = bias; k.out2 = qacc;
+    return run(b, k, stream);
+  }
+};
+
+// The extern "C" surface, identical for every backend.
+#define SS_DEFINE_C_API(BE)                                                                                          \
+  extern "C" {                                                                                                       \
+  int ss_model_create(const ss_model_desc *d, int dev, ss_model **out) { return ss_api<BE>::model_create(d, dev, out); } \
+  void ss_model_destroy(ss_model *m) { ss_api<BE>::model_destroy(m); }                                               \
+  int ss_model_dims(const ss_model *m, int32_t *nq, int32_t *nv, int32_t *nu, int32_t *nb) {                          \
+    if (!m) return ss_api<BE>::fail(SS_ERR_INVALID, "null model");                                                   \
+    if (nq) *nq = m->hm.h.nq; if (nv) *nv = m->hm.h.nv; if (nu) *nu = m->hm.h.nu; if (nb) *nb = m->hm.h.nb;          \
+    return SS_OK;                                                                                                    \
+  }                                                                                                                  \
+  int ss_obs_size(const ss_model *m, const ss_env_cfg *c) { return (m && c) ? ss::obs_size(m->hm.h, *c) : SS_ERR_INVALID; } \
+  int ss_batch_create(const ss_model *m, const ss_env_cfg *c, const ss_state *s, ss_batch **o) { return ss_api<BE>::batch_create(m, c, s, o); } \
+  void ss_batch_destroy(ss_batch *b) { delete b; }                                                                   \
+  int ss_reset(ss_batch *b, const uint8_t *mask, const float *fa, const float *tr, float *obs, void *st) { return ss_api<BE>::reset(b, mask, fa, tr, obs, st); } \
+  int ss_step(ss_batch *b, const float *a, const float *tr, float *obs, float *rew, uint8_t *te, uint8_t *tu, void *st) { return ss_api<BE>::step(b, a, tr, obs, rew, te, tu, st); } \
+  int ss_substep(ss_batch *b, const float *a, int n, void *st) { return ss_api<BE>::substep(b, a, n, st); }          \
+  int ss_kinematics(ss_batch *b, float *xpos, float *xmat, void *st) { return ss_api<BE>::kinematics(b, xpos, xmat, st); } \
+  int ss_debug_forward(ss_batch *b, const float *tq, float *M, float *bias, float *qacc, void *st) { return ss_api<BE>::debug_forward(b, tq, M, bias, qacc, st); } \
+  int ss_debug_decode(const ss_model *m, int32_t *out, int32_t *ne) {                                                \
+    if (!m || !ne) return ss_api<BE>::fail(SS_ERR_INVALID, "null argument");                                         \
+    *ne = m->hm.h.ne;                                                                                                \
+    if (out) for (int e = 0; e < m->hm.h.ne; e++) out[e] = (int32_t)m->hm.shared[m->hm.h.o_decode + e];              \
+    return SS_OK;                                                                                                    \
+  }                                                                                                                  \
+  int ss_launch_info(const ss_batch *b, int32_t *epw, int32_t *lds, int32_t *regs) {                                 \
+    if (!b) return ss_api<BE>::fail(SS_ERR_INVALID, "null batch");                                                   \
+    if (epw) *epw = b->envs_per_wg; if (lds) *lds = (int32_t)b->lds_bytes; if (regs) *regs = BE::kernel_regs();      \
+    return SS_OK;                                                                                                    \
+  }                                                                                                                  \
+  const char *ss_last_error(void) { return ss::last_error().c_str(); }                                               \
+  }

@@ -1,0 +1,238 @@
+// ss_tables.h — host-side construction of the index/constant tables the wavefront kernel uses.
+//
+// One environment is stepped by one 64-lane wavefront.  The kernel works on "nodes": node 0 = the
+// root's 3 translational dofs, node 1 = its 3 rotational dofs, node b+1 = the 3 hinges of body b,
+// so dof d belongs to node d/3 and every node is a 3x3 block of the joint-space matrices.  The
+// tree-sparse matrix H (mass matrix / Newton Hessian) is stored as chain-dense block rows:
+// node n at depth L has 3 rows of W = 3L+3 floats (columns = the dofs along its ancestor chain in
+// root-to-node order, then its own 3), which is exactly the sparsity pattern of M (Featherstone's
+// branch-induced sparsity; SURVEY.md §8a "nnz(M)").
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/smplsim_hip.h"
+#include "ss_hdr.h"
+
+namespace ss {
+
+struct HostModel {
+  Hdr h{};
+  std::vector<uint32_t> shared;   // tables copied into LDS once per workgroup
+  std::vector<float> bodyc;       // [nb][kBodyC]: off3 ipos3 mass Ibody6 invw_tr  (loaded into registers)
+  std::vector<float> candc;       // [ncand][kCandC]
+  std::vector<int32_t> candb;     // [ncand] body of each candidate, bit 8: capsule
+  std::vector<float> actc;        // [nv][4]: kp kd tlim (per dof, 0 for unactuated), [nv][2] scale offset -> in dofc
+  std::vector<int32_t> dof_act;   // [nv] actuator index of a dof or -1
+  std::vector<uint8_t> legal;     // [nb]
+  uint64_t illegal_mask = 0;      // bodies whose floor contact terminates the episode
+  std::string error;
+};
+
+inline uint32_t f2u(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+
+inline void quat2mat(const double *q, double *m) {
+  double w = q[0], x = q[1], y = q[2], z = q[3];
+  double n = std::sqrt(w * w + x * x + y * y + z * z);
+  w /= n; x /= n; y /= n; z /= n;
+  m[0] = 1 - 2 * (y * y + z * z); m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y);
+  m[3] = 2 * (x * y + w * z); m[4] = 1 - 2 * (x * x + z * z); m[5] = 2 * (y * z - w * x);
+  m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = 1 - 2 * (x * x + y * y);
+}
+
+inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
+  Hdr &h = out.h;
+  const int nb = d.nbody;
+  if (nb < 1 || nb > 63) { out.error = "nbody must be in [1,63]"; return false; }
+  if (d.body_parent[0] != -1) { out.error = "body 0 must be the root"; return false; }
+  for (int b = 1; b < nb; b++)
+    if (d.body_parent[b] < 0 || d.body_parent[b] >= b) { out.error = "parents must precede children"; return false; }
+  h.nb = nb; h.nn = nb + 1; h.nv = 6 + 3 * (nb - 1); h.nq = h.nv + 1; h.nu = d.nu;
+  const int nn = h.nn, nv = h.nv;
+
+  // ---- node tree
+  std::vector<int> nparent(nn), ndepth(nn), bdepth(nb);
+  nparent[0] = -1; ndepth[0] = 0; nparent[1] = 0; ndepth[1] = 1; bdepth[0] = 0;
+  for (int b = 1; b < nb; b++) {
+    int p = d.body_parent[b];
+    nparent[b + 1] = p + 1; ndepth[b + 1] = ndepth[p + 1] + 1; bdepth[b] = bdepth[p] + 1;
+  }
+  int nlev = 0, nblev = 0;
+  for (int n = 0; n < nn; n++) nlev = std::max(nlev, ndepth[n] + 1);
+  for (int b = 0; b < nb; b++) nblev = std::max(nblev, bdepth[b] + 1);
+  h.nlev = nlev; h.nblev = nblev; h.maxD = 3 * (nlev - 1);
+  std::vector<int> nbase(nn);
+  int ne = 0;
+  for (int n = 0; n < nn; n++) { nbase[n] = ne; ne += 3 * (3 * ndepth[n] + 3); }
+  h.ne = ne;
+  const int CW = h.maxD > 0 ? h.maxD : 1;                  // chain table row width (in dofs)
+  const int CN = nlev;                                     // chain node table row width
+  std::vector<int> chainnode(nn * CN, 0), chainrow(nn * CW, 0);
+  for (int n = 0; n < nn; n++) {
+    std::vector<int> anc;                                  // root -> parent
+    for (int a = nparent[n]; a >= 0; a = nparent[a]) anc.insert(anc.begin(), a);
+    for (size_t k = 0; k < anc.size(); k++) {
+      chainnode[n * CN + k] = anc[k];
+      int Wa = 3 * ndepth[anc[k]] + 3;
+      for (int r = 0; r < 3; r++) chainrow[n * CW + 3 * k + r] = nbase[anc[k]] + r * Wa;
+    }
+    chainnode[n * CN + anc.size()] = n;                    // convenient: chain includes self at its depth
+  }
+  std::vector<int> decode(ne);
+  for (int n = 0; n < nn; n++) {
+    int D = 3 * ndepth[n], W = D + 3;
+    for (int r = 0; r < 3; r++)
+      for (int j = 0; j < W; j++) {
+        int col = j < D ? 3 * chainnode[n * CN + j / 3] + j % 3 : 3 * n + (j - D);
+        decode[nbase[n] + r * W + j] = ((3 * n + r) << 16) | col;
+      }
+  }
+  std::vector<int> levstart(nlev + 1, 0), levnodes, blevstart(nblev + 1, 0), blevbodies;
+  for (int L = 0; L < nlev; L++) {
+    levstart[L] = (int)levnodes.size();
+    for (int n = 0; n < nn; n++) if (ndepth[n] == L) levnodes.push_back(n);
+  }
+  levstart[nlev] = (int)levnodes.size();
+  for (int L = 0; L < nblev; L++) {
+    blevstart[L] = (int)blevbodies.size();
+    for (int b = 0; b < nb; b++) if (bdepth[b] == L) blevbodies.push_back(b);
+  }
+  blevstart[nblev] = (int)blevbodies.size();
+
+  // ---- dof constants: arm, lo, hi, limited, invw, kp, kd, tlim, ascale, aoffset, actuated, pad
+  std::vector<float> dofc(nv * kDofC, 0.f);
+  out.dof_act.assign(nv, -1);
+  for (int i = 0; i < d.nu; i++) {
+    int dof = d.actuator_dof[i];
+    if (dof < 6 || dof >= nv || out.dof_act[dof] >= 0) { out.error = "bad actuator_dof"; return false; }
+    out.dof_act[dof] = i;
+  }
+  for (int i = 0; i < nv; i++) {
+    float *c = &dofc[i * kDofC];
+    c[0] = (float)d.dof_armature[i];
+    c[1] = (float)d.jnt_range[2 * i]; c[2] = (float)d.jnt_range[2 * i + 1];
+    c[3] = (i >= 6 && d.jnt_limited[i]) ? 1.f : 0.f;
+    c[4] = (float)d.dof_invweight0[i];
+    int a = out.dof_act[i];
+    if (a >= 0) {
+      c[5] = (float)d.kp[a]; c[6] = (float)d.kd[a]; c[7] = (float)d.torque_lim[a];
+      c[8] = (float)d.act_scale[a]; c[9] = (float)d.act_offset[a]; c[10] = 1.f; c[11] = (float)a;
+    } else c[11] = -1.f;
+  }
+
+  // ---- body constants (registers): off3 ipos3 mass Ibody(xx xy xz yy yz zz) invw_tr
+  out.bodyc.assign(nb * kBodyC, 0.f);
+  for (int b = 0; b < nb; b++) {
+    float *c = &out.bodyc[b * kBodyC];
+    for (int k = 0; k < 3; k++) { c[k] = (float)d.body_pos[3 * b + k]; c[3 + k] = (float)d.body_ipos[3 * b + k]; }
+    c[6] = (float)d.body_mass[b];
+    double R[9]; quat2mat(d.body_iquat + 4 * b, R);
+    double I[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+      double s = 0; for (int k = 0; k < 3; k++) s += R[3 * i + k] * d.body_inertia[3 * b + k] * R[3 * j + k];
+      I[3 * i + j] = s;
+    }
+    c[7] = (float)I[0]; c[8] = (float)I[1]; c[9] = (float)I[2]; c[10] = (float)I[4]; c[11] = (float)I[5]; c[12] = (float)I[8];
+    c[13] = (float)d.body_invweight0[2 * b];
+  }
+  // root offset is the initial position, not a parent-frame offset
+  out.bodyc[0] = out.bodyc[1] = out.bodyc[2] = 0.f;
+
+  // ---- contact candidates: boxes first (8 corners each, 8-aligned), then capsule ends
+  out.candc.clear(); out.candb.clear();
+  for (int b = 0; b < nb; b++) {
+    if (d.geom_type[b] != SS_GEOM_BOX) continue;
+    double G[9]; quat2mat(d.geom_quat + 4 * b, G);
+    for (int i = 0; i < 8; i++) {
+      double v[3] = {(i & 1) ? d.geom_size[3 * b] : -d.geom_size[3 * b], (i & 2) ? d.geom_size[3 * b + 1] : -d.geom_size[3 * b + 1],
+                     (i & 4) ? d.geom_size[3 * b + 2] : -d.geom_size[3 * b + 2]};
+      float c[kCandC] = {0};
+      for (int r = 0; r < 3; r++) {
+        c[r] = (float)(G[3 * r] * v[0] + G[3 * r + 1] * v[1] + G[3 * r + 2] * v[2]);   // corner vector (body frame)
+        c[3 + r] = (float)d.geom_pos[3 * b + r];                                        // box centre (body frame)
+      }
+      c[7] = (float)d.body_invweight0[2 * b];
+      out.candc.insert(out.candc.end(), c, c + kCandC); out.candb.push_back(b);
+    }
+  }
+  for (int b = 0; b < nb; b++) {
+    if (d.geom_type[b] != SS_GEOM_CAPSULE) continue;
+    double G[9]; quat2mat(d.geom_quat + 4 * b, G);
+    for (int s = 0; s < 2; s++) {
+      double sg = s ? -1.0 : 1.0;
+      float c[kCandC] = {0};
+      for (int r = 0; r < 3; r++) {
+        c[r] = (float)(d.geom_pos[3 * b + r] + sg * G[3 * r + 2] * d.geom_size[3 * b + 1]);  // end-sphere centre (body frame)
+        c[3 + r] = (float)G[3 * r + 2];                                                      // capsule axis (body frame)
+      }
+      c[6] = (float)d.geom_size[3 * b];                                                      // radius
+      c[7] = (float)d.body_invweight0[2 * b];
+      out.candc.insert(out.candc.end(), c, c + kCandC); out.candb.push_back(b | 256);
+    }
+  }
+  h.ncand = (int)out.candb.size();
+  out.legal.assign(nb, 0);
+  out.illegal_mask = 0;
+  for (int b = 0; b < nb; b++) {
+    out.legal[b] = d.legal_contact ? d.legal_contact[b] : 0;
+    if (!out.legal[b]) out.illegal_mask |= (1ull << b);
+  }
+
+  // ---- shared blob
+  auto &S = out.shared; S.clear();
+  auto push_i = [&](const std::vector<int> &v) { int o = (int)S.size(); for (int x : v) S.push_back((uint32_t)x); return o; };
+  h.o_dofc = (int)S.size(); for (float f : dofc) S.push_back(f2u(f));
+  h.o_decode = push_i(decode);
+  h.o_chainrow = push_i(chainrow);
+  h.o_chainnode = push_i(chainnode);
+  h.o_nbase = push_i(nbase);
+  h.o_ndepth = push_i(ndepth);
+  h.o_nparent = push_i(nparent);
+  h.o_levstart = push_i(levstart);
+  h.o_levnodes = push_i(levnodes);
+  std::vector<int> bpar(d.body_parent, d.body_parent + nb);
+  h.o_bparent = push_i(bpar);
+  h.o_blevstart = push_i(blevstart);
+  h.o_blevbodies = push_i(blevbodies);
+  h.shared_words = (int)S.size();
+
+  // ---- per-env LDS layout (floats)
+  int maxU = 0;                                            // U buffer: nodes-in-level * 3 * D
+  for (int L = 1; L < nlev; L++) maxU = std::max(maxU, (levstart[L + 1] - levstart[L]) * 9 * L);
+  int o = 0;
+  auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
+  h.l_H = take(ne);
+  h.l_S = take(6 * nv);
+  h.l_G = take(std::max(6 * nv, maxU));                    // G doubles as the U buffer of the factorization
+  h.l_Dinv = take(6 * nn);
+  h.l_R = take(9 * nb); h.l_r = take(3 * nb);
+  h.l_Ic = take(10 * nb); h.l_K = take(21 * nb);
+  h.l_V = take(6 * nb); h.l_Ab = take(6 * nb); h.l_Ad = take(6 * nb); h.l_Gb = take(6 * nb);
+  h.l_q = take(nv + 1); h.l_v = take(nv); h.l_a = take(nv); h.l_tau = take(nv); h.l_grad = take(nv);
+  h.l_delta = take(nv); h.l_C = take(nv); h.l_diag = take(nv);
+  h.l_misc = take(16);
+  h.env_floats = o;
+
+  h.dt = (float)d.timestep; h.grav = (float)d.gravity; h.margin = (float)d.margin; h.mu = (float)d.friction;
+  for (int k = 0; k < 5; k++) h.solimp[k] = (float)d.solimp[k];
+  double dmax = d.solimp[1];
+  double tc = d.solref[0] < 2 * d.timestep ? 2 * d.timestep : d.solref[0];
+  h.K = (float)(1.0 / (dmax * dmax * tc * tc * d.solref[1] * d.solref[1]));
+  h.B = (float)(2.0 / (dmax * tc));
+  for (int k = 0; k < 3; k++) h.qpos0_root[k] = (float)d.qpos0[k];
+  if (d.impratio != 1.0) { out.error = "impratio != 1 is not supported"; return false; }
+  return true;
+}
+
+inline int obs_size(const Hdr &h, const ss_env_cfg &c) {
+  int nd = 3 * (h.nb - 1);
+  int n = (c.root_height_obs ? 1 : 0) + nd + (c.self_obs_v == 1 ? 6 * h.nb + 6 + nd : 12 * h.nb);
+  if (c.task == SS_TASK_SPEED) n += 3;
+  if (c.task == SS_TASK_GETUP) n += 1;
+  return n;
+}
+
+}  // namespace ss

@@ -1,0 +1,165 @@
+"""GPU parity tests proper (-m gpu): the HIP path, through the product API and the C ABI, against the
+float64 CPU oracle on the same seeded inputs, plus size-independent properties at the benchmark size."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from helpers import FEET, default_qpos, model_const, oracle_model  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+# Stated tolerances (float32 kernel vs float64 oracle), per control step = 15 mj_steps:
+TOL_QPOS, TOL_QVEL, TOL_OBS, TOL_REW = 1e-4, 5e-3, 5e-3, 1e-4
+
+
+@pytest.fixture(scope="module")
+def vec():
+    from smplsim_amd.batch import SMPLSimVecEnv
+    return SMPLSimVecEnv
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def test_extension_is_loaded_not_a_fallback():
+    from smplsim_amd import _lib
+    L = _lib.lib()
+    assert L._name.endswith("libsmplsim_hip.so")
+    with open("/proc/self/maps") as f:
+        assert "libsmplsim_hip.so" in f.read()
+
+
+def test_forward_pieces_match_oracle(vec):
+    from test_kernel_emu import _states
+    om, mc = oracle_model(), model_const()
+    Q, V = _states(12, 11)
+    env = vec(12, autoreset=False)
+    env.set_state(Q, V)
+    rs = np.random.default_rng(1)
+    tq = rs.normal(size=(12, 69)) * 20
+    xpos, xmat = env.kinematics()
+    dec, Me, bias, qacc = env.debug_forward(torch.tensor(tq, device=env.device))
+    torch.cuda.synchronize()
+    xpos, Me, bias, qacc = _np(xpos), _np(Me), _np(bias), _np(qacc)
+    rows, cols = dec >> 16, dec & 0xFFFF
+    for i in range(12):
+        d = O.OracleData(om); d.qpos = Q[i]; d.qvel = V[i]; d.ctrl = tq[i]; d.forward()
+        assert np.abs(xpos[i] - d.xpos).max() < 2e-6
+        low = rows >= cols
+        assert np.abs(Me[i][low] - d.M[rows[low], cols[low]]).max() < 2e-6 * np.abs(d.M).max()
+        assert np.abs(bias[i] - d.bias).max() < 2e-6 * max(1.0, np.abs(d.bias).max())
+        assert np.abs(qacc[i] - d.qacc).max() < 5e-5 * np.abs(d.qacc).max(), (i, d.ncon)
+        touch = sum(1 << b for b in range(24) if d.touch[b])
+        assert (int(env.touch[i, 0].item()) & 0xFFFFFFFF) == touch
+
+
+def test_free_running_rollout_tracks_oracle(vec):
+    env = vec(8, autoreset=False)
+    obs, _ = env.reset()
+    oenv = O.OracleEnv(oracle_model())
+    assert np.abs(oenv.reset() - _np(obs)[0]).max() < 1e-6
+    rs = np.random.default_rng(0)
+    worst = np.zeros(3)
+    for i in range(40):
+        a = rs.uniform(-0.3, 0.3, 69)
+        obs, rew, term, trunc, _ = env.step(torch.tensor(np.tile(a, (8, 1)), device=env.device, dtype=torch.float32))
+        o_ref, r, te, tu = oenv.step(a)
+        worst = np.maximum(worst, [np.abs(_np(env.qpos)[0] - oenv.data.qpos).max(),
+                                   np.abs(_np(env.qvel)[0] - oenv.data.qvel).max(), np.abs(_np(obs)[0] - o_ref).max()])
+        assert (te, tu) == (bool(term[0]), bool(trunc[0]))
+    assert torch.equal(env.qpos[0], env.qpos[7])             # identical inputs -> bit-identical envs
+    assert worst[0] < 2 * TOL_QPOS and worst[1] < TOL_QVEL and worst[2] < TOL_OBS, worst
+
+
+@pytest.mark.parametrize("task,init", [("HumanoidSpeed", "Default"), ("HumanoidGetup", "Fall")])
+def test_task_envs_teacher_forced(vec, task, init):
+    from smplsim_amd import _cabi
+    om = oracle_model()
+    env = vec(4, task=task, state_init=init, autoreset=False)
+    oenv = O.OracleEnv(om, task=_cabi.TASKS[task], state_init=_cabi.STATE_INITS[init])
+    rs = np.random.default_rng(3)
+    fa, tr = rs.uniform(size=(3, 69)), rs.uniform(size=2)
+    dev = env.device
+    T = lambda x: torch.tensor(np.tile(np.asarray(x)[None], (4,) + (1,) * np.asarray(x).ndim), device=dev, dtype=torch.float32)
+    o_ref = oenv.reset(fall_actions=fa, task_rand=tr)
+    obs, _ = env.reset(fall_actions=T(fa), task_rand=T(tr))
+    assert np.abs(_np(env.qpos)[0] - oenv.data.qpos).max() < 2 * TOL_QPOS
+    assert np.abs(o_ref - _np(obs)[0]).max() < TOL_OBS
+    for i in range(12):
+        env.set_state(np.tile(oenv.data.qpos, (4, 1)), np.tile(oenv.data.qvel, (4, 1)), env.qpos_prev, env.qvel_prev)
+        a, tr = rs.uniform(-0.5, 0.5, 69), rs.uniform(size=2)
+        o_ref, r, te, tu = oenv.step(a, task_rand=tr)
+        obs, rew, term, trunc, _ = env.step(T(a), task_rand=T(tr))
+        assert np.abs(_np(env.qpos)[0] - oenv.data.qpos).max() < TOL_QPOS
+        assert np.abs(_np(env.qvel)[0] - oenv.data.qvel).max() < TOL_QVEL
+        assert np.abs(o_ref - _np(obs)[0]).max() < TOL_OBS
+        assert abs(r - float(rew[0])) < TOL_REW and (te, tu) == (bool(term[0]), bool(trunc[0]))
+
+
+def test_smplx_layout(vec):
+    from smplsim_amd.batch import ShardModel
+    env = vec(4, model=ShardModel(humanoid="smplx_humanoid"), autoreset=False)
+    oenv = O.OracleEnv(oracle_model("smplx_humanoid"))
+    obs, _ = env.reset()
+    assert env.obs_size == 625 and np.abs(oenv.reset() - _np(obs)[0]).max() < 1e-6
+    rs = np.random.default_rng(2)
+    for i in range(3):
+        a = rs.uniform(-0.2, 0.2, 153)
+        o_ref, *_ = oenv.step(a)
+        obs, *_ = env.step(torch.tensor(np.tile(a, (4, 1)), device=env.device, dtype=torch.float32))
+        assert np.abs(_np(env.qpos)[0] - oenv.data.qpos).max() < TOL_QPOS
+        assert np.abs(o_ref - _np(obs)[0]).max() < TOL_OBS
+
+
+def test_benchmark_size_properties(vec):
+    """4096 envs, full-range random actions (BASELINE config 2): size-independent properties —
+    finite state, unit root quaternions, deterministic replay, yaw invariance of the observation,
+    episode bookkeeping with device-side autoreset."""
+    N = 4096
+    env = vec(N, autoreset=True, seed=1)
+    env.reset()
+    g = torch.Generator(device=env.device); g.manual_seed(1234)
+    acts = [torch.rand(N, 69, generator=g, device=env.device) * 2 - 1 for _ in range(12)]
+    for a in acts:
+        obs, rew, term, trunc, info = env.step(a)
+    torch.cuda.synchronize()
+    q1, o1 = env.qpos.clone(), obs.clone()
+    assert torch.isfinite(env.qpos).all() and torch.isfinite(env.qvel).all() and torch.isfinite(obs).all()
+    assert (env.qpos[:, 3:7].norm(dim=1) - 1).abs().max() < 1e-4
+    assert int(env.cur_t.max()) == 12 and not term.any()
+    env2 = vec(N, autoreset=True, seed=1)
+    env2.reset()
+    for a in acts:
+        obs2, *_ = env2.step(a)
+    torch.cuda.synchronize()
+    assert torch.equal(q1, env2.qpos) and torch.equal(o1, obs2)      # bit-reproducible
+    # yaw invariance of proprioception (the reference's commented check, humanoid_env.py:497-504)
+    envy = vec(2, autoreset=False)
+    q = torch.tensor(np.tile(default_qpos(76), (2, 1)), dtype=torch.float32, device=env.device)
+    q[:, 7:] = 0.3 * torch.randn(1, 69, generator=g, device=env.device)
+    th = 1.1
+    yaw = torch.tensor([np.cos(th / 2), 0, 0, np.sin(th / 2)], dtype=torch.float32, device=env.device)
+    w1, x1, y1, z1 = yaw; w2, x2, y2, z2 = q[1, 3:7].clone()
+    q[1, 3:7] = torch.stack([w1*w2 - x1*x2 - y1*y2 - z1*z2, w1*x2 + x1*w2 + y1*z2 - z1*y2,
+                             w1*y2 - x1*z2 + y1*w2 + z1*x2, w1*z2 + x1*y2 - y1*x2 + z1*w2])
+    envy.set_state(q, torch.zeros(2, 75, device=env.device))
+    envy.substep(torch.zeros(2, 69, device=env.device), 1)
+    envy.cfg.state_init = 0
+    xpos, xmat = envy.kinematics()
+    torch.cuda.synchronize()
+    assert (xpos[0, :, 2] - xpos[1, :, 2]).abs().max() < 1e-5
+
+
+def test_episode_truncation_and_autoreset(vec):
+    env = vec(64, autoreset=True, episode_length=5)
+    env.reset()
+    z = torch.zeros(64, 69, device=env.device)
+    for i in range(6):
+        obs, rew, term, trunc, info = env.step(z)
+    torch.cuda.synchronize()
+    assert trunc.all() and int(env.cur_t.max()) == 0          # cur_t 6 > 5 -> truncated -> reset in the same call
+    assert torch.allclose(env.qpos[:, 2], torch.full((64,), 0.94, device=env.device))
+    assert "final_observation" in info and (info["final_observation"][:, 0] - 0.94).abs().max() > 1e-4

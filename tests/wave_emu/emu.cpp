@@ -1,0 +1,201 @@
+// emu.cpp — 64-fiber wavefront emulator: runs the *same* kernel source (smplsim_amd/csrc/ss_kernel.h)
+// on the CPU so the float32 kernel logic can be unit-tested against the oracle without a GPU.
+//
+// UNIT-TEST INFRASTRUCTURE ONLY.  The product (smplsim_amd/) never loads this library; the product
+// path is libsmplsim_hip.so and fails loudly when it is missing.
+//
+// Every lane of the wavefront is a cooperative fiber (hand-rolled x86-64 context switch).  A wave
+// sync / collective is a round-robin switch through all 64 fibers, so lanes only ever observe each
+// other's LDS writes across sync points — a stricter model than lock-step SIMT, which makes missing
+// syncs show up as wrong answers here.  Each collective carries a site id that is checked for
+// convergence (all lanes must arrive at the same site).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../smplsim_amd/csrc/ss_api.h"
+#include "../../smplsim_amd/csrc/ss_kernel.h"
+
+extern "C" void emu_switch(void **save_sp, void *load_sp);
+asm(R"(
+.text
+.globl emu_switch
+.type emu_switch,@function
+emu_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+)");
+
+namespace {
+
+constexpr int kLanes = 64;
+constexpr size_t kStack = 256 * 1024;
+
+struct WaveEmu;
+struct Fiber { void *sp; char *stack; };
+
+struct Machine {
+  Fiber fib[kLanes];
+  void *main_sp = nullptr;
+  int cur = -1;
+  int done[kLanes];
+  // collective scratch
+  float fx[kLanes];
+  unsigned long long ux[kLanes];
+  int siteh[4][kLanes];
+  unsigned narr[kLanes];
+  void (*entry)(int lane, void *arg) = nullptr;
+  void *arg = nullptr;
+  Machine() { for (int i = 0; i < kLanes; i++) fib[i].stack = (char *)aligned_alloc(64, kStack); }
+  ~Machine() { for (int i = 0; i < kLanes; i++) free(fib[i].stack); }
+};
+
+thread_local Machine *g_m = nullptr;
+
+extern "C" void emu_trampoline() {
+  Machine *m = g_m;
+  int lane = m->cur;
+  m->entry(lane, m->arg);
+  m->done[lane] = 1;
+  // return to main; never resumed
+  emu_switch(&m->fib[lane].sp, m->main_sp);
+  abort();
+}
+
+void yield_to_next(Machine *m) {
+  // round robin among unfinished fibers; when wrapping past the last lane control passes through main
+  int lane = m->cur;
+  emu_switch(&m->fib[lane].sp, m->main_sp);
+}
+
+void run_wave(Machine *m, void (*entry)(int, void *), void *arg) {
+  g_m = m;
+  m->entry = entry; m->arg = arg;
+  for (int i = 0; i < kLanes; i++) {
+    m->done[i] = 0; m->narr[i] = 0;
+    char *top = m->fib[i].stack + kStack;
+    top = (char *)((uintptr_t)top & ~(uintptr_t)15);
+    void **sp = (void **)(top - 64);
+    // layout (low -> high): r15 r14 r13 r12 rbx rbp ret pad
+    for (int k = 0; k < 6; k++) sp[k] = nullptr;
+    sp[6] = (void *)&emu_trampoline;
+    sp[7] = nullptr;
+    m->fib[i].sp = sp;
+  }
+  // scheduler: repeatedly sweep lanes 0..63, resuming each unfinished fiber until it yields or finishes
+  for (;;) {
+    int alive = 0;
+    for (int i = 0; i < kLanes; i++) {
+      if (m->done[i]) continue;
+      alive++;
+      m->cur = i;
+      emu_switch(&m->main_sp, m->fib[i].sp);
+    }
+    if (!alive) break;
+  }
+}
+
+struct WaveEmu {
+  Machine *m;
+  int ln;
+  int lane() const { return ln; }
+  void arrive(int id) {
+    // lane 0 is always the first to reach arrival #n (it runs first in every sweep): compare with it
+    unsigned n = ++m->narr[ln];
+    m->siteh[n & 3][ln] = id;
+    if (ln > 0 && !m->done[0] && m->siteh[n & 3][0] != id) {
+      fprintf(stderr, "wave_emu: divergent collective #%u (lane %d at site %d, lane 0 at site %d)\n", n, ln, id, m->siteh[n & 3][0]);
+      abort();
+    }
+    yield_to_next(m);
+  }
+  void sync() { arrive(1); }
+  float sum(float v) {
+    m->fx[ln] = v;
+    arrive(2);
+    float t[kLanes];
+    for (int i = 0; i < kLanes; i++) t[i] = m->fx[i];
+    for (int mask = 32; mask >= 1; mask >>= 1) {            // same butterfly order as the GPU's __shfl_xor ladder
+      float n[kLanes];
+      for (int i = 0; i < kLanes; i++) n[i] = t[i] + t[i ^ mask];
+      memcpy(t, n, sizeof t);
+    }
+    float r = t[ln];
+    arrive(3);                                              // nobody overwrites fx before everyone has read it
+    return r;
+  }
+  unsigned long long ballot(int p) {
+    m->ux[ln] = p ? 1ull : 0ull;
+    arrive(4);
+    unsigned long long r = 0;
+    for (int i = 0; i < kLanes; i++) r |= m->ux[i] << i;
+    arrive(5);
+    return r;
+  }
+  unsigned long long bor(unsigned long long v) {
+    m->ux[ln] = v;
+    arrive(6);
+    unsigned long long r = 0;
+    for (int i = 0; i < kLanes; i++) r |= m->ux[i];
+    arrive(7);
+    return r;
+  }
+  bool any(int p) { return ballot(p) != 0ull; }
+  void atomic_add(float *p, float v) { *p += v; }
+};
+
+struct LaunchCtx { const ss::KArgs *k; const uint32_t *T; float *L; int env; Machine *m; };
+
+template <int DOFP, int CANDP>
+void lane_entry(int lane, void *arg) {
+  LaunchCtx *c = (LaunchCtx *)arg;
+  WaveEmu w{c->m, lane};
+  ss::run_env<WaveEmu, DOFP, CANDP>(&w, c->k, c->T, c->L, c->env);
+}
+
+struct EmuBackend {
+  static void *alloc(size_t n) { return calloc(1, n); }
+  static void free_(void *p) { free(p); }
+  static bool upload(void *dst, const void *src, size_t n) { memcpy(dst, src, n); return true; }
+  static bool set_device(int) { return true; }
+  static int lds_capacity() { return 160 * 1024; }
+  static int kernel_regs() { return 0; }
+  static const char *launch(const ss::KArgs &k, int nenv, int envs_per_wg, size_t lds_bytes, void *) {
+    (void)envs_per_wg; (void)lds_bytes;
+    static thread_local Machine *m = new Machine();
+    std::vector<float> L(k.h.env_floats);
+    const int dofp = (k.h.nv + 63) / 64, candp = (k.h.ncand + 63) / 64;
+    for (int env = 0; env < nenv; env++) {
+      // poison LDS so that reads of never-written locations are visible
+      for (auto &x : L) x = __builtin_nanf("");
+      LaunchCtx c{&k, k.shared_g, L.data(), env, m};
+      void (*entry)(int, void *) = nullptr;
+      if (dofp == 2 && candp == 2) entry = lane_entry<2, 2>;
+      else if (dofp == 3 && candp == 3) entry = lane_entry<3, 3>;
+      else if (dofp == 3 && candp == 2) entry = lane_entry<3, 2>;
+      else if (dofp == 2 && candp == 3) entry = lane_entry<2, 3>;
+      else if (dofp == 1 && candp == 1) entry = lane_entry<1, 1>;
+      else return "no kernel variant for this model size";
+      run_wave(m, entry, &c);
+    }
+    return nullptr;
+  }
+};
+
+}  // namespace
+
+SS_DEFINE_C_API(EmuBackend)

@@ -1,0 +1,107 @@
+"""numpy front-end to the wavefront-emulator build of the kernel (tests/wave_emu/libss_emu.so).
+
+UNIT-TEST INFRASTRUCTURE ONLY: it runs the kernel source on the CPU (64 fibers = 64 lanes) so the
+float32 kernel logic can be checked against the oracle in the GPU-less build container.  It binds
+the same C ABI as the product library, with host (numpy) buffers instead of device pointers.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from smplsim_amd import _cabi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libss_emu.so"])
+        _LIB = _cabi.bind(C.CDLL(os.path.join(_HERE, "libss_emu.so")))
+    return _LIB
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class EmuBatch:
+    def __init__(self, mc, tables, num_envs, legal_bodies=(), timestep=1.0 / 450, **cfg):
+        L = lib()
+        self.mc = mc
+        desc, self._keep = _cabi.make_model_desc(mc, *tables, legal_bodies=legal_bodies, timestep=timestep)
+        self.model = C.c_void_p()
+        self._chk(L.ss_model_create(C.byref(desc), 0, C.byref(self.model)))
+        self.cfg = _cabi.make_env_cfg(**cfg)
+        N, nq, nv, nb = num_envs, mc.nq, mc.nv, mc.nbody
+        self.N = N
+        self.qpos = np.zeros((N, nq), np.float32); self.qvel = np.zeros((N, nv), np.float32)
+        self.qpos_prev = np.zeros((N, nq), np.float32); self.qvel_prev = np.zeros((N, nv), np.float32)
+        self.qacc_warm = np.zeros((N, nv), np.float32); self.body_vel = np.zeros((N, nb, 6), np.float32)
+        self.touch = np.zeros((N, 2), np.int32); self.cur_t = np.zeros(N, np.int32)
+        self.task = np.zeros((N, 4), np.float32); self.nwarn = np.zeros(N, np.int32)
+        self.solver_iters = np.zeros(N, np.int32)
+        self.qpos[:, 3] = 1; self.qpos_prev[:, 3] = 1
+        st = _cabi.State(N, *[_p(x) for x in (self.qpos, self.qvel, self.qpos_prev, self.qvel_prev, self.qacc_warm,
+                                             self.body_vel, self.touch, self.cur_t, self.task, self.nwarn,
+                                             self.solver_iters)])
+        self.batch = C.c_void_p()
+        self._chk(L.ss_batch_create(self.model, C.byref(self.cfg), C.byref(st), C.byref(self.batch)))
+        self.obs_size = L.ss_obs_size(self.model, C.byref(self.cfg))
+        self.obs = np.zeros((N, self.obs_size), np.float32)
+        self.reward = np.zeros(N, np.float32)
+        self.terminated = np.zeros(N, np.uint8); self.truncated = np.zeros(N, np.uint8)
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RuntimeError(f"ss error {rc}: {lib().ss_last_error().decode()}")
+
+    def set_state(self, qpos, qvel, qpos_prev=None, qvel_prev=None, warm=None):
+        self.qpos[:] = qpos; self.qvel[:] = qvel
+        self.qpos_prev[:] = qpos if qpos_prev is None else qpos_prev
+        self.qvel_prev[:] = qvel if qvel_prev is None else qvel_prev
+        if warm is not None:
+            self.qacc_warm[:] = warm
+
+    def reset(self, mask=None, fall_actions=None, task_rand=None):
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        fa = None if fall_actions is None else np.ascontiguousarray(fall_actions, np.float32)
+        tr = None if task_rand is None else np.ascontiguousarray(task_rand, np.float32)
+        self._chk(lib().ss_reset(self.batch, _p(m), _p(fa), _p(tr), _p(self.obs), None))
+        return self.obs.copy()
+
+    def step(self, actions, task_rand=None):
+        a = np.ascontiguousarray(actions, np.float32)
+        tr = None if task_rand is None else np.ascontiguousarray(task_rand, np.float32)
+        self._chk(lib().ss_step(self.batch, _p(a), _p(tr), _p(self.obs), _p(self.reward), _p(self.terminated),
+                                _p(self.truncated), None))
+        return self.obs.copy(), self.reward.copy(), self.terminated.copy().astype(bool), self.truncated.copy().astype(bool)
+
+    def substep(self, actions, n):
+        a = np.ascontiguousarray(actions, np.float32)
+        self._chk(lib().ss_substep(self.batch, _p(a), n, None))
+
+    def kinematics(self):
+        xpos = np.zeros((self.N, self.mc.nbody, 3), np.float32); xmat = np.zeros((self.N, self.mc.nbody, 9), np.float32)
+        self._chk(lib().ss_kinematics(self.batch, _p(xpos), _p(xmat), None))
+        return xpos, xmat
+
+    def debug_forward(self, torques=None):
+        ne = C.c_int32()
+        self._chk(lib().ss_debug_decode(self.model, None, C.byref(ne)))
+        dec = np.zeros(ne.value, np.int32)
+        self._chk(lib().ss_debug_decode(self.model, _p(dec), C.byref(ne)))
+        Me = np.zeros((self.N, ne.value), np.float32)
+        bias = np.zeros((self.N, self.mc.nv), np.float32); qacc = np.zeros((self.N, self.mc.nv), np.float32)
+        tq = None if torques is None else np.ascontiguousarray(torques, np.float32)
+        self._chk(lib().ss_debug_forward(self.batch, _p(tq), _p(Me), _p(bias), _p(qacc), None))
+        nv = self.mc.nv
+        M = np.zeros((self.N, nv, nv), np.float32)
+        rows, cols = dec >> 16, dec & 0xFFFF
+        lower = rows >= cols
+        M[:, rows[lower], cols[lower]] = Me[:, lower]
+        M[:, cols[lower], rows[lower]] = Me[:, lower]
+        return M, bias, qacc
