@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 CSV outputs (kernel trace stats + PMC passes) into small text/JSON files.
+Usage: prof_summarize.py <prof_dir> <out_prefix>"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+prof, out = sys.argv[1], sys.argv[2]
+summary = {}
+# kernel trace: per-kernel count / avg / total duration
+for f in glob.glob(os.path.join(prof, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    agg = defaultdict(lambda: [0, 0.0])
+    rows = list(csv.DictReader(open(f)))
+    for r in rows:
+        d = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+        a = agg[r["Kernel_Name"]]
+        a[0] += 1; a[1] += d
+    tot = sum(a[1] for a in agg.values())
+    summary["kernel_trace"] = [
+        {"kernel": k[:100], "calls": a[0], "total_ms": a[1] / 1e6, "avg_us": a[1] / a[0] / 1e3, "pct": 100 * a[1] / tot}
+        for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1])][:12]
+    if rows:
+        r0 = [r for r in rows if "ss_env_kernel" in r["Kernel_Name"]]
+        if r0:
+            summary["step_kernel_resources"] = {k: r0[0].get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size")}
+# PMC passes: per-kernel mean of each counter (sum over dispatch dims as reported)
+for d in sorted(glob.glob(os.path.join(prof, "pmc_*"))):
+    if not os.path.isdir(d):
+        continue
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        agg = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+        for r in csv.DictReader(open(f)):
+            kname = r["Kernel_Name"]
+            if "ss_env_kernel" not in kname:
+                continue
+            key = "step" if r.get("Grid_Size") else "k"
+            a = agg[kname[:60]][r["Counter_Name"]]
+            a[0] += 1; a[1] += float(r["Counter_Value"])
+        for kname, cs in agg.items():
+            summary.setdefault("pmc", {}).setdefault(kname, {}).update({c: {"dispatches": a[0], "mean_per_dispatch": a[1] / a[0]} for c, a in cs.items()})
+json.dump(summary, open(out + ".json", "w"), indent=1)
+with open(out + ".txt", "w") as fo:
+    for e in summary.get("kernel_trace", []):
+        fo.write(f"{e['pct']:6.2f}%  calls={e['calls']:5d}  avg={e['avg_us']:10.1f} us  total={e['total_ms']:9.2f} ms  {e['kernel']}\n")
+    fo.write(json.dumps(summary.get("step_kernel_resources", {})) + "\n")
+    for kname, cs in summary.get("pmc", {}).items():
+        fo.write(f"PMC {kname}\n")
+        for c, a in sorted(cs.items()):
+            fo.write(f"   {c:28s} mean/dispatch={a['mean_per_dispatch']:.6g}  (n={a['dispatches']})\n")
+print(open(out + ".txt").read())
