@@ -155,7 +155,7 @@ struct ss_api {
   int ss_debug_decode(const ss_model *m, int32_t *out, int32_t *ne) {                                                \
     if (!m || !ne) return ss_api<BE>::fail(SS_ERR_INVALID, "null argument");                                         \
     *ne = m->hm.h.ne;                                                                                                \
-    if (out) for (int e = 0; e < m->hm.h.ne; e++) out[e] = (int32_t)m->hm.shared[m->hm.h.o_decode + e];              \
+    if (out) for (int e = 0; e < m->hm.h.ne; e++) out[e] = (int32_t)m->hm.decode[e];              \
     return SS_OK;                                                                                                    \
   }                                                                                                                  \
   int ss_launch_info(const ss_batch *b, int32_t *epw, int32_t *lds, int32_t *regs) {                                 \

@@ -14,10 +14,10 @@ constexpr int kCandC = 8;    // floats per contact candidate
 // Header passed to the kernels by value: dims, table offsets (32-bit words into the shared blob),
 // per-env LDS layout (float offsets) and physics scalars.
 struct Hdr {
-  int nb, nn, nv, nq, nu, ne, ncand, nlev, nblev, maxD;
+  int nb, nn, nv, nq, nu, ne, ncand, nlev, nblev, maxD, nblk;
+  int levstart[20], blevstart[20];   // node / body level offsets (kernel arguments -> scalar loads)
   // shared-blob word offsets
-  int o_dofc, o_decode, o_chainrow, o_chainnode, o_nbase, o_ndepth, o_nparent, o_levstart, o_levnodes,
-      o_bparent, o_blevstart, o_blevbodies, shared_words;
+  int o_dofc, o_chainnode, o_nbase, o_ndepth, o_levnodes, o_bparent, o_blevbodies, o_blk, o_trilut, shared_words;
   // per-env LDS float offsets
   int l_H, l_S, l_G, l_Dinv, l_R, l_r, l_Ic, l_K, l_V, l_Ab, l_Ad, l_Gb, l_q, l_v, l_a, l_tau, l_grad,
       l_delta, l_C, l_diag, l_misc, env_floats;

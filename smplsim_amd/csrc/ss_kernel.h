@@ -41,6 +41,7 @@ struct Contact {
   int body, active;
 };
 struct Limit { float sign, D, aref, jar, jd; };
+struct alignas(16) float4_t { float x, y, z, w; };
 
 SS_DEV float bits2f(uint32_t u) { union { uint32_t u; float f; } c; c.u = u; return c.f; }
 SS_DEV bool is_bad(float x) { return !(x <= 1e10f && x >= -1e10f); }
@@ -54,14 +55,12 @@ struct Sim {
   // per-env LDS arrays
   float *H, *S, *G, *Dinv, *R, *r, *Ic, *Kc, *V, *Ab, *Ad, *Gb, *q, *v, *a, *tau, *grad, *delta, *C, *diag, *misc;
   // per-lane constants
-  float bc[kBodyC];
   int bpar, bdep;
-  float cc[CANDP][kCandC];
-  int cb[CANDP];
   // per-lane state
   float Ib[10], fb[6], sv[6];
   Contact con[CANDP];
   Limit lim[DOFP];
+  float perr[DOFP];
   int iters, nwarn_add;
   unsigned long long touchmask;
 
@@ -77,23 +76,12 @@ struct Sim {
     q = L + h.l_q; v = L + h.l_v; a = L + h.l_a; tau = L + h.l_tau; grad = L + h.l_grad;
     delta = L + h.l_delta; C = L + h.l_C; diag = L + h.l_diag; misc = L + h.l_misc;
     bpar = -1; bdep = -1;
-    for (int i = 0; i < kBodyC; i++) bc[i] = 0.f;
-    if (lane < h.nb) {
-      for (int i = 0; i < kBodyC; i++) bc[i] = k->bodyc[lane * kBodyC + i];
-      bpar = ti(h.o_bparent, lane);
-      bdep = ti(h.o_ndepth, lane + 1) - 1;
-    }
-    for (int p = 0; p < CANDP; p++) {
-      int c = p * 64 + lane;
-      cb[p] = -1;
-      for (int i = 0; i < kCandC; i++) cc[p][i] = 0.f;
-      if (c < h.ncand) {
-        cb[p] = k->candb[c];
-        for (int i = 0; i < kCandC; i++) cc[p][i] = k->candc[c * kCandC + i];
-      }
-      con[p].active = 0;
-    }
+    if (lane < h.nb) { bpar = ti(h.o_bparent, lane); bdep = ti(h.o_ndepth, lane + 1) - 1; }
+#pragma unroll
+    for (int p = 0; p < CANDP; p++) con[p].active = 0;
+#pragma unroll
     for (int p = 0; p < DOFP; p++) lim[p].sign = 0.f;
+#pragma unroll
     for (int i = 0; i < 6; i++) sv[i] = 0.f;
     iters = 0; nwarn_add = 0; touchmask = 0ull;
   }
@@ -107,7 +95,7 @@ struct Sim {
   SS_DEV void tree_accumulate(float *arr) {               // arr[b] += sum over descendants, in place
     const Hdr &h = k->h;
     for (int L = h.nblev - 1; L >= 1; --L) {
-      int s = ti(h.o_blevstart, L), n = (ti(h.o_blevstart, L + 1) - s) * NC;
+      int s = h.blevstart[L], n = (h.blevstart[L + 1] - s) * NC;
       for (int idx = lane; idx < n; idx += 64) {
         int bi = idx / NC, c = idx - bi * NC;
         int b = ti(h.o_blevbodies, s + bi), p = ti(h.o_bparent, b);
@@ -138,6 +126,13 @@ struct Sim {
     const Hdr &h = k->h;
     float vb[6] = {0, 0, 0, 0, 0, 0}, ab[6] = {0, 0, 0, 0, 0, 0};
     float Rb[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, rb[3] = {0, 0, 0};
+    float bc[kBodyC];                                       // this lane's body constants (L1/L2-resident table)
+    {
+      const float4_t *src = reinterpret_cast<const float4_t *>(k->bodyc + (lane < h.nb ? lane : 0) * kBodyC);
+      const float4_t b0 = src[0], b1 = src[1], b2 = src[2], b3 = src[3];
+      bc[0] = b0.x; bc[1] = b0.y; bc[2] = b0.z; bc[3] = b0.w; bc[4] = b1.x; bc[5] = b1.y; bc[6] = b1.z; bc[7] = b1.w;
+      bc[8] = b2.x; bc[9] = b2.y; bc[10] = b2.z; bc[11] = b2.w; bc[12] = b3.x; bc[13] = b3.y; bc[14] = b3.z; bc[15] = b3.w;
+    }
     if (lane == 0) {
       float qw = q[3], qx = q[4], qy = q[5], qz = q[6];
       float n = sqrtf(qw * qw + qx * qx + qy * qy + qz * qz);
@@ -145,10 +140,13 @@ struct Sim {
       Rb[0] = 1 - 2 * (qy * qy + qz * qz); Rb[1] = 2 * (qx * qy - qw * qz); Rb[2] = 2 * (qx * qz + qw * qy);
       Rb[3] = 2 * (qx * qy + qw * qz); Rb[4] = 1 - 2 * (qx * qx + qz * qz); Rb[5] = 2 * (qy * qz - qw * qx);
       Rb[6] = 2 * (qx * qz - qw * qy); Rb[7] = 2 * (qy * qz + qw * qx); Rb[8] = 1 - 2 * (qx * qx + qy * qy);
+#pragma unroll
       for (int i = 0; i < 9; i++) R[i] = Rb[i];
       r[0] = r[1] = r[2] = 0.f;
+#pragma unroll
       for (int d = 0; d < 6; d++) for (int c = 0; c < 6; c++) S[6 * d + c] = 0.f;
       S[0 * 6 + 3] = 1.f; S[1 * 6 + 4] = 1.f; S[2 * 6 + 5] = 1.f;
+#pragma unroll
       for (int d = 0; d < 3; d++) { S[6 * (3 + d) + 0] = Rb[d]; S[6 * (3 + d) + 1] = Rb[3 + d]; S[6 * (3 + d) + 2] = Rb[6 + d]; }
       if (with_dyn) {
         float wl0 = v[3], wl1 = v[4], wl2 = v[5];
@@ -160,6 +158,7 @@ struct Sim {
         ab[3] = vb[4] * vb[2] - vb[5] * vb[1];
         ab[4] = vb[5] * vb[0] - vb[3] * vb[2];
         ab[5] = vb[3] * vb[1] - vb[4] * vb[0];
+#pragma unroll
         for (int c = 0; c < 6; c++) { V[c] = vb[c]; Ad[c] = ab[c]; }
       }
     }
@@ -168,12 +167,16 @@ struct Sim {
       if (bdep == L) {
         const int b = lane, n = b + 1;
         float Rp[9], rp[3];
+#pragma unroll
         for (int i = 0; i < 9; i++) Rp[i] = R[9 * bpar + i];
+#pragma unroll
         for (int i = 0; i < 3; i++) rp[i] = r[3 * bpar + i];
+#pragma unroll
         for (int i = 0; i < 3; i++) rb[i] = rp[i] + Rp[3 * i] * bc[0] + Rp[3 * i + 1] * bc[1] + Rp[3 * i + 2] * bc[2];
         float sx, cx, sy, cy, sz, cz;
         sincosf(q[3 * b + 4], &sx, &cx); sincosf(q[3 * b + 5], &sy, &cy); sincosf(q[3 * b + 6], &sz, &cz);
         float ax[3], ay[3], az[3], c0[3], c1[3], c2[3];
+#pragma unroll
         for (int i = 0; i < 3; i++) {
           float p0 = Rp[3 * i], p1 = Rp[3 * i + 1], p2 = Rp[3 * i + 2];
           ax[i] = p0;
@@ -183,21 +186,28 @@ struct Sim {
           az[i] = r22;
           c0[i] = cz * r20 + sz * r11; c1[i] = -sz * r20 + cz * r11; c2[i] = r22;   // R3 = R2 Rz
         }
+#pragma unroll
         for (int i = 0; i < 3; i++) { Rb[3 * i] = c0[i]; Rb[3 * i + 1] = c1[i]; Rb[3 * i + 2] = c2[i]; }
+#pragma unroll
         for (int i = 0; i < 9; i++) R[9 * b + i] = Rb[i];
+#pragma unroll
         for (int i = 0; i < 3; i++) r[3 * b + i] = rb[i];
         float sd[3][6];
         const float *axs[3] = {ax, ay, az};
+#pragma unroll
         for (int j = 0; j < 3; j++) {
           const float *A_ = axs[j];
           sd[j][0] = A_[0]; sd[j][1] = A_[1]; sd[j][2] = A_[2];
           sd[j][3] = rb[1] * A_[2] - rb[2] * A_[1];
           sd[j][4] = rb[2] * A_[0] - rb[0] * A_[2];
           sd[j][5] = rb[0] * A_[1] - rb[1] * A_[0];
+#pragma unroll
           for (int c = 0; c < 6; c++) S[6 * (3 * n + j) + c] = sd[j][c];
         }
         if (with_dyn) {
+#pragma unroll
           for (int c = 0; c < 6; c++) { vb[c] = V[6 * bpar + c]; ab[c] = Ad[6 * bpar + c]; }
+#pragma unroll
           for (int j = 0; j < 3; j++) {
             float qd = v[3 * n + j];
             const float *s = sd[j];
@@ -207,8 +217,10 @@ struct Sim {
             float d1 = vb[2] * s[3] - vb[0] * s[5] + vb[5] * s[0] - vb[3] * s[2];
             float d2 = vb[0] * s[4] - vb[1] * s[3] + vb[3] * s[1] - vb[4] * s[0];
             ab[0] += c0_ * qd; ab[1] += c1_ * qd; ab[2] += c2_ * qd; ab[3] += d0 * qd; ab[4] += d1 * qd; ab[5] += d2 * qd;
+#pragma unroll
             for (int c = 0; c < 6; c++) vb[c] += s[c] * qd;
           }
+#pragma unroll
           for (int c = 0; c < 6; c++) { V[6 * b + c] = vb[c]; Ad[6 * b + c] = ab[c]; }
         }
       }
@@ -225,6 +237,7 @@ struct Sim {
       // Ibar = Rb Ibody Rb^T
       float Bm[9] = {bc[7], bc[8], bc[9], bc[8], bc[10], bc[11], bc[9], bc[11], bc[12]};
       float RB[9];
+#pragma unroll
       for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
         RB[3 * i + j] = Rb[3 * i] * Bm[j] + Rb[3 * i + 1] * Bm[3 + j] + Rb[3 * i + 2] * Bm[6 + j];
       float Ixx = RB[0] * Rb[0] + RB[1] * Rb[1] + RB[2] * Rb[2];
@@ -236,6 +249,7 @@ struct Sim {
       Ib[0] = m; Ib[1] = m * cx_; Ib[2] = m * cy_; Ib[3] = m * cz_;
       Ib[4] = Ixx + m * (cy_ * cy_ + cz_ * cz_); Ib[5] = Ixy - m * cx_ * cy_; Ib[6] = Ixz - m * cx_ * cz_;
       Ib[7] = Iyy + m * (cx_ * cx_ + cz_ * cz_); Ib[8] = Iyz - m * cy_ * cz_; Ib[9] = Izz + m * (cx_ * cx_ + cy_ * cy_);
+#pragma unroll
       for (int i = 0; i < 10; i++) Ic[10 * b + i] = Ib[i];
       // f = I (a - a_grav) + v x* (I v)
       float ag[6] = {ab[0], ab[1], ab[2], ab[3], ab[4], ab[5] - h.grav};
@@ -247,6 +261,7 @@ struct Sim {
       fb[3] = Ia[3] + vb[1] * Iv[5] - vb[2] * Iv[4];
       fb[4] = Ia[4] + vb[2] * Iv[3] - vb[0] * Iv[5];
       fb[5] = Ia[5] + vb[0] * Iv[4] - vb[1] * Iv[3];
+#pragma unroll
       for (int c = 0; c < 6; c++) Gb[6 * b + c] = fb[c];
       // framelinvel / frameangvel of the body frame origin
       sv[0] = vb[3] + vb[1] * rb[2] - vb[2] * rb[1];
@@ -257,7 +272,7 @@ struct Sim {
     w->sync();
     // composite inertia and bias force C = S^T subtree(f): one fused level sweep (16 comps per body)
     for (int L = h.nblev - 1; L >= 1; --L) {
-      int s = ti(h.o_blevstart, L), n = (ti(h.o_blevstart, L + 1) - s) * 16;
+      int s = h.blevstart[L], n = (h.blevstart[L + 1] - s) * 16;
       for (int idx = lane; idx < n; idx += 64) {
         int bi = idx >> 4, c = idx & 15;
         int b = ti(h.o_blevbodies, s + bi), p = ti(h.o_bparent, b);
@@ -266,11 +281,13 @@ struct Sim {
       }
       w->sync();
     }
+#pragma unroll
     for (int p = 0; p < DOFP; p++) {
       int i = p * 64 + lane;
       if (i < h.nv) {
         int n = i / 3, b = n > 0 ? n - 1 : 0;
         float s = 0.f;
+#pragma unroll
         for (int c = 0; c < 6; c++) s += S[6 * i + c] * Gb[6 * b + c];
         C[i] = s;
       }
@@ -308,16 +325,25 @@ struct Sim {
     const Hdr &h = k->h;
     const float pz = q[2], mu = h.mu;
     touchmask = 0ull;
+#pragma unroll
     for (int p = 0; p < CANDP; p++) {
       Contact &c = con[p];
       c.active = 0;
       int qual = 0;
       float dist = 0.f, px = 0, py = 0, pzr = 0;
-      const bool valid = cb[p] >= 0;
-      const int b = valid ? (cb[p] & 255) : 0;
-      const bool caps = valid && (cb[p] & 256);
+      const int cidx = p * 64 + lane;
+      const bool valid = cidx < h.ncand;
+      const int cbp = valid ? k->candb[cidx] : 0;
+      const int b = cbp & 255;
+      const bool caps = valid && (cbp & 256);
+      float cv[kCandC];
+      {
+        const float4_t *src = reinterpret_cast<const float4_t *>(k->candc + (valid ? cidx : 0) * kCandC);
+        const float4_t c0 = src[0], c1 = src[1];
+        cv[0] = c0.x; cv[1] = c0.y; cv[2] = c0.z; cv[3] = c0.w; cv[4] = c1.x; cv[5] = c1.y; cv[6] = c1.z; cv[7] = c1.w;
+      }
       if (valid) {
-        const float *Rb = R + 9 * b, *rb = r + 3 * b, *cv = cc[p];
+        const float *Rb = R + 9 * b, *rb = r + 3 * b;
         if (!caps) {
           float ldist = Rb[6] * cv[0] + Rb[7] * cv[1] + Rb[8] * cv[2];
           float dcen = pz + rb[2] + Rb[6] * cv[3] + Rb[7] * cv[4] + Rb[8] * cv[5];
@@ -358,7 +384,7 @@ struct Sim {
         float vz = vb[5] + vb[0] * py - vb[1] * px;
         float vt1 = c.t1x * vx + c.t1y * vy, vt2 = -c.t1y * vx + c.t1x * vy;
         float imp = impedance(dist, h.margin);
-        float R0 = (1.f - imp) / imp * cc[p][7] * (1.f + mu * mu);
+        float R0 = (1.f - imp) / imp * cv[7] * (1.f + mu * mu);
         if (R0 < 1e-15f) R0 = 1e-15f;
         float Rpy = 2.f * mu * mu * R0;
         c.D = 1.f / Rpy;
@@ -370,6 +396,7 @@ struct Sim {
       }
       touchmask |= w->bor(act ? (1ull << b) : 0ull);         // wave-wide OR: bodies touching the floor
     }
+#pragma unroll
     for (int p = 0; p < DOFP; p++) {
       int i = p * 64 + lane;
       Limit &l = lim[p];
@@ -392,6 +419,7 @@ struct Sim {
   // rows: jar (from A = Ab, x = a) or jd (from A = Ad, x = delta)
   SS_DEV void eval_rows(const float *A, const float *x, bool is_delta) {
     const float mu = k->h.mu;
+#pragma unroll
     for (int p = 0; p < CANDP; p++) {
       Contact &c = con[p];
       if (!c.active) continue;
@@ -403,6 +431,7 @@ struct Sim {
       if (is_delta) { c.jd[0] = az + t1; c.jd[1] = az - t1; c.jd[2] = az + t2; c.jd[3] = az - t2; }
       else { c.jar[0] = az + t1 - c.aref[0]; c.jar[1] = az - t1 - c.aref[1]; c.jar[2] = az + t2 - c.aref[2]; c.jar[3] = az - t2 - c.aref[3]; }
     }
+#pragma unroll
     for (int p = 0; p < DOFP; p++) {
       int i = p * 64 + lane;
       Limit &l = lim[p];
@@ -412,86 +441,128 @@ struct Sim {
   }
 
   // ------------------------------------------------------------------ H assembly: H(i,j) = S_j . (Hc_body(i) S_i) + diag
-  // Hc = expand(Ic) + Kc (Kc must hold subtree sums, or zeros)
+  // Hc = expand(Ic) + Kc (Kc must hold subtree sums, or zeros).  Work items are 3x3 blocks
+  // (node n, chain position J <= depth(n)); block (n,J)[r][c] = S[3 aJ + c] . G[3 n + r].
   SS_DEV void assemble_H() {
     const Hdr &h = k->h;
+#pragma unroll
     for (int p = 0; p < DOFP; p++) {
       int i = p * 64 + lane;
       if (i < h.nv) {
         int n = i / 3, b = n > 0 ? n - 1 : 0;
         const float *I = Ic + 10 * b, *Km = Kc + 21 * b, *s = S + 6 * i;
+        const float s0 = s[0], s1 = s[1], s2 = s[2], s3 = s[3], s4 = s[4], s5 = s[5];
+        const float x[6] = {s0, s1, s2, s3, s4, s5};
         float g[6];
-        imul(I, s, g);
-        const int off[6] = {0, 6, 11, 15, 18, 20};
-        for (int a_ = 0; a_ < 6; a_++) {
-          float acc = 0.f;
-          for (int c = 0; c < 6; c++) {
-            int lo = a_ < c ? a_ : c, hi = a_ < c ? c : a_;
-            acc += Km[off[lo] + (hi - lo)] * s[c];
-          }
-          g[a_] += acc;
-        }
-        for (int c = 0; c < 6; c++) G[6 * i + c] = g[c];
+        imul(I, x, g);
+        g[0] += Km[0] * s0 + Km[1] * s1 + Km[2] * s2 + Km[3] * s3 + Km[4] * s4 + Km[5] * s5;
+        g[1] += Km[1] * s0 + Km[6] * s1 + Km[7] * s2 + Km[8] * s3 + Km[9] * s4 + Km[10] * s5;
+        g[2] += Km[2] * s0 + Km[7] * s1 + Km[11] * s2 + Km[12] * s3 + Km[13] * s4 + Km[14] * s5;
+        g[3] += Km[3] * s0 + Km[8] * s1 + Km[12] * s2 + Km[15] * s3 + Km[16] * s4 + Km[17] * s5;
+        g[4] += Km[4] * s0 + Km[9] * s1 + Km[13] * s2 + Km[16] * s3 + Km[18] * s4 + Km[19] * s5;
+        g[5] += Km[5] * s0 + Km[10] * s1 + Km[14] * s2 + Km[17] * s3 + Km[19] * s4 + Km[20] * s5;
+        float *go = G + 6 * i;
+        go[0] = g[0]; go[1] = g[1]; go[2] = g[2]; go[3] = g[3]; go[4] = g[4]; go[5] = g[5];
       }
     }
     w->sync();
-    for (int e = lane; e < h.ne; e += 64) {
-      int code = ti(h.o_decode, e), i = code >> 16, j = code & 0xFFFF;
-      const float *sj = S + 6 * j, *gi = G + 6 * i;
-      float acc = sj[0] * gi[0] + sj[1] * gi[1] + sj[2] * gi[2] + sj[3] * gi[3] + sj[4] * gi[4] + sj[5] * gi[5];
-      if (i == j) acc += diag[i];
-      H[e] = acc;
+    for (int e = lane; e < h.nblk; e += 64) {
+      const int code = ti(h.o_blk, e), n = code >> 8, J = code & 255;
+      const int aJ = ti(h.o_chainnode, n * h.nlev + J);
+      const int d = ti(h.o_ndepth, n), Wd = 3 * d + 3, base = ti(h.o_nbase, n);
+      const float *sj = S + 18 * aJ, *gi = G + 18 * n;
+      float sv_[18], gv_[18];
+#pragma unroll
+      for (int t = 0; t < 18; t++) { sv_[t] = sj[t]; gv_[t] = gi[t]; }
+      const bool dg = (aJ == n);
+#pragma unroll
+      for (int r_ = 0; r_ < 3; r_++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          float acc = 0.f;
+#pragma unroll
+          for (int t = 0; t < 6; t++) acc += sv_[6 * c + t] * gv_[6 * r_ + t];
+          if (dg && r_ == c) acc += diag[3 * n + r_];
+          H[base + r_ * Wd + 3 * J + c] = acc;
+        }
+      }
     }
     w->sync();
   }
 
   // ------------------------------------------------------------------ level-parallel 3x3-block L^T D L
+  // H = L^T D L with unit block-lower-triangular L on the tree pattern; node k at depth d couples to its
+  // d ancestor nodes through the 3 x 3d block row P_k.  Per level (deepest first):
+  //   phase 1  Dinv_k = inv(diag block), U_k = Dinv_k P_k
+  //   phase 2  ancestor blocks (I >= J) -= P_k[:,I]^T U_k[:,J]      (LDS float atomics: nodes of one
+  //            level in different branches update the same ancestor blocks)
+  //   phase 3  P_k <- U_k (rows of L)
   SS_DEV void factor_H() {
     const Hdr &h = k->h;
     float *U = G;                                            // G is free between assembly and the next one
     for (int L = h.nlev - 1; L >= 0; --L) {
-      const int s = ti(h.o_levstart, L), nk = ti(h.o_levstart, L + 1) - s, D = 3 * L, Wd = D + 3;
-      const int cols = D > 0 ? D : 1;
-      // phase 1: Dinv_k and U = Dinv_k P
-      for (int idx = lane; idx < nk * cols; idx += 64) {
-        int kk = idx / cols, j = idx - kk * cols;
+      const int s = h.levstart[L], nk = h.levstart[L + 1] - s, D = 3 * L, Wd = D + 3;
+      const int Lc = L > 0 ? L : 1;
+      const float rLc = 1.0f / (float)Lc;
+      for (int idx = lane; idx < nk * Lc; idx += 64) {
+        int kk = (int)(((float)idx + 0.5f) * rLc), J = idx - kk * Lc;
         int n = ti(h.o_levnodes, s + kk), base = ti(h.o_nbase, n);
-        float d00 = H[base + D], d10 = H[base + Wd + D], d11 = H[base + Wd + D + 1];
-        float d20 = H[base + 2 * Wd + D], d21 = H[base + 2 * Wd + D + 1], d22 = H[base + 2 * Wd + D + 2];
+        const float *db = H + base + D;
+        float d00 = db[0], d10 = db[Wd], d11 = db[Wd + 1], d20 = db[2 * Wd], d21 = db[2 * Wd + 1], d22 = db[2 * Wd + 2];
         float c00 = d11 * d22 - d21 * d21, c01 = d21 * d20 - d10 * d22, c02 = d10 * d21 - d11 * d20;
-        float det = d00 * c00 + d10 * c01 + d20 * c02;
-        float id = 1.f / det;
+        float id = 1.f / (d00 * c00 + d10 * c01 + d20 * c02);
         float i00 = c00 * id, i01 = c01 * id, i02 = c02 * id;
         float i11 = (d00 * d22 - d20 * d20) * id, i12 = (d10 * d20 - d00 * d21) * id, i22 = (d00 * d11 - d10 * d10) * id;
-        if (j == 0) { float *o = Dinv + 6 * n; o[0] = i00; o[1] = i01; o[2] = i02; o[3] = i11; o[4] = i12; o[5] = i22; }
-        if (j < D) {
-          float p0 = H[base + j], p1 = H[base + Wd + j], p2 = H[base + 2 * Wd + j];
-          U[(kk * 3 + 0) * D + j] = i00 * p0 + i01 * p1 + i02 * p2;
-          U[(kk * 3 + 1) * D + j] = i01 * p0 + i11 * p1 + i12 * p2;
-          U[(kk * 3 + 2) * D + j] = i02 * p0 + i12 * p1 + i22 * p2;
+        if (J == 0) { float *o = Dinv + 6 * n; o[0] = i00; o[1] = i01; o[2] = i02; o[3] = i11; o[4] = i12; o[5] = i22; }
+        if (L > 0) {
+          const float *pb = H + base + 3 * J;
+          float *ub = U + (kk * 3) * D + 3 * J;
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            float p0 = pb[c], p1 = pb[Wd + c], p2 = pb[2 * Wd + c];
+            ub[c] = i00 * p0 + i01 * p1 + i02 * p2;
+            ub[D + c] = i01 * p0 + i11 * p1 + i12 * p2;
+            ub[2 * D + c] = i02 * p0 + i12 * p1 + i22 * p2;
+          }
         }
       }
-      if (L == 0) { w->sync(); break; }
       w->sync();
-      // phase 2: ancestor block -= P^T U   (lower triangle i >= j over the chain positions)
-      const int Tn = D * (D + 1) / 2;
+      if (L == 0) break;
+      const int Tn = L * (L + 1) / 2;
+      const float rT = 1.0f / (float)Tn;
       for (int idx = lane; idx < nk * Tn; idx += 64) {
-        int kk = idx / Tn, t = idx - kk * Tn;
-        int i = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
-        while ((i + 1) * (i + 2) / 2 <= t) i++;
-        while (i * (i + 1) / 2 > t) i--;
-        int j = t - i * (i + 1) / 2;
+        int kk = (int)(((float)idx + 0.5f) * rT), t = idx - kk * Tn;
+        int ij = ti(h.o_trilut, t), I = ij >> 8, J = ij & 255;
         int n = ti(h.o_levnodes, s + kk), base = ti(h.o_nbase, n);
-        float val = H[base + i] * U[(kk * 3) * D + j] + H[base + Wd + i] * U[(kk * 3 + 1) * D + j] + H[base + 2 * Wd + i] * U[(kk * 3 + 2) * D + j];
-        int dst = ti(h.o_chainrow, n * h.maxD + i) + j;
-        w->atomic_add(&H[dst], -val);
+        int aI = ti(h.o_chainnode, n * h.nlev + I), Wa = 3 * I + 3;
+        const float *pb = H + base + 3 * I, *ub = U + (kk * 3) * D + 3 * J;
+        float P_[9], U_[9];
+#pragma unroll
+        for (int r_ = 0; r_ < 3; r_++) {
+#pragma unroll
+          for (int c = 0; c < 3; c++) { P_[3 * r_ + c] = pb[r_ * Wd + c]; U_[3 * r_ + c] = ub[r_ * D + c]; }
+        }
+        float *dst = H + ti(h.o_nbase, aI) + 3 * J;
+#pragma unroll
+        for (int a_ = 0; a_ < 3; a_++) {
+#pragma unroll
+          for (int b_ = 0; b_ < 3; b_++) {
+            float val = P_[a_] * U_[b_] + P_[3 + a_] * U_[3 + b_] + P_[6 + a_] * U_[6 + b_];
+            w->atomic_add(&dst[a_ * Wa + b_], -val);
+          }
+        }
       }
       w->sync();
-      // phase 3: overwrite P by U (the L factor rows)
-      for (int idx = lane; idx < nk * D; idx += 64) {
-        int kk = idx / D, j = idx - kk * D;
+      for (int idx = lane; idx < nk * L; idx += 64) {
+        int kk = (int)(((float)idx + 0.5f) * rLc), J = idx - kk * L;
         int n = ti(h.o_levnodes, s + kk), base = ti(h.o_nbase, n);
-        H[base + j] = U[(kk * 3) * D + j]; H[base + Wd + j] = U[(kk * 3 + 1) * D + j]; H[base + 2 * Wd + j] = U[(kk * 3 + 2) * D + j];
+        float *pb = H + base + 3 * J;
+        const float *ub = U + (kk * 3) * D + 3 * J;
+#pragma unroll
+        for (int r_ = 0; r_ < 3; r_++) {
+#pragma unroll
+          for (int c = 0; c < 3; c++) pb[r_ * Wd + c] = ub[r_ * D + c];
+        }
       }
       w->sync();
     }
@@ -501,13 +572,17 @@ struct Sim {
   SS_DEV void solve_H(float *x) {
     const Hdr &h = k->h;
     for (int L = h.nlev - 1; L >= 1; --L) {                  // x <- L^-T x (leaves to root)
-      const int s = ti(h.o_levstart, L), nk = ti(h.o_levstart, L + 1) - s, D = 3 * L, Wd = D + 3;
-      for (int idx = lane; idx < nk * D; idx += 64) {
-        int kk = idx / D, j = idx - kk * D;
+      const int s = h.levstart[L], nk = h.levstart[L + 1] - s, Wd = 3 * L + 3;
+      const float rL = 1.0f / (float)L;
+      for (int idx = lane; idx < nk * L; idx += 64) {
+        int kk = (int)(((float)idx + 0.5f) * rL), J = idx - kk * L;
         int n = ti(h.o_levnodes, s + kk), base = ti(h.o_nbase, n);
-        float val = H[base + j] * x[3 * n] + H[base + Wd + j] * x[3 * n + 1] + H[base + 2 * Wd + j] * x[3 * n + 2];
-        int dj = 3 * ti(h.o_chainnode, n * h.nlev + j / 3) + j % 3;
-        w->atomic_add(&x[dj], -val);
+        int aJ = ti(h.o_chainnode, n * h.nlev + J);
+        const float *ub = H + base + 3 * J;
+        float z0 = x[3 * n], z1 = x[3 * n + 1], z2 = x[3 * n + 2];
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+          w->atomic_add(&x[3 * aJ + c], -(ub[c] * z0 + ub[Wd + c] * z1 + ub[2 * Wd + c] * z2));
       }
       w->sync();
     }
@@ -520,14 +595,17 @@ struct Sim {
     }
     w->sync();
     for (int L = 1; L < h.nlev; L++) {                        // x <- L^-1 x (root to leaves)
-      const int s = ti(h.o_levstart, L), nk = ti(h.o_levstart, L + 1) - s, D = 3 * L, Wd = D + 3;
-      for (int idx = lane; idx < nk * D; idx += 64) {
-        int kk = idx / D, j = idx - kk * D;
+      const int s = h.levstart[L], nk = h.levstart[L + 1] - s, Wd = 3 * L + 3;
+      const float rL = 1.0f / (float)L;
+      for (int idx = lane; idx < nk * L; idx += 64) {
+        int kk = (int)(((float)idx + 0.5f) * rL), J = idx - kk * L;
         int n = ti(h.o_levnodes, s + kk), base = ti(h.o_nbase, n);
-        float xj = x[3 * ti(h.o_chainnode, n * h.nlev + j / 3) + j % 3];
-        w->atomic_add(&x[3 * n], -H[base + j] * xj);
-        w->atomic_add(&x[3 * n + 1], -H[base + Wd + j] * xj);
-        w->atomic_add(&x[3 * n + 2], -H[base + 2 * Wd + j] * xj);
+        int aJ = ti(h.o_chainnode, n * h.nlev + J);
+        const float *ub = H + base + 3 * J;
+        float y0 = x[3 * aJ], y1 = x[3 * aJ + 1], y2 = x[3 * aJ + 2];
+#pragma unroll
+        for (int r_ = 0; r_ < 3; r_++)
+          w->atomic_add(&x[3 * n + r_], -(ub[r_ * Wd] * y0 + ub[r_ * Wd + 1] * y1 + ub[r_ * Wd + 2] * y2));
       }
       w->sync();
     }
@@ -536,14 +614,17 @@ struct Sim {
   // ------------------------------------------------------------------ Newton solve of the constrained acceleration
   SS_DEV void ls_eval(float al, float c1, float c2, float &d1, float &d2) {
     float s1 = 0.f, s2 = 0.f;
+#pragma unroll
     for (int p = 0; p < CANDP; p++) {
       const Contact &c = con[p];
       if (!c.active) continue;
+#pragma unroll
       for (int r_ = 0; r_ < 4; r_++) {
         float x = c.jar[r_] + al * c.jd[r_];
         if (x < 0.f) { s1 += c.D * x * c.jd[r_]; s2 += c.D * c.jd[r_] * c.jd[r_]; }
       }
     }
+#pragma unroll
     for (int p = 0; p < DOFP; p++) {
       const Limit &l = lim[p];
       if (l.sign == 0.f) continue;
@@ -554,189 +635,208 @@ struct Sim {
     d2 = c2 + w->sum(s2);
   }
 
-  SS_DEV void newton() {
-    const Hdr &h = k->h;
-    const float mu = h.mu;
-    const int maxit = k->cfg.newton_iters > 0 ? k->cfg.newton_iters : 8;
+  // Newton on MuJoCo's convex primal problem, split so that the shared assemble/factor/solve site sits
+  // between newton_prepare() and newton_finish() in the driver's solver loop.
+  SS_DEV void newton_begin() {
     body_accel(a, Ab);
     w->sync();
     eval_rows(Ab, a, false);
-    for (int it = 0; it < maxit; it++) {
-      iters++;
-      // ---- Gb = I_b A_b ; zero Kc
-      if (lane < h.nb) {
-        float Ia[6];
-        imul(Ib, Ab + 6 * lane, Ia);
-        for (int c = 0; c < 6; c++) Gb[6 * lane + c] = Ia[c];
-        for (int c = 0; c < 21; c++) Kc[21 * lane + c] = 0.f;
-      }
-      w->sync();
-      // ---- contact forces and K_b = sum_rows D u u^T, u = (rho x w ; w)
-      int nact = 0;
-      for (int p = 0; p < CANDP; p++) {
-        const Contact &c = con[p];
-        if (!c.active) continue;
-        float f[4], fx = 0, fy = 0, fz = 0;
-        float Wxx = 0, Wxy = 0, Wxz = 0, Wyy = 0, Wyz = 0, Wzz = 0;
-        const float wx[4] = {mu * c.t1x, -mu * c.t1x, -mu * c.t1y, mu * c.t1y};
-        const float wy[4] = {mu * c.t1y, -mu * c.t1y, mu * c.t1x, -mu * c.t1x};
-        for (int r_ = 0; r_ < 4; r_++) {
-          f[r_] = c.jar[r_] < 0.f ? -c.D * c.jar[r_] : 0.f;
-          if (c.jar[r_] < 0.f) {
-            nact++;
-            fx += f[r_] * wx[r_]; fy += f[r_] * wy[r_]; fz += f[r_];
-            Wxx += c.D * wx[r_] * wx[r_]; Wxy += c.D * wx[r_] * wy[r_]; Wxz += c.D * wx[r_];
-            Wyy += c.D * wy[r_] * wy[r_]; Wyz += c.D * wy[r_]; Wzz += c.D;
-          }
-        }
-        if (Wzz == 0.f) continue;
-        float *g = Gb + 6 * c.body;
-        w->atomic_add(&g[0], -(c.ry * fz - c.rz * fy));
-        w->atomic_add(&g[1], -(c.rz * fx - c.rx * fz));
-        w->atomic_add(&g[2], -(c.rx * fy - c.ry * fx));
-        w->atomic_add(&g[3], -fx); w->atomic_add(&g[4], -fy); w->atomic_add(&g[5], -fz);
-        // Y = P W (columns rho x W[:,j]), Z = rows rho x Y[i,:]
-        const float Wm[9] = {Wxx, Wxy, Wxz, Wxy, Wyy, Wyz, Wxz, Wyz, Wzz};
-        float Y[9], Z[9];
-        for (int j = 0; j < 3; j++) {
-          float c0 = Wm[j], c1 = Wm[3 + j], c2 = Wm[6 + j];
-          Y[j] = c.ry * c2 - c.rz * c1; Y[3 + j] = c.rz * c0 - c.rx * c2; Y[6 + j] = c.rx * c1 - c.ry * c0;
-        }
-        for (int i = 0; i < 3; i++) {
-          float y0 = Y[3 * i], y1 = Y[3 * i + 1], y2 = Y[3 * i + 2];
-          Z[3 * i] = c.ry * y2 - c.rz * y1; Z[3 * i + 1] = c.rz * y0 - c.rx * y2; Z[3 * i + 2] = c.rx * y1 - c.ry * y0;
-        }
-        float *Kb = Kc + 21 * c.body;
-        w->atomic_add(&Kb[0], Z[0]); w->atomic_add(&Kb[1], Z[1]); w->atomic_add(&Kb[2], Z[2]);
-        w->atomic_add(&Kb[3], Y[0]); w->atomic_add(&Kb[4], Y[1]); w->atomic_add(&Kb[5], Y[2]);
-        w->atomic_add(&Kb[6], Z[4]); w->atomic_add(&Kb[7], Z[5]);
-        w->atomic_add(&Kb[8], Y[3]); w->atomic_add(&Kb[9], Y[4]); w->atomic_add(&Kb[10], Y[5]);
-        w->atomic_add(&Kb[11], Z[8]);
-        w->atomic_add(&Kb[12], Y[6]); w->atomic_add(&Kb[13], Y[7]); w->atomic_add(&Kb[14], Y[8]);
-        w->atomic_add(&Kb[15], Wxx); w->atomic_add(&Kb[16], Wxy); w->atomic_add(&Kb[17], Wxz);
-        w->atomic_add(&Kb[18], Wyy); w->atomic_add(&Kb[19], Wyz); w->atomic_add(&Kb[20], Wzz);
-      }
-      w->sync();
-      const bool any_contact_row = w->any(nact > 0);
-      // ---- subtree sums of Gb (6) and Kc (21)
-      for (int L = h.nblev - 1; L >= 1; --L) {
-        int s = ti(h.o_blevstart, L), nbod = ti(h.o_blevstart, L + 1) - s;
-        int ncomp = any_contact_row ? 27 : 6, n = nbod * ncomp;
-        for (int idx = lane; idx < n; idx += 64) {
-          int bi = idx / ncomp, c = idx - bi * ncomp;
-          int b = ti(h.o_blevbodies, s + bi), p = ti(h.o_bparent, b);
-          if (c < 6) w->atomic_add(&Gb[6 * p + c], Gb[6 * b + c]);
-          else w->atomic_add(&Kc[21 * p + c - 6], Kc[21 * b + c - 6]);
-        }
-        w->sync();
-      }
-      // ---- gradient and diagonal terms
-      float gg = 0.f;
-      for (int p = 0; p < DOFP; p++) {
-        int i = p * 64 + lane;
-        if (i < h.nv) {
-          int n = i / 3, b = n > 0 ? n - 1 : 0;
-          float s = C[i] + dc(i, 0) * a[i] - tau[i];
-          for (int c = 0; c < 6; c++) s += S[6 * i + c] * Gb[6 * b + c];
-          float dg = dc(i, 0);
-          const Limit &l = lim[p];
-          if (l.sign != 0.f && l.jar < 0.f) { s += l.sign * l.D * l.jar; dg += l.D; }
-          grad[i] = s; diag[i] = dg; delta[i] = -s;
-          gg += s * s;
-        }
-      }
-      (void)gg;
-      w->sync();
-      assemble_H();
-      factor_H();
-      solve_H(delta);
-      // ---- line search along delta
-      body_accel(delta, Ad);
-      w->sync();
-      eval_rows(Ad, delta, true);
-      float dg_ = 0.f, s_a = 0.f, s_b = 0.f;
-      for (int p = 0; p < DOFP; p++) { int i = p * 64 + lane; if (i < h.nv) dg_ += delta[i] * grad[i]; }
-      for (int p = 0; p < CANDP; p++) {
-        const Contact &c = con[p];
-        if (!c.active) continue;
-        for (int r_ = 0; r_ < 4; r_++) if (c.jar[r_] < 0.f) { s_a += c.D * c.jar[r_] * c.jd[r_]; s_b += c.D * c.jd[r_] * c.jd[r_]; }
-      }
-      for (int p = 0; p < DOFP; p++) {
-        const Limit &l = lim[p];
-        if (l.sign != 0.f && l.jar < 0.f) { s_a += l.D * l.jar * l.jd; s_b += l.D * l.jd * l.jd; }
-      }
-      dg_ = w->sum(dg_); s_a = w->sum(s_a); s_b = w->sum(s_b);
-      const float c1 = dg_ - s_a, c2 = -dg_ - s_b;          // phi'(al) = c1 + al c2 + sum_active(al) D (jar + al jd) jd
-      float al = 1.f, d1, d2;
-      ls_eval(1.f, c1, c2, d1, d2);
-      // accept when |phi'| is 1e-3 of phi'(0) = delta.grad, or at the rounding level of its terms
-      const float tol = 1e-3f * fabsf(dg_) + 2e-6f * (fabsf(dg_) + fabsf(s_a) + fabsf(s_b));
-      bool exact = true;
-      if (!(fabsf(d1) <= tol)) {
-        exact = false;
-        float lo = 0.f, hi = 1.f;
-        if (d1 < 0.f) {                                     // minimum beyond 1: expand
-          for (int e_ = 0; e_ < 6 && d1 < 0.f; e_++) { lo = hi; hi *= 2.f; ls_eval(hi, c1, c2, d1, d2); }
-          al = hi;
-        }
-        for (int ls = 0; ls < 10; ls++) {
-          if (fabsf(d1) <= tol) break;
-          if (d1 < 0.f) lo = al; else hi = al;
-          float nx = d2 > 0.f ? al - d1 / d2 : 0.5f * (lo + hi);
-          if (!(nx > lo && nx < hi)) nx = 0.5f * (lo + hi);
-          al = nx;
-          ls_eval(al, c1, c2, d1, d2);
-        }
-      }
-      // ---- take the step; detect active-set changes
-      int changed = 0;
-      for (int p = 0; p < DOFP; p++) { int i = p * 64 + lane; if (i < h.nv) a[i] += al * delta[i]; }
-      for (int idx = lane; idx < 6 * h.nb; idx += 64) Ab[idx] += al * Ad[idx];
-      for (int p = 0; p < CANDP; p++) {
-        Contact &c = con[p];
-        if (!c.active) continue;
-        for (int r_ = 0; r_ < 4; r_++) {
-          float nj = c.jar[r_] + al * c.jd[r_];
-          changed |= (nj < 0.f) != (c.jar[r_] < 0.f);
-          c.jar[r_] = nj;
-        }
-      }
-      for (int p = 0; p < DOFP; p++) {
-        Limit &l = lim[p];
-        if (l.sign == 0.f) continue;
-        float nj = l.jar + al * l.jd;
-        changed |= (nj < 0.f) != (l.jar < 0.f);
-        l.jar = nj;
-      }
-      w->sync();
-      if (!w->any(changed) && exact) break;
+  }
+
+  // gradient (-> grad, delta = -grad), diagonal terms and the per-body contact matrices Kc
+  SS_DEV void newton_prepare() {
+    const Hdr &h = k->h;
+    const float mu = h.mu;
+    iters++;
+    if (lane < h.nb) {
+      float Ia[6];
+      imul(Ib, Ab + 6 * lane, Ia);
+#pragma unroll
+      for (int c = 0; c < 6; c++) Gb[6 * lane + c] = Ia[c];
+#pragma unroll
+      for (int c = 0; c < 21; c++) Kc[21 * lane + c] = 0.f;
     }
+    w->sync();
+    // ---- contact forces and K_b = sum_rows D u u^T, u = (rho x w ; w)
+    int nact = 0;
+#pragma unroll
+    for (int p = 0; p < CANDP; p++) {
+      const Contact &c = con[p];
+      if (!c.active) continue;
+      float fx = 0, fy = 0, fz = 0;
+      float Wxx = 0, Wxy = 0, Wxz = 0, Wyy = 0, Wyz = 0, Wzz = 0;
+#pragma unroll
+      for (int r_ = 0; r_ < 4; r_++) {
+        const float sgn = (r_ & 1) ? -mu : mu;
+        const float wx = r_ < 2 ? sgn * c.t1x : -sgn * c.t1y;
+        const float wy = r_ < 2 ? sgn * c.t1y : sgn * c.t1x;
+        if (c.jar[r_] < 0.f) {
+          const float f = -c.D * c.jar[r_];
+          nact++;
+          fx += f * wx; fy += f * wy; fz += f;
+          Wxx += c.D * wx * wx; Wxy += c.D * wx * wy; Wxz += c.D * wx;
+          Wyy += c.D * wy * wy; Wyz += c.D * wy; Wzz += c.D;
+        }
+      }
+      if (Wzz == 0.f) continue;
+      float *g = Gb + 6 * c.body;
+      w->atomic_add(&g[0], -(c.ry * fz - c.rz * fy));
+      w->atomic_add(&g[1], -(c.rz * fx - c.rx * fz));
+      w->atomic_add(&g[2], -(c.rx * fy - c.ry * fx));
+      w->atomic_add(&g[3], -fx); w->atomic_add(&g[4], -fy); w->atomic_add(&g[5], -fz);
+      // Y = [rho]x W (ang-lin block), Z = rows rho x Y[i,:] (ang-ang block)
+      const float Y0 = c.ry * Wxz - c.rz * Wxy, Y1 = c.ry * Wyz - c.rz * Wyy, Y2 = c.ry * Wzz - c.rz * Wyz;
+      const float Y3 = c.rz * Wxx - c.rx * Wxz, Y4 = c.rz * Wxy - c.rx * Wyz, Y5 = c.rz * Wxz - c.rx * Wzz;
+      const float Y6 = c.rx * Wxy - c.ry * Wxx, Y7 = c.rx * Wyy - c.ry * Wxy, Y8 = c.rx * Wyz - c.ry * Wxz;
+      const float Z0 = c.ry * Y2 - c.rz * Y1, Z1 = c.rz * Y0 - c.rx * Y2, Z2 = c.rx * Y1 - c.ry * Y0;
+      const float Z4 = c.rz * Y3 - c.rx * Y5, Z5 = c.rx * Y4 - c.ry * Y3;
+      const float Z8 = c.rx * Y7 - c.ry * Y6;
+      float *Kb = Kc + 21 * c.body;
+      w->atomic_add(&Kb[0], Z0); w->atomic_add(&Kb[1], Z1); w->atomic_add(&Kb[2], Z2);
+      w->atomic_add(&Kb[3], Y0); w->atomic_add(&Kb[4], Y1); w->atomic_add(&Kb[5], Y2);
+      w->atomic_add(&Kb[6], Z4); w->atomic_add(&Kb[7], Z5);
+      w->atomic_add(&Kb[8], Y3); w->atomic_add(&Kb[9], Y4); w->atomic_add(&Kb[10], Y5);
+      w->atomic_add(&Kb[11], Z8);
+      w->atomic_add(&Kb[12], Y6); w->atomic_add(&Kb[13], Y7); w->atomic_add(&Kb[14], Y8);
+      w->atomic_add(&Kb[15], Wxx); w->atomic_add(&Kb[16], Wxy); w->atomic_add(&Kb[17], Wxz);
+      w->atomic_add(&Kb[18], Wyy); w->atomic_add(&Kb[19], Wyz); w->atomic_add(&Kb[20], Wzz);
+    }
+    w->sync();
+    const bool any_contact_row = w->any(nact > 0);
+    // ---- subtree sums of Gb (6) and, when any contact row is active, Kc (21)
+    const int ncomp = any_contact_row ? 27 : 6;
+    for (int L = h.nblev - 1; L >= 1; --L) {
+      const int s = h.blevstart[L], n = (h.blevstart[L + 1] - s) * ncomp;
+      const float rn = 1.0f / (float)ncomp;
+      for (int idx = lane; idx < n; idx += 64) {
+        int bi = (int)(((float)idx + 0.5f) * rn), c = idx - bi * ncomp;
+        int b = ti(h.o_blevbodies, s + bi), p = ti(h.o_bparent, b);
+        if (c < 6) w->atomic_add(&Gb[6 * p + c], Gb[6 * b + c]);
+        else w->atomic_add(&Kc[21 * p + c - 6], Kc[21 * b + c - 6]);
+      }
+      w->sync();
+    }
+    // ---- gradient and diagonal terms
+#pragma unroll
+    for (int p = 0; p < DOFP; p++) {
+      int i = p * 64 + lane;
+      if (i < h.nv) {
+        int n = i / 3, b = n > 0 ? n - 1 : 0;
+        const float *si = S + 6 * i, *gb = Gb + 6 * b;
+        float s_ = C[i] + dc(i, 0) * a[i] - tau[i];
+        s_ += si[0] * gb[0] + si[1] * gb[1] + si[2] * gb[2] + si[3] * gb[3] + si[4] * gb[4] + si[5] * gb[5];
+        float dg = dc(i, 0);
+        const Limit &l = lim[p];
+        if (l.sign != 0.f && l.jar < 0.f) { s_ += l.sign * l.D * l.jar; dg += l.D; }
+        grad[i] = s_; diag[i] = dg; delta[i] = -s_;
+      }
+    }
+    w->sync();
+  }
+
+  // exact line search along delta, step, active-set change detection; returns true when converged
+  SS_DEV bool newton_finish() {
+    const Hdr &h = k->h;
+    body_accel(delta, Ad);
+    w->sync();
+    eval_rows(Ad, delta, true);
+    float dg_ = 0.f, s_a = 0.f, s_b = 0.f;
+#pragma unroll
+    for (int p = 0; p < DOFP; p++) { int i = p * 64 + lane; if (i < h.nv) dg_ += delta[i] * grad[i]; }
+#pragma unroll
+    for (int p = 0; p < CANDP; p++) {
+      const Contact &c = con[p];
+      if (!c.active) continue;
+#pragma unroll
+      for (int r_ = 0; r_ < 4; r_++) if (c.jar[r_] < 0.f) { s_a += c.D * c.jar[r_] * c.jd[r_]; s_b += c.D * c.jd[r_] * c.jd[r_]; }
+    }
+#pragma unroll
+    for (int p = 0; p < DOFP; p++) {
+      const Limit &l = lim[p];
+      if (l.sign != 0.f && l.jar < 0.f) { s_a += l.D * l.jar * l.jd; s_b += l.D * l.jd * l.jd; }
+    }
+    dg_ = w->sum(dg_); s_a = w->sum(s_a); s_b = w->sum(s_b);
+    const float c1 = dg_ - s_a, c2 = -dg_ - s_b;            // phi'(al) = c1 + al c2 + sum_active(al) D (jar + al jd) jd
+    float al = 1.f, d1, d2;
+    ls_eval(1.f, c1, c2, d1, d2);
+    // accept when |phi'| is 1e-3 of phi'(0) = delta.grad, or at the rounding level of its terms
+    const float tol = 1e-3f * fabsf(dg_) + 2e-6f * (fabsf(dg_) + fabsf(s_a) + fabsf(s_b));
+    bool exact = true;
+    if (!(fabsf(d1) <= tol)) {
+      exact = false;
+      float lo = 0.f, hi = 1.f;
+      for (int ls = 0; ls < 16; ls++) {                     // one ls_eval site: expand while phi' < 0 at hi, then safeguarded Newton
+        if (fabsf(d1) <= tol) break;
+        float nx;
+        if (d1 < 0.f && al >= hi) { lo = al; hi = 2.f * al; nx = hi; }
+        else {
+          if (d1 < 0.f) lo = al; else hi = al;
+          nx = d2 > 0.f ? al - d1 / d2 : 0.5f * (lo + hi);
+          if (!(nx > lo && nx < hi)) nx = 0.5f * (lo + hi);
+        }
+        al = nx;
+        ls_eval(al, c1, c2, d1, d2);
+      }
+    }
+    int changed = 0;
+#pragma unroll
+    for (int p = 0; p < DOFP; p++) { int i = p * 64 + lane; if (i < h.nv) a[i] += al * delta[i]; }
+    for (int idx = lane; idx < 6 * h.nb; idx += 64) Ab[idx] += al * Ad[idx];
+#pragma unroll
+    for (int p = 0; p < CANDP; p++) {
+      Contact &c = con[p];
+      if (!c.active) continue;
+#pragma unroll
+      for (int r_ = 0; r_ < 4; r_++) {
+        float nj = c.jar[r_] + al * c.jd[r_];
+        changed |= (nj < 0.f) != (c.jar[r_] < 0.f);
+        c.jar[r_] = nj;
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < DOFP; p++) {
+      Limit &l = lim[p];
+      if (l.sign == 0.f) continue;
+      float nj = l.jar + al * l.jd;
+      changed |= (nj < 0.f) != (l.jar < 0.f);
+      l.jar = nj;
+    }
+    w->sync();
+    return !w->any(changed) && exact;
   }
 
   // ------------------------------------------------------------------ controllers (torque for the NEXT mj_step)
-  // uses M, C of the forward pass that is in LDS (the "stale" qM / qfrc_bias) with the current q, v
-  SS_DEV void controller(const float *action, float abias) {
+  // `pd` (PIDController with zero integral gain, reference controllers.py:335-346) and `torque`
+  // (SimpleTorqueController :45-46)
+  SS_DEV void simple_controller(const float *action, float abias) {
     const Hdr &h = k->h;
     const int mode = k->cfg.control_mode;
-    if (mode != SS_CTRL_UHC_PD) {
-      for (int p = 0; p < DOFP; p++) {
-        int i = p * 64 + lane;
-        if (i < h.nv) {
-          float t = 0.f;
-          if (dc(i, 10) != 0.f) {
-            float act = action[(int)dc(i, 11)] + abias, lim_ = dc(i, 7);
-            if (mode == SS_CTRL_PD) t = -dc(i, 5) * (q[i + 1] - (act * dc(i, 8) + dc(i, 9))) - dc(i, 6) * v[i];
-            else t = act * k->cfg.power_scale * lim_;
-            t = fminf(fmaxf(t, -lim_), lim_);
-          }
-          tau[i] = t;
+#pragma unroll
+    for (int p = 0; p < DOFP; p++) {
+      int i = p * 64 + lane;
+      if (i < h.nv) {
+        float t = 0.f;
+        if (dc(i, 10) != 0.f) {
+          float act = action[(int)dc(i, 11)] + abias, lim_ = dc(i, 7);
+          if (mode == SS_CTRL_PD) t = -dc(i, 5) * (q[i + 1] - (act * dc(i, 8) + dc(i, 9))) - dc(i, 6) * v[i];
+          else t = act * k->cfg.power_scale * lim_;
+          t = fminf(fmaxf(t, -lim_), lim_);
         }
+        tau[i] = t;
       }
-      w->sync();
-      return;
     }
-    float perr[DOFP];
-    if (lane < h.nb) for (int c = 0; c < 21; c++) Kc[21 * lane + c] = 0.f;
+    w->sync();
+  }
+
+  // Stable PD (reference controllers.py:116-190): (M + Kd dt) qdd = -C - Kp e - Kd v on the M, C of the
+  // forward pass that is in LDS (the "stale" qM / qfrc_bias) with the current q, v
+  SS_DEV void spd_prepare(const float *action, float abias) {
+    const Hdr &h = k->h;
+    if (lane < h.nb) {
+#pragma unroll
+      for (int c = 0; c < 21; c++) Kc[21 * lane + c] = 0.f;
+    }
+#pragma unroll
     for (int p = 0; p < DOFP; p++) {
       int i = p * 64 + lane;
       perr[p] = 0.f;
@@ -748,9 +848,10 @@ struct Sim {
       }
     }
     w->sync();
-    assemble_H();
-    factor_H();
-    solve_H(delta);
+  }
+  SS_DEV void spd_finish() {
+    const Hdr &h = k->h;
+#pragma unroll
     for (int p = 0; p < DOFP; p++) {
       int i = p * 64 + lane;
       if (i < h.nv) {
@@ -786,6 +887,7 @@ struct Sim {
       q[6] = qw * rz + qx * ry - qy * rx + qz * rw;
     }
     w->sync();                                              // lane 0 read v[3:6] before lanes 3-5 update them
+#pragma unroll
     for (int p = 0; p < DOFP; p++) {
       int i = p * 64 + lane;
       if (i < h.nv) {
@@ -813,26 +915,6 @@ struct Sim {
     if (lane == 0) { q[0] = h.qpos0_root[0]; q[1] = h.qpos0_root[1]; q[2] = h.qpos0_root[2]; q[3] = 1.f; }
     nwarn_add++;
     w->sync();
-  }
-
-  // mj_forward (without integration): leaves qacc in a[], M/C pieces (S, Ic, C) in LDS
-  SS_DEV void forward() {
-    forward_kin(true);
-    make_constraints();
-    newton();
-  }
-
-  // one mj_step given tau; `next_action` != null: also compute the controller torque for the next substep
-  SS_DEV void mj_step(const float *next_action, float abias) {
-    const Hdr &h = k->h;
-    if (any_bad(q, h.nq) || any_bad(v, h.nv)) reset_data();          // mj_checkPos / mj_checkVel
-    for (int attempt = 0; attempt < 2; attempt++) {
-      forward();
-      if (!any_bad(a, h.nv)) break;                                  // mj_checkAcc
-      reset_data();
-    }
-    integrate();
-    if (next_action) controller(next_action, abias);
   }
 
   // ------------------------------------------------------------------ observations (self_obs_v 1 / 2) + task tail
@@ -885,6 +967,15 @@ struct Sim {
 };
 
 // ---------------------------------------------------------------------- per-env driver (all modes)
+// One loop over "forward passes"; every heavy stage has exactly one call site in its body (code size:
+// the stages are force-inlined, and the instruction cache is shared by the CU's wavefronts).
+//   PROLOGUE  forward at the state of the previous launch's last mj_forward -> stale M, C; first torque
+//   SUBSTEP   mj_step: forward, constraints, Newton, Euler; then the controller torque for the next one
+//   RESETFWD  reset_sim(): mj_forward at the reset state (sensors, contacts; no solve needed)
+//   FINAL     mj_kinematics on the new qpos for the observation
+enum { K_PROLOGUE = 0, K_SUBSTEP = 1, K_RESETFWD = 2, K_FINAL = 3 };
+enum { SOLVE_DUMP_M = 0, SOLVE_NEWTON = 1, SOLVE_SPD = 2 };
+
 template <class W, int DOFP, int CANDP>
 SS_DEV void run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env) {
   const Hdr &h = k->h;
@@ -894,142 +985,143 @@ SS_DEV void run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env) 
   Sim<W, DOFP, CANDP> sim;
   sim.init(w, k, T, L, env);
   const int lane = sim.lane;
+  const int mode = k->mode;
   float *qg = st.qpos + (size_t)env * h.nq, *vg = st.qvel + (size_t)env * h.nv;
   float *qpg = st.qpos_prev + (size_t)env * h.nq, *vpg = st.qvel_prev + (size_t)env * h.nv;
   float *wg = st.qacc_warm + (size_t)env * h.nv;
   float *tk = st.task + (size_t)env * 4;
   const float *act = k->actions ? k->actions + (size_t)env * h.nu : nullptr;
   const float *trand = k->task_rand ? k->task_rand + (size_t)env * 2 : nullptr;
+  const float *fa = k->fall_actions ? k->fall_actions + (size_t)env * 3 * h.nu : nullptr;
   float *obs = k->obs ? k->obs + (size_t)env * k->obs_size : nullptr;
+  const int maxit = cf.newton_iters > 0 ? cf.newton_iters : 8;
 
-  if (k->mode == MODE_KINEMATICS) {
-    sim.load(sim.q, qg, h.nq);
+  int cur_t = st.cur_t[env];
+  float tar = tk[0], change = tk[1], recov = tk[2];
+  int nsub = k->nsub;
+  // StateInit.Fall draws action = U[0,1) - 0.5 (humanoid_env.py:487): the -0.5 is applied in the controller
+  const float abias = (mode == MODE_RESET) ? -0.5f : 0.f;
+  const bool is_debug = mode == MODE_DEBUG_FORWARD;
+
+  // ---- task bookkeeping that precedes the physics (HumanoidTask.reset / pre_physics_step: update_task)
+  const bool resample = (mode == MODE_RESET && cf.task != SS_TASK_BASE) ||
+                        (mode == MODE_STEP && cf.task != SS_TASK_BASE && (float)cur_t >= change);
+  if (mode == MODE_RESET && cf.task == SS_TASK_GETUP) recov = (float)cf.recovery_steps;
+  if (resample) {                                            // uses the OLD cur_t on reset (reference quirk)
+    float u0 = trand ? trand[0] : 0.f, u1 = trand ? trand[1] : 0.f;
+    if (cf.task == SS_TASK_SPEED) {
+      tar = (cf.tar_speed_max - cf.tar_speed_min) * u0 + cf.tar_speed_min;
+      change = (float)(cur_t + cf.speed_change_min + (int)floorf(u1 * (float)(cf.speed_change_max - cf.speed_change_min)));
+    } else {
+      tar = (cf.tar_height_max - cf.tar_height_min) * u0 + cf.tar_height_min;
+      change = (float)(cur_t + cf.height_change_min + (int)floorf(u1 * (float)(cf.height_change_max - cf.height_change_min)));
+    }
+  }
+
+  // ---- initial LDS state
+  sim.load(sim.a, wg, h.nv);
+  if (mode == MODE_RESET) {
+    for (int i = lane; i < h.nq; i += 64) sim.q[i] = 0.f;
+    for (int i = lane; i < h.nv; i += 64) sim.v[i] = 0.f;
     w->sync();
-    sim.forward_kin(false);
+    if (lane == 0) {
+      if (cf.state_init == SS_INIT_DEFAULT) { sim.q[2] = 0.94f; sim.q[3] = sim.q[4] = sim.q[5] = sim.q[6] = 0.5f; }
+      else { sim.q[2] = 0.3f; sim.q[3] = 1.f; }
+    }
+    nsub = cf.state_init == SS_INIT_FALL ? 3 * cf.control_freq_inv : 0;
+  } else if (mode == MODE_KINEMATICS || is_debug) {
+    sim.load(sim.q, qg, h.nq); sim.load(sim.v, vg, h.nv);
+    if (is_debug) for (int i = lane; i < h.nv; i += 64) { int ai = (int)sim.dc(i, 11); sim.tau[i] = (act && ai >= 0) ? act[ai] : 0.f; }
+    nsub = is_debug ? 1 : 0;
+  } else {
+    sim.load(sim.q, qpg, h.nq); sim.load(sim.v, vpg, h.nv);
+  }
+  w->sync();
+
+  float prev_x = 0.f, prev_y = 0.f;
+  // pass sequence: [PROLOGUE] SUBSTEP*nsub [RESETFWD | FINAL]
+  int s = (nsub > 0 && !is_debug) ? -1 : 0;
+  const int last_kind = mode == MODE_RESET ? K_RESETFWD : ((mode == MODE_STEP || mode == MODE_KINEMATICS) ? K_FINAL : -1);
+  for (;;) {
+    int kind = s < 0 ? K_PROLOGUE : (s < nsub ? K_SUBSTEP : last_kind);
+    if (kind < 0) break;
+    if (kind == K_SUBSTEP && !is_debug) {
+      if (sim.any_bad(sim.q, h.nq) || sim.any_bad(sim.v, h.nv)) sim.reset_data();   // mj_checkPos / mj_checkVel
+      if (s == nsub - 1) { sim.store(qpg, sim.q, h.nq); sim.store(vpg, sim.v, h.nv); }   // stale source of the next launch
+    }
+    sim.forward_kin(kind != K_FINAL);
+    if (kind == K_FINAL) break;
+    if (kind == K_SUBSTEP || kind == K_RESETFWD) sim.make_constraints();
+    if (kind == K_RESETFWD) break;
+    int solve = SOLVE_SPD;
+    const float *next_action = nullptr;
+    if (kind == K_PROLOGUE) {
+      if (mode != MODE_RESET) { sim.load(sim.q, qg, h.nq); sim.load(sim.v, vg, h.nv); w->sync(); }
+      prev_x = sim.q[0]; prev_y = sim.q[1];
+      next_action = (mode == MODE_RESET) ? fa : act;
+    } else {
+      sim.newton_begin();
+      solve = is_debug ? SOLVE_DUMP_M : SOLVE_NEWTON;
+      if (s + 1 < nsub) next_action = (mode == MODE_RESET) ? fa + (size_t)((s + 1) / cf.control_freq_inv) * h.nu : act;
+    }
+    bool redo = false;
+    int it = 0;
+    for (;;) {                                               // solver loop: one assemble/factor/solve site
+      if (solve == SOLVE_NEWTON) sim.newton_prepare();
+      else if (solve == SOLVE_SPD) {
+        if (cf.control_mode != SS_CTRL_UHC_PD) { sim.simple_controller(next_action, abias); break; }
+        sim.spd_prepare(next_action, abias);
+      } else {                                               // plain mass matrix for the diagnostics dump
+        if (lane < h.nb) for (int c = 0; c < 21; c++) sim.Kc[21 * lane + c] = 0.f;
+        for (int i = lane; i < h.nv; i += 64) sim.diag[i] = sim.dc(i, 0);
+        w->sync();
+      }
+      sim.assemble_H();
+      if (solve == SOLVE_DUMP_M) {
+        sim.store(k->out0 + (size_t)env * h.ne, sim.H, h.ne); sim.store(k->out1 + (size_t)env * h.nv, sim.C, h.nv);
+        w->sync();
+        solve = SOLVE_NEWTON;
+        continue;
+      }
+      sim.factor_H();
+      sim.solve_H(sim.delta);
+      if (solve == SOLVE_SPD) { sim.spd_finish(); break; }
+      const bool conv = sim.newton_finish();
+      if (!conv && ++it < maxit) continue;
+      if (is_debug) break;
+      if (sim.any_bad(sim.a, h.nv)) { sim.reset_data(); redo = true; break; }        // mj_checkAcc -> autoreset
+      sim.integrate();
+      if (!next_action) break;
+      solve = SOLVE_SPD;
+    }
+    if (!redo) s++;
+    if (is_debug) break;
+  }
+
+  if (mode == MODE_KINEMATICS) {
     if (lane < h.nb) {
       for (int c = 0; c < 3; c++) k->out0[((size_t)env * h.nb + lane) * 3 + c] = sim.r[3 * lane + c] + sim.q[c];
       for (int c = 0; c < 9; c++) k->out1[((size_t)env * h.nb + lane) * 9 + c] = sim.R[9 * lane + c];
     }
     return;
   }
-  if (k->mode == MODE_DEBUG_FORWARD) {                       // mj_forward at (qpos, qvel) with tau from `actions` as raw torques
-    sim.load(sim.q, qg, h.nq); sim.load(sim.v, vg, h.nv); sim.load(sim.a, wg, h.nv);
-    for (int i = lane; i < h.nv; i += 64) { int ai = (int)sim.dc(i, 11); sim.tau[i] = (act && ai >= 0) ? act[ai] : 0.f; }
-    w->sync();
-    sim.forward_kin(true);
-    if (lane < h.nb) for (int c = 0; c < 21; c++) sim.Kc[21 * lane + c] = 0.f;
-    for (int i = lane; i < h.nv; i += 64) sim.diag[i] = sim.dc(i, 0);
-    w->sync();
-    sim.assemble_H();
-    sim.store(k->out0 + (size_t)env * h.ne, sim.H, h.ne);
-    sim.store(k->out1 + (size_t)env * h.nv, sim.C, h.nv);
-    w->sync();
-    sim.make_constraints();
-    sim.newton();
-    sim.store(k->out2 + (size_t)env * h.nv, sim.a, h.nv);
-    if (lane == 0) { st.solver_iters[env] = sim.iters; st.touch[2 * env] = (int)(sim.touchmask & 0xFFFFFFFFull); st.touch[2 * env + 1] = (int)(sim.touchmask >> 32); }
-    return;
-  }
-
-  int cur_t = st.cur_t[env];
-  float tar = tk[0], change = tk[1], recov = tk[2];
-  int nsub = k->nsub;
-  // StateInit.Fall draws action = U[0,1) - 0.5 (humanoid_env.py:487): the -0.5 is applied in the controller
-  const float abias = (k->mode == MODE_RESET) ? -0.5f : 0.f;
-
-  if (k->mode == MODE_RESET) {
-    // HumanoidGetup.reset / HumanoidTask.reset: task targets are resampled with the OLD cur_t
-    if (cf.task == SS_TASK_GETUP) recov = (float)cf.recovery_steps;
-    if (cf.task != SS_TASK_BASE) {
-      float u0 = trand ? trand[0] : 0.f, u1 = trand ? trand[1] : 0.f;
-      if (cf.task == SS_TASK_SPEED) {
-        tar = (cf.tar_speed_max - cf.tar_speed_min) * u0 + cf.tar_speed_min;
-        change = (float)(cur_t + cf.speed_change_min + (int)floorf(u1 * (float)(cf.speed_change_max - cf.speed_change_min)));
-      } else {
-        tar = (cf.tar_height_max - cf.tar_height_min) * u0 + cf.tar_height_min;
-        change = (float)(cur_t + cf.height_change_min + (int)floorf(u1 * (float)(cf.height_change_max - cf.height_change_min)));
-      }
-    }
-    for (int i = lane; i < h.nq; i += 64) sim.q[i] = 0.f;
-    for (int i = lane; i < h.nv; i += 64) sim.v[i] = 0.f;
-    sim.load(sim.a, wg, h.nv);
-    w->sync();
-    if (lane == 0) {
-      if (cf.state_init == SS_INIT_DEFAULT) { sim.q[2] = 0.94f; sim.q[3] = sim.q[4] = sim.q[5] = sim.q[6] = 0.5f; }
-      else { sim.q[2] = 0.3f; sim.q[3] = 1.f; }
-    }
-    w->sync();
-    nsub = 0;
-    if (cf.state_init == SS_INIT_FALL) nsub = 3 * cf.control_freq_inv;
-  } else {
-    sim.load(sim.q, qpg, h.nq); sim.load(sim.v, vpg, h.nv); sim.load(sim.a, wg, h.nv);
-    w->sync();
-  }
-
-  const float *fa = k->fall_actions ? k->fall_actions + (size_t)env * 3 * h.nu : nullptr;
-
-  if (k->mode == MODE_STEP && cf.task != SS_TASK_BASE) {     // pre_physics_step: update_task
-    if ((float)cur_t >= change) {
-      float u0 = trand ? trand[0] : 0.f, u1 = trand ? trand[1] : 0.f;
-      if (cf.task == SS_TASK_SPEED) {
-        tar = (cf.tar_speed_max - cf.tar_speed_min) * u0 + cf.tar_speed_min;
-        change = (float)(cur_t + cf.speed_change_min + (int)floorf(u1 * (float)(cf.speed_change_max - cf.speed_change_min)));
-      } else {
-        tar = (cf.tar_height_max - cf.tar_height_min) * u0 + cf.tar_height_min;
-        change = (float)(cur_t + cf.height_change_min + (int)floorf(u1 * (float)(cf.height_change_max - cf.height_change_min)));
-      }
-    }
-  }
-
-  float prev_x = 0.f, prev_y = 0.f;
-  if (nsub > 0) {
-    // ---- prologue: rebuild the stale M, C at the previous forward state, then the first torque
-    if (k->mode != MODE_RESET) {
-      sim.forward_kin(true);
-      sim.load(sim.q, qg, h.nq); sim.load(sim.v, vg, h.nv);
-      w->sync();
-    } else {
-      sim.forward_kin(true);                                 // mj_forward at the Fall state (humanoid_env.py:484)
-    }
-    prev_x = sim.q[0]; prev_y = sim.q[1];
-    const float *a0 = (k->mode == MODE_RESET) ? fa : act;
-    sim.controller(a0, abias);
-    for (int s = 0; s < nsub; s++) {
-      const float *next = nullptr;
-      if (s + 1 < nsub) next = (k->mode == MODE_RESET) ? fa + (size_t)((s + 1) / cf.control_freq_inv) * h.nu : act;
-      if (s == nsub - 1) {                                   // state of the last forward = next launch's stale source
-        sim.store(qpg, sim.q, h.nq); sim.store(vpg, sim.v, h.nv);
-      }
-      sim.mj_step(next, abias);
-    }
-  }
-
-  if (k->mode == MODE_RESET) {
-    // reset_sim: mj_forward at the reset state -> stale source == current state; sensors/contacts refreshed
-    sim.forward_kin(true);
-    sim.make_constraints();
-    sim.store(qpg, sim.q, h.nq); sim.store(vpg, sim.v, h.nv);
-    cur_t = 0;
-  }
-  sim.store(qg, sim.q, h.nq); sim.store(vg, sim.v, h.nv); sim.store(wg, sim.a, h.nv);
-  if (lane < h.nb) for (int c = 0; c < 6; c++) st.body_vel[((size_t)env * h.nb + lane) * 6 + c] = sim.sv[c];
   const unsigned long long touch = sim.touchmask;
   if (lane == 0) {
     st.touch[2 * env] = (int)(touch & 0xFFFFFFFFull); st.touch[2 * env + 1] = (int)(touch >> 32);
     st.solver_iters[env] = sim.iters;
     if (sim.nwarn_add) st.nwarn[env] += sim.nwarn_add;
   }
-  if (k->mode == MODE_SUBSTEP) return;
+  if (is_debug) { sim.store(k->out2 + (size_t)env * h.nv, sim.a, h.nv); return; }
+  if (mode == MODE_RESET) { sim.store(qpg, sim.q, h.nq); sim.store(vpg, sim.v, h.nv); cur_t = 0; }
+  sim.store(qg, sim.q, h.nq); sim.store(vg, sim.v, h.nv); sim.store(wg, sim.a, h.nv);
+  if (lane < h.nb) for (int c = 0; c < 6; c++) st.body_vel[((size_t)env * h.nb + lane) * 6 + c] = sim.sv[c];
+  if (mode == MODE_SUBSTEP) return;
 
-  // ---- post_physics_step: cur_t, observation (mj_kinematics on the new qpos), reward, reset flags
-  if (k->mode == MODE_STEP) {
-    cur_t += 1;
-    w->sync();
-    sim.forward_kin(false);
-  }
+  // ---- post_physics_step: cur_t, observation, reward, reset flags
+  if (mode == MODE_STEP) cur_t += 1;
   if (obs) sim.write_obs(obs, tar);
   if (lane == 0) {
-    if (k->mode == MODE_STEP) {
+    if (mode == MODE_STEP) {
       float rew = 0.f;
       int term = 0, trunc = cur_t > cf.episode_length;
       const int illegal = (touch & k->illegal_mask) != 0ull;

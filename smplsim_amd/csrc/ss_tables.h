@@ -28,6 +28,7 @@ struct HostModel {
   std::vector<float> actc;        // [nv][4]: kp kd tlim (per dof, 0 for unactuated), [nv][2] scale offset -> in dofc
   std::vector<int32_t> dof_act;   // [nv] actuator index of a dof or -1
   std::vector<uint8_t> legal;     // [nb]
+  std::vector<int> decode;        // [ne] (row_dof << 16 | col_dof) of every stored H entry (host-side, diagnostics)
   uint64_t illegal_mask = 0;      // bodies whose floor contact terminates the episode
   std::string error;
 };
@@ -181,27 +182,34 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
     if (!out.legal[b]) out.illegal_mask |= (1ull << b);
   }
 
-  // ---- shared blob
+  // ---- shared blob (copied into LDS once per workgroup)
+  if (nlev > 19 || nblev > 19) { out.error = "tree too deep"; return false; }
+  for (int L = 0; L <= nlev; L++) h.levstart[L] = levstart[L];
+  for (int L = 0; L <= nblev; L++) h.blevstart[L] = blevstart[L];
+  std::vector<int> blk, trilut;
+  for (int n = 0; n < nn; n++) for (int J = 0; J <= ndepth[n]; J++) blk.push_back((n << 8) | J);
+  h.nblk = (int)blk.size();
+  for (int I = 0; I < nlev; I++) for (int J = 0; J <= I; J++) trilut.push_back((I << 8) | J);
+  out.decode = decode;
   auto &S = out.shared; S.clear();
   auto push_i = [&](const std::vector<int> &v) { int o = (int)S.size(); for (int x : v) S.push_back((uint32_t)x); return o; };
   h.o_dofc = (int)S.size(); for (float f : dofc) S.push_back(f2u(f));
-  h.o_decode = push_i(decode);
-  h.o_chainrow = push_i(chainrow);
   h.o_chainnode = push_i(chainnode);
   h.o_nbase = push_i(nbase);
   h.o_ndepth = push_i(ndepth);
-  h.o_nparent = push_i(nparent);
-  h.o_levstart = push_i(levstart);
   h.o_levnodes = push_i(levnodes);
   std::vector<int> bpar(d.body_parent, d.body_parent + nb);
   h.o_bparent = push_i(bpar);
-  h.o_blevstart = push_i(blevstart);
   h.o_blevbodies = push_i(blevbodies);
+  h.o_blk = push_i(blk);
+  h.o_trilut = push_i(trilut);
   h.shared_words = (int)S.size();
+  (void)chainrow; (void)nparent;
 
   // ---- per-env LDS layout (floats)
   int maxU = 0;                                            // U buffer: nodes-in-level * 3 * D
   for (int L = 1; L < nlev; L++) maxU = std::max(maxU, (levstart[L + 1] - levstart[L]) * 9 * L);
+  if (nn > 64) { out.error = "too many nodes"; return false; }
   int o = 0;
   auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
   h.l_H = take(ne);
