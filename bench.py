@@ -127,6 +127,8 @@ def main():
     finite = bool(torch.isfinite(env.obs_buf).all().item())
     nwarn = int(env.nwarn.sum().item())
     iters = float(env.solver_iters.float().mean().item())
+    it_sorted = torch.sort(env.solver_iters.float()).values
+    it_p50, it_p99, it_max = (float(it_sorted[int(q * (N - 1))].item()) for q in (0.5, 0.99, 1.0))
 
     if rank == 0:
         total_envs = N * world
@@ -141,7 +143,7 @@ def main():
                                    "Stable-PD, fresh uniform(-1,1) actions per control step, 15 mj_steps @450 Hz per "
                                    "step, obs v1 (289 f32) + reward + reset flags fused, device-side autoreset",
                        "envs_per_gpu": N, "parallelism": f"independent shards x{world} (no collective)",
-                       "launch": env.launch_info(), "mean_newton_iters_per_step": iters, "autoresets_total": nwarn,
+                       "launch": env.launch_info(), "mean_newton_iters_per_step": iters, "newton_iters_p50_p99_max": [it_p50, it_p99, it_max], "autoresets_total": nwarn,
                        "obs_finite": finite},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "ss_env_kernel<2,2> (MODE_STEP)", "kernel_ms": kern_ms,

@@ -24,6 +24,7 @@ struct WaveGpu {
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
     return v;
   }
+  __device__ __forceinline__ int opaque(int x) const { return __builtin_amdgcn_readfirstlane(x); }   // wave-uniform, optimizer-opaque
   __device__ __forceinline__ unsigned long long ballot(int p) const { return __ballot(p); }
   __device__ __forceinline__ bool any(int p) const { return __any(p) != 0; }
   __device__ __forceinline__ unsigned long long bor(unsigned long long v) const {
@@ -36,7 +37,7 @@ struct WaveGpu {
   }
 };
 
-template <int DOFP, int CANDP>
+template <int DOFP, int CANDP, int SLOTP>
 __global__ void __launch_bounds__(512) ss_env_kernel(const ss::KArgs k) {
   extern __shared__ __align__(16) uint32_t lds[];
   for (int i = threadIdx.x; i < k.h.shared_words; i += blockDim.x) lds[i] = k.shared_g[i];
@@ -46,16 +47,13 @@ __global__ void __launch_bounds__(512) ss_env_kernel(const ss::KArgs k) {
   if (env >= k.st.num_envs) return;
   float *L = reinterpret_cast<float *>(lds + ((k.h.shared_words + 3) & ~3)) + (size_t)wave * k.h.env_floats;
   WaveGpu w{(int)(threadIdx.x & 63)};
-  ss::run_env<WaveGpu, DOFP, CANDP>(&w, &k, lds, L, env);
+  ss::run_env<WaveGpu, DOFP, CANDP, SLOTP>(&w, &k, lds, L, env);
 }
 
 typedef void (*kern_t)(const ss::KArgs);
-kern_t pick_kernel(int dofp, int candp) {
-  if (dofp == 2 && candp == 2) return ss_env_kernel<2, 2>;
-  if (dofp == 3 && candp == 3) return ss_env_kernel<3, 3>;
-  if (dofp == 3 && candp == 2) return ss_env_kernel<3, 2>;
-  if (dofp == 2 && candp == 3) return ss_env_kernel<2, 3>;
-  if (dofp == 1 && candp == 1) return ss_env_kernel<1, 1>;
+kern_t pick_kernel(int dofp, int candp, int slotp) {
+  if (dofp == 2 && candp == 2 && slotp == 1) return ss_env_kernel<2, 2, 1>;      // SMPL layout (24 bodies)
+  if (dofp == 3 && candp <= 3 && slotp <= 2) return ss_env_kernel<3, 3, 2>;      // SMPL-X/H layout (52 bodies)
   return nullptr;
 }
 
@@ -69,7 +67,7 @@ struct HipBackend {
   static int kernel_regs() { return regs_ref(); }
   static const char *launch(const ss::KArgs &k, int nenv, int envs_per_wg, size_t lds_bytes, void *stream) {
     const int dofp = (k.h.nv + 63) / 64, candp = (k.h.ncand + 63) / 64;
-    kern_t kern = pick_kernel(dofp, candp);
+    kern_t kern = pick_kernel(dofp, candp, (k.h.nslot + 63) / 64);
     if (!kern) return "no kernel variant for this model size";
     static thread_local kern_t configured = nullptr;
     static thread_local size_t configured_lds = 0;

@@ -69,7 +69,7 @@ struct ss_api {
     if (cfg->control_freq_inv < 1) return fail(SS_ERR_INVALID, "control_freq_inv must be >= 1");
     const ss::Hdr &h = m->hm.h;
     const int dofp = (h.nv + 63) / 64, candp = (h.ncand + 63) / 64;
-    if (dofp > 3 || candp > 3) return fail(SS_ERR_INVALID, "model too large for the compiled kernel variants");
+    if (dofp > 3 || candp > 3 || (h.nslot + 63) / 64 > 2) return fail(SS_ERR_INVALID, "model too large for the compiled kernel variants");
     ss_batch *b = new (std::nothrow) ss_batch();
     if (!b) return fail(SS_ERR_NOMEM, "out of host memory");
     b->m = m; b->cfg = *cfg; b->st = *st;

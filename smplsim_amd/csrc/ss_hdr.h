@@ -14,7 +14,7 @@ constexpr int kCandC = 8;    // floats per contact candidate
 // Header passed to the kernels by value: dims, table offsets (32-bit words into the shared blob),
 // per-env LDS layout (float offsets) and physics scalars.
 struct Hdr {
-  int nb, nn, nv, nq, nu, ne, ncand, nlev, nblev, maxD, nblk;
+  int nb, nn, nv, nq, nu, ne, ncand, nlev, nblev, maxD, nblk, nbox, nslot;
   int levstart[20], blevstart[20];   // node / body level offsets (kernel arguments -> scalar loads)
   // shared-blob word offsets
   int o_dofc, o_chainnode, o_nbase, o_ndepth, o_levnodes, o_bparent, o_blevbodies, o_blk, o_trilut, shared_words;

@@ -46,7 +46,7 @@ struct alignas(16) float4_t { float x, y, z, w; };
 SS_DEV float bits2f(uint32_t u) { union { uint32_t u; float f; } c; c.u = u; return c.f; }
 SS_DEV bool is_bad(float x) { return !(x <= 1e10f && x >= -1e10f); }
 
-template <class W, int DOFP, int CANDP>
+template <class W, int DOFP, int CANDP, int SLOTP>
 struct Sim {
   W *w;
   const KArgs *k;
@@ -57,8 +57,8 @@ struct Sim {
   // per-lane constants
   int bpar, bdep;
   // per-lane state
-  float Ib[10], fb[6], sv[6];
-  Contact con[CANDP];
+  float Ib[10];
+  Contact con[SLOTP];
   Limit lim[DOFP];
   float perr[DOFP];
   int iters, nwarn_add;
@@ -78,11 +78,9 @@ struct Sim {
     bpar = -1; bdep = -1;
     if (lane < h.nb) { bpar = ti(h.o_bparent, lane); bdep = ti(h.o_ndepth, lane + 1) - 1; }
 #pragma unroll
-    for (int p = 0; p < CANDP; p++) con[p].active = 0;
+    for (int p = 0; p < SLOTP; p++) con[p].active = 0;
 #pragma unroll
     for (int p = 0; p < DOFP; p++) lim[p].sign = 0.f;
-#pragma unroll
-    for (int i = 0; i < 6; i++) sv[i] = 0.f;
     iters = 0; nwarn_add = 0; touchmask = 0ull;
   }
 
@@ -122,7 +120,7 @@ struct Sim {
 
   // ------------------------------------------------------------------ kinematics + velocities + inertia + bias
   // with_dyn = false: positions/orientations only (observation FK)
-  SS_DEV void forward_kin(bool with_dyn) {
+  SS_DEV void forward_kin(bool with_dyn, bool write_sensors) {
     const Hdr &h = k->h;
     float vb[6] = {0, 0, 0, 0, 0, 0}, ab[6] = {0, 0, 0, 0, 0, 0};
     float Rb[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, rb[3] = {0, 0, 0};
@@ -253,7 +251,7 @@ struct Sim {
       for (int i = 0; i < 10; i++) Ic[10 * b + i] = Ib[i];
       // f = I (a - a_grav) + v x* (I v)
       float ag[6] = {ab[0], ab[1], ab[2], ab[3], ab[4], ab[5] - h.grav};
-      float Ia[6], Iv[6];
+      float Ia[6], Iv[6], fb[6];
       imul(Ib, ag, Ia); imul(Ib, vb, Iv);
       fb[0] = Ia[0] + vb[1] * Iv[2] - vb[2] * Iv[1] + vb[4] * Iv[5] - vb[5] * Iv[4];
       fb[1] = Ia[1] + vb[2] * Iv[0] - vb[0] * Iv[2] + vb[5] * Iv[3] - vb[3] * Iv[5];
@@ -263,11 +261,14 @@ struct Sim {
       fb[5] = Ia[5] + vb[0] * Iv[4] - vb[1] * Iv[3];
 #pragma unroll
       for (int c = 0; c < 6; c++) Gb[6 * b + c] = fb[c];
-      // framelinvel / frameangvel of the body frame origin
-      sv[0] = vb[3] + vb[1] * rb[2] - vb[2] * rb[1];
-      sv[1] = vb[4] + vb[2] * rb[0] - vb[0] * rb[2];
-      sv[2] = vb[5] + vb[0] * rb[1] - vb[1] * rb[0];
-      sv[3] = vb[0]; sv[4] = vb[1]; sv[5] = vb[2];
+      // framelinvel / frameangvel of the body frame origin (the env reads the LAST forward's values)
+      if (write_sensors) {
+        float *svo = k->st.body_vel + ((size_t)env * h.nb + b) * 6;
+        svo[0] = vb[3] + vb[1] * rb[2] - vb[2] * rb[1];
+        svo[1] = vb[4] + vb[2] * rb[0] - vb[0] * rb[2];
+        svo[2] = vb[5] + vb[0] * rb[1] - vb[1] * rb[0];
+        svo[3] = vb[0]; svo[4] = vb[1]; svo[5] = vb[2];
+      }
     }
     w->sync();
     // composite inertia and bias force C = S^T subtree(f): one fused level sweep (16 comps per body)
@@ -315,6 +316,7 @@ struct Sim {
     if (x <= 0.f) return si[0];
     float y;
     if (si[4] == 1.f) y = x;
+    else if (si[4] == 2.f) y = x <= si[3] ? x * x / si[3] : 1.f - (1.f - x) * (1.f - x) / (1.f - si[3]);   // MuJoCo default
     else if (x <= si[3]) y = powf(x, si[4]) / powf(si[3], si[4] - 1.f);
     else y = 1.f - powf(1.f - x, si[4]) / powf(1.f - si[3], si[4] - 1.f);
     return si[0] + y * (si[1] - si[0]);
@@ -325,12 +327,16 @@ struct Sim {
     const Hdr &h = k->h;
     const float pz = q[2], mu = h.mu;
     touchmask = 0ull;
+    // contact records are compacted through LDS (H is free here) into one slot per lane:
+    // box b keeps at most 4 corners -> slots 4b..4b+3, capsule end e -> slot 4*nbox + e
+    float *rec = H;
+#pragma unroll
+    for (int p = 0; p < SLOTP; p++) { int sl = p * 64 + lane; if (sl < h.nslot) rec[13 * sl] = 0.f; }
+    w->sync();
 #pragma unroll
     for (int p = 0; p < CANDP; p++) {
-      Contact &c = con[p];
-      c.active = 0;
       int qual = 0;
-      float dist = 0.f, px = 0, py = 0, pzr = 0;
+      float dist = 0.f, px = 0, py = 0, pzr = 0, t1x = 0.f, t1y = 1.f;
       const int cidx = p * 64 + lane;
       const bool valid = cidx < h.ncand;
       const int cbp = valid ? k->candb[cidx] : 0;
@@ -353,7 +359,6 @@ struct Sim {
           px = rb[0] + Rb[0] * lx + Rb[1] * ly + Rb[2] * lz;
           py = rb[1] + Rb[3] * lx + Rb[4] * ly + Rb[5] * lz;
           pzr = rb[2] + Rb[6] * lx + Rb[7] * ly + Rb[8] * lz - 0.5f * dist;
-          c.t1x = 0.f; c.t1y = 1.f;
         } else {
           float czw = pz + rb[2] + Rb[6] * cv[0] + Rb[7] * cv[1] + Rb[8] * cv[2];
           dist = czw - cv[6];
@@ -364,38 +369,54 @@ struct Sim {
           float axx = Rb[0] * cv[3] + Rb[1] * cv[4] + Rb[2] * cv[5];
           float axy = Rb[3] * cv[3] + Rb[4] * cv[4] + Rb[5] * cv[5];
           float nn = sqrtf(axx * axx + axy * axy);
-          if (nn < 1e-15f) { c.t1x = 1.f; c.t1y = 0.f; } else { c.t1x = axx / nn; c.t1y = axy / nn; }
+          if (nn < 1e-15f) { t1x = 1.f; t1y = 0.f; } else { t1x = axx / nn; t1y = axy / nn; }
         }
       }
       unsigned long long bal = w->ballot(qual && !caps);
-      int act = qual;
+      int act = qual, slot = 0;
       if (valid && !caps) {                                   // plane-box: first 4 qualifying corners in index order
         int grp = lane & ~7;
         unsigned bits = (unsigned)((bal >> grp) & 0xFFull) & ((1u << (lane & 7)) - 1u);
         int rank = 0;
         for (unsigned t = bits; t; t &= t - 1) rank++;
         act = qual && rank < 4;
-      }
+        slot = 4 * (cidx >> 3) + rank;
+      } else if (valid) slot = 4 * h.nbox + (cidx - 8 * h.nbox);
       if (act) {
-        c.active = 1; c.body = b; c.rx = px; c.ry = py; c.rz = pzr;
         const float *vb = V + 6 * b;
         float vx = vb[3] + vb[1] * pzr - vb[2] * py;
         float vy = vb[4] + vb[2] * px - vb[0] * pzr;
         float vz = vb[5] + vb[0] * py - vb[1] * px;
-        float vt1 = c.t1x * vx + c.t1y * vy, vt2 = -c.t1y * vx + c.t1x * vy;
+        float vt1 = t1x * vx + t1y * vy, vt2 = -t1y * vx + t1x * vy;
         float imp = impedance(dist, h.margin);
         float R0 = (1.f - imp) / imp * cv[7] * (1.f + mu * mu);
         if (R0 < 1e-15f) R0 = 1e-15f;
         float Rpy = 2.f * mu * mu * R0;
-        c.D = 1.f / Rpy;
         float kterm = h.K * imp * (dist - h.margin);
-        c.aref[0] = -h.B * (vz + mu * vt1) - kterm;
-        c.aref[1] = -h.B * (vz - mu * vt1) - kterm;
-        c.aref[2] = -h.B * (vz + mu * vt2) - kterm;
-        c.aref[3] = -h.B * (vz - mu * vt2) - kterm;
+        float *o = rec + 13 * slot;
+        o[0] = 1.f; o[1] = (float)b; o[2] = px; o[3] = py; o[4] = pzr; o[5] = t1x; o[6] = t1y; o[7] = 1.f / Rpy;
+        o[8] = -h.B * (vz + mu * vt1) - kterm;
+        o[9] = -h.B * (vz - mu * vt1) - kterm;
+        o[10] = -h.B * (vz + mu * vt2) - kterm;
+        o[11] = -h.B * (vz - mu * vt2) - kterm;
       }
       touchmask |= w->bor(act ? (1ull << b) : 0ull);         // wave-wide OR: bodies touching the floor
     }
+    w->sync();
+#pragma unroll
+    for (int p = 0; p < SLOTP; p++) {
+      Contact &c = con[p];
+      const int sl = p * 64 + lane;
+      c.active = 0;
+      if (sl < h.nslot) {
+        const float *o = rec + 13 * sl;
+        if (o[0] != 0.f) {
+          c.active = 1; c.body = (int)o[1]; c.rx = o[2]; c.ry = o[3]; c.rz = o[4]; c.t1x = o[5]; c.t1y = o[6]; c.D = o[7];
+          c.aref[0] = o[8]; c.aref[1] = o[9]; c.aref[2] = o[10]; c.aref[3] = o[11];
+        }
+      }
+    }
+    w->sync();                                               // records consumed before H is reused
 #pragma unroll
     for (int p = 0; p < DOFP; p++) {
       int i = p * 64 + lane;
@@ -420,7 +441,7 @@ struct Sim {
   SS_DEV void eval_rows(const float *A, const float *x, bool is_delta) {
     const float mu = k->h.mu;
 #pragma unroll
-    for (int p = 0; p < CANDP; p++) {
+    for (int p = 0; p < SLOTP; p++) {
       Contact &c = con[p];
       if (!c.active) continue;
       const float *Ab_ = A + 6 * c.body;
@@ -615,7 +636,7 @@ struct Sim {
   SS_DEV void ls_eval(float al, float c1, float c2, float &d1, float &d2) {
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int p = 0; p < CANDP; p++) {
+    for (int p = 0; p < SLOTP; p++) {
       const Contact &c = con[p];
       if (!c.active) continue;
 #pragma unroll
@@ -660,7 +681,7 @@ struct Sim {
     // ---- contact forces and K_b = sum_rows D u u^T, u = (rho x w ; w)
     int nact = 0;
 #pragma unroll
-    for (int p = 0; p < CANDP; p++) {
+    for (int p = 0; p < SLOTP; p++) {
       const Contact &c = con[p];
       if (!c.active) continue;
       float fx = 0, fy = 0, fz = 0;
@@ -744,7 +765,7 @@ struct Sim {
 #pragma unroll
     for (int p = 0; p < DOFP; p++) { int i = p * 64 + lane; if (i < h.nv) dg_ += delta[i] * grad[i]; }
 #pragma unroll
-    for (int p = 0; p < CANDP; p++) {
+    for (int p = 0; p < SLOTP; p++) {
       const Contact &c = con[p];
       if (!c.active) continue;
 #pragma unroll
@@ -783,7 +804,7 @@ struct Sim {
     for (int p = 0; p < DOFP; p++) { int i = p * 64 + lane; if (i < h.nv) a[i] += al * delta[i]; }
     for (int idx = lane; idx < 6 * h.nb; idx += 64) Ab[idx] += al * Ad[idx];
 #pragma unroll
-    for (int p = 0; p < CANDP; p++) {
+    for (int p = 0; p < SLOTP; p++) {
       Contact &c = con[p];
       if (!c.active) continue;
 #pragma unroll
@@ -953,6 +974,7 @@ struct Sim {
       o += nd;
     } else {
       if (lane < nb) {
+        const float *sv = k->st.body_vel + ((size_t)env * nb + lane) * 6;   // written by this lane in forward_kin
         float *d0 = obs + o + 3 * lane, *d1 = obs + o + 3 * nb + 3 * lane;
         d0[0] = ch * sv[0] + sh * sv[1]; d0[1] = -sh * sv[0] + ch * sv[1]; d0[2] = sv[2];
         d1[0] = ch * sv[3] + sh * sv[4]; d1[1] = -sh * sv[3] + ch * sv[4]; d1[2] = sv[5];
@@ -976,13 +998,13 @@ struct Sim {
 enum { K_PROLOGUE = 0, K_SUBSTEP = 1, K_RESETFWD = 2, K_FINAL = 3 };
 enum { SOLVE_DUMP_M = 0, SOLVE_NEWTON = 1, SOLVE_SPD = 2 };
 
-template <class W, int DOFP, int CANDP>
+template <class W, int DOFP, int CANDP, int SLOTP>
 SS_DEV void run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env) {
   const Hdr &h = k->h;
   const ss_env_cfg &cf = k->cfg;
   const ss_state &st = k->st;
   if (k->mask && !k->mask[env]) return;
-  Sim<W, DOFP, CANDP> sim;
+  Sim<W, DOFP, CANDP, SLOTP> sim;
   sim.init(w, k, T, L, env);
   const int lane = sim.lane;
   const int mode = k->mode;
@@ -1043,13 +1065,15 @@ SS_DEV void run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env) 
   int s = (nsub > 0 && !is_debug) ? -1 : 0;
   const int last_kind = mode == MODE_RESET ? K_RESETFWD : ((mode == MODE_STEP || mode == MODE_KINEMATICS) ? K_FINAL : -1);
   for (;;) {
-    int kind = s < 0 ? K_PROLOGUE : (s < nsub ? K_SUBSTEP : last_kind);
+    // opaque(): keeps the optimizer from jump-threading the state variables (it would clone every stage per state)
+    const int kind = w->opaque(s < 0 ? K_PROLOGUE : (s < nsub ? K_SUBSTEP : last_kind));
     if (kind < 0) break;
     if (kind == K_SUBSTEP && !is_debug) {
       if (sim.any_bad(sim.q, h.nq) || sim.any_bad(sim.v, h.nv)) sim.reset_data();   // mj_checkPos / mj_checkVel
       if (s == nsub - 1) { sim.store(qpg, sim.q, h.nq); sim.store(vpg, sim.v, h.nv); }   // stale source of the next launch
     }
-    sim.forward_kin(kind != K_FINAL);
+    // the env reads the sensors of the LAST forward only: write them on the last mj_step / the reset forward
+    sim.forward_kin(kind != K_FINAL, kind == K_RESETFWD || (kind == K_SUBSTEP && s == nsub - 1));
     if (kind == K_FINAL) break;
     if (kind == K_SUBSTEP || kind == K_RESETFWD) sim.make_constraints();
     if (kind == K_RESETFWD) break;
@@ -1067,6 +1091,7 @@ SS_DEV void run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env) 
     bool redo = false;
     int it = 0;
     for (;;) {                                               // solver loop: one assemble/factor/solve site
+      solve = w->opaque(solve);
       if (solve == SOLVE_NEWTON) sim.newton_prepare();
       else if (solve == SOLVE_SPD) {
         if (cf.control_mode != SS_CTRL_UHC_PD) { sim.simple_controller(next_action, abias); break; }
@@ -1114,7 +1139,6 @@ SS_DEV void run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env) 
   if (is_debug) { sim.store(k->out2 + (size_t)env * h.nv, sim.a, h.nv); return; }
   if (mode == MODE_RESET) { sim.store(qpg, sim.q, h.nq); sim.store(vpg, sim.v, h.nv); cur_t = 0; }
   sim.store(qg, sim.q, h.nq); sim.store(vg, sim.v, h.nv); sim.store(wg, sim.a, h.nv);
-  if (lane < h.nb) for (int c = 0; c < 6; c++) st.body_vel[((size_t)env * h.nb + lane) * 6 + c] = sim.sv[c];
   if (mode == MODE_SUBSTEP) return;
 
   // ---- post_physics_step: cur_t, observation, reward, reset flags

@@ -175,6 +175,9 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
     }
   }
   h.ncand = (int)out.candb.size();
+  h.nbox = 0;
+  for (int b = 0; b < nb; b++) h.nbox += d.geom_type[b] == SS_GEOM_BOX;
+  h.nslot = 4 * h.nbox + 2 * (nb - h.nbox);
   out.legal.assign(nb, 0);
   out.illegal_mask = 0;
   for (int b = 0; b < nb; b++) {
@@ -210,6 +213,7 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   int maxU = 0;                                            // U buffer: nodes-in-level * 3 * D
   for (int L = 1; L < nlev; L++) maxU = std::max(maxU, (levstart[L + 1] - levstart[L]) * 9 * L);
   if (nn > 64) { out.error = "too many nodes"; return false; }
+  if (13 * h.nslot > ne) { out.error = "contact record buffer does not fit"; return false; }
   int o = 0;
   auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
   h.l_H = take(ne);

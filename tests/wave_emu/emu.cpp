@@ -155,16 +155,17 @@ struct WaveEmu {
     return r;
   }
   bool any(int p) { return ballot(p) != 0ull; }
+  int opaque(int x) { volatile int y = x; return y; }
   void atomic_add(float *p, float v) { *p += v; }
 };
 
 struct LaunchCtx { const ss::KArgs *k; const uint32_t *T; float *L; int env; Machine *m; };
 
-template <int DOFP, int CANDP>
+template <int DOFP, int CANDP, int SLOTP>
 void lane_entry(int lane, void *arg) {
   LaunchCtx *c = (LaunchCtx *)arg;
   WaveEmu w{c->m, lane};
-  ss::run_env<WaveEmu, DOFP, CANDP>(&w, c->k, c->T, c->L, c->env);
+  ss::run_env<WaveEmu, DOFP, CANDP, SLOTP>(&w, c->k, c->T, c->L, c->env);
 }
 
 struct EmuBackend {
@@ -184,11 +185,9 @@ struct EmuBackend {
       for (auto &x : L) x = __builtin_nanf("");
       LaunchCtx c{&k, k.shared_g, L.data(), env, m};
       void (*entry)(int, void *) = nullptr;
-      if (dofp == 2 && candp == 2) entry = lane_entry<2, 2>;
-      else if (dofp == 3 && candp == 3) entry = lane_entry<3, 3>;
-      else if (dofp == 3 && candp == 2) entry = lane_entry<3, 2>;
-      else if (dofp == 2 && candp == 3) entry = lane_entry<2, 3>;
-      else if (dofp == 1 && candp == 1) entry = lane_entry<1, 1>;
+      const int slotp = (k.h.nslot + 63) / 64;
+      if (dofp == 2 && candp == 2 && slotp == 1) entry = lane_entry<2, 2, 1>;
+      else if (dofp == 3 && candp <= 3 && slotp <= 2) entry = lane_entry<3, 3, 2>;
       else return "no kernel variant for this model size";
       run_wave(m, entry, &c);
     }
