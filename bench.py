@@ -71,22 +71,18 @@ def main():
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from smplsim_amd import shard
+    rank, local_rank, world = shard.rank_info()
+    dist = shard.init_process_group("nccl", local_rank) if world > 1 else None
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     from smplsim_amd.batch import SMPLSimVecEnv
     N = args.envs_per_gpu
     env = SMPLSimVecEnv(N, device=local_rank, task="HumanoidEnv", state_init="Default", self_obs_v=1,
-                        autoreset=True, seed=1234 + rank)
+                        autoreset=True, seed=shard.shard_seed(1234, rank))
     g = torch.Generator(device=dev)
-    g.manual_seed(1234 + rank)
+    g.manual_seed(shard.shard_seed(1234, rank))
     env.reset()
 
     def one_step():
@@ -97,10 +93,7 @@ def main():
         one_step()
 
     def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+        shard.barrier(dist, world, dev)
 
     # per-launch duration of the dominant kernel (the fused step), HIP events on the launch stream
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -119,10 +112,7 @@ def main():
         _check(lib().ss_reset(env.handle, _ptr(env.reset_buf), None, None, _ptr(env.obs_buf), env._stream()))
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = shard.max_over_ranks(dist, world, elapsed, dev)
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
     finite = bool(torch.isfinite(env.obs_buf).all().item())
     nwarn = int(env.nwarn.sum().item())
@@ -132,7 +122,7 @@ def main():
 
     if rank == 0:
         total_envs = N * world
-        value = total_envs * args.steps / elapsed
+        value = shard.whole_job_throughput(total_envs * args.steps, elapsed)
         bstep = algorithmic_bytes(env.nq, env.nv, env.nu, env.obs_size)
         ach = N * bstep / (kern_ms * 1e-3) / 1e9
         out = {

@@ -1,0 +1,246 @@
+"""Gym-style single-env surface of the reference, backed by the batched HIP stepper.
+
+Keeps the call surface of reference smpl_sim/envs/base_env.py:64-110 and
+smpl_sim/envs/humanoid_env.py:148-184,509-512 (constructor from a cfg object, `reset(seed, options)
+-> (obs, info)`, `step(action) -> (obs, reward, terminated, truncated, info)` with
+`info['critic_state']`, `observation_space`, `action_space`, `actuator_names`, `np_random`,
+`seed()`, `close()`, `render()`), so `Agent.sample_worker` (reference agents/agent.py:64-109) and
+`examples/benchmark.py:87-116` run unchanged.  Physics, controller, observation and reward run
+in one HIP launch on a 1-env batch (`SMPLSimVecEnv`); `SMPLSimGymVecEnv` exposes the same batch
+with numpy in/out for `gym.vector`-style callers (`num_envs`, `step(actions=...)`).
+
+Not provided (outside the hot path): viewers / rendering, SMPL_Robot shape
+generation (needs the licensed SMPL files) — the packaged mean-body model is used, exactly the
+reference's own fallback (humanoid_env.py:249-254).
+"""
+import os
+import types
+
+import numpy as np
+
+from ..batch import SMPLSimVecEnv, ShardModel
+from ..mjcf_writer import default_xml_str
+from ..spaces import Box
+
+
+class _MjDataView:
+    """The few mjData fields callers of the reference env read (examples/env_humanoid_test.py:44)."""
+
+    def __init__(self, env):
+        self._e = env
+
+    @property
+    def qpos(self):
+        return self._e._vec.qpos[0].cpu().numpy().astype(np.float64)
+
+    @property
+    def qvel(self):
+        return self._e._vec.qvel[0].cpu().numpy().astype(np.float64)
+
+    @property
+    def ctrl(self):
+        return np.zeros(self._e._vec.nu)
+
+
+class HumanoidEnv:
+    metadata = {"render_modes": ["human", "rgb_array"], "render_fps": 30}
+    _TASK = "HumanoidEnv"
+
+    def __init__(self, cfg, device=0, num_envs=1):
+        self.cfg = cfg
+        e, r = cfg.env, cfg.robot
+        self.clip_actions = e.clip_actions
+        self.render_mode = e.get("render_mode", None) if hasattr(e, "get") else getattr(e, "render_mode", None)
+        self.headless = getattr(cfg, "headless", True)
+        self.sim_timestep_inv = e.sim_timestep_inv
+        self.sim_timestep = 1.0 / self.sim_timestep_inv
+        self.control_freq_inv = e.control_frequency_inv
+        self.dt = self.sim_timestep * self.control_freq_inv
+        self.control_mode = e.control_mode
+        self.power_scale = e.power_scale
+        self.max_episode_length = e.episode_length
+        self._root_height_obs = e.root_height_obs
+        self.self_obs_v = e.self_obs_v
+        self.dtype = np.float32
+        self.humanoid_type = r.humanoid_type
+        if self.humanoid_type not in ("smpl", "smplh", "smplx"):
+            raise NotImplementedError(f"humanoid_type: {self.humanoid_type}")
+        if self.control_mode not in ("uhc_pd", "pd", "torque"):
+            raise NotImplementedError(f"control_mode {self.control_mode!r} is not supported by the HIP stepper")
+        if self.self_obs_v == 2 and not r.create_vel_sensors:
+            raise AssertionError("self_obs_v=2 needs robot.create_vel_sensors (reference humanoid_env.py:297)")
+        if r.has_shape_variation:
+            raise NotImplementedError("shape variation needs the licensed SMPL files (SURVEY.md §8f-3)")
+        smpl_dir = r.get("smpl_data_dir", "data/smpl") if hasattr(r, "get") else "data/smpl"
+        if os.path.exists(smpl_dir):
+            print("SMPL files found, but SMPL_Robot generation is not part of this package; using the mean neutral body")
+        self.default_xml_str = default_xml_str("smpl_humanoid" if self.humanoid_type == "smpl" else "smplx_humanoid")
+        self.contact_bodies = list(e.contact_bodies)
+        kw = self._task_kwargs(e)
+        self._model = ShardModel(xml=self.default_xml_str, device=device, contact_bodies=self.contact_bodies,
+                                 control_mode=self.control_mode, clip_actions=self.clip_actions,
+                                 pdp_scale=e.pdp_scale, pdd_scale=e.pdd_scale, sim_timestep_inv=self.sim_timestep_inv)
+        self._vec = SMPLSimVecEnv(num_envs, model=self._model, task=self._TASK, state_init=e.state_init,
+                                  self_obs_v=self.self_obs_v, control_mode=self.control_mode,
+                                  episode_length=self.max_episode_length, control_freq_inv=self.control_freq_inv,
+                                  root_height_obs=self._root_height_obs, power_scale=float(self.power_scale),
+                                  autoreset=False, **kw)
+        mc = self._model.mc
+        self.mj_body_names = ["world"] + list(mc.body_names)
+        self.body_names_orig = list(mc.body_names)
+        self.num_rigid_bodies = mc.nbody
+        self.dof_names = self.body_names_orig[1:]
+        self.dof_size = mc.nu
+        self.actuator_names = list(mc.actuator_names)
+        self.qpos_lim, self.qvel_lim = mc.nq, mc.nv
+        self.jkp, self.jkd, self.torque_lim, self._pd_action_scale, self._pd_action_offset = self._model.tables
+        self.mj_data = _MjDataView(self)
+        self.mj_model = types.SimpleNamespace(nq=mc.nq, nv=mc.nv, nu=mc.nu, nbody=mc.nbody + 1,
+                                              opt=types.SimpleNamespace(timestep=self.sim_timestep))
+        n_obs, n_act = self.get_obs_size(), self.get_action_size()
+        self.observation_space = Box(-np.inf * np.ones(n_obs), np.inf * np.ones(n_obs), dtype=self.dtype)
+        lim = np.ones(n_act) if self.clip_actions else np.inf * np.ones(n_act)
+        self.action_space = Box(-lim, lim, dtype=self.dtype)
+        self.np_random = np.random.default_rng()
+        self.cur_t = 0
+        self.reward_info = {}
+        self.viewer = self.renderer = None
+
+    # ---- sizes
+    def _task_kwargs(self, e):
+        return {}
+
+    def get_action_size(self):
+        return self.dof_size
+
+    def get_obs_size(self):
+        return self._vec.obs_size
+
+    def get_self_obs_size(self):
+        return self._vec.obs_size - self.get_task_obs_size()
+
+    def get_task_obs_size(self):
+        return 0
+
+    # ---- gym API
+    def seed(self, seed=None):
+        self.np_random = np.random.default_rng(seed)
+
+    def _rands(self):
+        import torch
+        v = self._vec
+        fa = tr = None
+        if v.state_init == 1:   # Fall: action = np_random.random(nu) - 0.5, three times (humanoid_env.py:485-488)
+            fa = torch.as_tensor(self.np_random.random((v.num_envs, 3, v.nu)), dtype=torch.float32, device=v.device)
+        if v.task_id != 0:      # task targets use the global numpy RNG in the reference (humanoid_speed.py:97-103)
+            tr = torch.as_tensor(np.random.random((v.num_envs, 2)), dtype=torch.float32, device=v.device)
+        return fa, tr
+
+    def reset(self, seed=None, options=None):
+        if seed is not None:
+            self.seed(seed)
+        fa, tr = self._rands()
+        obs, _ = self._vec.reset(fall_actions=fa, task_rand=tr)
+        self.cur_t = 0
+        o = obs[0].cpu().numpy().astype(self.dtype)
+        return o, {"critic_state": o}
+
+    def step(self, action):
+        import torch
+        v = self._vec
+        a = torch.as_tensor(np.asarray(action, dtype=np.float32)[None, : v.nu], device=v.device)
+        _, tr = self._rands() if v.task_id != 0 else (None, None)
+        obs, rew, term, trunc, _ = v.step(a, task_rand=tr)
+        self.cur_t += 1
+        o = obs[0].cpu().numpy().astype(self.dtype)
+        info = dict(self.reward_info)
+        info["critic_state"] = o
+        return o, float(rew[0].item()), bool(term[0].item()), bool(trunc[0].item()), info
+
+    def render(self):
+        return None
+
+    def close(self):
+        self._vec.close()
+
+    # ---- state accessors used by callers of the reference env
+    def get_qpos(self):
+        return self.mj_data.qpos
+
+    def get_qvel(self):
+        return self.mj_data.qvel
+
+    def get_body_xpos(self):
+        return self._vec.kinematics()[0][0].cpu().numpy().astype(np.float64)
+
+    def get_root_pos(self):
+        return self.get_qpos()[:3].copy()
+
+
+class HumanoidTask(HumanoidEnv):
+    pass
+
+
+class HumanoidSpeed(HumanoidTask):
+    _TASK = "HumanoidSpeed"
+
+    def _task_kwargs(self, e):
+        return dict(tar_speed=(e.tar_speed_min, e.tar_speed_max),
+                    speed_change=(e.speed_change_steps_min, e.speed_change_steps_max))
+
+    def get_task_obs_size(self):
+        return 3
+
+
+class HumanoidGetup(HumanoidTask):
+    _TASK = "HumanoidGetup"
+
+    def _task_kwargs(self, e):
+        return dict(tar_height=(e.tar_height_min, e.tar_height_max),
+                    height_change=(e.height_change_steps_min, e.height_change_steps_max),
+                    recovery_steps=e.recovery_steps)
+
+    def get_task_obs_size(self):
+        return 1
+
+
+class SMPLSimGymVecEnv:
+    """numpy-in / numpy-out vector env with the attributes `examples/benchmark.py:97-116` touches on a
+    `gym.vector` env (`num_envs`, `action_space.sample()`, `reset(seed=)`, `step(actions=)`), backed by one
+    HIP launch for all envs instead of one OS process per env (reference benchmark.py:78-81)."""
+
+    def __init__(self, cfg, num_envs, device=0, autoreset=True):
+        import torch
+        cls = {"HumanoidEnv": HumanoidEnv, "HumanoidSpeed": HumanoidSpeed, "HumanoidGetup": HumanoidGetup}[cfg.env.task]
+        self._single = cls(cfg, device=device, num_envs=num_envs)
+        self._vec = self._single._vec
+        self._vec.autoreset = autoreset
+        self.num_envs = num_envs
+        self.single_observation_space = self._single.observation_space
+        self.single_action_space = self._single.action_space
+        n_act = self._single.get_action_size()
+        lim = np.ones((num_envs, n_act))
+        self.action_space = Box(-lim, lim, dtype=np.float32)
+        self.observation_space = Box(-np.inf * np.ones((num_envs, self._vec.obs_size)),
+                                     np.inf * np.ones((num_envs, self._vec.obs_size)), dtype=np.float32)
+        self._torch = torch
+
+    def reset(self, seed=None, options=None):
+        if seed is not None:
+            self._single.seed(seed)
+            self._vec.gen.manual_seed(int(seed))
+        obs, _ = self._vec.reset()
+        o = obs.cpu().numpy()
+        return o, {"critic_state": o}
+
+    def step(self, actions):
+        t = self._torch
+        a = t.as_tensor(np.asarray(actions, dtype=np.float32), device=self._vec.device)
+        obs, rew, term, trunc, info = self._vec.step(a)
+        out = {"critic_state": obs.cpu().numpy()}
+        if "final_observation" in info:
+            out["final_observation"] = info["final_observation"].cpu().numpy()
+        return obs.cpu().numpy(), rew.cpu().numpy().astype(np.float64), term.cpu().numpy(), trunc.cpu().numpy(), out
+
+    def close(self):
+        self._vec.close()

@@ -1,0 +1,67 @@
+"""Multi-GPU sharding of the env batch: independent shards, one process per GPU, no data-path collective.
+
+Every env is an independent unit (own qpos/qvel/targets; model constants replicated), so a node steps
+`world * envs_per_gpu` envs with no exchange step at all.  The only cross-rank operations
+are the benchmark's barrier and the max-over-ranks of the elapsed time (RCCL when on GPUs, gloo on CPU).
+"""
+import os
+
+
+def rank_info():
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def shard_range(total_envs, world, rank):
+    """Contiguous block of env ids owned by `rank` (env i -> rank i // ceil(total/world))."""
+    per = -(-total_envs // world)
+    lo = min(rank * per, total_envs)
+    return lo, min(lo + per, total_envs)
+
+
+def shard_seed(base_seed, rank):
+    return int(base_seed) + int(rank)
+
+
+def init_process_group(backend, local_rank=None):
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend)
+    return dist
+
+
+def barrier(dist, world, device=None):
+    import torch
+    if device is not None and device.type == "cuda":
+        torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+        if device is not None and device.type == "cuda":
+            torch.cuda.synchronize(device)
+
+
+def max_over_ranks(dist, world, value, device=None):
+    import torch
+    if world == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(dist, world, value, device=None):
+    import torch
+    if world == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def whole_job_throughput(total_units, elapsed_max):
+    """env-steps/s of the whole job: units processed by all ranks / slowest rank's time."""
+    return total_units / elapsed_max

@@ -163,3 +163,43 @@ def test_episode_truncation_and_autoreset(vec):
     assert trunc.all() and int(env.cur_t.max()) == 0          # cur_t 6 > 5 -> truncated -> reset in the same call
     assert torch.allclose(env.qpos[:, 2], torch.full((64,), 0.94, device=env.device))
     assert "final_observation" in info and (info["final_observation"][:, 0] - 0.94).abs().max() > 1e-4
+
+
+def test_gym_style_single_env_matches_oracle():
+    """The reference's single-env surface (HumanoidEnv(cfg).reset/step, numpy in/out)."""
+    import smpl_sim.envs.tasks as tasks                       # the reference's import path
+    from smplsim_amd.config import default_cfg
+    env = tasks.HumanoidEnv(default_cfg("HumanoidEnv"))
+    oenv = O.OracleEnv(oracle_model())
+    obs, info = env.reset(seed=54)
+    assert obs.dtype == np.float32 and obs.shape == (289,) and info["critic_state"] is obs
+    assert env.observation_space.shape == (289,) and env.action_space.shape == (69,) and env.actuator_names[0] == "L_Hip_x"
+    assert np.abs(obs - oenv.reset()).max() < 1e-6
+    env.action_space.seed(0)
+    action = env.action_space.sample()                        # benchmark.py:100 reuses one action for all reps
+    for i in range(5):
+        obs, rew, term, trunc, info = env.step(action=action)
+        o_ref, r, te, tu = oenv.step(action.astype(np.float64))
+        assert isinstance(rew, float) and isinstance(term, bool) and isinstance(trunc, bool)
+        assert np.abs(obs - o_ref).max() < 5e-3 * max(1.0, np.abs(o_ref[220:]).max())
+        assert (term, trunc) == (te, tu)
+    env.close()
+
+
+def test_benchmark_harness_shape_runs():
+    """evaluate_env of reference examples/benchmark.py:97-116, re-stated on the vector env."""
+    import time
+    from smplsim_amd.config import default_cfg
+    from smplsim_amd.envs import SMPLSimGymVecEnv
+    env = SMPLSimGymVecEnv(default_cfg("HumanoidEnv"), 64)
+    num_envs = env.num_envs if hasattr(env, "num_envs") else 1
+    action = env.action_space.sample()
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter(); env.reset(seed=54); times.append(time.perf_counter() - t0)
+    times = []
+    for _ in range(5):
+        t0 = time.perf_counter(); out = env.step(actions=action); times.append(time.perf_counter() - t0)
+    sps = num_envs * 5 / np.sum(times)
+    assert out[0].shape == (64, 289) and np.isfinite(out[0]).all() and sps > 0
+    env.close()

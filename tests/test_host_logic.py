@@ -1,0 +1,123 @@
+"""CPU-side tests (-m "not gpu"): host logic, the C-ABI library's exported symbols (no compute calls without
+a GPU), loud failure without a GPU, config/space shims and the multi-process (gloo, world_size 2) shard path."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    from smplsim_amd import _cabi, _lib
+    path = _lib.build()
+    lib = ctypes.CDLL(path)
+    header = open(os.path.join(ROOT, "include", "smplsim_hip.h")).read()
+    declared = set(re.findall(r"\b(ss_[a-z_]+)\s*\(", header))
+    declared -= {"ss_status"}
+    assert declared == set(_cabi.EXPORTS), declared ^ set(_cabi.EXPORTS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    lib.ss_last_error.restype = ctypes.c_char_p
+    assert lib.ss_last_error() is not None
+
+
+def test_struct_layouts_match_the_header():
+    """ctypes mirrors must have the same field order/count as the C structs."""
+    from smplsim_amd import _cabi
+    header = open(os.path.join(ROOT, "include", "smplsim_hip.h")).read()
+    for cname, ctype in (("ss_model_desc", _cabi.ModelDesc), ("ss_env_cfg", _cabi.EnvCfg), ("ss_state", _cabi.State)):
+        end = header.index("} %s;" % cname)
+        body = header[header.rindex("typedef struct {", 0, end) + len("typedef struct {"):end]
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            parts = decl.split(",")
+            for i, p in enumerate(parts):
+                nm = re.sub(r"\[.*?\]", "", p.strip().split()[-1]).lstrip("*")
+                names.append(nm)
+        assert names == [f[0] for f in ctype._fields_], (cname, names)
+
+
+def test_no_gpu_no_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from smplsim_amd.batch import SMPLSimVecEnv
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        SMPLSimVecEnv(4)
+
+
+def test_product_never_imports_the_oracle_or_the_emulator():
+    pkg = os.path.join(ROOT, "smplsim_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+(oracle|tests|wave_emu)\b", src, re.M), f
+                assert "liboracle" not in src and "libss_emu" not in src, f
+
+
+def test_config_and_spaces_shims():
+    from smplsim_amd.config import AttrDict, default_cfg
+    from smplsim_amd.spaces import Box
+    cfg = default_cfg("HumanoidGetup", episode_length=50)
+    assert cfg.env.state_init == "Fall" and cfg.env.episode_length == 50 and cfg.robot.get("remove_toe", False) is False
+    assert AttrDict({"a": {"b": 1}}).a.b == 1
+    b = Box(-np.ones(69), np.ones(69), dtype=np.float32)
+    x = b.sample()
+    assert x.shape == (69,) and x.dtype == np.float32 and b.contains(x)
+
+
+def test_shard_ranges_partition_the_batch():
+    from smplsim_amd.shard import shard_range, shard_seed
+    for total, world in ((32768, 8), (4096, 1), (10, 4), (8192, 8)):
+        seen = []
+        for r in range(world):
+            lo, hi = shard_range(total, world, r)
+            seen.extend(range(lo, hi))
+        assert seen == list(range(total))
+    assert shard_seed(1234, 3) == 1237
+
+
+_WORKER = r'''
+import os, sys, time, json
+sys.path.insert(0, %r)
+import torch
+from smplsim_amd import shard
+rank, local_rank, world = shard.rank_info()
+dist = shard.init_process_group("gloo")
+lo, hi = shard.shard_range(64, world, rank)
+shard.barrier(dist, world)
+t0 = time.perf_counter()
+time.sleep(0.05 * (rank + 1))            # the "step" of this shard: rank 1 is slower
+shard.barrier(dist, world)
+el = shard.max_over_ranks(dist, world, time.perf_counter() - t0)
+n = shard.sum_over_ranks(dist, world, hi - lo)
+if rank == 0:
+    print(json.dumps({"elapsed": el, "units": n, "value": shard.whole_job_throughput(n, el)}))
+dist.destroy_process_group()
+'''
+
+
+def test_world_size_2_gloo_shards(tmp_path):
+    """The N>1 bench path on CPU: one process per shard, barrier + max-over-ranks timing, whole-job value."""
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER % ROOT)
+    port = 29600 + os.getpid() % 200
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    import json
+    res = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert res["units"] == 64 and res["elapsed"] >= 0.1 and abs(res["value"] - 64 / res["elapsed"]) < 1e-6
