@@ -43,11 +43,18 @@ __global__ void __launch_bounds__(512) ss_env_kernel(const ss::KArgs k) {
   for (int i = threadIdx.x; i < k.h.shared_words; i += blockDim.x) lds[i] = k.shared_g[i];
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> LDS bases stay in SGPRs
-  const int env = blockIdx.x * (blockDim.x >> 6) + wave;
-  if (env >= k.st.num_envs) return;
   float *L = reinterpret_cast<float *>(lds + ((k.h.shared_words + 3) & ~3)) + (size_t)wave * k.h.env_floats;
   WaveGpu w{(int)(threadIdx.x & 63)};
-  ss::run_env<WaveGpu, DOFP, CANDP, SLOTP>(&w, &k, lds, L, env);
+  // persistent wavefronts: env-steps have heavy-tailed cost (Newton iterations), so every wave pulls the
+  // next env id from a device counter instead of owning a fixed slice of the batch
+  for (;;) {
+    int env = 0;
+    if (w.ln == 0) env = atomicAdd(k.work_counter, 1);
+    env = __builtin_amdgcn_readfirstlane(env);
+    if (env >= k.st.num_envs) break;
+    ss::run_env<WaveGpu, DOFP, CANDP, SLOTP>(&w, &k, lds, L, env);
+    w.sync();
+  }
 }
 
 typedef void (*kern_t)(const ss::KArgs);
@@ -63,6 +70,7 @@ struct HipBackend {
   static bool upload(void *dst, const void *src, size_t n) { return hipMemcpy(dst, src, n, hipMemcpyHostToDevice) == hipSuccess; }
   static bool set_device(int d) { return hipSetDevice(d) == hipSuccess; }
   static int lds_capacity() { return 160 * 1024; }
+  static int num_cus() { int d = 0, n = 256; if (hipGetDevice(&d) == hipSuccess) { hipDeviceProp_t p; if (hipGetDeviceProperties(&p, d) == hipSuccess) n = p.multiProcessorCount; } return n; }
   static int &regs_ref() { static int r = 0; return r; }
   static int kernel_regs() { return regs_ref(); }
   static const char *launch(const ss::KArgs &k, int nenv, int envs_per_wg, size_t lds_bytes, void *stream) {
@@ -78,7 +86,12 @@ struct HipBackend {
       if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern)) == hipSuccess) regs_ref() = fa.numRegs;
       configured = kern; configured_lds = lds_bytes;
     }
-    dim3 grid((nenv + envs_per_wg - 1) / envs_per_wg), block(64 * envs_per_wg);
+    static thread_local int cus = num_cus();
+    int wgs = (nenv + envs_per_wg - 1) / envs_per_wg;
+    const int resident = cus * (int)(lds_capacity() / lds_bytes > 0 ? lds_capacity() / lds_bytes : 1);
+    if (wgs > resident) wgs = resident;                      // persistent: one resident set of workgroups
+    if (hipMemsetAsync(k.work_counter, 0, sizeof(int32_t), (hipStream_t)stream) != hipSuccess) return "hipMemsetAsync failed";
+    dim3 grid(wgs), block(64 * envs_per_wg);
     hipLaunchKernelGGL(kern, grid, block, lds_bytes, (hipStream_t)stream, k);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? nullptr : hipGetErrorString(e);

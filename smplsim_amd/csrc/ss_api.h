@@ -28,6 +28,7 @@ struct ss_batch {
   int envs_per_wg = 1;
   size_t lds_bytes = 0;
   int obs_size = 0;
+  int32_t *d_counter = nullptr;
 };
 
 template <class BE>
@@ -82,6 +83,8 @@ struct ss_api {
     if (e > 8) e = 8;
     b->envs_per_wg = e;
     b->lds_bytes = shared_b + (size_t)e * env_b;
+    b->d_counter = (int32_t *)BE::alloc(sizeof(int32_t));
+    if (!b->d_counter) { delete b; return fail(SS_ERR_NOMEM, "device allocation failed"); }
     *out = b;
     return SS_OK;
   }
@@ -92,6 +95,7 @@ struct ss_api {
     k.shared_g = m->d_shared; k.bodyc = m->d_bodyc; k.candc = m->d_candc; k.candb = m->d_candb;
     k.illegal_mask = m->hm.illegal_mask;
     k.mode = mode; k.nsub = b->cfg.control_freq_inv; k.obs_size = b->obs_size;
+    k.work_counter = b->d_counter;
     return k;
   }
   static int run(const ss_batch *b, const ss::KArgs &k, void *stream) {
@@ -146,7 +150,7 @@ struct ss_api {
   }                                                                                                                  \
   int ss_obs_size(const ss_model *m, const ss_env_cfg *c) { return (m && c) ? ss::obs_size(m->hm.h, *c) : SS_ERR_INVALID; } \
   int ss_batch_create(const ss_model *m, const ss_env_cfg *c, const ss_state *s, ss_batch **o) { return ss_api<BE>::batch_create(m, c, s, o); } \
-  void ss_batch_destroy(ss_batch *b) { delete b; }                                                                   \
+  void ss_batch_destroy(ss_batch *b) { if (b) { BE::free_(b->d_counter); delete b; } }                                                                   \
   int ss_reset(ss_batch *b, const uint8_t *mask, const float *fa, const float *tr, float *obs, void *st) { return ss_api<BE>::reset(b, mask, fa, tr, obs, st); } \
   int ss_step(ss_batch *b, const float *a, const float *tr, float *obs, float *rew, uint8_t *te, uint8_t *tu, void *st) { return ss_api<BE>::step(b, a, tr, obs, rew, te, tu, st); } \
   int ss_substep(ss_batch *b, const float *a, int n, void *st) { return ss_api<BE>::substep(b, a, n, st); }          \

@@ -14,10 +14,11 @@ constexpr int kCandC = 8;    // floats per contact candidate
 // Header passed to the kernels by value: dims, table offsets (32-bit words into the shared blob),
 // per-env LDS layout (float offsets) and physics scalars.
 struct Hdr {
-  int nb, nn, nv, nq, nu, ne, ncand, nlev, nblev, maxD, nblk, nbox, nslot;
+  int nb, nn, nv, nq, nu, ne, ncand, nlev, nblev, maxD, nblk, nbox, nslot, maxU;
   int levstart[20], blevstart[20];   // node / body level offsets (kernel arguments -> scalar loads)
+  int itemA[20], itemB[20];          // per-level offsets into the packed work-item tables
   // shared-blob word offsets
-  int o_dofc, o_chainnode, o_nbase, o_ndepth, o_levnodes, o_bparent, o_blevbodies, o_blk, o_trilut, shared_words;
+  int o_dofc, o_chainnode, o_nbase, o_ndepth, o_levnodes, o_bparent, o_blevbodies, o_blk, o_itemA, o_itemB, shared_words;
   // per-env LDS float offsets
   int l_H, l_S, l_G, l_Dinv, l_R, l_r, l_Ic, l_K, l_V, l_Ab, l_Ad, l_Gb, l_q, l_v, l_a, l_tau, l_grad,
       l_delta, l_C, l_diag, l_misc, env_floats;
@@ -43,6 +44,7 @@ struct KArgs {
   const float *task_rand;     // [N,2] or null
   const float *fall_actions;  // [N,3,nu] or null
   const uint8_t *mask;        // [N] or null
+  int32_t *work_counter;      // device word, zeroed before each launch: persistent waves pull env ids from it
   float *obs, *reward;
   uint8_t *terminated, *truncated;
   float *out0, *out1, *out2;  // kinematics: xpos, xmat ; debug forward: M entries [N,ne], bias [N,nv], qacc [N,nv]

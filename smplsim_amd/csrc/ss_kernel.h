@@ -103,17 +103,21 @@ struct Sim {
     }
   }
 
-  // A[b] = sum over the dofs d on the chain of body b of S[d] * x[d]   (spatial accel without bias)
-  SS_DEV void body_accel(const float *x, float *A) {
+  // A[b] = sum over the dofs d on the chain of body b of S[d] * x[d]   (spatial accel without bias).
+  // Two stages: per-node contributions c_n = S[3n..3n+2] x[3n..3n+2] (into `tmp`, 6 floats per node),
+  // then each (body, component) adds the <= depth+1 node contributions along its chain.
+  SS_DEV void body_accel(const float *x, float *A, float *tmp) {
     const Hdr &h = k->h;
+    for (int idx = lane; idx < 6 * h.nn; idx += 64) {
+      int n = idx / 6, c = idx - 6 * n, d = 3 * n;
+      tmp[idx] = S[6 * d + c] * x[d] + S[6 * d + 6 + c] * x[d + 1] + S[6 * d + 12 + c] * x[d + 2];
+    }
+    w->sync();
     for (int idx = lane; idx < 6 * h.nb; idx += 64) {
       int b = idx / 6, c = idx - 6 * b, n = b + 1;
       int dn = ti(h.o_ndepth, n);
       float s = 0.f;
-      for (int kk = 0; kk <= dn; kk++) {
-        int d = 3 * ti(h.o_chainnode, n * h.nlev + kk);
-        s += S[6 * d + c] * x[d] + S[6 * d + 6 + c] * x[d + 1] + S[6 * d + 12 + c] * x[d + 2];
-      }
+      for (int kk = 0; kk <= dn; kk++) s += tmp[6 * ti(h.o_chainnode, n * h.nlev + kk) + c];
       A[idx] = s;
     }
   }
@@ -160,6 +164,18 @@ struct Sim {
         for (int c = 0; c < 6; c++) { V[c] = vb[c]; Ad[c] = ab[c]; }
       }
     }
+    // local rotation Rl = Rx Ry Rz and the hinge axes in the parent frame, once per body (not per level)
+    float Rl[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, ayl[3] = {0, 1, 0}, azl[3] = {0, 0, 1};
+    if (lane >= 1 && lane < h.nb) {
+      float sx, cx, sy, cy, sz, cz;
+      sincosf(q[3 * lane + 4], &sx, &cx); sincosf(q[3 * lane + 5], &sy, &cy); sincosf(q[3 * lane + 6], &sz, &cz);
+      // Rx Ry = [[cy,0,sy],[sx sy,cx,-sx cy],[-cx sy,sx,cx cy]] ; times Rz
+      Rl[0] = cy * cz;                 Rl[1] = -cy * sz;                Rl[2] = sy;
+      Rl[3] = sx * sy * cz + cx * sz;  Rl[4] = -sx * sy * sz + cx * cz; Rl[5] = -sx * cy;
+      Rl[6] = -cx * sy * cz + sx * sz; Rl[7] = cx * sy * sz + sx * cz;  Rl[8] = cx * cy;
+      ayl[0] = 0.f; ayl[1] = cx; ayl[2] = sx;                // Rx e_y
+      azl[0] = sy; azl[1] = -sx * cy; azl[2] = cx * cy;      // Rx Ry e_z
+    }
     w->sync();
     for (int L = 1; L < h.nblev; L++) {
       if (bdep == L) {
@@ -169,36 +185,27 @@ struct Sim {
         for (int i = 0; i < 9; i++) Rp[i] = R[9 * bpar + i];
 #pragma unroll
         for (int i = 0; i < 3; i++) rp[i] = r[3 * bpar + i];
-#pragma unroll
-        for (int i = 0; i < 3; i++) rb[i] = rp[i] + Rp[3 * i] * bc[0] + Rp[3 * i + 1] * bc[1] + Rp[3 * i + 2] * bc[2];
-        float sx, cx, sy, cy, sz, cz;
-        sincosf(q[3 * b + 4], &sx, &cx); sincosf(q[3 * b + 5], &sy, &cy); sincosf(q[3 * b + 6], &sz, &cz);
-        float ax[3], ay[3], az[3], c0[3], c1[3], c2[3];
+        float sd[3][6];
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-          float p0 = Rp[3 * i], p1 = Rp[3 * i + 1], p2 = Rp[3 * i + 2];
-          ax[i] = p0;
-          float r11 = cx * p1 + sx * p2, r12 = -sx * p1 + cx * p2;       // R1 = Rp Rx (col0 = p0)
-          ay[i] = r11;
-          float r20 = cy * p0 - sy * r12, r22 = sy * p0 + cy * r12;       // R2 = R1 Ry (col1 = r11)
-          az[i] = r22;
-          c0[i] = cz * r20 + sz * r11; c1[i] = -sz * r20 + cz * r11; c2[i] = r22;   // R3 = R2 Rz
+          const float p0 = Rp[3 * i], p1 = Rp[3 * i + 1], p2 = Rp[3 * i + 2];
+          rb[i] = rp[i] + p0 * bc[0] + p1 * bc[1] + p2 * bc[2];
+          Rb[3 * i] = p0 * Rl[0] + p1 * Rl[3] + p2 * Rl[6];
+          Rb[3 * i + 1] = p0 * Rl[1] + p1 * Rl[4] + p2 * Rl[7];
+          Rb[3 * i + 2] = p0 * Rl[2] + p1 * Rl[5] + p2 * Rl[8];
+          sd[0][i] = p0;                                             // world axes of the x, y, z hinges
+          sd[1][i] = p1 * ayl[1] + p2 * ayl[2];
+          sd[2][i] = p0 * azl[0] + p1 * azl[1] + p2 * azl[2];
         }
-#pragma unroll
-        for (int i = 0; i < 3; i++) { Rb[3 * i] = c0[i]; Rb[3 * i + 1] = c1[i]; Rb[3 * i + 2] = c2[i]; }
 #pragma unroll
         for (int i = 0; i < 9; i++) R[9 * b + i] = Rb[i];
 #pragma unroll
         for (int i = 0; i < 3; i++) r[3 * b + i] = rb[i];
-        float sd[3][6];
-        const float *axs[3] = {ax, ay, az};
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-          const float *A_ = axs[j];
-          sd[j][0] = A_[0]; sd[j][1] = A_[1]; sd[j][2] = A_[2];
-          sd[j][3] = rb[1] * A_[2] - rb[2] * A_[1];
-          sd[j][4] = rb[2] * A_[0] - rb[0] * A_[2];
-          sd[j][5] = rb[0] * A_[1] - rb[1] * A_[0];
+          sd[j][3] = rb[1] * sd[j][2] - rb[2] * sd[j][1];
+          sd[j][4] = rb[2] * sd[j][0] - rb[0] * sd[j][2];
+          sd[j][5] = rb[0] * sd[j][1] - rb[1] * sd[j][0];
 #pragma unroll
           for (int c = 0; c < 6; c++) S[6 * (3 * n + j) + c] = sd[j][c];
         }
@@ -488,14 +495,13 @@ struct Sim {
     }
     w->sync();
     for (int e = lane; e < h.nblk; e += 64) {
-      const int code = ti(h.o_blk, e), n = code >> 8, J = code & 255;
-      const int aJ = ti(h.o_chainnode, n * h.nlev + J);
-      const int d = ti(h.o_ndepth, n), Wd = 3 * d + 3, base = ti(h.o_nbase, n);
+      const int w0 = ti(h.o_blk, 2 * e), w1 = ti(h.o_blk, 2 * e + 1);
+      const int aJ = w0 & 255, n = (w0 >> 8) & 255, dst = w1 & 0xFFFF, Wd = w1 >> 16;
+      const bool dg = (w0 >> 16) & 1;
       const float *sj = S + 18 * aJ, *gi = G + 18 * n;
       float sv_[18], gv_[18];
 #pragma unroll
       for (int t = 0; t < 18; t++) { sv_[t] = sj[t]; gv_[t] = gi[t]; }
-      const bool dg = (aJ == n);
 #pragma unroll
       for (int r_ = 0; r_ < 3; r_++) {
 #pragma unroll
@@ -504,7 +510,7 @@ struct Sim {
 #pragma unroll
           for (int t = 0; t < 6; t++) acc += sv_[6 * c + t] * gv_[6 * r_ + t];
           if (dg && r_ == c) acc += diag[3 * n + r_];
-          H[base + r_ * Wd + 3 * J + c] = acc;
+          H[dst + r_ * Wd + c] = acc;
         }
       }
     }
@@ -520,69 +526,73 @@ struct Sim {
   //   phase 3  P_k <- U_k (rows of L)
   SS_DEV void factor_H() {
     const Hdr &h = k->h;
-    float *U = G;                                            // G is free between assembly and the next one
+    // U is double-buffered in G (free between assembly and the next one) so that "P_k <- U_k" of level L+1
+    // shares a phase with "U = Dinv P" of level L
     for (int L = h.nlev - 1; L >= 0; --L) {
-      const int s = h.levstart[L], nk = h.levstart[L + 1] - s, D = 3 * L, Wd = D + 3;
-      const int Lc = L > 0 ? L : 1;
-      const float rLc = 1.0f / (float)Lc;
-      for (int idx = lane; idx < nk * Lc; idx += 64) {
-        int kk = (int)(((float)idx + 0.5f) * rLc), J = idx - kk * Lc;
-        int n = ti(h.o_levnodes, s + kk), base = ti(h.o_nbase, n);
-        const float *db = H + base + D;
-        float d00 = db[0], d10 = db[Wd], d11 = db[Wd + 1], d20 = db[2 * Wd], d21 = db[2 * Wd + 1], d22 = db[2 * Wd + 2];
-        float c00 = d11 * d22 - d21 * d21, c01 = d21 * d20 - d10 * d22, c02 = d10 * d21 - d11 * d20;
-        float id = 1.f / (d00 * c00 + d10 * c01 + d20 * c02);
-        float i00 = c00 * id, i01 = c01 * id, i02 = c02 * id;
-        float i11 = (d00 * d22 - d20 * d20) * id, i12 = (d10 * d20 - d00 * d21) * id, i22 = (d00 * d11 - d10 * d10) * id;
-        if (J == 0) { float *o = Dinv + 6 * n; o[0] = i00; o[1] = i01; o[2] = i02; o[3] = i11; o[4] = i12; o[5] = i22; }
-        if (L > 0) {
-          const float *pb = H + base + 3 * J;
-          float *ub = U + (kk * 3) * D + 3 * J;
+      const int D = 3 * L, Wd = D + 3;
+      float *U = G + (L & 1) * h.maxU;
+      if (L + 1 < h.nlev) {                                  // phase 3 of the level below: rows of L
+        const int Dn = D + 3, Wn = Dn + 3;
+        const float *Un = G + ((L + 1) & 1) * h.maxU;
+        const int i0 = h.itemA[L + 1], ni = h.itemA[L + 2] - i0;
+        for (int idx = lane; idx < ni; idx += 64) {
+          const int it = ti(h.o_itemA, i0 + idx), base = it & 4095, J = (it >> 24) & 15, kk = (it >> 28) & 15;
+          float *pb = H + base + 3 * J;
+          const float *ub = Un + (kk * 3) * Dn + 3 * J;
 #pragma unroll
-          for (int c = 0; c < 3; c++) {
-            float p0 = pb[c], p1 = pb[Wd + c], p2 = pb[2 * Wd + c];
-            ub[c] = i00 * p0 + i01 * p1 + i02 * p2;
-            ub[D + c] = i01 * p0 + i11 * p1 + i12 * p2;
-            ub[2 * D + c] = i02 * p0 + i12 * p1 + i22 * p2;
+          for (int r_ = 0; r_ < 3; r_++) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) pb[r_ * Wn + c] = ub[r_ * Dn + c];
+          }
+        }
+      }
+      {                                                      // phase 1: Dinv_k, U_k = Dinv_k P_k
+        const int i0 = h.itemA[L], ni = h.itemA[L + 1] - i0;
+        for (int idx = lane; idx < ni; idx += 64) {
+          const int it = ti(h.o_itemA, i0 + idx), base = it & 4095, n = (it >> 12) & 63, J = (it >> 24) & 15, kk = (it >> 28) & 15;
+          const float *db = H + base + D;
+          float d00 = db[0], d10 = db[Wd], d11 = db[Wd + 1], d20 = db[2 * Wd], d21 = db[2 * Wd + 1], d22 = db[2 * Wd + 2];
+          float c00 = d11 * d22 - d21 * d21, c01 = d21 * d20 - d10 * d22, c02 = d10 * d21 - d11 * d20;
+          float id = 1.f / (d00 * c00 + d10 * c01 + d20 * c02);
+          float i00 = c00 * id, i01 = c01 * id, i02 = c02 * id;
+          float i11 = (d00 * d22 - d20 * d20) * id, i12 = (d10 * d20 - d00 * d21) * id, i22 = (d00 * d11 - d10 * d10) * id;
+          if (J == 0) { float *o = Dinv + 6 * n; o[0] = i00; o[1] = i01; o[2] = i02; o[3] = i11; o[4] = i12; o[5] = i22; }
+          if (L > 0) {
+            const float *pb = H + base + 3 * J;
+            float *ub = U + (kk * 3) * D + 3 * J;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+              float p0 = pb[c], p1 = pb[Wd + c], p2 = pb[2 * Wd + c];
+              ub[c] = i00 * p0 + i01 * p1 + i02 * p2;
+              ub[D + c] = i01 * p0 + i11 * p1 + i12 * p2;
+              ub[2 * D + c] = i02 * p0 + i12 * p1 + i22 * p2;
+            }
           }
         }
       }
       w->sync();
       if (L == 0) break;
-      const int Tn = L * (L + 1) / 2;
-      const float rT = 1.0f / (float)Tn;
-      for (int idx = lane; idx < nk * Tn; idx += 64) {
-        int kk = (int)(((float)idx + 0.5f) * rT), t = idx - kk * Tn;
-        int ij = ti(h.o_trilut, t), I = ij >> 8, J = ij & 255;
-        int n = ti(h.o_levnodes, s + kk), base = ti(h.o_nbase, n);
-        int aI = ti(h.o_chainnode, n * h.nlev + I), Wa = 3 * I + 3;
-        const float *pb = H + base + 3 * I, *ub = U + (kk * 3) * D + 3 * J;
-        float P_[9], U_[9];
+      {                                                      // phase 2: ancestor blocks (I >= J) -= P[:,I]^T U[:,J]
+        const int i0 = h.itemB[L], ni = h.itemB[L + 1] - i0;
+        for (int idx = lane; idx < ni; idx += 64) {
+          const int w0 = ti(h.o_itemB, 2 * (i0 + idx)), w1 = ti(h.o_itemB, 2 * (i0 + idx) + 1);
+          const float *pb = H + (w0 & 0xFFFF), *ub = U + (w0 >> 16);
+          float *dst = H + (w1 & 0xFFFF);
+          const int Wa = w1 >> 16;
+          float P_[9], U_[9];
 #pragma unroll
-        for (int r_ = 0; r_ < 3; r_++) {
+          for (int r_ = 0; r_ < 3; r_++) {
 #pragma unroll
-          for (int c = 0; c < 3; c++) { P_[3 * r_ + c] = pb[r_ * Wd + c]; U_[3 * r_ + c] = ub[r_ * D + c]; }
-        }
-        float *dst = H + ti(h.o_nbase, aI) + 3 * J;
-#pragma unroll
-        for (int a_ = 0; a_ < 3; a_++) {
-#pragma unroll
-          for (int b_ = 0; b_ < 3; b_++) {
-            float val = P_[a_] * U_[b_] + P_[3 + a_] * U_[3 + b_] + P_[6 + a_] * U_[6 + b_];
-            w->atomic_add(&dst[a_ * Wa + b_], -val);
+            for (int c = 0; c < 3; c++) { P_[3 * r_ + c] = pb[r_ * Wd + c]; U_[3 * r_ + c] = ub[r_ * D + c]; }
           }
-        }
-      }
-      w->sync();
-      for (int idx = lane; idx < nk * L; idx += 64) {
-        int kk = (int)(((float)idx + 0.5f) * rLc), J = idx - kk * L;
-        int n = ti(h.o_levnodes, s + kk), base = ti(h.o_nbase, n);
-        float *pb = H + base + 3 * J;
-        const float *ub = U + (kk * 3) * D + 3 * J;
 #pragma unroll
-        for (int r_ = 0; r_ < 3; r_++) {
+          for (int a_ = 0; a_ < 3; a_++) {
 #pragma unroll
-          for (int c = 0; c < 3; c++) pb[r_ * Wd + c] = ub[r_ * D + c];
+            for (int b_ = 0; b_ < 3; b_++) {
+              float val = P_[a_] * U_[b_] + P_[3 + a_] * U_[3 + b_] + P_[6 + a_] * U_[6 + b_];
+              w->atomic_add(&dst[a_ * Wa + b_], -val);
+            }
+          }
         }
       }
       w->sync();
@@ -593,12 +603,9 @@ struct Sim {
   SS_DEV void solve_H(float *x) {
     const Hdr &h = k->h;
     for (int L = h.nlev - 1; L >= 1; --L) {                  // x <- L^-T x (leaves to root)
-      const int s = h.levstart[L], nk = h.levstart[L + 1] - s, Wd = 3 * L + 3;
-      const float rL = 1.0f / (float)L;
-      for (int idx = lane; idx < nk * L; idx += 64) {
-        int kk = (int)(((float)idx + 0.5f) * rL), J = idx - kk * L;
-        int n = ti(h.o_levnodes, s + kk), base = ti(h.o_nbase, n);
-        int aJ = ti(h.o_chainnode, n * h.nlev + J);
+      const int Wd = 3 * L + 3, i0 = h.itemA[L], ni = h.itemA[L + 1] - i0;
+      for (int idx = lane; idx < ni; idx += 64) {
+        const int it = ti(h.o_itemA, i0 + idx), base = it & 4095, n = (it >> 12) & 63, aJ = (it >> 18) & 63, J = (it >> 24) & 15;
         const float *ub = H + base + 3 * J;
         float z0 = x[3 * n], z1 = x[3 * n + 1], z2 = x[3 * n + 2];
 #pragma unroll
@@ -616,12 +623,9 @@ struct Sim {
     }
     w->sync();
     for (int L = 1; L < h.nlev; L++) {                        // x <- L^-1 x (root to leaves)
-      const int s = h.levstart[L], nk = h.levstart[L + 1] - s, Wd = 3 * L + 3;
-      const float rL = 1.0f / (float)L;
-      for (int idx = lane; idx < nk * L; idx += 64) {
-        int kk = (int)(((float)idx + 0.5f) * rL), J = idx - kk * L;
-        int n = ti(h.o_levnodes, s + kk), base = ti(h.o_nbase, n);
-        int aJ = ti(h.o_chainnode, n * h.nlev + J);
+      const int Wd = 3 * L + 3, i0 = h.itemA[L], ni = h.itemA[L + 1] - i0;
+      for (int idx = lane; idx < ni; idx += 64) {
+        const int it = ti(h.o_itemA, i0 + idx), base = it & 4095, n = (it >> 12) & 63, aJ = (it >> 18) & 63, J = (it >> 24) & 15;
         const float *ub = H + base + 3 * J;
         float y0 = x[3 * aJ], y1 = x[3 * aJ + 1], y2 = x[3 * aJ + 2];
 #pragma unroll
@@ -659,7 +663,7 @@ struct Sim {
   // Newton on MuJoCo's convex primal problem, split so that the shared assemble/factor/solve site sits
   // between newton_prepare() and newton_finish() in the driver's solver loop.
   SS_DEV void newton_begin() {
-    body_accel(a, Ab);
+    body_accel(a, Ab, G);                                    // G is free outside assemble/factor
     w->sync();
     eval_rows(Ab, a, false);
   }
@@ -758,7 +762,7 @@ struct Sim {
   // exact line search along delta, step, active-set change detection; returns true when converged
   SS_DEV bool newton_finish() {
     const Hdr &h = k->h;
-    body_accel(delta, Ad);
+    body_accel(delta, Ad, G);
     w->sync();
     eval_rows(Ad, delta, true);
     float dg_ = 0.f, s_a = 0.f, s_b = 0.f;
@@ -799,9 +803,17 @@ struct Sim {
         ls_eval(al, c1, c2, d1, d2);
       }
     }
-    int changed = 0;
+    int changed = 0, moving = 0;
 #pragma unroll
-    for (int p = 0; p < DOFP; p++) { int i = p * 64 + lane; if (i < h.nv) a[i] += al * delta[i]; }
+    for (int p = 0; p < DOFP; p++) {
+      int i = p * 64 + lane;
+      if (i < h.nv) {
+        const float st_ = al * delta[i], an = a[i] + st_;
+        a[i] = an;
+        // still moving: the step is above float32 resolution of the iterate (false for NaN/inf too)
+        moving |= fabsf(st_) > 4e-7f * fabsf(an) + 1e-12f && fabsf(an) <= 1e10f;
+      }
+    }
     for (int idx = lane; idx < 6 * h.nb; idx += 64) Ab[idx] += al * Ad[idx];
 #pragma unroll
     for (int p = 0; p < SLOTP; p++) {
@@ -823,7 +835,8 @@ struct Sim {
       l.jar = nj;
     }
     w->sync();
-    return !w->any(changed) && exact;
+    // converged: full Newton step with an unchanged active set, or no representable progress any more
+    return (!w->any(changed) && exact) || !w->any(moving);
   }
 
   // ------------------------------------------------------------------ controllers (torque for the NEXT mj_step)

@@ -189,10 +189,38 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   if (nlev > 19 || nblev > 19) { out.error = "tree too deep"; return false; }
   for (int L = 0; L <= nlev; L++) h.levstart[L] = levstart[L];
   for (int L = 0; L <= nblev; L++) h.blevstart[L] = blevstart[L];
-  std::vector<int> blk, trilut;
-  for (int n = 0; n < nn; n++) for (int J = 0; J <= ndepth[n]; J++) blk.push_back((n << 8) | J);
-  h.nblk = (int)blk.size();
-  for (int I = 0; I < nlev; I++) for (int J = 0; J <= I; J++) trilut.push_back((I << 8) | J);
+  // packed work-item records (one LDS read per item instead of a chain of dependent table reads):
+  //  blk   (assemble)           w0 = aJ | n<<8 | diag<<16      w1 = (base_n + 3J) | Wd<<16
+  //  itemA (U=Dinv P, copy, triangular sweeps), per level: base_k(12) | n(6)<<12 | aJ(6)<<18 | J(4)<<24 | kk(4)<<28
+  //  itemB (ancestor block update), per level:  w0 = (base_k + 3I) | (kk*3*D + 3J)<<16   w1 = (base_aI + 3J) | Wa<<16
+  std::vector<int> blk, itemA, itemB;
+  for (int n = 0; n < nn; n++) for (int J = 0; J <= ndepth[n]; J++) {
+    int aJ = chainnode[n * CN + J], Wd = 3 * ndepth[n] + 3;
+    blk.push_back(aJ | (n << 8) | ((aJ == n) << 16));
+    blk.push_back((nbase[n] + 3 * J) | (Wd << 16));
+  }
+  h.nblk = (int)blk.size() / 2;
+  for (int L = 0; L < nlev; L++) {
+    h.itemA[L] = (int)itemA.size(); h.itemB[L] = (int)itemB.size() / 2;
+    int nk = levstart[L + 1] - levstart[L], D = 3 * L;
+    if (nk > 16 || L > 15 || ne > 4095) { out.error = "model exceeds the packed item-table field widths"; return false; }
+    for (int kk = 0; kk < nk; kk++) {
+      int n = levnodes[levstart[L] + kk];
+      for (int J = 0; J < std::max(L, 1); J++) {
+        int aJ = L > 0 ? chainnode[n * CN + J] : 0;
+        itemA.push_back(nbase[n] | (n << 12) | (aJ << 18) | (J << 24) | (kk << 28));
+      }
+    }
+    for (int kk = 0; kk < nk; kk++) {
+      int n = levnodes[levstart[L] + kk];
+      for (int I = 0; I < L; I++) for (int J = 0; J <= I; J++) {
+        int aI = chainnode[n * CN + I], Wa = 3 * I + 3;
+        itemB.push_back((nbase[n] + 3 * I) | ((kk * 3 * D + 3 * J) << 16));
+        itemB.push_back((nbase[aI] + 3 * J) | (Wa << 16));
+      }
+    }
+  }
+  h.itemA[nlev] = (int)itemA.size(); h.itemB[nlev] = (int)itemB.size() / 2;
   out.decode = decode;
   auto &S = out.shared; S.clear();
   auto push_i = [&](const std::vector<int> &v) { int o = (int)S.size(); for (int x : v) S.push_back((uint32_t)x); return o; };
@@ -205,7 +233,8 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   h.o_bparent = push_i(bpar);
   h.o_blevbodies = push_i(blevbodies);
   h.o_blk = push_i(blk);
-  h.o_trilut = push_i(trilut);
+  h.o_itemA = push_i(itemA);
+  h.o_itemB = push_i(itemB);
   h.shared_words = (int)S.size();
   (void)chainrow; (void)nparent;
 
@@ -218,7 +247,8 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
   h.l_H = take(ne);
   h.l_S = take(6 * nv);
-  h.l_G = take(std::max(6 * nv, maxU));                    // G doubles as the U buffer of the factorization
+  h.l_G = take(std::max(6 * nv, 2 * maxU));                // G doubles as the (double-buffered) U buffer of the factorization
+  h.maxU = maxU;
   h.l_Dinv = take(6 * nn);
   h.l_R = take(9 * nb); h.l_r = take(3 * nb);
   h.l_Ic = take(10 * nb); h.l_K = take(21 * nb);

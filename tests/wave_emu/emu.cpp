@@ -180,6 +180,7 @@ struct EmuBackend {
     static thread_local Machine *m = new Machine();
     std::vector<float> L(k.h.env_floats);
     const int dofp = (k.h.nv + 63) / 64, candp = (k.h.ncand + 63) / 64;
+    *k.work_counter = 0;
     for (int env = 0; env < nenv; env++) {
       // poison LDS so that reads of never-written locations are visible
       for (auto &x : L) x = __builtin_nanf("");
