@@ -128,6 +128,8 @@ int ss_kinematics(ss_batch *b, float *xpos, float *xmat, void *stream);
  * and the constrained qacc [N,nv].  ss_debug_decode returns for every sparse entry (row_dof << 16 | col_dof). */
 int ss_debug_forward(ss_batch *b, const float *torques, float *M_entries, float *bias, float *qacc, void *stream);
 int ss_debug_decode(const ss_model *m, int32_t *out, int32_t *ne);
+/* -DSS_PROFILE builds only: accumulated shader-clock ticks per kernel stage (tools/stage_profile.py) */
+int ss_debug_prof(ss_batch *b, unsigned long long *out, int n);
 
 /* launch geometry actually used (envs per workgroup, LDS bytes per workgroup) */
 int ss_launch_info(const ss_batch *b, int32_t *envs_per_wg, int32_t *lds_bytes, int32_t *kernel_regs);

@@ -24,7 +24,11 @@ struct WaveGpu {
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
     return v;
   }
+  __device__ __forceinline__ unsigned long long clock() const { return __builtin_readcyclecounter(); }
+  __device__ __forceinline__ void atomic_add_u64(unsigned long long *p, unsigned long long v) const { atomicAdd(p, v); }
   __device__ __forceinline__ int opaque(int x) const { return __builtin_amdgcn_readfirstlane(x); }   // wave-uniform, optimizer-opaque
+  __device__ __forceinline__ float shfl_xor(float v, int m) const { return __shfl_xor(v, m, 64); }
+  __device__ __forceinline__ int shfl_xor_i(int v, int m) const { return __shfl_xor(v, m, 64); }
   __device__ __forceinline__ unsigned long long ballot(int p) const { return __ballot(p); }
   __device__ __forceinline__ bool any(int p) const { return __any(p) != 0; }
   __device__ __forceinline__ unsigned long long bor(unsigned long long v) const {
@@ -69,6 +73,7 @@ struct HipBackend {
   static void free_(void *p) { if (p) (void)hipFree(p); }
   static bool upload(void *dst, const void *src, size_t n) { return hipMemcpy(dst, src, n, hipMemcpyHostToDevice) == hipSuccess; }
   static bool set_device(int d) { return hipSetDevice(d) == hipSuccess; }
+  static bool download(void *dst, const void *src, size_t n) { return hipMemcpy(dst, src, n, hipMemcpyDeviceToHost) == hipSuccess; }
   static int lds_capacity() { return 160 * 1024; }
   static int num_cus() { int d = 0, n = 256; if (hipGetDevice(&d) == hipSuccess) { hipDeviceProp_t p; if (hipGetDeviceProperties(&p, d) == hipSuccess) n = p.multiProcessorCount; } return n; }
   static int &regs_ref() { static int r = 0; return r; }

@@ -29,6 +29,7 @@ struct ss_batch {
   size_t lds_bytes = 0;
   int obs_size = 0;
   int32_t *d_counter = nullptr;
+  unsigned long long *d_prof = nullptr;   // SS_PROFILE builds only
 };
 
 template <class BE>
@@ -83,6 +84,10 @@ struct ss_api {
     if (e > 8) e = 8;
     b->envs_per_wg = e;
     b->lds_bytes = shared_b + (size_t)e * env_b;
+#ifdef SS_PROFILE
+    b->d_prof = (unsigned long long *)BE::alloc(64 * sizeof(unsigned long long));
+    if (b->d_prof) { unsigned long long z[64] = {0}; BE::upload(b->d_prof, z, sizeof z); }
+#endif
     b->d_counter = (int32_t *)BE::alloc(sizeof(int32_t));
     if (!b->d_counter) { delete b; return fail(SS_ERR_NOMEM, "device allocation failed"); }
     *out = b;
@@ -96,6 +101,7 @@ struct ss_api {
     k.illegal_mask = m->hm.illegal_mask;
     k.mode = mode; k.nsub = b->cfg.control_freq_inv; k.obs_size = b->obs_size;
     k.work_counter = b->d_counter;
+    k.prof = b->d_prof;
     return k;
   }
   static int run(const ss_batch *b, const ss::KArgs &k, void *stream) {
@@ -150,7 +156,11 @@ struct ss_api {
   }                                                                                                                  \
   int ss_obs_size(const ss_model *m, const ss_env_cfg *c) { return (m && c) ? ss::obs_size(m->hm.h, *c) : SS_ERR_INVALID; } \
   int ss_batch_create(const ss_model *m, const ss_env_cfg *c, const ss_state *s, ss_batch **o) { return ss_api<BE>::batch_create(m, c, s, o); } \
-  void ss_batch_destroy(ss_batch *b) { if (b) { BE::free_(b->d_counter); delete b; } }                                                                   \
+  void ss_batch_destroy(ss_batch *b) { if (b) { BE::free_(b->d_counter); BE::free_(b->d_prof); delete b; } }          \
+  int ss_debug_prof(ss_batch *b, unsigned long long *out, int n) {                                                   \
+    if (!b || !out || !b->d_prof) return ss_api<BE>::fail(SS_ERR_INVALID, "not a profiling build");                 \
+    return BE::download(out, b->d_prof, (size_t)n * 8) ? SS_OK : SS_ERR_HIP;                                         \
+  }                                                                   \
   int ss_reset(ss_batch *b, const uint8_t *mask, const float *fa, const float *tr, float *obs, void *st) { return ss_api<BE>::reset(b, mask, fa, tr, obs, st); } \
   int ss_step(ss_batch *b, const float *a, const float *tr, float *obs, float *rew, uint8_t *te, uint8_t *tu, void *st) { return ss_api<BE>::step(b, a, tr, obs, rew, te, tu, st); } \
   int ss_substep(ss_batch *b, const float *a, int n, void *st) { return ss_api<BE>::substep(b, a, n, st); }          \

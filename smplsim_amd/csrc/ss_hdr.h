@@ -17,8 +17,9 @@ struct Hdr {
   int nb, nn, nv, nq, nu, ne, ncand, nlev, nblev, maxD, nblk, nbox, nslot, maxU;
   int levstart[20], blevstart[20];   // node / body level offsets (kernel arguments -> scalar loads)
   int itemA[20], itemB[20];          // per-level offsets into the packed work-item tables
+  int accp[20], bsol[20];            // per-level offsets: tree-accumulation parents, backward-solve targets
   // shared-blob word offsets
-  int o_dofc, o_chainnode, o_nbase, o_ndepth, o_levnodes, o_bparent, o_blevbodies, o_blk, o_itemA, o_itemB, shared_words;
+  int o_dofc, o_chainnode, o_nbase, o_ndepth, o_levnodes, o_bparent, o_blevbodies, o_blk, o_itemA, o_itemB, o_fsrc, o_accp, o_children, o_bsol, o_bsrc, shared_words;
   // per-env LDS float offsets
   int l_H, l_S, l_G, l_Dinv, l_R, l_r, l_Ic, l_K, l_V, l_Ab, l_Ad, l_Gb, l_q, l_v, l_a, l_tau, l_grad,
       l_delta, l_C, l_diag, l_misc, env_floats;
@@ -44,6 +45,7 @@ struct KArgs {
   const float *task_rand;     // [N,2] or null
   const float *fall_actions;  // [N,3,nu] or null
   const uint8_t *mask;        // [N] or null
+  unsigned long long *prof;   // optional stage-cycle accumulators (SS_PROFILE builds), else null
   int32_t *work_counter;      // device word, zeroed before each launch: persistent waves pull env ids from it
   float *obs, *reward;
   uint8_t *terminated, *truncated;

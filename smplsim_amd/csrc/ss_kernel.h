@@ -31,7 +31,19 @@
 #define SS_DEV inline
 #endif
 
+// Optional in-kernel stage timing (build with -DSS_PROFILE): lane 0 accumulates shader clock ticks per
+// stage and adds them to k->prof[stage] (device array of 64-bit counters) at the end of each env.
+#ifdef SS_PROFILE
+#define SS_T0() unsigned long long t__ = w->clock()
+#define SS_TICK(id) do { unsigned long long n__ = w->clock(); sim.prof[id] += n__ - t__; t__ = n__; } while (0)
+#else
+#define SS_T0() do {} while (0)
+#define SS_TICK(id) do {} while (0)
+#endif
+
 namespace ss {
+
+enum { PF_FWD = 0, PF_CONS, PF_NBEGIN, PF_NPREP, PF_ASM, PF_FACTOR, PF_SOLVE, PF_NFIN, PF_SPDPREP, PF_SPDFIN, PF_INTEG, PF_MISC, PF_COUNT };
 
 struct Contact {
   float rx, ry, rz;      // contact point relative to the root origin
@@ -62,11 +74,17 @@ struct Sim {
   Limit lim[DOFP];
   float perr[DOFP];
   int iters, nwarn_add;
+#ifdef SS_PROFILE
+  unsigned long long prof[PF_COUNT];
+#endif
   unsigned long long touchmask;
 
   SS_DEV int ti(int off, int i) const { return (int)T[off + i]; }
   SS_DEV float tf(int off, int i) const { return bits2f(T[off + i]); }
   SS_DEV float dc(int dof, int f) const { return tf(k->h.o_dofc, dof * kDofC + f); }
+  // body of a contact slot: box b owns slots 4b'..4b'+3 (b' = box order), capsule ends follow
+  SS_DEV int h_box_body(int sl) const { return k->candb[8 * (sl >> 2)] & 255; }
+  SS_DEV int h_caps_body(int sl) const { int e = sl - 4 * k->h.nbox; int ci = 8 * k->h.nbox + e; return ci < k->h.ncand ? (k->candb[ci] & 255) : 0; }
 
   SS_DEV void init(W *w_, const KArgs *k_, const uint32_t *T_, float *L, int env_) {
     w = w_; k = k_; T = T_; lane = w->lane(); env = env_;
@@ -82,6 +100,9 @@ struct Sim {
 #pragma unroll
     for (int p = 0; p < DOFP; p++) lim[p].sign = 0.f;
     iters = 0; nwarn_add = 0; touchmask = 0ull;
+#ifdef SS_PROFILE
+    for (int i = 0; i < PF_COUNT; i++) prof[i] = 0ull;
+#endif
   }
 
   // ------------------------------------------------------------------ HBM <-> LDS
@@ -89,15 +110,21 @@ struct Sim {
   SS_DEV void store(float *dst, const float *src, int n) { for (int i = lane; i < n; i += 64) dst[i] = src[i]; }
 
   // ------------------------------------------------------------------ tree helpers
-  template <int NC>
-  SS_DEV void tree_accumulate(float *arr) {               // arr[b] += sum over descendants, in place
+  // children -> parent sums, deepest level first, in place ("pull": one lane owns one (parent, component)
+  // and adds its children, so no LDS atomics are needed — ds_add_f32 is a CU-wide serial resource on gfx950,
+  // profiles/r01c_lds_ubench.txt).  Component c < NA lives in A (stride NA), the rest in B (stride NB).
+  template <int NA, int NB>
+  SS_DEV void tree_pull(float *A, float *B) {
     const Hdr &h = k->h;
-    for (int L = h.nblev - 1; L >= 1; --L) {
-      int s = h.blevstart[L], n = (h.blevstart[L + 1] - s) * NC;
+    constexpr int NC = NA + NB;
+    for (int L = h.nblev - 2; L >= 0; --L) {
+      const int i0 = h.accp[L], n = (h.accp[L + 1] - i0) * NC;
       for (int idx = lane; idx < n; idx += 64) {
-        int bi = idx / NC, c = idx - bi * NC;
-        int b = ti(h.o_blevbodies, s + bi), p = ti(h.o_bparent, b);
-        w->atomic_add(&arr[p * NC + c], arr[b * NC + c]);
+        const int pi = idx / NC, c = idx - pi * NC;
+        const int e = ti(h.o_accp, i0 + pi), p = e & 255, cs = (e >> 8) & 4095, cc = e >> 20;
+        float acc = 0.f;
+        if (c < NA) { for (int j = 0; j < cc; j++) acc += A[ti(h.o_children, cs + j) * NA + c]; A[p * NA + c] += acc; }
+        else { for (int j = 0; j < cc; j++) acc += B[ti(h.o_children, cs + j) * NB + c - NA]; B[p * NB + c - NA] += acc; }
       }
       w->sync();
     }
@@ -278,17 +305,8 @@ struct Sim {
       }
     }
     w->sync();
-    // composite inertia and bias force C = S^T subtree(f): one fused level sweep (16 comps per body)
-    for (int L = h.nblev - 1; L >= 1; --L) {
-      int s = h.blevstart[L], n = (h.blevstart[L + 1] - s) * 16;
-      for (int idx = lane; idx < n; idx += 64) {
-        int bi = idx >> 4, c = idx & 15;
-        int b = ti(h.o_blevbodies, s + bi), p = ti(h.o_bparent, b);
-        if (c < 10) w->atomic_add(&Ic[10 * p + c], Ic[10 * b + c]);
-        else w->atomic_add(&Gb[6 * p + c - 10], Gb[6 * b + c - 10]);
-      }
-      w->sync();
-    }
+    // composite inertia and bias force C = S^T subtree(f): one fused level sweep (10 + 6 comps per body)
+    tree_pull<10, 6>(Ic, Gb);
 #pragma unroll
     for (int p = 0; p < DOFP; p++) {
       int i = p * 64 + lane;
@@ -572,26 +590,34 @@ struct Sim {
       }
       w->sync();
       if (L == 0) break;
-      {                                                      // phase 2: ancestor blocks (I >= J) -= P[:,I]^T U[:,J]
+      {                                                      // phase 2: ancestor blocks (I >= J) -= sum_k P_k[:,I]^T U_k[:,J]
         const int i0 = h.itemB[L], ni = h.itemB[L + 1] - i0;
         for (int idx = lane; idx < ni; idx += 64) {
           const int w0 = ti(h.o_itemB, 2 * (i0 + idx)), w1 = ti(h.o_itemB, 2 * (i0 + idx) + 1);
-          const float *pb = H + (w0 & 0xFFFF), *ub = U + (w0 >> 16);
-          float *dst = H + (w1 & 0xFFFF);
-          const int Wa = w1 >> 16;
-          float P_[9], U_[9];
+          float *dst = H + (w0 & 0xFFFF);
+          const int Wa = w0 >> 16, s0 = w1 & 0xFFFF, ns = w1 >> 16;
+          float acc[9];
 #pragma unroll
-          for (int r_ = 0; r_ < 3; r_++) {
+          for (int t = 0; t < 9; t++) acc[t] = 0.f;
+          for (int si = 0; si < ns; si++) {                   // the level's nodes below this ancestor block (pull)
+            const int src = ti(h.o_fsrc, s0 + si);
+            const float *pb = H + (src & 0xFFFF), *ub = U + (src >> 16);
+            float P_[9], U_[9];
 #pragma unroll
-            for (int c = 0; c < 3; c++) { P_[3 * r_ + c] = pb[r_ * Wd + c]; U_[3 * r_ + c] = ub[r_ * D + c]; }
+            for (int r_ = 0; r_ < 3; r_++) {
+#pragma unroll
+              for (int c = 0; c < 3; c++) { P_[3 * r_ + c] = pb[r_ * Wd + c]; U_[3 * r_ + c] = ub[r_ * D + c]; }
+            }
+#pragma unroll
+            for (int a_ = 0; a_ < 3; a_++) {
+#pragma unroll
+              for (int b_ = 0; b_ < 3; b_++) acc[3 * a_ + b_] += P_[a_] * U_[b_] + P_[3 + a_] * U_[3 + b_] + P_[6 + a_] * U_[6 + b_];
+            }
           }
 #pragma unroll
           for (int a_ = 0; a_ < 3; a_++) {
 #pragma unroll
-            for (int b_ = 0; b_ < 3; b_++) {
-              float val = P_[a_] * U_[b_] + P_[3 + a_] * U_[3 + b_] + P_[6 + a_] * U_[6 + b_];
-              w->atomic_add(&dst[a_ * Wa + b_], -val);
-            }
+            for (int b_ = 0; b_ < 3; b_++) dst[a_ * Wa + b_] -= acc[3 * a_ + b_];
           }
         }
       }
@@ -599,18 +625,24 @@ struct Sim {
     }
   }
 
-  // solve H x = b in place (x holds b on entry)
-  SS_DEV void solve_H(float *x) {
+  // solve H x = b in place (x holds b on entry); `tmp` = scratch for the forward sweep's partial products
+  SS_DEV void solve_H(float *x, float *tmp) {
     const Hdr &h = k->h;
-    for (int L = h.nlev - 1; L >= 1; --L) {                  // x <- L^-T x (leaves to root)
-      const int Wd = 3 * L + 3, i0 = h.itemA[L], ni = h.itemA[L + 1] - i0;
+    for (int L = h.nlev - 1; L >= 1; --L) {                  // x <- L^-T x (leaves to root), pull per ancestor node
+      const int Wd = 3 * L + 3, i0 = h.bsol[L], ni = h.bsol[L + 1] - i0;
       for (int idx = lane; idx < ni; idx += 64) {
-        const int it = ti(h.o_itemA, i0 + idx), base = it & 4095, n = (it >> 12) & 63, aJ = (it >> 18) & 63, J = (it >> 24) & 15;
-        const float *ub = H + base + 3 * J;
-        float z0 = x[3 * n], z1 = x[3 * n + 1], z2 = x[3 * n + 2];
-#pragma unroll
-        for (int c = 0; c < 3; c++)
-          w->atomic_add(&x[3 * aJ + c], -(ub[c] * z0 + ub[Wd + c] * z1 + ub[2 * Wd + c] * z2));
+        const int aJ = ti(h.o_bsol, 2 * (i0 + idx)), w1 = ti(h.o_bsol, 2 * (i0 + idx) + 1);
+        const int s0 = w1 & 0xFFFF, ns = w1 >> 16;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int si = 0; si < ns; si++) {
+          const int src = ti(h.o_bsrc, s0 + si), n = src >> 16;
+          const float *ub = H + (src & 0xFFFF);
+          const float z0 = x[3 * n], z1 = x[3 * n + 1], z2 = x[3 * n + 2];
+          a0 += ub[0] * z0 + ub[Wd] * z1 + ub[2 * Wd] * z2;
+          a1 += ub[1] * z0 + ub[Wd + 1] * z1 + ub[2 * Wd + 1] * z2;
+          a2 += ub[2] * z0 + ub[Wd + 2] * z1 + ub[2 * Wd + 2] * z2;
+        }
+        x[3 * aJ] -= a0; x[3 * aJ + 1] -= a1; x[3 * aJ + 2] -= a2;
       }
       w->sync();
     }
@@ -624,13 +656,21 @@ struct Sim {
     w->sync();
     for (int L = 1; L < h.nlev; L++) {                        // x <- L^-1 x (root to leaves)
       const int Wd = 3 * L + 3, i0 = h.itemA[L], ni = h.itemA[L + 1] - i0;
-      for (int idx = lane; idx < ni; idx += 64) {
-        const int it = ti(h.o_itemA, i0 + idx), base = it & 4095, n = (it >> 12) & 63, aJ = (it >> 18) & 63, J = (it >> 24) & 15;
+      for (int idx = lane; idx < ni; idx += 64) {             // partial products U_k[:,J] x_J, one item per (k, J)
+        const int it = ti(h.o_itemA, i0 + idx), base = it & 4095, aJ = (it >> 18) & 63, J = (it >> 24) & 15, kk = (it >> 28) & 15;
         const float *ub = H + base + 3 * J;
-        float y0 = x[3 * aJ], y1 = x[3 * aJ + 1], y2 = x[3 * aJ + 2];
+        const float y0 = x[3 * aJ], y1 = x[3 * aJ + 1], y2 = x[3 * aJ + 2];
+        float *o = tmp + (kk * L + J) * 3;
 #pragma unroll
-        for (int r_ = 0; r_ < 3; r_++)
-          w->atomic_add(&x[3 * n + r_], -(ub[r_ * Wd] * y0 + ub[r_ * Wd + 1] * y1 + ub[r_ * Wd + 2] * y2));
+        for (int r_ = 0; r_ < 3; r_++) o[r_] = ub[r_ * Wd] * y0 + ub[r_ * Wd + 1] * y1 + ub[r_ * Wd + 2] * y2;
+      }
+      w->sync();
+      const int s = h.levstart[L], nk = h.levstart[L + 1] - s;
+      for (int idx = lane; idx < 3 * nk; idx += 64) {         // one lane per (k, row): sum the L partials
+        const int kk = idx / 3, r_ = idx - 3 * kk, n = ti(h.o_levnodes, s + kk);
+        float acc = 0.f;
+        for (int J = 0; J < L; J++) acc += tmp[(kk * L + J) * 3 + r_];
+        x[3 * n + r_] -= acc;
       }
       w->sync();
     }
@@ -682,65 +722,72 @@ struct Sim {
       for (int c = 0; c < 21; c++) Kc[21 * lane + c] = 0.f;
     }
     w->sync();
-    // ---- contact forces and K_b = sum_rows D u u^T, u = (rho x w ; w)
+    // ---- contact forces and K_b = sum_rows D u u^T, u = (rho x w ; w).  The (<= 4) contacts of a box sit in
+    // 4 adjacent lanes and the 2 ends of a capsule in 2 adjacent lanes (slot layout of make_constraints), so the
+    // per-body sums are quad shuffles; the group's first lane then owns the body's row (no atomics).
     int nact = 0;
 #pragma unroll
     for (int p = 0; p < SLOTP; p++) {
       const Contact &c = con[p];
-      if (!c.active) continue;
-      float fx = 0, fy = 0, fz = 0;
-      float Wxx = 0, Wxy = 0, Wxz = 0, Wyy = 0, Wyz = 0, Wzz = 0;
+      const int sl = p * 64 + lane;
+      const bool boxlane = sl < 4 * h.nbox;
+      float vals[27];
 #pragma unroll
-      for (int r_ = 0; r_ < 4; r_++) {
-        const float sgn = (r_ & 1) ? -mu : mu;
-        const float wx = r_ < 2 ? sgn * c.t1x : -sgn * c.t1y;
-        const float wy = r_ < 2 ? sgn * c.t1y : sgn * c.t1x;
-        if (c.jar[r_] < 0.f) {
-          const float f = -c.D * c.jar[r_];
-          nact++;
-          fx += f * wx; fy += f * wy; fz += f;
-          Wxx += c.D * wx * wx; Wxy += c.D * wx * wy; Wxz += c.D * wx;
-          Wyy += c.D * wy * wy; Wyz += c.D * wy; Wzz += c.D;
+      for (int t = 0; t < 27; t++) vals[t] = 0.f;
+      if (c.active) {
+        float fx = 0, fy = 0, fz = 0;
+        float Wxx = 0, Wxy = 0, Wxz = 0, Wyy = 0, Wyz = 0, Wzz = 0;
+#pragma unroll
+        for (int r_ = 0; r_ < 4; r_++) {
+          const float sgn = (r_ & 1) ? -mu : mu;
+          const float wx = r_ < 2 ? sgn * c.t1x : -sgn * c.t1y;
+          const float wy = r_ < 2 ? sgn * c.t1y : sgn * c.t1x;
+          if (c.jar[r_] < 0.f) {
+            const float f = -c.D * c.jar[r_];
+            nact++;
+            fx += f * wx; fy += f * wy; fz += f;
+            Wxx += c.D * wx * wx; Wxy += c.D * wx * wy; Wxz += c.D * wx;
+            Wyy += c.D * wy * wy; Wyz += c.D * wy; Wzz += c.D;
+          }
         }
+        // force part: -(rho x f ; f)
+        vals[0] = -(c.ry * fz - c.rz * fy); vals[1] = -(c.rz * fx - c.rx * fz); vals[2] = -(c.rx * fy - c.ry * fx);
+        vals[3] = -fx; vals[4] = -fy; vals[5] = -fz;
+        // Y = [rho]x W (ang-lin block), Z = rows rho x Y[i,:] (ang-ang block)
+        const float Y0 = c.ry * Wxz - c.rz * Wxy, Y1 = c.ry * Wyz - c.rz * Wyy, Y2 = c.ry * Wzz - c.rz * Wyz;
+        const float Y3 = c.rz * Wxx - c.rx * Wxz, Y4 = c.rz * Wxy - c.rx * Wyz, Y5 = c.rz * Wxz - c.rx * Wzz;
+        const float Y6 = c.rx * Wxy - c.ry * Wxx, Y7 = c.rx * Wyy - c.ry * Wxy, Y8 = c.rx * Wyz - c.ry * Wxz;
+        vals[6] = c.ry * Y2 - c.rz * Y1; vals[7] = c.rz * Y0 - c.rx * Y2; vals[8] = c.rx * Y1 - c.ry * Y0;
+        vals[9] = Y0; vals[10] = Y1; vals[11] = Y2;
+        vals[12] = c.rz * Y3 - c.rx * Y5; vals[13] = c.rx * Y4 - c.ry * Y3;
+        vals[14] = Y3; vals[15] = Y4; vals[16] = Y5;
+        vals[17] = c.rx * Y7 - c.ry * Y6;
+        vals[18] = Y6; vals[19] = Y7; vals[20] = Y8;
+        vals[21] = Wxx; vals[22] = Wxy; vals[23] = Wxz; vals[24] = Wyy; vals[25] = Wyz; vals[26] = Wzz;
       }
-      if (Wzz == 0.f) continue;
-      float *g = Gb + 6 * c.body;
-      w->atomic_add(&g[0], -(c.ry * fz - c.rz * fy));
-      w->atomic_add(&g[1], -(c.rz * fx - c.rx * fz));
-      w->atomic_add(&g[2], -(c.rx * fy - c.ry * fx));
-      w->atomic_add(&g[3], -fx); w->atomic_add(&g[4], -fy); w->atomic_add(&g[5], -fz);
-      // Y = [rho]x W (ang-lin block), Z = rows rho x Y[i,:] (ang-ang block)
-      const float Y0 = c.ry * Wxz - c.rz * Wxy, Y1 = c.ry * Wyz - c.rz * Wyy, Y2 = c.ry * Wzz - c.rz * Wyz;
-      const float Y3 = c.rz * Wxx - c.rx * Wxz, Y4 = c.rz * Wxy - c.rx * Wyz, Y5 = c.rz * Wxz - c.rx * Wzz;
-      const float Y6 = c.rx * Wxy - c.ry * Wxx, Y7 = c.rx * Wyy - c.ry * Wxy, Y8 = c.rx * Wyz - c.ry * Wxz;
-      const float Z0 = c.ry * Y2 - c.rz * Y1, Z1 = c.rz * Y0 - c.rx * Y2, Z2 = c.rx * Y1 - c.ry * Y0;
-      const float Z4 = c.rz * Y3 - c.rx * Y5, Z5 = c.rx * Y4 - c.ry * Y3;
-      const float Z8 = c.rx * Y7 - c.ry * Y6;
-      float *Kb = Kc + 21 * c.body;
-      w->atomic_add(&Kb[0], Z0); w->atomic_add(&Kb[1], Z1); w->atomic_add(&Kb[2], Z2);
-      w->atomic_add(&Kb[3], Y0); w->atomic_add(&Kb[4], Y1); w->atomic_add(&Kb[5], Y2);
-      w->atomic_add(&Kb[6], Z4); w->atomic_add(&Kb[7], Z5);
-      w->atomic_add(&Kb[8], Y3); w->atomic_add(&Kb[9], Y4); w->atomic_add(&Kb[10], Y5);
-      w->atomic_add(&Kb[11], Z8);
-      w->atomic_add(&Kb[12], Y6); w->atomic_add(&Kb[13], Y7); w->atomic_add(&Kb[14], Y8);
-      w->atomic_add(&Kb[15], Wxx); w->atomic_add(&Kb[16], Wxy); w->atomic_add(&Kb[17], Wxz);
-      w->atomic_add(&Kb[18], Wyy); w->atomic_add(&Kb[19], Wyz); w->atomic_add(&Kb[20], Wzz);
+      // group sums: xor 1 (pairs), then xor 2 for box quads
+#pragma unroll
+      for (int t = 0; t < 27; t++) {
+        float v1 = vals[t] + w->shfl_xor(vals[t], 1);
+        float v2 = w->shfl_xor(v1, 2);
+        vals[t] = boxlane ? v1 + v2 : v1;
+      }
+      const int grp_any = w->shfl_xor_i(c.active, 1) | c.active;
+      const int grp_any2 = w->shfl_xor_i(grp_any, 2) | grp_any;
+      const int body_of_group = boxlane ? h_box_body(sl) : h_caps_body(sl);
+      const bool leader = boxlane ? ((sl & 3) == 0 && grp_any2) : ((sl & 1) == 0 && grp_any);
+      if (leader && sl < h.nslot) {
+        float *g = Gb + 6 * body_of_group, *Kb = Kc + 21 * body_of_group;
+#pragma unroll
+        for (int t = 0; t < 6; t++) g[t] += vals[t];
+#pragma unroll
+        for (int t = 0; t < 21; t++) Kb[t] = vals[6 + t];
+      }
     }
     w->sync();
     const bool any_contact_row = w->any(nact > 0);
     // ---- subtree sums of Gb (6) and, when any contact row is active, Kc (21)
-    const int ncomp = any_contact_row ? 27 : 6;
-    for (int L = h.nblev - 1; L >= 1; --L) {
-      const int s = h.blevstart[L], n = (h.blevstart[L + 1] - s) * ncomp;
-      const float rn = 1.0f / (float)ncomp;
-      for (int idx = lane; idx < n; idx += 64) {
-        int bi = (int)(((float)idx + 0.5f) * rn), c = idx - bi * ncomp;
-        int b = ti(h.o_blevbodies, s + bi), p = ti(h.o_bparent, b);
-        if (c < 6) w->atomic_add(&Gb[6 * p + c], Gb[6 * b + c]);
-        else w->atomic_add(&Kc[21 * p + c - 6], Kc[21 * b + c - 6]);
-      }
-      w->sync();
-    }
+    if (any_contact_row) tree_pull<6, 21>(Gb, Kc); else tree_pull<6, 0>(Gb, Kc);
     // ---- gradient and diagonal terms
 #pragma unroll
     for (int p = 0; p < DOFP; p++) {
@@ -1077,6 +1124,7 @@ SS_DEV void run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env) 
   // pass sequence: [PROLOGUE] SUBSTEP*nsub [RESETFWD | FINAL]
   int s = (nsub > 0 && !is_debug) ? -1 : 0;
   const int last_kind = mode == MODE_RESET ? K_RESETFWD : ((mode == MODE_STEP || mode == MODE_KINEMATICS) ? K_FINAL : -1);
+  SS_T0();
   for (;;) {
     // opaque(): keeps the optimizer from jump-threading the state variables (it would clone every stage per state)
     const int kind = w->opaque(s < 0 ? K_PROLOGUE : (s < nsub ? K_SUBSTEP : last_kind));
@@ -1086,9 +1134,12 @@ SS_DEV void run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env) 
       if (s == nsub - 1) { sim.store(qpg, sim.q, h.nq); sim.store(vpg, sim.v, h.nv); }   // stale source of the next launch
     }
     // the env reads the sensors of the LAST forward only: write them on the last mj_step / the reset forward
+    SS_TICK(PF_MISC);
     sim.forward_kin(kind != K_FINAL, kind == K_RESETFWD || (kind == K_SUBSTEP && s == nsub - 1));
+    SS_TICK(PF_FWD);
     if (kind == K_FINAL) break;
     if (kind == K_SUBSTEP || kind == K_RESETFWD) sim.make_constraints();
+    SS_TICK(PF_CONS);
     if (kind == K_RESETFWD) break;
     int solve = SOLVE_SPD;
     const float *next_action = nullptr;
@@ -1098,6 +1149,7 @@ SS_DEV void run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env) 
       next_action = (mode == MODE_RESET) ? fa : act;
     } else {
       sim.newton_begin();
+      SS_TICK(PF_NBEGIN);
       solve = is_debug ? SOLVE_DUMP_M : SOLVE_NEWTON;
       if (s + 1 < nsub) next_action = (mode == MODE_RESET) ? fa + (size_t)((s + 1) / cf.control_freq_inv) * h.nu : act;
     }
@@ -1105,16 +1157,18 @@ SS_DEV void run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env) 
     int it = 0;
     for (;;) {                                               // solver loop: one assemble/factor/solve site
       solve = w->opaque(solve);
-      if (solve == SOLVE_NEWTON) sim.newton_prepare();
+      if (solve == SOLVE_NEWTON) { sim.newton_prepare(); SS_TICK(PF_NPREP); }
       else if (solve == SOLVE_SPD) {
         if (cf.control_mode != SS_CTRL_UHC_PD) { sim.simple_controller(next_action, abias); break; }
         sim.spd_prepare(next_action, abias);
+        SS_TICK(PF_SPDPREP);
       } else {                                               // plain mass matrix for the diagnostics dump
         if (lane < h.nb) for (int c = 0; c < 21; c++) sim.Kc[21 * lane + c] = 0.f;
         for (int i = lane; i < h.nv; i += 64) sim.diag[i] = sim.dc(i, 0);
         w->sync();
       }
       sim.assemble_H();
+      SS_TICK(PF_ASM);
       if (solve == SOLVE_DUMP_M) {
         sim.store(k->out0 + (size_t)env * h.ne, sim.H, h.ne); sim.store(k->out1 + (size_t)env * h.nv, sim.C, h.nv);
         w->sync();
@@ -1122,13 +1176,17 @@ SS_DEV void run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env) 
         continue;
       }
       sim.factor_H();
-      sim.solve_H(sim.delta);
-      if (solve == SOLVE_SPD) { sim.spd_finish(); break; }
+      SS_TICK(PF_FACTOR);
+      sim.solve_H(sim.delta, sim.G);
+      SS_TICK(PF_SOLVE);
+      if (solve == SOLVE_SPD) { sim.spd_finish(); SS_TICK(PF_SPDFIN); break; }
       const bool conv = sim.newton_finish();
+      SS_TICK(PF_NFIN);
       if (!conv && ++it < maxit) continue;
       if (is_debug) break;
       if (sim.any_bad(sim.a, h.nv)) { sim.reset_data(); redo = true; break; }        // mj_checkAcc -> autoreset
       sim.integrate();
+      SS_TICK(PF_INTEG);
       if (!next_action) break;
       solve = SOLVE_SPD;
     }
@@ -1136,6 +1194,9 @@ SS_DEV void run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env) 
     if (is_debug) break;
   }
 
+#ifdef SS_PROFILE
+  if (lane == 0 && k->prof) for (int i = 0; i < PF_COUNT; i++) w->atomic_add_u64(k->prof + i, sim.prof[i]);
+#endif
   if (mode == MODE_KINEMATICS) {
     if (lane < h.nb) {
       for (int c = 0; c < 3; c++) k->out0[((size_t)env * h.nb + lane) * 3 + c] = sim.r[3 * lane + c] + sim.q[c];

@@ -193,7 +193,7 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   //  blk   (assemble)           w0 = aJ | n<<8 | diag<<16      w1 = (base_n + 3J) | Wd<<16
   //  itemA (U=Dinv P, copy, triangular sweeps), per level: base_k(12) | n(6)<<12 | aJ(6)<<18 | J(4)<<24 | kk(4)<<28
   //  itemB (ancestor block update), per level:  w0 = (base_k + 3I) | (kk*3*D + 3J)<<16   w1 = (base_aI + 3J) | Wa<<16
-  std::vector<int> blk, itemA, itemB;
+  std::vector<int> blk, itemA, itemB, fsrc, bsol, bsrc, accp, children;
   for (int n = 0; n < nn; n++) for (int J = 0; J <= ndepth[n]; J++) {
     int aJ = chainnode[n * CN + J], Wd = 3 * ndepth[n] + 3;
     blk.push_back(aJ | (n << 8) | ((aJ == n) << 16));
@@ -211,15 +211,58 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
         itemA.push_back(nbase[n] | (n << 12) | (aJ << 18) | (J << 24) | (kk << 28));
       }
     }
-    for (int kk = 0; kk < nk; kk++) {
-      int n = levnodes[levstart[L] + kk];
-      for (int I = 0; I < L; I++) for (int J = 0; J <= I; J++) {
-        int aI = chainnode[n * CN + I], Wa = 3 * I + 3;
-        itemB.push_back((nbase[n] + 3 * I) | ((kk * 3 * D + 3 * J) << 16));
-        itemB.push_back((nbase[aI] + 3 * J) | (Wa << 16));
+    // itemB, pull form: one item per distinct target block (aI, J); its sources are the level-L nodes below aI
+    //   w0 = (base_aI + 3J) | Wa<<16     w1 = src_start | nsrc<<16     fsrc: (base_k + 3I) | (kk*3*D + 3J)<<16
+    for (int I = 0; I < L; I++) for (int J = 0; J <= I; J++) {
+      std::vector<int> seen;
+      for (int kk = 0; kk < nk; kk++) {
+        int aI = chainnode[levnodes[levstart[L] + kk] * CN + I];
+        bool dup = false; for (int a : seen) dup |= (a == aI);
+        if (dup) continue;
+        seen.push_back(aI);
+        int start = (int)fsrc.size(), cnt = 0;
+        for (int k2 = 0; k2 < nk; k2++) {
+          int n2 = levnodes[levstart[L] + k2];
+          if (chainnode[n2 * CN + I] != aI) continue;
+          fsrc.push_back((nbase[n2] + 3 * I) | ((k2 * 3 * D + 3 * J) << 16)); cnt++;
+        }
+        itemB.push_back((nbase[aI] + 3 * J) | ((3 * I + 3) << 16));
+        itemB.push_back(start | (cnt << 16));
+      }
+    }
+    // backward-solve targets: one per distinct ancestor node of the level's nodes
+    //   w0 = aJ      w1 = src_start | nsrc<<16      bsrc: (base_k + 3J) | n_k<<16
+    h.bsol[L] = (int)bsol.size() / 2;
+    for (int J = 0; J < L; J++) {
+      std::vector<int> seen;
+      for (int kk = 0; kk < nk; kk++) {
+        int aJ = chainnode[levnodes[levstart[L] + kk] * CN + J];
+        bool dup = false; for (int a : seen) dup |= (a == aJ);
+        if (dup) continue;
+        seen.push_back(aJ);
+        int start = (int)bsrc.size(), cnt = 0;
+        for (int k2 = 0; k2 < nk; k2++) {
+          int n2 = levnodes[levstart[L] + k2];
+          if (chainnode[n2 * CN + J] != aJ) continue;
+          bsrc.push_back((nbase[n2] + 3 * J) | (n2 << 16)); cnt++;
+        }
+        bsol.push_back(aJ); bsol.push_back(start | (cnt << 16));
       }
     }
   }
+  h.bsol[nlev] = (int)bsol.size() / 2;
+  if (fsrc.size() > 65535 || bsrc.size() > 65535) { out.error = "source tables too large"; return false; }
+  // tree accumulation (children -> parent), pull form, per body level: p | cstart<<8 | ccount<<20
+  for (int L = 0; L < nblev; L++) {
+    h.accp[L] = (int)accp.size();
+    for (int b = 0; b < nb; b++) {
+      if (bdepth[b] != L) continue;
+      int start = (int)children.size(), cnt = 0;
+      for (int c = 0; c < nb; c++) if (d.body_parent[c] == b) { children.push_back(c); cnt++; }
+      if (cnt) accp.push_back(b | (start << 8) | (cnt << 20));
+    }
+  }
+  h.accp[nblev] = (int)accp.size();
   h.itemA[nlev] = (int)itemA.size(); h.itemB[nlev] = (int)itemB.size() / 2;
   out.decode = decode;
   auto &S = out.shared; S.clear();
@@ -235,6 +278,11 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   h.o_blk = push_i(blk);
   h.o_itemA = push_i(itemA);
   h.o_itemB = push_i(itemB);
+  h.o_fsrc = push_i(fsrc);
+  h.o_accp = push_i(accp);
+  h.o_children = push_i(children);
+  h.o_bsol = push_i(bsol);
+  h.o_bsrc = push_i(bsrc);
   h.shared_words = (int)S.size();
   (void)chainrow; (void)nparent;
 

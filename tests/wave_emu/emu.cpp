@@ -154,8 +154,24 @@ struct WaveEmu {
     arrive(7);
     return r;
   }
+  float shfl_xor(float v, int mask) {
+    m->fx[ln] = v;
+    arrive(8);
+    float r = m->fx[ln ^ mask];
+    arrive(9);
+    return r;
+  }
+  int shfl_xor_i(int v, int mask) {
+    m->ux[ln] = (unsigned long long)(unsigned)v;
+    arrive(10);
+    int r = (int)(unsigned)m->ux[ln ^ mask];
+    arrive(11);
+    return r;
+  }
   bool any(int p) { return ballot(p) != 0ull; }
   int opaque(int x) { volatile int y = x; return y; }
+  unsigned long long clock() { return 0; }
+  void atomic_add_u64(unsigned long long *p, unsigned long long v) { *p += v; }
   void atomic_add(float *p, float v) { *p += v; }
 };
 
@@ -173,6 +189,7 @@ struct EmuBackend {
   static void free_(void *p) { free(p); }
   static bool upload(void *dst, const void *src, size_t n) { memcpy(dst, src, n); return true; }
   static bool set_device(int) { return true; }
+  static bool download(void *dst, const void *src, size_t n) { memcpy(dst, src, n); return true; }
   static int lds_capacity() { return 160 * 1024; }
   static int kernel_regs() { return 0; }
   static const char *launch(const ss::KArgs &k, int nenv, int envs_per_wg, size_t lds_bytes, void *) {

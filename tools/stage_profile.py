@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""In-kernel stage timing: builds a -DSS_PROFILE variant of the library on the GPU box, runs the bench
+workload for a few steps and prints shader-clock ticks per stage (summed over all waves, and per mj_step)."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+from smplsim_amd import _cabi, _lib
+
+prof_so = os.path.join(ROOT, "gpurun_out", "libsmplsim_hip_prof.so")
+os.makedirs(os.path.dirname(prof_so), exist_ok=True)
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DSS_PROFILE",
+                       os.path.join(_lib.SRC_DIR, "smplsim_hip.hip"), "-o", prof_so])
+_lib._LIB = _cabi.bind(C.CDLL(prof_so))
+from smplsim_amd.batch import SMPLSimVecEnv
+
+N, steps = 4096, int(os.environ.get("STEPS", "30"))
+env = SMPLSimVecEnv(N, autoreset=True, seed=1234)
+g = torch.Generator(device=env.device); g.manual_seed(1234)
+env.reset()
+for _ in range(steps):
+    env.step(torch.rand(N, 69, generator=g, device=env.device) * 2 - 1)
+torch.cuda.synchronize()
+out = (C.c_ulonglong * 64)()
+rc = _lib.lib().ss_debug_prof(env.handle, out, 16)
+names = ["fwd_kin", "constraints", "newton_begin", "newton_prepare", "assemble", "factor", "solve", "newton_finish",
+         "spd_prepare", "spd_finish", "integrate", "misc"]
+tot = sum(out[i] for i in range(12))
+iters = float(env.solver_iters.float().mean().item())
+res = {"rc": rc, "total_ticks": tot, "mean_newton_iters": iters, "stages": {}}
+nsub = N * (steps + 0) * 15
+for i, nm in enumerate(names):
+    res["stages"][nm] = {"pct": 100.0 * out[i] / tot, "ticks_per_mj_step_per_wave": out[i] / nsub}
+print(json.dumps(res, indent=1))
+json.dump(res, open(os.path.join(ROOT, "gpurun_out", "stage_profile.json"), "w"), indent=1)
