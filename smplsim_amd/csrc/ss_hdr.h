@@ -19,7 +19,7 @@ struct Hdr {
   int itemA[20], itemB[20];          // per-level offsets into the packed work-item tables
   int accp[20], bsol[20];            // per-level offsets: tree-accumulation parents, backward-solve targets
   // shared-blob word offsets
-  int o_dofc, o_chainnode, o_nbase, o_ndepth, o_levnodes, o_bparent, o_blevbodies, o_blk, o_itemA, o_itemB, o_fsrc, o_accp, o_children, o_bsol, o_bsrc, shared_words;
+  int o_dofc, o_chainnode, o_nbase, o_ndepth, o_levnodes, o_bparent, o_blevbodies, o_blk, o_itemA, o_itemB, o_fsrc, o_accp, o_children, o_bsol, o_bsrc, o_subsize, shared_words;   // o_bsrc: (kk*3*D + 3J) | n_k<<16 into the U buffer
   // per-env LDS float offsets
   int l_H, l_S, l_G, l_Dinv, l_R, l_r, l_Ic, l_K, l_V, l_Ab, l_Ad, l_Gb, l_q, l_v, l_a, l_tau, l_grad,
       l_delta, l_C, l_diag, l_misc, env_floats;

@@ -130,6 +130,19 @@ struct Sim {
     }
   }
 
+  // out[b][c] = sum of in[d][c] over the subtree of b = the contiguous index range [b, b + size_b) (depth-first
+  // body order): one phase of independent LDS reads instead of a level-by-level sweep.
+  template <int NC>
+  SS_DEV void subtree_sum(const float *in, float *out) {
+    const Hdr &h = k->h;
+    for (int idx = lane; idx < NC * h.nb; idx += 64) {
+      const int b = idx / NC, c = idx - b * NC, n = ti(h.o_subsize, b);
+      float acc = 0.f;
+      for (int j = 0; j < n; j++) acc += in[(b + j) * NC + c];
+      out[idx] = acc;
+    }
+  }
+
   // A[b] = sum over the dofs d on the chain of body b of S[d] * x[d]   (spatial accel without bias).
   // Two stages: per-node contributions c_n = S[3n..3n+2] x[3n..3n+2] (into `tmp`, 6 floats per node),
   // then each (body, component) adds the <= depth+1 node contributions along its chain.
@@ -282,7 +295,7 @@ struct Sim {
       Ib[4] = Ixx + m * (cy_ * cy_ + cz_ * cz_); Ib[5] = Ixy - m * cx_ * cy_; Ib[6] = Ixz - m * cx_ * cz_;
       Ib[7] = Iyy + m * (cx_ * cx_ + cz_ * cz_); Ib[8] = Iyz - m * cy_ * cz_; Ib[9] = Izz + m * (cx_ * cx_ + cy_ * cy_);
 #pragma unroll
-      for (int i = 0; i < 10; i++) Ic[10 * b + i] = Ib[i];
+      for (int i = 0; i < 10; i++) Kc[10 * b + i] = Ib[i];    // Kc is free here: input of the composite-inertia sums
       // f = I (a - a_grav) + v x* (I v)
       float ag[6] = {ab[0], ab[1], ab[2], ab[3], ab[4], ab[5] - h.grav};
       float Ia[6], Iv[6], fb[6];
@@ -294,7 +307,7 @@ struct Sim {
       fb[4] = Ia[4] + vb[2] * Iv[3] - vb[0] * Iv[5];
       fb[5] = Ia[5] + vb[0] * Iv[4] - vb[1] * Iv[3];
 #pragma unroll
-      for (int c = 0; c < 6; c++) Gb[6 * b + c] = fb[c];
+      for (int c = 0; c < 6; c++) Ad[6 * b + c] = fb[c];     // Ad (bias-accel scratch of the sweep) is free again
       // framelinvel / frameangvel of the body frame origin (the env reads the LAST forward's values)
       if (write_sensors) {
         float *svo = k->st.body_vel + ((size_t)env * h.nb + b) * 6;
@@ -305,8 +318,10 @@ struct Sim {
       }
     }
     w->sync();
-    // composite inertia and bias force C = S^T subtree(f): one fused level sweep (10 + 6 comps per body)
-    tree_pull<10, 6>(Ic, Gb);
+    // composite inertia Ic and subtree bias force Gb (C = S^T Gb): subtree range sums, one phase
+    subtree_sum<10>(Kc, Ic);
+    subtree_sum<6>(Ad, Gb);
+    w->sync();
 #pragma unroll
     for (int p = 0; p < DOFP; p++) {
       int i = p * 64 + lane;
@@ -542,7 +557,9 @@ struct Sim {
   //   phase 2  ancestor blocks (I >= J) -= P_k[:,I]^T U_k[:,J]      (LDS float atomics: nodes of one
   //            level in different branches update the same ancestor blocks)
   //   phase 3  P_k <- U_k (rows of L)
-  SS_DEV void factor_H() {
+  // also applies x <- L^-T x (the leaves-to-root sweep of the solve) level by level: at level L the entries of the
+  // level's nodes are final, and U_k is at hand in the U buffer
+  SS_DEV void factor_H(float *x) {
     const Hdr &h = k->h;
     // U is double-buffered in G (free between assembly and the next one) so that "P_k <- U_k" of level L+1
     // shares a phase with "U = Dinv P" of level L
@@ -620,32 +637,30 @@ struct Sim {
             for (int b_ = 0; b_ < 3; b_++) dst[a_ * Wa + b_] -= acc[3 * a_ + b_];
           }
         }
+        const int j0 = h.bsol[L], nj = h.bsol[L + 1] - j0;    // x_anc -= sum_k U_k[:,J]^T x_k   (pull per ancestor node)
+        for (int idx = lane; idx < nj; idx += 64) {
+          const int aJ = ti(h.o_bsol, 2 * (j0 + idx)), w1 = ti(h.o_bsol, 2 * (j0 + idx) + 1);
+          const int s0 = w1 & 0xFFFF, ns = w1 >> 16;
+          float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+          for (int si = 0; si < ns; si++) {
+            const int src = ti(h.o_bsrc, s0 + si), n = src >> 16;
+            const float *ub = U + (src & 0xFFFF);
+            const float z0 = x[3 * n], z1 = x[3 * n + 1], z2 = x[3 * n + 2];
+            a0 += ub[0] * z0 + ub[D] * z1 + ub[2 * D] * z2;
+            a1 += ub[1] * z0 + ub[D + 1] * z1 + ub[2 * D + 1] * z2;
+            a2 += ub[2] * z0 + ub[D + 2] * z1 + ub[2 * D + 2] * z2;
+          }
+          x[3 * aJ] -= a0; x[3 * aJ + 1] -= a1; x[3 * aJ + 2] -= a2;
+        }
       }
       w->sync();
     }
   }
 
-  // solve H x = b in place (x holds b on entry); `tmp` = scratch for the forward sweep's partial products
+  // finish H x = b after factor_H(x): x <- L^-1 D^-1 x; `tmp` = scratch for the forward sweep's partial products
   SS_DEV void solve_H(float *x, float *tmp) {
     const Hdr &h = k->h;
-    for (int L = h.nlev - 1; L >= 1; --L) {                  // x <- L^-T x (leaves to root), pull per ancestor node
-      const int Wd = 3 * L + 3, i0 = h.bsol[L], ni = h.bsol[L + 1] - i0;
-      for (int idx = lane; idx < ni; idx += 64) {
-        const int aJ = ti(h.o_bsol, 2 * (i0 + idx)), w1 = ti(h.o_bsol, 2 * (i0 + idx) + 1);
-        const int s0 = w1 & 0xFFFF, ns = w1 >> 16;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-        for (int si = 0; si < ns; si++) {
-          const int src = ti(h.o_bsrc, s0 + si), n = src >> 16;
-          const float *ub = H + (src & 0xFFFF);
-          const float z0 = x[3 * n], z1 = x[3 * n + 1], z2 = x[3 * n + 2];
-          a0 += ub[0] * z0 + ub[Wd] * z1 + ub[2 * Wd] * z2;
-          a1 += ub[1] * z0 + ub[Wd + 1] * z1 + ub[2 * Wd + 1] * z2;
-          a2 += ub[2] * z0 + ub[Wd + 2] * z1 + ub[2 * Wd + 2] * z2;
-        }
-        x[3 * aJ] -= a0; x[3 * aJ + 1] -= a1; x[3 * aJ + 2] -= a2;
-      }
-      w->sync();
-    }
+    // (x <- L^-T x was applied inside factor_H)
     if (lane < h.nn) {                                        // x <- D^-1 x
       const float *o = Dinv + 6 * lane;
       float x0 = x[3 * lane], x1 = x[3 * lane + 1], x2 = x[3 * lane + 2];
@@ -717,9 +732,9 @@ struct Sim {
       float Ia[6];
       imul(Ib, Ab + 6 * lane, Ia);
 #pragma unroll
-      for (int c = 0; c < 6; c++) Gb[6 * lane + c] = Ia[c];
+      for (int c = 0; c < 6; c++) Ad[6 * lane + c] = Ia[c];    // per-body terms go to scratch (Ad, H), subtree sums to Gb, Kc
 #pragma unroll
-      for (int c = 0; c < 21; c++) Kc[21 * lane + c] = 0.f;
+      for (int c = 0; c < 21; c++) H[21 * lane + c] = 0.f;
     }
     w->sync();
     // ---- contact forces and K_b = sum_rows D u u^T, u = (rho x w ; w).  The (<= 4) contacts of a box sit in
@@ -777,7 +792,7 @@ struct Sim {
       const int body_of_group = boxlane ? h_box_body(sl) : h_caps_body(sl);
       const bool leader = boxlane ? ((sl & 3) == 0 && grp_any2) : ((sl & 1) == 0 && grp_any);
       if (leader && sl < h.nslot) {
-        float *g = Gb + 6 * body_of_group, *Kb = Kc + 21 * body_of_group;
+        float *g = Ad + 6 * body_of_group, *Kb = H + 21 * body_of_group;
 #pragma unroll
         for (int t = 0; t < 6; t++) g[t] += vals[t];
 #pragma unroll
@@ -787,7 +802,13 @@ struct Sim {
     w->sync();
     const bool any_contact_row = w->any(nact > 0);
     // ---- subtree sums of Gb (6) and, when any contact row is active, Kc (21)
-    if (any_contact_row) tree_pull<6, 21>(Gb, Kc); else tree_pull<6, 0>(Gb, Kc);
+    subtree_sum<6>(Ad, Gb);
+    if (any_contact_row) subtree_sum<21>(H, Kc);
+    else if (lane < h.nb) {
+#pragma unroll
+      for (int c = 0; c < 21; c++) Kc[21 * lane + c] = 0.f;
+    }
+    w->sync();
     // ---- gradient and diagonal terms
 #pragma unroll
     for (int p = 0; p < DOFP; p++) {
@@ -1175,7 +1196,7 @@ SS_DEV void run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env) 
         solve = SOLVE_NEWTON;
         continue;
       }
-      sim.factor_H();
+      sim.factor_H(sim.delta);
       SS_TICK(PF_FACTOR);
       sim.solve_H(sim.delta, sim.G);
       SS_TICK(PF_SOLVE);

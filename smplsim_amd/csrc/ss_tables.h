@@ -231,7 +231,7 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
       }
     }
     // backward-solve targets: one per distinct ancestor node of the level's nodes
-    //   w0 = aJ      w1 = src_start | nsrc<<16      bsrc: (base_k + 3J) | n_k<<16
+    //   w0 = aJ      w1 = src_start | nsrc<<16      bsrc: (kk*3*D + 3J) | n_k<<16   (U buffer offset, node)
     h.bsol[L] = (int)bsol.size() / 2;
     for (int J = 0; J < L; J++) {
       std::vector<int> seen;
@@ -244,7 +244,7 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
         for (int k2 = 0; k2 < nk; k2++) {
           int n2 = levnodes[levstart[L] + k2];
           if (chainnode[n2 * CN + J] != aJ) continue;
-          bsrc.push_back((nbase[n2] + 3 * J) | (n2 << 16)); cnt++;
+          bsrc.push_back((k2 * 3 * D + 3 * J) | (n2 << 16)); cnt++;       // U-buffer offset of U_k[:, J], node of z_k
         }
         bsol.push_back(aJ); bsol.push_back(start | (cnt << 16));
       }
@@ -283,6 +283,18 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   h.o_children = push_i(children);
   h.o_bsol = push_i(bsol);
   h.o_bsrc = push_i(bsrc);
+  {
+    // subtree sizes: bodies are in depth-first order, so the subtree of b is the index range [b, b + size)
+    std::vector<int> subsize(nb, 1);
+    for (int b = nb - 1; b >= 1; b--) subsize[d.body_parent[b]] += subsize[b];
+    for (int b = 0; b < nb; b++) {
+      for (int c = b + 1; c < b + subsize[b]; c++) {
+        int a = c; while (a > b) a = d.body_parent[a];
+        if (a != b) { out.error = "bodies must be in depth-first order"; return false; }
+      }
+    }
+    h.o_subsize = push_i(subsize);
+  }
   h.shared_words = (int)S.size();
   (void)chainrow; (void)nparent;
 
