@@ -22,6 +22,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ENVS_PER_GPU = 4096
+WORKLOADS = {
+    "smpl": "BASELINE config 2: {N} SMPL humanoids per GPU (24 bodies, nv=75), flat ground, Stable-PD, fresh uniform(-1,1) "
+            "actions per control step, 15 mj_steps @450 Hz per step, obs v1 (289 f32) + reward + reset flags fused, "
+            "device-side autoreset",
+    "getup": "BASELINE config 3 shard: {N} SMPL humanoids, env=getup (obs 290, height reward, contact termination, 60-step "
+             "recovery), StateInit.Fall (45 warm-up mj_steps per reset), uniform(-1,1) actions; kernel_ms includes the masked reset launch",
+    "smplx": "BASELINE config 4: {N} SMPL-X/H-layout humanoids (52 bodies, nv=159, nu=153), base env, obs v1 (625 f32), uniform(-1,1) actions",
+}
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -30,35 +38,46 @@ def algorithmic_bytes(nq, nv, nu, nobs):
     return 4 * (2 * nq + 2 * nv + nu + nobs + 1) + 2
 
 
+def usable_cores():
+    """Cores this process may really use: sched affinity capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(seconds=12.0):
     """The CPU oracle (float64 C restatement; 'port', NOT MuJoCo — MuJoCo is not installable here) on the
     host cores, same workload shape, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import oracle_model
     from oracle import oracle as O
-    cores = len(os.sched_getaffinity(0))
+    cores = usable_cores()
     om = oracle_model()
+    rs = np.random.default_rng(1234)
+    # single-thread rate first (short), then all usable cores on a sample sized for ~`seconds`
+    e1 = [O.OracleEnv(om)]
+    e1[0].reset()
+    t0 = time.perf_counter()
+    O.batch_rollout(e1, rs.uniform(-1, 1, (40, 1, 69)), 1)
+    rate1 = 40 / (time.perf_counter() - t0)
     nenv = cores * 4
     envs = [O.OracleEnv(om) for _ in range(nenv)]
     for e in envs:
         e.reset()
-    rs = np.random.default_rng(1234)
-    steps = 8
-    acts = rs.uniform(-1, 1, (steps, nenv, 69))
-    t0 = time.perf_counter()
-    done = O.batch_rollout(envs, acts, cores)
-    dt = time.perf_counter() - t0
-    rate = done / dt
-    # scale the sample to ~`seconds` of CPU work
-    steps2 = max(steps, int(steps * seconds / max(dt, 1e-3)))
-    steps2 = min(steps2, 400)
+    steps2 = int(max(8, min(400, seconds * rate1 * cores / nenv)))
     acts = rs.uniform(-1, 1, (steps2, nenv, 69))
     t0 = time.perf_counter()
     done = O.batch_rollout(envs, acts, cores)
     dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "single_thread_value": rate1,
             "sample": f"{nenv} envs x {steps2} control steps, uniform(-1,1) actions, float64 C oracle "
-                      f"(oracle/oracle.c), one env per thread-slice over {cores} threads, {dt:.1f}s"}
+                      f"(oracle/oracle.c; NOT MuJoCo), {cores} threads (cgroup/affinity-usable cores), {dt:.1f}s"}
 
 
 def main():
@@ -68,6 +87,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="smpl", choices=["smpl", "getup", "smplx"],
+                    help="smpl = BASELINE config 2 (the metric); getup = config 3 shard (Fall init, getup task); smplx = config 4")
     args = ap.parse_args()
 
     import torch
@@ -79,8 +100,16 @@ def main():
 
     from smplsim_amd.batch import SMPLSimVecEnv
     N = args.envs_per_gpu
-    env = SMPLSimVecEnv(N, device=local_rank, task="HumanoidEnv", state_init="Default", self_obs_v=1,
-                        autoreset=True, seed=shard.shard_seed(1234, rank))
+    if args.workload == "smpl":
+        env = SMPLSimVecEnv(N, device=local_rank, task="HumanoidEnv", state_init="Default", self_obs_v=1,
+                            autoreset=True, seed=shard.shard_seed(1234, rank))
+    elif args.workload == "getup":
+        env = SMPLSimVecEnv(N, device=local_rank, task="HumanoidGetup", state_init="Fall", self_obs_v=1,
+                            autoreset=True, seed=shard.shard_seed(1234, rank))
+    else:
+        from smplsim_amd.batch import ShardModel
+        env = SMPLSimVecEnv(N, model=ShardModel(humanoid="smplx_humanoid", device=local_rank), task="HumanoidEnv",
+                            state_init="Default", self_obs_v=1, autoreset=True, seed=shard.shard_seed(1234, rank))
     g = torch.Generator(device=dev)
     g.manual_seed(shard.shard_seed(1234, rank))
     env.reset()
@@ -104,12 +133,17 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         a = torch.rand(N, env.nu, generator=g, device=dev) * 2 - 1
-        ev0[i].record()
-        _check(lib().ss_step(env.handle, _ptr(a), None, _ptr(env.obs_buf), _ptr(env.rew_buf), _ptr(env.terminated),
-                             _ptr(env.truncated), env._stream()))
-        ev1[i].record()
-        torch.bitwise_or(env.terminated, env.truncated, out=env.reset_buf)
-        _check(lib().ss_reset(env.handle, _ptr(env.reset_buf), None, None, _ptr(env.obs_buf), env._stream()))
+        if args.workload == "smpl":
+            ev0[i].record()
+            _check(lib().ss_step(env.handle, _ptr(a), None, _ptr(env.obs_buf), _ptr(env.rew_buf), _ptr(env.terminated),
+                                 _ptr(env.truncated), env._stream()))
+            ev1[i].record()
+            torch.bitwise_or(env.terminated, env.truncated, out=env.reset_buf)
+            _check(lib().ss_reset(env.handle, _ptr(env.reset_buf), None, None, _ptr(env.obs_buf), env._stream()))
+        else:
+            ev0[i].record()
+            env.step(a)                                     # step + masked autoreset (Fall warm-up / task targets)
+            ev1[i].record()
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = shard.max_over_ranks(dist, world, elapsed, dev)
@@ -129,9 +163,7 @@ def main():
             "metric": "env-steps/sec (whole node), 4096-env SMPL rollout", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE config 2: {N} SMPL humanoids per GPU (24 bodies, nv=75), flat ground, "
-                                   "Stable-PD, fresh uniform(-1,1) actions per control step, 15 mj_steps @450 Hz per "
-                                   "step, obs v1 (289 f32) + reward + reset flags fused, device-side autoreset",
+            "config": {"workload": WORKLOADS[args.workload].format(N=N),
                        "envs_per_gpu": N, "parallelism": f"independent shards x{world} (no collective)",
                        "launch": env.launch_info(), "mean_newton_iters_per_step": iters, "newton_iters_p50_p99_max": [it_p50, it_p99, it_max], "autoresets_total": nwarn,
                        "obs_finite": finite},

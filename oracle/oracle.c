@@ -145,7 +145,7 @@ struct om_data {
   int touch[OM_MAXB];
   int nefc, maxrow;
   double *J, *epos, *emargin, *ediag, *eD, *eR, *earef, *eforce, *ejar, *ejd;
-  double *H, *work;                            /* nv x nv each */
+  double *H, *work, *work2;                    /* nv x nv each */
   int solver_iter, nwarn;
 };
 
@@ -303,6 +303,7 @@ om_data *om_data_create(const om_model *m) {
   d->M = (double *)calloc((size_t)nv * nv, sizeof(double));
   d->H = (double *)calloc((size_t)nv * nv, sizeof(double));
   d->work = (double *)calloc((size_t)nv * nv, sizeof(double));
+  d->work2 = (double *)calloc((size_t)nv * nv, sizeof(double));
   d->J = (double *)calloc((size_t)d->maxrow * nv, sizeof(double));
   double **arrs[] = {&d->epos, &d->emargin, &d->ediag, &d->eD, &d->eR, &d->earef, &d->eforce, &d->ejar, &d->ejd};
   for (unsigned i = 0; i < sizeof arrs / sizeof arrs[0]; i++) *arrs[i] = (double *)calloc(d->maxrow, sizeof(double));
@@ -311,7 +312,7 @@ om_data *om_data_create(const om_model *m) {
 }
 void om_data_destroy(om_data *d) {
   if (!d) return;
-  free(d->M); free(d->H); free(d->work); free(d->J);
+  free(d->M); free(d->H); free(d->work); free(d->work2); free(d->J);
   free(d->epos); free(d->emargin); free(d->ediag); free(d->eD); free(d->eR); free(d->earef);
   free(d->eforce); free(d->ejar); free(d->ejd);
   free(d);
@@ -712,7 +713,7 @@ void om_step(const om_model *m, om_data *d) {
 void om_spd_torque(const om_model *m, const om_data *d, const double *action, double *tau) {
   int nv = m->nv, nu = m->nu;
   double dt = m->dt;
-  double *A = (double *)malloc(sizeof(double) * nv * nv);
+  double *A = d->work2;                                   /* per-data scratch (no malloc in the hot loop) */
   double kp[OM_MAXV] = {0}, kd[OM_MAXV] = {0}, perr[OM_MAXV] = {0}, rhs[OM_MAXV];
   memcpy(A, d->M, sizeof(double) * nv * nv);
   for (int i = 0; i < nu; i++) {
@@ -732,7 +733,6 @@ void om_spd_torque(const om_model *m, const om_data *d, const double *action, do
     double t = -m->kp[i] * perr[dof] - m->kd[i] * (d->qvel[dof] + rhs[dof] * dt);
     tau[i] = t > m->tlim[i] ? m->tlim[i] : (t < -m->tlim[i] ? -m->tlim[i] : t);
   }
-  free(A);
 }
 
 void om_ctrl_torque(const om_model *m, const om_data *d, int mode, double power_scale, const double *action, double *tau) {

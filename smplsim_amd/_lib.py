@@ -20,14 +20,15 @@ class ExtensionMissing(RuntimeError):
     pass
 
 
-def build(verbose=False):
+def build(verbose=False, force=False):
     """hipcc --offload-arch=gfx950 build of the kernels + C ABI (cross-compiles without a GPU)."""
     srcs = [os.path.join(SRC_DIR, f) for f in ("smplsim_hip.hip", "ss_kernel.h", "ss_api.h", "ss_tables.h", "ss_hdr.h")]
     srcs.append(os.path.join(os.path.dirname(_PKG), "include", "smplsim_hip.h"))
-    if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", srcs[0], "-o", LIB_PATH]
+    opt = os.environ.get("SS_HIPCC_OPT", "-O3").split()
+    cmd = [hipcc, "--offload-arch=gfx950", *opt, "-std=c++17", "-shared", "-fPIC", srcs[0], "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
