@@ -1,0 +1,115 @@
+"""Edge cases of the C ABI and the kernel driver, run on the wavefront emulator (CPU): ragged batch sizes,
+empty / full reset masks, non-finite actions, error paths, state round trips, episode bookkeeping."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import FEET, default_qpos, model_const, oracle_model, pd_tables
+from oracle import oracle as O
+from smplsim_amd import _cabi
+from wave_emu import emu
+
+
+def _batch(n, **kw):
+    mc = model_const()
+    return emu.EmuBatch(mc, pd_tables(mc), n, legal_bodies=FEET, **kw)
+
+
+@pytest.mark.parametrize("n", [1, 5, 9])
+def test_ragged_batch_sizes_are_env_independent(n):
+    """Every env of a batch evolves exactly as it would alone (no cross-env coupling, any N)."""
+    rs = np.random.default_rng(n)
+    acts = rs.uniform(-0.4, 0.4, (3, n, 69))
+    eb = _batch(n)
+    eb.reset()
+    for a in acts:
+        eb.step(a)
+    solo = _batch(1)
+    solo.reset()
+    for a in acts:
+        solo.step(a[n - 1:n])
+    assert np.array_equal(eb.qpos[n - 1], solo.qpos[0]) and np.array_equal(eb.obs[n - 1], solo.obs[0])
+
+
+def test_reset_masks_empty_and_full():
+    eb = _batch(3)
+    eb.reset()
+    eb.step(np.full((3, 69), 0.2))
+    q = eb.qpos.copy(); t = eb.cur_t.copy()
+    eb.reset(mask=[0, 0, 0])
+    assert np.array_equal(eb.qpos, q) and np.array_equal(eb.cur_t, t)
+    eb.reset(mask=[1, 1, 1])
+    assert np.allclose(eb.qpos[:, 2], 0.94) and (eb.cur_t == 0).all()
+    assert np.array_equal(eb.qpos, eb.qpos_prev) and np.array_equal(eb.qvel, eb.qvel_prev)
+
+
+def test_non_finite_action_triggers_mujoco_style_autoreset():
+    eb = _batch(2)
+    eb.reset()
+    a = np.zeros((2, 69)); a[0, 3] = np.nan
+    obs, rew, term, trunc = eb.step(a)
+    assert eb.nwarn[0] >= 1 and eb.nwarn[1] == 0
+    assert np.isfinite(eb.qpos).all() and np.isfinite(eb.qvel).all() and np.isfinite(obs[1]).all()
+
+
+def test_error_paths_return_status_and_message():
+    L = emu.lib()
+    mc = model_const()
+    desc, keep = _cabi.make_model_desc(mc, *pd_tables(mc))
+    model = C.c_void_p()
+    assert L.ss_model_create(C.byref(desc), 0, C.byref(model)) == 0
+    cfg = _cabi.make_env_cfg()
+    st = _cabi.State(4)                                        # every buffer NULL
+    batch = C.c_void_p()
+    assert L.ss_batch_create(model, C.byref(cfg), C.byref(st), C.byref(batch)) == -1
+    assert b"ss_state buffer" in L.ss_last_error()
+    eb = _batch(1, state_init=_cabi.INIT_FALL)
+    with pytest.raises(RuntimeError, match="fall_actions"):
+        eb.reset()                                             # StateInit.Fall without its random draws
+    bad = _cabi.make_env_cfg(self_obs_v=3)
+    assert L.ss_batch_create(model, C.byref(bad), C.byref(st), C.byref(batch)) == -1
+    # a model whose bodies are not in depth-first order is rejected by the table builder
+    par = mc.body_parent.copy(); par[5] = 9                    # R_Hip under Torso, which comes later
+    desc2, keep2 = _cabi.make_model_desc(mc, *pd_tables(mc))
+    arr = np.ascontiguousarray(par, np.int32); desc2.body_parent = arr.ctypes.data_as(C.c_void_p)
+    m2 = C.c_void_p()
+    assert L.ss_model_create(C.byref(desc2), 0, C.byref(m2)) == -1 and L.ss_last_error()
+    L.ss_model_destroy(model)
+
+
+def test_state_round_trip_replays_bit_identically():
+    """get/set of the full state (incl. the stale-forward source and the warm start) reproduces a run exactly."""
+    rs = np.random.default_rng(8)
+    acts = rs.uniform(-0.5, 0.5, (4, 1, 69))
+    a = _batch(1); a.reset()
+    a.step(acts[0]); a.step(acts[1])
+    snap = [x.copy() for x in (a.qpos, a.qvel, a.qpos_prev, a.qvel_prev, a.qacc_warm, a.cur_t, a.task)]
+    a.step(acts[2]); a.step(acts[3])
+    b = _batch(1)
+    b.qpos[:], b.qvel[:], b.qpos_prev[:], b.qvel_prev[:], b.qacc_warm[:], b.cur_t[:], b.task[:] = snap
+    b.step(acts[2]); b.step(acts[3])
+    assert np.array_equal(a.qpos, b.qpos) and np.array_equal(a.qvel, b.qvel) and np.array_equal(a.obs, b.obs)
+
+
+def test_speed_task_termination_and_truncation_flags_match_oracle():
+    """Let the humanoid collapse (zero actions): illegal floor contacts must terminate the speed task at the
+    same control step as the oracle; episode_length truncation uses the strict `>` of the reference."""
+    om = oracle_model()
+    eb = _batch(1, task=_cabi.TASK_SPEED, episode_length=40)
+    env = O.OracleEnv(om, task=O.TASK_SPEED, episode_length=40)
+    tr = [0.3, 0.6]
+    env.reset(task_rand=tr); eb.reset(task_rand=[tr])
+    rs = np.random.default_rng(0)
+    first_term = None
+    for i in range(45):
+        a = rs.uniform(-0.3, 0.3, 69)                          # the rollout of test_kernel_emu: on the floor by step ~30
+        eb.set_state(env.data.qpos, env.data.qvel, eb.qpos_prev, eb.qvel_prev)
+        o_ref, r, te, tu = env.step(a, task_rand=tr)
+        o, r2, te2, tu2 = eb.step(a[None], task_rand=[tr])
+        assert (te, tu) == (bool(te2[0]), bool(tu2[0])), i
+        assert abs(r - r2[0]) < 1e-4
+        if te and first_term is None:
+            first_term = i
+        assert tu == (i + 1 > 40)
+    assert first_term is not None and first_term > 5

@@ -203,3 +203,45 @@ def test_benchmark_harness_shape_runs():
     sps = num_envs * 5 / np.sum(times)
     assert out[0].shape == (64, 289) and np.isfinite(out[0]).all() and sps > 0
     env.close()
+
+
+@pytest.mark.parametrize("n", [1, 5, 4097])
+def test_ragged_batch_sizes(vec, n):
+    """Any N (not a multiple of the 8 envs per workgroup; more envs than resident waves): last env == env alone."""
+    rs = np.random.default_rng(n)
+    acts = torch.tensor(rs.uniform(-0.4, 0.4, (3, 1, 69)), dtype=torch.float32, device="cuda:0")
+    env = vec(n, autoreset=False)
+    env.reset()
+    for a in acts:
+        env.step(a.expand(n, 69).contiguous())
+    solo = vec(1, autoreset=False)
+    solo.reset()
+    for a in acts:
+        solo.step(a.contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(env.qpos[n - 1], solo.qpos[0]) and torch.equal(env.obs_buf[n - 1], solo.obs_buf[0])
+    assert torch.equal(env.qpos[0], solo.qpos[0])
+
+
+def test_nan_action_autoreset_and_empty_mask(vec):
+    env = vec(16, autoreset=False)
+    env.reset()
+    a = torch.zeros(16, 69, device=env.device); a[3, 7] = float("nan")
+    env.step(a)
+    torch.cuda.synchronize()
+    assert int(env.nwarn[3]) >= 1 and int(env.nwarn.sum()) == int(env.nwarn[3])
+    assert torch.isfinite(env.qpos).all() and torch.isfinite(env.qvel).all()
+    q = env.qpos.clone()
+    env.reset(mask=torch.zeros(16, dtype=torch.uint8, device=env.device))
+    torch.cuda.synchronize()
+    assert torch.equal(q, env.qpos)
+
+
+def test_c_abi_error_paths_on_gpu():
+    import ctypes as C
+    from smplsim_amd import _cabi, _lib
+    L = _lib.lib()
+    st = _cabi.State(4)
+    batch = C.c_void_p()
+    assert L.ss_batch_create(None, None, C.byref(st), C.byref(batch)) == -1 and L.ss_last_error()
+    assert L.ss_step(None, None, None, None, None, None, None, None) == -1

@@ -1,8 +1,8 @@
-rocprofv3 -L 2>/dev/null | grep -i -E "IFETCH|ICACHE|INST_CACHE|SQC_" | head -30
-for opt in "-O3" "-Os" "-O2" "-O3 -mllvm -amdgpu-unroll-threshold-private=0 -fno-unroll-loops"; do
+for opt in "-O3 -ffast-math" "-O3 -fno-math-errno -freciprocal-math" "-O3"; do
   SS_HIPCC_OPT="$opt" python -c "from smplsim_amd import _lib; _lib.build(force=True)" 2>/dev/null
-  echo "== $opt: $(/opt/rocm/lib/llvm/bin/llvm-readelf -s --wide smplsim_amd/libsmplsim_hip.so 2>/dev/null | grep -c xx)"
+  echo "== $opt"
   python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('ms/step',round(d['ms_per_step'],3), d['config']['launch'])"
+  timeout 300 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | tail -1
 done
