@@ -9,6 +9,10 @@
 #include "ss_api.h"
 #include "ss_kernel.h"
 
+#ifndef SS_MAX_THREADS
+#define SS_MAX_THREADS 704   // 11 waves: LDS fits 11 SMPL envs per CU; 3 waves/SIMD caps the kernel at 168 VGPRs
+#endif
+
 namespace {
 
 struct WaveGpu {
@@ -42,7 +46,7 @@ struct WaveGpu {
 };
 
 template <int DOFP, int CANDP, int SLOTP>
-__global__ void __launch_bounds__(512) ss_env_kernel(const ss::KArgs k) {
+__global__ void __launch_bounds__(SS_MAX_THREADS) ss_env_kernel(const ss::KArgs k) {
   extern __shared__ __align__(16) uint32_t lds[];
   for (int i = threadIdx.x; i < k.h.shared_words; i += blockDim.x) lds[i] = k.shared_g[i];
   __syncthreads();
@@ -96,6 +100,7 @@ struct HipBackend {
     const int resident = cus * (int)(lds_capacity() / lds_bytes > 0 ? lds_capacity() / lds_bytes : 1);
     if (wgs > resident) wgs = resident;                      // persistent: one resident set of workgroups
     if (hipMemsetAsync(k.work_counter, 0, sizeof(int32_t), (hipStream_t)stream) != hipSuccess) return "hipMemsetAsync failed";
+    if (64 * envs_per_wg > SS_MAX_THREADS) envs_per_wg = SS_MAX_THREADS / 64;
     dim3 grid(wgs), block(64 * envs_per_wg);
     hipLaunchKernelGGL(kern, grid, block, lds_bytes, (hipStream_t)stream, k);
     hipError_t e = hipGetLastError();

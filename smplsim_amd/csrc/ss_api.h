@@ -5,6 +5,7 @@
 //   static int lds_capacity();   static const char *launch(const ss::KArgs &, int nenv, int envs_per_wg, size_t lds_bytes, void *stream);
 //   static bool set_device(int);
 #pragma once
+#include <cstdlib>
 #include <new>
 #include <string>
 
@@ -81,7 +82,8 @@ struct ss_api {
     int cap = BE::lds_capacity();
     int e = (int)((cap - (long)shared_b) / (long)env_b);
     if (e < 1) { delete b; return fail(SS_ERR_LDS, "model does not fit in LDS"); }
-    if (e > 8) e = 8;
+    if (e > 16) e = 16;
+    { const char *cap = getenv("SS_ENVS_PER_WG"); if (cap && atoi(cap) > 0 && atoi(cap) < e) e = atoi(cap); }
     b->envs_per_wg = e;
     b->lds_bytes = shared_b + (size_t)e * env_b;
 #ifdef SS_PROFILE

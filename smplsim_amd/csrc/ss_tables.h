@@ -305,16 +305,31 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   if (13 * h.nslot > ne) { out.error = "contact record buffer does not fit"; return false; }
   int o = 0;
   auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
+  // Arrays with disjoint lifetimes share storage (LDS capacity sets the number of resident envs per CU):
+  //   H region  : contact records (make_constraints) | per-body K inputs, subtree-summed Kc and Gb (forward_kin /
+  //               newton_prepare, dead before assemble_H writes H) | the matrix itself
+  //   G region  : R, r and Ad (forward pass .. constraints / row evaluation) | G_i = Hc S_i (assembly) | U buffers |
+  //               scratch of body_accel / the forward triangular sweep
+  //   grad,delta: V (body velocities, dead after make_constraints)
   h.l_H = take(ne);
+  if (48 * nb > ne || 13 * h.nslot > ne) { out.error = "H region too small for its aliases"; return false; }
+  h.l_K = h.l_H + 21 * nb;                                 // Kc (subtree sums); inputs live at H[0 .. 21 nb)
+  h.l_Gb = h.l_H + 42 * nb;
   h.l_S = take(6 * nv);
-  h.l_G = take(std::max(6 * nv, 2 * maxU));                // G doubles as the (double-buffered) U buffer of the factorization
+  const int gneed = std::max(std::max(6 * nv, 2 * maxU), 18 * nb);
+  h.l_G = take(gneed);                                     // also the (double-buffered) U buffer of the factorization
   h.maxU = maxU;
+  h.l_R = h.l_G; h.l_r = h.l_G + 9 * nb;                   // R, r: first 12 nb floats of G
+  h.l_Ad = h.l_G + gneed - 6 * nb;                         // Ad: last 6 nb floats of G (body_accel scratch uses G[0 .. 6 nn))
+  if (12 * nb > gneed - 6 * nb || 6 * nn > gneed - 6 * nb) { out.error = "G region too small for its aliases"; return false; }
   h.l_Dinv = take(6 * nn);
-  h.l_R = take(9 * nb); h.l_r = take(3 * nb);
-  h.l_Ic = take(10 * nb); h.l_K = take(21 * nb);
-  h.l_V = take(6 * nb); h.l_Ab = take(6 * nb); h.l_Ad = take(6 * nb); h.l_Gb = take(6 * nb);
-  h.l_q = take(nv + 1); h.l_v = take(nv); h.l_a = take(nv); h.l_tau = take(nv); h.l_grad = take(nv);
-  h.l_delta = take(nv); h.l_C = take(nv); h.l_diag = take(nv);
+  h.l_Ic = take(10 * nb);
+  h.l_Ab = take(6 * nb);
+  h.l_q = take(nv + 1); h.l_v = take(nv); h.l_a = take(nv); h.l_tau = take(nv);
+  h.l_grad = take(nv); h.l_delta = take(nv);
+  h.l_V = h.l_grad;                                        // V: 6 nb <= 2 (nv+pad) floats of grad + delta
+  if (6 * nb > h.l_delta + nv - h.l_grad) { out.error = "V alias does not fit"; return false; }
+  h.l_C = take(nv); h.l_diag = take(nv);
   h.l_misc = take(16);
   h.env_floats = o;
 
