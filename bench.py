@@ -127,23 +127,12 @@ def main():
     # per-launch duration of the dominant kernel (the fused step), HIP events on the launch stream
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    import ctypes as C
-    from smplsim_amd.batch import _check, _ptr, lib
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         a = torch.rand(N, env.nu, generator=g, device=dev) * 2 - 1
-        if args.workload == "smpl":
-            ev0[i].record()
-            _check(lib().ss_step(env.handle, _ptr(a), None, _ptr(env.obs_buf), _ptr(env.rew_buf), _ptr(env.terminated),
-                                 _ptr(env.truncated), env._stream()))
-            ev1[i].record()
-            torch.bitwise_or(env.terminated, env.truncated, out=env.reset_buf)
-            _check(lib().ss_reset(env.handle, _ptr(env.reset_buf), None, None, _ptr(env.obs_buf), env._stream()))
-        else:
-            ev0[i].record()
-            env.step(a)                                     # step + masked autoreset (Fall warm-up / task targets)
-            ev1[i].record()
+        # env.step = LPT hand-out order (argsort of last step's Newton counts) + the fused step launch + masked autoreset
+        env.step(a, _events=(ev0[i], ev1[i]))
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = shard.max_over_ranks(dist, world, elapsed, dev)

@@ -117,6 +117,11 @@ int ss_reset(ss_batch *b, const uint8_t *mask, const float *fall_actions, const 
 int ss_step(ss_batch *b, const float *actions, const float *task_rand, float *obs, float *reward,
             uint8_t *terminated, uint8_t *truncated, void *stream);
 
+/* Scheduling hint (no effect on results): a permutation [N] of env ids (device pointer, caller-owned, NULL = natural
+ * order).  The persistent wavefronts pull env ids in this order; passing the envs sorted by their previous step's
+ * `solver_iters` (descending) starts the expensive ones first (longest-processing-time-first). */
+int ss_set_order(ss_batch *b, const int32_t *order);
+
 /* n x (controller + mj_step) without the env epilogue — substep-granular parity/debugging */
 int ss_substep(ss_batch *b, const float *actions, int n_substeps, void *stream);
 

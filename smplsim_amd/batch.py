@@ -60,7 +60,8 @@ class SMPLSimVecEnv:
     def __init__(self, num_envs, model=None, device=0, task="HumanoidEnv", state_init="Default", self_obs_v=1,
                  control_mode="uhc_pd", episode_length=300, control_freq_inv=15, root_height_obs=True,
                  power_scale=1.0, tar_speed=(0.0, 5.0), speed_change=(100, 200), tar_height=(0.5, 1.2),
-                 height_change=(100, 200), recovery_steps=60, newton_iters=8, autoreset=True, seed=0, **model_kw):
+                 height_change=(100, 200), recovery_steps=60, newton_iters=8, autoreset=True, seed=0, lpt_order=True,
+                 **model_kw):
         if not torch.cuda.is_available():
             raise RuntimeError("SMPLSimVecEnv needs a ROCm GPU (MI355X); there is no CPU fallback")
         self.model = model if model is not None else ShardModel(device=device, control_mode=control_mode, **model_kw)
@@ -102,6 +103,10 @@ class SMPLSimVecEnv:
         self.action_size = self.nu
         self.actuator_names = list(mc.actuator_names)
         self._keep = self._keep2 = None
+        # longest-processing-time-first hand-out: env-step cost ~ Newton iterations, which are heavy-tailed and
+        # autocorrelated from one control step to the next (scheduling only; results do not depend on it)
+        self.lpt_order = bool(lpt_order) and N > 64
+        self.order = torch.arange(N, dtype=torch.int32, device=dev)
 
     # ---- random inputs the reference draws from np.random inside the env (targets, Fall actions)
     def _task_rand(self):
@@ -126,13 +131,24 @@ class SMPLSimVecEnv:
         _check(lib().ss_reset(self.handle, _ptr(m), _ptr(fa), _ptr(tr), _ptr(self.obs_buf), self._stream()))
         return self.obs_buf, {"critic_state": self.obs_buf}
 
-    def step(self, actions, task_rand=None):
+    def step(self, actions, task_rand=None, _events=None):
+        """One control step of every env (+ masked autoreset).  `_events` = (start, end) torch.cuda.Event pair recorded
+        around the step launch only (bench.py's per-launch kernel timing)."""
         actions = actions.to(torch.float32).contiguous()
         assert actions.shape == (self.num_envs, self.nu) and actions.device == self.device
         tr = task_rand if task_rand is not None else self._task_rand()
         self._keep = (actions, tr)
+        if self.lpt_order:
+            self.order = torch.argsort(self.solver_iters, descending=True).to(torch.int32)
+            _check(lib().ss_set_order(self.handle, _ptr(self.order)))
+        if _events:
+            _events[0].record()
         _check(lib().ss_step(self.handle, _ptr(actions), _ptr(tr), _ptr(self.obs_buf), _ptr(self.rew_buf),
                              _ptr(self.terminated), _ptr(self.truncated), self._stream()))
+        if _events:
+            _events[1].record()
+        if self.lpt_order:
+            _check(lib().ss_set_order(self.handle, None))      # resets / diagnostics use the natural order
         info = {}
         if self.autoreset:
             # autoreset of finished envs: device-side mask, no host sync (GymVectEnv semantics,

@@ -60,6 +60,7 @@ __global__ void __launch_bounds__(SS_MAX_THREADS) ss_env_kernel(const ss::KArgs 
     if (w.ln == 0) env = atomicAdd(k.work_counter, 1);
     env = __builtin_amdgcn_readfirstlane(env);
     if (env >= k.st.num_envs) break;
+    if (k.order) env = __builtin_amdgcn_readfirstlane(k.order[env]);   // longest-processing-time-first hand-out
     ss::run_env<WaveGpu, DOFP, CANDP, SLOTP>(&w, &k, lds, L, env);
     w.sync();
   }

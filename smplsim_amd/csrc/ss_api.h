@@ -31,6 +31,7 @@ struct ss_batch {
   int obs_size = 0;
   int32_t *d_counter = nullptr;
   unsigned long long *d_prof = nullptr;   // SS_PROFILE builds only
+  const int32_t *order = nullptr;         // caller-owned device array or null
 };
 
 template <class BE>
@@ -104,6 +105,7 @@ struct ss_api {
     k.mode = mode; k.nsub = b->cfg.control_freq_inv; k.obs_size = b->obs_size;
     k.work_counter = b->d_counter;
     k.prof = b->d_prof;
+    k.order = b->order;
     return k;
   }
   static int run(const ss_batch *b, const ss::KArgs &k, void *stream) {
@@ -159,6 +161,10 @@ struct ss_api {
   int ss_obs_size(const ss_model *m, const ss_env_cfg *c) { return (m && c) ? ss::obs_size(m->hm.h, *c) : SS_ERR_INVALID; } \
   int ss_batch_create(const ss_model *m, const ss_env_cfg *c, const ss_state *s, ss_batch **o) { return ss_api<BE>::batch_create(m, c, s, o); } \
   void ss_batch_destroy(ss_batch *b) { if (b) { BE::free_(b->d_counter); BE::free_(b->d_prof); delete b; } }          \
+  int ss_set_order(ss_batch *b, const int32_t *order) {                                                              \
+    if (!b) return ss_api<BE>::fail(SS_ERR_INVALID, "null batch");                                                  \
+    b->order = order; return SS_OK;                                                                                  \
+  }                                                                                                                  \
   int ss_debug_prof(ss_batch *b, unsigned long long *out, int n) {                                                   \
     if (!b || !out || !b->d_prof) return ss_api<BE>::fail(SS_ERR_INVALID, "not a profiling build");                 \
     return BE::download(out, b->d_prof, (size_t)n * 8) ? SS_OK : SS_ERR_HIP;                                         \

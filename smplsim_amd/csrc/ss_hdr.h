@@ -46,6 +46,7 @@ struct KArgs {
   const float *fall_actions;  // [N,3,nu] or null
   const uint8_t *mask;        // [N] or null
   unsigned long long *prof;   // optional stage-cycle accumulators (SS_PROFILE builds), else null
+  const int32_t *order;       // optional [N] processing order of the envs (heavy first), or null
   int32_t *work_counter;      // device word, zeroed before each launch: persistent waves pull env ids from it
   float *obs, *reward;
   uint8_t *terminated, *truncated;

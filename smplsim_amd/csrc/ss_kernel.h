@@ -43,7 +43,15 @@
 
 namespace ss {
 
-enum { PF_FWD = 0, PF_CONS, PF_NBEGIN, PF_NPREP, PF_ASM, PF_FACTOR, PF_SOLVE, PF_NFIN, PF_SPDPREP, PF_SPDFIN, PF_INTEG, PF_MISC, PF_COUNT };
+enum { PF_FWD = 0, PF_CONS, PF_NBEGIN, PF_NPREP, PF_ASM, PF_FACTOR, PF_SOLVE, PF_NFIN, PF_SPDPREP, PF_SPDFIN, PF_INTEG, PF_MISC,
+       PF_F_P13, PF_F_SYNC1, PF_F_P2, PF_F_BSOL, PF_F_SYNC2, PF_COUNT };
+#ifdef SS_PROFILE
+#define SS_FT0() unsigned long long ft__ = w->clock()
+#define SS_FTICK(id) do { unsigned long long n__ = w->clock(); prof[id] += n__ - ft__; ft__ = n__; } while (0)
+#else
+#define SS_FT0() do {} while (0)
+#define SS_FTICK(id) do {} while (0)
+#endif
 
 struct Contact {
   float rx, ry, rz;      // contact point relative to the root origin
@@ -563,6 +571,7 @@ struct Sim {
     const Hdr &h = k->h;
     // U is double-buffered in G (free between assembly and the next one) so that "P_k <- U_k" of level L+1
     // shares a phase with "U = Dinv P" of level L
+    SS_FT0();
     for (int L = h.nlev - 1; L >= 0; --L) {
       const int D = 3 * L, Wd = D + 3;
       float *U = G + (L & 1) * h.maxU;
@@ -605,7 +614,9 @@ struct Sim {
           }
         }
       }
+      SS_FTICK(PF_F_P13);
       w->sync();
+      SS_FTICK(PF_F_SYNC1);
       if (L == 0) break;
       {                                                      // phase 2: ancestor blocks (I >= J) -= sum_k P_k[:,I]^T U_k[:,J]
         const int i0 = h.itemB[L], ni = h.itemB[L + 1] - i0;
@@ -637,6 +648,7 @@ struct Sim {
             for (int b_ = 0; b_ < 3; b_++) dst[a_ * Wa + b_] -= acc[3 * a_ + b_];
           }
         }
+        SS_FTICK(PF_F_P2);
         const int j0 = h.bsol[L], nj = h.bsol[L + 1] - j0;    // x_anc -= sum_k U_k[:,J]^T x_k   (pull per ancestor node)
         for (int idx = lane; idx < nj; idx += 64) {
           const int aJ = ti(h.o_bsol, 2 * (j0 + idx)), w1 = ti(h.o_bsol, 2 * (j0 + idx) + 1);
@@ -652,8 +664,10 @@ struct Sim {
           }
           x[3 * aJ] -= a0; x[3 * aJ + 1] -= a1; x[3 * aJ + 2] -= a2;
         }
+        SS_FTICK(PF_F_BSOL);
       }
       w->sync();
+      SS_FTICK(PF_F_SYNC2);
     }
   }
 

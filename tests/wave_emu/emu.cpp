@@ -201,7 +201,7 @@ struct EmuBackend {
     for (int env = 0; env < nenv; env++) {
       // poison LDS so that reads of never-written locations are visible
       for (auto &x : L) x = __builtin_nanf("");
-      LaunchCtx c{&k, k.shared_g, L.data(), env, m};
+      LaunchCtx c{&k, k.shared_g, L.data(), k.order ? k.order[env] : env, m};
       void (*entry)(int, void *) = nullptr;
       const int slotp = (k.h.nslot + 63) / 64;
       if (dofp == 2 && candp == 2 && slotp == 1) entry = lane_entry<2, 2, 1>;

@@ -29,9 +29,9 @@ for _ in range(steps):
     env.step(torch.rand(N, 69, generator=g, device=env.device) * 2 - 1)
 torch.cuda.synchronize()
 out = (C.c_ulonglong * 64)()
-rc = _lib.lib().ss_debug_prof(env.handle, out, 16)
+rc = _lib.lib().ss_debug_prof(env.handle, out, 24)
 names = ["fwd_kin", "constraints", "newton_begin", "newton_prepare", "assemble", "factor", "solve", "newton_finish",
-         "spd_prepare", "spd_finish", "integrate", "misc"]
+         "spd_prepare", "spd_finish", "integrate", "misc", "factor:phase1+3", "factor:sync1", "factor:phase2", "factor:bsol", "factor:sync2"]
 tot = sum(out[i] for i in range(12))
 iters = float(env.solver_iters.float().mean().item())
 res = {"rc": rc, "total_ticks": tot, "mean_newton_iters": iters, "stages": {}}
