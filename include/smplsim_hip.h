@@ -31,7 +31,7 @@ typedef enum {
 } ss_status;
 
 enum { SS_GEOM_BOX = 0, SS_GEOM_CAPSULE = 1 };
-enum { SS_TASK_BASE = 0, SS_TASK_SPEED = 1, SS_TASK_GETUP = 2 };      /* reference tasks/humanoid_{speed,getup}.py */
+enum { SS_TASK_BASE = 0, SS_TASK_SPEED = 1, SS_TASK_GETUP = 2, SS_TASK_REACH = 3 };   /* reference tasks/humanoid_{speed,getup,reach}.py */
 enum { SS_INIT_DEFAULT = 0, SS_INIT_FALL = 1 };                        /* HumanoidEnv.StateInit, humanoid_env.py:141-146 */
 enum { SS_CTRL_UHC_PD = 0, SS_CTRL_PD = 1, SS_CTRL_TORQUE = 2 };       /* control_mode, humanoid_env.py:312-323 */
 
@@ -71,6 +71,9 @@ typedef struct {
   float tar_speed_min, tar_speed_max; int32_t speed_change_min, speed_change_max;
   float tar_height_min, tar_height_max; int32_t height_change_min, height_change_max, recovery_steps;
   int32_t newton_iters;          /* max Newton iterations of the constraint solve per substep (default 8) */
+  /* reach task (tasks/humanoid_reach.py): target x,y in +-tar_dist_max, z in [tar_height_min, tar_height_max], resampled
+   * every [height_change_min, height_change_max) steps; reward on the world position of body `reach_body` */
+  float tar_dist_max; int32_t reach_body;
 } ss_env_cfg;
 
 /* Device buffers of one shard of environments (all caller-owned, float32 unless noted). */
@@ -85,7 +88,7 @@ typedef struct {
                                    (the framelinvel/frameangvel sensors, humanoid_env.py:539-544) */
   int32_t *touch;     /* [N,2]   bit b of the 64-bit mask set: body b touched the floor at the last forward (mjData.contact) */
   int32_t *cur_t;     /* [N]     BaseEnv.cur_t */
-  float *task;        /* [N,4]   tar_speed|tar_height, change_steps, recovery_counter, unused */
+  float *task;        /* [N,4]   speed/getup: tar_speed|tar_height, change_steps, recovery_counter, 0 ; reach: tar xyz, change_steps */
   int32_t *nwarn;     /* [N]     count of MuJoCo-style autoresets (mj_checkPos/Vel/Acc) */
   int32_t *solver_iters; /* [N]  Newton iterations spent in the last step (diagnostic) */
 } ss_state;
@@ -106,7 +109,8 @@ void ss_batch_destroy(ss_batch *b);
 
 /* HumanoidEnv.reset()/HumanoidTask.reset() (humanoid_env.py:471-512, humanoid_task.py:6-9) for the envs
  * whose mask byte is non-zero (mask NULL = all).  fall_actions [N,3,nu] uniform(0,1) draws consumed by
- * StateInit.Fall (may be NULL for Default); task_rand [N,2] uniform(0,1) draws for target resampling
+ * StateInit.Fall (may be NULL for Default); task_rand [N,4] uniform(0,1) draws for target resampling
+ * (speed/getup use [0]=target, [1]=change steps; reach uses [0..2]=target xyz, [3]=change steps)
  * (may be NULL for the base task).  obs [N,obs_size] is written for the reset envs only. */
 int ss_reset(ss_batch *b, const uint8_t *mask, const float *fall_actions, const float *task_rand,
              float *obs, void *stream);

@@ -815,7 +815,8 @@ struct om_env {
   om_data *d;
   om_env_cfg cfg;
   int cur_t;
-  double tar;            /* tar_speed or tar_height */
+  double tar;            /* tar_speed or tar_height (reach: tar_pos x) */
+  double tar_yz[2];      /* reach: tar_pos y, z */
   double change_steps;
   int recovery_counter;
   double prev_root_pos[3];
@@ -831,17 +832,17 @@ om_data *om_env_data(om_env *e) { return e->d; }
 int om_env_obs_size(const om_env *e) {
   int nb = e->m->nbody, nd = 3 * (nb - 1);
   int n = (e->cfg.root_height_obs ? 1 : 0) + nd + (e->cfg.self_obs_v == 1 ? nb * 6 + 6 + nd : nb * 12);
-  if (e->cfg.task == OM_TASK_SPEED) n += 3;
+  if (e->cfg.task == OM_TASK_SPEED || e->cfg.task == OM_TASK_REACH) n += 3;
   if (e->cfg.task == OM_TASK_GETUP) n += 1;
   return n;
 }
 void om_env_get_task(const om_env *e, double *o) {
   o[0] = e->cur_t; o[1] = e->tar; o[2] = e->change_steps; o[3] = e->recovery_counter;
-  v3cpy(o + 4, e->prev_root_pos);
+  v3cpy(o + 4, e->prev_root_pos); o[7] = e->tar_yz[0]; o[8] = e->tar_yz[1];
 }
 void om_env_set_task(om_env *e, const double *i) {
   e->cur_t = (int)i[0]; e->tar = i[1]; e->change_steps = i[2]; e->recovery_counter = (int)i[3];
-  v3cpy(e->prev_root_pos, i + 4);
+  v3cpy(e->prev_root_pos, i + 4); e->tar_yz[0] = i[7]; e->tar_yz[1] = i[8];
 }
 
 static void env_reset_task(om_env *e, const double *u) {
@@ -853,6 +854,11 @@ static void env_reset_task(om_env *e, const double *u) {
   } else if (c->task == OM_TASK_GETUP) {
     e->tar = (c->tar_height_max - c->tar_height_min) * u[0] + c->tar_height_min;
     int ch = c->height_change_min + (int)floor(u[1] * (c->height_change_max - c->height_change_min));
+    e->change_steps = e->cur_t + ch;
+  } else if (c->task == OM_TASK_REACH) {                     /* humanoid_reach.py:81-92 */
+    e->tar = c->tar_dist_max * (2.0 * u[0] - 1.0); e->tar_yz[0] = c->tar_dist_max * (2.0 * u[1] - 1.0);
+    e->tar_yz[1] = (c->tar_height_max - c->tar_height_min) * u[2] + c->tar_height_min;
+    int ch = c->height_change_min + (int)floor(u[3] * (c->height_change_max - c->height_change_min));
     e->change_steps = e->cur_t + ch;
   }
 }
@@ -875,6 +881,11 @@ static void env_obs(om_env *e, float *obs) {
     obs[n++] = (float)r[0]; obs[n++] = (float)r[1]; obs[n++] = (float)e->tar;
   } else if (e->cfg.task == OM_TASK_GETUP) {
     obs[n++] = (float)e->tar;
+  } else if (e->cfg.task == OM_TASK_REACH) {                 /* compute_location_observations, humanoid_reach.py:21-30 */
+    double hq[4], l[3] = {e->tar - d->qpos[0], e->tar_yz[0] - d->qpos[1], e->tar_yz[1] - d->qpos[2]}, r[3];
+    heading_quat_inv(d->qpos + 3, hq);
+    npt_quat_rotate(hq, l, r);
+    obs[n++] = (float)r[0]; obs[n++] = (float)r[1]; obs[n++] = (float)r[2];
   }
 }
 
@@ -899,7 +910,7 @@ void om_quat_op(int op, const double *a, const double *b, double *out) {
 
 void om_env_reset(om_env *e, const double *fall_actions, const double *task_rand, float *obs) {
   const om_model *m = e->m; om_data *d = e->d;
-  static const double zero2[2] = {0, 0};
+  static const double zero2[4] = {0, 0, 0, 0};
   if (e->cfg.task == OM_TASK_GETUP) e->recovery_counter = e->cfg.recovery_steps;
   if (e->cfg.task != OM_TASK_BASE) env_reset_task(e, task_rand ? task_rand : zero2);  /* uses the OLD cur_t */
   memset(d->qpos, 0, sizeof d->qpos); memset(d->qvel, 0, sizeof d->qvel);
@@ -927,7 +938,7 @@ static int legal_contacts(const om_env *e) {
 void om_env_step(om_env *e, const double *action, const double *task_rand, float *obs, double *reward,
                  int *terminated, int *truncated) {
   const om_env_cfg *c = &e->cfg; om_data *d = e->d;
-  static const double zero2[2] = {0, 0};
+  static const double zero2[4] = {0, 0, 0, 0};
   /* pre_physics_step */
   if (c->task != OM_TASK_BASE && e->cur_t >= e->change_steps) env_reset_task(e, task_rand ? task_rand : zero2);
   if (c->task == OM_TASK_SPEED) v3cpy(e->prev_root_pos, d->xpos[0]);
@@ -947,6 +958,11 @@ void om_env_step(om_env *e, const double *action, const double *task_rand, float
     rew = exp(-4.0 * diff * diff);
     if (e->recovery_counter > 0) { e->recovery_counter -= 1; term = 0; trunc = 0; }
     else term = !legal_contacts(e);
+  } else if (c->task == OM_TASK_REACH) {                     /* reach_reward, humanoid_reach.py:10-19 */
+    const double *p = d->xpos[c->reach_body];
+    double dx = e->tar - p[0], dy = e->tar_yz[0] - p[1], dz = e->tar_yz[1] - p[2];
+    rew = exp(-4.0 * (dx * dx + dy * dy + dz * dz));
+    term = !legal_contacts(e);
   }
   *reward = rew; *terminated = term; *truncated = trunc;
 }

@@ -71,7 +71,7 @@ void om_ctrl_torque(const om_model *m, const om_data *d, int control_mode, doubl
                     const double *action, double *tau);
 
 /* ---- env layer (reference humanoid_env.py / humanoid_task.py / tasks) ---- */
-enum { OM_TASK_BASE = 0, OM_TASK_SPEED = 1, OM_TASK_GETUP = 2 };
+enum { OM_TASK_BASE = 0, OM_TASK_SPEED = 1, OM_TASK_GETUP = 2, OM_TASK_REACH = 3 };
 enum { OM_INIT_DEFAULT = 0, OM_INIT_FALL = 1 };
 typedef struct {
   int task, state_init, self_obs_v, control_mode /*0 uhc_pd,1 pd,2 torque*/;
@@ -79,21 +79,23 @@ typedef struct {
   double power_scale;
   double tar_speed_min, tar_speed_max; int speed_change_min, speed_change_max;
   double tar_height_min, tar_height_max; int height_change_min, height_change_max, recovery_steps;
+  double tar_dist_max; int reach_body;     /* reach task (tasks/humanoid_reach.py); target change steps reuse height_change_* */
 } om_env_cfg;
 
 om_env *om_env_create(const om_model *m, const om_env_cfg *cfg);
 void om_env_destroy(om_env *e);
 int om_env_obs_size(const om_env *e);
 om_data *om_env_data(om_env *e);
-/* fall_actions: [3,nu] uniform(0,1) draws (used when state_init == Fall), task_rand: [2] uniform(0,1) */
+/* fall_actions: [3,nu] uniform(0,1) draws (used when state_init == Fall), task_rand: [4] uniform(0,1)
+ * (speed/getup: [0] target, [1] change steps; reach: [0..2] target xyz, [3] change steps) */
 void om_env_reset(om_env *e, const double *fall_actions, const double *task_rand, float *obs);
 void om_env_step(om_env *e, const double *action, const double *task_rand, float *obs, double *reward,
                  int *terminated, int *truncated);
 void om_env_obs(om_env *e, float *obs);   /* compute_observations() on the current state */
 void om_quat_op(int op, const double *a, const double *b, double *out);
-/* task scalars: [cur_t, tar_speed|tar_height, change_steps, recovery_counter, prev_root_pos xyz] */
-void om_env_get_task(const om_env *e, double *out7);
-void om_env_set_task(om_env *e, const double *in7);
+/* task scalars: [cur_t, tar_speed|tar_height|tar_x, change_steps, recovery_counter, prev_root_pos xyz, tar_y, tar_z] */
+void om_env_get_task(const om_env *e, double *out9);
+void om_env_set_task(om_env *e, const double *in9);
 
 /* obs functions alone (pinned against the reference's numpy code) */
 void om_obs_v1(int nbody, const double *qpos, const double *qvel, const double *xpos, const double *xquat,

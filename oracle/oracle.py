@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-TASK_BASE, TASK_SPEED, TASK_GETUP = 0, 1, 2
+TASK_BASE, TASK_SPEED, TASK_GETUP, TASK_REACH = 0, 1, 2, 3
 INIT_DEFAULT, INIT_FALL = 0, 1
 
 # field ids (oracle.h)
@@ -45,7 +45,7 @@ class _EnvCfg(C.Structure):
         ("tar_speed_min", C.c_double), ("tar_speed_max", C.c_double), ("speed_change_min", C.c_int),
         ("speed_change_max", C.c_int),
         ("tar_height_min", C.c_double), ("tar_height_max", C.c_double), ("height_change_min", C.c_int),
-        ("height_change_max", C.c_int), ("recovery_steps", C.c_int),
+        ("height_change_max", C.c_int), ("recovery_steps", C.c_int), ("tar_dist_max", C.c_double), ("reach_body", C.c_int),
     ]
 
 
@@ -253,16 +253,21 @@ class OracleData:
                 pass
 
 
+def _rand4(u):
+    u = np.asarray(u, dtype=np.float64).ravel()
+    return np.ascontiguousarray(np.concatenate([u, np.zeros(4)])[:4])
+
+
 class OracleEnv:
     def __init__(self, model, task=TASK_BASE, state_init=INIT_DEFAULT, self_obs_v=1, control_mode=0,
                  episode_length=300, control_freq_inv=15, root_height_obs=True, power_scale=1.0,
                  tar_speed=(0.0, 5.0), speed_change=(100, 200), tar_height=(0.5, 1.2), height_change=(100, 200),
-                 recovery_steps=60):
+                 recovery_steps=60, tar_dist_max=1.0, reach_body=0):
         self.m = model
         cfg = _EnvCfg(task, state_init, self_obs_v, control_mode, episode_length, control_freq_inv,
                       int(root_height_obs), power_scale, tar_speed[0], tar_speed[1], speed_change[0],
                       speed_change[1], tar_height[0], tar_height[1], height_change[0], height_change[1],
-                      recovery_steps)
+                      recovery_steps, tar_dist_max, reach_body)
         self.h = lib().om_env_create(model.h, C.byref(cfg))
         self.data = OracleData(model, handle=lib().om_env_data(self.h))
         self.obs_size = lib().om_env_obs_size(self.h)
@@ -270,14 +275,14 @@ class OracleEnv:
     def reset(self, fall_actions=None, task_rand=None):
         obs = np.zeros(self.obs_size, dtype=np.float32)
         fa = None if fall_actions is None else np.ascontiguousarray(fall_actions, dtype=np.float64)
-        tr = None if task_rand is None else np.ascontiguousarray(task_rand, dtype=np.float64)
+        tr = None if task_rand is None else _rand4(task_rand)
         lib().om_env_reset(self.h, None if fa is None else _p(fa), None if tr is None else _p(tr), _p(obs))
         return obs
 
     def step(self, action, task_rand=None):
         obs = np.zeros(self.obs_size, dtype=np.float32)
         a = np.ascontiguousarray(action, dtype=np.float64)
-        tr = None if task_rand is None else np.ascontiguousarray(task_rand, dtype=np.float64)
+        tr = None if task_rand is None else _rand4(task_rand)
         rew = C.c_double(); te = C.c_int(); tu = C.c_int()
         lib().om_env_step(self.h, _p(a), None if tr is None else _p(tr), _p(obs), C.byref(rew), C.byref(te), C.byref(tu))
         return obs, rew.value, bool(te.value), bool(tu.value)
@@ -288,12 +293,12 @@ class OracleEnv:
         return obs
 
     def get_task(self):
-        o = np.zeros(7)
+        o = np.zeros(9)
         lib().om_env_get_task(self.h, _p(o))
         return o
 
     def set_task(self, v):
-        v = np.ascontiguousarray(v, dtype=np.float64)
+        v = np.ascontiguousarray(np.concatenate([np.asarray(v, dtype=np.float64), np.zeros(9)])[:9], dtype=np.float64)
         lib().om_env_set_task(self.h, _p(v))
 
     def __del__(self):

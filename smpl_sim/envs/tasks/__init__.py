@@ -1,1 +1,1 @@
-from smplsim_amd.envs import HumanoidEnv, HumanoidGetup, HumanoidSpeed  # noqa: F401
+from smplsim_amd.envs import HumanoidEnv, HumanoidGetup, HumanoidReach, HumanoidSpeed  # noqa: F401

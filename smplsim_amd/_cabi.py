@@ -8,10 +8,10 @@ import ctypes as C
 
 import numpy as np
 
-TASK_BASE, TASK_SPEED, TASK_GETUP = 0, 1, 2
+TASK_BASE, TASK_SPEED, TASK_GETUP, TASK_REACH = 0, 1, 2, 3
 INIT_DEFAULT, INIT_FALL = 0, 1
 CTRL_UHC_PD, CTRL_PD, CTRL_TORQUE = 0, 1, 2
-TASKS = {"HumanoidEnv": TASK_BASE, "HumanoidSpeed": TASK_SPEED, "HumanoidGetup": TASK_GETUP}
+TASKS = {"HumanoidEnv": TASK_BASE, "HumanoidSpeed": TASK_SPEED, "HumanoidGetup": TASK_GETUP, "HumanoidReach": TASK_REACH}
 CONTROL_MODES = {"uhc_pd": CTRL_UHC_PD, "pd": CTRL_PD, "torque": CTRL_TORQUE}
 STATE_INITS = {"Default": INIT_DEFAULT, "Fall": INIT_FALL}
 
@@ -40,6 +40,7 @@ class EnvCfg(C.Structure):
         ("speed_change_max", C.c_int32),
         ("tar_height_min", C.c_float), ("tar_height_max", C.c_float), ("height_change_min", C.c_int32),
         ("height_change_max", C.c_int32), ("recovery_steps", C.c_int32), ("newton_iters", C.c_int32),
+        ("tar_dist_max", C.c_float), ("reach_body", C.c_int32),
     ]
 
 
@@ -109,7 +110,7 @@ def make_model_desc(mc, kp, kd, torque_lim, act_scale, act_offset, legal_bodies=
 def make_env_cfg(task=TASK_BASE, state_init=INIT_DEFAULT, self_obs_v=1, control_mode=CTRL_UHC_PD,
                  episode_length=300, control_freq_inv=15, root_height_obs=True, power_scale=1.0,
                  tar_speed=(0.0, 5.0), speed_change=(100, 200), tar_height=(0.5, 1.2), height_change=(100, 200),
-                 recovery_steps=60, newton_iters=8):
+                 recovery_steps=60, newton_iters=8, tar_dist_max=1.0, reach_body=0):
     return EnvCfg(task, state_init, self_obs_v, control_mode, episode_length, control_freq_inv, int(root_height_obs),
                   power_scale, tar_speed[0], tar_speed[1], speed_change[0], speed_change[1], tar_height[0],
-                  tar_height[1], height_change[0], height_change[1], recovery_steps, newton_iters)
+                  tar_height[1], height_change[0], height_change[1], recovery_steps, newton_iters, tar_dist_max, reach_body)

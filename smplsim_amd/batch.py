@@ -60,7 +60,8 @@ class SMPLSimVecEnv:
     def __init__(self, num_envs, model=None, device=0, task="HumanoidEnv", state_init="Default", self_obs_v=1,
                  control_mode="uhc_pd", episode_length=300, control_freq_inv=15, root_height_obs=True,
                  power_scale=1.0, tar_speed=(0.0, 5.0), speed_change=(100, 200), tar_height=(0.5, 1.2),
-                 height_change=(100, 200), recovery_steps=60, newton_iters=8, autoreset=True, seed=0, lpt_order=True,
+                 height_change=(100, 200), recovery_steps=60, tar_dist_max=1.0, reach_body="R_Hand", newton_iters=8,
+                 autoreset=True, seed=0, lpt_order=True,
                  **model_kw):
         if not torch.cuda.is_available():
             raise RuntimeError("SMPLSimVecEnv needs a ROCm GPU (MI355X); there is no CPU fallback")
@@ -75,7 +76,8 @@ class SMPLSimVecEnv:
             control_mode=_cabi.CONTROL_MODES[control_mode], episode_length=episode_length,
             control_freq_inv=control_freq_inv, root_height_obs=root_height_obs, power_scale=power_scale,
             tar_speed=tar_speed, speed_change=speed_change, tar_height=tar_height, height_change=height_change,
-            recovery_steps=recovery_steps, newton_iters=newton_iters)
+            recovery_steps=recovery_steps, newton_iters=newton_iters, tar_dist_max=tar_dist_max,
+            reach_body=mc.body_names.index(reach_body) if isinstance(reach_body, str) else int(reach_body))
         N, dev = self.num_envs, self.device
         f32 = dict(dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
@@ -112,7 +114,7 @@ class SMPLSimVecEnv:
     def _task_rand(self):
         if self.task_id == _cabi.TASK_BASE:
             return None
-        return torch.rand(self.num_envs, 2, generator=self.gen, device=self.device)
+        return torch.rand(self.num_envs, 4, generator=self.gen, device=self.device)
 
     def _fall_actions(self):
         if self.state_init != _cabi.INIT_FALL:

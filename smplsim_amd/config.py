@@ -36,6 +36,9 @@ ENV_CFGS = {
     "HumanoidGetup": dict(_ENV_COMMON, task="HumanoidGetup", state_init="Fall", recovery_steps=60, tar_height_min=0.5,
                           tar_height_max=1.2, height_change_steps_min=100, height_change_steps_max=200,
                           contact_bodies=["R_Ankle", "L_Ankle", "R_Toe", "L_Toe"]),
+    "HumanoidReach": dict(_ENV_COMMON, task="HumanoidReach", contact_bodies=["R_Ankle", "L_Ankle", "R_Toe", "L_Toe"],
+                          reach_body_name="R_Hand", tar_dist_max=1, tar_height_min=0.2, tar_height_max=2.0,
+                          tar_change_steps_min=50, tar_change_steps_max=100),
 }
 ROBOT_CFG = dict(humanoid_type="smpl", has_upright_start=False, has_shape_obs=False, has_weight_obs=False,
                  has_shape_variation=False, has_mesh=False, replace_feet=True, has_jt_limit=False,

@@ -71,6 +71,7 @@ struct ss_api {
       return fail(SS_ERR_INVALID, "every ss_state buffer must be provided");
     if (cfg->self_obs_v != 1 && cfg->self_obs_v != 2) return fail(SS_ERR_INVALID, "self_obs_v must be 1 or 2");
     if (cfg->control_freq_inv < 1) return fail(SS_ERR_INVALID, "control_freq_inv must be >= 1");
+    if (cfg->task == SS_TASK_REACH && (cfg->reach_body < 0 || cfg->reach_body >= m->hm.h.nb)) return fail(SS_ERR_INVALID, "reach_body out of range");
     const ss::Hdr &h = m->hm.h;
     const int dofp = (h.nv + 63) / 64, candp = (h.ncand + 63) / 64;
     if (dofp > 3 || candp > 3 || (h.nslot + 63) / 64 > 2) return fail(SS_ERR_INVALID, "model too large for the compiled kernel variants");

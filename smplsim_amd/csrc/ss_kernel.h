@@ -1034,7 +1034,7 @@ struct Sim {
   }
 
   // ------------------------------------------------------------------ observations (self_obs_v 1 / 2) + task tail
-  SS_DEV void write_obs(float *obs, float tar) {
+  SS_DEV void write_obs(float *obs, float tar, float tar_y, float tar_z) {
     const Hdr &h = k->h;
     const ss_env_cfg &cf = k->cfg;
     // heading from remove_base_rot(root quat): rotated x axis = third column of the root rotation
@@ -1079,6 +1079,10 @@ struct Sim {
     if (lane == 0) {
       if (cf.task == SS_TASK_SPEED) { obs[o] = ch; obs[o + 1] = -sh; obs[o + 2] = tar; }
       else if (cf.task == SS_TASK_GETUP) obs[o] = tar;
+      else if (cf.task == SS_TASK_REACH) {                  // heading^-1 (tar_pos - root_pos), humanoid_reach.py:21-30
+        const float dx = tar - q[0], dy = tar_y - q[1];
+        obs[o] = ch * dx + sh * dy; obs[o + 1] = -sh * dx + ch * dy; obs[o + 2] = tar_z - q[2];
+      }
     }
   }
 };
@@ -1108,13 +1112,16 @@ SS_DEV void run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env) 
   float *wg = st.qacc_warm + (size_t)env * h.nv;
   float *tk = st.task + (size_t)env * 4;
   const float *act = k->actions ? k->actions + (size_t)env * h.nu : nullptr;
-  const float *trand = k->task_rand ? k->task_rand + (size_t)env * 2 : nullptr;
+  const float *trand = k->task_rand ? k->task_rand + (size_t)env * 4 : nullptr;
   const float *fa = k->fall_actions ? k->fall_actions + (size_t)env * 3 * h.nu : nullptr;
   float *obs = k->obs ? k->obs + (size_t)env * k->obs_size : nullptr;
   const int maxit = cf.newton_iters > 0 ? cf.newton_iters : 8;
 
   int cur_t = st.cur_t[env];
-  float tar = tk[0], change = tk[1], recov = tk[2];
+  // task scalars: speed/getup [target, change_steps, recovery, -] ; reach [tx, ty, tz, change_steps]
+  const bool is_reach = cf.task == SS_TASK_REACH;
+  float tar = tk[0], tar_y = tk[1], tar_z = tk[2];
+  float change = is_reach ? tk[3] : tk[1], recov = is_reach ? 0.f : tk[2];
   int nsub = k->nsub;
   // StateInit.Fall draws action = U[0,1) - 0.5 (humanoid_env.py:487): the -0.5 is applied in the controller
   const float abias = (mode == MODE_RESET) ? -0.5f : 0.f;
@@ -1125,13 +1132,17 @@ SS_DEV void run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env) 
                         (mode == MODE_STEP && cf.task != SS_TASK_BASE && (float)cur_t >= change);
   if (mode == MODE_RESET && cf.task == SS_TASK_GETUP) recov = (float)cf.recovery_steps;
   if (resample) {                                            // uses the OLD cur_t on reset (reference quirk)
-    float u0 = trand ? trand[0] : 0.f, u1 = trand ? trand[1] : 0.f;
+    const float u0 = trand ? trand[0] : 0.f, u1 = trand ? trand[1] : 0.f, u2 = trand ? trand[2] : 0.f, u3 = trand ? trand[3] : 0.f;
     if (cf.task == SS_TASK_SPEED) {
       tar = (cf.tar_speed_max - cf.tar_speed_min) * u0 + cf.tar_speed_min;
       change = (float)(cur_t + cf.speed_change_min + (int)floorf(u1 * (float)(cf.speed_change_max - cf.speed_change_min)));
-    } else {
+    } else if (cf.task == SS_TASK_GETUP) {
       tar = (cf.tar_height_max - cf.tar_height_min) * u0 + cf.tar_height_min;
       change = (float)(cur_t + cf.height_change_min + (int)floorf(u1 * (float)(cf.height_change_max - cf.height_change_min)));
+    } else {                                                 // reach (humanoid_reach.py:81-92)
+      tar = cf.tar_dist_max * (2.f * u0 - 1.f); tar_y = cf.tar_dist_max * (2.f * u1 - 1.f);
+      tar_z = (cf.tar_height_max - cf.tar_height_min) * u2 + cf.tar_height_min;
+      change = (float)(cur_t + cf.height_change_min + (int)floorf(u3 * (float)(cf.height_change_max - cf.height_change_min)));
     }
   }
 
@@ -1252,7 +1263,7 @@ SS_DEV void run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env) 
 
   // ---- post_physics_step: cur_t, observation, reward, reset flags
   if (mode == MODE_STEP) cur_t += 1;
-  if (obs) sim.write_obs(obs, tar);
+  if (obs) sim.write_obs(obs, tar, tar_y, tar_z);
   if (lane == 0) {
     if (mode == MODE_STEP) {
       float rew = 0.f;
@@ -1269,13 +1280,19 @@ SS_DEV void run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env) 
         rew = expf(-4.f * diff * diff);
         if (recov > 0.f) { recov -= 1.f; term = 0; trunc = 0; }
         else term = illegal;
+      } else if (cf.task == SS_TASK_REACH) {                 // reach_reward on the reach body's world position
+        const float *rb = sim.r + 3 * cf.reach_body;
+        const float dx = tar - (sim.q[0] + rb[0]), dy = tar_y - (sim.q[1] + rb[1]), dz = tar_z - (sim.q[2] + rb[2]);
+        rew = expf(-4.f * (dx * dx + dy * dy + dz * dz));
+        term = illegal;
       }
       if (k->reward) k->reward[env] = rew;
       if (k->terminated) k->terminated[env] = (uint8_t)term;
       if (k->truncated) k->truncated[env] = (uint8_t)trunc;
     }
     st.cur_t[env] = cur_t;
-    tk[0] = tar; tk[1] = change; tk[2] = recov;
+    if (is_reach) { tk[0] = tar; tk[1] = tar_y; tk[2] = tar_z; tk[3] = change; }
+    else { tk[0] = tar; tk[1] = change; tk[2] = recov; }
   }
 }
 

@@ -347,7 +347,7 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
 inline int obs_size(const Hdr &h, const ss_env_cfg &c) {
   int nd = 3 * (h.nb - 1);
   int n = (c.root_height_obs ? 1 : 0) + nd + (c.self_obs_v == 1 ? 6 * h.nb + 6 + nd : 12 * h.nb);
-  if (c.task == SS_TASK_SPEED) n += 3;
+  if (c.task == SS_TASK_SPEED || c.task == SS_TASK_REACH) n += 3;
   if (c.task == SS_TASK_GETUP) n += 1;
   return n;
 }

@@ -1,1 +1,2 @@
-from .humanoid_env import HumanoidEnv, HumanoidGetup, HumanoidSpeed, HumanoidTask, SMPLSimGymVecEnv  # noqa: F401
+from .humanoid_env import (HumanoidEnv, HumanoidGetup, HumanoidReach, HumanoidSpeed, HumanoidTask,  # noqa: F401
+                           SMPLSimGymVecEnv)

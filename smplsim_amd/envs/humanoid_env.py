@@ -133,7 +133,7 @@ class HumanoidEnv:
         if v.state_init == 1:   # Fall: action = np_random.random(nu) - 0.5, three times (humanoid_env.py:485-488)
             fa = torch.as_tensor(self.np_random.random((v.num_envs, 3, v.nu)), dtype=torch.float32, device=v.device)
         if v.task_id != 0:      # task targets use the global numpy RNG in the reference (humanoid_speed.py:97-103)
-            tr = torch.as_tensor(np.random.random((v.num_envs, 2)), dtype=torch.float32, device=v.device)
+            tr = torch.as_tensor(np.random.random((v.num_envs, 4)), dtype=torch.float32, device=v.device)
         return fa, tr
 
     def reset(self, seed=None, options=None):
@@ -204,6 +204,17 @@ class HumanoidGetup(HumanoidTask):
         return 1
 
 
+class HumanoidReach(HumanoidTask):
+    _TASK = "HumanoidReach"
+
+    def _task_kwargs(self, e):
+        return dict(tar_height=(e.tar_height_min, e.tar_height_max), tar_dist_max=e.tar_dist_max,
+                    height_change=(e.tar_change_steps_min, e.tar_change_steps_max), reach_body=e.reach_body_name)
+
+    def get_task_obs_size(self):
+        return 3
+
+
 class SMPLSimGymVecEnv:
     """numpy-in / numpy-out vector env with the attributes `examples/benchmark.py:97-116` touches on a
     `gym.vector` env (`num_envs`, `action_space.sample()`, `reset(seed=)`, `step(actions=)`), backed by one
@@ -211,7 +222,8 @@ class SMPLSimGymVecEnv:
 
     def __init__(self, cfg, num_envs, device=0, autoreset=True):
         import torch
-        cls = {"HumanoidEnv": HumanoidEnv, "HumanoidSpeed": HumanoidSpeed, "HumanoidGetup": HumanoidGetup}[cfg.env.task]
+        cls = {"HumanoidEnv": HumanoidEnv, "HumanoidSpeed": HumanoidSpeed, "HumanoidGetup": HumanoidGetup,
+               "HumanoidReach": HumanoidReach}[cfg.env.task]
         self._single = cls(cfg, device=device, num_envs=num_envs)
         self._vec = self._single._vec
         self._vec.autoreset = autoreset

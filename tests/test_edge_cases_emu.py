@@ -98,7 +98,7 @@ def test_speed_task_termination_and_truncation_flags_match_oracle():
     om = oracle_model()
     eb = _batch(1, task=_cabi.TASK_SPEED, episode_length=40)
     env = O.OracleEnv(om, task=O.TASK_SPEED, episode_length=40)
-    tr = [0.3, 0.6]
+    tr = [0.3, 0.6, 0.0, 0.0]
     env.reset(task_rand=tr); eb.reset(task_rand=[tr])
     rs = np.random.default_rng(0)
     first_term = None

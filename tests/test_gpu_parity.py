@@ -74,14 +74,15 @@ def test_free_running_rollout_tracks_oracle(vec):
     assert worst[0] < 2 * TOL_QPOS and worst[1] < TOL_QVEL and worst[2] < TOL_OBS, worst
 
 
-@pytest.mark.parametrize("task,init", [("HumanoidSpeed", "Default"), ("HumanoidGetup", "Fall")])
+@pytest.mark.parametrize("task,init", [("HumanoidSpeed", "Default"), ("HumanoidGetup", "Fall"), ("HumanoidReach", "Default")])
 def test_task_envs_teacher_forced(vec, task, init):
     from smplsim_amd import _cabi
     om = oracle_model()
-    env = vec(4, task=task, state_init=init, autoreset=False)
-    oenv = O.OracleEnv(om, task=_cabi.TASKS[task], state_init=_cabi.STATE_INITS[init])
+    kw = dict(tar_dist_max=1.0, tar_height=(0.2, 2.0), height_change=(50, 100)) if task == "HumanoidReach" else {}
+    env = vec(4, task=task, state_init=init, autoreset=False, **kw)
+    oenv = O.OracleEnv(om, task=_cabi.TASKS[task], state_init=_cabi.STATE_INITS[init], reach_body=23, **kw)
     rs = np.random.default_rng(3)
-    fa, tr = rs.uniform(size=(3, 69)), rs.uniform(size=2)
+    fa, tr = rs.uniform(size=(3, 69)), rs.uniform(size=4)
     dev = env.device
     T = lambda x: torch.tensor(np.tile(np.asarray(x)[None], (4,) + (1,) * np.asarray(x).ndim), device=dev, dtype=torch.float32)
     o_ref = oenv.reset(fall_actions=fa, task_rand=tr)
@@ -90,7 +91,7 @@ def test_task_envs_teacher_forced(vec, task, init):
     assert np.abs(o_ref - _np(obs)[0]).max() < TOL_OBS
     for i in range(12):
         env.set_state(np.tile(oenv.data.qpos, (4, 1)), np.tile(oenv.data.qvel, (4, 1)), env.qpos_prev, env.qvel_prev)
-        a, tr = rs.uniform(-0.5, 0.5, 69), rs.uniform(size=2)
+        a, tr = rs.uniform(-0.5, 0.5, 69), rs.uniform(size=4)
         o_ref, r, te, tu = oenv.step(a, task_rand=tr)
         obs, rew, term, trunc, _ = env.step(T(a), task_rand=T(tr))
         assert np.abs(_np(env.qpos)[0] - oenv.data.qpos).max() < TOL_QPOS

@@ -66,24 +66,26 @@ def test_free_running_rollout_tracks_oracle():
     assert worst[0] < 2e-4 and worst[1] < 5e-3 and worst[2] < 5e-3, worst
 
 
-@pytest.mark.parametrize("task,init", [(O.TASK_SPEED, O.INIT_DEFAULT), (O.TASK_GETUP, O.INIT_FALL)])
+@pytest.mark.parametrize("task,init", [(O.TASK_SPEED, O.INIT_DEFAULT), (O.TASK_GETUP, O.INIT_FALL), (O.TASK_REACH, O.INIT_DEFAULT)])
 def test_task_envs_teacher_forced(task, init):
     """Speed / getup tasks incl. the Fall reset (45 warm-up mj_steps): per-step map with the kernel state
     re-synchronised to the oracle's every step (teacher forcing)."""
     om = oracle_model()
-    eb = _batch(1, task=task, state_init=init)
-    env = O.OracleEnv(om, task=task, state_init=init)
+    kw = dict(reach_body=23, tar_dist_max=1.0, tar_height=(0.2, 2.0), height_change=(50, 100)) if task == O.TASK_REACH else {}
+    eb = _batch(1, task=task, state_init=init, **kw)
+    env = O.OracleEnv(om, task=task, state_init=init, **kw)
     rs = np.random.default_rng(3)
-    fa, tr = rs.uniform(size=(3, 69)), rs.uniform(size=2)
+    fa, tr = rs.uniform(size=(3, 69)), rs.uniform(size=4)
     o_ref = env.reset(fall_actions=fa, task_rand=tr)
     o_emu = eb.reset(fall_actions=fa[None], task_rand=tr[None])[0]
     assert np.abs(eb.qpos[0] - env.data.qpos).max() < 2e-4
     assert np.abs(o_ref - o_emu).max() < 5e-3
-    assert np.allclose(eb.task[0, :3], env.get_task()[1:4])
+    t = env.get_task()
+    assert np.allclose(eb.task[0], [t[1], t[7], t[8], t[2]] if task == O.TASK_REACH else [t[1], t[2], t[3], 0])
     for i in range(12):
         # teacher forcing: the oracle's current state + the state of its last forward + warm start
         eb.set_state(env.data.qpos, env.data.qvel, eb.qpos_prev, eb.qvel_prev)
-        a, tr = rs.uniform(-0.5, 0.5, 69), rs.uniform(size=2)
+        a, tr = rs.uniform(-0.5, 0.5, 69), rs.uniform(size=4)
         o_ref, r, te, tu = env.step(a, task_rand=tr)
         o_emu, r2, te2, tu2 = eb.step(a[None], task_rand=tr[None])
         assert np.abs(eb.qpos[0] - env.data.qpos).max() < 1e-4

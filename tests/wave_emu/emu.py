@@ -28,6 +28,15 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def _rand4(tr, n):
+    if tr is None:
+        return None
+    t = np.zeros((n, 4), np.float32)
+    a = np.asarray(tr, np.float32).reshape(n, -1)
+    t[:, :a.shape[1]] = a
+    return t
+
+
 class EmuBatch:
     def __init__(self, mc, tables, num_envs, legal_bodies=(), timestep=1.0 / 450, **cfg):
         L = lib()
@@ -69,13 +78,13 @@ class EmuBatch:
     def reset(self, mask=None, fall_actions=None, task_rand=None):
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
         fa = None if fall_actions is None else np.ascontiguousarray(fall_actions, np.float32)
-        tr = None if task_rand is None else np.ascontiguousarray(task_rand, np.float32)
+        tr = _rand4(task_rand, self.N)
         self._chk(lib().ss_reset(self.batch, _p(m), _p(fa), _p(tr), _p(self.obs), None))
         return self.obs.copy()
 
     def step(self, actions, task_rand=None):
         a = np.ascontiguousarray(actions, np.float32)
-        tr = None if task_rand is None else np.ascontiguousarray(task_rand, np.float32)
+        tr = _rand4(task_rand, self.N)
         self._chk(lib().ss_step(self.batch, _p(a), _p(tr), _p(self.obs), _p(self.reward), _p(self.terminated),
                                 _p(self.truncated), None))
         return self.obs.copy(), self.reward.copy(), self.terminated.copy().astype(bool), self.truncated.copy().astype(bool)
