@@ -70,6 +70,8 @@ class SMPLSimVecEnv:
         self.num_envs, self.device = int(num_envs), torch.device("cuda", self.model.device)
         self.nq, self.nv, self.nu, self.nbody = mc.nq, mc.nv, mc.nu, mc.nbody
         self.task_id = _cabi.TASKS[task] if isinstance(task, str) else int(task)
+        if self.task_id == _cabi.TASK_REACH and isinstance(reach_body, str) and reach_body not in mc.body_names:
+            raise ValueError(f"reach_body {reach_body!r} is not a body of this model")
         self.state_init = _cabi.STATE_INITS[state_init] if isinstance(state_init, str) else int(state_init)
         self.cfg = _cabi.make_env_cfg(
             task=self.task_id, state_init=self.state_init, self_obs_v=self_obs_v,
@@ -77,7 +79,7 @@ class SMPLSimVecEnv:
             control_freq_inv=control_freq_inv, root_height_obs=root_height_obs, power_scale=power_scale,
             tar_speed=tar_speed, speed_change=speed_change, tar_height=tar_height, height_change=height_change,
             recovery_steps=recovery_steps, newton_iters=newton_iters, tar_dist_max=tar_dist_max,
-            reach_body=mc.body_names.index(reach_body) if isinstance(reach_body, str) else int(reach_body))
+            reach_body=self._body_index(mc, reach_body))
         N, dev = self.num_envs, self.device
         f32 = dict(dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
@@ -109,6 +111,14 @@ class SMPLSimVecEnv:
         # autocorrelated from one control step to the next (scheduling only; results do not depend on it)
         self.lpt_order = bool(lpt_order) and N > 64
         self.order = torch.arange(N, dtype=torch.int32, device=dev)
+
+    @staticmethod
+    def _body_index(mc, body):
+        if not isinstance(body, str):
+            return int(body)
+        if body in mc.body_names:
+            return mc.body_names.index(body)
+        return 0   # e.g. SMPL-X has no R_Hand body; only the reach task reads this field (checked there)
 
     # ---- random inputs the reference draws from np.random inside the env (targets, Fall actions)
     def _task_rand(self):
