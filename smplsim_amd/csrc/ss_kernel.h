@@ -53,6 +53,8 @@ enum { PF_FWD = 0, PF_CONS, PF_NBEGIN, PF_NPREP, PF_ASM, PF_FACTOR, PF_SOLVE, PF
 #define SS_FTICK(id) do {} while (0)
 #endif
 
+struct alignas(16) float4_t { float x, y, z, w; };
+
 struct Contact {
   float rx, ry, rz;      // contact point relative to the root origin
   float t1x, t1y;        // first tangent (unit, in the floor plane); second = (-t1y, t1x)
@@ -61,9 +63,10 @@ struct Contact {
   int body, active;
 };
 struct Limit { float sign, D, aref, jar, jd; };
-struct alignas(16) float4_t { float x, y, z, w; };
 
 SS_DEV float bits2f(uint32_t u) { union { uint32_t u; float f; } c; c.u = u; return c.f; }
+SS_DEV float4_t ld4(const float *p) { return *reinterpret_cast<const float4_t *>(p); }      // 16-byte aligned LDS row
+SS_DEV void st4(float *p, float a, float b, float c) { float4_t v; v.x = a; v.y = b; v.z = c; v.w = 0.f; *reinterpret_cast<float4_t *>(p) = v; }
 SS_DEV bool is_bad(float x) { return !(x <= 1e10f && x >= -1e10f); }
 
 template <class W, int DOFP, int CANDP, int SLOTP>
@@ -536,13 +539,14 @@ struct Sim {
     }
     w->sync();
     for (int e = lane; e < h.nblk; e += 64) {
-      const int w0 = ti(h.o_blk, 2 * e), w1 = ti(h.o_blk, 2 * e + 1);
-      const int aJ = w0 & 255, n = (w0 >> 8) & 255, dst = w1 & 0xFFFF, Wd = w1 >> 16;
+      const int w0 = ti(h.o_blk, 2 * e), boff = ti(h.o_blk, 2 * e + 1);
+      const int aJ = w0 & 255, n = (w0 >> 8) & 255;
       const bool dg = (w0 >> 16) & 1;
       const float *sj = S + 18 * aJ, *gi = G + 18 * n;
       float sv_[18], gv_[18];
 #pragma unroll
       for (int t = 0; t < 18; t++) { sv_[t] = sj[t]; gv_[t] = gi[t]; }
+      float o_[9];
 #pragma unroll
       for (int r_ = 0; r_ < 3; r_++) {
 #pragma unroll
@@ -550,67 +554,62 @@ struct Sim {
           float acc = 0.f;
 #pragma unroll
           for (int t = 0; t < 6; t++) acc += sv_[6 * c + t] * gv_[6 * r_ + t];
-          if (dg && r_ == c) acc += diag[3 * n + r_];
-          H[dst + r_ * Wd + c] = acc;
+          o_[3 * r_ + c] = acc;
         }
       }
+      if (dg) { o_[0] += diag[3 * n]; o_[4] += diag[3 * n + 1]; o_[8] += diag[3 * n + 2]; }
+      float *hb = H + boff;
+      st4(hb, o_[0], o_[1], o_[2]); st4(hb + 4, o_[3], o_[4], o_[5]); st4(hb + 8, o_[6], o_[7], o_[8]);
     }
     w->sync();
   }
 
   // ------------------------------------------------------------------ level-parallel 3x3-block L^T D L
   // H = L^T D L with unit block-lower-triangular L on the tree pattern; node k at depth d couples to its
-  // d ancestor nodes through the 3 x 3d block row P_k.  Per level (deepest first):
-  //   phase 1  Dinv_k = inv(diag block), U_k = Dinv_k P_k
-  //   phase 2  ancestor blocks (I >= J) -= P_k[:,I]^T U_k[:,J]      (LDS float atomics: nodes of one
-  //            level in different branches update the same ancestor blocks)
-  //   phase 3  P_k <- U_k (rows of L)
-  // also applies x <- L^-T x (the leaves-to-root sweep of the solve) level by level: at level L the entries of the
-  // level's nodes are final, and U_k is at hand in the U buffer
+  // d ancestor nodes through the blocks P_k[:, J].  H is stored block-major, 3 rows x 4 floats per block, so a
+  // block row is one 16-byte LDS access at (table offset + immediate).  Per level (deepest first), two phases:
+  //   A  Dinv_k = inv(diag block); U_k = Dinv_k P_k is written in place (rows of L); P_k is parked in a scratch
+  //      buffer for phase B
+  //   B  every ancestor block (I >= J) with descendants at this level -= sum_k P_k[:,I]^T U_k[:,J]  ("pull": one lane
+  //      owns one target block, so no LDS atomics), and x_anc -= sum_k U_k[:,J]^T x_k — the leaves-to-root sweep of
+  //      the solve, fused in because x_k is final once its level is reached.
+  // A lone wavefront pays ~14 ticks per LDS instruction and ~8 per dependent VALU instruction (profiles/r01g), and
+  // launch time is the serial time of the slowest env, so this code minimises instructions on the serial path.
+  SS_DEV static float rcp_nr(float x) {                      // 1/x: hardware reciprocal + one Newton step
+#if defined(__HIPCC__)
+    float r = __builtin_amdgcn_rcpf(x);
+#else
+    float r = 1.0f / x;
+#endif
+    return r * (2.0f - x * r);
+  }
+
   SS_DEV void factor_H(float *x) {
     const Hdr &h = k->h;
-    // U is double-buffered in G (free between assembly and the next one) so that "P_k <- U_k" of level L+1
-    // shares a phase with "U = Dinv P" of level L
+    float *Pb = G;                                           // G is free between assembly and the next one
     SS_FT0();
     for (int L = h.nlev - 1; L >= 0; --L) {
-      const int D = 3 * L, Wd = D + 3;
-      float *U = G + (L & 1) * h.maxU;
-      if (L + 1 < h.nlev) {                                  // phase 3 of the level below: rows of L
-        const int Dn = D + 3, Wn = Dn + 3;
-        const float *Un = G + ((L + 1) & 1) * h.maxU;
-        const int i0 = h.itemA[L + 1], ni = h.itemA[L + 2] - i0;
-        for (int idx = lane; idx < ni; idx += 64) {
-          const int it = ti(h.o_itemA, i0 + idx), base = it & 4095, J = (it >> 24) & 15, kk = (it >> 28) & 15;
-          float *pb = H + base + 3 * J;
-          const float *ub = Un + (kk * 3) * Dn + 3 * J;
-#pragma unroll
-          for (int r_ = 0; r_ < 3; r_++) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) pb[r_ * Wn + c] = ub[r_ * Dn + c];
-          }
-        }
-      }
-      {                                                      // phase 1: Dinv_k, U_k = Dinv_k P_k
+      {                                                      // phase A
         const int i0 = h.itemA[L], ni = h.itemA[L + 1] - i0;
         for (int idx = lane; idx < ni; idx += 64) {
-          const int it = ti(h.o_itemA, i0 + idx), base = it & 4095, n = (it >> 12) & 63, J = (it >> 24) & 15, kk = (it >> 28) & 15;
-          const float *db = H + base + D;
-          float d00 = db[0], d10 = db[Wd], d11 = db[Wd + 1], d20 = db[2 * Wd], d21 = db[2 * Wd + 1], d22 = db[2 * Wd + 2];
-          float c00 = d11 * d22 - d21 * d21, c01 = d21 * d20 - d10 * d22, c02 = d10 * d21 - d11 * d20;
-          float id = 1.f / (d00 * c00 + d10 * c01 + d20 * c02);
-          float i00 = c00 * id, i01 = c01 * id, i02 = c02 * id;
-          float i11 = (d00 * d22 - d20 * d20) * id, i12 = (d10 * d20 - d00 * d21) * id, i22 = (d00 * d11 - d10 * d10) * id;
+          const int it = ti(h.o_itemA, i0 + idx), boff = it & 8191, n = (it >> 13) & 63, J = (it >> 19) & 15, kk = (it >> 23) & 15;
+          float *pb = H + boff;
+          const float *db = pb + 12 * (L - J);               // diagonal block of the same node
+          const float4_t d0 = ld4(db), d1 = ld4(db + 4), d2 = ld4(db + 8);
+          float4_t p0 = d0, p1 = d1, p2 = d2;
+          if (L > 0) { p0 = ld4(pb); p1 = ld4(pb + 4); p2 = ld4(pb + 8); }
+          const float d00 = d0.x, d10 = d1.x, d11 = d1.y, d20 = d2.x, d21 = d2.y, d22 = d2.z;
+          const float c00 = d11 * d22 - d21 * d21, c01 = d21 * d20 - d10 * d22, c02 = d10 * d21 - d11 * d20;
+          const float id = rcp_nr(d00 * c00 + d10 * c01 + d20 * c02);
+          const float i00 = c00 * id, i01 = c01 * id, i02 = c02 * id;
+          const float i11 = (d00 * d22 - d20 * d20) * id, i12 = (d10 * d20 - d00 * d21) * id, i22 = (d00 * d11 - d10 * d10) * id;
           if (J == 0) { float *o = Dinv + 6 * n; o[0] = i00; o[1] = i01; o[2] = i02; o[3] = i11; o[4] = i12; o[5] = i22; }
           if (L > 0) {
-            const float *pb = H + base + 3 * J;
-            float *ub = U + (kk * 3) * D + 3 * J;
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-              float p0 = pb[c], p1 = pb[Wd + c], p2 = pb[2 * Wd + c];
-              ub[c] = i00 * p0 + i01 * p1 + i02 * p2;
-              ub[D + c] = i01 * p0 + i11 * p1 + i12 * p2;
-              ub[2 * D + c] = i02 * p0 + i12 * p1 + i22 * p2;
-            }
+            float *qb = Pb + (kk * L + J) * 12;
+            st4(qb, p0.x, p0.y, p0.z); st4(qb + 4, p1.x, p1.y, p1.z); st4(qb + 8, p2.x, p2.y, p2.z);
+            st4(pb, i00 * p0.x + i01 * p1.x + i02 * p2.x, i00 * p0.y + i01 * p1.y + i02 * p2.y, i00 * p0.z + i01 * p1.z + i02 * p2.z);
+            st4(pb + 4, i01 * p0.x + i11 * p1.x + i12 * p2.x, i01 * p0.y + i11 * p1.y + i12 * p2.y, i01 * p0.z + i11 * p1.z + i12 * p2.z);
+            st4(pb + 8, i02 * p0.x + i12 * p1.x + i22 * p2.x, i02 * p0.y + i12 * p1.y + i22 * p2.y, i02 * p0.z + i12 * p1.z + i22 * p2.z);
           }
         }
       }
@@ -618,51 +617,40 @@ struct Sim {
       w->sync();
       SS_FTICK(PF_F_SYNC1);
       if (L == 0) break;
-      {                                                      // phase 2: ancestor blocks (I >= J) -= sum_k P_k[:,I]^T U_k[:,J]
+      {                                                      // phase B, block updates
         const int i0 = h.itemB[L], ni = h.itemB[L + 1] - i0;
         for (int idx = lane; idx < ni; idx += 64) {
-          const int w0 = ti(h.o_itemB, 2 * (i0 + idx)), w1 = ti(h.o_itemB, 2 * (i0 + idx) + 1);
+          const int w0 = ti(h.o_itemB, 2 * (i0 + idx)), s0 = ti(h.o_itemB, 2 * (i0 + idx) + 1);
           float *dst = H + (w0 & 0xFFFF);
-          const int Wa = w0 >> 16, s0 = w1 & 0xFFFF, ns = w1 >> 16;
-          float acc[9];
-#pragma unroll
-          for (int t = 0; t < 9; t++) acc[t] = 0.f;
-          for (int si = 0; si < ns; si++) {                   // the level's nodes below this ancestor block (pull)
+          const int ns = w0 >> 16;
+          float4_t a0 = ld4(dst), a1 = ld4(dst + 4), a2 = ld4(dst + 8);
+          for (int si = 0; si < ns; si++) {                   // the level's nodes below this ancestor block
             const int src = ti(h.o_fsrc, s0 + si);
-            const float *pb = H + (src & 0xFFFF), *ub = U + (src >> 16);
-            float P_[9], U_[9];
-#pragma unroll
-            for (int r_ = 0; r_ < 3; r_++) {
-#pragma unroll
-              for (int c = 0; c < 3; c++) { P_[3 * r_ + c] = pb[r_ * Wd + c]; U_[3 * r_ + c] = ub[r_ * D + c]; }
-            }
-#pragma unroll
-            for (int a_ = 0; a_ < 3; a_++) {
-#pragma unroll
-              for (int b_ = 0; b_ < 3; b_++) acc[3 * a_ + b_] += P_[a_] * U_[b_] + P_[3 + a_] * U_[3 + b_] + P_[6 + a_] * U_[6 + b_];
-            }
+            const float *pq = Pb + (src & 0xFFFF), *ub = H + (src >> 16);
+            const float4_t p0 = ld4(pq), p1 = ld4(pq + 4), p2 = ld4(pq + 8);
+            const float4_t u0 = ld4(ub), u1 = ld4(ub + 4), u2 = ld4(ub + 8);
+            a0.x -= p0.x * u0.x + p1.x * u1.x + p2.x * u2.x; a0.y -= p0.x * u0.y + p1.x * u1.y + p2.x * u2.y; a0.z -= p0.x * u0.z + p1.x * u1.z + p2.x * u2.z;
+            a1.x -= p0.y * u0.x + p1.y * u1.x + p2.y * u2.x; a1.y -= p0.y * u0.y + p1.y * u1.y + p2.y * u2.y; a1.z -= p0.y * u0.z + p1.y * u1.z + p2.y * u2.z;
+            a2.x -= p0.z * u0.x + p1.z * u1.x + p2.z * u2.x; a2.y -= p0.z * u0.y + p1.z * u1.y + p2.z * u2.y; a2.z -= p0.z * u0.z + p1.z * u1.z + p2.z * u2.z;
           }
-#pragma unroll
-          for (int a_ = 0; a_ < 3; a_++) {
-#pragma unroll
-            for (int b_ = 0; b_ < 3; b_++) dst[a_ * Wa + b_] -= acc[3 * a_ + b_];
-          }
+          st4(dst, a0.x, a0.y, a0.z); st4(dst + 4, a1.x, a1.y, a1.z); st4(dst + 8, a2.x, a2.y, a2.z);
         }
         SS_FTICK(PF_F_P2);
         const int j0 = h.bsol[L], nj = h.bsol[L + 1] - j0;    // x_anc -= sum_k U_k[:,J]^T x_k   (pull per ancestor node)
         for (int idx = lane; idx < nj; idx += 64) {
-          const int aJ = ti(h.o_bsol, 2 * (j0 + idx)), w1 = ti(h.o_bsol, 2 * (j0 + idx) + 1);
-          const int s0 = w1 & 0xFFFF, ns = w1 >> 16;
-          float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+          const int w0 = ti(h.o_bsol, 2 * (j0 + idx)), s0 = ti(h.o_bsol, 2 * (j0 + idx) + 1);
+          const int aJ = w0 & 255, ns = w0 >> 8;
+          float b0 = x[3 * aJ], b1 = x[3 * aJ + 1], b2 = x[3 * aJ + 2];
           for (int si = 0; si < ns; si++) {
             const int src = ti(h.o_bsrc, s0 + si), n = src >> 16;
-            const float *ub = U + (src & 0xFFFF);
+            const float *ub = H + (src & 0xFFFF);
+            const float4_t u0 = ld4(ub), u1 = ld4(ub + 4), u2 = ld4(ub + 8);
             const float z0 = x[3 * n], z1 = x[3 * n + 1], z2 = x[3 * n + 2];
-            a0 += ub[0] * z0 + ub[D] * z1 + ub[2 * D] * z2;
-            a1 += ub[1] * z0 + ub[D + 1] * z1 + ub[2 * D + 1] * z2;
-            a2 += ub[2] * z0 + ub[D + 2] * z1 + ub[2 * D + 2] * z2;
+            b0 -= u0.x * z0 + u1.x * z1 + u2.x * z2;
+            b1 -= u0.y * z0 + u1.y * z1 + u2.y * z2;
+            b2 -= u0.z * z0 + u1.z * z1 + u2.z * z2;
           }
-          x[3 * aJ] -= a0; x[3 * aJ + 1] -= a1; x[3 * aJ + 2] -= a2;
+          x[3 * aJ] = b0; x[3 * aJ + 1] = b1; x[3 * aJ + 2] = b2;
         }
         SS_FTICK(PF_F_BSOL);
       }
@@ -671,10 +659,9 @@ struct Sim {
     }
   }
 
-  // finish H x = b after factor_H(x): x <- L^-1 D^-1 x; `tmp` = scratch for the forward sweep's partial products
-  SS_DEV void solve_H(float *x, float *tmp) {
+  // finish H x = b after factor_H(x): x <- L^-1 D^-1 x
+  SS_DEV void solve_H(float *x) {
     const Hdr &h = k->h;
-    // (x <- L^-T x was applied inside factor_H)
     if (lane < h.nn) {                                        // x <- D^-1 x
       const float *o = Dinv + 6 * lane;
       float x0 = x[3 * lane], x1 = x[3 * lane + 1], x2 = x[3 * lane + 2];
@@ -683,23 +670,19 @@ struct Sim {
       x[3 * lane + 2] = o[2] * x0 + o[4] * x1 + o[5] * x2;
     }
     w->sync();
-    for (int L = 1; L < h.nlev; L++) {                        // x <- L^-1 x (root to leaves)
-      const int Wd = 3 * L + 3, i0 = h.itemA[L], ni = h.itemA[L + 1] - i0;
-      for (int idx = lane; idx < ni; idx += 64) {             // partial products U_k[:,J] x_J, one item per (k, J)
-        const int it = ti(h.o_itemA, i0 + idx), base = it & 4095, aJ = (it >> 18) & 63, J = (it >> 24) & 15, kk = (it >> 28) & 15;
-        const float *ub = H + base + 3 * J;
-        const float y0 = x[3 * aJ], y1 = x[3 * aJ + 1], y2 = x[3 * aJ + 2];
-        float *o = tmp + (kk * L + J) * 3;
-#pragma unroll
-        for (int r_ = 0; r_ < 3; r_++) o[r_] = ub[r_ * Wd] * y0 + ub[r_ * Wd + 1] * y1 + ub[r_ * Wd + 2] * y2;
-      }
-      w->sync();
+    for (int L = 1; L < h.nlev; L++) {                        // x <- L^-1 x (root to leaves): one lane per (node, row)
       const int s = h.levstart[L], nk = h.levstart[L + 1] - s;
-      for (int idx = lane; idx < 3 * nk; idx += 64) {         // one lane per (k, row): sum the L partials
+      for (int idx = lane; idx < 3 * nk; idx += 64) {
         const int kk = idx / 3, r_ = idx - 3 * kk, n = ti(h.o_levnodes, s + kk);
-        float acc = 0.f;
-        for (int J = 0; J < L; J++) acc += tmp[(kk * L + J) * 3 + r_];
-        x[3 * n + r_] -= acc;
+        const float *ub = H + ti(h.o_nbase, n) + 4 * r_;
+        const int cn = h.o_chainnode + n * h.nlev;
+        float acc = x[3 * n + r_];
+        for (int J = 0; J < L; J++) {                         // independent reads: one 16-byte row of U and the ancestor's x
+          const int aJ = ti(cn, J);
+          const float4_t u = ld4(ub + 12 * J);
+          acc -= u.x * x[3 * aJ] + u.y * x[3 * aJ + 1] + u.z * x[3 * aJ + 2];
+        }
+        x[3 * n + r_] = acc;
       }
       w->sync();
     }
@@ -1223,7 +1206,7 @@ SS_DEV void run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env) 
       }
       sim.factor_H(sim.delta);
       SS_TICK(PF_FACTOR);
-      sim.solve_H(sim.delta, sim.G);
+      sim.solve_H(sim.delta);
       SS_TICK(PF_SOLVE);
       if (solve == SOLVE_SPD) { sim.spd_finish(); SS_TICK(PF_SPDFIN); break; }
       const bool conv = sim.newton_finish();

@@ -65,9 +65,11 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   for (int n = 0; n < nn; n++) nlev = std::max(nlev, ndepth[n] + 1);
   for (int b = 0; b < nb; b++) nblev = std::max(nblev, bdepth[b] + 1);
   h.nlev = nlev; h.nblev = nblev; h.maxD = 3 * (nlev - 1);
+  // H storage: node n at depth d owns d+1 blocks (J = 0..d-1 couple to its ancestors, J = d is the diagonal
+  // block), each 3 rows x 4 floats (one 16-byte row per ds_read_b128; the 4th float is padding)
   std::vector<int> nbase(nn);
   int ne = 0;
-  for (int n = 0; n < nn; n++) { nbase[n] = ne; ne += 3 * (3 * ndepth[n] + 3); }
+  for (int n = 0; n < nn; n++) { nbase[n] = ne; ne += 12 * (ndepth[n] + 1); }
   h.ne = ne;
   const int CW = h.maxD > 0 ? h.maxD : 1;                  // chain table row width (in dofs)
   const int CN = nlev;                                     // chain node table row width
@@ -75,22 +77,15 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   for (int n = 0; n < nn; n++) {
     std::vector<int> anc;                                  // root -> parent
     for (int a = nparent[n]; a >= 0; a = nparent[a]) anc.insert(anc.begin(), a);
-    for (size_t k = 0; k < anc.size(); k++) {
-      chainnode[n * CN + k] = anc[k];
-      int Wa = 3 * ndepth[anc[k]] + 3;
-      for (int r = 0; r < 3; r++) chainrow[n * CW + 3 * k + r] = nbase[anc[k]] + r * Wa;
-    }
+    for (size_t k = 0; k < anc.size(); k++) chainnode[n * CN + k] = anc[k];
     chainnode[n * CN + anc.size()] = n;                    // convenient: chain includes self at its depth
   }
-  std::vector<int> decode(ne);
-  for (int n = 0; n < nn; n++) {
-    int D = 3 * ndepth[n], W = D + 3;
-    for (int r = 0; r < 3; r++)
-      for (int j = 0; j < W; j++) {
-        int col = j < D ? 3 * chainnode[n * CN + j / 3] + j % 3 : 3 * n + (j - D);
-        decode[nbase[n] + r * W + j] = ((3 * n + r) << 16) | col;
-      }
-  }
+  std::vector<int> decode(ne, -1);                         // (row_dof << 16 | col_dof) per stored float, -1 = padding
+  for (int n = 0; n < nn; n++)
+    for (int J = 0; J <= ndepth[n]; J++)
+      for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++)
+          decode[nbase[n] + 12 * J + 4 * r + c] = ((3 * n + r) << 16) | (3 * chainnode[n * CN + J] + c);
   std::vector<int> levstart(nlev + 1, 0), levnodes, blevstart(nblev + 1, 0), blevbodies;
   for (int L = 0; L < nlev; L++) {
     levstart[L] = (int)levnodes.size();
@@ -189,30 +184,31 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   if (nlev > 19 || nblev > 19) { out.error = "tree too deep"; return false; }
   for (int L = 0; L <= nlev; L++) h.levstart[L] = levstart[L];
   for (int L = 0; L <= nblev; L++) h.blevstart[L] = blevstart[L];
-  // packed work-item records (one LDS read per item instead of a chain of dependent table reads):
-  //  blk   (assemble)           w0 = aJ | n<<8 | diag<<16      w1 = (base_n + 3J) | Wd<<16
-  //  itemA (U=Dinv P, copy, triangular sweeps), per level: base_k(12) | n(6)<<12 | aJ(6)<<18 | J(4)<<24 | kk(4)<<28
-  //  itemB (ancestor block update), per level:  w0 = (base_k + 3I) | (kk*3*D + 3J)<<16   w1 = (base_aI + 3J) | Wa<<16
+  // packed work-item records (one LDS read per item instead of a chain of dependent table reads); every block is
+  // addressed by its float offset into H (or into the scratch buffer of parked P blocks, 12 floats per block):
+  //  blk   (assemble)                 w0 = aJ | n<<8 | diag<<16            w1 = block(n,J)
+  //  itemA (phase A, per level)       block(k,J)(13b) | n(6)<<13 | J(4)<<19 | kk(4)<<23
+  //  itemB (phase B targets)          w0 = block(aI,J) | nsrc<<16          w1 = src_start
+  //        fsrc                       scratch block (kk*L + I)*12 | block(k,J)<<16
+  //  bsol  (fused leaves-to-root sweep targets)   w0 = aJ | nsrc<<8        w1 = src_start
+  //        bsrc                       block(k,J) | n_k<<16
   std::vector<int> blk, itemA, itemB, fsrc, bsol, bsrc, accp, children;
+  if (ne > 8191) { out.error = "H too large for the packed item tables"; return false; }
   for (int n = 0; n < nn; n++) for (int J = 0; J <= ndepth[n]; J++) {
-    int aJ = chainnode[n * CN + J], Wd = 3 * ndepth[n] + 3;
+    int aJ = chainnode[n * CN + J];
     blk.push_back(aJ | (n << 8) | ((aJ == n) << 16));
-    blk.push_back((nbase[n] + 3 * J) | (Wd << 16));
+    blk.push_back(nbase[n] + 12 * J);
   }
   h.nblk = (int)blk.size() / 2;
   for (int L = 0; L < nlev; L++) {
     h.itemA[L] = (int)itemA.size(); h.itemB[L] = (int)itemB.size() / 2;
-    int nk = levstart[L + 1] - levstart[L], D = 3 * L;
-    if (nk > 16 || L > 15 || ne > 4095) { out.error = "model exceeds the packed item-table field widths"; return false; }
+    int nk = levstart[L + 1] - levstart[L];
+    if (nk > 16 || L > 15) { out.error = "model exceeds the packed item-table field widths"; return false; }
     for (int kk = 0; kk < nk; kk++) {
       int n = levnodes[levstart[L] + kk];
-      for (int J = 0; J < std::max(L, 1); J++) {
-        int aJ = L > 0 ? chainnode[n * CN + J] : 0;
-        itemA.push_back(nbase[n] | (n << 12) | (aJ << 18) | (J << 24) | (kk << 28));
-      }
+      for (int J = 0; J < std::max(L, 1); J++)
+        itemA.push_back((nbase[n] + 12 * J) | (n << 13) | (J << 19) | (kk << 23));
     }
-    // itemB, pull form: one item per distinct target block (aI, J); its sources are the level-L nodes below aI
-    //   w0 = (base_aI + 3J) | Wa<<16     w1 = src_start | nsrc<<16     fsrc: (base_k + 3I) | (kk*3*D + 3J)<<16
     for (int I = 0; I < L; I++) for (int J = 0; J <= I; J++) {
       std::vector<int> seen;
       for (int kk = 0; kk < nk; kk++) {
@@ -224,14 +220,12 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
         for (int k2 = 0; k2 < nk; k2++) {
           int n2 = levnodes[levstart[L] + k2];
           if (chainnode[n2 * CN + I] != aI) continue;
-          fsrc.push_back((nbase[n2] + 3 * I) | ((k2 * 3 * D + 3 * J) << 16)); cnt++;
+          fsrc.push_back(((k2 * L + I) * 12) | ((nbase[n2] + 12 * J) << 16)); cnt++;
         }
-        itemB.push_back((nbase[aI] + 3 * J) | ((3 * I + 3) << 16));
-        itemB.push_back(start | (cnt << 16));
+        itemB.push_back((nbase[aI] + 12 * J) | (cnt << 16));
+        itemB.push_back(start);
       }
     }
-    // backward-solve targets: one per distinct ancestor node of the level's nodes
-    //   w0 = aJ      w1 = src_start | nsrc<<16      bsrc: (kk*3*D + 3J) | n_k<<16   (U buffer offset, node)
     h.bsol[L] = (int)bsol.size() / 2;
     for (int J = 0; J < L; J++) {
       std::vector<int> seen;
@@ -244,14 +238,14 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
         for (int k2 = 0; k2 < nk; k2++) {
           int n2 = levnodes[levstart[L] + k2];
           if (chainnode[n2 * CN + J] != aJ) continue;
-          bsrc.push_back((k2 * 3 * D + 3 * J) | (n2 << 16)); cnt++;       // U-buffer offset of U_k[:, J], node of z_k
+          bsrc.push_back((nbase[n2] + 12 * J) | (n2 << 16)); cnt++;
         }
-        bsol.push_back(aJ); bsol.push_back(start | (cnt << 16));
+        bsol.push_back(aJ | (cnt << 8)); bsol.push_back(start);
       }
     }
   }
+  h.itemA[nlev] = (int)itemA.size(); h.itemB[nlev] = (int)itemB.size() / 2;
   h.bsol[nlev] = (int)bsol.size() / 2;
-  if (fsrc.size() > 65535 || bsrc.size() > 65535) { out.error = "source tables too large"; return false; }
   // tree accumulation (children -> parent), pull form, per body level: p | cstart<<8 | ccount<<20
   for (int L = 0; L < nblev; L++) {
     h.accp[L] = (int)accp.size();
@@ -296,11 +290,11 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
     h.o_subsize = push_i(subsize);
   }
   h.shared_words = (int)S.size();
-  (void)chainrow; (void)nparent;
+  (void)chainrow; (void)nparent; (void)CW;
 
   // ---- per-env LDS layout (floats)
   int maxU = 0;                                            // U buffer: nodes-in-level * 3 * D
-  for (int L = 1; L < nlev; L++) maxU = std::max(maxU, (levstart[L + 1] - levstart[L]) * 9 * L);
+  for (int L = 1; L < nlev; L++) maxU = std::max(maxU, (levstart[L + 1] - levstart[L]) * 12 * L);
   if (nn > 64) { out.error = "too many nodes"; return false; }
   if (13 * h.nslot > ne) { out.error = "contact record buffer does not fit"; return false; }
   int o = 0;
@@ -316,8 +310,8 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   h.l_K = h.l_H + 21 * nb;                                 // Kc (subtree sums); inputs live at H[0 .. 21 nb)
   h.l_Gb = h.l_H + 42 * nb;
   h.l_S = take(6 * nv);
-  const int gneed = std::max(std::max(6 * nv, 2 * maxU), 18 * nb);
-  h.l_G = take(gneed);                                     // also the (double-buffered) U buffer of the factorization
+  const int gneed = std::max(std::max(6 * nv, maxU), 18 * nb);
+  h.l_G = take(gneed);                                     // also the scratch buffer of parked P blocks in the factorization
   h.maxU = maxU;
   h.l_R = h.l_G; h.l_r = h.l_G + 9 * nb;                   // R, r: first 12 nb floats of G
   h.l_Ad = h.l_G + gneed - 6 * nb;                         // Ad: last 6 nb floats of G (body_accel scratch uses G[0 .. 6 nn))

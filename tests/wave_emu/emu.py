@@ -109,8 +109,9 @@ class EmuBatch:
         self._chk(lib().ss_debug_forward(self.batch, _p(tq), _p(Me), _p(bias), _p(qacc), None))
         nv = self.mc.nv
         M = np.zeros((self.N, nv, nv), np.float32)
-        rows, cols = dec >> 16, dec & 0xFFFF
-        lower = rows >= cols
+        valid = dec >= 0                                       # -1 marks the padding float of each 16-byte block row
+        rows, cols = np.where(valid, dec >> 16, 0), np.where(valid, dec & 0xFFFF, 0)
+        lower = valid & (rows >= cols)
         M[:, rows[lower], cols[lower]] = Me[:, lower]
         M[:, cols[lower], rows[lower]] = Me[:, lower]
         return M, bias, qacc

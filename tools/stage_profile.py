@@ -21,7 +21,7 @@ subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-
 _lib._LIB = _cabi.bind(C.CDLL(prof_so))
 from smplsim_amd.batch import SMPLSimVecEnv
 
-N, steps = 4096, int(os.environ.get("STEPS", "30"))
+N, steps = int(os.environ.get("NENV", "4096")), int(os.environ.get("STEPS", "30"))
 env = SMPLSimVecEnv(N, autoreset=True, seed=1234)
 g = torch.Generator(device=env.device); g.manual_seed(1234)
 env.reset()
