@@ -144,6 +144,13 @@ def main():
     it_p50, it_p99, it_max = (float(it_sorted[int(q * (N - 1))].item()) for q in (0.5, 0.99, 1.0))
 
     if rank == 0:
+        # HBM bytes per step launch from the committed PMC passes of this same command (tools/gpu_prof.sh);
+        # PMC counters cannot be read from inside the process, so the figure is the profiled one or null
+        traffic, traffic_src = None, None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"hbm_traffic_{args.workload}.json")
+        if os.path.exists(tpath) and N == 4096:
+            tj = json.load(open(tpath))
+            traffic, traffic_src = tj["bytes_per_step_launch"], "profiles/" + os.path.basename(tpath)
         total_envs = N * world
         value = shard.whole_job_throughput(total_envs * args.steps, elapsed)
         bstep = algorithmic_bytes(env.nq, env.nv, env.nu, env.obs_size)
@@ -157,7 +164,8 @@ def main():
                        "launch": env.launch_info(), "mean_newton_iters_per_step": iters, "newton_iters_p50_p99_max": [it_p50, it_p99, it_max], "autoresets_total": nwarn,
                        "obs_finite": finite},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "ss_env_kernel<2,2> (MODE_STEP)", "kernel_ms": kern_ms,
+                         "traffic": traffic, "traffic_unit": "bytes per step launch", "traffic_source": traffic_src,
+                         "kernel": "ss_env_kernel (MODE_STEP)", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_env_step": bstep,
                          "note": "path is LDS-latency/VALU bound, not HBM bound (DESIGN.md §roofline)"},
         }

@@ -9,8 +9,14 @@
 #include "ss_api.h"
 #include "ss_kernel.h"
 
+// launch bounds per kernel variant = the number of envs whose LDS slices fit one CU, rounded up to whole waves per
+// SIMD.  SMPL: 10 envs -> 3 waves/SIMD -> 168-VGPR cap (7% faster than 8 envs at 256 VGPRs, at 3x the spill traffic:
+// profiles/r01i_ab_launch_bounds.txt).  SMPL-X: 3 envs fit -> 1 wave/SIMD, the whole 512-VGPR file, no spills.
 #ifndef SS_MAX_THREADS
-#define SS_MAX_THREADS 704   // 11 waves: LDS fits 11 SMPL envs per CU; 3 waves/SIMD caps the kernel at 168 VGPRs
+#define SS_MAX_THREADS 704
+#endif
+#ifndef SS_MAX_THREADS_X
+#define SS_MAX_THREADS_X 256
 #endif
 
 namespace {
@@ -31,6 +37,7 @@ struct WaveGpu {
   __device__ __forceinline__ unsigned long long clock() const { return __builtin_readcyclecounter(); }
   __device__ __forceinline__ void atomic_add_u64(unsigned long long *p, unsigned long long v) const { atomicAdd(p, v); }
   __device__ __forceinline__ int opaque(int x) const { return __builtin_amdgcn_readfirstlane(x); }   // wave-uniform, optimizer-opaque
+  __device__ __forceinline__ int opaque_v(int x) const { asm volatile("" : "+v"(x)); return x; }   // per-lane value, optimizer-opaque
   __device__ __forceinline__ float shfl_xor(float v, int m) const { return __shfl_xor(v, m, 64); }
   __device__ __forceinline__ int shfl_xor_i(int v, int m) const { return __shfl_xor(v, m, 64); }
   __device__ __forceinline__ unsigned long long ballot(int p) const { return __ballot(p); }
@@ -45,8 +52,8 @@ struct WaveGpu {
   }
 };
 
-template <int DOFP, int CANDP, int SLOTP>
-__global__ void __launch_bounds__(SS_MAX_THREADS) ss_env_kernel(const ss::KArgs k) {
+template <int DOFP, int CANDP, int SLOTP, int MAXT>
+__global__ void __launch_bounds__(MAXT) ss_env_kernel(const ss::KArgs k) {
   extern __shared__ __align__(16) uint32_t lds[];
   for (int i = threadIdx.x; i < k.h.shared_words; i += blockDim.x) lds[i] = k.shared_g[i];
   __syncthreads();
@@ -68,8 +75,8 @@ __global__ void __launch_bounds__(SS_MAX_THREADS) ss_env_kernel(const ss::KArgs 
 
 typedef void (*kern_t)(const ss::KArgs);
 kern_t pick_kernel(int dofp, int candp, int slotp) {
-  if (dofp == 2 && candp == 2 && slotp == 1) return ss_env_kernel<2, 2, 1>;      // SMPL layout (24 bodies)
-  if (dofp == 3 && candp <= 3 && slotp <= 2) return ss_env_kernel<3, 3, 2>;      // SMPL-X/H layout (52 bodies)
+  if (dofp == 2 && candp == 2 && slotp == 1) return ss_env_kernel<2, 2, 1, SS_MAX_THREADS>;      // SMPL layout (24 bodies)
+  if (dofp == 3 && candp <= 3 && slotp <= 2) return ss_env_kernel<3, 3, 2, SS_MAX_THREADS_X>;      // SMPL-X/H layout (52 bodies)
   return nullptr;
 }
 
@@ -81,6 +88,7 @@ struct HipBackend {
   static bool download(void *dst, const void *src, size_t n) { return hipMemcpy(dst, src, n, hipMemcpyDeviceToHost) == hipSuccess; }
   static int lds_capacity() { return 160 * 1024; }
   static int num_cus() { int d = 0, n = 256; if (hipGetDevice(&d) == hipSuccess) { hipDeviceProp_t p; if (hipGetDeviceProperties(&p, d) == hipSuccess) n = p.multiProcessorCount; } return n; }
+  static int max_waves(int dofp, int candp, int slotp) { return (dofp == 2 && candp == 2 && slotp == 1 ? SS_MAX_THREADS : SS_MAX_THREADS_X) / 64; }
   static int &regs_ref() { static int r = 0; return r; }
   static int kernel_regs() { return regs_ref(); }
   static const char *launch(const ss::KArgs &k, int nenv, int envs_per_wg, size_t lds_bytes, void *stream) {
@@ -101,7 +109,6 @@ struct HipBackend {
     const int resident = cus * (int)(lds_capacity() / lds_bytes > 0 ? lds_capacity() / lds_bytes : 1);
     if (wgs > resident) wgs = resident;                      // persistent: one resident set of workgroups
     if (hipMemsetAsync(k.work_counter, 0, sizeof(int32_t), (hipStream_t)stream) != hipSuccess) return "hipMemsetAsync failed";
-    if (64 * envs_per_wg > SS_MAX_THREADS) envs_per_wg = SS_MAX_THREADS / 64;
     dim3 grid(wgs), block(64 * envs_per_wg);
     hipLaunchKernelGGL(kern, grid, block, lds_bytes, (hipStream_t)stream, k);
     hipError_t e = hipGetLastError();

@@ -2,7 +2,7 @@
 // backend: the HIP backend in smplsim_hip.hip (the product) and the wavefront-emulator backend in
 // tests/wave_emu/emu.cpp (unit-test infrastructure).  A backend provides:
 //   static void *alloc(size_t);  static void free_(void *);  static bool upload(void *dst, const void *src, size_t);
-//   static int lds_capacity();   static const char *launch(const ss::KArgs &, int nenv, int envs_per_wg, size_t lds_bytes, void *stream);
+//   static int lds_capacity();   static int max_waves(int dofp, int candp, int slotp);   static const char *launch(const ss::KArgs &, int nenv, int envs_per_wg, size_t lds_bytes, void *stream);
 //   static bool set_device(int);
 #pragma once
 #include <cstdlib>
@@ -84,7 +84,7 @@ struct ss_api {
     int cap = BE::lds_capacity();
     int e = (int)((cap - (long)shared_b) / (long)env_b);
     if (e < 1) { delete b; return fail(SS_ERR_LDS, "model does not fit in LDS"); }
-    if (e > 16) e = 16;
+    { const int mw = BE::max_waves(dofp, candp, (h.nslot + 63) / 64); if (e > mw) e = mw; }   // launch bound of the kernel variant
     { const char *cap = getenv("SS_ENVS_PER_WG"); if (cap && atoi(cap) > 0 && atoi(cap) < e) e = atoi(cap); }
     b->envs_per_wg = e;
     b->lds_bytes = shared_b + (size_t)e * env_b;

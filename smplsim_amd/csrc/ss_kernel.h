@@ -116,6 +116,19 @@ struct Sim {
 #endif
   }
 
+  // lane id re-read through an optimizer-opaque move at the top of every stage: lane-derived LDS/table addresses
+  // are then recomputed per stage (a few VALU ops) instead of being hoisted out of the state machine and
+  // spilled to scratch for the whole launch
+  SS_DEV void fresh() { lane = w->opaque_v(lane); }
+  // constraint registers are rebuilt by make_constraints() of the same pass; clearing them at the top of a pass ends
+  // their live ranges there, so they do not occupy VGPRs (or scratch) across forward_kin
+  SS_DEV void drop_constraints() {
+#pragma unroll
+    for (int p = 0; p < SLOTP; p++) con[p] = Contact{};
+#pragma unroll
+    for (int p = 0; p < DOFP; p++) { lim[p] = Limit{}; perr[p] = 0.f; }
+  }
+
   // ------------------------------------------------------------------ HBM <-> LDS
   SS_DEV void load(float *dst, const float *src, int n) { for (int i = lane; i < n; i += 64) dst[i] = src[i]; }
   SS_DEV void store(float *dst, const float *src, int n) { for (int i = lane; i < n; i += 64) dst[i] = src[i]; }
@@ -176,6 +189,7 @@ struct Sim {
   // ------------------------------------------------------------------ kinematics + velocities + inertia + bias
   // with_dyn = false: positions/orientations only (observation FK)
   SS_DEV void forward_kin(bool with_dyn, bool write_sensors) {
+    fresh();
     const Hdr &h = k->h;
     float vb[6] = {0, 0, 0, 0, 0, 0}, ab[6] = {0, 0, 0, 0, 0, 0};
     float Rb[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, rb[3] = {0, 0, 0};
@@ -375,6 +389,7 @@ struct Sim {
 
   // ------------------------------------------------------------------ floor contacts + joint limits
   SS_DEV void make_constraints() {
+    fresh();
     const Hdr &h = k->h;
     const float pz = q[2], mu = h.mu;
     touchmask = 0ull;
@@ -516,6 +531,7 @@ struct Sim {
   // Hc = expand(Ic) + Kc (Kc must hold subtree sums, or zeros).  Work items are 3x3 blocks
   // (node n, chain position J <= depth(n)); block (n,J)[r][c] = S[3 aJ + c] . G[3 n + r].
   SS_DEV void assemble_H() {
+    fresh();
     const Hdr &h = k->h;
 #pragma unroll
     for (int p = 0; p < DOFP; p++) {
@@ -585,6 +601,7 @@ struct Sim {
   }
 
   SS_DEV void factor_H(float *x) {
+    fresh();
     const Hdr &h = k->h;
     float *Pb = G;                                           // G is free between assembly and the next one
     SS_FT0();
@@ -661,6 +678,7 @@ struct Sim {
 
   // finish H x = b after factor_H(x): x <- L^-1 D^-1 x
   SS_DEV void solve_H(float *x) {
+    fresh();
     const Hdr &h = k->h;
     if (lane < h.nn) {                                        // x <- D^-1 x
       const float *o = Dinv + 6 * lane;
@@ -715,6 +733,7 @@ struct Sim {
   // Newton on MuJoCo's convex primal problem, split so that the shared assemble/factor/solve site sits
   // between newton_prepare() and newton_finish() in the driver's solver loop.
   SS_DEV void newton_begin() {
+    fresh();
     body_accel(a, Ab, G);                                    // G is free outside assemble/factor
     w->sync();
     eval_rows(Ab, a, false);
@@ -722,6 +741,7 @@ struct Sim {
 
   // gradient (-> grad, delta = -grad), diagonal terms and the per-body contact matrices Kc
   SS_DEV void newton_prepare() {
+    fresh();
     const Hdr &h = k->h;
     const float mu = h.mu;
     iters++;
@@ -826,6 +846,7 @@ struct Sim {
 
   // exact line search along delta, step, active-set change detection; returns true when converged
   SS_DEV bool newton_finish() {
+    fresh();
     const Hdr &h = k->h;
     body_accel(delta, Ad, G);
     w->sync();
@@ -930,6 +951,7 @@ struct Sim {
   // Stable PD (reference controllers.py:116-190): (M + Kd dt) qdd = -C - Kp e - Kd v on the M, C of the
   // forward pass that is in LDS (the "stale" qM / qfrc_bias) with the current q, v
   SS_DEV void spd_prepare(const float *action, float abias) {
+    fresh();
     const Hdr &h = k->h;
     if (lane < h.nb) {
 #pragma unroll
@@ -949,6 +971,7 @@ struct Sim {
     w->sync();
   }
   SS_DEV void spd_finish() {
+    fresh();
     const Hdr &h = k->h;
 #pragma unroll
     for (int p = 0; p < DOFP; p++) {
@@ -968,6 +991,7 @@ struct Sim {
 
   // ------------------------------------------------------------------ semi-implicit Euler
   SS_DEV void integrate() {
+    fresh();
     const Hdr &h = k->h;
     const float dt = h.dt;
     if (lane == 0) {
@@ -1018,6 +1042,7 @@ struct Sim {
 
   // ------------------------------------------------------------------ observations (self_obs_v 1 / 2) + task tail
   SS_DEV void write_obs(float *obs, float tar, float tar_y, float tar_z) {
+    fresh();
     const Hdr &h = k->h;
     const ss_env_cfg &cf = k->cfg;
     // heading from remove_base_rot(root quat): rotated x axis = third column of the root rotation
@@ -1088,7 +1113,7 @@ SS_DEV void run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env) 
   if (k->mask && !k->mask[env]) return;
   Sim<W, DOFP, CANDP, SLOTP> sim;
   sim.init(w, k, T, L, env);
-  const int lane = sim.lane;
+  int lane = sim.lane;
   const int mode = k->mode;
   float *qg = st.qpos + (size_t)env * h.nq, *vg = st.qvel + (size_t)env * h.nv;
   float *qpg = st.qpos_prev + (size_t)env * h.nq, *vpg = st.qvel_prev + (size_t)env * h.nv;
@@ -1157,6 +1182,10 @@ SS_DEV void run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env) 
   for (;;) {
     // opaque(): keeps the optimizer from jump-threading the state variables (it would clone every stage per state)
     const int kind = w->opaque(s < 0 ? K_PROLOGUE : (s < nsub ? K_SUBSTEP : last_kind));
+    // opaque_v(): lane-derived LDS/table addresses are recomputed per pass instead of being hoisted out of the
+    // state machine and spilled to scratch for the whole launch
+    lane = sim.lane = w->opaque_v(sim.lane);
+    sim.drop_constraints();
     if (kind < 0) break;
     if (kind == K_SUBSTEP && !is_debug) {
       if (sim.any_bad(sim.q, h.nq) || sim.any_bad(sim.v, h.nv)) sim.reset_data();   // mj_checkPos / mj_checkVel
@@ -1186,6 +1215,7 @@ SS_DEV void run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env) 
     int it = 0;
     for (;;) {                                               // solver loop: one assemble/factor/solve site
       solve = w->opaque(solve);
+      lane = sim.lane = w->opaque_v(sim.lane);
       if (solve == SOLVE_NEWTON) { sim.newton_prepare(); SS_TICK(PF_NPREP); }
       else if (solve == SOLVE_SPD) {
         if (cf.control_mode != SS_CTRL_UHC_PD) { sim.simple_controller(next_action, abias); break; }

@@ -170,6 +170,7 @@ struct WaveEmu {
   }
   bool any(int p) { return ballot(p) != 0ull; }
   int opaque(int x) { volatile int y = x; return y; }
+  int opaque_v(int x) { volatile int y = x; return y; }
   unsigned long long clock() { return 0; }
   void atomic_add_u64(unsigned long long *p, unsigned long long v) { *p += v; }
   void atomic_add(float *p, float v) { *p += v; }
@@ -192,6 +193,7 @@ struct EmuBackend {
   static bool download(void *dst, const void *src, size_t n) { memcpy(dst, src, n); return true; }
   static int lds_capacity() { return 160 * 1024; }
   static int kernel_regs() { return 0; }
+  static int max_waves(int, int, int) { return 16; }
   static const char *launch(const ss::KArgs &k, int nenv, int envs_per_wg, size_t lds_bytes, void *) {
     (void)envs_per_wg; (void)lds_bytes;
     static thread_local Machine *m = new Machine();
