@@ -133,10 +133,9 @@ int ss_substep(ss_batch *b, const float *actions, int n_substeps, void *stream);
 int ss_kinematics(ss_batch *b, float *xpos, float *xmat, void *stream);
 
 /* Diagnostics for parity triage: one mj_forward at (qpos, qvel) with raw joint torques [N,nu] (NULL = 0);
- * writes the tree-sparse mass-matrix entries [N,ne] (mj_fullM's data before scattering), qfrc_bias [N,nv]
- * and the constrained qacc [N,nv].  ss_debug_decode returns for every sparse entry (row_dof << 16 | col_dof). */
-int ss_debug_forward(ss_batch *b, const float *torques, float *M_entries, float *bias, float *qacc, void *stream);
-int ss_debug_decode(const ss_model *m, int32_t *out, int32_t *ne);
+ * writes the dense joint-space mass matrix [N,nv,nv] (what mj_fullM returns; the stepping path itself never forms
+ * it), qfrc_bias [N,nv] and the constrained qacc [N,nv]. */
+int ss_debug_forward(ss_batch *b, const float *torques, float *M, float *bias, float *qacc, void *stream);
 /* -DSS_PROFILE builds only: accumulated shader-clock ticks per kernel stage (tools/stage_profile.py) */
 int ss_debug_prof(ss_batch *b, unsigned long long *out, int n);
 

@@ -186,17 +186,13 @@ class SMPLSimVecEnv:
         return xpos, xmat
 
     def debug_forward(self, torques=None):
-        """(decode, M entries, qfrc_bias, qacc) of one mj_forward at the current state (parity triage)."""
-        ne = C.c_int32()
-        _check(lib().ss_debug_decode(self.model.handle, None, C.byref(ne)))
-        dec = np.zeros(ne.value, np.int32)
-        _check(lib().ss_debug_decode(self.model.handle, dec.ctypes.data_as(C.c_void_p), C.byref(ne)))
-        Me = torch.zeros(self.num_envs, ne.value, device=self.device)
+        """(M [N,nv,nv], qfrc_bias, qacc) of one mj_forward at the current state (parity triage)."""
+        M = torch.zeros(self.num_envs, self.nv, self.nv, device=self.device)
         bias = torch.zeros(self.num_envs, self.nv, device=self.device)
         qacc = torch.zeros(self.num_envs, self.nv, device=self.device)
         tq = None if torques is None else torques.to(torch.float32).contiguous()
-        _check(lib().ss_debug_forward(self.handle, _ptr(tq), _ptr(Me), _ptr(bias), _ptr(qacc), self._stream()))
-        return dec, Me, bias, qacc
+        _check(lib().ss_debug_forward(self.handle, _ptr(tq), _ptr(M), _ptr(bias), _ptr(qacc), self._stream()))
+        return M, bias, qacc
 
     def set_state(self, qpos, qvel, qpos_prev=None, qvel_prev=None, warm=None):
         """Teacher forcing / checkpoint restore.  *_prev default to the state itself (== after mj_forward)."""

@@ -13,10 +13,10 @@
 // SIMD.  SMPL: 10 envs -> 3 waves/SIMD -> 168-VGPR cap (7% faster than 8 envs at 256 VGPRs, at 3x the spill traffic:
 // profiles/r01i_ab_launch_bounds.txt).  SMPL-X: 3 envs fit -> 1 wave/SIMD, the whole 512-VGPR file, no spills.
 #ifndef SS_MAX_THREADS
-#define SS_MAX_THREADS 704
+#define SS_MAX_THREADS 768
 #endif
 #ifndef SS_MAX_THREADS_X
-#define SS_MAX_THREADS_X 256
+#define SS_MAX_THREADS_X 384
 #endif
 
 namespace {
@@ -52,7 +52,7 @@ struct WaveGpu {
   }
 };
 
-template <int DOFP, int CANDP, int SLOTP, int MAXT>
+template <int DOFP, int CANDP, int SLOTP, int NPASS, int MAXT>
 __global__ void __launch_bounds__(MAXT) ss_env_kernel(const ss::KArgs k) {
   extern __shared__ __align__(16) uint32_t lds[];
   for (int i = threadIdx.x; i < k.h.shared_words; i += blockDim.x) lds[i] = k.shared_g[i];
@@ -68,15 +68,15 @@ __global__ void __launch_bounds__(MAXT) ss_env_kernel(const ss::KArgs k) {
     env = __builtin_amdgcn_readfirstlane(env);
     if (env >= k.st.num_envs) break;
     if (k.order) env = __builtin_amdgcn_readfirstlane(k.order[env]);   // longest-processing-time-first hand-out
-    ss::run_env<WaveGpu, DOFP, CANDP, SLOTP>(&w, &k, lds, L, env);
+    ss::run_env<WaveGpu, DOFP, CANDP, SLOTP, NPASS>(&w, &k, lds, L, env);
     w.sync();
   }
 }
 
 typedef void (*kern_t)(const ss::KArgs);
-kern_t pick_kernel(int dofp, int candp, int slotp) {
-  if (dofp == 2 && candp == 2 && slotp == 1) return ss_env_kernel<2, 2, 1, SS_MAX_THREADS>;      // SMPL layout (24 bodies)
-  if (dofp == 3 && candp <= 3 && slotp <= 2) return ss_env_kernel<3, 3, 2, SS_MAX_THREADS_X>;      // SMPL-X/H layout (52 bodies)
+kern_t pick_kernel(int variant) {
+  if (variant == 0) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS>;      // SMPL layout (24 bodies)
+  if (variant == 1) return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X>;    // SMPL-X/H layout (52 bodies)
   return nullptr;
 }
 
@@ -88,12 +88,11 @@ struct HipBackend {
   static bool download(void *dst, const void *src, size_t n) { return hipMemcpy(dst, src, n, hipMemcpyDeviceToHost) == hipSuccess; }
   static int lds_capacity() { return 160 * 1024; }
   static int num_cus() { int d = 0, n = 256; if (hipGetDevice(&d) == hipSuccess) { hipDeviceProp_t p; if (hipGetDeviceProperties(&p, d) == hipSuccess) n = p.multiProcessorCount; } return n; }
-  static int max_waves(int dofp, int candp, int slotp) { return (dofp == 2 && candp == 2 && slotp == 1 ? SS_MAX_THREADS : SS_MAX_THREADS_X) / 64; }
+  static int max_waves(int variant) { return (variant == 0 ? SS_MAX_THREADS : SS_MAX_THREADS_X) / 64; }
   static int &regs_ref() { static int r = 0; return r; }
   static int kernel_regs() { return regs_ref(); }
   static const char *launch(const ss::KArgs &k, int nenv, int envs_per_wg, size_t lds_bytes, void *stream) {
-    const int dofp = (k.h.nv + 63) / 64, candp = (k.h.ncand + 63) / 64;
-    kern_t kern = pick_kernel(dofp, candp, (k.h.nslot + 63) / 64);
+    kern_t kern = pick_kernel(ss::kernel_variant(k.h));
     if (!kern) return "no kernel variant for this model size";
     static thread_local kern_t configured = nullptr;
     static thread_local size_t configured_lds = 0;

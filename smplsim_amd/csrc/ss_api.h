@@ -2,7 +2,7 @@
 // backend: the HIP backend in smplsim_hip.hip (the product) and the wavefront-emulator backend in
 // tests/wave_emu/emu.cpp (unit-test infrastructure).  A backend provides:
 //   static void *alloc(size_t);  static void free_(void *);  static bool upload(void *dst, const void *src, size_t);
-//   static int lds_capacity();   static int max_waves(int dofp, int candp, int slotp);   static const char *launch(const ss::KArgs &, int nenv, int envs_per_wg, size_t lds_bytes, void *stream);
+//   static int lds_capacity();   static int max_waves(int variant);   static const char *launch(const ss::KArgs &, int nenv, int envs_per_wg, size_t lds_bytes, void *stream);
 //   static bool set_device(int);
 #pragma once
 #include <cstdlib>
@@ -73,8 +73,7 @@ struct ss_api {
     if (cfg->control_freq_inv < 1) return fail(SS_ERR_INVALID, "control_freq_inv must be >= 1");
     if (cfg->task == SS_TASK_REACH && (cfg->reach_body < 0 || cfg->reach_body >= m->hm.h.nb)) return fail(SS_ERR_INVALID, "reach_body out of range");
     const ss::Hdr &h = m->hm.h;
-    const int dofp = (h.nv + 63) / 64, candp = (h.ncand + 63) / 64;
-    if (dofp > 3 || candp > 3 || (h.nslot + 63) / 64 > 2) return fail(SS_ERR_INVALID, "model too large for the compiled kernel variants");
+    if (ss::kernel_variant(h) < 0) return fail(SS_ERR_INVALID, "model too large for the compiled kernel variants");
     ss_batch *b = new (std::nothrow) ss_batch();
     if (!b) return fail(SS_ERR_NOMEM, "out of host memory");
     b->m = m; b->cfg = *cfg; b->st = *st;
@@ -84,7 +83,7 @@ struct ss_api {
     int cap = BE::lds_capacity();
     int e = (int)((cap - (long)shared_b) / (long)env_b);
     if (e < 1) { delete b; return fail(SS_ERR_LDS, "model does not fit in LDS"); }
-    { const int mw = BE::max_waves(dofp, candp, (h.nslot + 63) / 64); if (e > mw) e = mw; }   // launch bound of the kernel variant
+    { const int mw = BE::max_waves(ss::kernel_variant(h)); if (e > mw) e = mw; }   // launch bound of the kernel variant
     { const char *cap = getenv("SS_ENVS_PER_WG"); if (cap && atoi(cap) > 0 && atoi(cap) < e) e = atoi(cap); }
     b->envs_per_wg = e;
     b->lds_bytes = shared_b + (size_t)e * env_b;
@@ -141,10 +140,10 @@ struct ss_api {
     k.out0 = xpos; k.out1 = xmat;
     return run(b, k, stream);
   }
-  static int debug_forward(ss_batch *b, const float *torques, float *M_entries, float *bias, float *qacc, void *stream) {
-    if (!b || !M_entries || !bias || !qacc) return fail(SS_ERR_INVALID, "null argument");
+  static int debug_forward(ss_batch *b, const float *torques, float *M, float *bias, float *qacc, void *stream) {
+    if (!b || !M || !bias || !qacc) return fail(SS_ERR_INVALID, "null argument");
     ss::KArgs k = base_args(b, ss::MODE_DEBUG_FORWARD);
-    k.actions = torques; k.out0 = M_entries; k.out1 = bias; k.out2 = qacc;
+    k.actions = torques; k.out0 = M; k.out1 = bias; k.out2 = qacc;
     return run(b, k, stream);
   }
 };
@@ -175,12 +174,6 @@ struct ss_api {
   int ss_substep(ss_batch *b, const float *a, int n, void *st) { return ss_api<BE>::substep(b, a, n, st); }          \
   int ss_kinematics(ss_batch *b, float *xpos, float *xmat, void *st) { return ss_api<BE>::kinematics(b, xpos, xmat, st); } \
   int ss_debug_forward(ss_batch *b, const float *tq, float *M, float *bias, float *qacc, void *st) { return ss_api<BE>::debug_forward(b, tq, M, bias, qacc, st); } \
-  int ss_debug_decode(const ss_model *m, int32_t *out, int32_t *ne) {                                                \
-    if (!m || !ne) return ss_api<BE>::fail(SS_ERR_INVALID, "null argument");                                         \
-    *ne = m->hm.h.ne;                                                                                                \
-    if (out) for (int e = 0; e < m->hm.h.ne; e++) out[e] = (int32_t)m->hm.decode[e];              \
-    return SS_OK;                                                                                                    \
-  }                                                                                                                  \
   int ss_launch_info(const ss_batch *b, int32_t *epw, int32_t *lds, int32_t *regs) {                                 \
     if (!b) return ss_api<BE>::fail(SS_ERR_INVALID, "null batch");                                                   \
     if (epw) *epw = b->envs_per_wg; if (lds) *lds = (int32_t)b->lds_bytes; if (regs) *regs = BE::kernel_regs();      \

@@ -14,18 +14,26 @@ constexpr int kCandC = 8;    // floats per contact candidate
 // Header passed to the kernels by value: dims, table offsets (32-bit words into the shared blob),
 // per-env LDS layout (float offsets) and physics scalars.
 struct Hdr {
-  int nb, nn, nv, nq, nu, ne, ncand, nlev, nblev, maxD, nblk, nbox, nslot, maxU;
-  int levstart[20], blevstart[20];   // node / body level offsets (kernel arguments -> scalar loads)
-  int itemA[20], itemB[20];          // per-level offsets into the packed work-item tables
-  int accp[20], bsol[20];            // per-level offsets: tree-accumulation parents, backward-solve targets
+  int nb, nn, nv, nq, nu, ncand, nlev, nblev, nbox, nslot, maxlev;
+  int levstart[20];                  // node level offsets (kernel arguments -> scalar loads)
   // shared-blob word offsets
-  int o_dofc, o_chainnode, o_nbase, o_ndepth, o_levnodes, o_bparent, o_blevbodies, o_blk, o_itemA, o_itemB, o_fsrc, o_accp, o_children, o_bsol, o_bsrc, o_subsize, shared_words;   // o_bsrc: (kk*3*D + 3J) | n_k<<16 into the U buffer
-  // per-env LDS float offsets
-  int l_H, l_S, l_G, l_Dinv, l_R, l_r, l_Ic, l_K, l_V, l_Ab, l_Ad, l_Gb, l_q, l_v, l_a, l_tau, l_grad,
-      l_delta, l_C, l_diag, l_misc, env_floats;
+  int o_dofc, o_chainnode, o_ndepth, o_lev, o_bparent, o_subsize, shared_words;
+  // per-env LDS float offsets.  Z = solver region: Aown | IA (2 level buffers) | Ubuf | Wst ; aliases: contact records
+  // at Z, R/r inside Wst, Gb and the body_accel scratch inside IA, Ad = An, V = grad+delta
+  int l_q, l_v, l_a, l_tau, l_C, l_grad, l_delta, l_diag, l_S, l_Ab, l_An, l_Aown, l_IA, l_Ubuf, l_Wst,
+      l_R, l_r, l_Gb, l_tmp, l_V, l_misc, ia_stride, env_floats;
   float dt, grav, margin, mu, solimp[5], K, B;   // K, B of aref (from solref, dmax)
   float qpos0_root[3];
 };
+
+// compiled kernel variants: 0 = SMPL-sized (<= 128 dofs / candidates, <= 64 contact slots, <= 8 nodes per tree level),
+// 1 = SMPL-X/H-sized (<= 192 dofs / candidates, <= 128 slots, <= 16 nodes per level); -1 = none fits
+inline int kernel_variant(const Hdr &h) {
+  const int dofp = (h.nv + 63) / 64, candp = (h.ncand + 63) / 64, slotp = (h.nslot + 63) / 64, npass = (h.maxlev + 7) / 8;
+  if (dofp <= 2 && candp <= 2 && slotp <= 1 && npass <= 1) return 0;
+  if (dofp <= 3 && candp <= 3 && slotp <= 2 && npass <= 2) return 1;
+  return -1;
+}
 
 enum { MODE_STEP = 0, MODE_SUBSTEP = 1, MODE_RESET = 2, MODE_KINEMATICS = 3, MODE_DEBUG_FORWARD = 4 };
 
@@ -50,7 +58,7 @@ struct KArgs {
   int32_t *work_counter;      // device word, zeroed before each launch: persistent waves pull env ids from it
   float *obs, *reward;
   uint8_t *terminated, *truncated;
-  float *out0, *out1, *out2;  // kinematics: xpos, xmat ; debug forward: M entries [N,ne], bias [N,nv], qacc [N,nv]
+  float *out0, *out1, *out2;  // kinematics: xpos, xmat ; debug forward: M [N,nv,nv], bias [N,nv], qacc [N,nv]
 };
 
 }  // namespace ss

@@ -69,14 +69,14 @@ SS_DEV float4_t ld4(const float *p) { return *reinterpret_cast<const float4_t *>
 SS_DEV void st4(float *p, float a, float b, float c) { float4_t v; v.x = a; v.y = b; v.z = c; v.w = 0.f; *reinterpret_cast<float4_t *>(p) = v; }
 SS_DEV bool is_bad(float x) { return !(x <= 1e10f && x >= -1e10f); }
 
-template <class W, int DOFP, int CANDP, int SLOTP>
+template <class W, int DOFP, int CANDP, int SLOTP, int NPASS>
 struct Sim {
   W *w;
   const KArgs *k;
   const uint32_t *T;      // shared tables in LDS
   int lane, env;
   // per-env LDS arrays
-  float *H, *S, *G, *Dinv, *R, *r, *Ic, *Kc, *V, *Ab, *Ad, *Gb, *q, *v, *a, *tau, *grad, *delta, *C, *diag, *misc;
+  float *S, *R, *r, *V, *Ab, *An, *Ad, *Gb, *tmpb, *Aown, *IA, *Ubuf, *Wst, *q, *v, *a, *tau, *grad, *delta, *C, *diag, *misc;
   // per-lane constants
   int bpar, bdep;
   // per-lane state
@@ -100,8 +100,8 @@ struct Sim {
   SS_DEV void init(W *w_, const KArgs *k_, const uint32_t *T_, float *L, int env_) {
     w = w_; k = k_; T = T_; lane = w->lane(); env = env_;
     const Hdr &h = k->h;
-    H = L + h.l_H; S = L + h.l_S; G = L + h.l_G; Dinv = L + h.l_Dinv; R = L + h.l_R; r = L + h.l_r;
-    Ic = L + h.l_Ic; Kc = L + h.l_K; V = L + h.l_V; Ab = L + h.l_Ab; Ad = L + h.l_Ad; Gb = L + h.l_Gb;
+    S = L + h.l_S; R = L + h.l_R; r = L + h.l_r; V = L + h.l_V; Ab = L + h.l_Ab; An = L + h.l_An; Ad = An;
+    Gb = L + h.l_Gb; tmpb = L + h.l_tmp; Aown = L + h.l_Aown; IA = L + h.l_IA; Ubuf = L + h.l_Ubuf; Wst = L + h.l_Wst;
     q = L + h.l_q; v = L + h.l_v; a = L + h.l_a; tau = L + h.l_tau; grad = L + h.l_grad;
     delta = L + h.l_delta; C = L + h.l_C; diag = L + h.l_diag; misc = L + h.l_misc;
     bpar = -1; bdep = -1;
@@ -134,26 +134,6 @@ struct Sim {
   SS_DEV void store(float *dst, const float *src, int n) { for (int i = lane; i < n; i += 64) dst[i] = src[i]; }
 
   // ------------------------------------------------------------------ tree helpers
-  // children -> parent sums, deepest level first, in place ("pull": one lane owns one (parent, component)
-  // and adds its children, so no LDS atomics are needed — ds_add_f32 is a CU-wide serial resource on gfx950,
-  // profiles/r01c_lds_ubench.txt).  Component c < NA lives in A (stride NA), the rest in B (stride NB).
-  template <int NA, int NB>
-  SS_DEV void tree_pull(float *A, float *B) {
-    const Hdr &h = k->h;
-    constexpr int NC = NA + NB;
-    for (int L = h.nblev - 2; L >= 0; --L) {
-      const int i0 = h.accp[L], n = (h.accp[L + 1] - i0) * NC;
-      for (int idx = lane; idx < n; idx += 64) {
-        const int pi = idx / NC, c = idx - pi * NC;
-        const int e = ti(h.o_accp, i0 + pi), p = e & 255, cs = (e >> 8) & 4095, cc = e >> 20;
-        float acc = 0.f;
-        if (c < NA) { for (int j = 0; j < cc; j++) acc += A[ti(h.o_children, cs + j) * NA + c]; A[p * NA + c] += acc; }
-        else { for (int j = 0; j < cc; j++) acc += B[ti(h.o_children, cs + j) * NB + c - NA]; B[p * NB + c - NA] += acc; }
-      }
-      w->sync();
-    }
-  }
-
   // out[b][c] = sum of in[d][c] over the subtree of b = the contiguous index range [b, b + size_b) (depth-first
   // body order): one phase of independent LDS reads instead of a level-by-level sweep.
   template <int NC>
@@ -319,8 +299,6 @@ struct Sim {
       Ib[0] = m; Ib[1] = m * cx_; Ib[2] = m * cy_; Ib[3] = m * cz_;
       Ib[4] = Ixx + m * (cy_ * cy_ + cz_ * cz_); Ib[5] = Ixy - m * cx_ * cy_; Ib[6] = Ixz - m * cx_ * cz_;
       Ib[7] = Iyy + m * (cx_ * cx_ + cz_ * cz_); Ib[8] = Iyz - m * cy_ * cz_; Ib[9] = Izz + m * (cx_ * cx_ + cy_ * cy_);
-#pragma unroll
-      for (int i = 0; i < 10; i++) Kc[10 * b + i] = Ib[i];    // Kc is free here: input of the composite-inertia sums
       // f = I (a - a_grav) + v x* (I v)
       float ag[6] = {ab[0], ab[1], ab[2], ab[3], ab[4], ab[5] - h.grav};
       float Ia[6], Iv[6], fb[6];
@@ -343,8 +321,7 @@ struct Sim {
       }
     }
     w->sync();
-    // composite inertia Ic and subtree bias force Gb (C = S^T Gb): subtree range sums, one phase
-    subtree_sum<10>(Kc, Ic);
+    // subtree bias force Gb (C = S^T Gb): subtree range sums, one phase
     subtree_sum<6>(Ad, Gb);
     w->sync();
 #pragma unroll
@@ -393,9 +370,9 @@ struct Sim {
     const Hdr &h = k->h;
     const float pz = q[2], mu = h.mu;
     touchmask = 0ull;
-    // contact records are compacted through LDS (H is free here) into one slot per lane:
+    // contact records are compacted through LDS (the solver region is free here) into one slot per lane:
     // box b keeps at most 4 corners -> slots 4b..4b+3, capsule end e -> slot 4*nbox + e
-    float *rec = H;
+    float *rec = Aown;
 #pragma unroll
     for (int p = 0; p < SLOTP; p++) { int sl = p * 64 + lane; if (sl < h.nslot) rec[13 * sl] = 0.f; }
     w->sync();
@@ -482,7 +459,7 @@ struct Sim {
         }
       }
     }
-    w->sync();                                               // records consumed before H is reused
+    w->sync();                                               // records consumed before the solver region is reused
 #pragma unroll
     for (int p = 0; p < DOFP; p++) {
       int i = p * 64 + lane;
@@ -504,13 +481,14 @@ struct Sim {
   }
 
   // rows: jar (from A = Ab, x = a) or jd (from A = Ad, x = delta)
-  SS_DEV void eval_rows(const float *A, const float *x, bool is_delta) {
+  // A: spatial accelerations, body b at A + stride * b
+  SS_DEV void eval_rows(const float *A, int stride, const float *x, bool is_delta) {
     const float mu = k->h.mu;
 #pragma unroll
     for (int p = 0; p < SLOTP; p++) {
       Contact &c = con[p];
       if (!c.active) continue;
-      const float *Ab_ = A + 6 * c.body;
+      const float *Ab_ = A + stride * c.body;
       float ax = Ab_[3] + Ab_[1] * c.rz - Ab_[2] * c.ry;
       float ay = Ab_[4] + Ab_[2] * c.rx - Ab_[0] * c.rz;
       float az = Ab_[5] + Ab_[0] * c.ry - Ab_[1] * c.rx;
@@ -527,71 +505,148 @@ struct Sim {
     }
   }
 
-  // ------------------------------------------------------------------ H assembly: H(i,j) = S_j . (Hc_body(i) S_i) + diag
-  // Hc = expand(Ic) + Kc (Kc must hold subtree sums, or zeros).  Work items are 3x3 blocks
-  // (node n, chain position J <= depth(n)); block (n,J)[r][c] = S[3 aJ + c] . G[3 n + r].
-  SS_DEV void assemble_H() {
-    fresh();
-    const Hdr &h = k->h;
-#pragma unroll
-    for (int p = 0; p < DOFP; p++) {
-      int i = p * 64 + lane;
-      if (i < h.nv) {
-        int n = i / 3, b = n > 0 ? n - 1 : 0;
-        const float *I = Ic + 10 * b, *Km = Kc + 21 * b, *s = S + 6 * i;
-        const float s0 = s[0], s1 = s[1], s2 = s[2], s3 = s[3], s4 = s[4], s5 = s[5];
-        const float x[6] = {s0, s1, s2, s3, s4, s5};
-        float g[6];
-        imul(I, x, g);
-        g[0] += Km[0] * s0 + Km[1] * s1 + Km[2] * s2 + Km[3] * s3 + Km[4] * s4 + Km[5] * s5;
-        g[1] += Km[1] * s0 + Km[6] * s1 + Km[7] * s2 + Km[8] * s3 + Km[9] * s4 + Km[10] * s5;
-        g[2] += Km[2] * s0 + Km[7] * s1 + Km[11] * s2 + Km[12] * s3 + Km[13] * s4 + Km[14] * s5;
-        g[3] += Km[3] * s0 + Km[8] * s1 + Km[12] * s2 + Km[15] * s3 + Km[16] * s4 + Km[17] * s5;
-        g[4] += Km[4] * s0 + Km[9] * s1 + Km[13] * s2 + Km[16] * s3 + Km[18] * s4 + Km[19] * s5;
-        g[5] += Km[5] * s0 + Km[10] * s1 + Km[14] * s2 + Km[17] * s3 + Km[19] * s4 + Km[20] * s5;
-        float *go = G + 6 * i;
-        go[0] = g[0]; go[1] = g[1]; go[2] = g[2]; go[3] = g[3]; go[4] = g[4]; go[5] = g[5];
-      }
+  // ------------------------------------------------------------------ articulated-body solve of  H x = b
+  // H = sum_b J_b^T A_b J_b + diag  (J_b = body Jacobian, A_b = 6x6 generalized inertia of body b: its spatial
+  // inertia, plus the contact matrix K_b in the Newton system; diag = armature (+ limit rows / Kd dt)).  That is a
+  // mass matrix with generalized body inertias, so the system is solved like forward dynamics, by Featherstone's
+  // articulated-body recursion over the node tree — H is never formed or factored.  All spatial quantities live
+  // in one world-aligned frame, so parent accumulation is a plain add.
+  //   up   (leaves -> root), node n:  IA = A_n + sum_children IA'_c,  pA = sum_children pA'_c
+  //        U = IA S_n, D = S_n^T U + diag_n, u = b_n - S_n^T pA, W = U D^-1, y = D^-1 u
+  //        IA' = IA - W U^T,  pA' = pA + U y            (handed to the parent)
+  //   down (root -> leaves):          x_n = y - W^T a_parent,  a_n = a_parent + S_n x_n
+  // Lane roles: 8 lanes per node of the level (lane = 8 * slot + r), lane r < 6 owns row r of the node's 6x6 / 6x3
+  // quantities; the 3x3 joint-space algebra is redundant per lane.  Two wave syncs per level going up, one going
+  // down.  Rows of the level's IA', pA' go through a two-level LDS buffer; (W_r, y_r) are kept per node.
+  // On return x holds the solution and An[8 n ..] the node accelerations a_n (= the body accelerations J_b x).
+  SS_DEV static void st4w(float *p, float a, float b, float c, float d) { float4_t v; v.x = a; v.y = b; v.z = c; v.w = d; *reinterpret_cast<float4_t *>(p) = v; }
+
+  SS_DEV void write_own_inertia() {                          // Aown[b] = expand(Ib), packed upper triangle (ang;lin)
+    if (lane < k->h.nb) {
+      float *o = Aown + 21 * lane;
+      const float m = Ib[0], cx = Ib[1], cy = Ib[2], cz = Ib[3];
+      o[0] = Ib[4]; o[1] = Ib[5]; o[2] = Ib[6]; o[3] = 0.f; o[4] = -cz; o[5] = cy;
+      o[6] = Ib[7]; o[7] = Ib[8]; o[8] = cz; o[9] = 0.f; o[10] = -cx;
+      o[11] = Ib[9]; o[12] = -cy; o[13] = cx; o[14] = 0.f;
+      o[15] = m; o[16] = 0.f; o[17] = 0.f; o[18] = m; o[19] = 0.f; o[20] = m;
     }
-    w->sync();
-    for (int e = lane; e < h.nblk; e += 64) {
-      const int w0 = ti(h.o_blk, 2 * e), boff = ti(h.o_blk, 2 * e + 1);
-      const int aJ = w0 & 255, n = (w0 >> 8) & 255;
-      const bool dg = (w0 >> 16) & 1;
-      const float *sj = S + 18 * aJ, *gi = G + 18 * n;
-      float sv_[18], gv_[18];
-#pragma unroll
-      for (int t = 0; t < 18; t++) { sv_[t] = sj[t]; gv_[t] = gi[t]; }
-      float o_[9];
-#pragma unroll
-      for (int r_ = 0; r_ < 3; r_++) {
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-          float acc = 0.f;
-#pragma unroll
-          for (int t = 0; t < 6; t++) acc += sv_[6 * c + t] * gv_[6 * r_ + t];
-          o_[3 * r_ + c] = acc;
-        }
-      }
-      if (dg) { o_[0] += diag[3 * n]; o_[4] += diag[3 * n + 1]; o_[8] += diag[3 * n + 2]; }
-      float *hb = H + boff;
-      st4(hb, o_[0], o_[1], o_[2]); st4(hb + 4, o_[3], o_[4], o_[5]); st4(hb + 8, o_[6], o_[7], o_[8]);
-    }
-    w->sync();
   }
 
-  // ------------------------------------------------------------------ level-parallel 3x3-block L^T D L
-  // H = L^T D L with unit block-lower-triangular L on the tree pattern; node k at depth d couples to its
-  // d ancestor nodes through the blocks P_k[:, J].  H is stored block-major, 3 rows x 4 floats per block, so a
-  // block row is one 16-byte LDS access at (table offset + immediate).  Per level (deepest first), two phases:
-  //   A  Dinv_k = inv(diag block); U_k = Dinv_k P_k is written in place (rows of L); P_k is parked in a scratch
-  //      buffer for phase B
-  //   B  every ancestor block (I >= J) with descendants at this level -= sum_k P_k[:,I]^T U_k[:,J]  ("pull": one lane
-  //      owns one target block, so no LDS atomics), and x_anc -= sum_k U_k[:,J]^T x_k — the leaves-to-root sweep of
-  //      the solve, fused in because x_k is final once its level is reached.
-  // A lone wavefront pays ~14 ticks per LDS instruction and ~8 per dependent VALU instruction (profiles/r01g), and
-  // launch time is the serial time of the slowest env, so this code minimises instructions on the serial path.
-  SS_DEV static float rcp_nr(float x) {                      // 1/x: hardware reciprocal + one Newton step
+  SS_DEV void aba_solve(float *x) {
+    fresh();
+    const Hdr &h = k->h;
+    const int r_ = lane & 7, g = lane >> 3;
+    int off[6];                                              // packed-symmetric offsets of row r_
+#pragma unroll
+    for (int c = 0; c < 6; c++) { const int lo = r_ < c ? r_ : c, hi = r_ < c ? c : r_; off[c] = (lo * (11 - lo)) / 2 + hi; }
+    SS_FT0();
+    for (int L = h.nlev - 1; L >= 0; --L) {
+      const int s0 = h.levstart[L], nk = h.levstart[L + 1] - s0;
+      float *cur = IA + (L & 1) * h.ia_stride;
+      const float *prev = IA + ((L + 1) & 1) * h.ia_stride;
+      float row[NPASS][6], pa[NPASS], Sr[NPASS][18], Ur[NPASS][3];
+      int nod[NPASS];
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ps++) {                    // ---- phase 1: articulated row, U_r = IA_r S
+        const int kk = ps * 8 + g;
+        nod[ps] = -1;
+        if (r_ < 6 && kk < nk) {
+          const int e = ti(h.o_lev, s0 + kk), n = e & 255, cfirst = (e >> 16) & 255, cc = (e >> 24) & 255;
+          nod[ps] = n;
+          float rw[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, pv = 0.f;
+          if (n > 0) {
+            const float *ao = Aown + 21 * (n - 1);
+#pragma unroll
+            for (int c = 0; c < 6; c++) rw[c] = ao[off[c]];
+          }
+          for (int j = 0; j < cc; j++) {
+            const float *src = prev + ((cfirst + j) * 6 + r_) * 8;
+            const float4_t v0 = ld4(src), v1 = ld4(src + 4);
+            rw[0] += v0.x; rw[1] += v0.y; rw[2] += v0.z; rw[3] += v0.w; rw[4] += v1.x; rw[5] += v1.y; pv += v1.z;
+          }
+          const float *sn = S + 18 * n;
+#pragma unroll
+          for (int t = 0; t < 18; t++) Sr[ps][t] = sn[t];
+#pragma unroll
+          for (int j = 0; j < 3; j++) {
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < 6; c++) acc += rw[c] * Sr[ps][6 * j + c];
+            Ur[ps][j] = acc;
+          }
+#pragma unroll
+          for (int c = 0; c < 6; c++) row[ps][c] = rw[c];
+          pa[ps] = pv;
+          st4w(Ubuf + (kk * 6 + r_) * 4, Ur[ps][0], Ur[ps][1], Ur[ps][2], pv);
+        }
+      }
+      SS_FTICK(PF_F_P13);
+      w->sync();
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ps++) {                    // ---- phase 2: joint-space 3x3 algebra, rows handed up
+        const int kk = ps * 8 + g, n = nod[ps];
+        if (n >= 0) {
+          float4_t U[6];
+#pragma unroll
+          for (int c = 0; c < 6; c++) U[c] = ld4(Ubuf + (kk * 6 + c) * 4);
+          const float *sr = Sr[ps];
+          float d00 = diag[3 * n], d10 = 0.f, d11 = diag[3 * n + 1], d20 = 0.f, d21 = 0.f, d22 = diag[3 * n + 2];
+          float u0 = x[3 * n], u1 = x[3 * n + 1], u2 = x[3 * n + 2];
+#pragma unroll
+          for (int c = 0; c < 6; c++) {
+            d00 += sr[c] * U[c].x; d10 += sr[6 + c] * U[c].x; d11 += sr[6 + c] * U[c].y;
+            d20 += sr[12 + c] * U[c].x; d21 += sr[12 + c] * U[c].y; d22 += sr[12 + c] * U[c].z;
+            u0 -= sr[c] * U[c].w; u1 -= sr[6 + c] * U[c].w; u2 -= sr[12 + c] * U[c].w;
+          }
+          const float c00 = d11 * d22 - d21 * d21, c01 = d21 * d20 - d10 * d22, c02 = d10 * d21 - d11 * d20;
+          const float id = rcp_nr(d00 * c00 + d10 * c01 + d20 * c02);
+          const float i00 = c00 * id, i01 = c01 * id, i02 = c02 * id;
+          const float i11 = (d00 * d22 - d20 * d20) * id, i12 = (d10 * d20 - d00 * d21) * id, i22 = (d00 * d11 - d10 * d10) * id;
+          const float y0 = i00 * u0 + i01 * u1 + i02 * u2, y1 = i01 * u0 + i11 * u1 + i12 * u2, y2 = i02 * u0 + i12 * u1 + i22 * u2;
+          const float a0 = Ur[ps][0], a1 = Ur[ps][1], a2 = Ur[ps][2];
+          const float w0 = a0 * i00 + a1 * i01 + a2 * i02, w1 = a0 * i01 + a1 * i11 + a2 * i12, w2 = a0 * i02 + a1 * i12 + a2 * i22;
+          float rn[6];
+#pragma unroll
+          for (int c = 0; c < 6; c++) rn[c] = row[ps][c] - (w0 * U[c].x + w1 * U[c].y + w2 * U[c].z);
+          const float pn = pa[ps] + a0 * y0 + a1 * y1 + a2 * y2;
+          float *dst = cur + (kk * 6 + r_) * 8;
+          st4w(dst, rn[0], rn[1], rn[2], rn[3]); st4w(dst + 4, rn[4], rn[5], pn, 0.f);
+          st4w(Wst + (n * 6 + r_) * 4, w0, w1, w2, r_ == 0 ? y0 : (r_ == 1 ? y1 : y2));
+        }
+      }
+      SS_FTICK(PF_F_P2);
+      w->sync();
+    }
+    SS_FTICK(PF_F_SYNC1);
+    for (int L = 0; L < h.nlev; L++) {                        // ---- downward sweep
+      const int s0 = h.levstart[L], nk = h.levstart[L + 1] - s0;
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ps++) {
+        const int kk = ps * 8 + g;
+        if (r_ < 6 && kk < nk) {
+          const int e = ti(h.o_lev, s0 + kk), n = e & 255, pn = (e >> 8) & 255;
+          float4_t p0, p1; p0.x = p0.y = p0.z = p0.w = 0.f; p1 = p0;
+          float apr = 0.f;
+          if (n > 0) { p0 = ld4(An + 8 * pn); p1 = ld4(An + 8 * pn + 4); apr = An[8 * pn + r_]; }
+          float4_t Wn[6];
+#pragma unroll
+          for (int c = 0; c < 6; c++) Wn[c] = ld4(Wst + (n * 6 + c) * 4);
+          const float ap[6] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y};
+          float x0 = Wn[0].w, x1 = Wn[1].w, x2 = Wn[2].w;
+#pragma unroll
+          for (int c = 0; c < 6; c++) { x0 -= Wn[c].x * ap[c]; x1 -= Wn[c].y * ap[c]; x2 -= Wn[c].z * ap[c]; }
+          const float *sn = S + 18 * n + r_;
+          An[8 * n + r_] = apr + sn[0] * x0 + sn[6] * x1 + sn[12] * x2;
+          if (r_ < 3) x[3 * n + r_] = r_ == 0 ? x0 : (r_ == 1 ? x1 : x2);
+        }
+      }
+      w->sync();
+    }
+    SS_FTICK(PF_F_BSOL);
+  }
+
+  // 1/x: hardware reciprocal + one Newton step
+  SS_DEV static float rcp_nr(float x) {
 #if defined(__HIPCC__)
     float r = __builtin_amdgcn_rcpf(x);
 #else
@@ -600,107 +655,29 @@ struct Sim {
     return r * (2.0f - x * r);
   }
 
-  SS_DEV void factor_H(float *x) {
-    fresh();
+  // joint-space matrix column j = M e_j by a body-level pass (diagnostics only: ss_debug_forward)
+  SS_DEV void dump_mass_matrix(float *out) {
     const Hdr &h = k->h;
-    float *Pb = G;                                           // G is free between assembly and the next one
-    SS_FT0();
-    for (int L = h.nlev - 1; L >= 0; --L) {
-      {                                                      // phase A
-        const int i0 = h.itemA[L], ni = h.itemA[L + 1] - i0;
-        for (int idx = lane; idx < ni; idx += 64) {
-          const int it = ti(h.o_itemA, i0 + idx), boff = it & 8191, n = (it >> 13) & 63, J = (it >> 19) & 15, kk = (it >> 23) & 15;
-          float *pb = H + boff;
-          const float *db = pb + 12 * (L - J);               // diagonal block of the same node
-          const float4_t d0 = ld4(db), d1 = ld4(db + 4), d2 = ld4(db + 8);
-          float4_t p0 = d0, p1 = d1, p2 = d2;
-          if (L > 0) { p0 = ld4(pb); p1 = ld4(pb + 4); p2 = ld4(pb + 8); }
-          const float d00 = d0.x, d10 = d1.x, d11 = d1.y, d20 = d2.x, d21 = d2.y, d22 = d2.z;
-          const float c00 = d11 * d22 - d21 * d21, c01 = d21 * d20 - d10 * d22, c02 = d10 * d21 - d11 * d20;
-          const float id = rcp_nr(d00 * c00 + d10 * c01 + d20 * c02);
-          const float i00 = c00 * id, i01 = c01 * id, i02 = c02 * id;
-          const float i11 = (d00 * d22 - d20 * d20) * id, i12 = (d10 * d20 - d00 * d21) * id, i22 = (d00 * d11 - d10 * d10) * id;
-          if (J == 0) { float *o = Dinv + 6 * n; o[0] = i00; o[1] = i01; o[2] = i02; o[3] = i11; o[4] = i12; o[5] = i22; }
-          if (L > 0) {
-            float *qb = Pb + (kk * L + J) * 12;
-            st4(qb, p0.x, p0.y, p0.z); st4(qb + 4, p1.x, p1.y, p1.z); st4(qb + 8, p2.x, p2.y, p2.z);
-            st4(pb, i00 * p0.x + i01 * p1.x + i02 * p2.x, i00 * p0.y + i01 * p1.y + i02 * p2.y, i00 * p0.z + i01 * p1.z + i02 * p2.z);
-            st4(pb + 4, i01 * p0.x + i11 * p1.x + i12 * p2.x, i01 * p0.y + i11 * p1.y + i12 * p2.y, i01 * p0.z + i11 * p1.z + i12 * p2.z);
-            st4(pb + 8, i02 * p0.x + i12 * p1.x + i22 * p2.x, i02 * p0.y + i12 * p1.y + i22 * p2.y, i02 * p0.z + i12 * p1.z + i22 * p2.z);
-          }
-        }
-      }
-      SS_FTICK(PF_F_P13);
+    for (int j = 0; j < h.nv; j++) {
+      for (int i = lane; i < h.nv; i += 64) delta[i] = i == j ? 1.f : 0.f;
       w->sync();
-      SS_FTICK(PF_F_SYNC1);
-      if (L == 0) break;
-      {                                                      // phase B, block updates
-        const int i0 = h.itemB[L], ni = h.itemB[L + 1] - i0;
-        for (int idx = lane; idx < ni; idx += 64) {
-          const int w0 = ti(h.o_itemB, 2 * (i0 + idx)), s0 = ti(h.o_itemB, 2 * (i0 + idx) + 1);
-          float *dst = H + (w0 & 0xFFFF);
-          const int ns = w0 >> 16;
-          float4_t a0 = ld4(dst), a1 = ld4(dst + 4), a2 = ld4(dst + 8);
-          for (int si = 0; si < ns; si++) {                   // the level's nodes below this ancestor block
-            const int src = ti(h.o_fsrc, s0 + si);
-            const float *pq = Pb + (src & 0xFFFF), *ub = H + (src >> 16);
-            const float4_t p0 = ld4(pq), p1 = ld4(pq + 4), p2 = ld4(pq + 8);
-            const float4_t u0 = ld4(ub), u1 = ld4(ub + 4), u2 = ld4(ub + 8);
-            a0.x -= p0.x * u0.x + p1.x * u1.x + p2.x * u2.x; a0.y -= p0.x * u0.y + p1.x * u1.y + p2.x * u2.y; a0.z -= p0.x * u0.z + p1.x * u1.z + p2.x * u2.z;
-            a1.x -= p0.y * u0.x + p1.y * u1.x + p2.y * u2.x; a1.y -= p0.y * u0.y + p1.y * u1.y + p2.y * u2.y; a1.z -= p0.y * u0.z + p1.y * u1.z + p2.y * u2.z;
-            a2.x -= p0.z * u0.x + p1.z * u1.x + p2.z * u2.x; a2.y -= p0.z * u0.y + p1.z * u1.y + p2.z * u2.y; a2.z -= p0.z * u0.z + p1.z * u1.z + p2.z * u2.z;
-          }
-          st4(dst, a0.x, a0.y, a0.z); st4(dst + 4, a1.x, a1.y, a1.z); st4(dst + 8, a2.x, a2.y, a2.z);
-        }
-        SS_FTICK(PF_F_P2);
-        const int j0 = h.bsol[L], nj = h.bsol[L + 1] - j0;    // x_anc -= sum_k U_k[:,J]^T x_k   (pull per ancestor node)
-        for (int idx = lane; idx < nj; idx += 64) {
-          const int w0 = ti(h.o_bsol, 2 * (j0 + idx)), s0 = ti(h.o_bsol, 2 * (j0 + idx) + 1);
-          const int aJ = w0 & 255, ns = w0 >> 8;
-          float b0 = x[3 * aJ], b1 = x[3 * aJ + 1], b2 = x[3 * aJ + 2];
-          for (int si = 0; si < ns; si++) {
-            const int src = ti(h.o_bsrc, s0 + si), n = src >> 16;
-            const float *ub = H + (src & 0xFFFF);
-            const float4_t u0 = ld4(ub), u1 = ld4(ub + 4), u2 = ld4(ub + 8);
-            const float z0 = x[3 * n], z1 = x[3 * n + 1], z2 = x[3 * n + 2];
-            b0 -= u0.x * z0 + u1.x * z1 + u2.x * z2;
-            b1 -= u0.y * z0 + u1.y * z1 + u2.y * z2;
-            b2 -= u0.z * z0 + u1.z * z1 + u2.z * z2;
-          }
-          x[3 * aJ] = b0; x[3 * aJ + 1] = b1; x[3 * aJ + 2] = b2;
-        }
-        SS_FTICK(PF_F_BSOL);
+      body_accel(delta, Ab, tmpb);
+      w->sync();
+      if (lane < h.nb) {
+        float Ia[6];
+        imul(Ib, Ab + 6 * lane, Ia);
+#pragma unroll
+        for (int c = 0; c < 6; c++) Ad[6 * lane + c] = Ia[c];
       }
       w->sync();
-      SS_FTICK(PF_F_SYNC2);
-    }
-  }
-
-  // finish H x = b after factor_H(x): x <- L^-1 D^-1 x
-  SS_DEV void solve_H(float *x) {
-    fresh();
-    const Hdr &h = k->h;
-    if (lane < h.nn) {                                        // x <- D^-1 x
-      const float *o = Dinv + 6 * lane;
-      float x0 = x[3 * lane], x1 = x[3 * lane + 1], x2 = x[3 * lane + 2];
-      x[3 * lane] = o[0] * x0 + o[1] * x1 + o[2] * x2;
-      x[3 * lane + 1] = o[1] * x0 + o[3] * x1 + o[4] * x2;
-      x[3 * lane + 2] = o[2] * x0 + o[4] * x1 + o[5] * x2;
-    }
-    w->sync();
-    for (int L = 1; L < h.nlev; L++) {                        // x <- L^-1 x (root to leaves): one lane per (node, row)
-      const int s = h.levstart[L], nk = h.levstart[L + 1] - s;
-      for (int idx = lane; idx < 3 * nk; idx += 64) {
-        const int kk = idx / 3, r_ = idx - 3 * kk, n = ti(h.o_levnodes, s + kk);
-        const float *ub = H + ti(h.o_nbase, n) + 4 * r_;
-        const int cn = h.o_chainnode + n * h.nlev;
-        float acc = x[3 * n + r_];
-        for (int J = 0; J < L; J++) {                         // independent reads: one 16-byte row of U and the ancestor's x
-          const int aJ = ti(cn, J);
-          const float4_t u = ld4(ub + 12 * J);
-          acc -= u.x * x[3 * aJ] + u.y * x[3 * aJ + 1] + u.z * x[3 * aJ + 2];
-        }
-        x[3 * n + r_] = acc;
+      subtree_sum<6>(Ad, Gb);
+      w->sync();
+      for (int i = lane; i < h.nv; i += 64) {
+        const int n = i / 3, b = n > 0 ? n - 1 : 0;
+        float s_ = i == j ? dc(i, 0) : 0.f;
+#pragma unroll
+        for (int c = 0; c < 6; c++) s_ += S[6 * i + c] * Gb[6 * b + c];
+        out[(size_t)j * h.nv + i] = s_;
       }
       w->sync();
     }
@@ -734,12 +711,12 @@ struct Sim {
   // between newton_prepare() and newton_finish() in the driver's solver loop.
   SS_DEV void newton_begin() {
     fresh();
-    body_accel(a, Ab, G);                                    // G is free outside assemble/factor
+    body_accel(a, Ab, tmpb);
     w->sync();
-    eval_rows(Ab, a, false);
+    eval_rows(Ab, 6, a, false);
   }
 
-  // gradient (-> grad, delta = -grad), diagonal terms and the per-body contact matrices Kc
+  // gradient (-> grad, delta = -grad), diagonal terms and the per-body generalized inertias Aown = I_b + K_b
   SS_DEV void newton_prepare() {
     fresh();
     const Hdr &h = k->h;
@@ -749,15 +726,13 @@ struct Sim {
       float Ia[6];
       imul(Ib, Ab + 6 * lane, Ia);
 #pragma unroll
-      for (int c = 0; c < 6; c++) Ad[6 * lane + c] = Ia[c];    // per-body terms go to scratch (Ad, H), subtree sums to Gb, Kc
-#pragma unroll
-      for (int c = 0; c < 21; c++) H[21 * lane + c] = 0.f;
+      for (int c = 0; c < 6; c++) Ad[6 * lane + c] = Ia[c];    // per-body terms go to Ad, their subtree sums to Gb
     }
+    write_own_inertia();
     w->sync();
     // ---- contact forces and K_b = sum_rows D u u^T, u = (rho x w ; w).  The (<= 4) contacts of a box sit in
     // 4 adjacent lanes and the 2 ends of a capsule in 2 adjacent lanes (slot layout of make_constraints), so the
     // per-body sums are quad shuffles; the group's first lane then owns the body's row (no atomics).
-    int nact = 0;
 #pragma unroll
     for (int p = 0; p < SLOTP; p++) {
       const Contact &c = con[p];
@@ -776,7 +751,6 @@ struct Sim {
           const float wy = r_ < 2 ? sgn * c.t1y : sgn * c.t1x;
           if (c.jar[r_] < 0.f) {
             const float f = -c.D * c.jar[r_];
-            nact++;
             fx += f * wx; fy += f * wy; fz += f;
             Wxx += c.D * wx * wx; Wxy += c.D * wx * wy; Wxz += c.D * wx;
             Wyy += c.D * wy * wy; Wyz += c.D * wy; Wzz += c.D;
@@ -809,22 +783,15 @@ struct Sim {
       const int body_of_group = boxlane ? h_box_body(sl) : h_caps_body(sl);
       const bool leader = boxlane ? ((sl & 3) == 0 && grp_any2) : ((sl & 1) == 0 && grp_any);
       if (leader && sl < h.nslot) {
-        float *g = Ad + 6 * body_of_group, *Kb = H + 21 * body_of_group;
+        float *g = Ad + 6 * body_of_group, *Kb = Aown + 21 * body_of_group;
 #pragma unroll
         for (int t = 0; t < 6; t++) g[t] += vals[t];
 #pragma unroll
-        for (int t = 0; t < 21; t++) Kb[t] = vals[6 + t];
+        for (int t = 0; t < 21; t++) Kb[t] += vals[6 + t];
       }
     }
     w->sync();
-    const bool any_contact_row = w->any(nact > 0);
-    // ---- subtree sums of Gb (6) and, when any contact row is active, Kc (21)
     subtree_sum<6>(Ad, Gb);
-    if (any_contact_row) subtree_sum<21>(H, Kc);
-    else if (lane < h.nb) {
-#pragma unroll
-      for (int c = 0; c < 21; c++) Kc[21 * lane + c] = 0.f;
-    }
     w->sync();
     // ---- gradient and diagonal terms
 #pragma unroll
@@ -848,9 +815,7 @@ struct Sim {
   SS_DEV bool newton_finish() {
     fresh();
     const Hdr &h = k->h;
-    body_accel(delta, Ad, G);
-    w->sync();
-    eval_rows(Ad, delta, true);
+    eval_rows(An + 8, 8, delta, true);                       // aba_solve left the body accelerations of delta in An
     float dg_ = 0.f, s_a = 0.f, s_b = 0.f;
 #pragma unroll
     for (int p = 0; p < DOFP; p++) { int i = p * 64 + lane; if (i < h.nv) dg_ += delta[i] * grad[i]; }
@@ -900,7 +865,7 @@ struct Sim {
         moving |= fabsf(st_) > 4e-7f * fabsf(an) + 1e-12f && fabsf(an) <= 1e10f;
       }
     }
-    for (int idx = lane; idx < 6 * h.nb; idx += 64) Ab[idx] += al * Ad[idx];
+    for (int idx = lane; idx < 6 * h.nb; idx += 64) { const int b = idx / 6; Ab[idx] += al * An[8 + 2 * b + idx]; }
 #pragma unroll
     for (int p = 0; p < SLOTP; p++) {
       Contact &c = con[p];
@@ -953,10 +918,7 @@ struct Sim {
   SS_DEV void spd_prepare(const float *action, float abias) {
     fresh();
     const Hdr &h = k->h;
-    if (lane < h.nb) {
-#pragma unroll
-      for (int c = 0; c < 21; c++) Kc[21 * lane + c] = 0.f;
-    }
+    write_own_inertia();
 #pragma unroll
     for (int p = 0; p < DOFP; p++) {
       int i = p * 64 + lane;
@@ -1103,15 +1065,15 @@ struct Sim {
 //   RESETFWD  reset_sim(): mj_forward at the reset state (sensors, contacts; no solve needed)
 //   FINAL     mj_kinematics on the new qpos for the observation
 enum { K_PROLOGUE = 0, K_SUBSTEP = 1, K_RESETFWD = 2, K_FINAL = 3 };
-enum { SOLVE_DUMP_M = 0, SOLVE_NEWTON = 1, SOLVE_SPD = 2 };
+enum { SOLVE_NEWTON = 1, SOLVE_SPD = 2 };
 
-template <class W, int DOFP, int CANDP, int SLOTP>
+template <class W, int DOFP, int CANDP, int SLOTP, int NPASS>
 SS_DEV void run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env) {
   const Hdr &h = k->h;
   const ss_env_cfg &cf = k->cfg;
   const ss_state &st = k->st;
   if (k->mask && !k->mask[env]) return;
-  Sim<W, DOFP, CANDP, SLOTP> sim;
+  Sim<W, DOFP, CANDP, SLOTP, NPASS> sim;
   sim.init(w, k, T, L, env);
   int lane = sim.lane;
   const int mode = k->mode;
@@ -1206,14 +1168,18 @@ SS_DEV void run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env) 
       prev_x = sim.q[0]; prev_y = sim.q[1];
       next_action = (mode == MODE_RESET) ? fa : act;
     } else {
+      if (is_debug) {                                        // diagnostics: dense mass matrix and bias force
+        sim.dump_mass_matrix(k->out0 + (size_t)env * h.nv * h.nv);
+        sim.store(k->out1 + (size_t)env * h.nv, sim.C, h.nv);
+      }
       sim.newton_begin();
       SS_TICK(PF_NBEGIN);
-      solve = is_debug ? SOLVE_DUMP_M : SOLVE_NEWTON;
+      solve = SOLVE_NEWTON;
       if (s + 1 < nsub) next_action = (mode == MODE_RESET) ? fa + (size_t)((s + 1) / cf.control_freq_inv) * h.nu : act;
     }
     bool redo = false;
     int it = 0;
-    for (;;) {                                               // solver loop: one assemble/factor/solve site
+    for (;;) {                                               // solver loop: one articulated-body solve site
       solve = w->opaque(solve);
       lane = sim.lane = w->opaque_v(sim.lane);
       if (solve == SOLVE_NEWTON) { sim.newton_prepare(); SS_TICK(PF_NPREP); }
@@ -1221,23 +1187,9 @@ SS_DEV void run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env) 
         if (cf.control_mode != SS_CTRL_UHC_PD) { sim.simple_controller(next_action, abias); break; }
         sim.spd_prepare(next_action, abias);
         SS_TICK(PF_SPDPREP);
-      } else {                                               // plain mass matrix for the diagnostics dump
-        if (lane < h.nb) for (int c = 0; c < 21; c++) sim.Kc[21 * lane + c] = 0.f;
-        for (int i = lane; i < h.nv; i += 64) sim.diag[i] = sim.dc(i, 0);
-        w->sync();
       }
-      sim.assemble_H();
-      SS_TICK(PF_ASM);
-      if (solve == SOLVE_DUMP_M) {
-        sim.store(k->out0 + (size_t)env * h.ne, sim.H, h.ne); sim.store(k->out1 + (size_t)env * h.nv, sim.C, h.nv);
-        w->sync();
-        solve = SOLVE_NEWTON;
-        continue;
-      }
-      sim.factor_H(sim.delta);
+      sim.aba_solve(sim.delta);
       SS_TICK(PF_FACTOR);
-      sim.solve_H(sim.delta);
-      SS_TICK(PF_SOLVE);
       if (solve == SOLVE_SPD) { sim.spd_finish(); SS_TICK(PF_SPDFIN); break; }
       const bool conv = sim.newton_finish();
       SS_TICK(PF_NFIN);

@@ -2,11 +2,10 @@
 //
 // One environment is stepped by one 64-lane wavefront.  The kernel works on "nodes": node 0 = the
 // root's 3 translational dofs, node 1 = its 3 rotational dofs, node b+1 = the 3 hinges of body b,
-// so dof d belongs to node d/3 and every node is a 3x3 block of the joint-space matrices.  The
-// tree-sparse matrix H (mass matrix / Newton Hessian) is stored as chain-dense block rows:
-// node n at depth L has 3 rows of W = 3L+3 floats (columns = the dofs along its ancestor chain in
-// root-to-node order, then its own 3), which is exactly the sparsity pattern of M (Featherstone's
-// branch-induced sparsity; SURVEY.md §8a "nnz(M)").
+// so dof d belongs to node d/3.  Every node is a 3-dof joint of an articulated-body recursion: node 0
+// carries a massless virtual body, node b+1 carries body b.  The joint-space matrices (mass matrix,
+// Newton Hessian M + J^T D J, Stable-PD matrix M + Kd dt) are never formed: systems with them are solved
+// by the articulated-body sweeps of ss_kernel.h (aba_solve), level by level over this node tree.
 #pragma once
 #include <cmath>
 #include <cstdint>
@@ -28,7 +27,6 @@ struct HostModel {
   std::vector<float> actc;        // [nv][4]: kp kd tlim (per dof, 0 for unactuated), [nv][2] scale offset -> in dofc
   std::vector<int32_t> dof_act;   // [nv] actuator index of a dof or -1
   std::vector<uint8_t> legal;     // [nb]
-  std::vector<int> decode;        // [ne] (row_dof << 16 | col_dof) of every stored H entry (host-side, diagnostics)
   uint64_t illegal_mask = 0;      // bodies whose floor contact terminates the episode
   std::string error;
 };
@@ -64,28 +62,15 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   int nlev = 0, nblev = 0;
   for (int n = 0; n < nn; n++) nlev = std::max(nlev, ndepth[n] + 1);
   for (int b = 0; b < nb; b++) nblev = std::max(nblev, bdepth[b] + 1);
-  h.nlev = nlev; h.nblev = nblev; h.maxD = 3 * (nlev - 1);
-  // H storage: node n at depth d owns d+1 blocks (J = 0..d-1 couple to its ancestors, J = d is the diagonal
-  // block), each 3 rows x 4 floats (one 16-byte row per ds_read_b128; the 4th float is padding)
-  std::vector<int> nbase(nn);
-  int ne = 0;
-  for (int n = 0; n < nn; n++) { nbase[n] = ne; ne += 12 * (ndepth[n] + 1); }
-  h.ne = ne;
-  const int CW = h.maxD > 0 ? h.maxD : 1;                  // chain table row width (in dofs)
+  h.nlev = nlev; h.nblev = nblev;
   const int CN = nlev;                                     // chain node table row width
-  std::vector<int> chainnode(nn * CN, 0), chainrow(nn * CW, 0);
+  std::vector<int> chainnode(nn * CN, 0);
   for (int n = 0; n < nn; n++) {
     std::vector<int> anc;                                  // root -> parent
     for (int a = nparent[n]; a >= 0; a = nparent[a]) anc.insert(anc.begin(), a);
     for (size_t k = 0; k < anc.size(); k++) chainnode[n * CN + k] = anc[k];
     chainnode[n * CN + anc.size()] = n;                    // convenient: chain includes self at its depth
   }
-  std::vector<int> decode(ne, -1);                         // (row_dof << 16 | col_dof) per stored float, -1 = padding
-  for (int n = 0; n < nn; n++)
-    for (int J = 0; J <= ndepth[n]; J++)
-      for (int r = 0; r < 3; r++)
-        for (int c = 0; c < 3; c++)
-          decode[nbase[n] + 12 * J + 4 * r + c] = ((3 * n + r) << 16) | (3 * chainnode[n * CN + J] + c);
   std::vector<int> levstart(nlev + 1, 0), levnodes, blevstart(nblev + 1, 0), blevbodies;
   for (int L = 0; L < nlev; L++) {
     levstart[L] = (int)levnodes.size();
@@ -183,100 +168,37 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   // ---- shared blob (copied into LDS once per workgroup)
   if (nlev > 19 || nblev > 19) { out.error = "tree too deep"; return false; }
   for (int L = 0; L <= nlev; L++) h.levstart[L] = levstart[L];
-  for (int L = 0; L <= nblev; L++) h.blevstart[L] = blevstart[L];
-  // packed work-item records (one LDS read per item instead of a chain of dependent table reads); every block is
-  // addressed by its float offset into H (or into the scratch buffer of parked P blocks, 12 floats per block):
-  //  blk   (assemble)                 w0 = aJ | n<<8 | diag<<16            w1 = block(n,J)
-  //  itemA (phase A, per level)       block(k,J)(13b) | n(6)<<13 | J(4)<<19 | kk(4)<<23
-  //  itemB (phase B targets)          w0 = block(aI,J) | nsrc<<16          w1 = src_start
-  //        fsrc                       scratch block (kk*L + I)*12 | block(k,J)<<16
-  //  bsol  (fused leaves-to-root sweep targets)   w0 = aJ | nsrc<<8        w1 = src_start
-  //        bsrc                       block(k,J) | n_k<<16
-  std::vector<int> blk, itemA, itemB, fsrc, bsol, bsrc, accp, children;
-  if (ne > 8191) { out.error = "H too large for the packed item tables"; return false; }
-  for (int n = 0; n < nn; n++) for (int J = 0; J <= ndepth[n]; J++) {
-    int aJ = chainnode[n * CN + J];
-    blk.push_back(aJ | (n << 8) | ((aJ == n) << 16));
-    blk.push_back(nbase[n] + 12 * J);
-  }
-  h.nblk = (int)blk.size() / 2;
+  // level records of the articulated-body sweeps, one word per node in level order:
+  //   n | parent_node<<8 | first_child_slot<<16 | child_count<<24
+  // (bodies are in depth-first order, so the children of a node are contiguous in the next level's list)
+  std::vector<int> lev(nn, 0);
+  int maxlev = 0;
   for (int L = 0; L < nlev; L++) {
-    h.itemA[L] = (int)itemA.size(); h.itemB[L] = (int)itemB.size() / 2;
-    int nk = levstart[L + 1] - levstart[L];
-    if (nk > 16 || L > 15) { out.error = "model exceeds the packed item-table field widths"; return false; }
+    const int nk = levstart[L + 1] - levstart[L];
+    maxlev = std::max(maxlev, nk);
     for (int kk = 0; kk < nk; kk++) {
-      int n = levnodes[levstart[L] + kk];
-      for (int J = 0; J < std::max(L, 1); J++)
-        itemA.push_back((nbase[n] + 12 * J) | (n << 13) | (J << 19) | (kk << 23));
-    }
-    for (int I = 0; I < L; I++) for (int J = 0; J <= I; J++) {
-      std::vector<int> seen;
-      for (int kk = 0; kk < nk; kk++) {
-        int aI = chainnode[levnodes[levstart[L] + kk] * CN + I];
-        bool dup = false; for (int a : seen) dup |= (a == aI);
-        if (dup) continue;
-        seen.push_back(aI);
-        int start = (int)fsrc.size(), cnt = 0;
-        for (int k2 = 0; k2 < nk; k2++) {
-          int n2 = levnodes[levstart[L] + k2];
-          if (chainnode[n2 * CN + I] != aI) continue;
-          fsrc.push_back(((k2 * L + I) * 12) | ((nbase[n2] + 12 * J) << 16)); cnt++;
-        }
-        itemB.push_back((nbase[aI] + 12 * J) | (cnt << 16));
-        itemB.push_back(start);
-      }
-    }
-    h.bsol[L] = (int)bsol.size() / 2;
-    for (int J = 0; J < L; J++) {
-      std::vector<int> seen;
-      for (int kk = 0; kk < nk; kk++) {
-        int aJ = chainnode[levnodes[levstart[L] + kk] * CN + J];
-        bool dup = false; for (int a : seen) dup |= (a == aJ);
-        if (dup) continue;
-        seen.push_back(aJ);
-        int start = (int)bsrc.size(), cnt = 0;
-        for (int k2 = 0; k2 < nk; k2++) {
-          int n2 = levnodes[levstart[L] + k2];
-          if (chainnode[n2 * CN + J] != aJ) continue;
-          bsrc.push_back((nbase[n2] + 12 * J) | (n2 << 16)); cnt++;
-        }
-        bsol.push_back(aJ | (cnt << 8)); bsol.push_back(start);
-      }
+      const int n = levnodes[levstart[L] + kk];
+      int cfirst = 0, cc = 0;
+      if (L + 1 < nlev)
+        for (int k2 = 0; k2 < levstart[L + 2] - levstart[L + 1]; k2++)
+          if (nparent[levnodes[levstart[L + 1] + k2]] == n) {
+            if (cc == 0) cfirst = k2;
+            else if (k2 != cfirst + cc) { out.error = "bodies must be in depth-first order"; return false; }
+            cc++;
+          }
+      lev[levstart[L] + kk] = n | ((n > 0 ? nparent[n] : 0) << 8) | (cfirst << 16) | (cc << 24);
     }
   }
-  h.itemA[nlev] = (int)itemA.size(); h.itemB[nlev] = (int)itemB.size() / 2;
-  h.bsol[nlev] = (int)bsol.size() / 2;
-  // tree accumulation (children -> parent), pull form, per body level: p | cstart<<8 | ccount<<20
-  for (int L = 0; L < nblev; L++) {
-    h.accp[L] = (int)accp.size();
-    for (int b = 0; b < nb; b++) {
-      if (bdepth[b] != L) continue;
-      int start = (int)children.size(), cnt = 0;
-      for (int c = 0; c < nb; c++) if (d.body_parent[c] == b) { children.push_back(c); cnt++; }
-      if (cnt) accp.push_back(b | (start << 8) | (cnt << 20));
-    }
-  }
-  h.accp[nblev] = (int)accp.size();
-  h.itemA[nlev] = (int)itemA.size(); h.itemB[nlev] = (int)itemB.size() / 2;
-  out.decode = decode;
+  if (maxlev > 16) { out.error = "more than 16 nodes in one tree level"; return false; }
+  h.maxlev = maxlev;
   auto &S = out.shared; S.clear();
   auto push_i = [&](const std::vector<int> &v) { int o = (int)S.size(); for (int x : v) S.push_back((uint32_t)x); return o; };
   h.o_dofc = (int)S.size(); for (float f : dofc) S.push_back(f2u(f));
   h.o_chainnode = push_i(chainnode);
-  h.o_nbase = push_i(nbase);
   h.o_ndepth = push_i(ndepth);
-  h.o_levnodes = push_i(levnodes);
+  h.o_lev = push_i(lev);
   std::vector<int> bpar(d.body_parent, d.body_parent + nb);
   h.o_bparent = push_i(bpar);
-  h.o_blevbodies = push_i(blevbodies);
-  h.o_blk = push_i(blk);
-  h.o_itemA = push_i(itemA);
-  h.o_itemB = push_i(itemB);
-  h.o_fsrc = push_i(fsrc);
-  h.o_accp = push_i(accp);
-  h.o_children = push_i(children);
-  h.o_bsol = push_i(bsol);
-  h.o_bsrc = push_i(bsrc);
   {
     // subtree sizes: bodies are in depth-first order, so the subtree of b is the index range [b, b + size)
     std::vector<int> subsize(nb, 1);
@@ -290,40 +212,31 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
     h.o_subsize = push_i(subsize);
   }
   h.shared_words = (int)S.size();
-  (void)chainrow; (void)nparent; (void)CW;
+  (void)blevstart; (void)blevbodies;
 
-  // ---- per-env LDS layout (floats)
-  int maxU = 0;                                            // U buffer: nodes-in-level * 3 * D
-  for (int L = 1; L < nlev; L++) maxU = std::max(maxU, (levstart[L + 1] - levstart[L]) * 12 * L);
+  // ---- per-env LDS layout (floats); arrays with disjoint lifetimes share storage (LDS capacity sets the number
+  // of resident envs per CU)
   if (nn > 64) { out.error = "too many nodes"; return false; }
-  if (13 * h.nslot > ne) { out.error = "contact record buffer does not fit"; return false; }
   int o = 0;
   auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
-  // Arrays with disjoint lifetimes share storage (LDS capacity sets the number of resident envs per CU):
-  //   H region  : contact records (make_constraints) | per-body K inputs, subtree-summed Kc and Gb (forward_kin /
-  //               newton_prepare, dead before assemble_H writes H) | the matrix itself
-  //   G region  : R, r and Ad (forward pass .. constraints / row evaluation) | G_i = Hc S_i (assembly) | U buffers |
-  //               scratch of body_accel / the forward triangular sweep
-  //   grad,delta: V (body velocities, dead after make_constraints)
-  h.l_H = take(ne);
-  if (48 * nb > ne || 13 * h.nslot > ne) { out.error = "H region too small for its aliases"; return false; }
-  h.l_K = h.l_H + 21 * nb;                                 // Kc (subtree sums); inputs live at H[0 .. 21 nb)
-  h.l_Gb = h.l_H + 42 * nb;
-  h.l_S = take(6 * nv);
-  const int gneed = std::max(std::max(6 * nv, maxU), 18 * nb);
-  h.l_G = take(gneed);                                     // also the scratch buffer of parked P blocks in the factorization
-  h.maxU = maxU;
-  h.l_R = h.l_G; h.l_r = h.l_G + 9 * nb;                   // R, r: first 12 nb floats of G
-  h.l_Ad = h.l_G + gneed - 6 * nb;                         // Ad: last 6 nb floats of G (body_accel scratch uses G[0 .. 6 nn))
-  if (12 * nb > gneed - 6 * nb || 6 * nn > gneed - 6 * nb) { out.error = "G region too small for its aliases"; return false; }
-  h.l_Dinv = take(6 * nn);
-  h.l_Ic = take(10 * nb);
-  h.l_Ab = take(6 * nb);
-  h.l_q = take(nv + 1); h.l_v = take(nv); h.l_a = take(nv); h.l_tau = take(nv);
+  h.l_q = take(nv + 1); h.l_v = take(nv); h.l_a = take(nv); h.l_tau = take(nv); h.l_C = take(nv);
   h.l_grad = take(nv); h.l_delta = take(nv);
-  h.l_V = h.l_grad;                                        // V: 6 nb <= 2 (nv+pad) floats of grad + delta
+  h.l_V = h.l_grad;                                        // V (body velocities): dead after make_constraints
   if (6 * nb > h.l_delta + nv - h.l_grad) { out.error = "V alias does not fit"; return false; }
-  h.l_C = take(nv); h.l_diag = take(nv);
+  h.l_diag = take(nv);
+  h.l_S = take(6 * nv);
+  h.l_Ab = take(6 * nb);
+  h.l_An = take(8 * nn);                                   // node accelerations of the last solve; Ad (6 nb) aliases it
+  // solver region Z
+  h.l_Aown = take(21 * nb);                                // per-body generalized inertia I_b + K_b, packed symmetric
+  h.ia_stride = 48 * maxlev;
+  const int ia_need = std::max(2 * h.ia_stride, ((6 * nb + 3) & ~3) + 6 * nn);
+  h.l_IA = take(ia_need);                                  // articulated rows of the current / previous level
+  h.l_Gb = h.l_IA; h.l_tmp = h.l_IA + ((6 * nb + 3) & ~3);  // subtree sums and body_accel scratch live outside solves
+  h.l_Ubuf = take(24 * maxlev);
+  if (13 * h.nslot > o - h.l_Aown) { out.error = "contact record buffer does not fit"; return false; }
+  h.l_Wst = take(24 * nn);                                 // (W_r, y_r) per node row, kept for the downward sweep
+  h.l_R = h.l_Wst; h.l_r = h.l_Wst + 9 * nb;               // R, r: forward kinematics .. constraints / observations
   h.l_misc = take(16);
   h.env_floats = o;
 

@@ -41,16 +41,13 @@ def test_forward_pieces_match_oracle(vec):
     rs = np.random.default_rng(1)
     tq = rs.normal(size=(12, 69)) * 20
     xpos, xmat = env.kinematics()
-    dec, Me, bias, qacc = env.debug_forward(torch.tensor(tq, device=env.device))
+    Me, bias, qacc = env.debug_forward(torch.tensor(tq, device=env.device))
     torch.cuda.synchronize()
     xpos, Me, bias, qacc = _np(xpos), _np(Me), _np(bias), _np(qacc)
-    valid = dec >= 0
-    rows, cols = np.where(valid, dec >> 16, 0), np.where(valid, dec & 0xFFFF, 0)
     for i in range(12):
         d = O.OracleData(om); d.qpos = Q[i]; d.qvel = V[i]; d.ctrl = tq[i]; d.forward()
         assert np.abs(xpos[i] - d.xpos).max() < 2e-6
-        low = valid & (rows >= cols)
-        assert np.abs(Me[i][low] - d.M[rows[low], cols[low]]).max() < 2e-6 * np.abs(d.M).max()
+        assert np.abs(Me[i] - d.M).max() < 2e-6 * np.abs(d.M).max()
         assert np.abs(bias[i] - d.bias).max() < 2e-6 * max(1.0, np.abs(d.bias).max())
         assert np.abs(qacc[i] - d.qacc).max() < 5e-5 * np.abs(d.qacc).max(), (i, d.ncon)
         touch = sum(1 << b for b in range(24) if d.touch[b])

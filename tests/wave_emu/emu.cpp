@@ -178,11 +178,11 @@ struct WaveEmu {
 
 struct LaunchCtx { const ss::KArgs *k; const uint32_t *T; float *L; int env; Machine *m; };
 
-template <int DOFP, int CANDP, int SLOTP>
+template <int DOFP, int CANDP, int SLOTP, int NPASS>
 void lane_entry(int lane, void *arg) {
   LaunchCtx *c = (LaunchCtx *)arg;
   WaveEmu w{c->m, lane};
-  ss::run_env<WaveEmu, DOFP, CANDP, SLOTP>(&w, c->k, c->T, c->L, c->env);
+  ss::run_env<WaveEmu, DOFP, CANDP, SLOTP, NPASS>(&w, c->k, c->T, c->L, c->env);
 }
 
 struct EmuBackend {
@@ -193,21 +193,20 @@ struct EmuBackend {
   static bool download(void *dst, const void *src, size_t n) { memcpy(dst, src, n); return true; }
   static int lds_capacity() { return 160 * 1024; }
   static int kernel_regs() { return 0; }
-  static int max_waves(int, int, int) { return 16; }
+  static int max_waves(int) { return 16; }
   static const char *launch(const ss::KArgs &k, int nenv, int envs_per_wg, size_t lds_bytes, void *) {
     (void)envs_per_wg; (void)lds_bytes;
     static thread_local Machine *m = new Machine();
     std::vector<float> L(k.h.env_floats);
-    const int dofp = (k.h.nv + 63) / 64, candp = (k.h.ncand + 63) / 64;
     *k.work_counter = 0;
     for (int env = 0; env < nenv; env++) {
       // poison LDS so that reads of never-written locations are visible
       for (auto &x : L) x = __builtin_nanf("");
       LaunchCtx c{&k, k.shared_g, L.data(), k.order ? k.order[env] : env, m};
       void (*entry)(int, void *) = nullptr;
-      const int slotp = (k.h.nslot + 63) / 64;
-      if (dofp == 2 && candp == 2 && slotp == 1) entry = lane_entry<2, 2, 1>;
-      else if (dofp == 3 && candp <= 3 && slotp <= 2) entry = lane_entry<3, 3, 2>;
+      const int variant = ss::kernel_variant(k.h);
+      if (variant == 0) entry = lane_entry<2, 2, 1, 1>;
+      else if (variant == 1) entry = lane_entry<3, 3, 2, 2>;
       else return "no kernel variant for this model size";
       run_wave(m, entry, &c);
     }

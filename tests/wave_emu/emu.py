@@ -99,19 +99,9 @@ class EmuBatch:
         return xpos, xmat
 
     def debug_forward(self, torques=None):
-        ne = C.c_int32()
-        self._chk(lib().ss_debug_decode(self.model, None, C.byref(ne)))
-        dec = np.zeros(ne.value, np.int32)
-        self._chk(lib().ss_debug_decode(self.model, _p(dec), C.byref(ne)))
-        Me = np.zeros((self.N, ne.value), np.float32)
-        bias = np.zeros((self.N, self.mc.nv), np.float32); qacc = np.zeros((self.N, self.mc.nv), np.float32)
-        tq = None if torques is None else np.ascontiguousarray(torques, np.float32)
-        self._chk(lib().ss_debug_forward(self.batch, _p(tq), _p(Me), _p(bias), _p(qacc), None))
         nv = self.mc.nv
         M = np.zeros((self.N, nv, nv), np.float32)
-        valid = dec >= 0                                       # -1 marks the padding float of each 16-byte block row
-        rows, cols = np.where(valid, dec >> 16, 0), np.where(valid, dec & 0xFFFF, 0)
-        lower = valid & (rows >= cols)
-        M[:, rows[lower], cols[lower]] = Me[:, lower]
-        M[:, cols[lower], rows[lower]] = Me[:, lower]
+        bias = np.zeros((self.N, nv), np.float32); qacc = np.zeros((self.N, nv), np.float32)
+        tq = None if torques is None else np.ascontiguousarray(torques, np.float32)
+        self._chk(lib().ss_debug_forward(self.batch, _p(tq), _p(M), _p(bias), _p(qacc), None))
         return M, bias, qacc
