@@ -76,11 +76,10 @@ struct Sim {
   const uint32_t *T;      // shared tables in LDS
   int lane, env;
   // per-env LDS arrays
-  float *S, *R, *r, *V, *Ab, *An, *Ad, *Gb, *tmpb, *Aown, *IA, *Ubuf, *Wst, *q, *v, *a, *tau, *grad, *delta, *C, *diag, *misc;
+  float *S, *R, *r, *V, *Ab, *An, *Ad, *Gb, *tmpb, *Aown, *IA, *Ubuf, *Wst, *q, *v, *a, *tau, *grad, *delta, *C, *diag, *Iown;
   // per-lane constants
   int bpar, bdep;
   // per-lane state
-  float Ib[10];
   Contact con[SLOTP];
   Limit lim[DOFP];
   float perr[DOFP];
@@ -103,7 +102,7 @@ struct Sim {
     S = L + h.l_S; R = L + h.l_R; r = L + h.l_r; V = L + h.l_V; Ab = L + h.l_Ab; An = L + h.l_An; Ad = An;
     Gb = L + h.l_Gb; tmpb = L + h.l_tmp; Aown = L + h.l_Aown; IA = L + h.l_IA; Ubuf = L + h.l_Ubuf; Wst = L + h.l_Wst;
     q = L + h.l_q; v = L + h.l_v; a = L + h.l_a; tau = L + h.l_tau; grad = L + h.l_grad;
-    delta = L + h.l_delta; C = L + h.l_C; diag = L + h.l_diag; misc = L + h.l_misc;
+    delta = L + h.l_delta; C = L + h.l_C; diag = L + h.l_diag; Iown = L + h.l_Iown;
     bpar = -1; bdep = -1;
     if (lane < h.nb) { bpar = ti(h.o_bparent, lane); bdep = ti(h.o_ndepth, lane + 1) - 1; }
 #pragma unroll
@@ -296,6 +295,7 @@ struct Sim {
       float Iyy = RB[3] * Rb[3] + RB[4] * Rb[4] + RB[5] * Rb[5];
       float Iyz = RB[3] * Rb[6] + RB[4] * Rb[7] + RB[5] * Rb[8];
       float Izz = RB[6] * Rb[6] + RB[7] * Rb[7] + RB[8] * Rb[8];
+      float Ib[10];
       Ib[0] = m; Ib[1] = m * cx_; Ib[2] = m * cy_; Ib[3] = m * cz_;
       Ib[4] = Ixx + m * (cy_ * cy_ + cz_ * cz_); Ib[5] = Ixy - m * cx_ * cy_; Ib[6] = Ixz - m * cx_ * cz_;
       Ib[7] = Iyy + m * (cx_ * cx_ + cz_ * cz_); Ib[8] = Iyz - m * cy_ * cz_; Ib[9] = Izz + m * (cx_ * cx_ + cy_ * cy_);
@@ -303,6 +303,8 @@ struct Sim {
       float ag[6] = {ab[0], ab[1], ab[2], ab[3], ab[4], ab[5] - h.grav};
       float Ia[6], Iv[6], fb[6];
       imul(Ib, ag, Ia); imul(Ib, vb, Iv);
+#pragma unroll
+      for (int i = 0; i < 10; i++) Iown[10 * b + i] = Ib[i];   // the body's own inertia stays in LDS for the solves of this pass
       fb[0] = Ia[0] + vb[1] * Iv[2] - vb[2] * Iv[1] + vb[4] * Iv[5] - vb[5] * Iv[4];
       fb[1] = Ia[1] + vb[2] * Iv[0] - vb[0] * Iv[2] + vb[5] * Iv[3] - vb[3] * Iv[5];
       fb[2] = Ia[2] + vb[0] * Iv[1] - vb[1] * Iv[0] + vb[3] * Iv[4] - vb[4] * Iv[3];
@@ -524,6 +526,7 @@ struct Sim {
   SS_DEV void write_own_inertia() {                          // Aown[b] = expand(Ib), packed upper triangle (ang;lin)
     if (lane < k->h.nb) {
       float *o = Aown + 21 * lane;
+      const float *Ib = Iown + 10 * lane;
       const float m = Ib[0], cx = Ib[1], cy = Ib[2], cz = Ib[3];
       o[0] = Ib[4]; o[1] = Ib[5]; o[2] = Ib[6]; o[3] = 0.f; o[4] = -cz; o[5] = cy;
       o[6] = Ib[7]; o[7] = Ib[8]; o[8] = cz; o[9] = 0.f; o[10] = -cx;
@@ -544,7 +547,7 @@ struct Sim {
       const int s0 = h.levstart[L], nk = h.levstart[L + 1] - s0;
       float *cur = IA + (L & 1) * h.ia_stride;
       const float *prev = IA + ((L + 1) & 1) * h.ia_stride;
-      float row[NPASS][6], pa[NPASS], Sr[NPASS][18], Ur[NPASS][3];
+      float row[NPASS][6], pa[NPASS], Ur[NPASS][3];
       int nod[NPASS];
 #pragma unroll
       for (int ps = 0; ps < NPASS; ps++) {                    // ---- phase 1: articulated row, U_r = IA_r S
@@ -566,12 +569,10 @@ struct Sim {
           }
           const float *sn = S + 18 * n;
 #pragma unroll
-          for (int t = 0; t < 18; t++) Sr[ps][t] = sn[t];
-#pragma unroll
           for (int j = 0; j < 3; j++) {
             float acc = 0.f;
 #pragma unroll
-            for (int c = 0; c < 6; c++) acc += rw[c] * Sr[ps][6 * j + c];
+            for (int c = 0; c < 6; c++) acc += rw[c] * sn[6 * j + c];
             Ur[ps][j] = acc;
           }
 #pragma unroll
@@ -589,7 +590,9 @@ struct Sim {
           float4_t U[6];
 #pragma unroll
           for (int c = 0; c < 6; c++) U[c] = ld4(Ubuf + (kk * 6 + c) * 4);
-          const float *sr = Sr[ps];
+          float sr[18];                                       // S_n again (cheaper than 18 registers held across the sync)
+#pragma unroll
+          for (int t = 0; t < 18; t++) sr[t] = S[18 * n + t];
           float d00 = diag[3 * n], d10 = 0.f, d11 = diag[3 * n + 1], d20 = 0.f, d21 = 0.f, d22 = diag[3 * n + 2];
           float u0 = x[3 * n], u1 = x[3 * n + 1], u2 = x[3 * n + 2];
 #pragma unroll
@@ -665,7 +668,7 @@ struct Sim {
       w->sync();
       if (lane < h.nb) {
         float Ia[6];
-        imul(Ib, Ab + 6 * lane, Ia);
+        imul(Iown + 10 * lane, Ab + 6 * lane, Ia);
 #pragma unroll
         for (int c = 0; c < 6; c++) Ad[6 * lane + c] = Ia[c];
       }
@@ -724,7 +727,7 @@ struct Sim {
     iters++;
     if (lane < h.nb) {
       float Ia[6];
-      imul(Ib, Ab + 6 * lane, Ia);
+      imul(Iown + 10 * lane, Ab + 6 * lane, Ia);
 #pragma unroll
       for (int c = 0; c < 6; c++) Ad[6 * lane + c] = Ia[c];    // per-body terms go to Ad, their subtree sums to Gb
     }

@@ -226,6 +226,7 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   h.l_diag = take(nv);
   h.l_S = take(6 * nv);
   h.l_Ab = take(6 * nb);
+  h.l_Iown = take(10 * nb);                                // own spatial inertia of every body (10 parameters)
   h.l_An = take(8 * nn);                                   // node accelerations of the last solve; Ad (6 nb) aliases it
   // solver region Z
   h.l_Aown = take(21 * nb);                                // per-body generalized inertia I_b + K_b, packed symmetric
@@ -233,11 +234,11 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   const int ia_need = std::max(2 * h.ia_stride, ((6 * nb + 3) & ~3) + 6 * nn);
   h.l_IA = take(ia_need);                                  // articulated rows of the current / previous level
   h.l_Gb = h.l_IA; h.l_tmp = h.l_IA + ((6 * nb + 3) & ~3);  // subtree sums and body_accel scratch live outside solves
-  h.l_Ubuf = take(24 * maxlev);
+  // U rows of the level in flight: only live in the upward sweep, An only from the downward sweep on
+  h.l_Ubuf = 24 * maxlev <= 8 * nn ? h.l_An : take(24 * maxlev);
   if (13 * h.nslot > o - h.l_Aown) { out.error = "contact record buffer does not fit"; return false; }
   h.l_Wst = take(24 * nn);                                 // (W_r, y_r) per node row, kept for the downward sweep
   h.l_R = h.l_Wst; h.l_r = h.l_Wst + 9 * nb;               // R, r: forward kinematics .. constraints / observations
-  h.l_misc = take(16);
   h.env_floats = o;
 
   h.dt = (float)d.timestep; h.grav = (float)d.gravity; h.margin = (float)d.margin; h.mu = (float)d.friction;

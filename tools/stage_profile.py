@@ -16,7 +16,7 @@ from smplsim_amd import _cabi, _lib
 
 prof_so = os.path.join(ROOT, "gpurun_out", "libsmplsim_hip_prof.so")
 os.makedirs(os.path.dirname(prof_so), exist_ok=True)
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DSS_PROFILE",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DSS_PROFILE", *os.environ.get("SS_EXTRA", "").split(),
                        os.path.join(_lib.SRC_DIR, "smplsim_hip.hip"), "-o", prof_so])
 _lib._LIB = _cabi.bind(C.CDLL(prof_so))
 from smplsim_amd.batch import SMPLSimVecEnv
@@ -30,8 +30,8 @@ for _ in range(steps):
 torch.cuda.synchronize()
 out = (C.c_ulonglong * 64)()
 rc = _lib.lib().ss_debug_prof(env.handle, out, 24)
-names = ["fwd_kin", "constraints", "newton_begin", "newton_prepare", "assemble", "factor", "solve", "newton_finish",
-         "spd_prepare", "spd_finish", "integrate", "misc", "factor:phase1+3", "factor:sync1", "factor:phase2", "factor:bsol", "factor:sync2"]
+names = ["fwd_kin", "constraints", "newton_begin", "newton_prepare", "(unused)", "aba_solve", "(unused)", "newton_finish",
+         "spd_prepare", "spd_finish", "integrate", "misc", "aba:up_phase1", "aba:up_last_sync", "aba:up_phase2", "aba:down", "(unused)"]
 tot = sum(out[i] for i in range(12))
 iters = float(env.solver_iters.float().mean().item())
 res = {"rc": rc, "total_ticks": tot, "mean_newton_iters": iters, "stages": {}}
