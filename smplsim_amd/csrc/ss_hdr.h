@@ -15,7 +15,7 @@ constexpr int kCandC = 8;    // floats per contact candidate
 // per-env LDS layout (float offsets) and physics scalars.
 struct Hdr {
   int nb, nn, nv, nq, nu, ncand, nlev, nblev, nbox, nslot, maxlev;
-  int levstart[20];                  // node level offsets (kernel arguments -> scalar loads)
+  unsigned long long nkpack[2];      // (nodes in level L) - 1, 4 bits per level: level bounds by SALU shifts, no table/kernarg loads
   // shared-blob word offsets
   int o_dofc, o_chainnode, o_ndepth, o_lev, o_bparent, o_subsize, shared_words;
   // per-env LDS float offsets.  Z = solver region: Aown | IA (2 level buffers) | Ubuf | Wst ; aliases: contact records

@@ -543,8 +543,11 @@ struct Sim {
 #pragma unroll
     for (int c = 0; c < 6; c++) { const int lo = r_ < c ? r_ : c, hi = r_ < c ? c : r_; off[c] = (lo * (11 - lo)) / 2 + hi; }
     SS_FT0();
+    const unsigned long long nk0 = h.nkpack[0], nk1 = h.nkpack[1];
+    int s0 = h.nn;
     for (int L = h.nlev - 1; L >= 0; --L) {
-      const int s0 = h.levstart[L], nk = h.levstart[L + 1] - s0;
+      const int nk = (int)(((L < 16 ? nk0 : nk1) >> (4 * (L & 15))) & 15ull) + 1;
+      s0 -= nk;
       float *cur = IA + (L & 1) * h.ia_stride;
       const float *prev = IA + ((L + 1) & 1) * h.ia_stride;
       float row[NPASS][6], pa[NPASS], Ur[NPASS][3];
@@ -562,17 +565,20 @@ struct Sim {
 #pragma unroll
             for (int c = 0; c < 6; c++) rw[c] = ao[off[c]];
           }
+          float sv[18];                                       // S_n: issued before the child loop, consumed after it
+          const float *sn = S + 18 * n;
+#pragma unroll
+          for (int t = 0; t < 18; t++) sv[t] = sn[t];
           for (int j = 0; j < cc; j++) {
             const float *src = prev + ((cfirst + j) * 6 + r_) * 8;
             const float4_t v0 = ld4(src), v1 = ld4(src + 4);
             rw[0] += v0.x; rw[1] += v0.y; rw[2] += v0.z; rw[3] += v0.w; rw[4] += v1.x; rw[5] += v1.y; pv += v1.z;
           }
-          const float *sn = S + 18 * n;
 #pragma unroll
           for (int j = 0; j < 3; j++) {
             float acc = 0.f;
 #pragma unroll
-            for (int c = 0; c < 6; c++) acc += rw[c] * sn[6 * j + c];
+            for (int c = 0; c < 6; c++) acc += rw[c] * sv[6 * j + c];
             Ur[ps][j] = acc;
           }
 #pragma unroll
@@ -621,8 +627,8 @@ struct Sim {
       w->sync();
     }
     SS_FTICK(PF_F_SYNC1);
-    for (int L = 0; L < h.nlev; L++) {                        // ---- downward sweep
-      const int s0 = h.levstart[L], nk = h.levstart[L + 1] - s0;
+    for (int L = 0; L < h.nlev; L++) {                        // ---- downward sweep (s0 is 0 again after the upward one)
+      const int nk = (int)(((L < 16 ? nk0 : nk1) >> (4 * (L & 15))) & 15ull) + 1;
 #pragma unroll
       for (int ps = 0; ps < NPASS; ps++) {
         const int kk = ps * 8 + g;
@@ -643,6 +649,7 @@ struct Sim {
           if (r_ < 3) x[3 * n + r_] = r_ == 0 ? x0 : (r_ == 1 ? x1 : x2);
         }
       }
+      s0 += nk;
       w->sync();
     }
     SS_FTICK(PF_F_BSOL);

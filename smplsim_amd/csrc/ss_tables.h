@@ -166,8 +166,7 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   }
 
   // ---- shared blob (copied into LDS once per workgroup)
-  if (nlev > 19 || nblev > 19) { out.error = "tree too deep"; return false; }
-  for (int L = 0; L <= nlev; L++) h.levstart[L] = levstart[L];
+  if (nlev > 32 || nblev > 32) { out.error = "tree too deep"; return false; }
   // level records of the articulated-body sweeps, one word per node in level order:
   //   n | parent_node<<8 | first_child_slot<<16 | child_count<<24
   // (bodies are in depth-first order, so the children of a node are contiguous in the next level's list)
@@ -191,6 +190,8 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   }
   if (maxlev > 16) { out.error = "more than 16 nodes in one tree level"; return false; }
   h.maxlev = maxlev;
+  h.nkpack[0] = h.nkpack[1] = 0ull;
+  for (int L = 0; L < nlev; L++) h.nkpack[L >> 4] |= (unsigned long long)(levstart[L + 1] - levstart[L] - 1) << (4 * (L & 15));
   auto &S = out.shared; S.clear();
   auto push_i = [&](const std::vector<int> &v) { int o = (int)S.size(); for (int x : v) S.push_back((uint32_t)x); return o; };
   h.o_dofc = (int)S.size(); for (float f : dofc) S.push_back(f2u(f));
