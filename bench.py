@@ -6,7 +6,7 @@ uniform(-1,1) actions every control step, obs v1 + reward + reset flags computed
 launch, device-side autoreset.  One "step" = one control step of every env on every rank
 (15 mj_steps each).  Weak scaling: independent shards, no collective in the data path.
 
-    python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus 1 --steps 1000 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 """
@@ -27,7 +27,7 @@ WORKLOADS = {
             "actions per control step, 15 mj_steps @450 Hz per step, obs v1 (289 f32) + reward + reset flags fused, "
             "device-side autoreset",
     "getup": "BASELINE config 3 shard: {N} SMPL humanoids, env=getup (obs 290, height reward, contact termination, 60-step "
-             "recovery), StateInit.Fall (45 warm-up mj_steps per reset), uniform(-1,1) actions; kernel_ms includes the masked reset launch",
+             "recovery), StateInit.Fall (45 warm-up mj_steps per reset), uniform(-1,1) actions (ms_per_step includes the masked Fall-reset launch, kernel_ms is the step launch)",
     "smplx": "BASELINE config 4: {N} SMPL-X/H-layout humanoids (52 bodies, nv=159, nu=153), base env, obs v1 (625 f32), uniform(-1,1) actions",
 }
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -69,7 +69,7 @@ def cpu_baseline(seconds=12.0):
     envs = [O.OracleEnv(om) for _ in range(nenv)]
     for e in envs:
         e.reset()
-    steps2 = int(max(8, min(400, seconds * rate1 * cores / nenv)))
+    steps2 = int(max(8, min(4000, seconds * rate1 * cores / nenv)))
     acts = rs.uniform(-1, 1, (steps2, nenv, 69))
     t0 = time.perf_counter()
     done = O.batch_rollout(envs, acts, cores)
@@ -83,7 +83,7 @@ def cpu_baseline(seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
