@@ -30,10 +30,20 @@ struct WaveGpu {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
   }
+  // cross-lane moves as DPP modifiers of VALU instructions (no LDS-crossbar ds_bpermute round trips):
+  // quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140
+  template <int CTRL> static __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+  template <int CTRL> static __device__ __forceinline__ float dpp_f(float v) { return __builtin_bit_cast(float, dpp_i<CTRL>(__builtin_bit_cast(int, v))); }
+  static __device__ __forceinline__ float rl(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+  // wave-wide sum, result in every lane: 4 DPP steps give every 16-lane row its sum, then 4 readlanes
   __device__ __forceinline__ float sum(float v) const {
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+    v += dpp_f<0xB1>(v); v += dpp_f<0x4E>(v); v += dpp_f<0x141>(v); v += dpp_f<0x140>(v);
+    return (rl(v, 0) + rl(v, 16)) + (rl(v, 32) + rl(v, 48));
   }
+  __device__ __forceinline__ float quad_xor1(float v) const { return dpp_f<0xB1>(v); }
+  __device__ __forceinline__ float quad_xor2(float v) const { return dpp_f<0x4E>(v); }
+  __device__ __forceinline__ int quad_xor1_i(int v) const { return dpp_i<0xB1>(v); }
+  __device__ __forceinline__ int quad_xor2_i(int v) const { return dpp_i<0x4E>(v); }
   __device__ __forceinline__ unsigned long long clock() const { return __builtin_readcyclecounter(); }
   __device__ __forceinline__ void atomic_add_u64(unsigned long long *p, unsigned long long v) const { atomicAdd(p, v); }
   __device__ __forceinline__ int opaque(int x) const { return __builtin_amdgcn_readfirstlane(x); }   // wave-uniform, optimizer-opaque
@@ -43,9 +53,12 @@ struct WaveGpu {
   __device__ __forceinline__ unsigned long long ballot(int p) const { return __ballot(p); }
   __device__ __forceinline__ bool any(int p) const { return __any(p) != 0; }
   __device__ __forceinline__ unsigned long long bor(unsigned long long v) const {
-    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-    for (int m = 32; m >= 1; m >>= 1) { lo |= (unsigned)__shfl_xor((int)lo, m, 64); hi |= (unsigned)__shfl_xor((int)hi, m, 64); }
-    return ((unsigned long long)hi << 32) | lo;
+    int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
+    lo |= dpp_i<0xB1>(lo); lo |= dpp_i<0x4E>(lo); lo |= dpp_i<0x141>(lo); lo |= dpp_i<0x140>(lo);
+    hi |= dpp_i<0xB1>(hi); hi |= dpp_i<0x4E>(hi); hi |= dpp_i<0x141>(hi); hi |= dpp_i<0x140>(hi);
+    const unsigned l = (unsigned)(__builtin_amdgcn_readlane(lo, 0) | __builtin_amdgcn_readlane(lo, 16) | __builtin_amdgcn_readlane(lo, 32) | __builtin_amdgcn_readlane(lo, 48));
+    const unsigned h = (unsigned)(__builtin_amdgcn_readlane(hi, 0) | __builtin_amdgcn_readlane(hi, 16) | __builtin_amdgcn_readlane(hi, 32) | __builtin_amdgcn_readlane(hi, 48));
+    return ((unsigned long long)h << 32) | l;
   }
   __device__ __forceinline__ void atomic_add(float *p, float v) const {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);

@@ -7,12 +7,12 @@
 // in ONE kernel launch.  It is a new design, not a translation of MuJoCo:
 //   * all rigid-body quantities are 6-D spatial vectors in a world-aligned frame whose origin is
 //     the root body (keeps |r| < 2 m so float32 cancellation in m r^2 terms stays ~1e-6);
-//   * the joint-space matrices are never formed densely: H(i,j) = S_j . (Hc_body(i) S_i) on the
-//     tree sparsity pattern, factored by a level-parallel 3x3-block L^T D L in LDS;
+//   * the joint-space matrices are never formed: every system H x = b (Newton Hessian, Stable-PD matrix)
+//     is solved by an articulated-body recursion over the joint tree in LDS (aba_solve);
 //   * MuJoCo's soft-constraint problem  min_a 1/2 (a-a_s)^T M (a-a_s) + sum_i s_i(J_i a - aref_i)
 //     is solved by Newton's method with the contact Jacobian folded into per-body 6x6 matrices:
-//     J^T D J = sum_b X_b^T K_b X_b, i.e. the Hessian M + J^T D J is assembled by the SAME composite
-//     "inertia" pass as M (floor contacts touch one ancestor chain, so the sparsity is unchanged);
+//     J^T D J = sum_b X_b^T K_b X_b, i.e. the Hessian M + J^T D J is the "mass matrix" of bodies with
+//     generalized inertias I_b + K_b, which is exactly what the recursion takes;
 //   * lanes are bodies / dofs / matrix entries / contact candidates depending on the stage; data
 //     crosses lanes through the env's LDS block only, separated by wave-level syncs.
 //
@@ -717,7 +717,7 @@ struct Sim {
     d2 = c2 + w->sum(s2);
   }
 
-  // Newton on MuJoCo's convex primal problem, split so that the shared assemble/factor/solve site sits
+  // Newton on MuJoCo's convex primal problem, split so that the shared articulated-body solve site sits
   // between newton_prepare() and newton_finish() in the driver's solver loop.
   SS_DEV void newton_begin() {
     fresh();
@@ -784,12 +784,12 @@ struct Sim {
       // group sums: xor 1 (pairs), then xor 2 for box quads
 #pragma unroll
       for (int t = 0; t < 27; t++) {
-        float v1 = vals[t] + w->shfl_xor(vals[t], 1);
-        float v2 = w->shfl_xor(v1, 2);
+        float v1 = vals[t] + w->quad_xor1(vals[t]);
+        float v2 = w->quad_xor2(v1);
         vals[t] = boxlane ? v1 + v2 : v1;
       }
-      const int grp_any = w->shfl_xor_i(c.active, 1) | c.active;
-      const int grp_any2 = w->shfl_xor_i(grp_any, 2) | grp_any;
+      const int grp_any = w->quad_xor1_i(c.active) | c.active;
+      const int grp_any2 = w->quad_xor2_i(grp_any) | grp_any;
       const int body_of_group = boxlane ? h_box_body(sl) : h_caps_body(sl);
       const bool leader = boxlane ? ((sl & 3) == 0 && grp_any2) : ((sl & 1) == 0 && grp_any);
       if (leader && sl < h.nslot) {

@@ -168,6 +168,10 @@ struct WaveEmu {
     arrive(11);
     return r;
   }
+  float quad_xor1(float v) { return shfl_xor(v, 1); }
+  float quad_xor2(float v) { return shfl_xor(v, 2); }
+  int quad_xor1_i(int v) { return shfl_xor_i(v, 1); }
+  int quad_xor2_i(int v) { return shfl_xor_i(v, 2); }
   bool any(int p) { return ballot(p) != 0ull; }
   int opaque(int x) { volatile int y = x; return y; }
   int opaque_v(int x) { volatile int y = x; return y; }
