@@ -24,10 +24,15 @@ namespace {
 struct WaveGpu {
   int ln;
   __device__ __forceinline__ int lane() const { return ln; }
-  // wave-level LDS hand-off: LDS ops of one wavefront execute in order; the asm statement is the
-  // compiler barrier and drains outstanding LDS traffic before any lane continues
+  // wave-level LDS hand-off: the DS instructions of one wavefront are issued and executed in program order, so a
+  // read that follows a write in the instruction stream sees it without draining lgkmcnt; what is needed is only
+  // that the compiler keeps LDS accesses on their side of the hand-off (memory clobber + scheduling barrier)
   __device__ __forceinline__ void sync() const {
+#ifdef SS_SYNC_DRAIN
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+    asm volatile("" ::: "memory");
+#endif
     __builtin_amdgcn_wave_barrier();
   }
   // cross-lane moves as DPP modifiers of VALU instructions (no LDS-crossbar ds_bpermute round trips):
