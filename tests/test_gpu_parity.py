@@ -113,6 +113,66 @@ def test_smplx_layout(vec):
         assert np.abs(o_ref - _np(obs)[0]).max() < TOL_OBS
 
 
+def test_smplx_free_running_with_floor_contact(vec):
+    """SMPL-X layout (52 bodies, two tree-level passes of the articulated-body sweeps), 20 control steps from Default:
+    the model settles onto its feet, so contacts, limits and the Newton solve are all exercised."""
+    from smplsim_amd.batch import ShardModel
+    env = vec(2, model=ShardModel(humanoid="smplx_humanoid"), autoreset=False)
+    oenv = O.OracleEnv(oracle_model("smplx_humanoid"))
+    obs, _ = env.reset(); oenv.reset()
+    rs = np.random.default_rng(7)
+    worst = np.zeros(2)
+    for i in range(20):
+        a = rs.uniform(-0.3, 0.3, 153)
+        o_ref, *_ = oenv.step(a)
+        obs, *_ = env.step(torch.tensor(np.tile(a, (2, 1)), device=env.device, dtype=torch.float32))
+        worst = np.maximum(worst, [np.abs(_np(env.qpos)[0] - oenv.data.qpos).max(), np.abs(o_ref - _np(obs)[0]).max()])
+    assert int(env.touch[0, 0].item()) != 0 or int(env.touch[0, 1].item()) != 0     # it does stand on the floor
+    assert worst[0] < 2 * TOL_QPOS and worst[1] < TOL_OBS, worst
+
+
+def test_obs_v2_on_gpu(vec):
+    """self_obs_v=2 (reference humanoid_env.py:637-687): per-body velocities from the sensors of the last mj_forward."""
+    env = vec(2, self_obs_v=2, autoreset=False)
+    oenv = O.OracleEnv(oracle_model(), self_obs_v=2)
+    obs, _ = env.reset()
+    assert env.obs_size == 358 and np.abs(oenv.reset() - _np(obs)[0]).max() < 1e-6
+    rs = np.random.default_rng(4)
+    for i in range(8):
+        a = rs.uniform(-0.3, 0.3, 69)
+        o_ref, *_ = oenv.step(a)
+        obs, *_ = env.step(torch.tensor(np.tile(a, (2, 1)), device=env.device, dtype=torch.float32))
+        assert np.abs(o_ref - _np(obs)[0]).max() < TOL_OBS
+        assert np.abs(_np(env.body_vel)[0, :, :3] - oenv.data.linvel).max() < TOL_QVEL
+
+
+@pytest.mark.parametrize("mode", ["pd", "torque"])
+def test_pd_and_torque_controllers_on_gpu(vec, mode):
+    """control_mode pd / torque (reference controllers.py:6-47,265-349) at substep granularity: explicit PD with the
+    stablepd gains amplifies differences ~15x per mj_step on the armature-dominated links."""
+    from smplsim_amd import _cabi
+    from test_kernel_emu import _states
+    from smplsim_amd.batch import ShardModel
+    om = oracle_model()
+    # tables with the stablepd torque limits for both modes: the reference leaves torque_lim at zero in `torque`
+    # mode (humanoid_env.py:341-349 only fills it for pd / uhc_pd), which would make this check vacuous
+    env = vec(2, model=ShardModel(control_mode="uhc_pd"), control_mode=mode, power_scale=1.0, autoreset=False)
+    m = _cabi.CONTROL_MODES[mode]
+    d = O.OracleData(om)
+    Q, V = _states(1, 5)
+    Q[0, 2] = 1.5
+    d.qpos = Q[0]; d.qvel = V[0] * 0.1; d.forward()
+    env.set_state(np.tile(Q, (2, 1)), np.tile(V * 0.1, (2, 1)))
+    a = np.random.default_rng(m).uniform(-0.5, 0.5, 69)
+    for s_ in range(2):
+        d.ctrl = d.ctrl_torque(a, mode=m, power_scale=1.0); d.step()
+    env.substep(torch.tensor(np.tile(a, (2, 1)), device=env.device, dtype=torch.float32), 2)
+    torch.cuda.synchronize()
+    vmax = max(1.0, np.abs(d.qvel).max())
+    assert np.abs(_np(env.qvel)[0] - d.qvel).max() < 1e-4 * vmax
+    assert np.abs(_np(env.qpos)[0] - d.qpos).max() < 1e-5 * vmax
+
+
 def test_benchmark_size_properties(vec):
     """4096 envs, full-range random actions (BASELINE config 2): size-independent properties —
     finite state, unit root quaternions, deterministic replay, yaw invariance of the observation,
