@@ -16,7 +16,7 @@ from smplsim_amd import _cabi, _lib
 
 prof_so = os.path.join(ROOT, "gpurun_out", "libsmplsim_hip_prof.so")
 os.makedirs(os.path.dirname(prof_so), exist_ok=True)
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DSS_PROFILE", *os.environ.get("SS_EXTRA", "").split(),
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", *_lib.DEFAULT_OPT.split(), "-std=c++17", "-shared", "-fPIC", "-DSS_PROFILE", *os.environ.get("SS_EXTRA", "").split(),
                        os.path.join(_lib.SRC_DIR, "smplsim_hip.hip"), "-o", prof_so])
 _lib._LIB = _cabi.bind(C.CDLL(prof_so))
 from smplsim_amd.batch import SMPLSimVecEnv
