@@ -44,7 +44,8 @@
 namespace ss {
 
 enum { PF_FWD = 0, PF_CONS, PF_NBEGIN, PF_NPREP, PF_ASM, PF_FACTOR, PF_SOLVE, PF_NFIN, PF_SPDPREP, PF_SPDFIN, PF_INTEG, PF_MISC,
-       PF_F_P13, PF_F_SYNC1, PF_F_P2, PF_F_BSOL, PF_F_SYNC2, PF_COUNT };
+       PF_F_P13, PF_F_SYNC1, PF_F_P2, PF_F_BSOL, PF_F_SYNC2,
+       PF_K_PRO, PF_K_LEV, PF_K_INERTIA, PF_K_SUMS, PF_P_BASE, PF_P_CONTACT, PF_P_SUMS, PF_P_GRAD, PF_COUNT };
 #ifdef SS_PROFILE
 #define SS_FT0() unsigned long long ft__ = w->clock()
 #define SS_FTICK(id) do { unsigned long long n__ = w->clock(); prof[id] += n__ - ft__; ft__ = n__; } while (0)
@@ -67,6 +68,21 @@ struct Limit { float sign, D, aref, jar, jd; };
 SS_DEV float bits2f(uint32_t u) { union { uint32_t u; float f; } c; c.u = u; return c.f; }
 SS_DEV float4_t ld4(const float *p) { return *reinterpret_cast<const float4_t *>(p); }      // 16-byte aligned LDS row
 SS_DEV void st4(float *p, float a, float b, float c) { float4_t v; v.x = a; v.y = b; v.z = c; v.w = 0.f; *reinterpret_cast<float4_t *>(p) = v; }
+// sin and cos of an angle of at most a few hundred radians (joint angles, half rotation angles): Cody-Waite reduction
+// by pi/2 and the single-precision minimax polynomials on [-pi/4, pi/4] (abs. error ~1e-7).  libm's sincosf carries a
+// Payne-Hanek path for huge arguments (private scratch array, ~600 instructions per inlined call site).
+SS_DEV void sincos_small(float x, float *sn, float *cs) {
+  const float kf = rintf(x * 0.636619772367581343f);
+  const int ki = (int)kf;
+  float r = fmaf(-kf, 1.5707962512969971f, x);
+  r = fmaf(-kf, 7.5497894158615964e-08f, r);
+  const float z = r * r;
+  const float sp = r + r * z * (-1.6666654611e-1f + z * (8.3321608736e-3f + z * -1.9515295891e-4f));
+  const float cp = 1.0f - 0.5f * z + z * z * (4.166664568298827e-2f + z * (-1.388731625493765e-3f + z * 2.443315711809948e-5f));
+  const float a = (ki & 1) ? cp : sp, b = (ki & 1) ? sp : cp;
+  *sn = (ki & 2) ? -a : a;
+  *cs = ((ki + 1) & 2) ? -b : b;
+}
 SS_DEV bool is_bad(float x) { return !(x <= 1e10f && x >= -1e10f); }
 
 template <class W, int DOFP, int CANDP, int SLOTP, int NPASS>
@@ -135,14 +151,22 @@ struct Sim {
   // ------------------------------------------------------------------ tree helpers
   // out[b][c] = sum of in[d][c] over the subtree of b = the contiguous index range [b, b + size_b) (depth-first
   // body order): one phase of independent LDS reads instead of a level-by-level sweep.
+  // Bodies are handed to the lanes in order of decreasing subtree size (o_sumorder) so that the long ranges share
+  // a pass, and every trip of the range loop issues 4 independent reads (a lane-serial read-add chain costs a full
+  // LDS round trip per element: this was 9 % of the step, profiles/r01r_*).
   template <int NC>
   SS_DEV void subtree_sum(const float *in, float *out) {
     const Hdr &h = k->h;
     for (int idx = lane; idx < NC * h.nb; idx += 64) {
-      const int b = idx / NC, c = idx - b * NC, n = ti(h.o_subsize, b);
+      const int o = idx / NC, c = idx - o * NC, e = ti(h.o_sumorder, o), b = e & 255, n = e >> 8;
+      const float *p = in + b * NC + c;
       float acc = 0.f;
-      for (int j = 0; j < n; j++) acc += in[(b + j) * NC + c];
-      out[idx] = acc;
+      for (int j = 0; j < n; j += 4) {
+        const int j1 = j + 1 < n ? j + 1 : j, j2 = j + 2 < n ? j + 2 : j, j3 = j + 3 < n ? j + 3 : j;
+        const float a0 = p[j * NC], a1 = p[j1 * NC], a2 = p[j2 * NC], a3 = p[j3 * NC];
+        acc += (a0 + (j + 1 < n ? a1 : 0.f)) + ((j + 2 < n ? a2 : 0.f) + (j + 3 < n ? a3 : 0.f));
+      }
+      out[b * NC + c] = acc;
     }
   }
 
@@ -158,9 +182,14 @@ struct Sim {
     w->sync();
     for (int idx = lane; idx < 6 * h.nb; idx += 64) {
       int b = idx / 6, c = idx - 6 * b, n = b + 1;
-      int dn = ti(h.o_ndepth, n);
+      const int dn = ti(h.o_ndepth, n), row = h.o_chainnode + n * h.nlev;
       float s = 0.f;
-      for (int kk = 0; kk <= dn; kk++) s += tmp[6 * ti(h.o_chainnode, n * h.nlev + kk) + c];
+      for (int kk = 0; kk <= dn; kk += 4) {                  // 4 independent (table, data) read pairs per trip
+        const int k1 = kk + 1 <= dn ? kk + 1 : kk, k2 = kk + 2 <= dn ? kk + 2 : kk, k3 = kk + 3 <= dn ? kk + 3 : kk;
+        const int n0 = ti(row, kk), n1 = ti(row, k1), n2 = ti(row, k2), n3 = ti(row, k3);
+        const float a0 = tmp[6 * n0 + c], a1 = tmp[6 * n1 + c], a2 = tmp[6 * n2 + c], a3 = tmp[6 * n3 + c];
+        s += (a0 + (kk + 1 <= dn ? a1 : 0.f)) + ((kk + 2 <= dn ? a2 : 0.f) + (kk + 3 <= dn ? a3 : 0.f));
+      }
       A[idx] = s;
     }
   }
@@ -170,6 +199,7 @@ struct Sim {
   SS_DEV void forward_kin(bool with_dyn, bool write_sensors) {
     fresh();
     const Hdr &h = k->h;
+    SS_FT0();
     float vb[6] = {0, 0, 0, 0, 0, 0}, ab[6] = {0, 0, 0, 0, 0, 0};
     float Rb[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, rb[3] = {0, 0, 0};
     float bc[kBodyC];                                       // this lane's body constants (L1/L2-resident table)
@@ -212,7 +242,7 @@ struct Sim {
     float Rl[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, ayl[3] = {0, 1, 0}, azl[3] = {0, 0, 1};
     if (lane >= 1 && lane < h.nb) {
       float sx, cx, sy, cy, sz, cz;
-      sincosf(q[3 * lane + 4], &sx, &cx); sincosf(q[3 * lane + 5], &sy, &cy); sincosf(q[3 * lane + 6], &sz, &cz);
+      sincos_small(q[3 * lane + 4], &sx, &cx); sincos_small(q[3 * lane + 5], &sy, &cy); sincos_small(q[3 * lane + 6], &sz, &cz);
       // Rx Ry = [[cy,0,sy],[sx sy,cx,-sx cy],[-cx sy,sx,cx cy]] ; times Rz
       Rl[0] = cy * cz;                 Rl[1] = -cy * sz;                Rl[2] = sy;
       Rl[3] = sx * sy * cz + cx * sz;  Rl[4] = -sx * sy * sz + cx * cz; Rl[5] = -sx * cy;
@@ -221,6 +251,7 @@ struct Sim {
       azl[0] = sy; azl[1] = -sx * cy; azl[2] = cx * cy;      // Rx Ry e_z
     }
     w->sync();
+    SS_FTICK(PF_K_PRO);
     for (int L = 1; L < h.nblev; L++) {
       if (bdep == L) {
         const int b = lane, n = b + 1;
@@ -275,6 +306,7 @@ struct Sim {
       }
       w->sync();
     }
+    SS_FTICK(PF_K_LEV);
     if (!with_dyn) return;
     // ---- body spatial inertia about the root origin (world axes), bias force, sensor velocities
     if (lane < h.nb) {
@@ -323,6 +355,7 @@ struct Sim {
       }
     }
     w->sync();
+    SS_FTICK(PF_K_INERTIA);
     // subtree bias force Gb (C = S^T Gb): subtree range sums, one phase
     subtree_sum<6>(Ad, Gb);
     w->sync();
@@ -338,6 +371,7 @@ struct Sim {
       }
     }
     w->sync();
+    SS_FTICK(PF_K_SUMS);
   }
 
   // spatial inertia (10 params, about the origin) times motion vector (w;u) -> force (n;f)
@@ -732,6 +766,7 @@ struct Sim {
     const Hdr &h = k->h;
     const float mu = h.mu;
     iters++;
+    SS_FT0();
     if (lane < h.nb) {
       float Ia[6];
       imul(Iown + 10 * lane, Ab + 6 * lane, Ia);
@@ -740,6 +775,7 @@ struct Sim {
     }
     write_own_inertia();
     w->sync();
+    SS_FTICK(PF_P_BASE);
     // ---- contact forces and K_b = sum_rows D u u^T, u = (rho x w ; w).  The (<= 4) contacts of a box sit in
     // 4 adjacent lanes and the 2 ends of a capsule in 2 adjacent lanes (slot layout of make_constraints), so the
     // per-body sums are quad shuffles; the group's first lane then owns the body's row (no atomics).
@@ -801,8 +837,10 @@ struct Sim {
       }
     }
     w->sync();
+    SS_FTICK(PF_P_CONTACT);
     subtree_sum<6>(Ad, Gb);
     w->sync();
+    SS_FTICK(PF_P_SUMS);
     // ---- gradient and diagonal terms
 #pragma unroll
     for (int p = 0; p < DOFP; p++) {
@@ -819,6 +857,7 @@ struct Sim {
       }
     }
     w->sync();
+    SS_FTICK(PF_P_GRAD);
   }
 
   // exact line search along delta, step, active-set change detection; returns true when converged
@@ -971,7 +1010,7 @@ struct Sim {
       float nw = sqrtf(wx * wx + wy * wy + wz * wz);
       float ang = dt * nw, ax, ay, az;
       if (nw < 1e-15f) { ax = 1; ay = 0; az = 0; ang = 0; } else { ax = wx / nw; ay = wy / nw; az = wz / nw; }
-      float sh, ch; sincosf(0.5f * ang, &sh, &ch);
+      float sh, ch; sincos_small(0.5f * ang, &sh, &ch);
       float qw = q[3], qx = q[4], qy = q[5], qz = q[6];
       float n = sqrtf(qw * qw + qx * qx + qy * qy + qz * qz);
       if (n < 1e-15f) { qw = 1; qx = qy = qz = 0; } else { float in = 1.f / n; qw *= in; qx *= in; qy *= in; qz *= in; }

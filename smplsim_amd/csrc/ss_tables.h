@@ -7,6 +7,7 @@
 // Newton Hessian M + J^T D J, Stable-PD matrix M + Kd dt) are never formed: systems with them are solved
 // by the articulated-body sweeps of ss_kernel.h (aba_solve), level by level over this node tree.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -210,7 +211,12 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
         if (a != b) { out.error = "bodies must be in depth-first order"; return false; }
       }
     }
-    h.o_subsize = push_i(subsize);
+    // (body | subtree size << 8), largest subtrees first
+    std::vector<int> order(nb);
+    for (int b = 0; b < nb; b++) order[b] = b;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return subsize[x] > subsize[y]; });
+    for (int b = 0; b < nb; b++) order[b] = order[b] | (subsize[order[b]] << 8);
+    h.o_sumorder = push_i(order);
   }
   h.shared_words = (int)S.size();
   (void)blevstart; (void)blevbodies;

@@ -29,9 +29,10 @@ for _ in range(steps):
     env.step(torch.rand(N, 69, generator=g, device=env.device) * 2 - 1)
 torch.cuda.synchronize()
 out = (C.c_ulonglong * 64)()
-rc = _lib.lib().ss_debug_prof(env.handle, out, 24)
+rc = _lib.lib().ss_debug_prof(env.handle, out, 32)
 names = ["fwd_kin", "constraints", "newton_begin", "newton_prepare", "(unused)", "aba_solve", "(unused)", "newton_finish",
-         "spd_prepare", "spd_finish", "integrate", "misc", "aba:up_phase1", "aba:up_last_sync", "aba:up_phase2", "aba:down", "(unused)"]
+         "spd_prepare", "spd_finish", "integrate", "misc", "aba:up_phase1", "aba:up_last_sync", "aba:up_phase2", "aba:down", "(unused)",
+         "fk:prologue", "fk:level_sweep", "fk:inertia_bias", "fk:subtree_C", "prep:base", "prep:contactK", "prep:subtree", "prep:grad"]
 tot = sum(out[i] for i in range(12))
 iters = float(env.solver_iters.float().mean().item())
 res = {"rc": rc, "total_ticks": tot, "mean_newton_iters": iters, "stages": {}}
