@@ -45,6 +45,8 @@ struct WaveGpu {
     v += dpp_f<0xB1>(v); v += dpp_f<0x4E>(v); v += dpp_f<0x141>(v); v += dpp_f<0x140>(v);
     return (rl(v, 0) + rl(v, 16)) + (rl(v, 32) + rl(v, 48));
   }
+  // sum over the lane's aligned group of 8 lanes: xor 1, xor 2, then the mirrored half row
+  __device__ __forceinline__ float sum8(float v) const { v += dpp_f<0xB1>(v); v += dpp_f<0x4E>(v); v += dpp_f<0x141>(v); return v; }
   __device__ __forceinline__ float quad_xor1(float v) const { return dpp_f<0xB1>(v); }
   __device__ __forceinline__ float quad_xor2(float v) const { return dpp_f<0x4E>(v); }
   __device__ __forceinline__ int quad_xor1_i(int v) const { return dpp_i<0xB1>(v); }

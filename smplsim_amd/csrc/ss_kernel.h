@@ -584,12 +584,14 @@ struct Sim {
       s0 -= nk;
       float *cur = IA + (L & 1) * h.ia_stride;
       const float *prev = IA + ((L + 1) & 1) * h.ia_stride;
-      float row[NPASS][6], pa[NPASS], Ur[NPASS][3];
+      float row[NPASS][6], pa[NPASS], Ur[NPASS][3], red[NPASS][9];
       int nod[NPASS];
 #pragma unroll
-      for (int ps = 0; ps < NPASS; ps++) {                    // ---- phase 1: articulated row, U_r = IA_r S
+      for (int ps = 0; ps < NPASS; ps++) {                    // ---- part 1: articulated row, U_r = IA_r S, partial S^T U
         const int kk = ps * 8 + g;
         nod[ps] = -1;
+#pragma unroll
+        for (int t = 0; t < 9; t++) red[ps][t] = 0.f;
         if (r_ < 6 && kk < nk) {
           const int e = ti(h.o_lev, s0 + kk), n = e & 255, cfirst = (e >> 16) & 255, cc = (e >> 24) & 255;
           nod[ps] = n;
@@ -603,6 +605,7 @@ struct Sim {
           const float *sn = S + 18 * n;
 #pragma unroll
           for (int t = 0; t < 18; t++) sv[t] = sn[t];
+          const float sr0 = sn[r_], sr1 = sn[6 + r_], sr2 = sn[12 + r_];   // row r of S_n
           for (int j = 0; j < cc; j++) {
             const float *src = prev + ((cfirst + j) * 6 + r_) * 8;
             const float4_t v0 = ld4(src), v1 = ld4(src + 4);
@@ -619,28 +622,28 @@ struct Sim {
           for (int c = 0; c < 6; c++) row[ps][c] = rw[c];
           pa[ps] = pv;
           st4w(Ubuf + (kk * 6 + r_) * 4, Ur[ps][0], Ur[ps][1], Ur[ps][2], pv);
+          // this row's terms of D = S^T U (lower triangle) and of S^T pA; the 8-lane sums below complete them
+          red[ps][0] = sr0 * Ur[ps][0]; red[ps][1] = sr1 * Ur[ps][0]; red[ps][2] = sr1 * Ur[ps][1];
+          red[ps][3] = sr2 * Ur[ps][0]; red[ps][4] = sr2 * Ur[ps][1]; red[ps][5] = sr2 * Ur[ps][2];
+          red[ps][6] = sr0 * pv; red[ps][7] = sr1 * pv; red[ps][8] = sr2 * pv;
         }
       }
       SS_FTICK(PF_F_P13);
-      w->sync();
+      w->sync();                                              // U rows visible to the node's other lanes
 #pragma unroll
-      for (int ps = 0; ps < NPASS; ps++) {                    // ---- phase 2: joint-space 3x3 algebra, rows handed up
+      for (int ps = 0; ps < NPASS; ps++)                      // sums over the node's 8 lanes (idle lanes hold zeros): no LDS
+#pragma unroll
+        for (int t = 0; t < 9; t++) red[ps][t] = w->sum8(red[ps][t]);
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ps++) {                    // ---- part 2: joint-space 3x3 algebra, rows handed up
         const int kk = ps * 8 + g, n = nod[ps];
         if (n >= 0) {
           float4_t U[6];
 #pragma unroll
           for (int c = 0; c < 6; c++) U[c] = ld4(Ubuf + (kk * 6 + c) * 4);
-          float sr[18];                                       // S_n again (cheaper than 18 registers held across the sync)
-#pragma unroll
-          for (int t = 0; t < 18; t++) sr[t] = S[18 * n + t];
-          float d00 = diag[3 * n], d10 = 0.f, d11 = diag[3 * n + 1], d20 = 0.f, d21 = 0.f, d22 = diag[3 * n + 2];
-          float u0 = x[3 * n], u1 = x[3 * n + 1], u2 = x[3 * n + 2];
-#pragma unroll
-          for (int c = 0; c < 6; c++) {
-            d00 += sr[c] * U[c].x; d10 += sr[6 + c] * U[c].x; d11 += sr[6 + c] * U[c].y;
-            d20 += sr[12 + c] * U[c].x; d21 += sr[12 + c] * U[c].y; d22 += sr[12 + c] * U[c].z;
-            u0 -= sr[c] * U[c].w; u1 -= sr[6 + c] * U[c].w; u2 -= sr[12 + c] * U[c].w;
-          }
+          const float d00 = red[ps][0] + diag[3 * n], d10 = red[ps][1], d11 = red[ps][2] + diag[3 * n + 1];
+          const float d20 = red[ps][3], d21 = red[ps][4], d22 = red[ps][5] + diag[3 * n + 2];
+          const float u0 = x[3 * n] - red[ps][6], u1 = x[3 * n + 1] - red[ps][7], u2 = x[3 * n + 2] - red[ps][8];
           const float c00 = d11 * d22 - d21 * d21, c01 = d21 * d20 - d10 * d22, c02 = d10 * d21 - d11 * d20;
           const float id = rcp_nr(d00 * c00 + d10 * c01 + d20 * c02);
           const float i00 = c00 * id, i01 = c01 * id, i02 = c02 * id;

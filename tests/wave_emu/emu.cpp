@@ -168,6 +168,14 @@ struct WaveEmu {
     arrive(11);
     return r;
   }
+  float sum8(float v) {                                      // sum over the lane's aligned group of 8
+    m->fx[ln] = v;
+    arrive(12);
+    float r = 0.f;
+    for (int i = 0; i < 8; i++) r += m->fx[(ln & ~7) + i];
+    arrive(13);
+    return r;
+  }
   float quad_xor1(float v) { return shfl_xor(v, 1); }
   float quad_xor2(float v) { return shfl_xor(v, 2); }
   int quad_xor1_i(int v) { return shfl_xor_i(v, 1); }
