@@ -33,7 +33,7 @@ typedef enum {
 enum { SS_GEOM_BOX = 0, SS_GEOM_CAPSULE = 1 };
 enum { SS_TASK_BASE = 0, SS_TASK_SPEED = 1, SS_TASK_GETUP = 2, SS_TASK_REACH = 3 };   /* reference tasks/humanoid_{speed,getup,reach}.py */
 enum { SS_INIT_DEFAULT = 0, SS_INIT_FALL = 1 };                        /* HumanoidEnv.StateInit, humanoid_env.py:141-146 */
-enum { SS_CTRL_UHC_PD = 0, SS_CTRL_PD = 1, SS_CTRL_TORQUE = 2 };       /* control_mode, humanoid_env.py:312-323 */
+enum { SS_CTRL_UHC_PD = 0, SS_CTRL_PD = 1, SS_CTRL_TORQUE = 2, SS_CTRL_SIMPLE_PID = 3, SS_CTRL_DEFAULT = 4 };   /* control_mode, humanoid_env.py:312-323 */
 
 /* Compiled model constants (host pointers, float64; produced by smplsim_amd.mjcf.compile_mjcf).
  * Replaces the mjModel built by mujoco.MjModel.from_xml_string (reference base_env.py:139-142)
@@ -91,6 +91,11 @@ typedef struct {
   float *task;        /* [N,4]   speed/getup: tar_speed|tar_height, change_steps, recovery_counter, 0 ; reach: tar xyz, change_steps */
   int32_t *nwarn;     /* [N]     count of MuJoCo-style autoresets (mj_checkPos/Vel/Acc) */
   int32_t *solver_iters; /* [N]  Newton iterations spent in the last step (diagnostic) */
+  /* control_mode simple_pid only (may be NULL otherwise): the state of the reference's SimplePID object
+   * (controllers.py:217-221), which lives as long as the env and is NOT cleared by reset() */
+  float *pid_integral;   /* [N,nu] */
+  float *pid_last_error; /* [N,nu] */
+  int32_t *pid_started;  /* [N]    0 until the controller ran once (its first derivative term is zero) */
 } ss_state;
 
 typedef struct ss_model ss_model;

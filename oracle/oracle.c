@@ -147,6 +147,10 @@ struct om_data {
   double *J, *epos, *emargin, *ediag, *eD, *eR, *earef, *eforce, *ejar, *ejd;
   double *H, *work, *work2;                    /* nv x nv each */
   int solver_iter, nwarn;
+  /* SimplePID state (reference controllers.py:193-262): per actuator integral and last error; pid_dt = the dt the env
+   * hands the controller (timestep * control_freq_inv, humanoid_env.py:319) */
+  double pid_i[OM_MAXV], pid_e[OM_MAXV], pid_dt;
+  int pid_started;
 };
 
 static void dof_jac(const om_model *m_unused, const om_data *d, int dof, const double *P, double *jv, double *jw) {
@@ -737,18 +741,30 @@ void om_spd_torque(const om_model *m, const om_data *d, const double *action, do
 
 void om_ctrl_torque(const om_model *m, const om_data *d, int mode, double power_scale, const double *action, double *tau) {
   if (mode == 0) { om_spd_torque(m, d, action, tau); return; }
+  om_data *ds = (om_data *)d;                               /* simple_pid keeps controller state in the data */
+  const double dtp = d->pid_dt > 0 ? d->pid_dt : 15.0 * m->dt;
   for (int i = 0; i < m->nu; i++) {
     int dof = m->act_dof[i];
     double t, lim = m->tlim[i];
+    if (mode == 4) { tau[i] = action[i]; continue; }        /* `default`: ctrl = action (humanoid_env.py:409-410) */
     if (mode == 1) {                                        /* PIDController with zero integral gain */
       double target = action[i] * m->ascale[i] + m->aoffset[i];
       t = -m->kp[i] * (d->qpos[dof + 1] - target) - m->kd[i] * d->qvel[dof];
+    } else if (mode == 3) {                                 /* SimplePID: gains kp, kd as passed (the env passes jkp/10, jkd/10), ki = 1 */
+      double err = action[i] * m->ascale[i] + m->aoffset[i] - d->qpos[dof + 1];
+      double derr = ds->pid_started ? err - ds->pid_e[i] : 0.0;
+      double in = ds->pid_i[i] + 1.0 * err * dtp;
+      in = in > lim ? lim : (in < -lim ? -lim : in);
+      t = m->kp[i] * err + in + m->kd[i] * derr / dtp;
+      ds->pid_i[i] = in; ds->pid_e[i] = err;
     } else {                                                /* SimpleTorqueController */
       t = action[i] * power_scale * lim;
     }
     tau[i] = t > lim ? lim : (t < -lim ? -lim : t);
   }
+  if (mode == 3) ds->pid_started = 1;
 }
+void om_set_pid_dt(om_data *d, double dt) { d->pid_dt = dt; }
 
 /* ------------------------------------------------------------------ observations */
 /* wxyz helpers of np_transform_utils.py */
@@ -825,6 +841,7 @@ struct om_env {
 om_env *om_env_create(const om_model *m, const om_env_cfg *cfg) {
   om_env *e = (om_env *)calloc(1, sizeof *e);
   e->m = m; e->d = om_data_create(m); e->cfg = *cfg;
+  e->d->pid_dt = m->dt * cfg->control_freq_inv;
   return e;
 }
 void om_env_destroy(om_env *e) { if (e) { om_data_destroy(e->d); free(e); } }

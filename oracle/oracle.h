@@ -66,15 +66,17 @@ void om_forward(const om_model *m, om_data *d);               /* mj_forward    *
 void om_step(const om_model *m, om_data *d);                  /* mj_step       */
 /* StablePDController.control (reference controllers.py:116-190) on the data's (stale) M, bias */
 void om_spd_torque(const om_model *m, const om_data *d, const double *action, double *tau);
-/* other controllers selectable by control_mode: 1 = pd (controllers.py:335-346), 2 = torque (:45-46) */
+/* other controllers selectable by control_mode: 1 = pd (controllers.py:335-346), 2 = torque (:45-46),
+ * 3 = simple_pid (:193-262; stateful: integral / last error live in the data), 4 = default (ctrl = action) */
 void om_ctrl_torque(const om_model *m, const om_data *d, int control_mode, double power_scale,
                     const double *action, double *tau);
+void om_set_pid_dt(om_data *d, double dt);                  /* dt handed to SimplePID (timestep * control_freq_inv) */
 
 /* ---- env layer (reference humanoid_env.py / humanoid_task.py / tasks) ---- */
 enum { OM_TASK_BASE = 0, OM_TASK_SPEED = 1, OM_TASK_GETUP = 2, OM_TASK_REACH = 3 };
 enum { OM_INIT_DEFAULT = 0, OM_INIT_FALL = 1 };
 typedef struct {
-  int task, state_init, self_obs_v, control_mode /*0 uhc_pd,1 pd,2 torque*/;
+  int task, state_init, self_obs_v, control_mode /*0 uhc_pd,1 pd,2 torque,3 simple_pid,4 default*/;
   int episode_length, control_freq_inv, root_height_obs;
   double power_scale;
   double tar_speed_min, tar_speed_max; int speed_change_min, speed_change_max;

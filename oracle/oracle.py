@@ -83,6 +83,8 @@ def lib():
         L.om_spd_torque.restype = None
         L.om_ctrl_torque.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
         L.om_ctrl_torque.restype = None
+        L.om_set_pid_dt.argtypes = [C.c_void_p, C.c_double]
+        L.om_set_pid_dt.restype = None
         L.om_env_obs_size.argtypes = [C.c_void_p]
         L.om_env_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.om_env_reset.restype = None
@@ -238,6 +240,9 @@ class OracleData:
         tau = np.zeros(self.m.nu)
         lib().om_spd_torque(self.m.h, self.h, _p(a), _p(tau))
         return tau
+
+    def set_pid_dt(self, dt):
+        lib().om_set_pid_dt(self.h, float(dt))
 
     def ctrl_torque(self, action, mode=0, power_scale=1.0):
         a = np.ascontiguousarray(action, dtype=np.float64)

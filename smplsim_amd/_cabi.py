@@ -10,9 +10,10 @@ import numpy as np
 
 TASK_BASE, TASK_SPEED, TASK_GETUP, TASK_REACH = 0, 1, 2, 3
 INIT_DEFAULT, INIT_FALL = 0, 1
-CTRL_UHC_PD, CTRL_PD, CTRL_TORQUE = 0, 1, 2
+CTRL_UHC_PD, CTRL_PD, CTRL_TORQUE, CTRL_SIMPLE_PID, CTRL_DEFAULT = 0, 1, 2, 3, 4
 TASKS = {"HumanoidEnv": TASK_BASE, "HumanoidSpeed": TASK_SPEED, "HumanoidGetup": TASK_GETUP, "HumanoidReach": TASK_REACH}
-CONTROL_MODES = {"uhc_pd": CTRL_UHC_PD, "pd": CTRL_PD, "torque": CTRL_TORQUE}
+CONTROL_MODES = {"uhc_pd": CTRL_UHC_PD, "pd": CTRL_PD, "torque": CTRL_TORQUE, "simple_pid": CTRL_SIMPLE_PID,
+                 "default": CTRL_DEFAULT}
 STATE_INITS = {"Default": INIT_DEFAULT, "Fall": INIT_FALL}
 
 
@@ -49,6 +50,7 @@ class State(C.Structure):
         ("num_envs", C.c_int32), ("qpos", C.c_void_p), ("qvel", C.c_void_p), ("qpos_prev", C.c_void_p),
         ("qvel_prev", C.c_void_p), ("qacc_warm", C.c_void_p), ("body_vel", C.c_void_p), ("touch", C.c_void_p),
         ("cur_t", C.c_void_p), ("task", C.c_void_p), ("nwarn", C.c_void_p), ("solver_iters", C.c_void_p),
+        ("pid_integral", C.c_void_p), ("pid_last_error", C.c_void_p), ("pid_started", C.c_void_p),
     ]
 
 

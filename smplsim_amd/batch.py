@@ -89,10 +89,14 @@ class SMPLSimVecEnv:
         self.touch = torch.zeros(N, 2, **i32); self.cur_t = torch.zeros(N, **i32)
         self.task_state = torch.zeros(N, 4, **f32); self.nwarn = torch.zeros(N, **i32)
         self.solver_iters = torch.zeros(N, **i32)
+        # SimplePID controller state (control_mode simple_pid; lives as long as the env, like the reference's object)
+        self.pid_integral = torch.zeros(N, self.nu, **f32); self.pid_last_error = torch.zeros(N, self.nu, **f32)
+        self.pid_started = torch.zeros(N, **i32)
         self.qpos[:, 3] = 1; self.qpos_prev[:, 3] = 1
         st = _cabi.State(N, *[_ptr(t) for t in (self.qpos, self.qvel, self.qpos_prev, self.qvel_prev, self.qacc_warm,
                                                self.body_vel, self.touch, self.cur_t, self.task_state, self.nwarn,
-                                               self.solver_iters)])
+                                               self.solver_iters, self.pid_integral, self.pid_last_error,
+                                               self.pid_started)])
         self.handle = C.c_void_p()
         _check(lib().ss_batch_create(self.model.handle, C.byref(self.cfg), C.byref(st), C.byref(self.handle)))
         self.obs_size = lib().ss_obs_size(self.model.handle, C.byref(self.cfg))

@@ -69,6 +69,9 @@ struct ss_api {
     if (!st->qpos || !st->qvel || !st->qpos_prev || !st->qvel_prev || !st->qacc_warm || !st->body_vel || !st->touch ||
         !st->cur_t || !st->task || !st->nwarn || !st->solver_iters)
       return fail(SS_ERR_INVALID, "every ss_state buffer must be provided");
+    if (cfg->control_mode < SS_CTRL_UHC_PD || cfg->control_mode > SS_CTRL_DEFAULT) return fail(SS_ERR_INVALID, "unknown control_mode");
+    if (cfg->control_mode == SS_CTRL_SIMPLE_PID && (!st->pid_integral || !st->pid_last_error || !st->pid_started))
+      return fail(SS_ERR_INVALID, "control_mode simple_pid needs the pid_* state buffers");
     if (cfg->self_obs_v != 1 && cfg->self_obs_v != 2) return fail(SS_ERR_INVALID, "self_obs_v must be 1 or 2");
     if (cfg->control_freq_inv < 1) return fail(SS_ERR_INVALID, "control_freq_inv must be >= 1");
     if (cfg->task == SS_TASK_REACH && (cfg->reach_body < 0 || cfg->reach_body >= m->hm.h.nb)) return fail(SS_ERR_INVALID, "reach_body out of range");

@@ -99,7 +99,7 @@ struct Sim {
   Contact con[SLOTP];
   Limit lim[DOFP];
   float perr[DOFP];
-  int iters, nwarn_add;
+  int iters, nwarn_add, pid_on;
 #ifdef SS_PROFILE
   unsigned long long prof[PF_COUNT];
 #endif
@@ -126,6 +126,7 @@ struct Sim {
 #pragma unroll
     for (int p = 0; p < DOFP; p++) lim[p].sign = 0.f;
     iters = 0; nwarn_add = 0; touchmask = 0ull;
+    pid_on = (k->cfg.control_mode == SS_CTRL_SIMPLE_PID && k->st.pid_started) ? k->st.pid_started[env] : 0;
 #ifdef SS_PROFILE
     for (int i = 0; i < PF_COUNT; i++) prof[i] = 0ull;
 #endif
@@ -948,20 +949,34 @@ struct Sim {
   SS_DEV void simple_controller(const float *action, float abias) {
     const Hdr &h = k->h;
     const int mode = k->cfg.control_mode;
+    const float dtp = h.dt * (float)k->cfg.control_freq_inv;   // the dt SimplePID is constructed with (humanoid_env.py:319)
 #pragma unroll
     for (int p = 0; p < DOFP; p++) {
       int i = p * 64 + lane;
       if (i < h.nv) {
         float t = 0.f;
         if (dc(i, 10) != 0.f) {
-          float act = action[(int)dc(i, 11)] + abias, lim_ = dc(i, 7);
-          if (mode == SS_CTRL_PD) t = -dc(i, 5) * (q[i + 1] - (act * dc(i, 8) + dc(i, 9))) - dc(i, 6) * v[i];
-          else t = act * k->cfg.power_scale * lim_;
-          t = fminf(fmaxf(t, -lim_), lim_);
+          const int ai = (int)dc(i, 11);
+          float act = action[ai] + abias, lim_ = dc(i, 7);
+          if (mode == SS_CTRL_DEFAULT) t = act;                // ctrl = action, unscaled and unclipped (humanoid_env.py:409-410)
+          else {
+            if (mode == SS_CTRL_PD) t = -dc(i, 5) * (q[i + 1] - (act * dc(i, 8) + dc(i, 9))) - dc(i, 6) * v[i];
+            else if (mode == SS_CTRL_SIMPLE_PID) {             // SimplePID (controllers.py:224-262), ki = 1, state in HBM
+              float *ip = k->st.pid_integral + (size_t)env * h.nu + ai, *ep = k->st.pid_last_error + (size_t)env * h.nu + ai;
+              const float err = act * dc(i, 8) + dc(i, 9) - q[i + 1];
+              const float derr = pid_on ? err - *ep : 0.f;
+              float in = *ip + err * dtp;
+              in = fminf(fmaxf(in, -lim_), lim_);
+              t = dc(i, 5) * err + in + dc(i, 6) * derr / dtp;
+              *ip = in; *ep = err;
+            } else t = act * k->cfg.power_scale * lim_;
+            t = fminf(fmaxf(t, -lim_), lim_);
+          }
         }
         tau[i] = t;
       }
     }
+    if (mode == SS_CTRL_SIMPLE_PID) pid_on = 1;
     w->sync();
   }
 
@@ -1271,6 +1286,7 @@ SS_DEV void run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env) 
   if (lane == 0) {
     st.touch[2 * env] = (int)(touch & 0xFFFFFFFFull); st.touch[2 * env + 1] = (int)(touch >> 32);
     st.solver_iters[env] = sim.iters;
+    if (cf.control_mode == SS_CTRL_SIMPLE_PID && st.pid_started) st.pid_started[env] = sim.pid_on;
     if (sim.nwarn_add) st.nwarn[env] += sim.nwarn_add;
   }
   if (is_debug) { sim.store(k->out2 + (size_t)env * h.nv, sim.a, h.nv); return; }

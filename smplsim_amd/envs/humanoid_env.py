@@ -65,7 +65,7 @@ class HumanoidEnv:
         self.humanoid_type = r.humanoid_type
         if self.humanoid_type not in ("smpl", "smplh", "smplx"):
             raise NotImplementedError(f"humanoid_type: {self.humanoid_type}")
-        if self.control_mode not in ("uhc_pd", "pd", "torque"):
+        if self.control_mode not in ("uhc_pd", "pd", "torque", "simple_pid", "default"):   # reference _AVAILABLE_CONTROLLERS
             raise NotImplementedError(f"control_mode {self.control_mode!r} is not supported by the HIP stepper")
         if self.self_obs_v == 2 and not r.create_vel_sensors:
             raise AssertionError("self_obs_v=2 needs robot.create_vel_sensors (reference humanoid_env.py:297)")

@@ -38,7 +38,8 @@ def build_pd_tables(actuator_names, jnt_range_of, clip_actions=True, control_mod
     jnt_range_of:   callable name -> (low, high) in radians.
     Mirrors humanoid_env.py:325-370 (scale = min(1.2*max|range|, pi), offset 0 when
     clip_actions; identity scaling otherwise) and setup_controller :312-323 (gains divided
-    by pdp_scale / pdd_scale).
+    by pdp_scale / pdd_scale; `simple_pid` gets jkp/10, jkd/10; `torque` and `default` leave gains and
+    torque limits at zero, exactly like the reference).
     """
     n = len(actuator_names)
     kp, kd, lim = np.zeros(n), np.zeros(n), np.zeros(n)
@@ -54,4 +55,7 @@ def build_pd_tables(actuator_names, jnt_range_of, clip_actions=True, control_mod
         scale, offset = 0.5 * (hi - lo), 0.5 * (hi + lo)
     else:
         scale, offset = np.ones(n), np.zeros(n)
+    if control_mode == "simple_pid":
+        # setup_controller :318-319: SimplePID(jkp / 10, ones, jkd / 10, ...) — not divided by pdp/pdd_scale; ki = 1
+        return kp / 10.0, kd / 10.0, lim, scale, offset
     return kp / pdp_scale, kd / pdd_scale, lim, scale, offset

@@ -185,6 +185,30 @@ def main():
     out["q_remove_base"] = np.array([npt.remove_base_rot(qa[i:i + 1])[0] for i in range(16)])
 
     path = os.path.join(HERE, "reference_vectors.npz")
+    # ---- the other controllers selectable by control_mode (humanoid_env.py:312-323), separate RNG stream so that the
+    # vectors above stay as they were: PIDController (`pd`, zero integral gain), SimpleTorqueController (`torque`, with
+    # the stablepd limits instead of the zeros the env leaves there) and the stateful SimplePID (`simple_pid`)
+    rs2 = np.random.default_rng(777)
+    pdc = ctrls.PIDController(fake._pd_action_scale, fake._pd_action_offset, fake.torque_lim, fake.jkp, fake.jkd, np.zeros_like(fake.jkd))
+    tqc = ctrls.SimpleTorqueController(0.7 * fake.torque_lim, fake.torque_lim)
+    pid = ctrls.SimplePID(fake.jkp / 10, np.ones_like(fake.jkp), fake.jkd / 10, (1.0 / 450) * 15, fake.torque_lim,
+                          fake._pd_action_scale, fake._pd_action_offset)
+    cq, cv, ca, cpd, ctq, cpid = [], [], [], [], [], []
+    q = rs2.uniform(-0.5, 0.5, nu)
+    a = rs2.uniform(-1, 1, nu)
+    model = types.SimpleNamespace(opt=types.SimpleNamespace(timestep=1.0 / 450))
+    for t in range(16):
+        if t % 5 == 4:
+            a = rs2.uniform(-1, 1, nu)
+        qd = rs2.normal(size=nu) * 2.0
+        data = types.SimpleNamespace(qpos=np.concatenate([np.zeros(7), q]), qvel=np.concatenate([np.zeros(6), qd]))
+        cq.append(q.copy()); cv.append(qd.copy()); ca.append(a.copy())
+        cpd.append(pdc.control(a, model, data)); ctq.append(tqc.control(a, model, data)); cpid.append(pid.control(a, model, data))
+        q = q + rs2.normal(size=nu) * 0.05
+    out["ctl_q"], out["ctl_qd"], out["ctl_action"] = np.array(cq), np.array(cv), np.array(ca)
+    out["ctl_pd"], out["ctl_torque"], out["ctl_simple_pid"] = np.array(cpd), np.array(ctq), np.array(cpid)
+    out["ctl_power_scale"] = np.array(0.7)
+
     np.savez_compressed(path, **out)
     print("wrote", path, {k: np.asarray(v).shape for k, v in out.items()})
 

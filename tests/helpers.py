@@ -24,9 +24,9 @@ def pd_tables(mc, **kw):
 
 
 @functools.lru_cache(maxsize=None)
-def oracle_model(name="smpl_humanoid", timestep=1.0 / 450):
+def oracle_model(name="smpl_humanoid", timestep=1.0 / 450, control_mode="uhc_pd"):
     mc = model_const(name)
-    kp, kd, tl, sc, of = pd_tables(mc)
+    kp, kd, tl, sc, of = pd_tables(mc, control_mode=control_mode)
     return O.OracleModel(default_xml_str(name), kp, kd, tl, sc, of, legal_bodies=FEET, timestep=timestep)
 
 

@@ -146,6 +146,33 @@ def test_obs_v2_on_gpu(vec):
         assert np.abs(_np(env.body_vel)[0, :, :3] - oenv.data.linvel).max() < TOL_QVEL
 
 
+@pytest.mark.parametrize("mode", ["simple_pid", "default"])
+def test_simple_pid_and_default_controllers_on_gpu(vec, mode):
+    """`simple_pid` (stateful, reference controllers.py:193-262) and `default` (ctrl = action) through the product API:
+    two launches of two mj_steps, the PID state persists in the caller-owned pid_* buffers between them."""
+    from smplsim_amd import _cabi
+    from test_kernel_emu import _states
+    env = vec(2, control_mode=mode, autoreset=False)
+    m = _cabi.CONTROL_MODES[mode]
+    d = O.OracleData(oracle_model(control_mode=mode)); d.set_pid_dt(15.0 / 450)
+    Q, V = _states(1, 5)
+    Q[0, 2] = 1.5
+    d.qpos = Q[0]; d.qvel = V[0] * 0.1; d.forward()
+    env.set_state(np.tile(Q, (2, 1)), np.tile(V * 0.1, (2, 1)))
+    rs = np.random.default_rng(m)
+    for launch in range(2):
+        a = rs.uniform(-0.5, 0.5, 69) * (1.0 if mode == "simple_pid" else 40.0)
+        for s_ in range(2):
+            d.ctrl = d.ctrl_torque(a, mode=m); d.step()
+        env.substep(torch.tensor(np.tile(a, (2, 1)), device=env.device, dtype=torch.float32), 2)
+        torch.cuda.synchronize()
+        vmax = max(1.0, np.abs(d.qvel).max())
+        assert np.abs(_np(env.qvel)[0] - d.qvel).max() < 1e-4 * vmax
+        assert np.abs(_np(env.qpos)[0] - d.qpos).max() < 1e-5 * vmax
+    if mode == "simple_pid":
+        assert int(env.pid_started[0].item()) == 1 and float(env.pid_integral.abs().max().item()) > 0
+
+
 @pytest.mark.parametrize("mode", ["pd", "torque"])
 def test_pd_and_torque_controllers_on_gpu(vec, mode):
     """control_mode pd / torque (reference controllers.py:6-47,265-349) at substep granularity: explicit PD with the

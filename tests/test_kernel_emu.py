@@ -128,6 +128,31 @@ def test_pd_and_torque_controllers_substep(mode):
     assert np.abs(eb.qpos[0] - d.qpos).max() < 1e-5 * vmax
 
 
+@pytest.mark.parametrize("mode,name", [(3, "simple_pid"), (4, "default")])
+def test_simple_pid_and_default_controllers_substep(mode, name):
+    """`simple_pid` (stateful SimplePID, reference controllers.py:193-262, gains jkp/10, 1, jkd/10) and `default`
+    (ctrl = action): two launches of two mj_steps each, so the PID state has to survive in the ss_state buffers."""
+    mc = model_const()
+    om = oracle_model(control_mode=name)
+    eb = emu.EmuBatch(mc, pd_tables(mc, control_mode=name), 1, legal_bodies=FEET, control_mode=mode)
+    d = O.OracleData(om); d.set_pid_dt(15.0 / 450)
+    Q, V = _states(1, 5)
+    Q[0, 2] = 1.5
+    d.qpos = Q[0]; d.qvel = V[0] * 0.1; d.forward()
+    eb.set_state(Q, V * 0.1)
+    rs = np.random.default_rng(mode)
+    for launch in range(2):
+        a = rs.uniform(-0.5, 0.5, 69) * (1.0 if mode == 3 else 40.0)      # `default` takes raw torques
+        for s_ in range(2):
+            d.ctrl = d.ctrl_torque(a, mode=mode); d.step()
+        eb.substep(a[None], 2)
+        vmax = max(1.0, np.abs(d.qvel).max())
+        assert np.abs(eb.qvel[0] - d.qvel).max() < 1e-4 * vmax
+        assert np.abs(eb.qpos[0] - d.qpos).max() < 1e-5 * vmax
+    if mode == 3:
+        assert eb.pid_started[0] == 1 and np.abs(eb.pid_integral).max() > 0
+
+
 def test_autoreset_on_bad_state_and_masked_reset():
     eb = _batch(2)
     eb.reset()
