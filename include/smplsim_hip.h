@@ -141,6 +141,15 @@ int ss_kinematics(ss_batch *b, float *xpos, float *xmat, void *stream);
  * writes the dense joint-space mass matrix [N,nv,nv] (what mj_fullM returns; the stepping path itself never forms
  * it), qfrc_bias [N,nv] and the constrained qacc [N,nv]. */
 int ss_debug_forward(ss_batch *b, const float *torques, float *M, float *bias, float *qacc, void *stream);
+/* ---- caller side of the path: device-side generalised advantage estimation for the PPO sampler that
+ * feeds ss_step.  The rollout is stored time-major [T,N]; one recursion per env column, exactly the loop of the
+ * reference's estimate_advantages (smpl_sim/learning/learning_utils.py:198-218):
+ *   delta_t = r_t + gamma * V_{t+1} * not_dead_t - V_t ;  A_t = delta_t + gamma * tau * A_{t+1} * not_done_t ;  R_t = V_t + A_t
+ * with V_T = bootstrap[n] (NULL = 0, which is what the reference's episode-complete batches amount to) and A_T = 0.
+ * Advantage normalisation (mean / std over the batch) is left to the caller.  Stateless; runs on the current device. */
+int ss_gae(const float *rewards, const float *not_done, const float *not_dead, const float *values, const float *bootstrap,
+           int32_t T, int32_t N, float gamma, float tau, float *advantages, float *returns, void *stream);
+
 /* -DSS_PROFILE builds only: accumulated shader-clock ticks per kernel stage (tools/stage_profile.py) */
 int ss_debug_prof(ss_batch *b, unsigned long long *out, int n);
 

@@ -1,0 +1,165 @@
+"""On-device PPO agent for the batched stepper.
+
+What it replaces in the reference: Agent.sample (agents/agent.py:64-145: up to 36 CPU worker processes, one env each,
+pickled Memory objects), the Python GAE loop (learning_utils.py:198-218) and AgentPPO.update_policy
+(agents/agent_ppo.py:20-99) — keeping their semantics (sampling from the Gaussian policy with eval-mode normalisation,
+obs clipping to clip_obs_range, actions clipped to the action space before they reach the env while the unclipped
+sample is what is stored, full-batch epochs of one critic step + one clipped-surrogate step, grad-norm clipping,
+the checkpoint dictionary layout of agent_humanoid.py:115-140).
+
+What is different by construction: N envs advance in lock step for a fixed horizon T instead of every worker finishing
+whole episodes, so a rollout column can end mid-episode; its last step bootstraps with V(next observation)
+(`bootstrap=False` reproduces the reference's zero).  Everything — observations, actions, rewards, flags, advantages —
+stays in HBM; the only host synchronisation per epoch is the logging read-back.
+"""
+from dataclasses import dataclass, field
+
+import torch
+
+from ..learning.gae import estimate_advantages_columns, normalize_advantages
+from ..learning.networks import MLP, PolicyGaussian, Value
+
+
+@dataclass
+class PPOConfig:
+    """Defaults = smpl_sim/data/cfg/learning/simple_mlp.yaml."""
+    gamma: float = 0.99
+    tau: float = 0.95
+    clip_epsilon: float = 0.2
+    opt_num_epochs: int = 10
+    value_opt_niter: int = 1
+    policy_lr: float = 5e-5
+    value_lr: float = 3e-4
+    policy_weightdecay: float = 0.0
+    value_weightdecay: float = 0.0
+    policy_grad_clip: float = 25.0
+    hidden: tuple = (2048, 1536, 1024, 1024, 512, 512)
+    activation: str = "silu"
+    log_std: float = -2.5
+    fix_std: bool = True
+    clip_obs: bool = True
+    clip_obs_range: tuple = (-5.0, 5.0)
+    clip_actions: bool = True
+    min_batch_size: int = 51200
+    bootstrap: bool = True
+    extra: dict = field(default_factory=dict)
+
+
+class AgentPPO:
+    def __init__(self, env, cfg=None, seed=0):
+        self.env, self.cfg = env, cfg or PPOConfig()
+        c = self.cfg
+        self.device = env.device
+        torch.manual_seed(seed)
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(seed)
+        self.state_dim, self.action_dim = env.obs_size, env.nu
+        self.policy_net = PolicyGaussian(self.state_dim, self.action_dim, c.hidden, c.activation, c.log_std, c.fix_std).to(self.device)
+        self.value_net = Value(MLP(self.state_dim, c.hidden, c.activation)).to(self.device)
+        self.optimizer_policy = torch.optim.Adam(self.policy_net.parameters(), lr=c.policy_lr, eps=1e-8, weight_decay=c.policy_weightdecay)
+        self.optimizer_value = torch.optim.Adam(self.value_net.parameters(), lr=c.value_lr, eps=1e-8, weight_decay=c.value_weightdecay)
+        self.epoch, self.num_steps = 0, 0
+        self.horizon = max(1, -(-c.min_batch_size // env.num_envs))
+        self._obs = None
+
+    # ------------------------------------------------------------------ sampling
+    def _prep_obs(self, obs):
+        lo, hi = self.cfg.clip_obs_range
+        return obs.clamp(lo, hi) if self.cfg.clip_obs else obs
+
+    def _prep_actions(self, actions):
+        # rescale_actions(low, high, clip(a, low, high)) with the env's action space [-1, 1] is the clip itself
+        return actions.clamp(-1.0, 1.0) if self.cfg.clip_actions else actions
+
+    @torch.no_grad()
+    def sample(self, horizon=None, mean_action=False):
+        """Roll all envs `horizon` control steps forward.  Returns time-major tensors on the env's device."""
+        env, T, N = self.env, horizon or self.horizon, self.env.num_envs
+        self.policy_net.eval()
+        if self._obs is None:
+            self._obs, _ = env.reset()
+        f = dict(device=self.device, dtype=torch.float32)
+        states = torch.empty(T, N, self.state_dim, **f)
+        actions = torch.empty(T, N, self.action_dim, **f)
+        rewards, not_done, not_dead = (torch.empty(T, N, **f) for _ in range(3))
+        state = self._prep_obs(self._obs)
+        for t in range(T):
+            states[t] = state
+            a = self.policy_net.select_action(state, mean_action, generator=self.gen)
+            actions[t] = a
+            obs, rew, died, timed_out, _ = env.step(self._prep_actions(a))
+            rewards[t] = rew
+            not_dead[t] = (~died).to(torch.float32)
+            not_done[t] = (~(died | timed_out)).to(torch.float32)
+            state = self._prep_obs(obs)                        # post-autoreset observation = first state of the next episode
+        self._obs = obs
+        self.num_steps += T * N
+        exps = torch.full((T, N), 0.0 if mean_action else 1.0, **f)
+        return dict(states=states, actions=actions, rewards=rewards, not_done=not_done, not_dead=not_dead, exps=exps,
+                    last_state=state.clone())
+
+    # ------------------------------------------------------------------ update
+    def ppo_loss(self, states, actions, advantages, fixed_log_probs):
+        log_probs = self.policy_net.get_log_prob(states, actions)
+        ratio = torch.exp(log_probs - fixed_log_probs)
+        clipped = ratio.clamp(1.0 - self.cfg.clip_epsilon, 1.0 + self.cfg.clip_epsilon)
+        return -torch.minimum(ratio * advantages, clipped * advantages).mean()
+
+    def update_value(self, critic_states, returns):
+        for _ in range(self.cfg.value_opt_niter):
+            loss = (self.value_net(critic_states) - returns).pow(2).mean()
+            self.optimizer_value.zero_grad(set_to_none=True)
+            loss.backward()
+            self.optimizer_value.step()
+        return loss.detach()
+
+    def update_params(self, batch):
+        c = self.cfg
+        T, N = batch["rewards"].shape
+        states = batch["states"].reshape(T * N, -1)
+        self.policy_net.eval(); self.value_net.eval()
+        with torch.no_grad():
+            values = self.value_net(states).reshape(T, N)
+            boot = self.value_net(batch["last_state"]).reshape(N) if c.bootstrap else None
+        adv, ret = estimate_advantages_columns(batch["rewards"], batch["not_done"], batch["not_dead"], values, c.gamma, c.tau, boot)
+        adv = normalize_advantages(adv).reshape(T * N, 1)
+        ret = ret.reshape(T * N, 1)
+        actions = batch["actions"].reshape(T * N, -1)
+        ind = batch["exps"].reshape(-1).nonzero(as_tuple=False).squeeze(1)
+        with torch.no_grad():
+            fixed_log_probs = self.policy_net.get_log_prob(states, actions)
+        self.policy_net.train(); self.value_net.train()        # RunningNorm statistics follow the training passes
+        s_i, a_i, adv_i, flp_i = states[ind], actions[ind], adv[ind], fixed_log_probs[ind]
+        info = {}
+        for _ in range(c.opt_num_epochs):
+            info["value_loss"] = self.update_value(states, ret)
+            loss = self.ppo_loss(s_i, a_i, adv_i, flp_i)
+            self.optimizer_policy.zero_grad(set_to_none=True)
+            loss.backward()
+            if c.policy_grad_clip is not None:
+                torch.nn.utils.clip_grad_norm_(self.policy_net.parameters(), c.policy_grad_clip)
+            self.optimizer_policy.step()
+            info["surr_loss"] = loss.detach()
+        self.epoch += 1
+        info["mean_reward"] = batch["rewards"].mean()
+        info["episodes_ended"] = (1.0 - batch["not_done"]).sum()
+        return info
+
+    def optimize_policy(self, epochs=1):
+        log = []
+        for _ in range(epochs):
+            log.append({k: float(v) for k, v in self.update_params(self.sample()).items()})
+        return log
+
+    # ------------------------------------------------------------------ checkpoints (agent_humanoid.py:115-140 layout)
+    def get_full_state_weights(self):
+        return {"policy": self.policy_net.state_dict(), "value": self.value_net.state_dict(), "epoch": self.epoch,
+                "optimizer_policy": self.optimizer_policy.state_dict(), "optimizer_value": self.optimizer_value.state_dict(),
+                "frame": self.num_steps}
+
+    def set_full_state_weights(self, state):
+        self.policy_net.load_state_dict(state["policy"]); self.value_net.load_state_dict(state["value"])
+        self.epoch = state["epoch"]
+        self.optimizer_value.load_state_dict(state["optimizer_value"])
+        self.optimizer_policy.load_state_dict(state["optimizer_policy"])
+        self.num_steps = state.get("frame", 0)

@@ -93,6 +93,23 @@ __global__ void __launch_bounds__(MAXT) ss_env_kernel(const ss::KArgs k) {
   }
 }
 
+// GAE: one lane per env column, time loop backwards; every [t, :] row access is coalesced across the wave.  HBM bound
+// and tiny (5 arrays of T*N floats), it only exists so that the rollout never leaves the device.
+__global__ void ss_gae_kernel(const float *rew, const float *nd, const float *ndead, const float *val, const float *boot,
+                              int T, int N, float gamma, float tau, float *adv, float *ret) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float next_v = boot ? boot[n] : 0.f, next_a = 0.f;
+  for (int t = T - 1; t >= 0; --t) {
+    const size_t i = (size_t)t * N + n;
+    const float v = val[i];
+    const float delta = rew[i] + gamma * next_v * ndead[i] - v;
+    const float a = delta + gamma * tau * next_a * nd[i];
+    adv[i] = a; ret[i] = v + a;
+    next_v = v; next_a = a;
+  }
+}
+
 typedef void (*kern_t)(const ss::KArgs);
 kern_t pick_kernel(int variant) {
   if (variant == 0) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS>;      // SMPL layout (24 bodies)
@@ -109,6 +126,12 @@ struct HipBackend {
   static int lds_capacity() { return 160 * 1024; }
   static int num_cus() { int d = 0, n = 256; if (hipGetDevice(&d) == hipSuccess) { hipDeviceProp_t p; if (hipGetDeviceProperties(&p, d) == hipSuccess) n = p.multiProcessorCount; } return n; }
   static int max_waves(int variant) { return (variant == 0 ? SS_MAX_THREADS : SS_MAX_THREADS_X) / 64; }
+  static const char *gae(const float *rew, const float *nd, const float *ndead, const float *val, const float *boot, int T, int N,
+                         float gamma, float tau, float *adv, float *ret, void *stream) {
+    hipLaunchKernelGGL(ss_gae_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, rew, nd, ndead, val, boot, T, N, gamma, tau, adv, ret);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? nullptr : hipGetErrorString(e);
+  }
   static int &regs_ref() { static int r = 0; return r; }
   static int kernel_regs() { return regs_ref(); }
   static const char *launch(const ss::KArgs &k, int nenv, int envs_per_wg, size_t lds_bytes, void *stream) {

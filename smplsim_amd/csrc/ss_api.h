@@ -168,6 +168,13 @@ struct ss_api {
     if (!b) return ss_api<BE>::fail(SS_ERR_INVALID, "null batch");                                                  \
     b->order = order; return SS_OK;                                                                                  \
   }                                                                                                                  \
+  int ss_gae(const float *rew, const float *nd, const float *ndead, const float *val, const float *boot, int32_t T,   \
+             int32_t N, float gamma, float tau, float *adv, float *ret, void *stream) {                             \
+    if (!rew || !nd || !ndead || !val || !adv || !ret) return ss_api<BE>::fail(SS_ERR_INVALID, "null argument");     \
+    if (T < 1 || N < 1) return ss_api<BE>::fail(SS_ERR_INVALID, "T and N must be positive");                         \
+    const char *err = BE::gae(rew, nd, ndead, val, boot, T, N, gamma, tau, adv, ret, stream);                         \
+    return err ? ss_api<BE>::fail(SS_ERR_HIP, err) : SS_OK;                                                          \
+  }                                                                                                                  \
   int ss_debug_prof(ss_batch *b, unsigned long long *out, int n) {                                                   \
     if (!b || !out || !b->d_prof) return ss_api<BE>::fail(SS_ERR_INVALID, "not a profiling build");                 \
     return BE::download(out, b->d_prof, (size_t)n * 8) ? SS_OK : SS_ERR_HIP;                                         \

@@ -209,6 +209,57 @@ def main():
     out["ctl_pd"], out["ctl_torque"], out["ctl_simple_pid"] = np.array(cpd), np.array(ctq), np.array(cpid)
     out["ctl_power_scale"] = np.array(0.7)
 
+    # ---- learning side: GAE, Gaussian policy / value nets, running norm, PPO surrogate, action rescale
+    import torch
+    import smpl_sim.learning.learning_utils as lu
+    from smpl_sim.learning.policy_gaussian import PolicyGaussian
+    from smpl_sim.learning.critic import Value
+    from smpl_sim.learning.mlp import MLP
+    from smpl_sim.agents.agent_ppo import AgentPPO
+    rs3 = np.random.default_rng(4242)
+    torch.manual_seed(4242)
+    nS = 300
+    rew = torch.tensor(rs3.normal(size=(nS, 1)), dtype=torch.float64)
+    val = torch.tensor(rs3.normal(size=(nS, 1)), dtype=torch.float64)
+    done = rs3.uniform(size=(nS, 1)) < 0.06
+    dead = done & (rs3.uniform(size=(nS, 1)) < 0.5)
+    done[-1] = True
+    nd, ndead = torch.tensor(1.0 - done), torch.tensor(1.0 - dead)
+    adv, ret = lu.estimate_advantages(rew.clone(), nd.clone(), ndead.clone(), val.clone(), 0.99, 0.95)
+    out["gae_rewards"], out["gae_values"], out["gae_not_done"], out["gae_not_dead"] = rew.numpy(), val.numpy(), nd.numpy(), ndead.numpy()
+    out["gae_adv"], out["gae_ret"] = adv.numpy(), ret.numpy()
+    lcfg = types.SimpleNamespace(learning=types.SimpleNamespace(mlp=types.SimpleNamespace(units=[16, 12], activation="silu"),
+                                                                fix_std=False, log_std=-1.0))
+    pol = PolicyGaussian(lcfg, action_dim=5, state_dim=11).double()
+    vnet = Value(MLP(11, [16, 12], "silu")).double()
+    xs = [torch.tensor(rs3.normal(size=(40, 11)) * (1 + i) + i, dtype=torch.float64) for i in range(3)]
+    pol.train()
+    for x in xs:                                              # three training-mode passes update the running norm
+        pol(x)
+    out["rn_inputs"] = np.stack([x.numpy() for x in xs])
+    out["rn_n"], out["rn_mean"], out["rn_var"], out["rn_std"] = (pol.norm.n.numpy(), pol.norm.mean.numpy(), pol.norm.var.numpy(), pol.norm.std.numpy())
+    pol.eval()
+    xq = torch.tensor(rs3.normal(size=(7, 11)) * 4, dtype=torch.float64)
+    aq = torch.tensor(rs3.normal(size=(7, 5)), dtype=torch.float64)
+    with torch.no_grad():
+        dist = pol(xq)
+        out["pol_x"], out["pol_a"] = xq.numpy(), aq.numpy()
+        out["pol_mean"], out["pol_logp"] = dist.loc.numpy(), pol.get_log_prob(xq, aq).numpy()
+        out["pol_norm_out"] = pol.norm(xq).numpy()
+        out["val_out"] = vnet(xq).numpy()
+    for k, v in pol.state_dict().items():
+        out["polsd_" + k] = v.numpy()
+    for k, v in vnet.state_dict().items():
+        out["valsd_" + k] = v.numpy()
+    fixed = torch.tensor(out["pol_logp"]) + torch.tensor(rs3.normal(size=(7, 1)) * 0.3)
+    advq = torch.tensor(rs3.normal(size=(7, 1)), dtype=torch.float64)
+    fake_agent = types.SimpleNamespace(policy_net=pol, clip_epsilon=0.2)
+    with torch.no_grad():
+        out["ppo_loss"] = AgentPPO.ppo_loss(fake_agent, xq, aq, advq, fixed, torch.arange(7)).numpy()
+    out["ppo_fixed"], out["ppo_adv"] = fixed.numpy(), advq.numpy()
+    lo, hi, act = rs3.uniform(-2, -1, 5), rs3.uniform(1, 3, 5), rs3.uniform(-1, 1, (4, 5))
+    out["resc_low"], out["resc_high"], out["resc_in"], out["resc_out"] = lo, hi, act, lu.rescale_actions(lo, hi, act)
+
     np.savez_compressed(path, **out)
     print("wrote", path, {k: np.asarray(v).shape for k, v in out.items()})
 

@@ -206,6 +206,21 @@ struct EmuBackend {
   static int lds_capacity() { return 160 * 1024; }
   static int kernel_regs() { return 0; }
   static int max_waves(int) { return 16; }
+  static const char *gae(const float *rew, const float *nd, const float *ndead, const float *val, const float *boot, int T, int N,
+                         float gamma, float tau, float *adv, float *ret, void *) {
+    for (int n = 0; n < N; n++) {                            // same float32 recursion as the device kernel
+      float next_v = boot ? boot[n] : 0.f, next_a = 0.f;
+      for (int t = T - 1; t >= 0; --t) {
+        const size_t i = (size_t)t * N + n;
+        const float v = val[i];
+        const float delta = rew[i] + gamma * next_v * ndead[i] - v;
+        const float a = delta + gamma * tau * next_a * nd[i];
+        adv[i] = a; ret[i] = v + a;
+        next_v = v; next_a = a;
+      }
+    }
+    return nullptr;
+  }
   static const char *launch(const ss::KArgs &k, int nenv, int envs_per_wg, size_t lds_bytes, void *) {
     (void)envs_per_wg; (void)lds_bytes;
     static thread_local Machine *m = new Machine();

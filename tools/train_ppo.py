@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""On-device PPO on the batched stepper: the training loop of the reference's `python smpl_sim/run.py env=speed`
+ with sampler, GAE and update on the GPU.  Prints one JSON line per epoch and a timing summary
+(env-steps/s of the sampler alone = stepper + policy inference, and of the whole epoch including the update).
+
+    python tools/train_ppo.py --task HumanoidSpeed --envs 4096 --epochs 5
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from smplsim_amd.agents.ppo import AgentPPO, PPOConfig
+from smplsim_amd.batch import SMPLSimVecEnv
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--task", default="HumanoidSpeed")
+    ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--epochs", type=int, default=5)
+    ap.add_argument("--min-batch-size", type=int, default=51200)
+    ap.add_argument("--hidden", default="2048,1536,1024,1024,512,512")
+    ap.add_argument("--opt-epochs", type=int, default=10)
+    ap.add_argument("--save", default="")
+    args = ap.parse_args()
+    env = SMPLSimVecEnv(args.envs, task=args.task, autoreset=True, seed=0)
+    cfg = PPOConfig(hidden=tuple(int(x) for x in args.hidden.split(",")), min_batch_size=args.min_batch_size, opt_num_epochs=args.opt_epochs)
+    agent = AgentPPO(env, cfg, seed=0)
+    ts, tu, n = 0.0, 0.0, 0
+    for ep in range(args.epochs):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        batch = agent.sample()
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        info = agent.update_params(batch)
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        T, N = batch["rewards"].shape
+        if ep > 0:                                           # epoch 0 carries allocator / library warm-up
+            ts += t1 - t0; tu += t2 - t1; n += T * N
+        print(json.dumps({"epoch": ep, "samples": T * N, "sample_s": round(t1 - t0, 4), "update_s": round(t2 - t1, 4),
+                          **{k: round(float(v), 5) for k, v in info.items()}}))
+    if n:
+        print(json.dumps({"summary": "on-device PPO", "task": args.task, "envs": args.envs, "mlp": args.hidden,
+                          "sampler_env_steps_per_s": round(n / ts), "epoch_env_steps_per_s": round(n / (ts + tu)),
+                          "sample_fraction": round(ts / (ts + tu), 3)}))
+    if args.save:
+        torch.save(agent.get_full_state_weights(), args.save)
+
+
+if __name__ == "__main__":
+    main()
