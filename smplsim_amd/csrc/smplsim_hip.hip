@@ -81,11 +81,17 @@ __global__ void __launch_bounds__(MAXT) ss_env_kernel(const ss::KArgs k) {
   float *L = reinterpret_cast<float *>(lds + ((k.h.shared_words + 3) & ~3)) + (size_t)wave * k.h.env_floats;
   WaveGpu w{(int)(threadIdx.x & 63)};
   // persistent wavefronts: env-steps have heavy-tailed cost (Newton iterations), so every wave pulls the
-  // next env id from a device counter instead of owning a fixed slice of the batch
+  // next env id from a device counter instead of owning a fixed slice of the batch.  The first env of every wave is
+  // its own global wave index (no atomic: thousands of waves hitting one counter at launch serialise in L2).
+  const int total_waves = (int)(gridDim.x * (blockDim.x >> 6));
+  bool first = true;
   for (;;) {
-    int env = 0;
-    if (w.ln == 0) env = atomicAdd(k.work_counter, 1);
-    env = __builtin_amdgcn_readfirstlane(env);
+    int env = wave * (int)gridDim.x + (int)blockIdx.x;       // consecutive (= similarly heavy) envs go to different CUs
+    if (!first) {
+      if (w.ln == 0) env = atomicAdd(k.work_counter, 1) + total_waves;
+      env = __builtin_amdgcn_readfirstlane(env);
+    }
+    first = false;
     if (env >= k.st.num_envs) break;
     if (k.order) env = __builtin_amdgcn_readfirstlane(k.order[env]);   // longest-processing-time-first hand-out
     ss::run_env<WaveGpu, DOFP, CANDP, SLOTP, NPASS>(&w, &k, lds, L, env);
