@@ -940,6 +940,11 @@ struct Sim {
     }
     w->sync();
     // converged: full Newton step with an unchanged active set, or no representable progress any more
+#if defined(SS_TRACE_NEWTON) && !defined(__HIPCC__)
+    { const bool ch = w->any(changed), mv = w->any(moving);
+      if (lane == 0) fprintf(stderr, "NT env %d it %d dg %.4e sa %.4e sb %.4e al %.4f exact %d changed %d moving %d\n", env, iters, dg_, s_a, s_b, al, (int)exact, (int)ch, (int)mv);
+      return (!ch && exact) || !mv; }
+#endif
     return (!w->any(changed) && exact) || !w->any(moving);
   }
 
