@@ -63,7 +63,7 @@ typedef struct {
   double timestep, gravity, solref[2], solimp[5], margin, friction, impratio;
 } ss_model_desc;
 
-/* Environment configuration (reference smpl_sim/data/cfg/env/*.yaml keys). */
+/* Environment configuration (the keys of the reference's smpl_sim/data/cfg/env yaml files). */
 typedef struct {
   int32_t task, state_init, self_obs_v, control_mode;
   int32_t episode_length, control_freq_inv, root_height_obs;

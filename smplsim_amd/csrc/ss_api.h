@@ -158,7 +158,10 @@ struct ss_api {
   void ss_model_destroy(ss_model *m) { ss_api<BE>::model_destroy(m); }                                               \
   int ss_model_dims(const ss_model *m, int32_t *nq, int32_t *nv, int32_t *nu, int32_t *nb) {                          \
     if (!m) return ss_api<BE>::fail(SS_ERR_INVALID, "null model");                                                   \
-    if (nq) *nq = m->hm.h.nq; if (nv) *nv = m->hm.h.nv; if (nu) *nu = m->hm.h.nu; if (nb) *nb = m->hm.h.nb;          \
+    if (nq) *nq = m->hm.h.nq;                                                                                        \
+    if (nv) *nv = m->hm.h.nv;                                                                                        \
+    if (nu) *nu = m->hm.h.nu;                                                                                        \
+    if (nb) *nb = m->hm.h.nb;                                                                                        \
     return SS_OK;                                                                                                    \
   }                                                                                                                  \
   int ss_obs_size(const ss_model *m, const ss_env_cfg *c) { return (m && c) ? ss::obs_size(m->hm.h, *c) : SS_ERR_INVALID; } \
@@ -186,7 +189,9 @@ struct ss_api {
   int ss_debug_forward(ss_batch *b, const float *tq, float *M, float *bias, float *qacc, void *st) { return ss_api<BE>::debug_forward(b, tq, M, bias, qacc, st); } \
   int ss_launch_info(const ss_batch *b, int32_t *epw, int32_t *lds, int32_t *regs) {                                 \
     if (!b) return ss_api<BE>::fail(SS_ERR_INVALID, "null batch");                                                   \
-    if (epw) *epw = b->envs_per_wg; if (lds) *lds = (int32_t)b->lds_bytes; if (regs) *regs = BE::kernel_regs();      \
+    if (epw) *epw = b->envs_per_wg;                                                                                  \
+    if (lds) *lds = (int32_t)b->lds_bytes;                                                                           \
+    if (regs) *regs = BE::kernel_regs();                                                                             \
     return SS_OK;                                                                                                    \
   }                                                                                                                  \
   const char *ss_last_error(void) { return ss::last_error().c_str(); }                                               \

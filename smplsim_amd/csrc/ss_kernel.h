@@ -67,7 +67,6 @@ struct Limit { float sign, D, aref, jar, jd; };
 
 SS_DEV float bits2f(uint32_t u) { union { uint32_t u; float f; } c; c.u = u; return c.f; }
 SS_DEV float4_t ld4(const float *p) { return *reinterpret_cast<const float4_t *>(p); }      // 16-byte aligned LDS row
-SS_DEV void st4(float *p, float a, float b, float c) { float4_t v; v.x = a; v.y = b; v.z = c; v.w = 0.f; *reinterpret_cast<float4_t *>(p) = v; }
 // sin and cos of an angle of at most a few hundred radians (joint angles, half rotation angles): Cody-Waite reduction
 // by pi/2 and the single-precision minimax polynomials on [-pi/4, pi/4] (abs. error ~1e-7).  libm's sincosf carries a
 // Payne-Hanek path for huge arguments (private scratch array, ~600 instructions per inlined call site).
