@@ -33,12 +33,15 @@ class ShardModel:
     """Compiled model + device tables (ss_model) for one device."""
 
     def __init__(self, xml=None, humanoid="smpl_humanoid", device=0, contact_bodies=DEFAULT_CONTACT_BODIES,
-                 control_mode="uhc_pd", clip_actions=True, pdp_scale=1.0, pdd_scale=1.0, sim_timestep_inv=450):
+                 control_mode="uhc_pd", clip_actions=True, pdp_scale=1.0, pdd_scale=1.0, sim_timestep_inv=450, tables=None):
+        """tables: optional (kp, kd, torque_lim, act_scale, act_offset) per actuator for models whose bodies are not in
+        the reference's gain table (humanoid_env.py:62-84)."""
         self.xml = xml if xml is not None else default_xml_str(humanoid)
         self.mc = compile_mjcf(self.xml)
         rng = {n: self.mc.jnt_range[6 + i] for i, n in enumerate(self.mc.joint_names)}
-        self.tables = build_pd_tables(self.mc.actuator_names, lambda n: rng[n], clip_actions=clip_actions,
-                                      control_mode=control_mode, pdp_scale=pdp_scale, pdd_scale=pdd_scale)
+        self.tables = tables if tables is not None else build_pd_tables(
+            self.mc.actuator_names, lambda n: rng[n], clip_actions=clip_actions, control_mode=control_mode,
+            pdp_scale=pdp_scale, pdd_scale=pdd_scale)
         self.device = int(device)
         desc, self._keep = _cabi.make_model_desc(self.mc, *self.tables, legal_bodies=tuple(contact_bodies),
                                                  timestep=1.0 / sim_timestep_inv)

@@ -200,6 +200,40 @@ def test_pd_and_torque_controllers_on_gpu(vec, mode):
     assert np.abs(_np(env.qpos)[0] - d.qpos).max() < 1e-5 * vmax
 
 
+@pytest.mark.parametrize("shape", ["chain15", "comb9"])
+def test_synthetic_trees_on_gpu(vec, shape):
+    """Deep chain (15 tree levels) and wide comb (9 nodes in one level: two 8-node passes, the large kernel variant)."""
+    from smplsim_amd.batch import ShardModel
+    from smplsim_amd.mjcf_writer import table_to_mjcf
+    from test_synthetic_trees_emu import _chain, _comb
+    xml = table_to_mjcf(_chain(14) if shape == "chain15" else _comb(9))
+    root_z = 2.8 if shape == "chain15" else 0.40
+    from smplsim_amd.mjcf import compile_mjcf
+    mc = compile_mjcf(xml)
+    nu = mc.nu
+    tables = (np.full(nu, 60.0), np.full(nu, 6.0), np.full(nu, 40.0), np.full(nu, 2.0), np.zeros(nu))
+    legal = tuple(mc.body_names)
+    env = vec(3, model=ShardModel(xml=xml, contact_bodies=legal, tables=tables), autoreset=False, reach_body=mc.body_names[-1])
+    om = O.OracleModel(xml, *tables, legal_bodies=legal)
+    rs = np.random.default_rng(len(shape))
+    q = np.zeros(mc.nq); q[2] = root_z; q[3] = 1.0
+    q[7:] = rs.uniform(-0.3, 0.3, mc.nq - 7)
+    v = rs.normal(size=mc.nv) * 0.3
+    env.set_state(np.tile(q, (3, 1)), np.tile(v, (3, 1)))
+    d = O.OracleData(om); d.qpos = q; d.qvel = v; d.ctrl = np.zeros(nu); d.forward()
+    M, bias, qacc = env.debug_forward(torch.zeros(3, nu, device=env.device))
+    torch.cuda.synchronize()
+    assert np.abs(_np(M)[0] - d.M).max() < 5e-6 * np.abs(d.M).max()
+    assert np.abs(_np(qacc)[0] - d.qacc).max() < 2e-4 * max(1.0, np.abs(d.qacc).max())
+    a = rs.uniform(-0.3, 0.3, nu)
+    for s_ in range(6):
+        d.ctrl = d.spd_torque(a); d.step()
+    env.substep(torch.tensor(np.tile(a, (3, 1)), device=env.device, dtype=torch.float32), 6)
+    torch.cuda.synchronize()
+    vmax = max(1.0, np.abs(d.qvel).max())
+    assert np.abs(_np(env.qpos)[0] - d.qpos).max() < 2e-5 * vmax and np.abs(_np(env.qvel)[0] - d.qvel).max() < 5e-4 * vmax
+
+
 def test_benchmark_size_properties(vec):
     """4096 envs, full-range random actions (BASELINE config 2): size-independent properties —
     finite state, unit root quaternions, deterministic replay, yaw invariance of the observation,

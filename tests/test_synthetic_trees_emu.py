@@ -1,0 +1,91 @@
+"""Tree shapes beyond the two shipped humanoids: the generic table construction (levels, child ranges, packed level
+sizes, two passes of 8 nodes per level) and the articulated-body sweeps against the oracle on synthetic MJCF models —
+a deep chain (15 tree levels) and a wide comb (9 branches: 9 nodes in a level -> the large kernel variant)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from smplsim_amd.mjcf import compile_mjcf
+from smplsim_amd.mjcf_writer import table_to_mjcf
+from wave_emu import emu
+
+
+def _body(name, parent, pos, box=False, length=0.18):
+    joints = [] if parent is None else [
+        {"name": f"{name}_{ax}", "axis": [float(ax == a) for a in "xyz"], "range": [-120.0, 120.0], "armature": "0.01",
+         "damping": "0", "stiffness": "0", "type": "hinge", "pos": "0 0 0"} for ax in "xyz"]
+    if box:
+        geom = {"name": name, "type": "box", "pos": [0.0, 0.0, -0.02], "size": [0.06, 0.05, 0.04], "quat": [1.0, 0.0, 0.0, 0.0], "density": "1000"}
+    else:
+        geom = {"name": name, "type": "capsule", "size": [0.035], "fromto": [0.0, 0.0, 0.0, 0.0, 0.02, -length], "density": "1200",
+                "contype": "1", "conaffinity": "1"}
+    return {"name": name, "parent": parent, "pos": list(pos), "freejoint": parent is None, "joints": joints, "geoms": [geom]}
+
+
+def _table(bodies):
+    return {"model": "synthetic", "default_joint": {"armature": "0.01", "damping": "0", "stiffness": "0", "limited": "true"},
+            "default_geom": {"contype": "7", "conaffinity": "1", "condim": "3", "margin": "0.001"},
+            "floor": {"name": "floor", "pos": [0, 0, 0], "size": [100, 100, 0.2], "conaffinity": 1, "condim": 3},
+            "bodies": bodies, "excludes": [], "vel_sensors": False,
+            "motors": [{"name": j["name"], "joint": j["name"], "gear": "1"} for b in bodies for j in b["joints"]]}
+
+
+def _chain(n):
+    bodies = [_body("B0", None, (0, 0, 0), box=True)]
+    for i in range(1, n):
+        bodies.append(_body(f"B{i}", f"B{i - 1}", (0.0, 0.02, -0.19), box=(i == n - 1)))
+    return _table(bodies)
+
+
+def _comb(branches):
+    bodies = [_body("Root", None, (0, 0, 0), box=True)]
+    for i in range(branches):                                  # depth-first order: every branch is contiguous
+        ang = 2 * np.pi * i / branches
+        bodies.append(_body(f"U{i}", "Root", (0.12 * np.cos(ang), 0.12 * np.sin(ang), -0.03)))
+        bodies.append(_body(f"L{i}", f"U{i}", (0.0, 0.02, -0.19), box=(i % 3 == 0)))
+    return _table(bodies)
+
+
+@pytest.mark.parametrize("name,table,root_z", [("chain15", _chain(14), 2.8), ("comb9", _comb(9), 0.40)])
+def test_synthetic_tree_matches_oracle(name, table, root_z):
+    xml = table_to_mjcf(table)
+    mc = compile_mjcf(xml)
+    nu = mc.nu
+    tables = (np.full(nu, 60.0), np.full(nu, 6.0), np.full(nu, 40.0), np.full(nu, 2.0), np.zeros(nu))
+    legal = tuple(mc.body_names)
+    om = O.OracleModel(xml, *tables, legal_bodies=legal)
+    eb = emu.EmuBatch(mc, tables, 2, legal_bodies=legal)
+    rs = np.random.default_rng(len(name))
+    q = np.zeros(mc.nq); q[2] = root_z; q[3] = 1.0
+    q[7:] = rs.uniform(-0.3, 0.3, mc.nq - 7)
+    v = rs.normal(size=mc.nv) * 0.3
+    d = O.OracleData(om); d.qpos = q; d.qvel = v; d.forward()
+    eb.set_state(np.tile(q, (2, 1)), np.tile(v, (2, 1)))
+    # pieces of one forward pass: kinematics, dense mass matrix, bias force, constrained acceleration
+    xpos, _ = eb.kinematics()
+    M, bias, qacc = eb.debug_forward(np.zeros((2, nu)))
+    d.ctrl = np.zeros(nu); d.forward()
+    assert np.abs(xpos[0] - d.xpos).max() < 5e-6
+    assert np.abs(M[0] - d.M).max() < 5e-6 * np.abs(d.M).max()
+    assert np.abs(bias[0] - d.bias).max() < 5e-6 * max(1.0, np.abs(d.bias).max())
+    assert np.abs(qacc[0] - d.qacc).max() < 2e-4 * max(1.0, np.abs(d.qacc).max()), d.ncon
+    # a few Stable-PD + mj_step substeps, free running (the comb starts just above the floor and lands on it)
+    a = rs.uniform(-0.3, 0.3, nu)
+    oenv = O.OracleEnv(om)
+    oenv.data.qpos = q; oenv.data.qvel = v; oenv.data.forward()
+    for s_ in range(6):
+        oenv.data.ctrl = oenv.data.spd_torque(a); oenv.data.step()
+    eb.substep(np.tile(a, (2, 1)), 6)
+    vmax = max(1.0, np.abs(oenv.data.qvel).max())
+    assert np.abs(eb.qpos[0] - oenv.data.qpos).max() < 2e-5 * vmax
+    assert np.abs(eb.qvel[0] - oenv.data.qvel).max() < 5e-4 * vmax
+    assert np.array_equal(eb.qpos[0], eb.qpos[1])
+
+
+def test_too_many_nodes_in_one_level_is_rejected():
+    xml = table_to_mjcf(_comb(17))                              # 17 nodes in one tree level > the 16 the kernels handle
+    mc = compile_mjcf(xml)
+    nu = mc.nu
+    tables = (np.full(nu, 60.0), np.full(nu, 6.0), np.full(nu, 40.0), np.full(nu, 2.0), np.zeros(nu))
+    with pytest.raises(RuntimeError, match="level|large"):
+        emu.EmuBatch(mc, tables, 1, legal_bodies=tuple(mc.body_names))
