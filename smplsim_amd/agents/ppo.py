@@ -42,6 +42,7 @@ class PPOConfig:
     clip_actions: bool = True
     min_batch_size: int = 51200
     bootstrap: bool = True
+    amp_bf16: bool = False      # run the update's network passes under bf16 autocast (MFMA rate); off = the reference's fp32
     extra: dict = field(default_factory=dict)
 
 
@@ -99,15 +100,22 @@ class AgentPPO:
                     last_state=state.clone())
 
     # ------------------------------------------------------------------ update
+    def _autocast(self):
+        on = self.cfg.amp_bf16 and self.device.type == "cuda"
+        return torch.autocast(device_type=self.device.type, dtype=torch.bfloat16, enabled=on)
+
     def ppo_loss(self, states, actions, advantages, fixed_log_probs):
-        log_probs = self.policy_net.get_log_prob(states, actions)
+        with self._autocast():
+            log_probs = self.policy_net.get_log_prob(states, actions).float()
         ratio = torch.exp(log_probs - fixed_log_probs)
         clipped = ratio.clamp(1.0 - self.cfg.clip_epsilon, 1.0 + self.cfg.clip_epsilon)
         return -torch.minimum(ratio * advantages, clipped * advantages).mean()
 
     def update_value(self, critic_states, returns):
         for _ in range(self.cfg.value_opt_niter):
-            loss = (self.value_net(critic_states) - returns).pow(2).mean()
+            with self._autocast():
+                pred = self.value_net(critic_states).float()
+            loss = (pred - returns).pow(2).mean()
             self.optimizer_value.zero_grad(set_to_none=True)
             loss.backward()
             self.optimizer_value.step()
@@ -126,8 +134,8 @@ class AgentPPO:
         ret = ret.reshape(T * N, 1)
         actions = batch["actions"].reshape(T * N, -1)
         ind = batch["exps"].reshape(-1).nonzero(as_tuple=False).squeeze(1)
-        with torch.no_grad():
-            fixed_log_probs = self.policy_net.get_log_prob(states, actions)
+        with torch.no_grad(), self._autocast():
+            fixed_log_probs = self.policy_net.get_log_prob(states, actions).float()
         self.policy_net.train(); self.value_net.train()        # RunningNorm statistics follow the training passes
         s_i, a_i, adv_i, flp_i = states[ind], actions[ind], adv[ind], fixed_log_probs[ind]
         info = {}

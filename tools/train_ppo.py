@@ -26,10 +26,11 @@ def main():
     ap.add_argument("--min-batch-size", type=int, default=51200)
     ap.add_argument("--hidden", default="2048,1536,1024,1024,512,512")
     ap.add_argument("--opt-epochs", type=int, default=10)
+    ap.add_argument("--amp-bf16", action="store_true", help="bf16 autocast for the update passes (not the reference numerics)")
     ap.add_argument("--save", default="")
     args = ap.parse_args()
     env = SMPLSimVecEnv(args.envs, task=args.task, autoreset=True, seed=0)
-    cfg = PPOConfig(hidden=tuple(int(x) for x in args.hidden.split(",")), min_batch_size=args.min_batch_size, opt_num_epochs=args.opt_epochs)
+    cfg = PPOConfig(hidden=tuple(int(x) for x in args.hidden.split(",")), min_batch_size=args.min_batch_size, opt_num_epochs=args.opt_epochs, amp_bf16=args.amp_bf16)
     agent = AgentPPO(env, cfg, seed=0)
     ts, tu, n = 0.0, 0.0, 0
     for ep in range(args.epochs):
