@@ -104,9 +104,12 @@ class AgentPPO:
         on = self.cfg.amp_bf16 and self.device.type == "cuda"
         return torch.autocast(device_type=self.device.type, dtype=torch.bfloat16, enabled=on)
 
+    def _f32(self, x):
+        return x.float() if x.dtype == torch.bfloat16 else x
+
     def ppo_loss(self, states, actions, advantages, fixed_log_probs):
         with self._autocast():
-            log_probs = self.policy_net.get_log_prob(states, actions).float()
+            log_probs = self._f32(self.policy_net.get_log_prob(states, actions))
         ratio = torch.exp(log_probs - fixed_log_probs)
         clipped = ratio.clamp(1.0 - self.cfg.clip_epsilon, 1.0 + self.cfg.clip_epsilon)
         return -torch.minimum(ratio * advantages, clipped * advantages).mean()
@@ -114,7 +117,7 @@ class AgentPPO:
     def update_value(self, critic_states, returns):
         for _ in range(self.cfg.value_opt_niter):
             with self._autocast():
-                pred = self.value_net(critic_states).float()
+                pred = self._f32(self.value_net(critic_states))
             loss = (pred - returns).pow(2).mean()
             self.optimizer_value.zero_grad(set_to_none=True)
             loss.backward()
@@ -135,7 +138,7 @@ class AgentPPO:
         actions = batch["actions"].reshape(T * N, -1)
         ind = batch["exps"].reshape(-1).nonzero(as_tuple=False).squeeze(1)
         with torch.no_grad(), self._autocast():
-            fixed_log_probs = self.policy_net.get_log_prob(states, actions).float()
+            fixed_log_probs = self._f32(self.policy_net.get_log_prob(states, actions))
         self.policy_net.train(); self.value_net.train()        # RunningNorm statistics follow the training passes
         s_i, a_i, adv_i, flp_i = states[ind], actions[ind], adv[ind], fixed_log_probs[ind]
         info = {}

@@ -58,7 +58,8 @@ def test_ppo_surrogate_and_action_rescale_match_reference():
     from smplsim_amd.agents.ppo import AgentPPO, PPOConfig
     g = golden()
     pol = _load(PolicyGaussian(11, 5, (16, 12), "silu", log_std=-1.0, fix_std=False).double(), g, "polsd_").eval()
-    fake = type("A", (), {"policy_net": pol, "cfg": PPOConfig()})()
+    fake = AgentPPO.__new__(AgentPPO)                         # no env needed for the loss itself
+    fake.policy_net, fake.cfg, fake.device = pol, PPOConfig(), torch.device("cpu")
     x, a = torch.tensor(g["pol_x"]), torch.tensor(g["pol_a"])
     with torch.no_grad():
         loss = AgentPPO.ppo_loss(fake, x, a, torch.tensor(g["ppo_adv"]), torch.tensor(g["ppo_fixed"]))
