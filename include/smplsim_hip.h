@@ -131,6 +131,14 @@ int ss_step(ss_batch *b, const float *actions, const float *task_rand, float *ob
  * `solver_iters` (descending) starts the expensive ones first (longest-processing-time-first). */
 int ss_set_order(ss_batch *b, const int32_t *order);
 
+/* ss_step followed, in the same launch, by the reset of every env whose episode just ended (terminated | truncated) —
+ * GymVectEnv's autoreset (reference nv/gymwrapper.py:53-60) without a second launch.  StateInit.Default only (a Fall
+ * reset is 45 mj_steps of work: use ss_step + masked ss_reset).  obs = observation of the step for every env (the
+ * "final_observation" of the envs that ended); obs_next = the observation the policy acts on next: the reset one for
+ * envs that ended, the same as obs otherwise.  reset_task_rand [N,4] feeds reset_task of the envs that ended. */
+int ss_step_autoreset(ss_batch *b, const float *actions, const float *task_rand, const float *reset_task_rand, float *obs,
+                      float *obs_next, float *reward, uint8_t *terminated, uint8_t *truncated, void *stream);
+
 /* n x (controller + mj_step) without the env epilogue — substep-granular parity/debugging */
 int ss_substep(ss_batch *b, const float *actions, int n_substeps, void *stream);
 

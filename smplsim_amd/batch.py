@@ -63,7 +63,7 @@ class SMPLSimVecEnv:
     def __init__(self, num_envs, model=None, device=0, task="HumanoidEnv", state_init="Default", self_obs_v=1,
                  control_mode="uhc_pd", episode_length=300, control_freq_inv=15, root_height_obs=True,
                  power_scale=1.0, tar_speed=(0.0, 5.0), speed_change=(100, 200), tar_height=(0.5, 1.2),
-                 height_change=(100, 200), recovery_steps=60, tar_dist_max=1.0, reach_body="R_Hand", newton_iters=8,
+                 height_change=(100, 200), recovery_steps=60, tar_dist_max=1.0, reach_body="R_Hand", newton_iters=8, fused_autoreset=True,
                  autoreset=True, seed=0, lpt_order=True,
                  **model_kw):
         if not torch.cuda.is_available():
@@ -108,6 +108,8 @@ class SMPLSimVecEnv:
         self.terminated = torch.zeros(N, dtype=torch.uint8, device=dev)
         self.truncated = torch.zeros(N, dtype=torch.uint8, device=dev)
         self.reset_buf = torch.zeros(N, dtype=torch.uint8, device=dev)
+        self.obs_final = torch.zeros(N, self.obs_size, **f32)
+        self._fused_autoreset = self.state_init == _cabi.INIT_DEFAULT and fused_autoreset
         self.autoreset = autoreset
         self.gen = torch.Generator(device=dev)
         self.gen.manual_seed(int(seed))
@@ -162,16 +164,30 @@ class SMPLSimVecEnv:
             _check(lib().ss_set_order(self.handle, _ptr(self.order)))
         if _events:
             _events[0].record()
+        info = {}
+        if self.autoreset and self._fused_autoreset:
+            # one launch: step + Default reset of the envs whose episode ended (GymVectEnv semantics, reference
+            # nv/gymwrapper.py:53-60): obs_final = the step's observation, obs_buf = what the policy acts on next
+            tr2 = self._task_rand()
+            self._keep2 = (tr2,)
+            _check(lib().ss_step_autoreset(self.handle, _ptr(actions), _ptr(tr), _ptr(tr2), _ptr(self.obs_final), _ptr(self.obs_buf),
+                                           _ptr(self.rew_buf), _ptr(self.terminated), _ptr(self.truncated), self._stream()))
+            if _events:
+                _events[1].record()
+            if self.lpt_order:
+                _check(lib().ss_set_order(self.handle, None))
+            info["final_observation"] = self.obs_final
+            info["critic_state"] = self.obs_buf
+            return self.obs_buf, self.rew_buf, self.terminated.bool(), self.truncated.bool(), info
         _check(lib().ss_step(self.handle, _ptr(actions), _ptr(tr), _ptr(self.obs_buf), _ptr(self.rew_buf),
                              _ptr(self.terminated), _ptr(self.truncated), self._stream()))
         if _events:
             _events[1].record()
         if self.lpt_order:
             _check(lib().ss_set_order(self.handle, None))      # resets / diagnostics use the natural order
-        info = {}
         if self.autoreset:
-            # autoreset of finished envs: device-side mask, no host sync (GymVectEnv semantics,
-            # reference nv/gymwrapper.py:53-60; the pre-reset observation is kept for the learner)
+            # autoreset of finished envs: device-side mask, no host sync (the Fall reset is 45 mj_steps of work per env,
+            # so it gets its own, load-balanced launch); the pre-reset observation is kept for the learner
             torch.bitwise_or(self.terminated, self.truncated, out=self.reset_buf)
             info["final_observation"] = self.obs_buf.clone()
             fa, tr2 = self._fall_actions(), self._task_rand()

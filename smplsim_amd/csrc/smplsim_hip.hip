@@ -51,6 +51,7 @@ struct WaveGpu {
   __device__ __forceinline__ float quad_xor2(float v) const { return dpp_f<0x4E>(v); }
   __device__ __forceinline__ int quad_xor1_i(int v) const { return dpp_i<0xB1>(v); }
   __device__ __forceinline__ int quad_xor2_i(int v) const { return dpp_i<0x4E>(v); }
+  __device__ __forceinline__ void mem_fence() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); }
   __device__ __forceinline__ unsigned long long clock() const { return __builtin_readcyclecounter(); }
   __device__ __forceinline__ void atomic_add_u64(unsigned long long *p, unsigned long long v) const { atomicAdd(p, v); }
   __device__ __forceinline__ int opaque(int x) const { return __builtin_amdgcn_readfirstlane(x); }   // wave-uniform, optimizer-opaque
@@ -94,8 +95,13 @@ __global__ void __launch_bounds__(MAXT) ss_env_kernel(const ss::KArgs k) {
     first = false;
     if (env >= k.st.num_envs) break;
     if (k.order) env = __builtin_amdgcn_readfirstlane(k.order[env]);   // longest-processing-time-first hand-out
-    ss::run_env<WaveGpu, DOFP, CANDP, SLOTP, NPASS>(&w, &k, lds, L, env);
-    w.sync();
+    int mode = k.mode;
+    for (int rep = 0; rep < 2; rep++) {                       // second trip = fused Default reset of an env whose episode ended
+      const bool again = ss::run_env<WaveGpu, DOFP, CANDP, SLOTP, NPASS>(&w, &k, lds, L, env, mode);
+      w.sync();
+      if (!again) break;
+      mode = ss::MODE_RESET;
+    }
   }
 }
 

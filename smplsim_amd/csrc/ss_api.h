@@ -131,6 +131,16 @@ struct ss_api {
     k.actions = actions; k.task_rand = task_rand; k.obs = obs; k.reward = reward; k.terminated = term; k.truncated = trunc;
     return run(b, k, stream);
   }
+  static int step_autoreset(ss_batch *b, const float *actions, const float *task_rand, const float *reset_task_rand, float *obs,
+                            float *obs_next, float *reward, uint8_t *term, uint8_t *trunc, void *stream) {
+    if (!b || !actions || !obs || !obs_next || !reward || !term || !trunc) return fail(SS_ERR_INVALID, "null argument");
+    if (b->cfg.state_init != SS_INIT_DEFAULT)
+      return fail(SS_ERR_INVALID, "in-launch autoreset is for StateInit.Default; use ss_step + a masked ss_reset for Fall");
+    ss::KArgs k = base_args(b, ss::MODE_STEP);
+    k.actions = actions; k.task_rand = task_rand; k.obs = obs; k.reward = reward; k.terminated = term; k.truncated = trunc;
+    k.fused_reset = 1; k.obs2 = obs_next; k.task_rand2 = reset_task_rand;
+    return run(b, k, stream);
+  }
   static int substep(ss_batch *b, const float *actions, int n, void *stream) {
     if (!b || !actions || n < 1) return fail(SS_ERR_INVALID, "bad argument");
     ss::KArgs k = base_args(b, ss::MODE_SUBSTEP);
@@ -184,6 +194,8 @@ struct ss_api {
   }                                                                   \
   int ss_reset(ss_batch *b, const uint8_t *mask, const float *fa, const float *tr, float *obs, void *st) { return ss_api<BE>::reset(b, mask, fa, tr, obs, st); } \
   int ss_step(ss_batch *b, const float *a, const float *tr, float *obs, float *rew, uint8_t *te, uint8_t *tu, void *st) { return ss_api<BE>::step(b, a, tr, obs, rew, te, tu, st); } \
+  int ss_step_autoreset(ss_batch *b, const float *a, const float *tr, const float *tr2, float *obs, float *obs_next, float *rew, \
+                        uint8_t *te, uint8_t *tu, void *st) { return ss_api<BE>::step_autoreset(b, a, tr, tr2, obs, obs_next, rew, te, tu, st); } \
   int ss_substep(ss_batch *b, const float *a, int n, void *st) { return ss_api<BE>::substep(b, a, n, st); }          \
   int ss_kinematics(ss_batch *b, float *xpos, float *xmat, void *st) { return ss_api<BE>::kinematics(b, xpos, xmat, st); } \
   int ss_debug_forward(ss_batch *b, const float *tq, float *M, float *bias, float *qacc, void *st) { return ss_api<BE>::debug_forward(b, tq, M, bias, qacc, st); } \

@@ -57,6 +57,11 @@ struct KArgs {
   const int32_t *order;       // optional [N] processing order of the envs (heavy first), or null
   int32_t *work_counter;      // device word, zeroed before each launch: persistent waves pull env ids from it
   float *obs, *reward;
+  // fused autoreset (ss_step_autoreset): envs whose step ends an episode run the Default reset in the same launch;
+  // obs2 receives the observation AFTER the (possible) reset for every env, task_rand2 feeds the reset's reset_task
+  int fused_reset;
+  float *obs2;
+  const float *task_rand2;
   uint8_t *terminated, *truncated;
   float *out0, *out1, *out2;  // kinematics: xpos, xmat ; debug forward: M [N,nv,nv], bias [N,nv], qacc [N,nv]
 };

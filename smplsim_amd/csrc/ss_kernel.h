@@ -1138,24 +1138,30 @@ struct Sim {
 enum { K_PROLOGUE = 0, K_SUBSTEP = 1, K_RESETFWD = 2, K_FINAL = 3 };
 enum { SOLVE_NEWTON = 1, SOLVE_SPD = 2 };
 
+// `mode` is k->mode, or MODE_RESET for the second, fused pass of ss_step_autoreset (the caller loops: one call site).
+// Returns true when the env's step ended its episode and the fused Default reset has to run next.
 template <class W, int DOFP, int CANDP, int SLOTP, int NPASS>
-SS_DEV void run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env) {
+SS_DEV bool run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env, int mode) {
   const Hdr &h = k->h;
   const ss_env_cfg &cf = k->cfg;
   const ss_state &st = k->st;
-  if (k->mask && !k->mask[env]) return;
+  const bool fused_pass = mode != k->mode;                    // the in-launch reset of an env that just finished
+  if (!fused_pass && k->mask && !k->mask[env]) return false;
   Sim<W, DOFP, CANDP, SLOTP, NPASS> sim;
   sim.init(w, k, T, L, env);
   int lane = sim.lane;
-  const int mode = k->mode;
   float *qg = st.qpos + (size_t)env * h.nq, *vg = st.qvel + (size_t)env * h.nv;
   float *qpg = st.qpos_prev + (size_t)env * h.nq, *vpg = st.qvel_prev + (size_t)env * h.nv;
   float *wg = st.qacc_warm + (size_t)env * h.nv;
   float *tk = st.task + (size_t)env * 4;
   const float *act = k->actions ? k->actions + (size_t)env * h.nu : nullptr;
-  const float *trand = k->task_rand ? k->task_rand + (size_t)env * 4 : nullptr;
-  const float *fa = k->fall_actions ? k->fall_actions + (size_t)env * 3 * h.nu : nullptr;
-  float *obs = k->obs ? k->obs + (size_t)env * k->obs_size : nullptr;
+  const float *trand_base = fused_pass ? k->task_rand2 : k->task_rand;
+  const float *trand = trand_base ? trand_base + (size_t)env * 4 : nullptr;
+  const float *fa = (k->fall_actions && !fused_pass) ? k->fall_actions + (size_t)env * 3 * h.nu : nullptr;
+  float *obs_base = fused_pass ? k->obs2 : k->obs;
+  float *obs = obs_base ? obs_base + (size_t)env * k->obs_size : nullptr;
+  // step pass of a fused launch: the post-step observation also goes to obs2 (envs that do not reset keep it)
+  float *obs_also = (!fused_pass && k->fused_reset && k->obs2) ? k->obs2 + (size_t)env * k->obs_size : nullptr;
   const int maxit = cf.newton_iters > 0 ? cf.newton_iters : 8;
 
   int cur_t = st.cur_t[env];
@@ -1284,27 +1290,32 @@ SS_DEV void run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env) 
       for (int c = 0; c < 3; c++) k->out0[((size_t)env * h.nb + lane) * 3 + c] = sim.r[3 * lane + c] + sim.q[c];
       for (int c = 0; c < 9; c++) k->out1[((size_t)env * h.nb + lane) * 9 + c] = sim.R[9 * lane + c];
     }
-    return;
+    return false;
   }
   const unsigned long long touch = sim.touchmask;
   if (lane == 0) {
     st.touch[2 * env] = (int)(touch & 0xFFFFFFFFull); st.touch[2 * env + 1] = (int)(touch >> 32);
-    st.solver_iters[env] = sim.iters;
+    if (!fused_pass) st.solver_iters[env] = sim.iters;      // the scheduling hint is the step's count, not the reset's
     if (cf.control_mode == SS_CTRL_SIMPLE_PID && st.pid_started) st.pid_started[env] = sim.pid_on;
     if (sim.nwarn_add) st.nwarn[env] += sim.nwarn_add;
   }
-  if (is_debug) { sim.store(k->out2 + (size_t)env * h.nv, sim.a, h.nv); return; }
+  if (is_debug) { sim.store(k->out2 + (size_t)env * h.nv, sim.a, h.nv); return false; }
   if (mode == MODE_RESET) { sim.store(qpg, sim.q, h.nq); sim.store(vpg, sim.v, h.nv); cur_t = 0; }
   sim.store(qg, sim.q, h.nq); sim.store(vg, sim.v, h.nv); sim.store(wg, sim.a, h.nv);
-  if (mode == MODE_SUBSTEP) return;
+  if (mode == MODE_SUBSTEP) return false;
 
   // ---- post_physics_step: cur_t, observation, reward, reset flags
   if (mode == MODE_STEP) cur_t += 1;
   if (obs) sim.write_obs(obs, tar, tar_y, tar_z);
-  if (lane == 0) {
+  if (obs && obs_also) {                                     // copy through the lanes that wrote it: fence, then read back
+    w->mem_fence();
+    for (int i = lane; i < k->obs_size; i += 64) obs_also[i] = obs[i];
+  }
+  int term = 0, trunc = 0;                                   // wave-uniform (all inputs are)
+  {
     if (mode == MODE_STEP) {
       float rew = 0.f;
-      int term = 0, trunc = cur_t > cf.episode_length;
+      trunc = cur_t > cf.episode_length;
       const int illegal = (touch & k->illegal_mask) != 0ull;
       if (cf.task == SS_TASK_SPEED) {
         float dtc = (float)cf.control_freq_inv * h.dt;
@@ -1323,14 +1334,21 @@ SS_DEV void run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env) 
         rew = expf(-4.f * (dx * dx + dy * dy + dz * dz));
         term = illegal;
       }
-      if (k->reward) k->reward[env] = rew;
-      if (k->terminated) k->terminated[env] = (uint8_t)term;
-      if (k->truncated) k->truncated[env] = (uint8_t)trunc;
+      if (lane == 0) {
+        if (k->reward) k->reward[env] = rew;
+        if (k->terminated) k->terminated[env] = (uint8_t)term;
+        if (k->truncated) k->truncated[env] = (uint8_t)trunc;
+      }
     }
+  }
+  if (lane == 0) {
     st.cur_t[env] = cur_t;
     if (is_reach) { tk[0] = tar; tk[1] = tar_y; tk[2] = tar_z; tk[3] = change; }
     else { tk[0] = tar; tk[1] = change; tk[2] = recov; }
   }
+  const bool again = !fused_pass && k->fused_reset && mode == MODE_STEP && (term || trunc);
+  if (again) w->mem_fence();                                 // the fused reset pass re-reads cur_t / task state from HBM
+  return again;
 }
 
 }  // namespace ss

@@ -113,3 +113,30 @@ def test_speed_task_termination_and_truncation_flags_match_oracle():
             first_term = i
         assert tu == (i + 1 > 40)
     assert first_term is not None and first_term > 5
+
+
+@pytest.mark.parametrize("task", [0, 1, 3])
+def test_fused_autoreset_equals_step_plus_masked_reset(task):
+    """ss_step_autoreset (one launch) against ss_step followed by a masked ss_reset: bit-identical state, observations and
+    flags, through speed-task terminations (falls) and a short episode_length that truncates."""
+    kw = dict(task=task, episode_length=5, tar_dist_max=1.0) if task else dict(task=task, episode_length=5)
+    a_env, b_env = _batch(3, **kw), _batch(3, **kw)
+    rs = np.random.default_rng(11 + task)
+    tr0 = rs.uniform(size=(3, 4))
+    a_env.reset(task_rand=tr0); b_env.reset(task_rand=tr0)
+    ended = 0
+    for t in range(14):
+        act = rs.uniform(-1, 1, (3, 69)) * (1.0 if t % 2 else 0.3)
+        tr, tr2 = rs.uniform(size=(3, 4)), rs.uniform(size=(3, 4))
+        obs_a, rew_a, te_a, tu_a = a_env.step(act, task_rand=tr)
+        done = te_a | tu_a
+        next_a = obs_a.copy()
+        if done.any():
+            next_a = a_env.reset(mask=done.astype(np.uint8), task_rand=tr2)
+        obs_b, next_b, rew_b, te_b, tu_b = b_env.step_autoreset(act, task_rand=tr, reset_task_rand=tr2)
+        ended += int(done.sum())
+        assert np.array_equal(te_a, te_b) and np.array_equal(tu_a, tu_b) and np.array_equal(rew_a, rew_b)
+        assert np.array_equal(obs_a, obs_b) and np.array_equal(next_a, next_b)
+        for f in ("qpos", "qvel", "qpos_prev", "qvel_prev", "qacc_warm", "cur_t", "task", "touch", "body_vel"):
+            assert np.array_equal(getattr(a_env, f), getattr(b_env, f)), (t, f)
+    assert ended >= 4

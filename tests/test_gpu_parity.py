@@ -285,6 +285,24 @@ def test_episode_truncation_and_autoreset(vec):
     assert "final_observation" in info and (info["final_observation"][:, 0] - 0.94).abs().max() > 1e-4
 
 
+def test_fused_autoreset_equals_two_launch_path(vec):
+    """ss_step_autoreset (default of SMPLSimVecEnv for StateInit.Default) against ss_step + masked ss_reset on the GPU."""
+    kw = dict(task="HumanoidSpeed", episode_length=6, seed=5)
+    a_env, b_env = vec(64, fused_autoreset=True, **kw), vec(64, fused_autoreset=False, **kw)
+    g = torch.Generator(device=a_env.device); g.manual_seed(2)
+    a_env.reset(); b_env.reset()
+    ended = 0
+    for t in range(20):
+        act = torch.rand(64, 69, generator=g, device=a_env.device) * 2 - 1
+        oa, ra, tea, tua, ia = a_env.step(act)
+        ob, rb, teb, tub, ib = b_env.step(act)
+        ended += int((tea | tua).sum())
+        assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(tea, teb) and torch.equal(tua, tub)
+        assert torch.equal(ia["final_observation"], ib["final_observation"])
+        assert torch.equal(a_env.qpos, b_env.qpos) and torch.equal(a_env.cur_t, b_env.cur_t) and torch.equal(a_env.task_state, b_env.task_state)
+    assert ended > 64
+
+
 def test_gym_style_single_env_matches_oracle():
     """The reference's single-env surface (HumanoidEnv(cfg).reset/step, numpy in/out)."""
     import smpl_sim.envs.tasks as tasks                       # the reference's import path

@@ -183,6 +183,7 @@ struct WaveEmu {
   bool any(int p) { return ballot(p) != 0ull; }
   int opaque(int x) { volatile int y = x; return y; }
   int opaque_v(int x) { volatile int y = x; return y; }
+  void mem_fence() { sync(); }                               // all lanes' stores done before anyone reads them back
   unsigned long long clock() { return 0; }
   void atomic_add_u64(unsigned long long *p, unsigned long long v) { *p += v; }
   void atomic_add(float *p, float v) { *p += v; }
@@ -194,7 +195,13 @@ template <int DOFP, int CANDP, int SLOTP, int NPASS>
 void lane_entry(int lane, void *arg) {
   LaunchCtx *c = (LaunchCtx *)arg;
   WaveEmu w{c->m, lane};
-  ss::run_env<WaveEmu, DOFP, CANDP, SLOTP, NPASS>(&w, c->k, c->T, c->L, c->env);
+  int mode = c->k->mode;
+  for (int rep = 0; rep < 2; rep++) {
+    const bool again = ss::run_env<WaveEmu, DOFP, CANDP, SLOTP, NPASS>(&w, c->k, c->T, c->L, c->env, mode);
+    w.sync();
+    if (!again) break;
+    mode = ss::MODE_RESET;
+  }
 }
 
 struct EmuBackend {

@@ -92,6 +92,14 @@ class EmuBatch:
                                 _p(self.truncated), None))
         return self.obs.copy(), self.reward.copy(), self.terminated.copy().astype(bool), self.truncated.copy().astype(bool)
 
+    def step_autoreset(self, actions, task_rand=None, reset_task_rand=None):
+        a = np.ascontiguousarray(actions, np.float32)
+        tr, tr2 = _rand4(task_rand, self.N), _rand4(reset_task_rand, self.N)
+        self.obs_next = np.zeros_like(self.obs)
+        self._chk(lib().ss_step_autoreset(self.batch, _p(a), _p(tr), _p(tr2), _p(self.obs), _p(self.obs_next), _p(self.reward),
+                                          _p(self.terminated), _p(self.truncated), None))
+        return self.obs.copy(), self.obs_next.copy(), self.reward.copy(), self.terminated.copy().astype(bool), self.truncated.copy().astype(bool)
+
     def substep(self, actions, n):
         a = np.ascontiguousarray(actions, np.float32)
         self._chk(lib().ss_substep(self.batch, _p(a), n, None))

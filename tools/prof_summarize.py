@@ -28,6 +28,9 @@ for f in glob.glob(os.path.join(prof, "trace", "**", "*kernel_trace.csv"), recur
         if len(r0) >= 3:
             dur = [(float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3 for r in r0]
             st, rs = dur[1::2], dur[2::2]
+            if rs and sum(rs) / len(rs) > 0.3 * sum(st) / len(st):   # fused autoreset: every launch after the first is a step
+                st, rs = dur[1:], []
+            summary["launches_alternate_step_reset"] = bool(rs)
             summary["step_launches"] = {"n": len(st), "avg_us": sum(st) / len(st), "min_us": min(st), "max_us": max(st)}
             if rs:
                 summary["autoreset_launches"] = {"n": len(rs), "avg_us": sum(rs) / len(rs)}
@@ -42,7 +45,8 @@ for d in sorted(glob.glob(os.path.join(prof, "pmc_*"))):
         agg = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
         rows = [r for r in csv.DictReader(open(f)) if "ss_env_kernel" in r["Kernel_Name"]]
         ids = sorted({int(r["Dispatch_Id"]) for r in rows})
-        kind = {d: ("initial_reset" if i == 0 else ("step" if i % 2 == 1 else "autoreset")) for i, d in enumerate(ids)}
+        alt = summary.get("launches_alternate_step_reset", True)
+        kind = {d: ("initial_reset" if i == 0 else ("step" if (i % 2 == 1 or not alt) else "autoreset")) for i, d in enumerate(ids)}
         for r in rows:
             a = agg[kind[int(r["Dispatch_Id"])] + " launches of " + r["Kernel_Name"][:40]][r["Counter_Name"]]
             a[0] += 1; a[1] += float(r["Counter_Value"])
