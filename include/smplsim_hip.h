@@ -130,6 +130,9 @@ int ss_step(ss_batch *b, const float *actions, const float *task_rand, float *ob
  * order).  The persistent wavefronts pull env ids in this order; passing the envs sorted by their previous step's
  * `solver_iters` (descending) starts the expensive ones first (longest-processing-time-first). */
 int ss_set_order(ss_batch *b, const int32_t *order);
+/* Same hint computed on the device: hand the envs out by decreasing ss_state.solver_iters of the last step (counting
+ * sort in one small launch on `stream`, library-owned buffer); stays in force until ss_set_order(b, NULL/other). */
+int ss_schedule_longest_first(ss_batch *b, void *stream);
 
 /* ss_step followed, in the same launch, by the reset of every env whose episode just ended (terminated | truncated) —
  * GymVectEnv's autoreset (reference nv/gymwrapper.py:53-60) without a second launch.  StateInit.Default only (a Fall

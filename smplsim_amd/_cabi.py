@@ -68,6 +68,7 @@ def bind(lib):
     lib.ss_kinematics.argtypes = [vp, vp, vp, vp]
     lib.ss_debug_forward.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.ss_step_autoreset.argtypes = [vp] * 10
+    lib.ss_schedule_longest_first.argtypes = [vp, vp]
     lib.ss_gae.argtypes = [vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_float, C.c_float, vp, vp, vp]
     lib.ss_debug_prof.argtypes = [vp, vp, C.c_int]
     lib.ss_set_order.argtypes = [vp, vp]
@@ -78,7 +79,7 @@ def bind(lib):
 
 EXPORTS = ["ss_model_create", "ss_model_destroy", "ss_model_dims", "ss_obs_size", "ss_batch_create",
            "ss_batch_destroy", "ss_reset", "ss_step", "ss_step_autoreset", "ss_substep", "ss_kinematics", "ss_debug_forward",
-           "ss_gae", "ss_debug_prof", "ss_set_order", "ss_launch_info", "ss_last_error"]
+           "ss_gae", "ss_debug_prof", "ss_set_order", "ss_schedule_longest_first", "ss_launch_info", "ss_last_error"]
 
 
 def make_model_desc(mc, kp, kd, torque_lim, act_scale, act_offset, legal_bodies=(), timestep=1.0 / 450):

@@ -159,9 +159,8 @@ class SMPLSimVecEnv:
         assert actions.shape == (self.num_envs, self.nu) and actions.device == self.device
         tr = task_rand if task_rand is not None else self._task_rand()
         self._keep = (actions, tr)
-        if self.lpt_order:
-            self.order = torch.argsort(self.solver_iters, descending=True).to(torch.int32)
-            _check(lib().ss_set_order(self.handle, _ptr(self.order)))
+        if self.lpt_order:                                     # longest-processing-time-first hand-out, computed on the device
+            _check(lib().ss_schedule_longest_first(self.handle, self._stream()))
         if _events:
             _events[0].record()
         info = {}

@@ -122,6 +122,18 @@ __global__ void ss_gae_kernel(const float *rew, const float *nd, const float *nd
   }
 }
 
+// hand-out order = envs by decreasing Newton-iteration count of the last step: one-workgroup counting sort
+__global__ void __launch_bounds__(1024) ss_order_kernel(const int32_t *iters, int32_t *order, int n) {
+  __shared__ int hist[256], offs[256];
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) { int key = iters[i]; key = key < 0 ? 0 : (key > 255 ? 255 : key); atomicAdd(&hist[255 - key], 1); }
+  __syncthreads();
+  if (threadIdx.x == 0) { int acc = 0; for (int i = 0; i < 256; i++) { offs[i] = acc; acc += hist[i]; } }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) { int key = iters[i]; key = key < 0 ? 0 : (key > 255 ? 255 : key); order[atomicAdd(&offs[255 - key], 1)] = i; }
+}
+
 typedef void (*kern_t)(const ss::KArgs);
 kern_t pick_kernel(int variant) {
   if (variant == 0) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS>;      // SMPL layout (24 bodies)
@@ -138,6 +150,11 @@ struct HipBackend {
   static int lds_capacity() { return 160 * 1024; }
   static int num_cus() { int d = 0, n = 256; if (hipGetDevice(&d) == hipSuccess) { hipDeviceProp_t p; if (hipGetDeviceProperties(&p, d) == hipSuccess) n = p.multiProcessorCount; } return n; }
   static int max_waves(int variant) { return (variant == 0 ? SS_MAX_THREADS : SS_MAX_THREADS_X) / 64; }
+  static const char *order_by_iters(const int32_t *iters, int32_t *order, int n, void *stream) {
+    hipLaunchKernelGGL(ss_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, iters, order, n);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? nullptr : hipGetErrorString(e);
+  }
   static const char *gae(const float *rew, const float *nd, const float *ndead, const float *val, const float *boot, int T, int N,
                          float gamma, float tau, float *adv, float *ret, void *stream) {
     hipLaunchKernelGGL(ss_gae_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, rew, nd, ndead, val, boot, T, N, gamma, tau, adv, ret);

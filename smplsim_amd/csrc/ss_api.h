@@ -32,6 +32,7 @@ struct ss_batch {
   int32_t *d_counter = nullptr;
   unsigned long long *d_prof = nullptr;   // SS_PROFILE builds only
   const int32_t *order = nullptr;         // caller-owned device array or null
+  int32_t *d_sched = nullptr;             // library-owned [N] hand-out order written by ss_schedule_longest_first
 };
 
 template <class BE>
@@ -176,10 +177,18 @@ struct ss_api {
   }                                                                                                                  \
   int ss_obs_size(const ss_model *m, const ss_env_cfg *c) { return (m && c) ? ss::obs_size(m->hm.h, *c) : SS_ERR_INVALID; } \
   int ss_batch_create(const ss_model *m, const ss_env_cfg *c, const ss_state *s, ss_batch **o) { return ss_api<BE>::batch_create(m, c, s, o); } \
-  void ss_batch_destroy(ss_batch *b) { if (b) { BE::free_(b->d_counter); BE::free_(b->d_prof); delete b; } }          \
+  void ss_batch_destroy(ss_batch *b) { if (b) { BE::free_(b->d_counter); BE::free_(b->d_prof); BE::free_(b->d_sched); delete b; } }          \
   int ss_set_order(ss_batch *b, const int32_t *order) {                                                              \
     if (!b) return ss_api<BE>::fail(SS_ERR_INVALID, "null batch");                                                  \
     b->order = order; return SS_OK;                                                                                  \
+  }                                                                                                                  \
+  int ss_schedule_longest_first(ss_batch *b, void *stream) {                                                        \
+    if (!b) return ss_api<BE>::fail(SS_ERR_INVALID, "null batch");                                                  \
+    if (!b->d_sched) b->d_sched = (int32_t *)BE::alloc(sizeof(int32_t) * (size_t)b->st.num_envs);                      \
+    if (!b->d_sched) return ss_api<BE>::fail(SS_ERR_NOMEM, "device allocation failed");                              \
+    const char *err = BE::order_by_iters(b->st.solver_iters, b->d_sched, b->st.num_envs, stream);                     \
+    if (err) return ss_api<BE>::fail(SS_ERR_HIP, err);                                                               \
+    b->order = b->d_sched; return SS_OK;                                                                             \
   }                                                                                                                  \
   int ss_gae(const float *rew, const float *nd, const float *ndead, const float *val, const float *boot, int32_t T,   \
              int32_t N, float gamma, float tau, float *adv, float *ret, void *stream) {                             \

@@ -140,3 +140,15 @@ def test_fused_autoreset_equals_step_plus_masked_reset(task):
         for f in ("qpos", "qvel", "qpos_prev", "qvel_prev", "qacc_warm", "cur_t", "task", "touch", "body_vel"):
             assert np.array_equal(getattr(a_env, f), getattr(b_env, f)), (t, f)
     assert ended >= 4
+
+
+def test_device_side_longest_first_schedule_is_a_sorted_permutation_and_changes_nothing():
+    eb, ref = _batch(5), _batch(5)
+    rs = np.random.default_rng(21)
+    eb.reset(); ref.reset()
+    for t in range(3):
+        act = rs.uniform(-1, 1, (5, 69))
+        eb._chk(emu.lib().ss_schedule_longest_first(eb.batch, None))
+        eb.step(act); ref.step(act)
+        assert np.array_equal(eb.qpos, ref.qpos) and np.array_equal(eb.obs, ref.obs)      # the hand-out order is only a hint
+    assert emu.lib().ss_schedule_longest_first(None, None) != 0

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 #include "../../smplsim_amd/csrc/ss_api.h"
@@ -213,6 +214,13 @@ struct EmuBackend {
   static int lds_capacity() { return 160 * 1024; }
   static int kernel_regs() { return 0; }
   static int max_waves(int) { return 16; }
+  static const char *order_by_iters(const int32_t *iters, int32_t *order, int n, void *) {
+    std::vector<int> idx(n);
+    for (int i = 0; i < n; i++) idx[i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return iters[a] > iters[b]; });
+    for (int i = 0; i < n; i++) order[i] = idx[i];
+    return nullptr;
+  }
   static const char *gae(const float *rew, const float *nd, const float *ndead, const float *val, const float *boot, int T, int N,
                          float gamma, float tau, float *adv, float *ret, void *) {
     for (int n = 0; n < N; n++) {                            // same float32 recursion as the device kernel
