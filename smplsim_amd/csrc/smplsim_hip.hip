@@ -1,17 +1,17 @@
 // smplsim_hip.hip — gfx950 (MI355X) build of the wavefront env stepper + the C ABI (include/smplsim_hip.h).
 //
-// Launch geometry: one workgroup = E wavefronts = E environments (E <= 8, chosen so that the shared
-// index tables + E per-env LDS blocks fit the CU's 160 KiB LDS); no workgroup barrier after the
-// table copy — the wavefronts of a workgroup never talk to each other.  4096 envs = 512 workgroups
-// of 512 threads = two resident rounds over the chip's 256 CUs.
+// Launch geometry: one workgroup per CU = E persistent wavefronts, each stepping one environment at a time (E chosen
+// so that the shared index tables + E per-env LDS slices fit the CU's 160 KiB LDS: 12 for SMPL, 5 for SMPL-X); no
+// workgroup barrier after the table copy — the wavefronts of a workgroup never talk to each other.  4096 envs =
+// 3072 resident wave slots: the first env of a wave is static, the rest come from a device counter.
 #include <hip/hip_runtime.h>
 
 #include "ss_api.h"
 #include "ss_kernel.h"
 
 // launch bounds per kernel variant = the number of envs whose LDS slices fit one CU, rounded up to whole waves per
-// SIMD.  SMPL: 10 envs -> 3 waves/SIMD -> 168-VGPR cap (7% faster than 8 envs at 256 VGPRs, at 3x the spill traffic:
-// profiles/r01i_ab_launch_bounds.txt).  SMPL-X: 3 envs fit -> 1 wave/SIMD, the whole 512-VGPR file, no spills.
+// SIMD.  SMPL: 12 envs -> 3 waves/SIMD -> 168-VGPR cap (~12 spilled dwords).  SMPL-X: 5 envs -> 2 waves/SIMD, 256 VGPRs,
+// no spills.  (History of the trade-off: profiles/r01i_ab_launch_bounds.txt.)
 #ifndef SS_MAX_THREADS
 #define SS_MAX_THREADS 768
 #endif
