@@ -151,20 +151,39 @@ struct Sim {
   // ------------------------------------------------------------------ tree helpers
   // out[b][c] = sum of in[d][c] over the subtree of b = the contiguous index range [b, b + size_b) (depth-first
   // body order): one phase of independent LDS reads instead of a level-by-level sweep.
-  // Bodies are handed to the lanes in order of decreasing subtree size (o_sumorder) so that the long ranges share
-  // a pass, and every trip of the range loop issues 4 independent reads (a lane-serial read-add chain costs a full
-  // LDS round trip per element: this was 9 % of the step, profiles/r01r_*).
+  // Two phases: (1) every body whose subtree has <= 8 bodies sums its range with one trip of 8 independent reads;
+  // (2) the few large subtrees add their "cover" — their own input, the finished sums of their small children and the
+  // cover of their large children (tables in ss_tables.h).  A lane-serial read-add chain over a 24-body range costs a
+  // full LDS round trip per element and sat on every Newton iteration's critical path (profiles/r01r_*).
+  // Must be called between hand-offs; it contains one.
   template <int NC>
   SS_DEV void subtree_sum(const float *in, float *out) {
     const Hdr &h = k->h;
-    for (int idx = lane; idx < NC * h.nb; idx += 64) {
-      const int o = idx / NC, c = idx - o * NC, e = ti(h.o_sumorder, o), b = e & 255, n = e >> 8;
+    for (int idx = lane; idx < NC * h.n_sumsmall; idx += 64) {
+      const int o = idx / NC, c = idx - o * NC, e = ti(h.o_sumsmall, o), b = e & 255, n = e >> 8;
       const float *p = in + b * NC + c;
+      float part[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) part[u] = p[(u < n ? u : 0) * NC];
+#pragma unroll
+      for (int u = 1; u < 8; u++) part[u] = u < n ? part[u] : 0.f;
+      out[b * NC + c] = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+    }
+    if (h.n_sumbig == 0) return;
+    w->sync();
+    for (int idx = lane; idx < NC * h.n_sumbig; idx += 64) {
+      const int o = idx / NC, c = idx - o * NC, e = ti(h.o_sumbig, o), b = e & 255, start = (e >> 8) & 4095, cnt = e >> 20;
       float acc = 0.f;
-      for (int j = 0; j < n; j += 4) {
-        const int j1 = j + 1 < n ? j + 1 : j, j2 = j + 2 < n ? j + 2 : j, j3 = j + 3 < n ? j + 3 : j;
-        const float a0 = p[j * NC], a1 = p[j1 * NC], a2 = p[j2 * NC], a3 = p[j3 * NC];
-        acc += (a0 + (j + 1 < n ? a1 : 0.f)) + ((j + 2 < n ? a2 : 0.f) + (j + 3 < n ? a3 : 0.f));
+      for (int j = 0; j < cnt; j += 4) {
+        float part[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int t = ti(h.o_sumcover, start + (j + u < cnt ? j + u : j));
+          part[u] = (t < 64 ? in : out)[(t & 63) * NC + c];
+        }
+#pragma unroll
+        for (int u = 1; u < 4; u++) part[u] = j + u < cnt ? part[u] : 0.f;
+        acc += (part[0] + part[1]) + (part[2] + part[3]);
       }
       out[b * NC + c] = acc;
     }

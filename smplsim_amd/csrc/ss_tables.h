@@ -211,12 +211,34 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
         if (a != b) { out.error = "bodies must be in depth-first order"; return false; }
       }
     }
-    // (body | subtree size << 8), largest subtrees first
+    // subtree sums in two phases (ss_kernel.h subtree_sum): bodies whose subtree has <= 8 bodies sum their index range
+    // directly (one trip of 8 reads); the few large ones add their own value, the finished sums of their small children
+    // and, recursively, the terms of their large children ("cover": index t < 64 = input of body t, t >= 64 = phase-1
+    // output of body t - 64).
+    const int kSmall = 8;
+    std::vector<int> small_l, big_l, cover;
     std::vector<int> order(nb);
     for (int b = 0; b < nb; b++) order[b] = b;
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return subsize[x] > subsize[y]; });
-    for (int b = 0; b < nb; b++) order[b] = order[b] | (subsize[order[b]] << 8);
-    h.o_sumorder = push_i(order);
+    for (int b : order) if (subsize[b] <= kSmall) small_l.push_back(b | (subsize[b] << 8));
+    std::vector<std::vector<int>> cov(nb);
+    for (int b = nb - 1; b >= 0; b--) {                        // children before parents (depth-first order)
+      if (subsize[b] <= kSmall) continue;
+      cov[b].push_back(b);
+      for (int c = b + 1; c < nb; c++) {
+        if (d.body_parent[c] != b) continue;
+        if (subsize[c] <= kSmall) cov[b].push_back(64 + c);
+        else cov[b].insert(cov[b].end(), cov[c].begin(), cov[c].end());
+      }
+    }
+    for (int b : order) {
+      if (subsize[b] <= kSmall) continue;
+      if (cov[b].size() > 255 || cover.size() > 4095) { out.error = "subtree cover table overflow"; return false; }
+      big_l.push_back(b | ((int)cover.size() << 8) | ((int)cov[b].size() << 20));
+      cover.insert(cover.end(), cov[b].begin(), cov[b].end());
+    }
+    h.n_sumsmall = (int)small_l.size(); h.n_sumbig = (int)big_l.size();
+    h.o_sumsmall = push_i(small_l); h.o_sumbig = push_i(big_l); h.o_sumcover = push_i(cover);
   }
   h.shared_words = (int)S.size();
   (void)blevstart; (void)blevbodies;
