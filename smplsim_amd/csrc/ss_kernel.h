@@ -598,7 +598,7 @@ struct Sim {
     SS_FT0();
     const unsigned long long nk0 = h.nkpack[0], nk1 = h.nkpack[1];
     int s0 = h.nn;
-    for (int L = h.nlev - 1; L >= 0; --L) {
+    for (int L = h.nlev - 1; L >= 2; --L) {                    // the two root nodes are solved together below
       const int nk = (int)(((L < 16 ? nk0 : nk1) >> (4 * (L & 15))) & 15ull) + 1;
       s0 -= nk;
       float *cur = IA + (L & 1) * h.ia_stride;
@@ -682,8 +682,70 @@ struct Sim {
       SS_FTICK(PF_F_P2);
       w->sync();
     }
+    // ---- root: body 0 and its free joint (nodes 0 and 1) as ONE 6-dof joint.  S_root = blockdiag(R, 1) is orthogonal
+    // and the free joint has neither armature nor limits nor gains, so  S^T (IA a + pA) = b  is the 6x6 system
+    // IA a = S b - pA  in world coordinates: no transform of the matrix, no hand-up, two tree levels less per sweep.
+    {
+      float *rows = IA + h.ia_stride;                          // the level buffer that level 2 did not use
+      const float *prev = IA;                                  // rows handed up by level 2
+      if (lane < 6) {
+        const int e = ti(h.o_lev, 1), cfirst = (e >> 16) & 255, cc = (e >> 24) & 255;
+        float rw[6], pv = 0.f;
+#pragma unroll
+        for (int c = 0; c < 6; c++) rw[c] = Aown[off[c]];
+        for (int j = 0; j < cc; j++) {
+          const float *src = prev + ((cfirst + j) * 6 + lane) * 8;
+          const float4_t v0 = ld4(src), v1 = ld4(src + 4);
+          rw[0] += v0.x; rw[1] += v0.y; rw[2] += v0.z; rw[3] += v0.w; rw[4] += v1.x; rw[5] += v1.y; pv += v1.z;
+        }
+        // (S b)_r: angular part R b_rot (S of node 1 holds the columns of R), linear part b_trans
+        const float sb = lane < 3 ? S[18 + lane] * x[3] + S[24 + lane] * x[4] + S[30 + lane] * x[5] : x[lane - 3];
+        st4w(rows + 8 * lane, rw[0], rw[1], rw[2], rw[3]); st4w(rows + 8 * lane + 4, rw[4], rw[5], sb - pv, 0.f);
+      }
+      w->sync();
+      float A6[6][6], f6[6];                                   // every lane solves the same 6x6 system (L D L^T)
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        const float4_t v0 = ld4(rows + 8 * i), v1 = ld4(rows + 8 * i + 4);
+        A6[i][0] = v0.x; A6[i][1] = v0.y; A6[i][2] = v0.z; A6[i][3] = v0.w; A6[i][4] = v1.x; A6[i][5] = v1.y; f6[i] = v1.z;
+      }
+      float Dv[6];
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+        float dj = A6[j][j];
+#pragma unroll
+        for (int kq = 0; kq < j; kq++) dj -= A6[j][kq] * A6[j][kq] * Dv[kq];
+        Dv[j] = dj;
+        const float inv = rcp_nr(dj);
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+          float l = A6[i][j];
+#pragma unroll
+          for (int kq = 0; kq < j; kq++) l -= A6[i][kq] * A6[j][kq] * Dv[kq];
+          A6[i][j] = l * inv;                                 // strict lower triangle becomes L
+        }
+      }
+#pragma unroll
+      for (int i = 1; i < 6; i++) {
+#pragma unroll
+        for (int kq = 0; kq < i; kq++) f6[i] -= A6[i][kq] * f6[kq];
+      }
+#pragma unroll
+      for (int i = 0; i < 6; i++) f6[i] *= rcp_nr(Dv[i]);
+#pragma unroll
+      for (int i = 4; i >= 0; i--) {
+#pragma unroll
+        for (int kq = i + 1; kq < 6; kq++) f6[i] -= A6[kq][i] * f6[kq];
+      }
+      // f6 = spatial acceleration of body 0; joint solution: x_trans = a_lin, x_rot = R^T a_ang
+      if (lane < 6) An[8 + lane] = lane == 0 ? f6[0] : lane == 1 ? f6[1] : lane == 2 ? f6[2] : lane == 3 ? f6[3] : lane == 4 ? f6[4] : f6[5];
+      if (lane < 3) x[lane] = lane == 0 ? f6[3] : (lane == 1 ? f6[4] : f6[5]);
+      else if (lane < 6) { const int j = lane - 3; x[lane] = S[18 + 6 * j] * f6[0] + S[18 + 6 * j + 1] * f6[1] + S[18 + 6 * j + 2] * f6[2]; }
+      w->sync();
+      s0 = 2;
+    }
     SS_FTICK(PF_F_SYNC1);
-    for (int L = 0; L < h.nlev; L++) {                        // ---- downward sweep (s0 is 0 again after the upward one)
+    for (int L = 2; L < h.nlev; L++) {                        // ---- downward sweep below the root
       const int nk = (int)(((L < 16 ? nk0 : nk1) >> (4 * (L & 15))) & 15ull) + 1;
 #pragma unroll
       for (int ps = 0; ps < NPASS; ps++) {

@@ -84,6 +84,8 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   }
   blevstart[nblev] = (int)blevbodies.size();
 
+  for (int i = 0; i < 6; i++)                              // the root solve treats the free joint as a plain 6x6 system
+    if (d.dof_armature[i] != 0.0) { out.error = "armature on the free joint is not supported"; return false; }
   // ---- dof constants: arm, lo, hi, limited, invw, kp, kd, tlim, ascale, aoffset, actuated, pad
   std::vector<float> dofc(nv * kDofC, 0.f);
   out.dof_act.assign(nv, -1);
