@@ -99,6 +99,7 @@ struct Sim {
   Limit lim[DOFP];
   float perr[DOFP];
   int iters, nwarn_add, pid_on;
+  int slot_body[SLOTP];    // body of this lane's contact slot(s): constant for the launch, read once from HBM
 #ifdef SS_PROFILE
   unsigned long long prof[PF_COUNT];
 #endif
@@ -125,6 +126,11 @@ struct Sim {
 #pragma unroll
     for (int p = 0; p < DOFP; p++) lim[p].sign = 0.f;
     iters = 0; nwarn_add = 0; touchmask = 0ull;
+#pragma unroll
+    for (int p = 0; p < SLOTP; p++) {
+      const int sl = p * 64 + lane;
+      slot_body[p] = sl < h.nslot ? (sl < 4 * h.nbox ? h_box_body(sl) : h_caps_body(sl)) : 0;
+    }
     pid_on = (k->cfg.control_mode == SS_CTRL_SIMPLE_PID && k->st.pid_started) ? k->st.pid_started[env] : 0;
 #ifdef SS_PROFILE
     for (int i = 0; i < PF_COUNT; i++) prof[i] = 0ull;
@@ -851,18 +857,11 @@ struct Sim {
     const float mu = h.mu;
     iters++;
     SS_FT0();
-    if (lane < h.nb) {
-      float Ia[6];
-      imul(Iown + 10 * lane, Ab + 6 * lane, Ia);
-#pragma unroll
-      for (int c = 0; c < 6; c++) Ad[6 * lane + c] = Ia[c];    // per-body terms go to Ad, their subtree sums to Gb
-    }
-    write_own_inertia();
-    w->sync();
-    SS_FTICK(PF_P_BASE);
     // ---- contact forces and K_b = sum_rows D u u^T, u = (rho x w ; w).  The (<= 4) contacts of a box sit in
     // 4 adjacent lanes and the 2 ends of a capsule in 2 adjacent lanes (slot layout of make_constraints), so the
-    // per-body sums are quad shuffles; the group's first lane then owns the body's row (no atomics).
+    // per-body sums are quad shuffles; the group's first lane owns the body: it writes the body's inertial force
+    // I_b a_b plus the contact force into Ad and its generalized inertia I_b + K_b into Aown (every body has one
+    // such lane, so there is no separate "base" phase and no atomics).
 #pragma unroll
     for (int p = 0; p < SLOTP; p++) {
       const Contact &c = con[p];
@@ -908,16 +907,20 @@ struct Sim {
         float v2 = w->quad_xor2(v1);
         vals[t] = boxlane ? v1 + v2 : v1;
       }
-      const int grp_any = w->quad_xor1_i(c.active) | c.active;
-      const int grp_any2 = w->quad_xor2_i(grp_any) | grp_any;
-      const int body_of_group = boxlane ? h_box_body(sl) : h_caps_body(sl);
-      const bool leader = boxlane ? ((sl & 3) == 0 && grp_any2) : ((sl & 1) == 0 && grp_any);
-      if (leader && sl < h.nslot) {
-        float *g = Ad + 6 * body_of_group, *Kb = Aown + 21 * body_of_group;
+      const bool leader = (boxlane ? (sl & 3) == 0 : (sl & 1) == 0) && sl < h.nslot;
+      if (leader) {
+        const int b = slot_body[p];
+        const float *I = Iown + 10 * b;
+        float Ia[6];
+        imul(I, Ab + 6 * b, Ia);
+        float *g = Ad + 6 * b, *o = Aown + 21 * b;
 #pragma unroll
-        for (int t = 0; t < 6; t++) g[t] += vals[t];
-#pragma unroll
-        for (int t = 0; t < 21; t++) Kb[t] += vals[6 + t];
+        for (int t = 0; t < 6; t++) g[t] = Ia[t] + vals[t];
+        const float m = I[0], cx = I[1], cy = I[2], cz = I[3];
+        o[0] = I[4] + vals[6]; o[1] = I[5] + vals[7]; o[2] = I[6] + vals[8]; o[3] = vals[9]; o[4] = vals[10] - cz; o[5] = vals[11] + cy;
+        o[6] = I[7] + vals[12]; o[7] = I[8] + vals[13]; o[8] = vals[14] + cz; o[9] = vals[15]; o[10] = vals[16] - cx;
+        o[11] = I[9] + vals[17]; o[12] = vals[18] - cy; o[13] = vals[19] + cx; o[14] = vals[20];
+        o[15] = m + vals[21]; o[16] = vals[22]; o[17] = vals[23]; o[18] = m + vals[24]; o[19] = vals[25]; o[20] = m + vals[26];
       }
     }
     w->sync();
