@@ -19,8 +19,8 @@ struct Hdr {
   // shared-blob word offsets
   int o_dofc, o_chainnode, o_ndepth, o_lev, o_bparent, o_sumsmall, o_sumbig, o_sumcover, n_sumsmall, n_sumbig, shared_words;
   // per-env LDS float offsets.  Z = solver region: Aown | IA (2 level buffers) | Ubuf | Wst ; aliases: contact records
-  // at Z, R/r inside Wst, Gb and the body_accel scratch inside IA, Ad = Ubuf = An, V = grad+delta
-  int l_q, l_v, l_a, l_tau, l_C, l_grad, l_delta, l_diag, l_S, l_Ab, l_An, l_Aown, l_IA, l_Ubuf, l_Wst,
+  // at Z, R/r inside Wst, Gb and the body_accel scratch inside IA, Ad = Ubuf = An, V = Pb
+  int l_q, l_v, l_a, l_tau, l_C, l_Pb, l_delta, l_diag, l_S, l_Ab, l_An, l_Aown, l_IA, l_Ubuf, l_Wst,
       l_R, l_r, l_Gb, l_tmp, l_V, l_Iown, ia_stride, env_floats;
   float dt, grav, margin, mu, solimp[5], K, B;   // K, B of aref (from solref, dmax)
   float qpos0_root[3];

@@ -91,7 +91,7 @@ struct Sim {
   const uint32_t *T;      // shared tables in LDS
   int lane, env;
   // per-env LDS arrays
-  float *S, *R, *r, *V, *Ab, *An, *Ad, *Gb, *tmpb, *Aown, *IA, *Ubuf, *Wst, *q, *v, *a, *tau, *grad, *delta, *C, *diag, *Iown;
+  float *S, *R, *r, *V, *Ab, *An, *Ad, *Gb, *tmpb, *Aown, *IA, *Ubuf, *Wst, *q, *v, *a, *tau, *Pb, *delta, *C, *diag, *Iown;
   // per-lane constants
   int bpar, bdep;
   // per-lane state
@@ -117,7 +117,7 @@ struct Sim {
     const Hdr &h = k->h;
     S = L + h.l_S; R = L + h.l_R; r = L + h.l_r; V = L + h.l_V; Ab = L + h.l_Ab; An = L + h.l_An; Ad = An;
     Gb = L + h.l_Gb; tmpb = L + h.l_tmp; Aown = L + h.l_Aown; IA = L + h.l_IA; Ubuf = L + h.l_Ubuf; Wst = L + h.l_Wst;
-    q = L + h.l_q; v = L + h.l_v; a = L + h.l_a; tau = L + h.l_tau; grad = L + h.l_grad;
+    q = L + h.l_q; v = L + h.l_v; a = L + h.l_a; tau = L + h.l_tau; Pb = L + h.l_Pb;
     delta = L + h.l_delta; C = L + h.l_C; diag = L + h.l_diag; Iown = L + h.l_Iown;
     bpar = -1; bdep = -1;
     if (lane < h.nb) { bpar = ti(h.o_bparent, lane); bdep = ti(h.o_ndepth, lane + 1) - 1; }
@@ -594,7 +594,8 @@ struct Sim {
     }
   }
 
-  SS_DEV void aba_solve(float *x) {
+  // pb: optional per-body bias force (6 per body): the system solved is  H x = b - sum_b J_b^T pb_b
+  SS_DEV void aba_solve(float *x, const float *pb) {
     fresh();
     const Hdr &h = k->h;
     const int r_ = lane & 7, g = lane >> 3;
@@ -620,7 +621,7 @@ struct Sim {
         if (r_ < 6 && kk < nk) {
           const int e = ti(h.o_lev, s0 + kk), n = e & 255, cfirst = (e >> 16) & 255, cc = (e >> 24) & 255;
           nod[ps] = n;
-          float rw[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, pv = 0.f;
+          float rw[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, pv = (pb && n > 0) ? pb[6 * (n - 1) + r_] : 0.f;
           if (n > 0) {
             const float *ao = Aown + 21 * (n - 1);
 #pragma unroll
@@ -696,7 +697,7 @@ struct Sim {
       const float *prev = IA;                                  // rows handed up by level 2
       if (lane < 6) {
         const int e = ti(h.o_lev, 1), cfirst = (e >> 16) & 255, cc = (e >> 24) & 255;
-        float rw[6], pv = 0.f;
+        float rw[6], pv = pb ? pb[lane] : 0.f;
 #pragma unroll
         for (int c = 0; c < 6; c++) rw[c] = Aown[off[c]];
         for (int j = 0; j < cc; j++) {
@@ -850,7 +851,8 @@ struct Sim {
     eval_rows(Ab, 6, a, false);
   }
 
-  // gradient (-> grad, delta = -grad), diagonal terms and the per-body generalized inertias Aown = I_b + K_b
+  // right-hand side of the Newton system in two parts — joint space (-> delta) and per-body forces Pb —, diagonal terms
+  // and the per-body generalized inertias Aown = I_b + K_b
   SS_DEV void newton_prepare() {
     fresh();
     const Hdr &h = k->h;
@@ -913,7 +915,7 @@ struct Sim {
         const float *I = Iown + 10 * b;
         float Ia[6];
         imul(I, Ab + 6 * b, Ia);
-        float *g = Ad + 6 * b, *o = Aown + 21 * b;
+        float *g = Pb + 6 * b, *o = Aown + 21 * b;
 #pragma unroll
         for (int t = 0; t < 6; t++) g[t] = Ia[t] + vals[t];
         const float m = I[0], cx = I[1], cy = I[2], cz = I[3];
@@ -923,24 +925,18 @@ struct Sim {
         o[15] = m + vals[21]; o[16] = vals[22]; o[17] = vals[23]; o[18] = m + vals[24]; o[19] = vals[25]; o[20] = m + vals[26];
       }
     }
-    w->sync();
     SS_FTICK(PF_P_CONTACT);
-    subtree_sum<6>(Ad, Gb);
-    w->sync();
-    SS_FTICK(PF_P_SUMS);
-    // ---- gradient and diagonal terms
+    // ---- joint-space part of the gradient (the body part S^T sum_subtree Pb is folded into the sweeps as their bias
+    // force, so there is no subtree summation here) and the diagonal terms; delta <- right-hand side
 #pragma unroll
     for (int p = 0; p < DOFP; p++) {
       int i = p * 64 + lane;
       if (i < h.nv) {
-        int n = i / 3, b = n > 0 ? n - 1 : 0;
-        const float *si = S + 6 * i, *gb = Gb + 6 * b;
         float s_ = C[i] + dc(i, 0) * a[i] - tau[i];
-        s_ += si[0] * gb[0] + si[1] * gb[1] + si[2] * gb[2] + si[3] * gb[3] + si[4] * gb[4] + si[5] * gb[5];
         float dg = dc(i, 0);
         const Limit &l = lim[p];
         if (l.sign != 0.f && l.jar < 0.f) { s_ += l.sign * l.D * l.jar; dg += l.D; }
-        grad[i] = s_; diag[i] = dg; delta[i] = -s_;
+        diag[i] = dg; delta[i] = -s_;
       }
     }
     w->sync();
@@ -954,7 +950,20 @@ struct Sim {
     eval_rows(An + 8, 8, delta, true);                       // aba_solve left the body accelerations of delta in An
     float dg_ = 0.f, s_a = 0.f, s_b = 0.f;
 #pragma unroll
-    for (int p = 0; p < DOFP; p++) { int i = p * 64 + lane; if (i < h.nv) dg_ += delta[i] * grad[i]; }
+    for (int p = 0; p < DOFP; p++) {                          // delta . gradient, joint-space part (same terms as newton_prepare)
+      int i = p * 64 + lane;
+      if (i < h.nv) {
+        float s_ = C[i] + dc(i, 0) * a[i] - tau[i];
+        const Limit &l = lim[p];
+        if (l.sign != 0.f && l.jar < 0.f) s_ += l.sign * l.D * l.jar;
+        dg_ += delta[i] * s_;
+      }
+    }
+    if (lane < h.nb) {                                        // body part: (J_b delta) . Pb_b
+      const float *ab_ = An + 8 * (lane + 1), *pb_ = Pb + 6 * lane;
+#pragma unroll
+      for (int c = 0; c < 6; c++) dg_ += ab_[c] * pb_[c];
+    }
 #pragma unroll
     for (int p = 0; p < SLOTP; p++) {
       const Contact &c = con[p];
@@ -1349,7 +1358,7 @@ SS_DEV bool run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env, 
         sim.spd_prepare(next_action, abias);
         SS_TICK(PF_SPDPREP);
       }
-      sim.aba_solve(sim.delta);
+      sim.aba_solve(sim.delta, solve == SOLVE_NEWTON ? sim.Pb : nullptr);
       SS_TICK(PF_FACTOR);
       if (solve == SOLVE_SPD) { sim.spd_finish(); SS_TICK(PF_SPDFIN); break; }
       const bool conv = sim.newton_finish();

@@ -251,9 +251,9 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   int o = 0;
   auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
   h.l_q = take(nv + 1); h.l_v = take(nv); h.l_a = take(nv); h.l_tau = take(nv); h.l_C = take(nv);
-  h.l_grad = take(nv); h.l_delta = take(nv);
-  h.l_V = h.l_grad;                                        // V (body velocities): dead after make_constraints
-  if (6 * nb > h.l_delta + nv - h.l_grad) { out.error = "V alias does not fit"; return false; }
+  h.l_delta = take(nv);
+  h.l_Pb = take(6 * nb);                                   // per-body force I a - f of the Newton iterate (bias of the sweeps)
+  h.l_V = h.l_Pb;                                          // V (body velocities): dead after make_constraints
   h.l_diag = take(nv);
   h.l_S = take(6 * nv);
   h.l_Ab = take(6 * nb);
