@@ -716,34 +716,37 @@ struct Sim {
         const float4_t v0 = ld4(rows + 8 * i), v1 = ld4(rows + 8 * i + 4);
         A6[i][0] = v0.x; A6[i][1] = v0.y; A6[i][2] = v0.z; A6[i][3] = v0.w; A6[i][4] = v1.x; A6[i][5] = v1.y; f6[i] = v1.z;
       }
-      float Dv[6];
+      // 2x2 block elimination with closed-form 3x3 inverses (shallow dependency chains; an L D L^T over 6 pivots is
+      // a 60-deep chain for a lone wave):  A = [P Q; Q^T T],  a_ang = (P - Q T^-1 Q^T)^-1 (f_a - Q T^-1 f_l),
+      // a_lin = T^-1 (f_l - Q^T a_ang)
+      float Ti[6], Si[6];                                      // symmetric inverses: 00 01 02 11 12 22
+      sym3_inverse(A6[3][3], A6[4][3], A6[4][4], A6[5][3], A6[5][4], A6[5][5], Ti);
+      float QT[3][3];                                          // Q T^-1
 #pragma unroll
-      for (int j = 0; j < 6; j++) {
-        float dj = A6[j][j];
-#pragma unroll
-        for (int kq = 0; kq < j; kq++) dj -= A6[j][kq] * A6[j][kq] * Dv[kq];
-        Dv[j] = dj;
-        const float inv = rcp_nr(dj);
-#pragma unroll
-        for (int i = j + 1; i < 6; i++) {
-          float l = A6[i][j];
-#pragma unroll
-          for (int kq = 0; kq < j; kq++) l -= A6[i][kq] * A6[j][kq] * Dv[kq];
-          A6[i][j] = l * inv;                                 // strict lower triangle becomes L
-        }
+      for (int i = 0; i < 3; i++) {
+        const float q0 = A6[i][3], q1 = A6[i][4], q2 = A6[i][5];
+        QT[i][0] = q0 * Ti[0] + q1 * Ti[1] + q2 * Ti[2];
+        QT[i][1] = q0 * Ti[1] + q1 * Ti[3] + q2 * Ti[4];
+        QT[i][2] = q0 * Ti[2] + q1 * Ti[4] + q2 * Ti[5];
       }
+      float Sc[3][3], ga[3];                                   // Schur complement P - Q T^-1 Q^T and its right-hand side
 #pragma unroll
-      for (int i = 1; i < 6; i++) {
+      for (int i = 0; i < 3; i++) {
 #pragma unroll
-        for (int kq = 0; kq < i; kq++) f6[i] -= A6[i][kq] * f6[kq];
+        for (int j = 0; j <= i; j++) Sc[i][j] = A6[i][j] - (QT[i][0] * A6[j][3] + QT[i][1] * A6[j][4] + QT[i][2] * A6[j][5]);
+        ga[i] = f6[i] - (QT[i][0] * f6[3] + QT[i][1] * f6[4] + QT[i][2] * f6[5]);
       }
-#pragma unroll
-      for (int i = 0; i < 6; i++) f6[i] *= rcp_nr(Dv[i]);
-#pragma unroll
-      for (int i = 4; i >= 0; i--) {
-#pragma unroll
-        for (int kq = i + 1; kq < 6; kq++) f6[i] -= A6[kq][i] * f6[kq];
-      }
+      sym3_inverse(Sc[0][0], Sc[1][0], Sc[1][1], Sc[2][0], Sc[2][1], Sc[2][2], Si);
+      const float aa0 = Si[0] * ga[0] + Si[1] * ga[1] + Si[2] * ga[2];
+      const float aa1 = Si[1] * ga[0] + Si[3] * ga[1] + Si[4] * ga[2];
+      const float aa2 = Si[2] * ga[0] + Si[4] * ga[1] + Si[5] * ga[2];
+      const float gl0 = f6[3] - (A6[0][3] * aa0 + A6[1][3] * aa1 + A6[2][3] * aa2);
+      const float gl1 = f6[4] - (A6[0][4] * aa0 + A6[1][4] * aa1 + A6[2][4] * aa2);
+      const float gl2 = f6[5] - (A6[0][5] * aa0 + A6[1][5] * aa1 + A6[2][5] * aa2);
+      f6[0] = aa0; f6[1] = aa1; f6[2] = aa2;
+      f6[3] = Ti[0] * gl0 + Ti[1] * gl1 + Ti[2] * gl2;
+      f6[4] = Ti[1] * gl0 + Ti[3] * gl1 + Ti[4] * gl2;
+      f6[5] = Ti[2] * gl0 + Ti[4] * gl1 + Ti[5] * gl2;
       // f6 = spatial acceleration of body 0; joint solution: x_trans = a_lin, x_rot = R^T a_ang
       if (lane < 6) An[8 + lane] = lane == 0 ? f6[0] : lane == 1 ? f6[1] : lane == 2 ? f6[2] : lane == 3 ? f6[3] : lane == 4 ? f6[4] : f6[5];
       if (lane < 3) x[lane] = lane == 0 ? f6[3] : (lane == 1 ? f6[4] : f6[5]);
@@ -778,6 +781,14 @@ struct Sim {
       w->sync();
     }
     SS_FTICK(PF_F_BSOL);
+  }
+
+  // inverse of the symmetric 3x3 [d00 d10 d20; d10 d11 d21; d20 d21 d22] -> (i00 i01 i02 i11 i12 i22)
+  SS_DEV static void sym3_inverse(float d00, float d10, float d11, float d20, float d21, float d22, float *o) {
+    const float c00 = d11 * d22 - d21 * d21, c01 = d21 * d20 - d10 * d22, c02 = d10 * d21 - d11 * d20;
+    const float id = rcp_nr(d00 * c00 + d10 * c01 + d20 * c02);
+    o[0] = c00 * id; o[1] = c01 * id; o[2] = c02 * id;
+    o[3] = (d00 * d22 - d20 * d20) * id; o[4] = (d10 * d20 - d00 * d21) * id; o[5] = (d00 * d11 - d10 * d10) * id;
   }
 
   // 1/x: hardware reciprocal + one Newton step
