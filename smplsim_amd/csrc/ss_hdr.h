@@ -17,7 +17,7 @@ struct Hdr {
   int nb, nn, nv, nq, nu, ncand, nlev, nblev, nbox, nslot, maxlev;
   unsigned long long nkpack[2];      // (nodes in level L) - 1, 4 bits per level: level bounds by SALU shifts, no table/kernarg loads
   // shared-blob word offsets
-  int o_dofc, o_chainnode, o_ndepth, o_lev, o_bparent, o_sumsmall, o_sumbig, o_sumcover, n_sumsmall, n_sumbig, shared_words;
+  int o_dofc, o_boff, o_chainnode, o_ndepth, o_lev, o_bparent, o_sumsmall, o_sumbig, o_sumcover, n_sumsmall, n_sumbig, shared_words;
   // per-env LDS float offsets.  Z = solver region: Aown | IA (2 level buffers) | Ubuf | Wst ; aliases: contact records
   // at Z, R/r inside Wst, Gb and the body_accel scratch inside IA, Ad = Ubuf = An, V = Pb
   int l_q, l_v, l_a, l_tau, l_C, l_Pb, l_delta, l_diag, l_S, l_Ab, l_An, l_Aown, l_IA, l_Ubuf, l_Wst,

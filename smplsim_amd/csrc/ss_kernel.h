@@ -205,6 +205,11 @@ struct Sim {
       tmp[idx] = S[6 * d + c] * x[d] + S[6 * d + 6 + c] * x[d + 1] + S[6 * d + 12 + c] * x[d + 2];
     }
     w->sync();
+    chain_sum(tmp, A);
+  }
+  // A[b] = sum of the node contributions tmp[n] (6 floats each) over the chain root .. node(b)
+  SS_DEV void chain_sum(const float *tmp, float *A) {
+    const Hdr &h = k->h;
     for (int idx = lane; idx < 6 * h.nb; idx += 64) {
       int b = idx / 6, c = idx - 6 * b, n = b + 1;
       const int dn = ti(h.o_ndepth, n), row = h.o_chainnode + n * h.nlev;
@@ -249,19 +254,6 @@ struct Sim {
       S[0 * 6 + 3] = 1.f; S[1 * 6 + 4] = 1.f; S[2 * 6 + 5] = 1.f;
 #pragma unroll
       for (int d = 0; d < 3; d++) { S[6 * (3 + d) + 0] = Rb[d]; S[6 * (3 + d) + 1] = Rb[3 + d]; S[6 * (3 + d) + 2] = Rb[6 + d]; }
-      if (with_dyn) {
-        float wl0 = v[3], wl1 = v[4], wl2 = v[5];
-        vb[0] = Rb[0] * wl0 + Rb[1] * wl1 + Rb[2] * wl2;
-        vb[1] = Rb[3] * wl0 + Rb[4] * wl1 + Rb[5] * wl2;
-        vb[2] = Rb[6] * wl0 + Rb[7] * wl1 + Rb[8] * wl2;
-        vb[3] = v[0]; vb[4] = v[1]; vb[5] = v[2];
-        // free joint: spatial bias acceleration (0 ; u x w)
-        ab[3] = vb[4] * vb[2] - vb[5] * vb[1];
-        ab[4] = vb[5] * vb[0] - vb[3] * vb[2];
-        ab[5] = vb[3] * vb[1] - vb[4] * vb[0];
-#pragma unroll
-        for (int c = 0; c < 6; c++) { V[c] = vb[c]; Ad[c] = ab[c]; }
-      }
     }
     // local rotation Rl = Rx Ry Rz and the hinge axes in the parent frame, once per body (not per level)
     float Rl[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, ayl[3] = {0, 1, 0}, azl[3] = {0, 0, 1};
@@ -275,64 +267,106 @@ struct Sim {
       ayl[0] = 0.f; ayl[1] = cx; ayl[2] = sx;                // Rx e_y
       azl[0] = sy; azl[1] = -sx * cy; azl[2] = cx * cy;      // Rx Ry e_z
     }
+    // The local rotations go through LDS (level-buffer region, free here) and every body walks its own chain of
+    // ancestors from the root: redundant arithmetic across lanes is free, a level-by-level sweep costs one LDS
+    // hand-off per tree level on every pass.
+    float *Rloc = IA;
+    if (lane >= 1 && lane < h.nb) {
+#pragma unroll
+      for (int i = 0; i < 9; i++) Rloc[9 * lane + i] = Rl[i];
+    }
     w->sync();
     SS_FTICK(PF_K_PRO);
-    for (int L = 1; L < h.nblev; L++) {
-      if (bdep == L) {
-        const int b = lane, n = b + 1;
-        float Rp[9], rp[3];
+    if (lane >= 1 && lane < h.nb) {
+      const int n = lane + 1, dn = ti(h.o_ndepth, n), row = h.o_chainnode + n * h.nlev;
+      float Rw[9], Rp[9];
 #pragma unroll
-        for (int i = 0; i < 9; i++) Rp[i] = R[9 * bpar + i];
+      for (int i = 0; i < 9; i++) { Rw[i] = R[i]; Rp[i] = Rw[i]; }
+      rb[0] = rb[1] = rb[2] = 0.f;
+      for (int kq = 2; kq <= dn; kq++) {                      // bodies on the chain below the root, ending with this one
+        const int a_ = ti(row, kq) - 1;
+        const float o0 = tf(h.o_boff, 3 * a_), o1 = tf(h.o_boff, 3 * a_ + 1), o2 = tf(h.o_boff, 3 * a_ + 2);
+        float La[9];
 #pragma unroll
-        for (int i = 0; i < 3; i++) rp[i] = r[3 * bpar + i];
-        float sd[3][6];
+        for (int i = 0; i < 9; i++) La[i] = Rloc[9 * a_ + i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) rb[i] += Rw[3 * i] * o0 + Rw[3 * i + 1] * o1 + Rw[3 * i + 2] * o2;
+#pragma unroll
+        for (int i = 0; i < 9; i++) Rp[i] = Rw[i];
 #pragma unroll
         for (int i = 0; i < 3; i++) {
           const float p0 = Rp[3 * i], p1 = Rp[3 * i + 1], p2 = Rp[3 * i + 2];
-          rb[i] = rp[i] + p0 * bc[0] + p1 * bc[1] + p2 * bc[2];
-          Rb[3 * i] = p0 * Rl[0] + p1 * Rl[3] + p2 * Rl[6];
-          Rb[3 * i + 1] = p0 * Rl[1] + p1 * Rl[4] + p2 * Rl[7];
-          Rb[3 * i + 2] = p0 * Rl[2] + p1 * Rl[5] + p2 * Rl[8];
-          sd[0][i] = p0;                                             // world axes of the x, y, z hinges
-          sd[1][i] = p1 * ayl[1] + p2 * ayl[2];
-          sd[2][i] = p0 * azl[0] + p1 * azl[1] + p2 * azl[2];
-        }
-#pragma unroll
-        for (int i = 0; i < 9; i++) R[9 * b + i] = Rb[i];
-#pragma unroll
-        for (int i = 0; i < 3; i++) r[3 * b + i] = rb[i];
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-          sd[j][3] = rb[1] * sd[j][2] - rb[2] * sd[j][1];
-          sd[j][4] = rb[2] * sd[j][0] - rb[0] * sd[j][2];
-          sd[j][5] = rb[0] * sd[j][1] - rb[1] * sd[j][0];
-#pragma unroll
-          for (int c = 0; c < 6; c++) S[6 * (3 * n + j) + c] = sd[j][c];
-        }
-        if (with_dyn) {
-#pragma unroll
-          for (int c = 0; c < 6; c++) { vb[c] = V[6 * bpar + c]; ab[c] = Ad[6 * bpar + c]; }
-#pragma unroll
-          for (int j = 0; j < 3; j++) {
-            float qd = v[3 * n + j];
-            const float *s = sd[j];
-            // (w;u) x_m (sw;su) = (w x sw ; w x su + u x sw)
-            float c0_ = vb[1] * s[2] - vb[2] * s[1], c1_ = vb[2] * s[0] - vb[0] * s[2], c2_ = vb[0] * s[1] - vb[1] * s[0];
-            float d0 = vb[1] * s[5] - vb[2] * s[4] + vb[4] * s[2] - vb[5] * s[1];
-            float d1 = vb[2] * s[3] - vb[0] * s[5] + vb[5] * s[0] - vb[3] * s[2];
-            float d2 = vb[0] * s[4] - vb[1] * s[3] + vb[3] * s[1] - vb[4] * s[0];
-            ab[0] += c0_ * qd; ab[1] += c1_ * qd; ab[2] += c2_ * qd; ab[3] += d0 * qd; ab[4] += d1 * qd; ab[5] += d2 * qd;
-#pragma unroll
-            for (int c = 0; c < 6; c++) vb[c] += s[c] * qd;
-          }
-#pragma unroll
-          for (int c = 0; c < 6; c++) { V[6 * b + c] = vb[c]; Ad[6 * b + c] = ab[c]; }
+          Rw[3 * i] = p0 * La[0] + p1 * La[3] + p2 * La[6];
+          Rw[3 * i + 1] = p0 * La[1] + p1 * La[4] + p2 * La[7];
+          Rw[3 * i + 2] = p0 * La[2] + p1 * La[5] + p2 * La[8];
         }
       }
-      w->sync();
+#pragma unroll
+      for (int i = 0; i < 9; i++) Rb[i] = Rw[i];
+      float sd[3][6];
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const float p0 = Rp[3 * i], p1 = Rp[3 * i + 1], p2 = Rp[3 * i + 2];
+        sd[0][i] = p0;                                             // world axes of the x, y, z hinges
+        sd[1][i] = p1 * ayl[1] + p2 * ayl[2];
+        sd[2][i] = p0 * azl[0] + p1 * azl[1] + p2 * azl[2];
+      }
+#pragma unroll
+      for (int i = 0; i < 9; i++) R[9 * lane + i] = Rb[i];
+#pragma unroll
+      for (int i = 0; i < 3; i++) r[3 * lane + i] = rb[i];
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        sd[j][3] = rb[1] * sd[j][2] - rb[2] * sd[j][1];
+        sd[j][4] = rb[2] * sd[j][0] - rb[0] * sd[j][2];
+        sd[j][5] = rb[0] * sd[j][1] - rb[1] * sd[j][0];
+#pragma unroll
+        for (int c = 0; c < 6; c++) S[6 * (3 * n + j) + c] = sd[j][c];
+      }
     }
+    w->sync();
     SS_FTICK(PF_K_LEV);
     if (!with_dyn) return;
+    // ---- body velocities V_b = sum_chain S qd, then the velocity-product accelerations: node terms + chain sums
+    body_accel(v, V, tmpb);
+    w->sync();
+    if (lane < h.nn) {
+      const int n = lane;
+      float d[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (n == 1) {                                          // free joint: (0 ; u x w)
+        d[3] = V[4] * V[2] - V[5] * V[1];
+        d[4] = V[5] * V[0] - V[3] * V[2];
+        d[5] = V[3] * V[1] - V[4] * V[0];
+      } else if (n >= 2) {
+        const float *vp = V + 6 * ti(h.o_bparent, n - 1);
+        float u[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) u[c] = vp[c];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          const float qd = v[3 * n + j];
+          float sj[6];
+#pragma unroll
+          for (int c = 0; c < 6; c++) sj[c] = S[6 * (3 * n + j) + c];
+          // (w;u) x_m (sw;su) = (w x sw ; w x su + u x sw)
+          d[0] += (u[1] * sj[2] - u[2] * sj[1]) * qd; d[1] += (u[2] * sj[0] - u[0] * sj[2]) * qd; d[2] += (u[0] * sj[1] - u[1] * sj[0]) * qd;
+          d[3] += (u[1] * sj[5] - u[2] * sj[4] + u[4] * sj[2] - u[5] * sj[1]) * qd;
+          d[4] += (u[2] * sj[3] - u[0] * sj[5] + u[5] * sj[0] - u[3] * sj[2]) * qd;
+          d[5] += (u[0] * sj[4] - u[1] * sj[3] + u[3] * sj[1] - u[4] * sj[0]) * qd;
+#pragma unroll
+          for (int c = 0; c < 6; c++) u[c] += sj[c] * qd;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 6; c++) tmpb[6 * n + c] = d[c];
+    }
+    w->sync();
+    chain_sum(tmpb, Ad);
+    w->sync();
+    if (lane < h.nb) {
+#pragma unroll
+      for (int c = 0; c < 6; c++) { vb[c] = V[6 * lane + c]; ab[c] = Ad[6 * lane + c]; }
+    }
     // ---- body spatial inertia about the root origin (world axes), bias force, sensor velocities
     if (lane < h.nb) {
       const int b = lane;

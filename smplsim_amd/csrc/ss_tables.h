@@ -198,6 +198,8 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   auto &S = out.shared; S.clear();
   auto push_i = [&](const std::vector<int> &v) { int o = (int)S.size(); for (int x : v) S.push_back((uint32_t)x); return o; };
   h.o_dofc = (int)S.size(); for (float f : dofc) S.push_back(f2u(f));
+  h.o_boff = (int)S.size();                                // body frame offsets in the parent frame (chain walk of forward_kin)
+  for (int b = 0; b < nb; b++) for (int k = 0; k < 3; k++) S.push_back(f2u(b == 0 ? 0.f : (float)d.body_pos[3 * b + k]));
   h.o_chainnode = push_i(chainnode);
   h.o_ndepth = push_i(ndepth);
   h.o_lev = push_i(lev);
