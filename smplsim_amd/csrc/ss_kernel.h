@@ -323,12 +323,25 @@ struct Sim {
 #pragma unroll
         for (int c = 0; c < 6; c++) S[6 * (3 * n + j) + c] = sd[j][c];
       }
+      if (with_dyn) {                                          // this node's term of the body velocities: S_n qd_n
+        const float q0 = v[3 * n], q1 = v[3 * n + 1], q2 = v[3 * n + 2];
+#pragma unroll
+        for (int c = 0; c < 6; c++) Ad[6 * n + c] = sd[0][c] * q0 + sd[1][c] * q1 + sd[2][c] * q2;
+      }
+    } else if (lane == 0 && with_dyn) {                        // root: translation node (0 ; v_lin), rotation node (R w_local ; 0)
+      const float wl0 = v[3], wl1 = v[4], wl2 = v[5];
+      Ad[0] = Ad[1] = Ad[2] = 0.f; Ad[3] = v[0]; Ad[4] = v[1]; Ad[5] = v[2];
+      Ad[6] = Rb[0] * wl0 + Rb[1] * wl1 + Rb[2] * wl2;
+      Ad[7] = Rb[3] * wl0 + Rb[4] * wl1 + Rb[5] * wl2;
+      Ad[8] = Rb[6] * wl0 + Rb[7] * wl1 + Rb[8] * wl2;
+      Ad[9] = Ad[10] = Ad[11] = 0.f;
     }
     w->sync();
     SS_FTICK(PF_K_LEV);
     if (!with_dyn) return;
-    // ---- body velocities V_b = sum_chain S qd, then the velocity-product accelerations: node terms + chain sums
-    body_accel(v, V, tmpb);
+    // ---- body velocities V_b = chain sums of the node terms written above, then the velocity-product accelerations:
+    // node terms + chain sums again
+    chain_sum(Ad, V);
     w->sync();
     if (lane < h.nn) {
       const int n = lane;
