@@ -207,20 +207,26 @@ struct Sim {
     w->sync();
     chain_sum(tmp, A);
   }
-  // A[b] = sum of the node contributions tmp[n] (6 floats each) over the chain root .. node(b)
-  SS_DEV void chain_sum(const float *tmp, float *A) {
+  // A[b] = sum of the node contributions tmp[n] (6 floats each) over the chain root .. node(b); optionally a second
+  // (tmp2 -> A2) pair in the same pass over the chain table
+  SS_DEV void chain_sum(const float *tmp, float *A, const float *tmp2 = nullptr, float *A2 = nullptr) {
     const Hdr &h = k->h;
     for (int idx = lane; idx < 6 * h.nb; idx += 64) {
       int b = idx / 6, c = idx - 6 * b, n = b + 1;
       const int dn = ti(h.o_ndepth, n), row = h.o_chainnode + n * h.nlev;
-      float s = 0.f;
+      float s = 0.f, s2 = 0.f;
       for (int kk = 0; kk <= dn; kk += 4) {                  // 4 independent (table, data) read pairs per trip
         const int k1 = kk + 1 <= dn ? kk + 1 : kk, k2 = kk + 2 <= dn ? kk + 2 : kk, k3 = kk + 3 <= dn ? kk + 3 : kk;
         const int n0 = ti(row, kk), n1 = ti(row, k1), n2 = ti(row, k2), n3 = ti(row, k3);
         const float a0 = tmp[6 * n0 + c], a1 = tmp[6 * n1 + c], a2 = tmp[6 * n2 + c], a3 = tmp[6 * n3 + c];
         s += (a0 + (kk + 1 <= dn ? a1 : 0.f)) + ((kk + 2 <= dn ? a2 : 0.f) + (kk + 3 <= dn ? a3 : 0.f));
+        if (tmp2) {
+          const float e0 = tmp2[6 * n0 + c], e1 = tmp2[6 * n1 + c], e2 = tmp2[6 * n2 + c], e3 = tmp2[6 * n3 + c];
+          s2 += (e0 + (kk + 1 <= dn ? e1 : 0.f)) + ((kk + 2 <= dn ? e2 : 0.f) + (kk + 3 <= dn ? e3 : 0.f));
+        }
       }
       A[idx] = s;
+      if (tmp2) A2[idx] = s2;
     }
   }
 
@@ -323,10 +329,15 @@ struct Sim {
 #pragma unroll
         for (int c = 0; c < 6; c++) S[6 * (3 * n + j) + c] = sd[j][c];
       }
-      if (with_dyn) {                                          // this node's term of the body velocities: S_n qd_n
-        const float q0 = v[3 * n], q1 = v[3 * n + 1], q2 = v[3 * n + 2];
+      if (with_dyn) {                                          // this node's terms of the body velocities S_n qd_n and of the
+        const float q0 = v[3 * n], q1 = v[3 * n + 1], q2 = v[3 * n + 2];      // body accelerations of the warm start S_n a_n
+        const float g0 = a[3 * n], g1 = a[3 * n + 1], g2 = a[3 * n + 2];
+        float *w2 = Wst + 12 * h.nb;                           // free part of the (W, y) region behind R, r
 #pragma unroll
-        for (int c = 0; c < 6; c++) Ad[6 * n + c] = sd[0][c] * q0 + sd[1][c] * q1 + sd[2][c] * q2;
+        for (int c = 0; c < 6; c++) {
+          Ad[6 * n + c] = sd[0][c] * q0 + sd[1][c] * q1 + sd[2][c] * q2;
+          w2[6 * n + c] = sd[0][c] * g0 + sd[1][c] * g1 + sd[2][c] * g2;
+        }
       }
     } else if (lane == 0 && with_dyn) {                        // root: translation node (0 ; v_lin), rotation node (R w_local ; 0)
       const float wl0 = v[3], wl1 = v[4], wl2 = v[5];
@@ -335,13 +346,20 @@ struct Sim {
       Ad[7] = Rb[3] * wl0 + Rb[4] * wl1 + Rb[5] * wl2;
       Ad[8] = Rb[6] * wl0 + Rb[7] * wl1 + Rb[8] * wl2;
       Ad[9] = Ad[10] = Ad[11] = 0.f;
+      float *w2 = Wst + 12 * h.nb;
+      const float g0 = a[3], g1 = a[4], g2 = a[5];
+      w2[0] = w2[1] = w2[2] = 0.f; w2[3] = a[0]; w2[4] = a[1]; w2[5] = a[2];
+      w2[6] = Rb[0] * g0 + Rb[1] * g1 + Rb[2] * g2;
+      w2[7] = Rb[3] * g0 + Rb[4] * g1 + Rb[5] * g2;
+      w2[8] = Rb[6] * g0 + Rb[7] * g1 + Rb[8] * g2;
+      w2[9] = w2[10] = w2[11] = 0.f;
     }
     w->sync();
     SS_FTICK(PF_K_LEV);
     if (!with_dyn) return;
     // ---- body velocities V_b = chain sums of the node terms written above, then the velocity-product accelerations:
     // node terms + chain sums again
-    chain_sum(Ad, V);
+    chain_sum(Ad, V, Wst + 12 * h.nb, Ab);                   // Ab: body accelerations of the iterate newton_begin starts from
     w->sync();
     if (lane < h.nn) {
       const int n = lane;
@@ -904,9 +922,7 @@ struct Sim {
   // between newton_prepare() and newton_finish() in the driver's solver loop.
   SS_DEV void newton_begin() {
     fresh();
-    body_accel(a, Ab, tmpb);
-    w->sync();
-    eval_rows(Ab, 6, a, false);
+    eval_rows(Ab, 6, a, false);                              // Ab = J_b a was left by forward_kin's chain sums
   }
 
   // right-hand side of the Newton system in two parts — joint space (-> delta) and per-body forces Pb —, diagonal terms
@@ -1399,6 +1415,8 @@ SS_DEV bool run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env, 
       if (is_debug) {                                        // diagnostics: dense mass matrix and bias force
         sim.dump_mass_matrix(k->out0 + (size_t)env * h.nv * h.nv);
         sim.store(k->out1 + (size_t)env * h.nv, sim.C, h.nv);
+        sim.body_accel(sim.a, sim.Ab, sim.tmpb);              // the dump used Ab as scratch
+        w->sync();
       }
       sim.newton_begin();
       SS_TICK(PF_NBEGIN);
