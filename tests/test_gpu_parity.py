@@ -348,6 +348,28 @@ def test_teacher_forced_parity_on_the_benchmark_distribution(vec):
     assert p90[0] < 1e-4 and p90[1] < 5e-3, p90
 
 
+def test_pipelined_sub_batches_equal_their_standalone_envs(vec):
+    """PipelinedVecEnv: G sub-batches on G streams, stepped round-robin, give exactly what the same shards give alone."""
+    from smplsim_amd.pipeline import PipelinedVecEnv
+    pipe = PipelinedVecEnv(256, sub_batches=4, seed=3, task="HumanoidSpeed")
+    solo = [vec(64, seed=3 + 1000 * g, task="HumanoidSpeed") for g in range(4)]
+    pipe.reset()
+    for e in solo:
+        e.reset()
+    gens = [torch.Generator(device=pipe.device) for _ in range(4)]
+    for t in range(6):
+        outs = []
+        for g in range(4):
+            gens[g].manual_seed(100 * t + g)
+            with pipe.stream(g):
+                a = torch.rand(64, 69, generator=gens[g], device=pipe.device) * 2 - 1
+            outs.append((a, pipe.step_async(g, a)))
+        pipe.synchronize()
+        for g, (a, (obs, rew, term, trunc, _)) in enumerate(outs):
+            o2, r2, te2, tu2, _ = solo[g].step(a)
+            assert torch.equal(obs, o2) and torch.equal(rew, r2) and torch.equal(term, te2) and torch.equal(trunc, tu2)
+
+
 def test_gym_style_single_env_matches_oracle():
     """The reference's single-env surface (HumanoidEnv(cfg).reset/step, numpy in/out)."""
     import smpl_sim.envs.tasks as tasks                       # the reference's import path

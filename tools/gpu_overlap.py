@@ -1,4 +1,4 @@
-"""Does overlapping the straggler tail of one sub-batch with the body of another help?  G independent sub-batches
+"""(See also smplsim_amd/pipeline.py, the packaged form of this.)  Does overlapping the straggler tail of one sub-batch with the body of another help?  G independent sub-batches
 (SMPLSimVecEnv of 4096/G envs each, own torch stream), stepped round-robin; time per step of all 4096 envs."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
