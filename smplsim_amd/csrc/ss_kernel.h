@@ -41,6 +41,11 @@
 #define SS_TICK(id) do {} while (0)
 #endif
 
+// relative tolerance of the exact line search on |phi'(alpha)| (MuJoCo's default opt.ls_tolerance = 0.01)
+#ifndef SS_LS_TOL
+#define SS_LS_TOL 1e-2f
+#endif
+
 namespace ss {
 
 enum { PF_FWD = 0, PF_CONS, PF_NBEGIN, PF_NPREP, PF_ASM, PF_FACTOR, PF_SOLVE, PF_NFIN, PF_SPDPREP, PF_SPDFIN, PF_INTEG, PF_MISC,
@@ -1054,8 +1059,8 @@ struct Sim {
     const float c1 = dg_ - s_a, c2 = -dg_ - s_b;            // phi'(al) = c1 + al c2 + sum_active(al) D (jar + al jd) jd
     float al = 1.f, d1, d2;
     ls_eval(1.f, c1, c2, d1, d2);
-    // accept when |phi'| is 1e-3 of phi'(0) = delta.grad, or at the rounding level of its terms
-    const float tol = 1e-3f * fabsf(dg_) + 2e-6f * (fabsf(dg_) + fabsf(s_a) + fabsf(s_b));
+    // accept when |phi'| is SS_LS_TOL of phi'(0) = delta.grad, or at the rounding level of its terms
+    const float tol = SS_LS_TOL * fabsf(dg_) + 2e-6f * (fabsf(dg_) + fabsf(s_a) + fabsf(s_b));
     bool exact = true;
     if (!(fabsf(d1) <= tol)) {
       exact = false;
