@@ -86,7 +86,8 @@ class AgentPPO:
         state = self._prep_obs(self._obs)
         for t in range(T):
             states[t] = state
-            a = self.policy_net.select_action(state, mean_action, generator=self.gen)
+            with self._autocast():
+                a = self._f32(self.policy_net.select_action(state, mean_action, generator=self.gen))
             actions[t] = a
             obs, rew, died, timed_out, _ = env.step(self._prep_actions(a))
             rewards[t] = rew
