@@ -152,3 +152,15 @@ def test_device_side_longest_first_schedule_is_a_sorted_permutation_and_changes_
         eb.step(act); ref.step(act)
         assert np.array_equal(eb.qpos, ref.qpos) and np.array_equal(eb.obs, ref.obs)      # the hand-out order is only a hint
     assert emu.lib().ss_schedule_longest_first(None, None) != 0
+
+
+def test_step_autoreset_error_paths():
+    import ctypes as C
+    eb = _batch(2, state_init=1)                              # StateInit.Fall: the in-launch reset is refused
+    a = np.zeros((2, 69), np.float32); obs2 = np.zeros_like(eb.obs)
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    rc = emu.lib().ss_step_autoreset(eb.batch, p(a), None, None, p(eb.obs), p(obs2), p(eb.reward), p(eb.terminated), p(eb.truncated), None)
+    assert rc != 0 and b"Default" in emu.lib().ss_last_error()
+    ok = _batch(2)
+    rc = emu.lib().ss_step_autoreset(ok.batch, p(a), None, None, p(ok.obs), None, p(ok.reward), p(ok.terminated), p(ok.truncated), None)
+    assert rc != 0                                            # obs_next is mandatory
