@@ -156,7 +156,7 @@ def main():
         bstep = algorithmic_bytes(env.nq, env.nv, env.nu, env.obs_size)
         ach = N * bstep / (kern_ms * 1e-3) / 1e9
         out = {
-            "metric": "env-steps/sec (whole node), 4096-env SMPL rollout", "value": value, "unit": "env-steps/s",
+            "metric": "env-steps/sec (whole node), 4096-env SMPL rollout at 1/2/4/8 MI355X", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload].format(N=N),
