@@ -1,4 +1,4 @@
-"""ctypes declarations of the C ABI in include/smplsim_hip.h (structs + prototypes).
+"""ctypes declarations of the C ABI in include/smplsim_hip.h and include/smplsim_motion.h (structs + prototypes).
 
 Pure declarations: `bind(cdll)` attaches argtypes/restypes to an already-loaded library.
 The product loads libsmplsim_hip.so through smplsim_amd/_lib.py; tests bind the same
@@ -9,12 +9,12 @@ import ctypes as C
 import numpy as np
 
 TASK_BASE, TASK_SPEED, TASK_GETUP, TASK_REACH = 0, 1, 2, 3
-INIT_DEFAULT, INIT_FALL = 0, 1
+INIT_DEFAULT, INIT_FALL, INIT_EXTERNAL = 0, 1, 2
 CTRL_UHC_PD, CTRL_PD, CTRL_TORQUE, CTRL_SIMPLE_PID, CTRL_DEFAULT = 0, 1, 2, 3, 4
 TASKS = {"HumanoidEnv": TASK_BASE, "HumanoidSpeed": TASK_SPEED, "HumanoidGetup": TASK_GETUP, "HumanoidReach": TASK_REACH}
 CONTROL_MODES = {"uhc_pd": CTRL_UHC_PD, "pd": CTRL_PD, "torque": CTRL_TORQUE, "simple_pid": CTRL_SIMPLE_PID,
                  "default": CTRL_DEFAULT}
-STATE_INITS = {"Default": INIT_DEFAULT, "Fall": INIT_FALL}
+STATE_INITS = {"Default": INIT_DEFAULT, "Fall": INIT_FALL, "External": INIT_EXTERNAL}
 
 
 class ModelDesc(C.Structure):
@@ -54,6 +54,32 @@ class State(C.Structure):
     ]
 
 
+class Skeleton(C.Structure):
+    _fields_ = [("nbody", C.c_int32), ("parent", C.c_void_p), ("smpl_2_mujoco", C.c_void_p)]
+
+
+MOTION_DATA_ARRAYS = ("length_starts", "motion_num_frames", "motion_dt", "motion_lengths", "frame_motion", "pose_aa", "trans",
+                      "offsets", "gts", "grs", "lrs", "gvs", "gavs", "dof_pos", "dvs", "qpos", "qvel")
+
+
+class MotionData(C.Structure):
+    _fields_ = [("num_motions", C.c_int32), ("num_frames", C.c_int32), ("nbody", C.c_int32)] + \
+               [(n, C.c_void_p) for n in MOTION_DATA_ARRAYS]
+
+
+MOTION_STATE_FIELDS = ("root_pos", "root_rot", "dof_pos", "root_vel", "root_ang_vel", "dof_vel", "rg_pos", "rb_rot", "body_vel",
+                       "body_ang_vel", "qpos", "qvel")
+
+
+class MotionState(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in MOTION_STATE_FIELDS]
+
+
+class ImitationCfg(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("k_pos", "k_rot", "k_vel", "k_ang_vel", "w_pos", "w_rot", "w_vel", "w_ang_vel",
+                                         "termination_distance", "obs_dt")]
+
+
 def bind(lib):
     vp = C.c_void_p
     lib.ss_model_create.argtypes = [C.POINTER(ModelDesc), C.c_int, C.POINTER(vp)]
@@ -74,12 +100,16 @@ def bind(lib):
     lib.ss_set_order.argtypes = [vp, vp]
     lib.ss_launch_info.argtypes = [vp] + [C.POINTER(C.c_int32)] * 3
     lib.ss_last_error.argtypes = []; lib.ss_last_error.restype = C.c_char_p
+    lib.ss_motion_cook.argtypes = [C.POINTER(Skeleton), C.POINTER(MotionData), C.c_int32, vp]
+    lib.ss_motion_state_at.argtypes = [C.POINTER(MotionData), vp, vp, vp, C.c_int32, C.c_int32, C.POINTER(MotionState), vp]
+    lib.ss_imitation_step.argtypes = [C.POINTER(MotionData), C.POINTER(ImitationCfg)] + [vp] * 3 + [C.c_int32] + [vp] * 8
     return lib
 
 
 EXPORTS = ["ss_model_create", "ss_model_destroy", "ss_model_dims", "ss_obs_size", "ss_batch_create",
            "ss_batch_destroy", "ss_reset", "ss_step", "ss_step_autoreset", "ss_substep", "ss_kinematics", "ss_debug_forward",
-           "ss_gae", "ss_debug_prof", "ss_set_order", "ss_schedule_longest_first", "ss_launch_info", "ss_last_error"]
+           "ss_gae", "ss_debug_prof", "ss_set_order", "ss_schedule_longest_first", "ss_launch_info", "ss_last_error",
+           "ss_motion_cook", "ss_motion_state_at", "ss_imitation_step"]
 
 
 def make_model_desc(mc, kp, kd, torque_lim, act_scale, act_offset, legal_bodies=(), timestep=1.0 / 450):

@@ -8,6 +8,7 @@
 
 #include "ss_api.h"
 #include "ss_kernel.h"
+#include "ss_motion_api.h"
 
 // launch bounds per kernel variant = the number of envs whose LDS slices fit one CU, rounded up to whole waves per
 // SIMD.  SMPL: 12 envs -> 3 waves/SIMD -> 168-VGPR cap (~12 spilled dwords).  SMPL-X: 5 envs -> 2 waves/SIMD, 256 VGPRs,
@@ -134,6 +135,35 @@ __global__ void __launch_bounds__(1024) ss_order_kernel(const int32_t *iters, in
   for (int i = threadIdx.x; i < n; i += blockDim.x) { int key = iters[i]; key = key < 0 ? 0 : (key > 255 ? 255 : key); order[atomicAdd(&offs[255 - key], 1)] = i; }
 }
 
+
+// ---- motion library (include/smplsim_motion.h; element / wave functions in ss_motion.h).  All HBM-bound gathers: the
+// grids are one thread per frame (FK: the chain stack of 64 frames fills 52 KiB of LDS), one wave per clip (the
+// sequential Euler-angle fix), one thread per (frame, body) and per (env, body).
+__global__ void __launch_bounds__(64) ss_motion_fk_kernel(const ss::mo::CookArgs a) {
+  __shared__ float stk[ss::mo::kMaxDepth * ss::mo::kStackSlots * 64];
+  const int f = blockIdx.x * 64 + threadIdx.x;
+  if (f < a.d.num_frames) ss::mo::fk_frame(a, f, stk + threadIdx.x, 64);
+}
+__global__ void __launch_bounds__(64) ss_motion_fix_kernel(const ss::mo::CookArgs a) {
+  WaveGpu w{(int)threadIdx.x};
+  ss::mo::dof_fix_clip(&w, a, (int)blockIdx.x);
+}
+__global__ void __launch_bounds__(256) ss_motion_vel_kernel(const ss::mo::CookArgs a) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int J = a.sk.nb;
+  if (idx < (long long)a.d.num_frames * J) ss::mo::vel_elem(a, (int)(idx / J), (int)(idx % J));
+}
+__global__ void __launch_bounds__(256) ss_motion_state_kernel(const ss::mo::StateArgs a) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int J = a.d.nbody;
+  if (idx < (long long)a.N * J) ss::mo::state_elem(a, (int)(idx / J), (int)(idx % J));
+}
+template <int LPE>
+__global__ void __launch_bounds__(256) ss_imitation_kernel(const ss::mo::ImArgs a) {
+  WaveGpu w{(int)(threadIdx.x & 63)};
+  ss::mo::imitation_wave<WaveGpu, LPE>(&w, a, (int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+}
+
 typedef void (*kern_t)(const ss::KArgs);
 kern_t pick_kernel(int variant) {
   if (variant == 0) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS>;      // SMPL layout (24 bodies)
@@ -160,6 +190,23 @@ struct HipBackend {
     hipLaunchKernelGGL(ss_gae_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, rew, nd, ndead, val, boot, T, N, gamma, tau, adv, ret);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? nullptr : hipGetErrorString(e);
+  }
+  static const char *hip_err() { hipError_t e = hipGetLastError(); return e == hipSuccess ? nullptr : hipGetErrorString(e); }
+  static const char *motion_cook(const ss::mo::CookArgs &a, void *stream) {
+    const int F = a.d.num_frames, J = a.sk.nb;
+    hipLaunchKernelGGL(ss_motion_fk_kernel, dim3((F + 63) / 64), dim3(64), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(ss_motion_fix_kernel, dim3(a.d.num_motions), dim3(64), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(ss_motion_vel_kernel, dim3((unsigned)(((long long)F * J + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return hip_err();
+  }
+  static const char *motion_state(const ss::mo::StateArgs &a, void *stream) {
+    hipLaunchKernelGGL(ss_motion_state_kernel, dim3((unsigned)(((long long)a.N * a.d.nbody + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return hip_err();
+  }
+  static const char *imitation(const ss::mo::ImArgs &a, void *stream) {
+    if (a.d.nbody <= 32) hipLaunchKernelGGL(ss_imitation_kernel<32>, dim3((a.N + 7) / 8), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(ss_imitation_kernel<64>, dim3((a.N + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+    return hip_err();
   }
   static int &regs_ref() { static int r = 0; return r; }
   static int kernel_regs() { return regs_ref(); }
@@ -190,3 +237,4 @@ struct HipBackend {
 }  // namespace
 
 SS_DEFINE_C_API(HipBackend)
+SS_DEFINE_MOTION_API(HipBackend)

@@ -1,0 +1,311 @@
+"""Motion library on the device: the reference's MotionLibSMPL over libsmplsim_hip.so.
+
+Mirrors `MotionLibBase` / `MotionLibSMPL` (reference smpl_sim/smpllib/motion_lib_base.py:38-458,
+smpl_sim/smpllib/motion_lib_smpl.py:50-155): same clip format (the AMASS pickles: {key: {"pose_aa" [T,72|156],
+"trans" [T,3], "fps"}}), same attribute names for the cooked arrays (gts, grs, lrs, gvs, gavs, grvs, gravs, dvs,
+dof_pos, qpos, qvel, length_starts, _motion_lengths, ...), same sampling interface (load_motions, sample_motions,
+sample_time, get_motion_state, get_motion_state_intervaled, termination-history based re-weighting).  Differences,
+all on purpose:
+
+  * the per-clip torch forward kinematics in worker processes (load_motion_with_skeleton, motion_lib_smpl.py:93-155)
+    is three HIP launches over every frame of every selected clip (ss_motion_cook); the arrays are torch tensors in HBM;
+  * joint offsets come from the compiled MJCF (body positions) instead of SMPL_Parser + betas — the SMPL model files
+    are not redistributable; per-clip offsets ([M,J,3], e.g. from the user's own SMPL_Parser) can be passed in;
+  * fix_trans_height (motion_lib_smpl.py:66-90) needs the SMPL mesh: FixHeightMode.no_fix is native, the other two
+    modes need a `height_fix` callable supplied by the user (called per clip on the host).
+
+There is no CPU path: without a GPU (and libsmplsim_hip.so) construction fails.
+"""
+import ctypes as C
+import os
+from enum import Enum
+
+import numpy as np
+import torch
+
+from . import _cabi
+
+SMPL_BONE_ORDER_NAMES = ["Pelvis", "L_Hip", "R_Hip", "Torso", "L_Knee", "R_Knee", "Spine", "L_Ankle", "R_Ankle", "Chest", "L_Toe",
+                         "R_Toe", "Neck", "L_Thorax", "R_Thorax", "Head", "L_Shoulder", "R_Shoulder", "L_Elbow", "R_Elbow",
+                         "L_Wrist", "R_Wrist", "L_Hand", "R_Hand"]
+
+
+class FixHeightMode(Enum):          # motion_lib_base.py:28-31
+    no_fix = 0
+    full_fix = 1
+    ankle_fix = 2
+
+
+class Skeleton:
+    """Body tree in MuJoCo (MJCF depth-first) order + the SMPL joint order permutation (Humanoid_Batch.__init__,
+    torch_smpl_humanoid_batch.py:38-78)."""
+
+    def __init__(self, body_names, parents, offsets, smpl_order_names=None):
+        self.body_names = list(body_names)
+        self.parents = np.asarray(parents, np.int32)
+        self.offsets = np.round(np.asarray(offsets, np.float32), decimals=5)        # update_model rounds to 5 decimals (:113)
+        order = list(smpl_order_names) if smpl_order_names is not None else (
+            SMPL_BONE_ORDER_NAMES if set(body_names) == set(SMPL_BONE_ORDER_NAMES) else list(body_names))
+        self.smpl_2_mujoco = np.array([order.index(n) for n in self.body_names], np.int32)
+        self.mujoco_2_smpl = np.array([self.body_names.index(n) for n in order], np.int32)
+        self.num_joints = len(self.body_names)
+
+    @classmethod
+    def from_model_const(cls, mc, smpl_order_names=None):
+        """From a compiled MJCF (smplsim_amd.mjcf.compile_mjcf): offsets = body positions in the parent frame."""
+        return cls(mc.body_names, mc.body_parent, mc.body_pos, smpl_order_names)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class MotionLibSMPL:
+    def __init__(self, motion_file, skeleton, device=0, fix_height=FixHeightMode.no_fix, min_length=-1, max_length=-1,
+                 randomrize_heading=False, filter_vel=True, height_fix=None, seed=0, _clib=None):
+        """motion_file: path of a joblib/pickle file, a directory of *.pkl files, or the dict itself.
+        `_clib` is a unit-test hook (the CPU emulator build of the same C ABI, host tensors)."""
+        if _clib is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("MotionLibSMPL needs a ROCm GPU (MI355X); there is no CPU fallback")
+            from ._lib import lib
+            self._lib = lib()
+            self.device = torch.device("cuda", int(device)) if not isinstance(device, torch.device) else device
+        else:
+            self._lib, self.device = _clib, torch.device("cpu")
+        self.skeleton = skeleton
+        self.fix_height, self.height_fix = fix_height, height_fix
+        if fix_height != FixHeightMode.no_fix and height_fix is None:
+            raise ValueError("fix_height modes other than no_fix need the SMPL mesh: pass a height_fix(pose_aa, trans) callable")
+        self.max_length, self.randomrize_heading, self.filter_vel = max_length, randomrize_heading, bool(filter_vel)
+        self.rng = np.random.default_rng(seed)
+        self.dtype = np.float32
+        self.curr_failed_keys = []
+        self.load_data(motion_file, min_length)
+        self.setup_constants()
+        self._num_motions = 0
+
+    # ---- MotionLibBase.load_data / setup_constants (:51-89)
+    def load_data(self, motion_file, min_length=-1):
+        if isinstance(motion_file, dict):
+            data = motion_file
+        elif os.path.isfile(motion_file):
+            import joblib
+            data = joblib.load(motion_file)
+        else:
+            import glob
+            import joblib
+            data = {}
+            for f in sorted(glob.glob(os.path.join(motion_file, "*.pkl"))):
+                data.update(joblib.load(f))
+        if min_length != -1:
+            data = {k: v for k, v in data.items() if len(v["pose_aa"]) >= min_length}
+        if not data:
+            raise ValueError("no motion clips")
+        self._motion_data_load = data
+        self._motion_data_list = list(data.values())
+        self._motion_data_keys = np.array(list(data.keys()))
+        self._num_unique_motions = len(self._motion_data_list)
+
+    def setup_constants(self):
+        n = self._num_unique_motions
+        self._curr_motion_ids = None
+        self._termination_history = np.zeros(n)
+        self._success_rate = np.zeros(n)
+        self._sampling_history = np.zeros(n)
+        self._sampling_prob = np.ones(n) / n
+        self._sampling_batch_prob = None
+
+    # ---- MotionLibBase.load_motions (:99-208)
+    def load_motions(self, num_motions=None, shape_params=None, random_sample=True, start_idx=0, offsets=None, silent=True):
+        """Select `num_motions` clips (default: one per entry of shape_params, as the reference does) and cook them.
+        offsets: optional [M,J,3] per-clip joint offsets (MuJoCo order); default = the skeleton's for every clip."""
+        if num_motions is None:
+            num_motions = len(shape_params) if shape_params is not None else self._num_unique_motions
+        M, J = int(num_motions), self.skeleton.num_joints
+        if random_sample:
+            idx = self.rng.choice(self._num_unique_motions, size=M, p=self._sampling_prob, replace=True)
+        else:
+            idx = np.remainder(np.arange(M) + start_idx, self._num_unique_motions)
+        self._curr_motion_ids = idx
+        self.curr_motion_keys = self._motion_data_keys[idx]
+        self._sampling_batch_prob = self._sampling_prob[idx] / self._sampling_prob[idx].sum()
+
+        poses, transs, nfs, fpss = [], [], [], []
+        for i in idx:
+            clip = self._motion_data_list[i]
+            fps = float(clip.get("fps", 30))
+            pose = np.asarray(clip["pose_aa"], np.float32)
+            trans = np.asarray(clip["trans"] if "trans" in clip else clip["trans_orig"], np.float32)
+            T = pose.shape[0]
+            if self.max_length != -1 and T >= self.max_length:          # motion_lib_smpl.py:108-113
+                s = int(self.rng.integers(0, T - self.max_length + 1))
+                pose, trans = pose[s:s + self.max_length], trans[s:s + self.max_length]
+            pose = pose.reshape(pose.shape[0], -1)
+            if pose.shape[1] == 156 and J == 24:                        # SMPL-H pickles: body joints + zero hands (:118-119)
+                pose = np.concatenate([pose[:, :66], np.zeros((pose.shape[0], 6), np.float32)], 1)
+            if pose.shape[1] != 3 * J:
+                raise ValueError(f"pose_aa has {pose.shape[1]} columns, the skeleton needs {3 * J}")
+            pose = pose.reshape(-1, J, 3).copy()
+            trans = trans.copy()
+            if pose.shape[0] < 2:
+                raise ValueError("a clip needs at least 2 frames")
+            if self.randomrize_heading:                                 # motion_lib_smpl.py:128-134
+                from scipy.spatial.transform import Rotation as sRot
+                rot = sRot.from_euler("xyz", [0.0, 0.0, np.pi * (2 * self.rng.random() - 1.0)])
+                pose[:, 0] = (rot * sRot.from_rotvec(pose[:, 0])).as_rotvec().astype(np.float32)
+                trans = (trans @ rot.as_matrix().T.astype(np.float32)).astype(np.float32)
+            if self.fix_height != FixHeightMode.no_fix:
+                trans = np.asarray(self.height_fix(pose, trans), np.float32)
+            poses.append(pose); transs.append(trans); nfs.append(pose.shape[0]); fpss.append(fps)
+
+        nf = np.array(nfs, np.int64)
+        self._motion_num_frames = nf
+        self._motion_fps = np.array(fpss, self.dtype)
+        self._motion_dt = (1.0 / self._motion_fps).astype(self.dtype)
+        self._motion_lengths = (1.0 / self._motion_fps * (nf - 1)).astype(self.dtype)
+        self._motion_aa = np.concatenate(poses).reshape(-1, 3 * J)
+        self._motion_bodies = np.zeros((M, 17), self.dtype) if shape_params is None else np.stack(shape_params).astype(self.dtype)
+        shifted = np.roll(nf, 1)
+        shifted[0] = 0
+        self.length_starts = shifted.cumsum(0)
+        self.motion_ids = np.arange(M)
+        self.num_bodies = self.num_joints = J
+        self._num_motions = M
+        F = int(nf.sum())
+        if F >= 2 ** 31 // (J * 9):
+            raise ValueError("too many frames for 32-bit indexing")
+        dev = self.device
+
+        def up(a, dt):
+            return torch.as_tensor(np.ascontiguousarray(a, dtype=dt)).to(dev)
+
+        off = np.broadcast_to(self.skeleton.offsets, (M, J, 3)) if offsets is None else np.asarray(offsets, np.float32).reshape(M, J, 3)
+        self._d = dict(
+            length_starts=up(self.length_starts, np.int32), motion_num_frames=up(nf, np.int32), motion_dt=up(self._motion_dt, np.float32),
+            motion_lengths=up(self._motion_lengths, np.float32), frame_motion=up(np.repeat(np.arange(M), nf), np.int32),
+            pose_aa=up(self._motion_aa, np.float32), trans=up(np.concatenate(transs), np.float32), offsets=up(off, np.float32))
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.gts = torch.empty(F, J, 3, **f32); self.grs = torch.empty(F, J, 4, **f32); self.lrs = torch.empty(F, J, 4, **f32)
+        self.gvs = torch.empty(F, J, 3, **f32); self.gavs = torch.empty(F, J, 3, **f32)
+        self.dof_pos = torch.empty(F, J - 1, 3, **f32); self.dvs = torch.empty(F, J - 1, 3, **f32)
+        self.qpos = torch.empty(F, 7 + 3 * (J - 1), **f32); self.qvel = torch.empty(F, 6 + 3 * (J - 1), **f32)
+        self.grvs, self.gravs = self.gvs[:, 0], self.gavs[:, 0]
+        self._d.update(gts=self.gts, grs=self.grs, lrs=self.lrs, gvs=self.gvs, gavs=self.gavs, dof_pos=self.dof_pos, dvs=self.dvs,
+                       qpos=self.qpos, qvel=self.qvel)
+        self.data = _cabi.MotionData(M, F, J, *[_ptr(self._d[n]) for n in _cabi.MOTION_DATA_ARRAYS])
+        sk = self.skeleton
+        self._sk_keep = (np.ascontiguousarray(sk.parents, np.int32), np.ascontiguousarray(sk.smpl_2_mujoco, np.int32))
+        skel = _cabi.Skeleton(J, self._sk_keep[0].ctypes.data_as(C.c_void_p), self._sk_keep[1].ctypes.data_as(C.c_void_p))
+        self._check(self._lib.ss_motion_cook(C.byref(skel), C.byref(self.data), int(self.filter_vel), self._stream()))
+        self.motion_lengths_t, self.motion_num_frames_t = self._d["motion_lengths"], self._d["motion_num_frames"]
+        if not silent:
+            print(f"###### Sampling {M:d} motions:", idx[:5], self.curr_motion_keys[:5],
+                  f"total length of {self.get_total_length():.3f}s and {F} frames.")
+        return M
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(f"libsmplsim_hip error {rc}: {self._lib.ss_last_error().decode()}")
+
+    def _stream(self):
+        if self.device.type != "cuda":
+            return None
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- bookkeeping (motion_lib_base.py:210-276)
+    def num_current_motions(self):
+        return self._num_motions
+
+    def num_all_motions(self):
+        return self._num_unique_motions
+
+    def get_total_length(self):
+        return float(self._motion_lengths.sum())
+
+    def get_termination_history(self):
+        return {"termination_history": self._termination_history, "failed_keys": self.curr_failed_keys}
+
+    def set_termination_history(self, termination_history):
+        self._termination_history = termination_history["termination_history"]
+        self.curr_failed_keys = termination_history["failed_keys"]
+        self.update_sampling_prob(self._termination_history)
+
+    def update_hard_sampling_weight(self, failed_keys):
+        if len(failed_keys) > 0:
+            keys = self._motion_data_keys.tolist()
+            idx = [keys.index(k) for k in failed_keys]
+            self._sampling_prob[:] = 0
+            self._sampling_prob[idx] = 1 / len(idx)
+        else:
+            self._sampling_prob = np.ones(self._num_unique_motions) / self._num_unique_motions
+
+    def update_soft_sampling_weight(self, failed_keys):
+        if len(failed_keys) > 0:
+            self.curr_failed_keys = failed_keys
+            keys = self._motion_data_keys.tolist()
+            idx = [keys.index(k) for k in failed_keys]
+            self._termination_history[idx] += 1
+            self.update_sampling_prob(self._termination_history)
+        else:
+            self._sampling_prob = np.ones(self._num_unique_motions) / self._num_unique_motions
+
+    def update_sampling_prob(self, termination_history):
+        if len(self._sampling_prob) == len(termination_history) and termination_history.sum() > 0:
+            self._sampling_prob[:] = termination_history / termination_history.sum()
+            self._termination_history = termination_history
+            return True
+        return False
+
+    # ---- sampling (:277-310), on the device
+    def sample_motions(self, n=1, generator=None):
+        p = torch.as_tensor(self._sampling_batch_prob, dtype=torch.float32, device=self.device)
+        return torch.multinomial(p, n, replacement=True, generator=generator).to(torch.int32)
+
+    def sample_time(self, motion_ids, truncate_time=None, generator=None):
+        phase = torch.rand(motion_ids.shape, device=self.device, generator=generator)
+        length = self.motion_lengths_t[motion_ids.long()]
+        if truncate_time is not None:
+            assert truncate_time >= 0.0
+            length = length - truncate_time
+        return phase * length
+
+    def get_motion_length(self, motion_ids=None):
+        return self.motion_lengths_t if motion_ids is None else self.motion_lengths_t[motion_ids.long()]
+
+    def get_motion_num_steps(self, motion_ids=None):
+        steps = (self._motion_num_frames * 30 / self._motion_fps).astype(int)
+        return steps if motion_ids is None else steps[np.asarray(motion_ids.cpu() if torch.is_tensor(motion_ids) else motion_ids)]
+
+    # ---- lookup (:311-423)
+    def _lookup(self, motion_ids, motion_times, offset, intervaled, fields):
+        ids = torch.as_tensor(motion_ids, device=self.device).to(torch.int32).contiguous()
+        times = torch.as_tensor(motion_times, device=self.device).to(torch.float32).contiguous()
+        off = None if offset is None else torch.as_tensor(offset, device=self.device).to(torch.float32).contiguous()
+        N, J = ids.shape[0], self.skeleton.num_joints
+        shapes = dict(root_pos=(N, 3), root_rot=(N, 4), dof_pos=(N, 3 * (J - 1)), root_vel=(N, 3), root_ang_vel=(N, 3),
+                      dof_vel=(N, 3 * (J - 1)), rg_pos=(N, J, 3), rb_rot=(N, J, 4), body_vel=(N, J, 3), body_ang_vel=(N, J, 3),
+                      qpos=(N, 7 + 3 * (J - 1)), qvel=(N, 6 + 3 * (J - 1)))
+        out = {k: torch.empty(shapes[k], dtype=torch.float32, device=self.device) for k in fields}
+        st = _cabi.MotionState(*[_ptr(out.get(k)) for k in _cabi.MOTION_STATE_FIELDS])
+        self._keep = (ids, times, off, out)
+        self._check(self._lib.ss_motion_state_at(C.byref(self.data), _ptr(ids), _ptr(times), _ptr(off), N, int(intervaled), C.byref(st),
+                                                 self._stream()))
+        return out, ids
+
+    def get_motion_state(self, motion_ids, motion_times, offset=None, with_qpos=False):
+        fields = ["root_pos", "root_rot", "dof_pos", "root_vel", "root_ang_vel", "dof_vel", "rg_pos", "rb_rot", "body_vel", "body_ang_vel"]
+        out, ids = self._lookup(motion_ids, motion_times, offset, False, fields + (["qpos", "qvel"] if with_qpos else []))
+        out["motion_bodies"] = torch.as_tensor(self._motion_bodies, device=self.device)[ids.long()]
+        return out
+
+    def get_motion_state_intervaled(self, motion_ids, motion_times, offset=None):
+        out, ids = self._lookup(motion_ids, motion_times, offset, True, list(_cabi.MOTION_STATE_FIELDS))
+        out["xpos"], out["xquat"] = out.pop("rg_pos"), out.pop("rb_rot")
+        out["dof_pos"] = out["dof_pos"].view(ids.shape[0], -1, 3)
+        out["motion_bodies"] = torch.as_tensor(self._motion_bodies, device=self.device)[ids.long()]
+        return out
+
+    def get_root_pos_smpl(self, motion_ids, motion_times):
+        out, _ = self._lookup(motion_ids, motion_times, None, False, ["root_pos"])
+        return out

@@ -16,7 +16,8 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     from smplsim_amd import _cabi, _lib
     path = _lib.build()
     lib = ctypes.CDLL(path)
-    header = open(os.path.join(ROOT, "include", "smplsim_hip.h")).read()
+    header = "".join(open(os.path.join(ROOT, "include", h)).read() for h in sorted(os.listdir(os.path.join(ROOT, "include"))))
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)        # prose in comments mentions reference functions
     declared = set(re.findall(r"\b(ss_[a-z_]+)\s*\(", header))
     declared -= {"ss_status"}
     assert declared == set(_cabi.EXPORTS), declared ^ set(_cabi.EXPORTS)
@@ -29,8 +30,10 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
 def test_struct_layouts_match_the_header():
     """ctypes mirrors must have the same field order/count as the C structs."""
     from smplsim_amd import _cabi
-    header = open(os.path.join(ROOT, "include", "smplsim_hip.h")).read()
-    for cname, ctype in (("ss_model_desc", _cabi.ModelDesc), ("ss_env_cfg", _cabi.EnvCfg), ("ss_state", _cabi.State)):
+    header = "".join(open(os.path.join(ROOT, "include", h)).read() for h in sorted(os.listdir(os.path.join(ROOT, "include"))))
+    for cname, ctype in (("ss_model_desc", _cabi.ModelDesc), ("ss_env_cfg", _cabi.EnvCfg), ("ss_state", _cabi.State),
+                         ("ss_skeleton", _cabi.Skeleton), ("ss_motion_data", _cabi.MotionData),
+                         ("ss_motion_state", _cabi.MotionState), ("ss_imitation_cfg", _cabi.ImitationCfg)):
         end = header.index("} %s;" % cname)
         body = header[header.rindex("typedef struct {", 0, end) + len("typedef struct {"):end]
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)

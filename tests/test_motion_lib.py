@@ -1,0 +1,255 @@
+"""Motion library (BASELINE config 4): oracle vs the reference's golden vectors, and the kernel source
+(ss_motion.h, run on the CPU emulator) vs both.  GPU twins of the kernel tests live in test_gpu_parity.py.
+
+Tolerances: everything is float32 arithmetic on both sides.  Positions / quaternions / Euler angles 2e-5 absolute;
+linear velocities 2e-3 (differences of float32 positions divided by dt <= 1/30); angular velocities 5e-2 rad/s
+unfiltered, 2e-2 filtered (the reference's angle = acos(2 w^2 - 1) of a float32 quaternion carries ~3e-4 rad of
+rounding noise per frame, times fps).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import motion_oracle as mo  # noqa: E402
+
+G = np.load(os.path.join(ROOT, "tests", "golden", "motion_vectors.npz"))
+TOL = dict(global_translation=2e-5, global_rotation=2e-5, local_rotation=2e-5, dof_pos=2e-5, qpos=2e-5,
+           global_velocity=2e-3, global_root_velocity=2e-3, dof_vels=2e-3,
+           global_angular_velocity=5e-2, global_root_angular_velocity=5e-2, qvel=5e-2)
+NAMES = dict(global_translation="gts", global_rotation="grs", local_rotation="lrs", global_velocity="gvs", global_angular_velocity="gavs",
+             dof_pos="dof_pos", dof_vels="dvs", qpos="qpos", qvel="qvel")
+
+
+def clip_dict():
+    nf = G["num_frames"]
+    st = np.concatenate([[0], np.cumsum(nf)])
+    return {f"clip{m}": dict(pose_aa=G["pose_aa"][st[m]:st[m + 1]].reshape(nf[m], 72), trans=G["trans"][st[m]:st[m + 1]], fps=float(G["fps"][m]))
+            for m in range(len(nf))}
+
+
+def make_lib(clib, filter_vel=True, device="cpu", **kw):
+    from smplsim_amd.motion_lib import MotionLibSMPL, Skeleton
+    from smplsim_amd.mjcf import compile_mjcf
+    from smplsim_amd.mjcf_writer import default_xml_str
+    mc = compile_mjcf(default_xml_str("smpl_humanoid"))
+    sk = Skeleton.from_model_const(mc)
+    assert (sk.smpl_2_mujoco == G["smpl_2_mujoco"]).all() and (sk.parents == G["parents"]).all()
+    assert np.abs(sk.offsets - G["offsets"]).max() < 1e-6        # fixture MJCF == what the golden generator parsed
+    lib = MotionLibSMPL(clip_dict(), sk, filter_vel=filter_vel, _clib=clib, **kw) if clib is not None else \
+        MotionLibSMPL(clip_dict(), sk, filter_vel=filter_vel, device=device, **kw)
+    lib.load_motions(random_sample=False)
+    return lib
+
+
+def check_cooked(lib, pre):
+    for k, attr in NAMES.items():
+        got = getattr(lib, attr).cpu().numpy()
+        ref = G[pre + k].reshape(got.shape)
+        if k.endswith("rotation"):
+            err = np.minimum(np.abs(got - ref).max(-1), np.abs(got + ref).max(-1)).max()
+        else:
+            err = np.abs(got - ref).max()
+        assert err < TOL[k], (pre, k, err)
+
+
+# ------------------------------------------------------------------ oracle pinned by the reference's outputs
+@pytest.mark.parametrize("filt", [True, False])
+def test_oracle_cook_matches_reference_fk_batch(filt):
+    nf = G["num_frames"]
+    st = np.concatenate([[0], np.cumsum(nf)])
+    pre = "f_" if filt else "n_"
+    for m in range(len(nf)):
+        s, e = st[m], st[m + 1]
+        r = mo.cook(G["pose_aa"][s:e], G["trans"][s:e], G["offsets"], G["parents"], G["smpl_2_mujoco"], 1 / float(G["fps"][m]), filt)
+        for k, v in r.items():
+            ref = G[pre + k][s:e]
+            assert np.abs(v.reshape(ref.shape) - ref).max() < TOL[k] * 0.2, (m, k)
+
+
+def test_oracle_fix_continuous_dof_is_exercised_by_the_golden_clips():
+    raw = mo.matrix_to_euler_xyz(mo.quaternion_to_matrix(mo.axis_angle_to_quaternion(G["pose_aa"].astype(np.float64)))[:, G["smpl_2_mujoco"]])[:, 1:]
+    assert (np.abs(raw - G["f_dof_pos"]) > 1e-3).sum() > 100
+
+
+def test_oracle_frame_lookup_and_slerp_match_reference():
+    nf = G["num_frames"].astype(np.int64)
+    starts = np.concatenate([[0], np.cumsum(nf)[:-1]])
+    dt = (1 / G["fps"]).astype(np.float32)
+    L = (1 / G["fps"] * (nf - 1)).astype(np.float32)
+    ids, t = G["q_ids"], G["q_times"]
+    fl = mo.intervaled_frame(t, L[ids], nf[ids], dt[ids]) + starts[ids]
+    assert np.abs(G["f_global_translation"][fl] + G["q_offset"][:, None] - G["iv_xpos"]).max() == 0
+    assert np.abs(G["f_qpos"][fl] - G["iv_qpos"]).max() == 0
+    i0, i1, bl = mo.calc_frame_blend(t, L[ids], nf[ids], dt[ids])
+    assert (i0 == np.floor(G["q_idx0"])).all()
+    s = mo.slerp(G["sl_q0"].astype(np.float64), G["sl_q1"].astype(np.float64), G["sl_t"].astype(np.float64))
+    assert np.abs(s - G["sl_out"]).max() < 2e-4          # float32 acos/sqrt conditioning of the reference near cos = 1
+
+
+# ------------------------------------------------------------------ kernel source on the CPU emulator
+@pytest.fixture(scope="module")
+def emu_lib():
+    from wave_emu import emu
+    return emu.lib()
+
+
+@pytest.mark.parametrize("filt", [True, False])
+def test_emu_cook_matches_reference(emu_lib, filt):
+    check_cooked(make_lib(emu_lib, filt), "f_" if filt else "n_")
+
+
+def test_emu_intervaled_lookup_matches_reference(emu_lib):
+    lib = make_lib(emu_lib)
+    st = lib.get_motion_state_intervaled(G["q_ids"], G["q_times"], offset=G["q_offset"])
+    # the lookup is a gather: compare with the same gather of the emulator-cooked arrays at the reference's frame choice
+    nf = G["num_frames"].astype(np.int64)
+    starts = np.concatenate([[0], np.cumsum(nf)[:-1]])
+    ids = G["q_ids"]
+    dt = (1 / G["fps"]).astype(np.float32)
+    L = (1 / G["fps"] * (nf - 1)).astype(np.float32)
+    fl = mo.intervaled_frame(G["q_times"], L[ids], nf[ids], dt[ids]) + starts[ids]
+    assert np.array_equal(st["xpos"].numpy(), lib.gts.numpy()[fl] + G["q_offset"][:, None])
+    assert np.array_equal(st["xquat"].numpy(), lib.grs.numpy()[fl])
+    assert np.array_equal(st["qpos"].numpy(), lib.qpos.numpy()[fl])      # the reference does not offset qpos (:341-355)
+    assert np.array_equal(st["qvel"].numpy(), lib.qvel.numpy()[fl])
+    assert np.array_equal(st["dof_pos"].numpy(), lib.dof_pos.numpy()[fl])
+    assert np.array_equal(st["body_vel"].numpy(), lib.gvs.numpy()[fl])
+    # and with the reference's own outputs
+    for k in ("root_pos", "root_rot", "root_vel", "xpos", "xquat", "body_vel", "qpos"):
+        tol = 2e-3 if "vel" in k else 2e-5
+        assert np.abs(st[k].numpy() - G["iv_" + k].reshape(st[k].shape)).max() < tol, k
+
+
+def lib_arrays(lib):
+    nf = lib._motion_num_frames
+    return dict(gts=lib.gts.cpu().numpy().astype(np.float64), grs=lib.grs.cpu().numpy().astype(np.float64), gvs=lib.gvs.cpu().numpy().astype(np.float64),
+                gavs=lib.gavs.cpu().numpy().astype(np.float64), dof_pos=lib.dof_pos.cpu().numpy().astype(np.float64), dvs=lib.dvs.cpu().numpy().astype(np.float64),
+                length_starts=lib.length_starts, num_frames=nf, dt=lib._motion_dt.astype(np.float64), lengths=lib._motion_lengths.astype(np.float64))
+
+
+def check_blended(lib, rs, n=200):
+    M = lib.num_current_motions()
+    ids = rs.integers(0, M, size=n)
+    times = (rs.uniform(-0.1, 1.1, size=n) * lib._motion_lengths[ids]).astype(np.float32)
+    off = rs.normal(size=(n, 3)).astype(np.float32)
+    got = lib.get_motion_state(ids, times, offset=off, with_qpos=True)
+    want = mo.motion_state(lib_arrays(lib), ids, times.astype(np.float64), off.astype(np.float64))
+    for k, v in want.items():
+        g = got[k].cpu().numpy()
+        if k.endswith("rot"):
+            err = np.minimum(np.abs(g - v).max(-1), np.abs(g + v).max(-1)).max()
+        else:
+            err = np.abs(g - v.reshape(g.shape)).max()
+        # float32 blend weight (error ~1e-5) times the frame-to-frame change, which is 100s of rad/s for the velocities here
+        assert err < (2e-4 if k.endswith("rot") else 5e-3 if "vel" in k else 1e-4), (k, err)
+    # qpos/qvel of the blended state: root pose + Euler dofs, body-frame root angular velocity
+    qp, qv = got["qpos"].cpu().numpy(), got["qvel"].cpu().numpy()
+    assert np.abs(qp[:, :3] - want["root_pos"]).max() < 1e-4 and np.abs(qp[:, 7:] - want["dof_pos"]).max() < 1e-4
+    R = mo.quaternion_to_matrix(want["root_rot"])
+    assert np.abs(qv[:, 3:6] - np.einsum("nba,nb->na", R, want["root_ang_vel"])).max() < 5e-3
+    assert np.abs(qv[:, 6:] - want["dof_vel"]).max() < 5e-3
+
+
+def test_emu_blended_lookup_matches_oracle(emu_lib):
+    check_blended(make_lib(emu_lib), np.random.default_rng(5))
+
+
+def random_sim_state(rs, n, J):
+    pos = rs.normal(size=(n, J, 3)) * 0.5 + np.array([0, 0, 0.9])
+    q = rs.normal(size=(n, J, 4))
+    q /= np.linalg.norm(q, axis=-1, keepdims=True)
+    vel = rs.normal(size=(n, J, 6))
+    return pos, q, vel
+
+
+def check_imitation(lib, clib, rs, n=37, device="cpu", stream=None):
+    import ctypes as C
+    from smplsim_amd import _cabi
+    J = 24
+    ids = rs.integers(0, lib.num_current_motions(), size=n).astype(np.int32)
+    times = (rs.uniform(0, 0.9, size=n) * lib._motion_lengths[ids]).astype(np.float32)
+    off = rs.normal(size=(n, 3)).astype(np.float32) * 0.1
+    # simulated humanoid = reference pose at `times` + noise, so that every reward term is in its sensitive range
+    ref = mo.motion_state(lib_arrays(lib), ids, times.astype(np.float64), off.astype(np.float64))
+    pos = ref["rg_pos"] + rs.normal(size=(n, J, 3)) * 0.05
+    dq = mo.axis_angle_to_quaternion(rs.normal(size=(n, J, 3)) * 0.2)
+    quat = mo.quat_mul(dq, ref["rb_rot"])
+    vel = np.concatenate([ref["body_vel"] + rs.normal(size=(n, J, 3)), ref["body_ang_vel"] + rs.normal(size=(n, J, 3))], -1)
+    pos[: n // 4] += rs.normal(size=(n // 4, 1, 3)) * 0.4          # some envs far off: termination
+    xmat = mo.quaternion_to_matrix(quat).reshape(n, J, 9)
+    cfg = _cabi.ImitationCfg(100.0, 10.0, 0.1, 0.1, 0.5, 0.3, 0.1, 0.1, 0.25, 1.0 / 30)
+    t = lambda a, dt=torch.float32: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(device)  # noqa: E731
+    d_ids, d_times, d_off, d_pos, d_mat, d_vel = t(ids, torch.int32), t(times), t(off), t(pos), t(xmat), t(vel)
+    obs = torch.zeros(n, 24 * J, device=device); rew = torch.zeros(n, device=device); parts = torch.zeros(n, 4, device=device)
+    term = torch.zeros(n, dtype=torch.uint8, device=device)
+    p = lambda x: C.c_void_p(x.data_ptr())  # noqa: E731
+    rc = clib.ss_imitation_step(C.byref(lib.data), C.byref(cfg), p(d_ids), p(d_times), p(d_off), n, p(d_pos), p(d_mat), p(d_vel),
+                                p(obs), p(rew), p(parts), p(term), stream)
+    assert rc == 0, clib.ss_last_error()
+    if device != "cpu":
+        torch.cuda.synchronize()
+    nxt = mo.motion_state(lib_arrays(lib), ids, (times + np.float32(1.0 / 30)).astype(np.float64), off.astype(np.float64))
+    want_obs = mo.imitation_obs(pos, quat, vel[..., :3], vel[..., 3:], nxt["rg_pos"], nxt["rb_rot"], nxt["body_vel"], nxt["body_ang_vel"])
+    want_rew, want_parts = mo.imitation_reward(pos, quat, vel[..., :3], vel[..., 3:], ref["rg_pos"], ref["rb_rot"], ref["body_vel"], ref["body_ang_vel"])
+    want_term = mo.imitation_reset(pos, ref["rg_pos"], 0.25)
+    assert np.abs(obs.cpu().numpy() - want_obs).max() < 2e-4
+    assert np.abs(parts.cpu().numpy() - want_parts).max() < 2e-5
+    assert np.abs(rew.cpu().numpy() - want_rew).max() < 2e-5
+    assert want_parts.min() < 0.5 < want_parts.max()
+    margin = np.abs(np.linalg.norm(pos - ref["rg_pos"], axis=-1).mean(-1) - 0.25) > 1e-4
+    assert (term.cpu().numpy().astype(bool) == want_term)[margin].all() and want_term.any() and not want_term.all()
+
+
+def test_emu_imitation_step_matches_oracle(emu_lib):
+    check_imitation(make_lib(emu_lib), emu_lib, np.random.default_rng(11))
+
+
+def test_motion_api_error_paths(emu_lib):
+    import ctypes as C
+    from smplsim_amd import _cabi
+    lib = make_lib(emu_lib)
+    par = np.array([-1, 0, 0, 1], np.int32)          # body 3's parent (1) is not on the chain of body 2: not depth-first
+    perm = np.arange(4, dtype=np.int32)
+    sk = _cabi.Skeleton(4, par.ctypes.data_as(C.c_void_p), perm.ctypes.data_as(C.c_void_p))
+    assert emu_lib.ss_motion_cook(C.byref(sk), C.byref(lib.data), 1, None) == -1
+    assert b"depth-first" in emu_lib.ss_last_error()
+    par2 = np.array(G["parents"], np.int32)
+    bad = np.zeros(24, np.int32)
+    sk = _cabi.Skeleton(24, par2.ctypes.data_as(C.c_void_p), bad.ctypes.data_as(C.c_void_p))
+    assert emu_lib.ss_motion_cook(C.byref(sk), C.byref(lib.data), 1, None) == -1
+    assert b"permutation" in emu_lib.ss_last_error()
+    st = _cabi.MotionState()
+    assert emu_lib.ss_motion_state_at(C.byref(lib.data), None, None, None, 4, 0, C.byref(st), None) == -1
+    assert emu_lib.ss_motion_state_at(C.byref(lib.data), C.c_void_p(1), C.c_void_p(1), None, 0, 0, C.byref(st), None) == -1
+
+
+def test_motion_lib_needs_gpu_without_test_hook():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from smplsim_amd.motion_lib import MotionLibSMPL, Skeleton
+    sk = Skeleton([f"b{i}" for i in range(3)], [-1, 0, 1], np.zeros((3, 3)))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        MotionLibSMPL({"a": dict(pose_aa=np.zeros((4, 9)), trans=np.zeros((4, 3)))}, sk)
+
+
+def test_sampling_and_history_interface(emu_lib):
+    lib = make_lib(emu_lib)
+    ids = lib.sample_motions(50)
+    assert ids.dtype == torch.int32 and int(ids.min()) >= 0 and int(ids.max()) < 3
+    t = lib.sample_time(ids)
+    assert (t >= 0).all() and (t <= lib.get_motion_length(ids)).all()
+    assert lib.num_current_motions() == 3 and lib.num_all_motions() == 3
+    assert abs(lib.get_total_length() - float(((G["num_frames"] - 1) / G["fps"]).sum())) < 1e-4
+    lib.update_soft_sampling_weight(["clip1"])
+    assert lib._sampling_prob[1] == 1.0
+    hist = lib.get_termination_history()
+    lib.update_hard_sampling_weight([])
+    assert np.allclose(lib._sampling_prob, 1 / 3)
+    lib.set_termination_history(hist)
+    assert lib._sampling_prob[1] == 1.0
+    assert list(lib.get_motion_num_steps()) == [int(n * 30 / f) for n, f in zip(G["num_frames"], G["fps"])]

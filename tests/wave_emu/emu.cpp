@@ -17,6 +17,7 @@
 
 #include "../../smplsim_amd/csrc/ss_api.h"
 #include "../../smplsim_amd/csrc/ss_kernel.h"
+#include "../../smplsim_amd/csrc/ss_motion_api.h"
 
 extern "C" void emu_switch(void **save_sp, void *load_sp);
 asm(R"(
@@ -236,6 +237,28 @@ struct EmuBackend {
     }
     return nullptr;
   }
+  // ---- motion library: the element functions run as plain loops, the two wave functions on the 64-fiber machine
+  struct FixCtx { const ss::mo::CookArgs *a; int m; Machine *mach; };
+  static void fix_entry(int lane, void *arg) { FixCtx *c = (FixCtx *)arg; WaveEmu w{c->mach, lane}; ss::mo::dof_fix_clip(&w, *c->a, c->m); }
+  struct ImCtx { const ss::mo::ImArgs *a; int wave; Machine *mach; };
+  template <int LPE> static void im_entry(int lane, void *arg) { ImCtx *c = (ImCtx *)arg; WaveEmu w{c->mach, lane}; ss::mo::imitation_wave<WaveEmu, LPE>(&w, *c->a, c->wave); }
+  static Machine *machine() { static thread_local Machine *m = new Machine(); return m; }
+  static const char *motion_cook(const ss::mo::CookArgs &a, void *) {
+    float stk[ss::mo::kMaxDepth * ss::mo::kStackSlots];
+    for (int f = 0; f < a.d.num_frames; f++) ss::mo::fk_frame(a, f, stk, 1);
+    for (int m = 0; m < a.d.num_motions; m++) { FixCtx c{&a, m, machine()}; run_wave(machine(), fix_entry, &c); }
+    for (int f = 0; f < a.d.num_frames; f++) for (int j = 0; j < a.sk.nb; j++) ss::mo::vel_elem(a, f, j);
+    return nullptr;
+  }
+  static const char *motion_state(const ss::mo::StateArgs &a, void *) {
+    for (int n = 0; n < a.N; n++) for (int j = 0; j < a.d.nbody; j++) ss::mo::state_elem(a, n, j);
+    return nullptr;
+  }
+  static const char *imitation(const ss::mo::ImArgs &a, void *) {
+    const int lpe = a.d.nbody <= 32 ? 32 : 64, per = 64 / lpe;
+    for (int wv = 0; wv * per < a.N; wv++) { ImCtx c{&a, wv, machine()}; run_wave(machine(), lpe == 32 ? im_entry<32> : im_entry<64>, &c); }
+    return nullptr;
+  }
   static const char *launch(const ss::KArgs &k, int nenv, int envs_per_wg, size_t lds_bytes, void *) {
     (void)envs_per_wg; (void)lds_bytes;
     static thread_local Machine *m = new Machine();
@@ -259,3 +282,4 @@ struct EmuBackend {
 }  // namespace
 
 SS_DEFINE_C_API(EmuBackend)
+SS_DEFINE_MOTION_API(EmuBackend)
