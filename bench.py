@@ -28,6 +28,10 @@ WORKLOADS = {
             "device-side autoreset",
     "getup": "BASELINE config 3 shard: {N} SMPL humanoids, env=getup (obs 290, height reward, contact termination, 60-step "
              "recovery), StateInit.Fall (45 warm-up mj_steps per reset), uniform(-1,1) actions (ms_per_step includes the masked Fall-reset launch, kernel_ms is the step launch)",
+    "imitation": "BASELINE config 5 shard: {N} SMPL humanoids tracking motion clips (synthetic smooth clips in the AMASS pickle "
+                 "format; no dataset in the image), reference-state init, PD replay of the clip as the policy, per step: ss_step "
+                 "(obs v2) + ss_kinematics + ss_imitation_step (clip lookup at t and t+dt, 576-float task obs, PHC tracking reward, "
+                 "early termination) + in-place re-initialisation of finished envs",
     "smplx": "BASELINE config 4: {N} SMPL-X/H-layout humanoids (52 bodies, nv=159, nu=153), base env, obs v1 (625 f32), uniform(-1,1) actions",
 }
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -80,14 +84,143 @@ def cpu_baseline(seconds=12.0):
                       f"(oracle/oracle.c; NOT MuJoCo), {cores} threads (cgroup/affinity-usable cores), {dt:.1f}s"}
 
 
+def synthetic_clips(num, frames, seed):
+    """Smooth random clips in the reference's pickle format ({key: {pose_aa [T,72], trans [T,3], fps}}): a standing pose plus
+    low-frequency joint oscillations and a slow walk of the root (there is no AMASS data in the image)."""
+    rs = np.random.default_rng(seed)
+    t = np.arange(frames)[:, None, None] / 30.0
+    clips = {}
+    for c in range(num):
+        amp = rs.uniform(0.05, 0.35, size=(1, 24, 1)) * rs.uniform(0.2, 1.0, size=(1, 24, 3))
+        amp[:, 0] *= 0.2
+        pose = amp * np.sin(2 * np.pi * rs.uniform(0.2, 1.2, size=(1, 24, 3)) * t + rs.uniform(0, 2 * np.pi, size=(1, 24, 3)))
+        # SMPL rest pose is y-up: the root rotation that stands the body up on the z-up floor (quaternion .5,.5,.5,.5)
+        from scipy.spatial.transform import Rotation as sRot
+        root = sRot.from_euler("z", rs.uniform(-np.pi, np.pi)) * sRot.from_quat([0.5, 0.5, 0.5, 0.5])
+        pose[:, 0] = (root * sRot.from_rotvec(pose[:, 0])).as_rotvec()
+        tt = t[:, 0, 0]
+        trans = np.stack([0.3 * tt * np.cos(c), 0.3 * tt * np.sin(c), 0.94 + 0.01 * np.sin(2 * tt)], -1)
+        clips[f"synthetic_{c:04d}"] = {"pose_aa": pose.reshape(frames, 72).astype(np.float32), "trans": trans.astype(np.float32), "fps": 30}
+    return clips
+
+
+def run_imitation(args, rank, local_rank, world, dist, dev):
+    import ctypes as C
+    import torch
+    from smplsim_amd import shard
+    from smplsim_amd._lib import lib
+    from smplsim_amd.batch import ShardModel, _ptr
+    from smplsim_amd.imitation import SMPLSimImitationVecEnv
+    from smplsim_amd.motion_lib import MotionLibSMPL, Skeleton
+    N = args.envs_per_gpu
+    model = ShardModel(device=local_rank)
+    clips = synthetic_clips(256, 300, shard.shard_seed(77, rank))
+    ml = MotionLibSMPL(clips, Skeleton.from_model_const(model.mc), device=local_rank, seed=shard.shard_seed(5, rank))
+    ml.load_motions()                                           # warm-up (module load), then timed
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ml.load_motions()
+    torch.cuda.synchronize()
+    load_s = time.perf_counter() - t0
+    F, J = ml.data.num_frames, 24
+    env = SMPLSimImitationVecEnv(N, ml, model=model, device=local_rank, seed=shard.shard_seed(1234, rank))
+    env.reset()
+
+    def one_step():
+        return env.step(env.reference_actions())
+
+    for _ in range(args.warmup):
+        one_step()
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    shard.barrier(dist, world, dev)
+    t0 = time.perf_counter()
+    rew_sum, ended = torch.zeros((), device=dev), torch.zeros((), device=dev)
+    for i in range(args.steps):
+        a = env.reference_actions()
+        ev0[i].record()
+        env.base.step(a)                                         # the physics launch (dominant kernel), timed per launch
+        ev1[i].record()
+        env._imitation(env.task_obs, env.rew_buf, env.reward_parts, env.terminated)
+        env._assemble()
+        done = env.terminated.bool() | ((env.times + env.dt) >= env.motion_len)
+        rew_sum += env.rew_buf.mean(); ended += done.sum()
+        env.reset(mask=done)
+    shard.barrier(dist, world, dev)
+    elapsed = shard.max_over_ranks(dist, world, time.perf_counter() - t0, dev)
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    # the row's own kernels, timed alone on this stream: imitation step (per launch) and the three cooking launches
+    reps = 200
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    e0.record()
+    for _ in range(reps):
+        lib().ss_imitation_step(C.byref(ml.data), C.byref(env.cfg), _ptr(env.motion_ids), _ptr(env.times), _ptr(env.offset), N, _ptr(env.xpos),
+                                _ptr(env.xmat), _ptr(env.base.body_vel), _ptr(env.task_obs), _ptr(env.rew_buf), _ptr(env.reward_parts),
+                                _ptr(env.terminated), st)
+    e1.record(); torch.cuda.synchronize()
+    im_ms = e0.elapsed_time(e1) / reps
+    from smplsim_amd import _cabi
+    sk = _cabi.Skeleton(J, ml._sk_keep[0].ctypes.data_as(C.c_void_p), ml._sk_keep[1].ctypes.data_as(C.c_void_p))
+    e0.record()
+    for _ in range(20):
+        lib().ss_motion_cook(C.byref(sk), C.byref(ml.data), 1, st)
+    e1.record(); torch.cuda.synchronize()
+    cook_ms = e0.elapsed_time(e1) / 20
+    if rank == 0:
+        im_bytes = 4 * (18 * J + 2 * 2 * 13 * J + 24 * J + 5) + 1          # sim state + 2 lookups x 2 frames + obs, reward, parts, flag
+        cook_bytes = 4 * (75 + 13 * J + 4 * J + 6 * J + 6 * (J - 1) + 76 + 75)  # raw clip in; gts,grs,lrs,gvs,gavs,dof_pos,dvs,qpos,qvel out
+        ach = N * im_bytes / (im_ms * 1e-3) / 1e9
+        out = {
+            "metric": "env-steps/sec (whole node), motion-imitation rollout", "value": shard.whole_job_throughput(N * world * args.steps, elapsed),
+            "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": WORKLOADS["imitation"].format(N=N), "envs_per_gpu": N, "clips": ml.num_current_motions(), "frames": F,
+                       "parallelism": f"independent shards x{world} (no collective)", "launch": env.base.launch_info(),
+                       "mean_reward": float(rew_sum.item()) / args.steps, "episodes_ended": int(ended.item()),
+                       "obs_finite": bool(torch.isfinite(env.obs_buf).all().item()),
+                       "step_kernel_ms": kern_ms, "load_motions_s (upload + cook)": load_s,
+                       "cook": {"ms": cook_ms, "frames_per_s": F / (cook_ms * 1e-3), "GB/s": F * cook_bytes / (cook_ms * 1e-3) / 1e9,
+                                "algorithmic_bytes_per_frame": cook_bytes}},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "ss_imitation_kernel<32>", "kernel_ms": im_ms, "algorithmic_bytes_per_env_step": im_bytes,
+                         "note": f"{N} envs x {im_bytes} B is far below what fills HBM for the ~us a launch lasts: launch-latency bound at this size; "
+                                 "the step's time is the physics launch (step_kernel_ms)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_motion()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline_motion():
+    """The NumPy restatement of the reference's per-clip fk_batch (oracle/motion_oracle.py; 'port') on a bounded sample."""
+    from oracle import motion_oracle as mo
+    from smplsim_amd.mjcf import compile_mjcf
+    from smplsim_amd.mjcf_writer import default_xml_str
+    from smplsim_amd.motion_lib import Skeleton
+    sk = Skeleton.from_model_const(compile_mjcf(default_xml_str("smpl_humanoid")))
+    clips = list(synthetic_clips(8, 300, 1).values())
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < 10.0:
+        for c in clips:
+            mo.cook(c["pose_aa"].reshape(-1, 24, 3), c["trans"], sk.offsets, sk.parents, sk.smpl_2_mujoco, 1 / 30, True)
+        n += len(clips)
+    dt = time.perf_counter() - t0
+    return {"value": n * 300 / dt, "unit": "frames/s (clip cooking)", "cores": 1, "kind": "port",
+            "sample": f"{n} clips x 300 frames through oracle/motion_oracle.cook (NumPy float64 restatement of fk_batch), {dt:.2f}s; "
+                      "compare with config.cook.frames_per_s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--envs-per-gpu", type=int, default=None, help="default 4096 (imitation: 1024 = 8192 envs on 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="smpl", choices=["smpl", "getup", "smplx"],
+    ap.add_argument("--workload", default="smpl", choices=["smpl", "getup", "smplx", "imitation"],
                     help="smpl = BASELINE config 2 (the metric); getup = config 3 shard (Fall init, getup task); smplx = config 4")
     args = ap.parse_args()
 
@@ -99,7 +232,11 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     from smplsim_amd.batch import SMPLSimVecEnv
+    if args.envs_per_gpu is None:
+        args.envs_per_gpu = 1024 if args.workload == "imitation" else ENVS_PER_GPU
     N = args.envs_per_gpu
+    if args.workload == "imitation":
+        return run_imitation(args, rank, local_rank, world, dist, dev)
     if args.workload == "smpl":
         env = SMPLSimVecEnv(N, device=local_rank, task="HumanoidEnv", state_init="Default", self_obs_v=1,
                             autoreset=True, seed=shard.shard_seed(1234, rank))

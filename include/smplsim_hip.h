@@ -32,7 +32,9 @@ typedef enum {
 
 enum { SS_GEOM_BOX = 0, SS_GEOM_CAPSULE = 1 };
 enum { SS_TASK_BASE = 0, SS_TASK_SPEED = 1, SS_TASK_GETUP = 2, SS_TASK_REACH = 3 };   /* reference tasks/humanoid_{speed,getup,reach}.py */
-enum { SS_INIT_DEFAULT = 0, SS_INIT_FALL = 1 };                        /* HumanoidEnv.StateInit, humanoid_env.py:141-146 */
+enum { SS_INIT_DEFAULT = 0, SS_INIT_FALL = 1,                          /* HumanoidEnv.StateInit, humanoid_env.py:141-146 */
+       SS_INIT_EXTERNAL = 2 };  /* reference-state init (imitation): ss_reset keeps the qpos/qvel the caller wrote into ss_state
+                                   (e.g. ss_motion_state_at's qpos/qvel) and runs the reset's mj_forward + observation on them */
 enum { SS_CTRL_UHC_PD = 0, SS_CTRL_PD = 1, SS_CTRL_TORQUE = 2, SS_CTRL_SIMPLE_PID = 3, SS_CTRL_DEFAULT = 4 };   /* control_mode, humanoid_env.py:312-323 */
 
 /* Compiled model constants (host pointers, float64; produced by smplsim_amd.mjcf.compile_mjcf).

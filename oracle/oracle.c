@@ -930,8 +930,10 @@ void om_env_reset(om_env *e, const double *fall_actions, const double *task_rand
   static const double zero2[4] = {0, 0, 0, 0};
   if (e->cfg.task == OM_TASK_GETUP) e->recovery_counter = e->cfg.recovery_steps;
   if (e->cfg.task != OM_TASK_BASE) env_reset_task(e, task_rand ? task_rand : zero2);  /* uses the OLD cur_t */
-  memset(d->qpos, 0, sizeof d->qpos); memset(d->qvel, 0, sizeof d->qvel);
-  if (e->cfg.state_init == OM_INIT_DEFAULT) {
+  if (e->cfg.state_init != OM_INIT_EXTERNAL) { memset(d->qpos, 0, sizeof d->qpos); memset(d->qvel, 0, sizeof d->qvel); }
+  if (e->cfg.state_init == OM_INIT_EXTERNAL) {
+    /* init_humanoid with a caller-provided state (reference-state init): only the mj_forward below */
+  } else if (e->cfg.state_init == OM_INIT_DEFAULT) {
     d->qpos[2] = 0.94; d->qpos[3] = d->qpos[4] = d->qpos[5] = d->qpos[6] = 0.5;
   } else {
     d->qpos[2] = 0.3; d->qpos[3] = 1;

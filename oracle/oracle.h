@@ -74,7 +74,7 @@ void om_set_pid_dt(om_data *d, double dt);                  /* dt handed to Simp
 
 /* ---- env layer (reference humanoid_env.py / humanoid_task.py / tasks) ---- */
 enum { OM_TASK_BASE = 0, OM_TASK_SPEED = 1, OM_TASK_GETUP = 2, OM_TASK_REACH = 3 };
-enum { OM_INIT_DEFAULT = 0, OM_INIT_FALL = 1 };
+enum { OM_INIT_DEFAULT = 0, OM_INIT_FALL = 1, OM_INIT_EXTERNAL = 2 /* keep the caller's qpos/qvel (reference-state init) */ };
 typedef struct {
   int task, state_init, self_obs_v, control_mode /*0 uhc_pd,1 pd,2 torque,3 simple_pid,4 default*/;
   int episode_length, control_freq_inv, root_height_obs;

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 TASK_BASE, TASK_SPEED, TASK_GETUP, TASK_REACH = 0, 1, 2, 3
-INIT_DEFAULT, INIT_FALL = 0, 1
+INIT_DEFAULT, INIT_FALL, INIT_EXTERNAL = 0, 1, 2
 
 # field ids (oracle.h)
 M_MASS, M_IPOS, M_IQUAT, M_INERTIA, M_GPOS, M_GQUAT, M_GSIZE, M_BODY_INVW, M_DOF_INVW, M_RANGE = range(10)

@@ -1368,12 +1368,16 @@ SS_DEV bool run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env, 
   // ---- initial LDS state
   sim.load(sim.a, wg, h.nv);
   if (mode == MODE_RESET) {
-    for (int i = lane; i < h.nq; i += 64) sim.q[i] = 0.f;
-    for (int i = lane; i < h.nv; i += 64) sim.v[i] = 0.f;
-    w->sync();
-    if (lane == 0) {
-      if (cf.state_init == SS_INIT_DEFAULT) { sim.q[2] = 0.94f; sim.q[3] = sim.q[4] = sim.q[5] = sim.q[6] = 0.5f; }
-      else { sim.q[2] = 0.3f; sim.q[3] = 1.f; }
+    if (cf.state_init == SS_INIT_EXTERNAL) {                  // reference-state init: the caller wrote qpos / qvel
+      sim.load(sim.q, qg, h.nq); sim.load(sim.v, vg, h.nv);
+    } else {
+      for (int i = lane; i < h.nq; i += 64) sim.q[i] = 0.f;
+      for (int i = lane; i < h.nv; i += 64) sim.v[i] = 0.f;
+      w->sync();
+      if (lane == 0) {
+        if (cf.state_init == SS_INIT_DEFAULT) { sim.q[2] = 0.94f; sim.q[3] = sim.q[4] = sim.q[5] = sim.q[6] = 0.5f; }
+        else { sim.q[2] = 0.3f; sim.q[3] = 1.f; }
+      }
     }
     nsub = cf.state_init == SS_INIT_FALL ? 3 * cf.control_freq_inv : 0;
   } else if (mode == MODE_KINEMATICS || is_debug) {

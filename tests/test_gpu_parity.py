@@ -450,3 +450,97 @@ def test_c_abi_error_paths_on_gpu():
     batch = C.c_void_p()
     assert L.ss_batch_create(None, None, C.byref(st), C.byref(batch)) == -1 and L.ss_last_error()
     assert L.ss_step(None, None, None, None, None, None, None, None) == -1
+
+
+# ---------------------------------------------------------------- motion library / imitation
+@pytest.mark.parametrize("filt", [True, False])
+def test_motion_cook_on_gpu_matches_reference_vectors(filt):
+    import test_motion_lib as T
+    lib = T.make_lib(None, filt, device=0)
+    torch.cuda.synchronize()
+    T.check_cooked(lib, "f_" if filt else "n_")
+
+
+def test_motion_lookup_on_gpu_matches_oracle_and_reference():
+    import test_motion_lib as T
+    lib = T.make_lib(None, device=0)
+    T.check_blended(lib, np.random.default_rng(5), n=1000)
+    st = lib.get_motion_state_intervaled(T.G["q_ids"], T.G["q_times"], offset=T.G["q_offset"])
+    for k in ("root_pos", "root_rot", "root_vel", "xpos", "xquat", "body_vel", "qpos"):
+        tol = 2e-3 if "vel" in k else 2e-5
+        assert np.abs(_np(st[k]) - T.G["iv_" + k].reshape(st[k].shape)).max() < tol, k
+
+
+def test_imitation_step_on_gpu_matches_oracle():
+    import test_motion_lib as T
+    from smplsim_amd import _lib
+    lib = T.make_lib(None, device=0)
+    T.check_imitation(lib, _lib.lib(), np.random.default_rng(11), n=37, device="cuda")
+    T.check_imitation(lib, _lib.lib(), np.random.default_rng(12), n=1000, device="cuda")
+
+
+def test_imitation_env_rollout_on_gpu_tracks_oracle():
+    """Reference-state init + PD replay of the clip for a few control steps: the simulator state against the float64 oracle
+    env started from the same state, the task observation / reward against motion_oracle on the GPU's own body state."""
+    import test_motion_lib as T
+    from oracle import motion_oracle as mo
+    from smplsim_amd.imitation import SMPLSimImitationVecEnv
+    lib = T.make_lib(None, device=0)
+    n, J = 6, 24
+    env = SMPLSimImitationVecEnv(n, lib, autoreset=False, seed=3)
+    ids = np.array([0, 1, 2, 0, 1, 2], np.int32)
+    t0 = np.array([0.1, 0.2, 0.3, 0.55, 0.4, 0.7], np.float32)
+    env.offset[:, 2] = 0.05                                  # the synthetic clips are not height-fixed: lift them off the floor
+    obs0, _ = env.reset(motion_ids=ids, start_times=t0)
+    torch.cuda.synchronize()
+    assert obs0.shape == (n, env.base.obs_size + 24 * J) and torch.isfinite(obs0).all()
+    arr = T.lib_arrays(lib)
+    off = _np(env.offset).astype(np.float64)
+    oenvs = []
+    for i in range(n):
+        oe = O.OracleEnv(oracle_model(), state_init=O.INIT_EXTERNAL, self_obs_v=2, episode_length=10 ** 6)
+        oe.data.qpos = _np(env.base.qpos)[i].astype(np.float64); oe.data.qvel = _np(env.base.qvel)[i].astype(np.float64)
+        assert np.abs(oe.reset() - _np(obs0)[i, :env.base.obs_size]).max() < 2e-4
+        oenvs.append(oe)
+    want0 = mo.motion_state(arr, ids, t0.astype(np.float64), off)
+    assert np.abs(_np(env.base.qpos)[:, :3] - want0["root_pos"]).max() < 1e-4
+    for k in range(4):
+        act = env.reference_actions()
+        obs, rew, term, trunc, info = env.step(act)
+        torch.cuda.synchronize()
+        a = _np(act).astype(np.float64)
+        for i, oe in enumerate(oenvs):
+            oe.step(a[i])
+            assert np.abs(oe.data.qpos - _np(env.base.qpos)[i]).max() < 5e-4, (k, i)
+        times = t0 + np.float32((k + 1) * env.dt)
+        assert np.abs(_np(env.times) - times).max() < 1e-6
+        xpos, xmat, bv = _np(env.xpos).astype(np.float64), _np(env.xmat).astype(np.float64), _np(env.base.body_vel).astype(np.float64)
+        quat = mo.matrix_to_quaternion(xmat.reshape(n, J, 3, 3))
+        ref = mo.motion_state(arr, ids, times.astype(np.float64), off)
+        fut = mo.motion_state(arr, ids, (times + np.float32(env.dt)).astype(np.float64), off)
+        want_obs = mo.imitation_obs(xpos, quat, bv[..., :3], bv[..., 3:], fut["rg_pos"], fut["rb_rot"], fut["body_vel"], fut["body_ang_vel"])
+        want_rew, _ = mo.imitation_reward(xpos, quat, bv[..., :3], bv[..., 3:], ref["rg_pos"], ref["rb_rot"], ref["body_vel"], ref["body_ang_vel"])
+        assert np.abs(_np(obs)[:, env.base.obs_size:] - want_obs).max() < 5e-4
+        assert np.abs(_np(rew) - want_rew).max() < 5e-5
+        assert not trunc.any()
+
+
+def test_imitation_env_autoreset_and_truncation_on_gpu():
+    import test_motion_lib as T
+    from smplsim_amd.imitation import SMPLSimImitationVecEnv
+    lib = T.make_lib(None, device=0)
+    env = SMPLSimImitationVecEnv(64, lib, seed=1)
+    env.offset[:, 2] = 0.05
+    obs, _ = env.reset()
+    ended = torch.zeros(64, dtype=torch.bool, device=env.device)
+    for k in range(45):                                      # the longest clip is 61 frames at 60 fps = 30 control steps
+        obs, rew, term, trunc, info = env.step(env.reference_actions())
+        done = term | trunc
+        ended |= done
+        # envs that just ended were re-initialised on a clip: time restarts, the final observation is kept for the learner
+        assert (env.base.cur_t[done] == 0).all() and (env.base.cur_t[~done] > 0).all()
+        assert torch.isfinite(obs).all() and torch.isfinite(rew).all() and (rew >= 0).all() and (rew <= 1.0001).all()
+        assert "final_observation" in info
+    torch.cuda.synchronize()
+    assert ended.all()
+    assert ((env.start_times + env.base.cur_t * env.dt) <= env.motion_len + 1e-5).all()

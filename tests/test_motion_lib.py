@@ -253,3 +253,54 @@ def test_sampling_and_history_interface(emu_lib):
     lib.set_termination_history(hist)
     assert lib._sampling_prob[1] == 1.0
     assert list(lib.get_motion_num_steps()) == [int(n * 30 / f) for n, f in zip(G["num_frames"], G["fps"])]
+
+
+# ------------------------------------------------------------------ reference-state init + imitation rollout (emulator)
+def test_emu_external_state_init_and_imitation_rollout_track_oracle(emu_lib):
+    """ss_reset with StateInit External on a clip's qpos/qvel, then 3 control steps replaying the clip through the PD
+    controller: simulator state vs the float64 oracle env, task obs / reward vs motion_oracle on the emulator's own state."""
+    import ctypes as C
+    from helpers import FEET, model_const, oracle_model, pd_tables
+    from oracle import oracle as O
+    from smplsim_amd import _cabi
+    from wave_emu import emu
+    lib = make_lib(emu_lib)
+    mc = model_const()
+    n, J = 3, 24
+    eb = emu.EmuBatch(mc, pd_tables(mc), n, legal_bodies=FEET, state_init=_cabi.INIT_EXTERNAL, self_obs_v=2, episode_length=10 ** 6)
+    ids = np.array([0, 1, 0], np.int32)
+    t0 = np.array([0.1, 0.2, 0.55], np.float32)
+    st = lib.get_motion_state(ids, t0, with_qpos=True)
+    eb.qpos[:], eb.qvel[:] = st["qpos"].numpy(), st["qvel"].numpy()
+    eb.qpos[:, 2] += 0.05                                    # lift the clips (they were not height-fixed) off the floor
+    obs0 = eb.reset()
+    oenvs = []
+    for i in range(n):
+        oe = O.OracleEnv(oracle_model(), state_init=O.INIT_EXTERNAL, self_obs_v=2, episode_length=10 ** 6)
+        oe.data.qpos = eb.qpos[i].astype(np.float64); oe.data.qvel = eb.qvel[i].astype(np.float64)
+        assert np.abs(oe.reset() - obs0[i]).max() < 2e-4
+        oenvs.append(oe)
+    assert (eb.cur_t == 0).all()
+    dt = 15 / 450.0
+    cfg = _cabi.ImitationCfg(100.0, 10.0, 0.1, 0.1, 0.5, 0.3, 0.1, 0.1, 0.25, dt)
+    arr = lib_arrays(lib)
+    for k in range(3):
+        nxt = lib.get_motion_state(ids, t0 + np.float32((k + 1) * dt))
+        act = np.clip(nxt["dof_pos"].numpy() / np.pi, -1, 1)
+        eb.step(act)
+        for i, oe in enumerate(oenvs):
+            oe.step(act[i].astype(np.float64))
+            assert np.abs(oe.data.qpos - eb.qpos[i]).max() < 5e-4, (k, i)
+        xpos, xmat = eb.kinematics()
+        times = (t0 + np.float32((k + 1) * dt)).astype(np.float32)
+        obs = np.zeros((n, 24 * J), np.float32); rew = np.zeros(n, np.float32); parts = np.zeros((n, 4), np.float32); term = np.zeros(n, np.uint8)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        assert emu_lib.ss_imitation_step(C.byref(lib.data), C.byref(cfg), p(ids), p(times), None, n, p(xpos), p(xmat), p(eb.body_vel),
+                                         p(obs), p(rew), p(parts), p(term), None) == 0
+        quat = mo.matrix_to_quaternion(xmat.reshape(n, J, 3, 3).astype(np.float64))
+        ref = mo.motion_state(arr, ids, times.astype(np.float64))
+        fut = mo.motion_state(arr, ids, (times + np.float32(dt)).astype(np.float64))
+        bv = eb.body_vel.astype(np.float64)
+        want_obs = mo.imitation_obs(xpos, quat, bv[..., :3], bv[..., 3:], fut["rg_pos"], fut["rb_rot"], fut["body_vel"], fut["body_ang_vel"])
+        want_rew, _ = mo.imitation_reward(xpos, quat, bv[..., :3], bv[..., 3:], ref["rg_pos"], ref["rb_rot"], ref["body_vel"], ref["body_ang_vel"])
+        assert np.abs(obs - want_obs).max() < 5e-4 and np.abs(rew - want_rew).max() < 5e-5
