@@ -141,11 +141,11 @@ def run_imitation(args, rank, local_rank, world, dist, dev):
         ev0[i].record()
         env.base.step(a)                                         # the physics launch (dominant kernel), timed per launch
         ev1[i].record()
-        env._imitation(env.task_obs, env.rew_buf, env.reward_parts, env.terminated)
-        env._assemble()
-        done = env.terminated.bool() | ((env.times + env.dt) >= env.motion_len)
-        rew_sum += env.rew_buf.mean(); ended += done.sum()
-        env.reset(mask=done)
+        env._imitation(None, env.rew_buf, env.reward_parts, env.terminated, env.truncated)
+        env.obs_buf[:, :env.self_obs_size] = env.base.obs_buf
+        torch.bitwise_or(env.terminated, env.truncated, out=env.reset_buf)
+        rew_sum += env.rew_buf.mean(); ended += env.reset_buf.sum()
+        env.reset(mask=env.reset_buf)
     shard.barrier(dist, world, dev)
     elapsed = shard.max_over_ranks(dist, world, time.perf_counter() - t0, dev)
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
@@ -155,9 +155,7 @@ def run_imitation(args, rank, local_rank, world, dist, dev):
     st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     e0.record()
     for _ in range(reps):
-        lib().ss_imitation_step(C.byref(ml.data), C.byref(env.cfg), _ptr(env.motion_ids), _ptr(env.times), _ptr(env.offset), N, _ptr(env.xpos),
-                                _ptr(env.xmat), _ptr(env.base.body_vel), _ptr(env.task_obs), _ptr(env.rew_buf), _ptr(env.reward_parts),
-                                _ptr(env.terminated), st)
+        env._imitation(None, env.rew_buf, env.reward_parts, env.terminated, env.truncated)
     e1.record(); torch.cuda.synchronize()
     im_ms = e0.elapsed_time(e1) / reps
     from smplsim_amd import _cabi

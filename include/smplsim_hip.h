@@ -150,6 +150,11 @@ int ss_substep(ss_batch *b, const float *actions, int n_substeps, void *stream);
 /* mj_kinematics readback: xpos [N,nbody,3], xquat-equivalent rotation matrices xmat [N,nbody,9] */
 int ss_kinematics(ss_batch *b, float *xpos, float *xmat, void *stream);
 
+/* Optional by-product of ss_step / ss_step_autoreset / ss_reset: the body frames of the launch's last forward (what a
+ * following ss_kinematics would return) are also written to xpos [N,nbody,3] / xmat [N,nbody,9] (caller-owned; both NULL =
+ * off).  Saves the extra launch for callers that need world body poses every step (the imitation task, smplsim_motion.h). */
+int ss_set_body_outputs(ss_batch *b, float *xpos, float *xmat);
+
 /* Diagnostics for parity triage: one mj_forward at (qpos, qvel) with raw joint torques [N,nu] (NULL = 0);
  * writes the dense joint-space mass matrix [N,nv,nv] (what mj_fullM returns; the stepping path itself never forms
  * it), qfrc_bias [N,nv] and the constrained qacc [N,nv]. */

@@ -78,28 +78,41 @@ typedef struct {
 
 /* MotionLibBase.get_motion_state (intervaled = 0: frames f0, f1 blended — lerp, slerp for rotations; motion_lib_base.py:
  * 359-423 with the integer frame numbers of its PHC original) or get_motion_state_intervaled (intervaled = 1: the single
- * frame of :311-355) for N (motion id, time) pairs; offset [N,3] is added to the body positions (NULL = none). */
+ * frame of :311-355) for N (motion id, time) pairs; offset [N,3] is added to the body positions (NULL = none); rows whose
+ * mask byte is 0 are left untouched (mask NULL = all) — with out->qpos / out->qvel pointing at ss_state.qpos / qvel this is
+ * the reference-state initialisation of the envs that just finished, in place. */
 int ss_motion_state_at(const ss_motion_data *data, const int32_t *motion_ids, const float *times, const float *offset,
-                       int32_t N, int32_t intervaled, const ss_motion_state *out, void *stream);
+                       const uint8_t *mask, int32_t N, int32_t intervaled, const ss_motion_state *out, void *stream);
+
+/* MotionLibBase.sample_motions + sample_time (motion_lib_base.py:277-292) on the device for the envs whose mask byte is set
+ * (NULL = all): rand [N,2] uniform(0,1) draws, cdf [M] the inclusive cumulative sum of the batch sampling probabilities
+ * (_sampling_batch_prob); motion_ids[n] = the clip whose CDF interval holds rand[n,0], start_times[n] = rand[n,1] *
+ * max(length - truncate_time, 0). */
+int ss_motion_resample(const ss_motion_data *data, const uint8_t *mask, const float *rand, const float *cdf, float truncate_time,
+                       int32_t N, int32_t *motion_ids, float *start_times, void *stream);
 
 /* Imitation task.  NOT in the reference (SURVEY.md 8f-2 asks to define it): PHC's tracking reward
  *   r = w_pos exp(-k_pos mean|dp|^2) + w_rot exp(-k_rot mean angle^2) + w_vel exp(-k_vel mean|dv|^2) + w_ang exp(-k_ang mean|dw|^2)
- * against the clip at `times`, early termination when the mean body distance exceeds termination_distance, and PHC's
- * v6 task observation against the clip at `times + obs_dt`, per body, in the root-heading frame:
+ * against the clip at time t = start_times[n] + cur_t[n] * obs_dt, early termination when the mean body distance exceeds
+ * termination_distance, truncation when t + obs_dt reaches the end of the clip, and PHC's v6 task observation against the
+ * clip at t + obs_dt, per body, in the root-heading frame:
  *   [dpos 3J | drot (tan-norm) 6J | dvel 3J | dangvel 3J | ref pos rel. root 3J | ref rot (tan-norm) 6J]   -> 24 J floats. */
 typedef struct {
   float k_pos, k_rot, k_vel, k_ang_vel;
   float w_pos, w_rot, w_vel, w_ang_vel;
   float termination_distance;
-  float obs_dt;
+  float obs_dt;                 /* control step (s): clip time advances by obs_dt per env step; the observation looks obs_dt ahead */
 } ss_imitation_cfg;
 
 /* One launch per control step: samples the clips for every env and body and reduces over bodies inside the wavefront.
- * xpos [N,J,3], xmat [N,J,9] (ss_kinematics), body_vel [N,J,6] (ss_state.body_vel) describe the simulated humanoid;
- * task_obs [N,24J], reward [N], reward_parts [N,4] (NULL = skip), terminated [N] bytes. */
-int ss_imitation_step(const ss_motion_data *data, const ss_imitation_cfg *cfg, const int32_t *motion_ids, const float *times,
-                      const float *offset, int32_t N, const float *xpos, const float *xmat, const float *body_vel,
-                      float *task_obs, float *reward, float *reward_parts, uint8_t *terminated, void *stream);
+ * xpos [N,J,3], xmat [N,J,9] (ss_set_body_outputs / ss_kinematics), body_vel [N,J,6] (ss_state.body_vel) describe the
+ * simulated humanoid; cur_t [N] = ss_state.cur_t (NULL = 0).  Outputs: task_obs rows of 24J floats at row stride obs_stride
+ * floats (so they can land behind the self observation in one policy input buffer); reward [N], reward_parts [N,4],
+ * terminated [N], truncated [N] bytes — each may be NULL.  Envs whose mask byte is 0 are skipped (mask NULL = all). */
+int ss_imitation_step(const ss_motion_data *data, const ss_imitation_cfg *cfg, const int32_t *motion_ids, const float *start_times,
+                      const int32_t *cur_t, const float *offset, const uint8_t *mask, int32_t N, const float *xpos, const float *xmat,
+                      const float *body_vel, float *task_obs, int32_t obs_stride, float *reward, float *reward_parts,
+                      uint8_t *terminated, uint8_t *truncated, void *stream);
 
 #ifdef __cplusplus
 }

@@ -98,18 +98,21 @@ def bind(lib):
     lib.ss_gae.argtypes = [vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_float, C.c_float, vp, vp, vp]
     lib.ss_debug_prof.argtypes = [vp, vp, C.c_int]
     lib.ss_set_order.argtypes = [vp, vp]
+    lib.ss_set_body_outputs.argtypes = [vp, vp, vp]
     lib.ss_launch_info.argtypes = [vp] + [C.POINTER(C.c_int32)] * 3
     lib.ss_last_error.argtypes = []; lib.ss_last_error.restype = C.c_char_p
     lib.ss_motion_cook.argtypes = [C.POINTER(Skeleton), C.POINTER(MotionData), C.c_int32, vp]
-    lib.ss_motion_state_at.argtypes = [C.POINTER(MotionData), vp, vp, vp, C.c_int32, C.c_int32, C.POINTER(MotionState), vp]
-    lib.ss_imitation_step.argtypes = [C.POINTER(MotionData), C.POINTER(ImitationCfg)] + [vp] * 3 + [C.c_int32] + [vp] * 8
+    lib.ss_motion_state_at.argtypes = [C.POINTER(MotionData), vp, vp, vp, vp, C.c_int32, C.c_int32, C.POINTER(MotionState), vp]
+    lib.ss_motion_resample.argtypes = [C.POINTER(MotionData), vp, vp, vp, C.c_float, C.c_int32, vp, vp, vp]
+    lib.ss_imitation_step.argtypes = [C.POINTER(MotionData), C.POINTER(ImitationCfg)] + [vp] * 5 + [C.c_int32] + [vp] * 4 + \
+                                     [C.c_int32] + [vp] * 5
     return lib
 
 
 EXPORTS = ["ss_model_create", "ss_model_destroy", "ss_model_dims", "ss_obs_size", "ss_batch_create",
            "ss_batch_destroy", "ss_reset", "ss_step", "ss_step_autoreset", "ss_substep", "ss_kinematics", "ss_debug_forward",
-           "ss_gae", "ss_debug_prof", "ss_set_order", "ss_schedule_longest_first", "ss_launch_info", "ss_last_error",
-           "ss_motion_cook", "ss_motion_state_at", "ss_imitation_step"]
+           "ss_gae", "ss_debug_prof", "ss_set_order", "ss_set_body_outputs", "ss_schedule_longest_first", "ss_launch_info", "ss_last_error",
+           "ss_motion_cook", "ss_motion_state_at", "ss_motion_resample", "ss_imitation_step"]
 
 
 def make_model_desc(mc, kp, kd, torque_lim, act_scale, act_offset, legal_bodies=(), timestep=1.0 / 450):

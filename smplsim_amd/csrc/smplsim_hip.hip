@@ -158,6 +158,10 @@ __global__ void __launch_bounds__(256) ss_motion_state_kernel(const ss::mo::Stat
   const int J = a.d.nbody;
   if (idx < (long long)a.N * J) ss::mo::state_elem(a, (int)(idx / J), (int)(idx % J));
 }
+__global__ void __launch_bounds__(256) ss_motion_resample_kernel(const ss::mo::ResampleArgs a) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n < a.N) ss::mo::resample_elem(a, n);
+}
 template <int LPE>
 __global__ void __launch_bounds__(256) ss_imitation_kernel(const ss::mo::ImArgs a) {
   WaveGpu w{(int)(threadIdx.x & 63)};
@@ -201,6 +205,10 @@ struct HipBackend {
   }
   static const char *motion_state(const ss::mo::StateArgs &a, void *stream) {
     hipLaunchKernelGGL(ss_motion_state_kernel, dim3((unsigned)(((long long)a.N * a.d.nbody + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return hip_err();
+  }
+  static const char *motion_resample(const ss::mo::ResampleArgs &a, void *stream) {
+    hipLaunchKernelGGL(ss_motion_resample_kernel, dim3((a.N + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
     return hip_err();
   }
   static const char *imitation(const ss::mo::ImArgs &a, void *stream) {

@@ -33,6 +33,7 @@ struct ss_batch {
   unsigned long long *d_prof = nullptr;   // SS_PROFILE builds only
   const int32_t *order = nullptr;         // caller-owned device array or null
   int32_t *d_sched = nullptr;             // library-owned [N] hand-out order written by ss_schedule_longest_first
+  float *body_xpos = nullptr, *body_xmat = nullptr;   // caller-owned, optional: written by every step / reset (ss_set_body_outputs)
 };
 
 template <class BE>
@@ -110,6 +111,7 @@ struct ss_api {
     k.work_counter = b->d_counter;
     k.prof = b->d_prof;
     k.order = b->order;
+    if (mode == ss::MODE_STEP || mode == ss::MODE_RESET) { k.out0 = b->body_xpos; k.out1 = b->body_xmat; }
     return k;
   }
   static int run(const ss_batch *b, const ss::KArgs &k, void *stream) {
@@ -181,6 +183,10 @@ struct ss_api {
   int ss_set_order(ss_batch *b, const int32_t *order) {                                                              \
     if (!b) return ss_api<BE>::fail(SS_ERR_INVALID, "null batch");                                                  \
     b->order = order; return SS_OK;                                                                                  \
+  }                                                                                                                  \
+  int ss_set_body_outputs(ss_batch *b, float *xpos, float *xmat) {                                                    \
+    if (!b || (!xpos) != (!xmat)) return ss_api<BE>::fail(SS_ERR_INVALID, "pass both buffers or neither");           \
+    b->body_xpos = xpos; b->body_xmat = xmat; return SS_OK;                                                          \
   }                                                                                                                  \
   int ss_schedule_longest_first(ss_batch *b, void *stream) {                                                        \
     if (!b) return ss_api<BE>::fail(SS_ERR_INVALID, "null batch");                                                  \

@@ -1463,13 +1463,12 @@ SS_DEV bool run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env, 
 #ifdef SS_PROFILE
   if (lane == 0 && k->prof) for (int i = 0; i < PF_COUNT; i++) w->atomic_add_u64(k->prof + i, sim.prof[i]);
 #endif
-  if (mode == MODE_KINEMATICS) {
-    if (lane < h.nb) {
-      for (int c = 0; c < 3; c++) k->out0[((size_t)env * h.nb + lane) * 3 + c] = sim.r[3 * lane + c] + sim.q[c];
-      for (int c = 0; c < 9; c++) k->out1[((size_t)env * h.nb + lane) * 9 + c] = sim.R[9 * lane + c];
-    }
-    return false;
+  // body frames of the last forward: mj_kinematics readback, and (ss_set_body_outputs) a by-product of every step / reset
+  if (k->out0 && !is_debug && mode != MODE_SUBSTEP && lane < h.nb) {
+    for (int c = 0; c < 3; c++) k->out0[((size_t)env * h.nb + lane) * 3 + c] = sim.r[3 * lane + c] + sim.q[c];
+    for (int c = 0; c < 9; c++) k->out1[((size_t)env * h.nb + lane) * 9 + c] = sim.R[9 * lane + c];
   }
+  if (mode == MODE_KINEMATICS) return false;
   const unsigned long long touch = sim.touchmask;
   if (lane == 0) {
     st.touch[2 * env] = (int)(touch & 0xFFFFFFFFull); st.touch[2 * env + 1] = (int)(touch >> 32);

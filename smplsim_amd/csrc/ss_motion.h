@@ -32,11 +32,13 @@ constexpr float kPi = 3.14159265358979323846f;
 
 struct Skel { int nb; int8_t parent[kMaxBodies]; uint8_t s2m[kMaxBodies]; };
 struct CookArgs { Skel sk; ss_motion_data d; int filter; float gw[2 * kGaussRadius + 1]; };
-struct StateArgs { ss_motion_data d; const int32_t *ids; const float *times; const float *offset; int N; int intervaled; ss_motion_state out; };
+struct StateArgs { ss_motion_data d; const int32_t *ids; const float *times; const float *offset; const uint8_t *mask; int N; int intervaled; ss_motion_state out; };
 struct ImArgs {
-  ss_motion_data d; ss_imitation_cfg c; const int32_t *ids; const float *times; const float *offset; int N;
-  const float *xpos, *xmat, *body_vel; float *obs, *reward, *parts; uint8_t *terminated;
+  ss_motion_data d; ss_imitation_cfg c; const int32_t *ids; const float *start_times; const int32_t *cur_t; const float *offset;
+  const uint8_t *mask; int N;
+  const float *xpos, *xmat, *body_vel; float *obs; int obs_stride; float *reward, *parts; uint8_t *terminated, *truncated;
 };
+struct ResampleArgs { ss_motion_data d; const uint8_t *mask; const float *rand; const float *cdf; float truncate; int N; int32_t *ids; float *start_times; };
 
 struct Q { float w, x, y, z; };
 
@@ -265,6 +267,7 @@ SS_DEV void sample_body(const ss_motion_data &d, int f0, int f1, float b, int j,
 
 // get_motion_state / get_motion_state_intervaled for (env n, body j)
 SS_DEV void state_elem(const StateArgs &a, int n, int j) {
+  if (a.mask && !a.mask[n]) return;
   const ss_motion_data &d = a.d;
   const ss_motion_state &o = a.out;
   const int J = d.nbody, J1 = J - 1, nq = 7 + 3 * J1, nv = 6 + 3 * J1, id = a.ids[n];
@@ -317,6 +320,18 @@ SS_DEV void state_elem(const StateArgs &a, int n, int j) {
   }
 }
 
+// MotionLibBase.sample_motions + sample_time (motion_lib_base.py:277-292) for the envs whose mask byte is set: clip by
+// inverse CDF of the batch sampling probabilities from rand[n,0], start time = rand[n,1] * (length - truncate)
+SS_DEV void resample_elem(const ResampleArgs &a, int n) {
+  if (a.mask && !a.mask[n]) return;
+  const int M = a.d.num_motions;
+  const float u = a.rand[2 * n];
+  int lo = 0, hi = M - 1;                                    // smallest m with cdf[m] > u
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.cdf[mid] > u) hi = mid; else lo = mid + 1; }
+  a.ids[n] = lo;
+  a.start_times[n] = a.rand[2 * n + 1] * fmaxf(a.d.motion_lengths[lo] - a.truncate, 0.f);
+}
+
 // ------------------------------------------------------------------------------------------------ imitation task
 // heading of the simulated root, the convention of the self observation (compute_humanoid_self_obs_v2,
 // humanoid_env.py:644-647: remove_base_rot, then calc_heading_quat_inv)
@@ -335,11 +350,11 @@ template <class W, int LPE>
 SS_DEV void imitation_wave(W *w, const ImArgs &a, int wave_id) {
   const ss_motion_data &d = a.d;
   const int J = d.nbody, lane = w->lane(), j = lane % LPE, n = wave_id * (64 / LPE) + lane / LPE;
-  const bool act = n < a.N && j < J;
-  float e_pos = 0.f, e_rot = 0.f, e_vel = 0.f, e_ang = 0.f, dist = 0.f;
+  const bool act = n < a.N && j < J && !(a.mask && !a.mask[n]);
+  float e_pos = 0.f, e_rot = 0.f, e_vel = 0.f, e_ang = 0.f, dist = 0.f, time = 0.f;
   if (act) {
     const int id = a.ids[n];
-    const float time = a.times[n];
+    time = a.start_times[n] + (a.cur_t ? (float)a.cur_t[n] * a.c.obs_dt : 0.f);
     const float *off = a.offset ? a.offset + (size_t)n * 3 : nullptr;
     const size_t nj = (size_t)n * J + j;
     const float *sp = a.xpos + nj * 3, *sv = a.body_vel + nj * 6, *rp = a.xpos + (size_t)n * J * 3;
@@ -363,7 +378,7 @@ SS_DEV void imitation_wave(W *w, const ImArgs &a, int wave_id) {
     frame_blend(d, id, time + a.c.obs_dt, &f0, &f1, &b);
     sample_body(d, f0, f1, b, j, off, &r);
     const Q hi = heading_inv(rq), hq = q_conj(hi);
-    float *ob = a.obs + (size_t)n * 24 * J;
+    float *ob = a.obs + (size_t)n * a.obs_stride;
     float t3[3], o3[3], o6[6];
     for (int c = 0; c < 3; c++) t3[c] = r.p[c] - sp[c];
     q_rot(hi, t3, o3); for (int c = 0; c < 3; c++) ob[3 * j + c] = o3[c];
@@ -385,9 +400,10 @@ SS_DEV void imitation_wave(W *w, const ImArgs &a, int wave_id) {
     const float ij = 1.f / (float)J;
     const float r0 = expf(-a.c.k_pos * e_pos * ij * (1.f / 3.f)), r1 = expf(-a.c.k_rot * e_rot * ij);
     const float r2 = expf(-a.c.k_vel * e_vel * ij * (1.f / 3.f)), r3 = expf(-a.c.k_ang_vel * e_ang * ij * (1.f / 3.f));
-    a.reward[n] = a.c.w_pos * r0 + a.c.w_rot * r1 + a.c.w_vel * r2 + a.c.w_ang_vel * r3;
+    if (a.reward) a.reward[n] = a.c.w_pos * r0 + a.c.w_rot * r1 + a.c.w_vel * r2 + a.c.w_ang_vel * r3;
     if (a.parts) { a.parts[4 * n] = r0; a.parts[4 * n + 1] = r1; a.parts[4 * n + 2] = r2; a.parts[4 * n + 3] = r3; }
-    a.terminated[n] = dist * ij > a.c.termination_distance ? 1 : 0;
+    if (a.terminated) a.terminated[n] = dist * ij > a.c.termination_distance ? 1 : 0;
+    if (a.truncated) a.truncated[n] = time + a.c.obs_dt >= d.motion_lengths[a.ids[n]] ? 1 : 0;   // no later frame to look ahead to
   }
 }
 

@@ -3,6 +3,7 @@
 //   static const char *motion_cook(const ss::mo::CookArgs &, void *stream);      // three launches: fk, dof fix, velocities
 //   static const char *motion_state(const ss::mo::StateArgs &, void *stream);
 //   static const char *imitation(const ss::mo::ImArgs &, void *stream);
+//   static const char *motion_resample(const ss::mo::ResampleArgs &, void *stream);
 #pragma once
 #include <cmath>
 #include <string>
@@ -69,23 +70,35 @@ inline const char *check_data(const ss_motion_data *d, bool cooking) {
     const char *e = BE::motion_cook(a, stream);                                                                       \
     return e ? ss_api<BE>::fail(SS_ERR_HIP, e) : SS_OK;                                                               \
   }                                                                                                                  \
-  int ss_motion_state_at(const ss_motion_data *data, const int32_t *ids, const float *times, const float *offset, int32_t N, \
-                         int32_t intervaled, const ss_motion_state *out, void *stream) {                              \
+  int ss_motion_state_at(const ss_motion_data *data, const int32_t *ids, const float *times, const float *offset,      \
+                         const uint8_t *mask, int32_t N, int32_t intervaled, const ss_motion_state *out, void *stream) { \
     if (const char *e = ss::mo::check_data(data, false)) return ss_api<BE>::fail(SS_ERR_INVALID, e);                   \
     if (!ids || !times || !out) return ss_api<BE>::fail(SS_ERR_INVALID, "null argument");                              \
     if (N < 1) return ss_api<BE>::fail(SS_ERR_INVALID, "N must be positive");                                          \
-    ss::mo::StateArgs a{*data, ids, times, offset, N, intervaled ? 1 : 0, *out};                                       \
+    ss::mo::StateArgs a{*data, ids, times, offset, mask, N, intervaled ? 1 : 0, *out};                                       \
     const char *e = BE::motion_state(a, stream);                                                                      \
     return e ? ss_api<BE>::fail(SS_ERR_HIP, e) : SS_OK;                                                               \
   }                                                                                                                  \
-  int ss_imitation_step(const ss_motion_data *data, const ss_imitation_cfg *cfg, const int32_t *ids, const float *times, \
-                        const float *offset, int32_t N, const float *xpos, const float *xmat, const float *body_vel, \
-                        float *task_obs, float *reward, float *parts, uint8_t *terminated, void *stream) {            \
+  int ss_motion_resample(const ss_motion_data *data, const uint8_t *mask, const float *rand, const float *cdf,        \
+                         float truncate_time, int32_t N, int32_t *ids, float *start_times, void *stream) {            \
     if (const char *e = ss::mo::check_data(data, false)) return ss_api<BE>::fail(SS_ERR_INVALID, e);                   \
-    if (!cfg || !ids || !times || !xpos || !xmat || !body_vel || !task_obs || !reward || !terminated)                  \
+    if (!rand || !cdf || !ids || !start_times) return ss_api<BE>::fail(SS_ERR_INVALID, "null argument");               \
+    if (N < 1 || truncate_time < 0.f) return ss_api<BE>::fail(SS_ERR_INVALID, "N must be positive, truncate_time >= 0"); \
+    ss::mo::ResampleArgs a{*data, mask, rand, cdf, truncate_time, N, ids, start_times};                               \
+    const char *e = BE::motion_resample(a, stream);                                                                  \
+    return e ? ss_api<BE>::fail(SS_ERR_HIP, e) : SS_OK;                                                               \
+  }                                                                                                                  \
+  int ss_imitation_step(const ss_motion_data *data, const ss_imitation_cfg *cfg, const int32_t *ids, const float *start_times, \
+                        const int32_t *cur_t, const float *offset, const uint8_t *mask, int32_t N, const float *xpos,  \
+                        const float *xmat, const float *body_vel, float *task_obs, int32_t obs_stride, float *reward,  \
+                        float *parts, uint8_t *terminated, uint8_t *truncated, void *stream) {                        \
+    if (const char *e = ss::mo::check_data(data, false)) return ss_api<BE>::fail(SS_ERR_INVALID, e);                   \
+    if (!cfg || !ids || !start_times || !xpos || !xmat || !body_vel || !task_obs)                                      \
       return ss_api<BE>::fail(SS_ERR_INVALID, "null argument");                                                      \
     if (N < 1) return ss_api<BE>::fail(SS_ERR_INVALID, "N must be positive");                                          \
-    ss::mo::ImArgs a{*data, *cfg, ids, times, offset, N, xpos, xmat, body_vel, task_obs, reward, parts, terminated};    \
+    if (obs_stride < 24 * data->nbody) return ss_api<BE>::fail(SS_ERR_INVALID, "obs_stride smaller than the task observation"); \
+    ss::mo::ImArgs a{*data, *cfg, ids, start_times, cur_t, offset, mask, N, xpos, xmat, body_vel, task_obs, obs_stride, reward, parts, \
+                     terminated, truncated};                                                                         \
     const char *e = BE::imitation(a, stream);                                                                         \
     return e ? ss_api<BE>::fail(SS_ERR_HIP, e) : SS_OK;                                                               \
   }                                                                                                                  \

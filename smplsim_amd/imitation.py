@@ -5,9 +5,11 @@ replica of PHC's", humanoid_env.py:636) but not the task itself; this env wires 
 
   reset   reference-state init: sample a clip and a start time per env, write the clip's qpos/qvel at that time into
           the simulator state (ss_motion_state_at -> ss_reset with StateInit "External")
-  step    ss_step (15 x (Stable-PD + mj_step), self observation)  ->  ss_kinematics (xpos, xmat)  ->
-          ss_imitation_step (clip lookup at t and t + dt, task observation, tracking reward, early termination)
-          obs = [self obs | task obs];  truncated when the clip ends;  finished envs are re-initialised in place.
+  step    ss_step (15 x (Stable-PD + mj_step), self observation, body frames via ss_set_body_outputs)  ->
+          ss_imitation_step (clip lookup at t and t + dt, task observation written behind the self observation, tracking
+          reward, early termination, truncation at the end of the clip)
+          finished envs are re-initialised in place: ss_motion_resample -> ss_motion_state_at (masked, straight into the
+          simulator's qpos / qvel) -> ss_reset (masked) -> ss_imitation_step (masked, observation only).
 
 All buffers are torch tensors on the shard's device; nothing leaves HBM between launches.
 """
@@ -41,68 +43,73 @@ class SMPLSimImitationVecEnv:
         f32 = dict(dtype=torch.float32, device=dev)
         self.motion_ids = torch.zeros(N, dtype=torch.int32, device=dev)
         self.start_times = torch.zeros(N, **f32)
-        self.motion_len = torch.zeros(N, **f32)
-        self.times = torch.zeros(N, **f32)
         self.offset = torch.zeros(N, 3, **f32)
         self.xpos = torch.zeros(N, J, 3, **f32); self.xmat = torch.zeros(N, J, 9, **f32)
-        self.task_obs = torch.zeros(N, 24 * J, **f32); self._task_obs_tmp = torch.zeros(N, 24 * J, **f32)
-        self.rew_buf = torch.zeros(N, **f32); self._rew_tmp = torch.zeros(N, **f32)
-        self.reward_parts = torch.zeros(N, 4, **f32); self._parts_tmp = torch.zeros(N, 4, **f32)
-        self.terminated = torch.zeros(N, dtype=torch.uint8, device=dev); self._term_tmp = torch.zeros(N, dtype=torch.uint8, device=dev)
         self.self_obs_size, self.task_obs_size = b.obs_size, 24 * J
         self.obs_size = self.self_obs_size + self.task_obs_size
-        self.obs_buf = torch.zeros(N, self.obs_size, **f32)
+        self.obs_buf = torch.zeros(N, self.obs_size, **f32)          # [self obs | task obs]: the kernels write the task part in place
+        self.task_obs = self.obs_buf[:, self.self_obs_size:]
+        self.rew_buf = torch.zeros(N, **f32)
+        self.reward_parts = torch.zeros(N, 4, **f32)
+        self.terminated = torch.zeros(N, dtype=torch.uint8, device=dev)
+        self.truncated = torch.zeros(N, dtype=torch.uint8, device=dev)
+        self.reset_buf = torch.zeros(N, dtype=torch.uint8, device=dev)
         self.action_size = b.nu
         self.gen = torch.Generator(device=dev)
         self.gen.manual_seed(int(seed) + 1)
+        # every step / reset launch also writes the body frames of its last forward: no separate ss_kinematics launch
+        _check(lib().ss_set_body_outputs(b.handle, _ptr(self.xpos), _ptr(self.xmat)))
 
-    # ---- one imitation launch on the current simulator state
-    def _imitation(self, task_obs, rew, parts, term):
+    @property
+    def times(self):
+        """Clip time of every env (s)."""
+        return self.start_times + self.base.cur_t.to(torch.float32) * self.dt
+
+    @property
+    def motion_len(self):
+        return self.motion_lib.get_motion_length(self.motion_ids)
+
+    # ---- one imitation launch on the current simulator state (envs with mask byte 0 are skipped)
+    def _imitation(self, mask, rew, parts, term, trunc):
         b = self.base
-        _check(lib().ss_kinematics(b.handle, _ptr(self.xpos), _ptr(self.xmat), b._stream()))
-        torch.add(self.start_times, b.cur_t.to(torch.float32), alpha=self.dt, out=self.times)
-        _check(lib().ss_imitation_step(C.byref(self.motion_lib.data), C.byref(self.cfg), _ptr(self.motion_ids), _ptr(self.times),
-                                       _ptr(self.offset), self.num_envs, _ptr(self.xpos), _ptr(self.xmat), _ptr(b.body_vel),
-                                       _ptr(task_obs), _ptr(rew), _ptr(parts), _ptr(term), b._stream()))
-
-    def _assemble(self):
-        self.obs_buf[:, :self.self_obs_size] = self.base.obs_buf
-        self.obs_buf[:, self.self_obs_size:] = self.task_obs
+        task_ptr = C.c_void_p(self.obs_buf.data_ptr() + 4 * self.self_obs_size)
+        _check(lib().ss_imitation_step(C.byref(self.motion_lib.data), C.byref(self.cfg), _ptr(self.motion_ids), _ptr(self.start_times),
+                                       _ptr(b.cur_t), _ptr(self.offset), _ptr(mask), self.num_envs, _ptr(self.xpos), _ptr(self.xmat),
+                                       _ptr(b.body_vel), task_ptr, self.obs_size, _ptr(rew), _ptr(parts), _ptr(term), _ptr(trunc),
+                                       b._stream()))
 
     def reset(self, mask=None, motion_ids=None, start_times=None):
-        """Reference-state init of all envs (mask None) or those with mask != 0."""
+        """Reference-state init of all envs (mask None) or those with mask != 0: new clip + start time (unless given), the
+        clip's qpos / qvel at that time written into the simulator state, mj_forward + observations — 4 launches, in place."""
         b, ml = self.base, self.motion_lib
-        m = torch.ones(self.num_envs, dtype=torch.bool, device=self.device) if mask is None else mask.to(self.device).bool()
-        ids = ml.sample_motions(self.num_envs, generator=self.gen) if motion_ids is None else torch.as_tensor(motion_ids, device=self.device).to(torch.int32)
+        m = None if mask is None else mask.to(self.device).to(torch.uint8).contiguous()
+        if motion_ids is None:
+            ml.resample(m, self.motion_ids, self.start_times, truncate_time=self.dt, generator=self.gen)
+            if start_times is None and not self.random_start:
+                self.start_times.zero_() if m is None else self.start_times.masked_fill_(m.bool(), 0.0)
+        else:
+            ids = torch.as_tensor(motion_ids, device=self.device).to(torch.int32)
+            self.motion_ids.copy_(ids if m is None else torch.where(m.bool(), ids, self.motion_ids))
         if start_times is not None:
             t0 = torch.as_tensor(start_times, device=self.device).to(torch.float32)
-        elif self.random_start:
-            t0 = ml.sample_time(ids, truncate_time=self.dt, generator=self.gen).clamp_(min=0.0)
-        else:
-            t0 = torch.zeros(self.num_envs, device=self.device)
-        self.motion_ids.copy_(torch.where(m, ids, self.motion_ids))
-        self.start_times.copy_(torch.where(m, t0, self.start_times))
-        self.motion_len.copy_(ml.get_motion_length(self.motion_ids))
-        out, _ = ml._lookup(self.motion_ids, self.start_times, self.offset, False, ["qpos", "qvel"])
-        b.qpos.copy_(torch.where(m[:, None], out["qpos"], b.qpos))
-        b.qvel.copy_(torch.where(m[:, None], out["qvel"], b.qvel))
+            self.start_times.copy_(t0 if m is None else torch.where(m.bool(), t0, self.start_times))
+        ml.write_state(self.motion_ids, self.start_times, self.offset, m, b.qpos, b.qvel)
         b.reset(mask=m)                                        # StateInit External: mj_forward + self observation on that state
-        self._imitation(self._task_obs_tmp, self._rew_tmp, self._parts_tmp, self._term_tmp)
-        self.task_obs.copy_(torch.where(m[:, None], self._task_obs_tmp, self.task_obs))
-        self._assemble()
+        self._imitation(m, None, None, None, None)             # task observation of the re-initialised envs only
+        self.obs_buf[:, :self.self_obs_size] = b.obs_buf
         return self.obs_buf, {"critic_state": self.obs_buf}
 
     def step(self, actions):
         b = self.base
         b.step(actions)
-        self._imitation(self.task_obs, self.rew_buf, self.reward_parts, self.terminated)
-        self._assemble()
-        terminated = self.terminated.bool()
-        truncated = (self.times + self.dt) >= self.motion_len            # no next reference frame left to track
+        self._imitation(None, self.rew_buf, self.reward_parts, self.terminated, self.truncated)
+        self.obs_buf[:, :self.self_obs_size] = b.obs_buf
+        terminated, truncated = self.terminated.bool(), self.truncated.bool()
         info = {"reward_parts": self.reward_parts}
         if self.autoreset:
             info["final_observation"] = self.obs_buf.clone()
-            self.reset(mask=terminated | truncated)
+            torch.bitwise_or(self.terminated, self.truncated, out=self.reset_buf)
+            self.reset(mask=self.reset_buf)
         info["critic_state"] = self.obs_buf
         return self.obs_buf, self.rew_buf, terminated, truncated, info
 

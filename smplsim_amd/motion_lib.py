@@ -199,6 +199,9 @@ class MotionLibSMPL:
         skel = _cabi.Skeleton(J, self._sk_keep[0].ctypes.data_as(C.c_void_p), self._sk_keep[1].ctypes.data_as(C.c_void_p))
         self._check(self._lib.ss_motion_cook(C.byref(skel), C.byref(self.data), int(self.filter_vel), self._stream()))
         self.motion_lengths_t, self.motion_num_frames_t = self._d["motion_lengths"], self._d["motion_num_frames"]
+        cdf = np.cumsum(self._sampling_batch_prob)
+        cdf[-1] = 1.0 + 1e-6                                        # rand < 1 always lands in a clip
+        self.sampling_cdf = up(cdf, np.float32)
         if not silent:
             print(f"###### Sampling {M:d} motions:", idx[:5], self.curr_motion_keys[:5],
                   f"total length of {self.get_total_length():.3f}s and {F} frames.")
@@ -278,6 +281,22 @@ class MotionLibSMPL:
         return steps if motion_ids is None else steps[np.asarray(motion_ids.cpu() if torch.is_tensor(motion_ids) else motion_ids)]
 
     # ---- lookup (:311-423)
+    def resample(self, mask, motion_ids, start_times, truncate_time=0.0, generator=None):
+        """sample_motions + sample_time for the envs with mask != 0 (None = all), in place, one launch
+        (motion_ids int32 [N], start_times float32 [N], device tensors)."""
+        N = motion_ids.shape[0]
+        rand = torch.rand(N, 2, device=self.device, generator=generator)
+        self._keep_rs = (rand, mask)
+        self._check(self._lib.ss_motion_resample(C.byref(self.data), _ptr(mask), _ptr(rand), _ptr(self.sampling_cdf), float(truncate_time), N,
+                                                 _ptr(motion_ids), _ptr(start_times), self._stream()))
+
+    def write_state(self, motion_ids, motion_times, offset, mask, qpos, qvel):
+        """Reference-state init in place: the clip's qpos / qvel at (id, time) into the rows of the simulator's qpos / qvel
+        tensors whose mask byte is set."""
+        st = _cabi.MotionState(**{"qpos": _ptr(qpos).value, "qvel": _ptr(qvel).value})
+        self._check(self._lib.ss_motion_state_at(C.byref(self.data), _ptr(motion_ids), _ptr(motion_times), _ptr(offset), _ptr(mask),
+                                                 motion_ids.shape[0], 0, C.byref(st), self._stream()))
+
     def _lookup(self, motion_ids, motion_times, offset, intervaled, fields):
         ids = torch.as_tensor(motion_ids, device=self.device).to(torch.int32).contiguous()
         times = torch.as_tensor(motion_times, device=self.device).to(torch.float32).contiguous()
@@ -289,8 +308,8 @@ class MotionLibSMPL:
         out = {k: torch.empty(shapes[k], dtype=torch.float32, device=self.device) for k in fields}
         st = _cabi.MotionState(*[_ptr(out.get(k)) for k in _cabi.MOTION_STATE_FIELDS])
         self._keep = (ids, times, off, out)
-        self._check(self._lib.ss_motion_state_at(C.byref(self.data), _ptr(ids), _ptr(times), _ptr(off), N, int(intervaled), C.byref(st),
-                                                 self._stream()))
+        self._check(self._lib.ss_motion_state_at(C.byref(self.data), _ptr(ids), _ptr(times), _ptr(off), None, N, int(intervaled),
+                                                 C.byref(st), self._stream()))
         return out, ids
 
     def get_motion_state(self, motion_ids, motion_times, offset=None, with_qpos=False):

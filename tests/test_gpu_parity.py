@@ -513,7 +513,7 @@ def test_imitation_env_rollout_on_gpu_tracks_oracle():
             oe.step(a[i])
             assert np.abs(oe.data.qpos - _np(env.base.qpos)[i]).max() < 5e-4, (k, i)
         times = t0 + np.float32((k + 1) * env.dt)
-        assert np.abs(_np(env.times) - times).max() < 1e-6
+        assert np.abs(_np(env.times) - times).max() < 1e-6 and not _np(env.truncated).any()
         xpos, xmat, bv = _np(env.xpos).astype(np.float64), _np(env.xmat).astype(np.float64), _np(env.base.body_vel).astype(np.float64)
         quat = mo.matrix_to_quaternion(xmat.reshape(n, J, 3, 3))
         ref = mo.motion_state(arr, ids, times.astype(np.float64), off)

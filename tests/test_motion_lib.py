@@ -188,8 +188,9 @@ def check_imitation(lib, clib, rs, n=37, device="cpu", stream=None):
     obs = torch.zeros(n, 24 * J, device=device); rew = torch.zeros(n, device=device); parts = torch.zeros(n, 4, device=device)
     term = torch.zeros(n, dtype=torch.uint8, device=device)
     p = lambda x: C.c_void_p(x.data_ptr())  # noqa: E731
-    rc = clib.ss_imitation_step(C.byref(lib.data), C.byref(cfg), p(d_ids), p(d_times), p(d_off), n, p(d_pos), p(d_mat), p(d_vel),
-                                p(obs), p(rew), p(parts), p(term), stream)
+    trunc = torch.zeros(n, dtype=torch.uint8, device=device)
+    rc = clib.ss_imitation_step(C.byref(lib.data), C.byref(cfg), p(d_ids), p(d_times), None, p(d_off), None, n, p(d_pos), p(d_mat), p(d_vel),
+                                p(obs), 24 * J, p(rew), p(parts), p(term), p(trunc), stream)
     assert rc == 0, clib.ss_last_error()
     if device != "cpu":
         torch.cuda.synchronize()
@@ -203,6 +204,17 @@ def check_imitation(lib, clib, rs, n=37, device="cpu", stream=None):
     assert want_parts.min() < 0.5 < want_parts.max()
     margin = np.abs(np.linalg.norm(pos - ref["rg_pos"], axis=-1).mean(-1) - 0.25) > 1e-4
     assert (term.cpu().numpy().astype(bool) == want_term)[margin].all() and want_term.any() and not want_term.all()
+    assert np.array_equal(trunc.cpu().numpy().astype(bool), times + np.float32(1.0 / 30) >= lib._motion_lengths[ids])
+    # masked launch with a row stride: only the selected envs' observation rows are written, nothing else
+    mask = torch.as_tensor((np.arange(n) % 3 == 0).astype(np.uint8)).to(device)
+    wide = torch.full((n, 24 * J + 7), -5.0, device=device)
+    rc = clib.ss_imitation_step(C.byref(lib.data), C.byref(cfg), p(d_ids), p(d_times), None, p(d_off), p(mask), n, p(d_pos), p(d_mat), p(d_vel),
+                                C.c_void_p(wide.data_ptr() + 4 * 7), 24 * J + 7, None, None, None, None, stream)
+    assert rc == 0
+    if device != "cpu":
+        torch.cuda.synchronize()
+    wide, mk = wide.cpu().numpy(), mask.cpu().numpy().astype(bool)
+    assert (wide[:, :7] == -5.0).all() and (wide[~mk] == -5.0).all() and np.array_equal(wide[mk][:, 7:], obs.cpu().numpy()[mk])
 
 
 def test_emu_imitation_step_matches_oracle(emu_lib):
@@ -224,8 +236,12 @@ def test_motion_api_error_paths(emu_lib):
     assert emu_lib.ss_motion_cook(C.byref(sk), C.byref(lib.data), 1, None) == -1
     assert b"permutation" in emu_lib.ss_last_error()
     st = _cabi.MotionState()
-    assert emu_lib.ss_motion_state_at(C.byref(lib.data), None, None, None, 4, 0, C.byref(st), None) == -1
-    assert emu_lib.ss_motion_state_at(C.byref(lib.data), C.c_void_p(1), C.c_void_p(1), None, 0, 0, C.byref(st), None) == -1
+    assert emu_lib.ss_motion_state_at(C.byref(lib.data), None, None, None, None, 4, 0, C.byref(st), None) == -1
+    assert emu_lib.ss_motion_state_at(C.byref(lib.data), C.c_void_p(1), C.c_void_p(1), None, None, 0, 0, C.byref(st), None) == -1
+    assert emu_lib.ss_motion_resample(C.byref(lib.data), None, None, None, 0.0, 4, None, None, None) == -1
+    assert emu_lib.ss_imitation_step(C.byref(lib.data), C.byref(_cabi.ImitationCfg()), C.c_void_p(1), C.c_void_p(1), None, None, None, 4, C.c_void_p(1),
+                                     C.c_void_p(1), C.c_void_p(1), C.c_void_p(1), 24 * 24 - 1, None, None, None, None, None) == -1
+    assert b"obs_stride" in emu_lib.ss_last_error()
 
 
 def test_motion_lib_needs_gpu_without_test_hook():
@@ -273,7 +289,10 @@ def test_emu_external_state_init_and_imitation_rollout_track_oracle(emu_lib):
     st = lib.get_motion_state(ids, t0, with_qpos=True)
     eb.qpos[:], eb.qvel[:] = st["qpos"].numpy(), st["qvel"].numpy()
     eb.qpos[:, 2] += 0.05                                    # lift the clips (they were not height-fixed) off the floor
+    eb.set_body_outputs()
     obs0 = eb.reset()
+    xp, xm = eb.kinematics()
+    assert np.array_equal(xp, eb.xpos_out) and np.array_equal(xm, eb.xmat_out)      # by-product of the reset launch
     oenvs = []
     for i in range(n):
         oe = O.OracleEnv(oracle_model(), state_init=O.INIT_EXTERNAL, self_obs_v=2, episode_length=10 ** 6)
@@ -292,11 +311,12 @@ def test_emu_external_state_init_and_imitation_rollout_track_oracle(emu_lib):
             oe.step(act[i].astype(np.float64))
             assert np.abs(oe.data.qpos - eb.qpos[i]).max() < 5e-4, (k, i)
         xpos, xmat = eb.kinematics()
+        assert np.array_equal(xpos, eb.xpos_out) and np.array_equal(xmat, eb.xmat_out)  # by-product of the step launch
         times = (t0 + np.float32((k + 1) * dt)).astype(np.float32)
         obs = np.zeros((n, 24 * J), np.float32); rew = np.zeros(n, np.float32); parts = np.zeros((n, 4), np.float32); term = np.zeros(n, np.uint8)
         p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
-        assert emu_lib.ss_imitation_step(C.byref(lib.data), C.byref(cfg), p(ids), p(times), None, n, p(xpos), p(xmat), p(eb.body_vel),
-                                         p(obs), p(rew), p(parts), p(term), None) == 0
+        assert emu_lib.ss_imitation_step(C.byref(lib.data), C.byref(cfg), p(ids), p(t0), p(eb.cur_t), None, None, n, p(xpos), p(xmat),
+                                         p(eb.body_vel), p(obs), 24 * J, p(rew), p(parts), p(term), None, None) == 0
         quat = mo.matrix_to_quaternion(xmat.reshape(n, J, 3, 3).astype(np.float64))
         ref = mo.motion_state(arr, ids, times.astype(np.float64))
         fut = mo.motion_state(arr, ids, (times + np.float32(dt)).astype(np.float64))
@@ -304,3 +324,27 @@ def test_emu_external_state_init_and_imitation_rollout_track_oracle(emu_lib):
         want_obs = mo.imitation_obs(xpos, quat, bv[..., :3], bv[..., 3:], fut["rg_pos"], fut["rb_rot"], fut["body_vel"], fut["body_ang_vel"])
         want_rew, _ = mo.imitation_reward(xpos, quat, bv[..., :3], bv[..., 3:], ref["rg_pos"], ref["rb_rot"], ref["body_vel"], ref["body_ang_vel"])
         assert np.abs(obs - want_obs).max() < 5e-4 and np.abs(rew - want_rew).max() < 5e-5
+
+
+def test_emu_resample_and_masked_state_write(emu_lib):
+    lib = make_lib(emu_lib)
+    n = 4000
+    ids = torch.full((n,), -1, dtype=torch.int32)
+    t0 = torch.full((n,), -1.0)
+    mask = torch.as_tensor((np.arange(n) % 4 != 0).astype(np.uint8))
+    lib.set_termination_history({"termination_history": np.array([1.0, 0.0, 3.0]), "failed_keys": []})   # p = (1/4, 0, 3/4)
+    lib.load_motions(random_sample=False)
+    lib.resample(mask, ids, t0, truncate_time=0.1, generator=torch.Generator().manual_seed(3))
+    mk = mask.numpy().astype(bool)
+    assert (ids.numpy()[~mk] == -1).all() and (t0.numpy()[~mk] == -1).all()
+    got = ids.numpy()[mk]
+    assert set(np.unique(got)) == {0, 2} and abs((got == 2).mean() - 0.75) < 0.03
+    L = lib._motion_lengths[got]
+    assert (t0.numpy()[mk] >= 0).all() and (t0.numpy()[mk] <= L - 0.1 + 1e-6).all() and t0.numpy()[mk].std() > 0.1
+    # masked reference-state write straight into "simulator" tensors
+    qpos, qvel = torch.full((n, 76), 7.0), torch.full((n, 75), 7.0)
+    ids2 = torch.where(torch.as_tensor(mk), ids, torch.zeros_like(ids))
+    lib.write_state(ids2, t0.clamp(min=0), None, mask, qpos, qvel)
+    want = lib.get_motion_state(ids2, t0.clamp(min=0), with_qpos=True)
+    assert (qpos[~torch.as_tensor(mk)] == 7.0).all() and torch.equal(qpos[torch.as_tensor(mk)], want["qpos"][torch.as_tensor(mk)])
+    assert torch.equal(qvel[torch.as_tensor(mk)], want["qvel"][torch.as_tensor(mk)])

@@ -254,6 +254,10 @@ struct EmuBackend {
     for (int n = 0; n < a.N; n++) for (int j = 0; j < a.d.nbody; j++) ss::mo::state_elem(a, n, j);
     return nullptr;
   }
+  static const char *motion_resample(const ss::mo::ResampleArgs &a, void *) {
+    for (int n = 0; n < a.N; n++) ss::mo::resample_elem(a, n);
+    return nullptr;
+  }
   static const char *imitation(const ss::mo::ImArgs &a, void *) {
     const int lpe = a.d.nbody <= 32 ? 32 : 64, per = 64 / lpe;
     for (int wv = 0; wv * per < a.N; wv++) { ImCtx c{&a, wv, machine()}; run_wave(machine(), lpe == 32 ? im_entry<32> : im_entry<64>, &c); }

@@ -104,6 +104,10 @@ class EmuBatch:
         a = np.ascontiguousarray(actions, np.float32)
         self._chk(lib().ss_substep(self.batch, _p(a), n, None))
 
+    def set_body_outputs(self):
+        self.xpos_out = np.zeros((self.N, self.mc.nbody, 3), np.float32); self.xmat_out = np.zeros((self.N, self.mc.nbody, 9), np.float32)
+        self._chk(lib().ss_set_body_outputs(self.batch, _p(self.xpos_out), _p(self.xmat_out)))
+
     def kinematics(self):
         xpos = np.zeros((self.N, self.mc.nbody, 3), np.float32); xmat = np.zeros((self.N, self.mc.nbody, 9), np.float32)
         self._chk(lib().ss_kinematics(self.batch, _p(xpos), _p(xmat), None))
