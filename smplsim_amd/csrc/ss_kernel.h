@@ -1312,7 +1312,10 @@ enum { SOLVE_NEWTON = 1, SOLVE_SPD = 2 };
 
 // `mode` is k->mode, or MODE_RESET for the second, fused pass of ss_step_autoreset (the caller loops: one call site).
 // Returns true when the env's step ended its episode and the fused Default reset has to run next.
-template <class W, int DOFP, int CANDP, int SLOTP, int NPASS>
+// BODYOUT: the instantiation whose step / reset passes also write the body frames (ss_set_body_outputs).  A separate
+// instantiation because the extra epilogue costs the headline step kernel 3.7% (register allocation of the hot loops
+// shifts) even when the pointer is null — callers that do not ask for it keep the plain one.
+template <class W, int DOFP, int CANDP, int SLOTP, int NPASS, bool BODYOUT = false>
 SS_DEV bool run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env, int mode) {
   const Hdr &h = k->h;
   const ss_env_cfg &cf = k->cfg;
@@ -1464,7 +1467,7 @@ SS_DEV bool run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env, 
   if (lane == 0 && k->prof) for (int i = 0; i < PF_COUNT; i++) w->atomic_add_u64(k->prof + i, sim.prof[i]);
 #endif
   // body frames of the last forward: mj_kinematics readback, and (ss_set_body_outputs) a by-product of every step / reset
-  if (k->out0 && !is_debug && mode != MODE_SUBSTEP && lane < h.nb) {
+  if ((mode == MODE_KINEMATICS || (BODYOUT && k->out0 && !is_debug && mode != MODE_SUBSTEP)) && lane < h.nb) {
     for (int c = 0; c < 3; c++) k->out0[((size_t)env * h.nb + lane) * 3 + c] = sim.r[3 * lane + c] + sim.q[c];
     for (int c = 0; c < 9; c++) k->out1[((size_t)env * h.nb + lane) * 9 + c] = sim.R[9 * lane + c];
   }

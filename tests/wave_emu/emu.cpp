@@ -199,7 +199,7 @@ void lane_entry(int lane, void *arg) {
   WaveEmu w{c->m, lane};
   int mode = c->k->mode;
   for (int rep = 0; rep < 2; rep++) {
-    const bool again = ss::run_env<WaveEmu, DOFP, CANDP, SLOTP, NPASS>(&w, c->k, c->T, c->L, c->env, mode);
+    const bool again = ss::run_env<WaveEmu, DOFP, CANDP, SLOTP, NPASS, true>(&w, c->k, c->T, c->L, c->env, mode);
     w.sync();
     if (!again) break;
     mode = ss::MODE_RESET;
