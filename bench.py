@@ -166,6 +166,10 @@ def run_imitation(args, rank, local_rank, world, dist, dev):
     e1.record(); torch.cuda.synchronize()
     cook_ms = e0.elapsed_time(e1) / 20
     if rank == 0:
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic_imitation.json")
+        if os.path.exists(tpath) and N == 1024:
+            traffic, traffic_src = json.load(open(tpath))["bytes_per_step_launch"], "profiles/hbm_traffic_imitation.json"
         im_bytes = 4 * (18 * J + 2 * 2 * 13 * J + 24 * J + 5) + 1          # sim state + 2 lookups x 2 frames + obs, reward, parts, flag
         cook_bytes = 4 * (75 + 13 * J + 4 * J + 6 * J + 6 * (J - 1) + 76 + 75)  # raw clip in; gts,grs,lrs,gvs,gavs,dof_pos,dvs,qpos,qvel out
         ach = N * im_bytes / (im_ms * 1e-3) / 1e9
@@ -180,8 +184,8 @@ def run_imitation(args, rank, local_rank, world, dist, dev):
                        "step_kernel_ms": kern_ms, "load_motions_s (upload + cook)": load_s,
                        "cook": {"ms": cook_ms, "frames_per_s": F / (cook_ms * 1e-3), "GB/s": F * cook_bytes / (cook_ms * 1e-3) / 1e9,
                                 "algorithmic_bytes_per_frame": cook_bytes}},
-            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "ss_imitation_kernel<32>", "kernel_ms": im_ms, "algorithmic_bytes_per_env_step": im_bytes,
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_unit": "bytes per launch", "traffic_source": traffic_src, "kernel": "ss_imitation_kernel<32>", "kernel_ms": im_ms, "algorithmic_bytes_per_env_step": im_bytes,
                          "note": f"{N} envs x {im_bytes} B is far below what fills HBM for the ~us a launch lasts: launch-latency bound at this size; "
                                  "the step's time is the physics launch (step_kernel_ms)"},
         }

@@ -137,21 +137,25 @@ __global__ void __launch_bounds__(1024) ss_order_kernel(const int32_t *iters, in
 
 
 // ---- motion library (include/smplsim_motion.h; element / wave functions in ss_motion.h).  All HBM-bound gathers: the
-// grids are one thread per frame (FK: the chain stack of 64 frames fills 52 KiB of LDS), one wave per clip (the
+// grids are one lane per (frame, body) for FK (tree levels in sequence through a small LDS tile), one wave per clip (the
 // sequential Euler-angle fix), one thread per (frame, body) and per (env, body).
-__global__ void __launch_bounds__(64) ss_motion_fk_kernel(const ss::mo::CookArgs a) {
-  __shared__ float stk[ss::mo::kMaxDepth * ss::mo::kStackSlots * 64];
-  const int f = blockIdx.x * 64 + threadIdx.x;
-  if (f < a.d.num_frames) ss::mo::fk_frame(a, f, stk + threadIdx.x, 64);
+template <int LPE>
+__global__ void __launch_bounds__(256) ss_motion_fk_kernel(const ss::mo::CookArgs a) {
+  __shared__ float xf[4 * 64 * ss::mo::kXformStride];
+  WaveGpu w{(int)(threadIdx.x & 63)};
+  const int wave = threadIdx.x >> 6;
+  ss::mo::fk_wave<WaveGpu, LPE>(&w, a, (int)(blockIdx.x * 4 + wave), xf + wave * 64 * ss::mo::kXformStride);
 }
 __global__ void __launch_bounds__(64) ss_motion_fix_kernel(const ss::mo::CookArgs a) {
   WaveGpu w{(int)threadIdx.x};
   ss::mo::dof_fix_clip(&w, a, (int)blockIdx.x);
 }
-__global__ void __launch_bounds__(256) ss_motion_vel_kernel(const ss::mo::CookArgs a) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int J = a.sk.nb;
-  if (idx < (long long)a.d.num_frames * J) ss::mo::vel_elem(a, (int)(idx / J), (int)(idx % J));
+__global__ void __launch_bounds__(128) ss_motion_vel_kernel(const ss::mo::CookArgs a) {
+  extern __shared__ float raw[];                             // per wave: (tile + 16) frames x J bodies x 6 floats
+  WaveGpu w{(int)(threadIdx.x & 63)};
+  const int wave = threadIdx.x >> 6, per = (ss::mo::kVelTile + 2 * ss::mo::kGaussRadius) * a.sk.nb * 6;
+  const int wave_id = (int)(blockIdx.x * (blockDim.x >> 6)) + wave;
+  if (wave_id * ss::mo::kVelTile < a.d.num_frames) ss::mo::vel_wave(&w, a, wave_id, raw + (size_t)wave * per);
 }
 __global__ void __launch_bounds__(256) ss_motion_state_kernel(const ss::mo::StateArgs a) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -198,9 +202,12 @@ struct HipBackend {
   static const char *hip_err() { hipError_t e = hipGetLastError(); return e == hipSuccess ? nullptr : hipGetErrorString(e); }
   static const char *motion_cook(const ss::mo::CookArgs &a, void *stream) {
     const int F = a.d.num_frames, J = a.sk.nb;
-    hipLaunchKernelGGL(ss_motion_fk_kernel, dim3((F + 63) / 64), dim3(64), 0, (hipStream_t)stream, a);
+    if (J <= 32) hipLaunchKernelGGL(ss_motion_fk_kernel<32>, dim3((F + 7) / 8), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(ss_motion_fk_kernel<64>, dim3((F + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
     hipLaunchKernelGGL(ss_motion_fix_kernel, dim3(a.d.num_motions), dim3(64), 0, (hipStream_t)stream, a);
-    hipLaunchKernelGGL(ss_motion_vel_kernel, dim3((unsigned)(((long long)F * J + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    const int vwaves = J <= 32 ? 2 : 1, tiles = (F + ss::mo::kVelTile - 1) / ss::mo::kVelTile;      // <= 40 KiB of LDS per workgroup
+    const size_t vlds = (size_t)vwaves * (ss::mo::kVelTile + 2 * ss::mo::kGaussRadius) * J * 6 * sizeof(float);
+    hipLaunchKernelGGL(ss_motion_vel_kernel, dim3((tiles + vwaves - 1) / vwaves), dim3(64 * vwaves), vlds, (hipStream_t)stream, a);
     return hip_err();
   }
   static const char *motion_state(const ss::mo::StateArgs &a, void *stream) {

@@ -1,8 +1,8 @@
 // ss_motion.h — motion-library kernels: cooking the clips, per-step lookup, imitation obs/reward.
 //
 // Written, like ss_kernel.h, so that the identical code is compiled by hipcc for gfx950 and by g++ for the CPU
-// emulator under tests/wave_emu (unit-test infrastructure only).  Element functions (one frame / one (frame, body) /
-// one (env, body)) have no cross-lane traffic; the two wave functions use the W policy for any() and shfl_xor().
+// emulator under tests/wave_emu (unit-test infrastructure only).  Element functions (one (frame, body) / one (env, body))
+// have no cross-lane traffic; the wave functions use the W policy for sync(), any() and shfl_xor().
 //
 // All of this is HBM-bound gather/scatter over flat frame arrays (no GEMM shape anywhere); what matters is that
 // consecutive lanes touch consecutive bodies of one frame so that a wave reads whole 288..1248-byte rows.
@@ -26,11 +26,11 @@ namespace mo {
 
 constexpr int kMaxBodies = 64;
 constexpr int kMaxDepth = 16;
-constexpr int kStackSlots = 13;          // world rotation (9) + position (3) + joint id of one level of the current chain
+constexpr int kXformStride = 13;         // world rotation (9) + position (3) of one body in LDS, padded to an odd stride
 constexpr int kGaussRadius = 8;          // scipy gaussian_filter1d(sigma=2): int(4 * 2 + 0.5)
 constexpr float kPi = 3.14159265358979323846f;
 
-struct Skel { int nb; int8_t parent[kMaxBodies]; uint8_t s2m[kMaxBodies]; };
+struct Skel { int nb, maxdepth; int8_t parent[kMaxBodies]; uint8_t s2m[kMaxBodies]; uint8_t depth[kMaxBodies]; };
 struct CookArgs { Skel sk; ss_motion_data d; int filter; float gw[2 * kGaussRadius + 1]; };
 struct StateArgs { ss_motion_data d; const int32_t *ids; const float *times; const float *offset; const uint8_t *mask; int N; int intervaled; ss_motion_state out; };
 struct ImArgs {
@@ -93,50 +93,55 @@ SS_DEV Q ldq(const float *p) { return Q{p[0], p[1], p[2], p[3]}; }
 SS_DEV void stq(float *p, const Q &q) { p[0] = q.w; p[1] = q.x; p[2] = q.y; p[3] = q.z; }
 
 // ------------------------------------------------------------------------------------------------ cooking
-// Forward kinematics of one frame (forward_kinematics_batch, torch_smpl_humanoid_batch.py:166-196).  The bodies are in
-// depth-first order, so the parent of body j is on the chain that led to body j-1: the chain's world transforms are
-// kept in a small stack (stk[(level * 13 + c) * ss], LDS on the GPU with ss = 64 so that lanes never collide).
-SS_DEV void fk_frame(const CookArgs &a, int f, float *stk, int ss) {
+// Forward kinematics (forward_kinematics_batch, torch_smpl_humanoid_batch.py:166-196): lane j of an LPE-lane group holds
+// body j of one frame, so every global load and store of a group is one contiguous row of the frame.  The tree is walked
+// level by level; a body reads its parent's world transform from the wave's LDS tile (xf[(group * LPE + body) * 13]).
+template <class W, int LPE>
+SS_DEV void fk_wave(W *w, const CookArgs &a, int wave_id, float *xf) {
   const ss_motion_data &d = a.d;
-  const int J = a.sk.nb, m = d.frame_motion[f], nq = 7 + 3 * (J - 1);
-  const float *off = d.offsets + (size_t)m * J * 3, *aa = d.pose_aa + (size_t)f * J * 3, *tr = d.trans + (size_t)f * 3;
-  int top = -1;
-  for (int j = 0; j < J; j++) {
-    const int s = a.sk.s2m[j], p = a.sk.parent[j];
-    const Q q = q_from_aa(aa[3 * s], aa[3 * s + 1], aa[3 * s + 2]);
+  const int J = a.sk.nb, lane = w->lane(), j = lane % LPE, g = lane / LPE, f = wave_id * (64 / LPE) + g, nq = 7 + 3 * (J - 1);
+  const bool act = f < d.num_frames && j < J;
+  float lm[9], R[9], P[3] = {0.f, 0.f, 0.f};
+  int p = -1, lev_j = -1;
+  const float *off = nullptr;
+  if (act) {
+    const int s = a.sk.s2m[j];
+    p = a.sk.parent[j]; lev_j = a.sk.depth[j];
+    off = d.offsets + ((size_t)d.frame_motion[f] * J + j) * 3;
+    const float *aa = d.pose_aa + ((size_t)f * J + s) * 3;
+    const Q q = q_from_aa(aa[0], aa[1], aa[2]);
     stq(d.lrs + ((size_t)f * J + s) * 4, q);
-    float lm[9], R[9], P[3];
     q_to_mat(q, lm);
-    if (p < 0) {
-      for (int c = 0; c < 9; c++) R[c] = lm[c];
-      for (int c = 0; c < 3; c++) P[c] = tr[c] + off[c];
-      top = 0;
-    } else {
-      while (top > 0 && (int)stk[(top * kStackSlots + 12) * ss] != p) top--;
-      float Rp[9], Pp[3];
-      for (int c = 0; c < 9; c++) Rp[c] = stk[(top * kStackSlots + c) * ss];
-      for (int c = 0; c < 3; c++) Pp[c] = stk[(top * kStackSlots + 9 + c) * ss];
-      const float *o = off + 3 * j;
-      for (int r = 0; r < 3; r++) {
-        P[r] = Rp[3 * r] * o[0] + Rp[3 * r + 1] * o[1] + Rp[3 * r + 2] * o[2] + Pp[r];
-        for (int c = 0; c < 3; c++) R[3 * r + c] = Rp[3 * r] * lm[c] + Rp[3 * r + 1] * lm[3 + c] + Rp[3 * r + 2] * lm[6 + c];
-      }
-      top++;
-    }
-    for (int c = 0; c < 9; c++) stk[(top * kStackSlots + c) * ss] = R[c];
-    for (int c = 0; c < 3; c++) stk[(top * kStackSlots + 9 + c) * ss] = P[c];
-    stk[(top * kStackSlots + 12) * ss] = (float)j;
-    float *gp = d.gts + ((size_t)f * J + j) * 3;
-    gp[0] = P[0]; gp[1] = P[1]; gp[2] = P[2];
-    stq(d.grs + ((size_t)f * J + j) * 4, mat_to_q(R));
     if (j >= 1) {                                            // matrix_to_euler_angles(.., "XYZ") (:331-364)
       float *dp = d.dof_pos + ((size_t)f * (J - 1) + (j - 1)) * 3;
       dp[0] = atan2f(-lm[5], lm[8]); dp[1] = asinf(clampf(lm[2], -1.f, 1.f)); dp[2] = atan2f(-lm[1], lm[0]);
-    } else {
-      float *qp = d.qpos + (size_t)f * nq;
-      qp[0] = P[0]; qp[1] = P[1]; qp[2] = P[2];
     }
     if (s == 0) stq(d.qpos + (size_t)f * nq + 3, q);         // qpos[3:7] = pose_quat[..., 0, :] (SMPL joint 0)
+  }
+  float *mine = xf + (g * LPE + j) * kXformStride;
+  for (int lev = 0; lev <= a.sk.maxdepth; lev++) {
+    if (lev_j == lev) {
+      if (p < 0) {
+        const float *tr = d.trans + (size_t)f * 3;
+        for (int c = 0; c < 9; c++) R[c] = lm[c];
+        for (int c = 0; c < 3; c++) P[c] = tr[c] + off[c];
+      } else {
+        const float *pp = xf + (g * LPE + p) * kXformStride;
+        for (int r = 0; r < 3; r++) {
+          P[r] = pp[3 * r] * off[0] + pp[3 * r + 1] * off[1] + pp[3 * r + 2] * off[2] + pp[9 + r];
+          for (int c = 0; c < 3; c++) R[3 * r + c] = pp[3 * r] * lm[c] + pp[3 * r + 1] * lm[3 + c] + pp[3 * r + 2] * lm[6 + c];
+        }
+      }
+      for (int c = 0; c < 9; c++) mine[c] = R[c];
+      for (int c = 0; c < 3; c++) mine[9 + c] = P[c];
+    }
+    w->sync();
+  }
+  if (act) {
+    float *gp = d.gts + ((size_t)f * J + j) * 3;
+    gp[0] = P[0]; gp[1] = P[1]; gp[2] = P[2];
+    stq(d.grs + ((size_t)f * J + j) * 4, mat_to_q(R));
+    if (j == 0) { float *qp = d.qpos + (size_t)f * nq; qp[0] = P[0]; qp[1] = P[1]; qp[2] = P[2]; }
   }
 }
 
@@ -173,50 +178,73 @@ SS_DEV void dof_fix_clip(W *w, const CookArgs &a, int m) {
   }
 }
 
-// _compute_velocity / _compute_angular_velocity (torch_smpl_humanoid_batch.py:198-221) + dof_vels, qvel (:148-161) of
-// body j in frame f: finite differences inside the clip, last difference repeated (linear) or zero (angular, whose last
-// quaternion difference is the identity), then the 17-tap Gaussian with the edge samples repeated.
-SS_DEV void vel_elem(const CookArgs &a, int f, int j) {
+// _compute_velocity / _compute_angular_velocity (torch_smpl_humanoid_batch.py:198-221) + dof_vels, qvel (:148-161): finite
+// differences inside the clip, last difference repeated (linear) or zero (angular, whose last quaternion difference is the
+// identity), then the 17-tap Gaussian with the edge samples repeated.  One wave owns kVelTile consecutive frames: it first
+// puts the raw velocities of those frames and of the 8 frames on either side into LDS (raw[(slot * J + body) * 6]), then
+// every output is 17 LDS taps — the acos / normalisation work is done ~2x per element instead of 17x.
+constexpr int kVelTile = 16;
+SS_DEV void raw_velocity(const CookArgs &a, int g, int j, float *o) {
   const ss_motion_data &d = a.d;
-  const int J = a.sk.nb, J1 = J - 1, m = d.frame_motion[f], s0 = d.length_starts[m], T = d.motion_num_frames[m], t = f - s0;
+  const int J = a.sk.nb, m = d.frame_motion[g], s0 = d.length_starts[m], T = d.motion_num_frames[m], t = g - s0;
   const float dt = d.motion_dt[m];
-  float lv[3] = {0.f, 0.f, 0.f}, av[3] = {0.f, 0.f, 0.f};
+  for (int c = 0; c < 6; c++) o[c] = 0.f;
+  if (T < 2) return;
+  const int b = t < T - 2 ? t : T - 2;
+  const float *p0 = d.gts + ((size_t)(s0 + b) * J + j) * 3, *p1 = p0 + (size_t)J * 3;
+  for (int c = 0; c < 3; c++) o[c] = (p1[c] - p0[c]) / dt;
+  if (t <= T - 2) {
+    const float *g0 = d.grs + ((size_t)g * J + j) * 4;
+    Q dq = q_mul(ldq(g0 + (size_t)J * 4), q_conj(ldq(g0)));
+    if (dq.w < 0.f) dq = Q{-dq.w, -dq.x, -dq.y, -dq.z};                         // quat_normalize = unit(pos(.))
+    const float n = fmaxf(sqrtf(dq.w * dq.w + dq.x * dq.x + dq.y * dq.y + dq.z * dq.z), 1e-9f);
+    dq = Q{dq.w / n, dq.x / n, dq.y / n, dq.z / n};
+    const float ang = acosf(clampf(2.f * dq.w * dq.w - 1.f, -1.f, 1.f));        // quat_angle_axis
+    const float an = fmaxf(sqrtf(dq.x * dq.x + dq.y * dq.y + dq.z * dq.z), 1e-10f);
+    o[3] = dq.x / an * ang / dt; o[4] = dq.y / an * ang / dt; o[5] = dq.z / an * ang / dt;
+  }
+}
+
+template <class W>
+SS_DEV void vel_wave(W *w, const CookArgs &a, int wave_id, float *raw) {
+  const ss_motion_data &d = a.d;
+  const int J = a.sk.nb, J1 = J - 1, F = d.num_frames, lane = w->lane();
+  const int f_lo = wave_id * kVelTile, g_lo = f_lo - kGaussRadius, nslot = kVelTile + 2 * kGaussRadius;
+  for (int idx = lane; idx < nslot * J; idx += 64) {
+    const int g = g_lo + idx / J;
+    if (g >= 0 && g < F) raw_velocity(a, g, idx % J, raw + (size_t)idx * 6);
+  }
+  w->sync();
   const int r = a.filter ? kGaussRadius : 0;
-  if (T >= 2) {
+  for (int idx = lane; idx < kVelTile * J; idx += 64) {
+    const int f = f_lo + idx / J, j = idx % J;
+    if (f >= F) break;
+    const int m = d.frame_motion[f], s0 = d.length_starts[m], T = d.motion_num_frames[m], t = f - s0;
+    const float dt = d.motion_dt[m];
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int k = -r; k <= r; k++) {
       int tt = t + k;
       tt = tt < 0 ? 0 : (tt > T - 1 ? T - 1 : tt);
       const float wgt = a.filter ? a.gw[k + kGaussRadius] : 1.f;
-      const int b = tt < T - 2 ? tt : T - 2;
-      const float *p0 = d.gts + ((size_t)(s0 + b) * J + j) * 3, *p1 = p0 + (size_t)J * 3;
-      for (int c = 0; c < 3; c++) lv[c] += wgt * ((p1[c] - p0[c]) / dt);
-      if (tt <= T - 2) {
-        const float *g0 = d.grs + ((size_t)(s0 + tt) * J + j) * 4;
-        Q dq = q_mul(ldq(g0 + (size_t)J * 4), q_conj(ldq(g0)));
-        if (dq.w < 0.f) dq = Q{-dq.w, -dq.x, -dq.y, -dq.z};                       // quat_normalize = unit(pos(.))
-        const float n = fmaxf(sqrtf(dq.w * dq.w + dq.x * dq.x + dq.y * dq.y + dq.z * dq.z), 1e-9f);
-        dq = Q{dq.w / n, dq.x / n, dq.y / n, dq.z / n};
-        const float ang = acosf(clampf(2.f * dq.w * dq.w - 1.f, -1.f, 1.f));      // quat_angle_axis
-        const float an = fmaxf(sqrtf(dq.x * dq.x + dq.y * dq.y + dq.z * dq.z), 1e-10f);
-        av[0] += wgt * (dq.x / an * ang / dt); av[1] += wgt * (dq.y / an * ang / dt); av[2] += wgt * (dq.z / an * ang / dt);
+      const float *x = raw + ((size_t)(s0 + tt - g_lo) * J + j) * 6;
+      for (int c = 0; c < 6; c++) acc[c] += wgt * x[c];
+    }
+    float *gv = d.gvs + ((size_t)f * J + j) * 3, *ga = d.gavs + ((size_t)f * J + j) * 3;
+    for (int c = 0; c < 3; c++) { gv[c] = acc[c]; ga[c] = acc[3 + c]; }
+    float *qv = d.qvel + (size_t)f * (6 + 3 * J1);
+    if (j >= 1) {
+      const int b = t < T - 2 ? t : T - 2;
+      float *dv = d.dvs + ((size_t)f * J1 + (j - 1)) * 3;
+      for (int c = 0; c < 3; c++) {
+        float v = 0.f;
+        if (T >= 2) { const float *x0 = d.dof_pos + ((size_t)(s0 + b) * J1 + (j - 1)) * 3; v = (x0[(size_t)J1 * 3 + c] - x0[c]) / dt; }
+        dv[c] = v; qv[6 + 3 * (j - 1) + c] = v;
       }
+    } else {                                                 // qvel[0:6]: world linear velocity, BODY-frame angular velocity
+      float Rm[9];
+      q_to_mat(ldq(d.lrs + ((size_t)f * J + a.sk.s2m[0]) * 4), Rm);
+      for (int c = 0; c < 3; c++) { qv[c] = acc[c]; qv[3 + c] = Rm[c] * acc[3] + Rm[3 + c] * acc[4] + Rm[6 + c] * acc[5]; }
     }
-  }
-  float *gv = d.gvs + ((size_t)f * J + j) * 3, *ga = d.gavs + ((size_t)f * J + j) * 3;
-  for (int c = 0; c < 3; c++) { gv[c] = lv[c]; ga[c] = av[c]; }
-  float *qv = d.qvel + (size_t)f * (6 + 3 * J1);
-  if (j >= 1) {
-    const int b = t < T - 2 ? t : T - 2;
-    float *dv = d.dvs + ((size_t)f * J1 + (j - 1)) * 3;
-    for (int c = 0; c < 3; c++) {
-      float v = 0.f;
-      if (T >= 2) { const float *x0 = d.dof_pos + ((size_t)(s0 + b) * J1 + (j - 1)) * 3; v = (x0[(size_t)J1 * 3 + c] - x0[c]) / dt; }
-      dv[c] = v; qv[6 + 3 * (j - 1) + c] = v;
-    }
-  } else {                                                   // qvel[0:6]: world linear velocity, BODY-frame angular velocity
-    float Rm[9];
-    q_to_mat(ldq(d.lrs + ((size_t)f * J + a.sk.s2m[0]) * 4), Rm);
-    for (int c = 0; c < 3; c++) { qv[c] = lv[c]; qv[3 + c] = Rm[c] * av[0] + Rm[3 + c] * av[1] + Rm[6 + c] * av[2]; }
   }
 }
 

@@ -14,7 +14,7 @@
 namespace ss {
 namespace mo {
 
-// packs and validates the skeleton: depth-first body order is what lets fk_frame keep only the current chain
+// packs and validates the skeleton (the reference's MuJoCo body order is depth-first; the level of each body drives fk_wave)
 inline bool pack_skeleton(const ss_skeleton *s, Skel *out, std::string *err) {
   if (!s || !s->parent || !s->smpl_2_mujoco) { *err = "null skeleton"; return false; }
   const int J = s->nbody;
@@ -38,6 +38,8 @@ inline bool pack_skeleton(const ss_skeleton *s, Skel *out, std::string *err) {
     }
     out->parent[j] = (int8_t)p;
     out->s2m[j] = (uint8_t)m;
+    out->depth[j] = (uint8_t)depth[j];
+    if (depth[j] > out->maxdepth) out->maxdepth = depth[j];
   }
   out->nb = J;
   return true;

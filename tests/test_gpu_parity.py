@@ -544,3 +544,10 @@ def test_imitation_env_autoreset_and_truncation_on_gpu():
     torch.cuda.synchronize()
     assert ended.all()
     assert ((env.start_times + env.base.cur_t * env.dt) <= env.motion_len + 1e-5).all()
+
+
+def test_motion_lib_52_body_skeleton_on_gpu():
+    import test_motion_lib as T
+    from smplsim_amd import _lib
+    lib, sk, clips = T.smplx_lib(None, device=0)
+    T.check_smplx(lib, sk, clips, _lib.lib(), device="cuda")

@@ -348,3 +348,69 @@ def test_emu_resample_and_masked_state_write(emu_lib):
     want = lib.get_motion_state(ids2, t0.clamp(min=0), with_qpos=True)
     assert (qpos[~torch.as_tensor(mk)] == 7.0).all() and torch.equal(qpos[torch.as_tensor(mk)], want["qpos"][torch.as_tensor(mk)])
     assert torch.equal(qvel[torch.as_tensor(mk)], want["qvel"][torch.as_tensor(mk)])
+
+
+# ------------------------------------------------------------------ 52-body skeleton (SMPL-X/H layout): 64 lanes per env
+def smplx_lib(clib, device="cpu"):
+    from smplsim_amd.motion_lib import MotionLibSMPL, Skeleton
+    from smplsim_amd.mjcf import compile_mjcf
+    from smplsim_amd.mjcf_writer import default_xml_str
+    mc = compile_mjcf(default_xml_str("smplx_humanoid"))
+    rs = np.random.default_rng(52)
+    perm = rs.permutation(52)
+    perm[list(perm).index(0)], perm[0] = perm[0], 0           # joint 0 stays the root, the rest in a scrambled "SMPL" order
+    order = [mc.body_names[i] for i in perm]
+    sk = Skeleton(mc.body_names, mc.body_parent, mc.body_pos, smpl_order_names=order)
+    clips = {}
+    for c, T in enumerate((33, 20)):
+        t = np.arange(T)[:, None, None] / 30.0
+        pose = rs.normal(size=(1, 52, 3)) * 0.4 + 0.5 * np.sin(2 * np.pi * rs.uniform(0.5, 2, size=(1, 52, 3)) * t)
+        trans = np.stack([0.5 * t[:, 0, 0], 0 * t[:, 0, 0], 0.95 + 0 * t[:, 0, 0]], -1)
+        clips[f"x{c}"] = dict(pose_aa=pose.reshape(T, -1).astype(np.float32), trans=trans.astype(np.float32), fps=30)
+    kw = dict(_clib=clib) if clib is not None else dict(device=device)
+    lib = MotionLibSMPL(clips, sk, **kw)
+    lib.load_motions(random_sample=False)
+    return lib, sk, clips
+
+
+def check_smplx(lib, sk, clips, clib, device="cpu"):
+    import ctypes as C
+    from smplsim_amd import _cabi
+    J = 52
+    st = 0
+    for c in clips.values():
+        T = c["pose_aa"].shape[0]
+        r = mo.cook(c["pose_aa"].reshape(T, J, 3), c["trans"], sk.offsets, sk.parents, sk.smpl_2_mujoco, 1 / 30, True)
+        for k, attr in NAMES.items():
+            got = getattr(lib, attr).cpu().numpy()[st:st + T]
+            ref = r[k].reshape(got.shape)
+            err = np.minimum(np.abs(got - ref).max(-1), np.abs(got + ref).max(-1)).max() if k.endswith("rotation") else np.abs(got - ref).max()
+            assert err < TOL[k], (k, err)
+        st += T
+    rs = np.random.default_rng(9)
+    n = 11
+    ids = rs.integers(0, 2, size=n).astype(np.int32)
+    times = (rs.uniform(0, 0.9, size=n) * lib._motion_lengths[ids]).astype(np.float32)
+    arr = lib_arrays(lib)
+    ref = mo.motion_state(arr, ids, times.astype(np.float64))
+    fut = mo.motion_state(arr, ids, (times + np.float32(1 / 30)).astype(np.float64))
+    pos = ref["rg_pos"] + rs.normal(size=(n, J, 3)) * 0.05
+    quat = mo.quat_mul(mo.axis_angle_to_quaternion(rs.normal(size=(n, J, 3)) * 0.2), ref["rb_rot"])
+    vel = np.concatenate([ref["body_vel"] + rs.normal(size=(n, J, 3)), ref["body_ang_vel"] + rs.normal(size=(n, J, 3))], -1)
+    cfg = _cabi.ImitationCfg(100.0, 10.0, 0.1, 0.1, 0.5, 0.3, 0.1, 0.1, 0.25, 1.0 / 30)
+    t = lambda a, dt=torch.float32: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(device)  # noqa: E731
+    d = [t(ids, torch.int32), t(times), t(pos), t(mo.quaternion_to_matrix(quat).reshape(n, J, 9)), t(vel)]
+    obs = torch.zeros(n, 24 * J, device=device); rew = torch.zeros(n, device=device); term = torch.zeros(n, dtype=torch.uint8, device=device)
+    p = lambda x: C.c_void_p(x.data_ptr())  # noqa: E731
+    assert clib.ss_imitation_step(C.byref(lib.data), C.byref(cfg), p(d[0]), p(d[1]), None, None, None, n, p(d[2]), p(d[3]), p(d[4]),
+                                  p(obs), 24 * J, p(rew), None, p(term), None, None) == 0
+    if device != "cpu":
+        torch.cuda.synchronize()
+    want_obs = mo.imitation_obs(pos, quat, vel[..., :3], vel[..., 3:], fut["rg_pos"], fut["rb_rot"], fut["body_vel"], fut["body_ang_vel"])
+    want_rew, _ = mo.imitation_reward(pos, quat, vel[..., :3], vel[..., 3:], ref["rg_pos"], ref["rb_rot"], ref["body_vel"], ref["body_ang_vel"])
+    assert np.abs(obs.cpu().numpy() - want_obs).max() < 2e-4 and np.abs(rew.cpu().numpy() - want_rew).max() < 2e-5
+
+
+def test_emu_52_body_skeleton_cook_and_imitation(emu_lib):
+    lib, sk, clips = smplx_lib(emu_lib)
+    check_smplx(lib, sk, clips, emu_lib)

@@ -240,14 +240,23 @@ struct EmuBackend {
   // ---- motion library: the element functions run as plain loops, the two wave functions on the 64-fiber machine
   struct FixCtx { const ss::mo::CookArgs *a; int m; Machine *mach; };
   static void fix_entry(int lane, void *arg) { FixCtx *c = (FixCtx *)arg; WaveEmu w{c->mach, lane}; ss::mo::dof_fix_clip(&w, *c->a, c->m); }
+  struct FkCtx { const ss::mo::CookArgs *a; int wave; Machine *mach; float *xf; };
+  template <int LPE> static void fk_entry(int lane, void *arg) { FkCtx *c = (FkCtx *)arg; WaveEmu w{c->mach, lane}; ss::mo::fk_wave<WaveEmu, LPE>(&w, *c->a, c->wave, c->xf); }
+  struct VelCtx { const ss::mo::CookArgs *a; int wave; Machine *mach; float *raw; };
+  static void vel_entry(int lane, void *arg) { VelCtx *c = (VelCtx *)arg; WaveEmu w{c->mach, lane}; ss::mo::vel_wave(&w, *c->a, c->wave, c->raw); }
   struct ImCtx { const ss::mo::ImArgs *a; int wave; Machine *mach; };
   template <int LPE> static void im_entry(int lane, void *arg) { ImCtx *c = (ImCtx *)arg; WaveEmu w{c->mach, lane}; ss::mo::imitation_wave<WaveEmu, LPE>(&w, *c->a, c->wave); }
   static Machine *machine() { static thread_local Machine *m = new Machine(); return m; }
   static const char *motion_cook(const ss::mo::CookArgs &a, void *) {
-    float stk[ss::mo::kMaxDepth * ss::mo::kStackSlots];
-    for (int f = 0; f < a.d.num_frames; f++) ss::mo::fk_frame(a, f, stk, 1);
+    float xf[64 * ss::mo::kXformStride];
+    const int lpe = a.sk.nb <= 32 ? 32 : 64, per = 64 / lpe;
+    for (int wv = 0; wv * per < a.d.num_frames; wv++) { FkCtx c{&a, wv, machine(), xf}; run_wave(machine(), lpe == 32 ? fk_entry<32> : fk_entry<64>, &c); }
     for (int m = 0; m < a.d.num_motions; m++) { FixCtx c{&a, m, machine()}; run_wave(machine(), fix_entry, &c); }
-    for (int f = 0; f < a.d.num_frames; f++) for (int j = 0; j < a.sk.nb; j++) ss::mo::vel_elem(a, f, j);
+    std::vector<float> raw((size_t)(ss::mo::kVelTile + 2 * ss::mo::kGaussRadius) * a.sk.nb * 6);
+    for (int wv = 0; wv * ss::mo::kVelTile < a.d.num_frames; wv++) {
+      for (auto &x : raw) x = __builtin_nanf("");            // reads of slots that were never written would show
+      VelCtx c{&a, wv, machine(), raw.data()}; run_wave(machine(), vel_entry, &c);
+    }
     return nullptr;
   }
   static const char *motion_state(const ss::mo::StateArgs &a, void *) {
