@@ -54,7 +54,7 @@ class SMPLSimImitationVecEnv:
         self.terminated = torch.zeros(N, dtype=torch.uint8, device=dev)
         self.truncated = torch.zeros(N, dtype=torch.uint8, device=dev)
         self.reset_buf = torch.zeros(N, dtype=torch.uint8, device=dev)
-        self.action_size = b.nu
+        self.action_size = self.nu = b.nu
         self.gen = torch.Generator(device=dev)
         self.gen.manual_seed(int(seed) + 1)
         # every step / reset launch also writes the body frames of its last forward: no separate ss_kinematics launch

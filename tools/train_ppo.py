@@ -4,6 +4,7 @@
 (env-steps/s of the sampler alone = stepper + policy inference, and of the whole epoch including the update).
 
     python tools/train_ppo.py --task HumanoidSpeed --envs 4096 --epochs 5
+    python tools/train_ppo.py --task HumanoidIm --envs 2048 --epochs 30      # motion imitation (synthetic clips unless --motion-file)
 """
 import argparse
 import json
@@ -28,8 +29,25 @@ def main():
     ap.add_argument("--opt-epochs", type=int, default=10)
     ap.add_argument("--amp-bf16", action="store_true", help="bf16 autocast for the update passes (not the reference numerics)")
     ap.add_argument("--save", default="")
+    ap.add_argument("--log-every", type=int, default=1)
+    ap.add_argument("--motion-file", default="", help="HumanoidIm: AMASS-style pickle ({key: {pose_aa, trans, fps}}); default = synthetic clips")
     args = ap.parse_args()
-    env = SMPLSimVecEnv(args.envs, task=args.task, autoreset=True, seed=0)
+    if args.task == "HumanoidIm":
+        from smplsim_amd.batch import ShardModel
+        from smplsim_amd.imitation import SMPLSimImitationVecEnv
+        from smplsim_amd.motion_lib import MotionLibSMPL, Skeleton
+        model = ShardModel(device=0)
+        if args.motion_file:
+            clips = args.motion_file
+        else:
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            from bench import synthetic_clips
+            clips = synthetic_clips(256, 300, 77)
+        ml = MotionLibSMPL(clips, Skeleton.from_model_const(model.mc), device=0)
+        ml.load_motions()
+        env = SMPLSimImitationVecEnv(args.envs, ml, model=model, seed=0)
+    else:
+        env = SMPLSimVecEnv(args.envs, task=args.task, autoreset=True, seed=0)
     cfg = PPOConfig(hidden=tuple(int(x) for x in args.hidden.split(",")), min_batch_size=args.min_batch_size, opt_num_epochs=args.opt_epochs, amp_bf16=args.amp_bf16)
     agent = AgentPPO(env, cfg, seed=0)
     ts, tu, n = 0.0, 0.0, 0
@@ -42,7 +60,11 @@ def main():
         T, N = batch["rewards"].shape
         if ep > 0:                                           # epoch 0 carries allocator / library warm-up
             ts += t1 - t0; tu += t2 - t1; n += T * N
+        if ep % args.log_every and ep != args.epochs - 1:
+            continue
+        ep_len = float(T * N / max(1.0, float((1.0 - batch["not_done"]).sum())))
         print(json.dumps({"epoch": ep, "samples": T * N, "sample_s": round(t1 - t0, 4), "update_s": round(t2 - t1, 4),
+                          "mean_episode_len": round(ep_len, 1),
                           **{k: round(float(v), 5) for k, v in info.items()}}))
     if n:
         print(json.dumps({"summary": "on-device PPO", "task": args.task, "envs": args.envs, "mlp": args.hidden,
