@@ -120,5 +120,41 @@ class SMPLSimImitationVecEnv:
         out, _ = self.motion_lib._lookup(self.motion_ids, t, None, False, ["dof_pos"])
         return (out["dof_pos"] / torch.pi).clamp_(-1.0, 1.0)
 
+    @torch.no_grad()
+    def evaluate(self, policy=None, max_steps=None):
+        """Score a policy the way the reference's evaluation scripts do (compute_metrics_lite, smpl_eval.py:58-94): env n
+        replays clip n % M from its first frame until the clip ends or the early-termination rule fires; body positions of
+        the simulated humanoid and of the clip are recorded on the device.  policy(obs) -> actions; None = PD clip replay.
+        Returns success rate (clips tracked to their end) and the mean metrics over the frames before termination."""
+        from . import metrics
+        ml, N = self.motion_lib, self.num_envs
+        auto, self.autoreset = self.autoreset, False
+        ids = torch.arange(N, device=self.device, dtype=torch.int32) % ml.num_current_motions()
+        obs, _ = self.reset(motion_ids=ids, start_times=torch.zeros(N, device=self.device))
+        steps = int(max_steps or torch.ceil(self.motion_len.max() / self.dt).item())
+        alive = torch.ones(N, dtype=torch.bool, device=self.device)
+        finished = torch.zeros(N, dtype=torch.bool, device=self.device)
+        pred, ref, valid = [], [], []
+        for _ in range(steps):
+            act = self.reference_actions() if policy is None else policy(obs)
+            obs, _, term, trunc, _ = self.step(act)
+            alive &= ~term
+            valid.append(alive & ~finished)
+            pred.append(self.xpos.clone())
+            ref.append(ml._lookup(self.motion_ids, self.times, self.offset, False, ["rg_pos"])[0]["rg_pos"])
+            finished |= trunc & alive
+        self.autoreset = auto
+        pred, ref, valid = torch.stack(pred), torch.stack(ref), torch.stack(valid)          # [T, N, ...]
+        pp, gg = [], []
+        for n in range(N):
+            k = int(valid[:, n].sum().item())
+            if k >= 3:                                           # the acceleration error needs three frames
+                pp.append(pred[:k, n]); gg.append(ref[:k, n])
+        out = {"success_rate": float(finished.float().mean().item()), "num_clips": N, "frames_scored": int(valid.sum().item())}
+        if pp:
+            m = metrics.compute_metrics_lite(pp, gg)
+            out.update({k: float(v.mean().item()) for k, v in m.items()})
+        return out
+
     def close(self):
         self.base.close()

@@ -14,6 +14,7 @@ writes tests/golden/motion_vectors.npz (committed).  Functions called, unmodifie
     matrix_to_euler_angles, fix_continous_dof, quat_mul_norm, quat_angle_axis}   smpl_sim/utils/pytorch3d_transforms.py
   * MotionLibBase._calc_frame_blend / get_motion_state_intervaled          smpl_sim/smpllib/motion_lib_base.py:311-355,442-453
   * torch_utils.slerp                                                      smpl_sim/utils/torch_utils.py:405-426
+  * smpl_eval.compute_metrics_lite (p_mpjpe, compute_error_vel/accel)      smpl_sim/smpllib/smpl_eval.py:58-138,298-339
 
 MotionLibBase.get_motion_state (:359-423) cannot run as written (it indexes NumPy arrays with the float frame numbers
 of _calc_frame_blend and calls Tensor.unsqueeze on NumPy arrays); its blend is pinned through slerp and the linear
@@ -136,6 +137,21 @@ def main():
     t = rs.uniform(0, 1, size=(256, 1)).astype(np.float32)
     out["sl_q0"], out["sl_q1"], out["sl_t"] = q0, q1, t
     out["sl_out"] = tu.slerp(torch.from_numpy(q0), torch.from_numpy(q1), torch.from_numpy(t)).numpy()
+
+    # ---- tracking metrics (smpl_sim/smpllib/smpl_eval.py:58-94): two sequences of different length
+    import smpl_sim.smpllib.smpl_eval as ev
+    pp, gp, pr, gr = [], [], [], []
+    for T in (17, 9):
+        gt = rs.normal(size=(T, 24, 3))
+        pred = gt + 0.05 * rs.normal(size=(T, 24, 3)) + 0.02 * np.sin(np.arange(T))[:, None, None]
+        qg = rs.normal(size=(T, 24, 4)); qg /= np.linalg.norm(qg, axis=-1, keepdims=True)
+        qp = qg + 0.1 * rs.normal(size=(T, 24, 4)); qp /= np.linalg.norm(qp, axis=-1, keepdims=True)
+        pp.append(pred); gp.append(gt); pr.append(qp); gr.append(qg)
+    m = ev.compute_metrics_lite(pp, gp, pr, gr, use_tqdm=False)
+    for k, v in m.items():
+        out["ev_" + k] = np.asarray(v)
+    for i in range(2):
+        out[f"ev_in_pred{i}"], out[f"ev_in_gt{i}"], out[f"ev_in_rpred{i}"], out[f"ev_in_rgt{i}"] = pp[i], gp[i], pr[i], gr[i]
 
     path = os.path.join(HERE, "motion_vectors.npz")
     np.savez_compressed(path, **out)

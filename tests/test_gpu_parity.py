@@ -551,3 +551,19 @@ def test_motion_lib_52_body_skeleton_on_gpu():
     from smplsim_amd import _lib
     lib, sk, clips = T.smplx_lib(None, device=0)
     T.check_smplx(lib, sk, clips, _lib.lib(), device="cuda")
+
+
+def test_imitation_evaluate_scores_a_pd_replay_on_gpu():
+    import test_motion_lib as T
+    from smplsim_amd.imitation import SMPLSimImitationVecEnv
+    lib = T.make_lib(None, device=0)
+    env = SMPLSimImitationVecEnv(6, lib, seed=1, termination_distance=10.0)      # never terminates: all frames are scored
+    env.offset[:, 2] = 0.05
+    r = env.evaluate()
+    assert r["success_rate"] == 1.0 and r["num_clips"] == 6 and r["frames_scored"] > 50
+    for k in ("mpjpe_g", "mpjpe_l", "mpjpe_pa", "vel_dist", "accel_dist"):
+        assert np.isfinite(r[k]) and r[k] >= 0
+    assert r["mpjpe_pa"] <= r["mpjpe_l"] + 1e-3 <= r["mpjpe_g"] + 2e-3              # alignment can only reduce the error
+    env2 = SMPLSimImitationVecEnv(6, lib, seed=1, termination_distance=1e-4)      # terminates at once
+    env2.offset[:, 2] = 0.05
+    assert env2.evaluate()["success_rate"] == 0.0

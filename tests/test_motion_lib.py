@@ -414,3 +414,17 @@ def check_smplx(lib, sk, clips, clib, device="cpu"):
 def test_emu_52_body_skeleton_cook_and_imitation(emu_lib):
     lib, sk, clips = smplx_lib(emu_lib)
     check_smplx(lib, sk, clips, emu_lib)
+
+
+# ------------------------------------------------------------------ tracking metrics vs the reference's smpl_eval
+def test_tracking_metrics_match_reference_smpl_eval():
+    from smplsim_amd import metrics
+    t = lambda a: torch.as_tensor(a, dtype=torch.float64)  # noqa: E731
+    m = metrics.compute_metrics_lite([t(G["ev_in_pred0"]), t(G["ev_in_pred1"])], [t(G["ev_in_gt0"]), t(G["ev_in_gt1"])],
+                                     [t(G["ev_in_rpred0"]), t(G["ev_in_rpred1"])], [t(G["ev_in_rgt0"]), t(G["ev_in_rgt1"])])
+    for k in ("mpjpe_g", "mpjpe_l", "mpjpe_pa", "accel_dist", "vel_dist", "rot_error"):
+        ref = G["ev_" + k]
+        assert m[k].shape == ref.shape, k
+        assert np.abs(m[k].numpy() - ref).max() < 1e-8 * max(1.0, np.abs(ref).max()), k
+    m32 = metrics.compute_metrics_lite([t(G["ev_in_pred0"]).float()], [t(G["ev_in_gt0"]).float()])
+    assert np.abs(m32["mpjpe_pa"].numpy() - G["ev_mpjpe_pa"][:17]).max() < 1e-2      # millimetres, float32

@@ -70,6 +70,11 @@ def main():
         print(json.dumps({"summary": "on-device PPO", "task": args.task, "envs": args.envs, "mlp": args.hidden,
                           "sampler_env_steps_per_s": round(n / ts), "epoch_env_steps_per_s": round(n / (ts + tu)),
                           "sample_fraction": round(ts / (ts + tu), 3)}))
+    if args.task == "HumanoidIm":                               # tracking quality of the mean action, every clip from its first frame
+        agent.policy_net.eval()
+        print(json.dumps({"eval": "compute_metrics_lite over all clips (mm)", **{k: round(v, 3) if isinstance(v, float) else v for k, v in
+                          env.evaluate(lambda o: agent._prep_actions(agent.policy_net.select_action(agent._prep_obs(o), True))).items()}}))
+        print(json.dumps({"eval": "PD clip replay (no policy)", **{k: round(v, 3) if isinstance(v, float) else v for k, v in env.evaluate().items()}}))
     if args.save:
         torch.save(agent.get_full_state_weights(), args.save)
 
