@@ -514,6 +514,8 @@ def test_imitation_env_rollout_on_gpu_tracks_oracle():
             assert np.abs(oe.data.qpos - _np(env.base.qpos)[i]).max() < 5e-4, (k, i)
         times = t0 + np.float32((k + 1) * env.dt)
         assert np.abs(_np(env.times) - times).max() < 1e-6 and not _np(env.truncated).any()
+        kx, km = env.base.kinematics()                       # the step launch's by-product == a separate mj_kinematics launch
+        assert torch.equal(kx, env.xpos) and torch.equal(km, env.xmat)
         xpos, xmat, bv = _np(env.xpos).astype(np.float64), _np(env.xmat).astype(np.float64), _np(env.base.body_vel).astype(np.float64)
         quat = mo.matrix_to_quaternion(xmat.reshape(n, J, 3, 3))
         ref = mo.motion_state(arr, ids, times.astype(np.float64), off)
@@ -567,3 +569,42 @@ def test_imitation_evaluate_scores_a_pd_replay_on_gpu():
     env2 = SMPLSimImitationVecEnv(6, lib, seed=1, termination_distance=1e-4)      # terminates at once
     env2.offset[:, 2] = 0.05
     assert env2.evaluate()["success_rate"] == 0.0
+
+
+def test_smplx_imitation_env_on_gpu():
+    """52-body model: the BODYOUT instantiation of the SMPL-X step kernel + the 64-lanes-per-env imitation kernel."""
+    import test_motion_lib as T
+    from oracle import motion_oracle as mo
+    from smplsim_amd.batch import ShardModel
+    from smplsim_amd.imitation import SMPLSimImitationVecEnv
+    lib, sk, clips = T.smplx_lib(None, device=0)
+    n, J = 5, 52
+    env = SMPLSimImitationVecEnv(n, lib, model=ShardModel(humanoid="smplx_humanoid", device=0), autoreset=False, seed=2)
+    ids = np.array([0, 1, 0, 1, 0], np.int32)
+    t0 = np.array([0.0, 0.1, 0.3, 0.2, 0.5], np.float32)
+    obs, _ = env.reset(motion_ids=ids, start_times=t0)
+    assert obs.shape == (n, env.base.obs_size + 24 * J)
+    om = oracle_model("smplx_humanoid")
+    oenvs = []
+    for i in range(n):
+        oe = O.OracleEnv(om, state_init=O.INIT_EXTERNAL, self_obs_v=2, episode_length=10 ** 6)
+        oe.data.qpos = _np(env.base.qpos)[i].astype(np.float64); oe.data.qvel = _np(env.base.qvel)[i].astype(np.float64)
+        assert np.abs(oe.reset() - _np(obs)[i, :env.base.obs_size]).max() < 5e-4
+        oenvs.append(oe)
+    arr = T.lib_arrays(lib)
+    for k in range(2):
+        act = env.reference_actions()
+        obs, rew, term, trunc, _ = env.step(act)
+        torch.cuda.synchronize()
+        for i, oe in enumerate(oenvs):
+            oe.step(_np(act)[i].astype(np.float64))
+            assert np.abs(oe.data.qpos - _np(env.base.qpos)[i]).max() < 1e-3, (k, i)
+        kx, km = env.base.kinematics()
+        assert torch.equal(kx, env.xpos) and torch.equal(km, env.xmat)
+        times = (t0 + np.float32((k + 1) * env.dt)).astype(np.float64)
+        xpos, bv = _np(env.xpos).astype(np.float64), _np(env.base.body_vel).astype(np.float64)
+        quat = mo.matrix_to_quaternion(_np(env.xmat).astype(np.float64).reshape(n, J, 3, 3))
+        ref, fut = mo.motion_state(arr, ids, times), mo.motion_state(arr, ids, times + np.float32(env.dt))
+        want_obs = mo.imitation_obs(xpos, quat, bv[..., :3], bv[..., 3:], fut["rg_pos"], fut["rb_rot"], fut["body_vel"], fut["body_ang_vel"])
+        want_rew, _ = mo.imitation_reward(xpos, quat, bv[..., :3], bv[..., 3:], ref["rg_pos"], ref["rb_rot"], ref["body_vel"], ref["body_ang_vel"])
+        assert np.abs(_np(obs)[:, env.base.obs_size:] - want_obs).max() < 1e-3 and np.abs(_np(rew) - want_rew).max() < 1e-4
