@@ -171,7 +171,8 @@ int ss_gae(const float *rewards, const float *not_done, const float *not_dead, c
 /* -DSS_PROFILE builds only: accumulated shader-clock ticks per kernel stage (tools/stage_profile.py) */
 int ss_debug_prof(ss_batch *b, unsigned long long *out, int n);
 
-/* launch geometry actually used (envs per workgroup, LDS bytes per workgroup) */
+/* launch geometry: resident envs per workgroup = per CU (LDS-capacity bound) and the LDS bytes of such a workgroup; batches
+ * smaller than (CUs x envs_per_wg) are launched with ceil(N / CUs) envs per workgroup so that they cover every CU */
 int ss_launch_info(const ss_batch *b, int32_t *envs_per_wg, int32_t *lds_bytes, int32_t *kernel_regs);
 
 const char *ss_last_error(void);

@@ -240,6 +240,13 @@ struct HipBackend {
       configured[slot] = kern; configured_lds[slot] = lds_bytes;
     }
     static thread_local int cus = num_cus();
+    // small batches: spread the envs over all CUs instead of filling a third of them with full workgroups — a wave that
+    // shares its CU with 3 others runs ~13% faster than one of 12 (1024 envs: 1.27 -> 1.13 ms per step launch)
+    const int per_cu = (nenv + cus - 1) / cus;
+    if (per_cu < envs_per_wg) {
+      envs_per_wg = per_cu < 1 ? 1 : per_cu;
+      lds_bytes = (size_t)((k.h.shared_words + 3) & ~3) * 4 + (size_t)envs_per_wg * k.h.env_floats * 4;
+    }
     int wgs = (nenv + envs_per_wg - 1) / envs_per_wg;
     const int resident = cus * (int)(lds_capacity() / lds_bytes > 0 ? lds_capacity() / lds_bytes : 1);
     if (wgs > resident) wgs = resident;                      // persistent: one resident set of workgroups
