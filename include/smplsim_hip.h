@@ -175,6 +175,12 @@ int ss_debug_prof(ss_batch *b, unsigned long long *out, int n);
  * smaller than (CUs x envs_per_wg) are launched with ceil(N / CUs) envs per workgroup so that they cover every CU */
 int ss_launch_info(const ss_batch *b, int32_t *envs_per_wg, int32_t *lds_bytes, int32_t *kernel_regs);
 
+/* Launch-geometry override for callers that step several batches concurrently on different streams (body-shape groups):
+ * envs_per_wg = run every launch of this batch with exactly that many envs per workgroup (1 .. ss_launch_info's value; 0 =
+ * automatic, which spreads a small batch over all CUs and thereby claims every CU's LDS); max_workgroups = cap on the
+ * persistent workgroups of a launch (0 = one per CU), so that K concurrent batches can each own 1/K of the CUs. */
+int ss_set_launch_geometry(ss_batch *b, int32_t envs_per_wg, int32_t max_workgroups);
+
 const char *ss_last_error(void);
 
 #ifdef __cplusplus

@@ -225,7 +225,7 @@ struct HipBackend {
   }
   static int &regs_ref() { static int r = 0; return r; }
   static int kernel_regs() { return regs_ref(); }
-  static const char *launch(const ss::KArgs &k, int nenv, int envs_per_wg, size_t lds_bytes, void *stream) {
+  static const char *launch(const ss::KArgs &k, int nenv, int envs_per_wg, size_t lds_bytes, void *stream, int fixed_epw, int max_wgs) {
     const bool bodyout = k.out0 && (k.mode == ss::MODE_STEP || k.mode == ss::MODE_RESET);
     kern_t kern = pick_kernel(ss::kernel_variant(k.h), bodyout);
     if (!kern) return "no kernel variant for this model size";
@@ -243,13 +243,17 @@ struct HipBackend {
     // small batches: spread the envs over all CUs instead of filling a third of them with full workgroups — a wave that
     // shares its CU with 3 others runs ~13% faster than one of 12 (1024 envs: 1.27 -> 1.13 ms per step launch)
     const int per_cu = (nenv + cus - 1) / cus;
-    if (per_cu < envs_per_wg) {
+    if (fixed_epw > 0) {                                      // fixed by the caller (ss_set_launch_geometry)
+      envs_per_wg = fixed_epw;
+      lds_bytes = (size_t)((k.h.shared_words + 3) & ~3) * 4 + (size_t)envs_per_wg * k.h.env_floats * 4;
+    } else if (per_cu < envs_per_wg) {
       envs_per_wg = per_cu < 1 ? 1 : per_cu;
       lds_bytes = (size_t)((k.h.shared_words + 3) & ~3) * 4 + (size_t)envs_per_wg * k.h.env_floats * 4;
     }
     int wgs = (nenv + envs_per_wg - 1) / envs_per_wg;
     const int resident = cus * (int)(lds_capacity() / lds_bytes > 0 ? lds_capacity() / lds_bytes : 1);
     if (wgs > resident) wgs = resident;                      // persistent: one resident set of workgroups
+    if (max_wgs > 0 && wgs > max_wgs) wgs = max_wgs;         // the caller shares the GPU between concurrent batches
     if (hipMemsetAsync(k.work_counter, 0, sizeof(int32_t), (hipStream_t)stream) != hipSuccess) return "hipMemsetAsync failed";
     dim3 grid(wgs), block(64 * envs_per_wg);
     hipLaunchKernelGGL(kern, grid, block, lds_bytes, (hipStream_t)stream, k);

@@ -2,7 +2,7 @@
 // backend: the HIP backend in smplsim_hip.hip (the product) and the wavefront-emulator backend in
 // tests/wave_emu/emu.cpp (unit-test infrastructure).  A backend provides:
 //   static void *alloc(size_t);  static void free_(void *);  static bool upload(void *dst, const void *src, size_t);
-//   static int lds_capacity();   static int max_waves(int variant);   static const char *launch(const ss::KArgs &, int nenv, int envs_per_wg, size_t lds_bytes, void *stream);
+//   static int lds_capacity();   static int max_waves(int variant);   static const char *launch(const ss::KArgs &, int nenv, int envs_per_wg, size_t lds_bytes, void *stream, int fixed_envs_per_wg, int max_wgs);
 //   static bool set_device(int);
 #pragma once
 #include <cstdlib>
@@ -34,6 +34,7 @@ struct ss_batch {
   const int32_t *order = nullptr;         // caller-owned device array or null
   int32_t *d_sched = nullptr;             // library-owned [N] hand-out order written by ss_schedule_longest_first
   float *body_xpos = nullptr, *body_xmat = nullptr;   // caller-owned, optional: written by every step / reset (ss_set_body_outputs)
+  int fixed_envs_per_wg = 0, max_wgs = 0; // ss_set_launch_geometry: 0 = automatic (small batches are spread over all CUs)
 };
 
 template <class BE>
@@ -116,7 +117,7 @@ struct ss_api {
   }
   static int run(const ss_batch *b, const ss::KArgs &k, void *stream) {
     if (!BE::set_device(b->m->device)) return fail(SS_ERR_HIP, "cannot select device");
-    const char *err = BE::launch(k, b->st.num_envs, b->envs_per_wg, b->lds_bytes, stream);
+    const char *err = BE::launch(k, b->st.num_envs, b->envs_per_wg, b->lds_bytes, stream, b->fixed_envs_per_wg, b->max_wgs);
     if (err) return fail(SS_ERR_HIP, err);
     return SS_OK;
   }
@@ -183,6 +184,11 @@ struct ss_api {
   int ss_set_order(ss_batch *b, const int32_t *order) {                                                              \
     if (!b) return ss_api<BE>::fail(SS_ERR_INVALID, "null batch");                                                  \
     b->order = order; return SS_OK;                                                                                  \
+  }                                                                                                                  \
+  int ss_set_launch_geometry(ss_batch *b, int32_t envs_per_wg, int32_t max_workgroups) {                              \
+    if (!b || envs_per_wg < 0 || envs_per_wg > b->envs_per_wg || max_workgroups < 0)                                   \
+      return ss_api<BE>::fail(SS_ERR_INVALID, "envs per workgroup must be in [0, ss_launch_info's value], max_workgroups >= 0"); \
+    b->fixed_envs_per_wg = envs_per_wg; b->max_wgs = max_workgroups; return SS_OK;                                     \
   }                                                                                                                  \
   int ss_set_body_outputs(ss_batch *b, float *xpos, float *xmat) {                                                    \
     if (!b || (!xpos) != (!xmat)) return ss_api<BE>::fail(SS_ERR_INVALID, "pass both buffers or neither");           \

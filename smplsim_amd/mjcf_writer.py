@@ -86,3 +86,21 @@ def load_table(name="smpl_humanoid"):
 
 def default_xml_str(name="smpl_humanoid"):
     return table_to_mjcf(load_table(name))
+
+
+def scaled_xml_str(name="smpl_humanoid", scale=1.0, limb_scale=None):
+    """A body-shape variant of a packaged model: every body offset, geom position / size / fromto scaled by `scale`, times
+    limb_scale[body] for that body's own offset and geoms (stand-in for the MJCFs SMPL_Robot writes for different betas,
+    reference smpl_sim/smpllib/smpl_local_robot.py — those need the SMPL model files)."""
+    import copy
+    t = copy.deepcopy(load_table(name))
+    limb_scale = limb_scale or {}
+    for b in t["bodies"]:
+        f = scale * limb_scale.get(b["name"], 1.0)
+        if b["parent"] is not None:
+            b["pos"] = [f * x for x in b["pos"]]
+        for g in b["geoms"]:
+            for k in ("pos", "size", "fromto"):
+                if k in g:
+                    g[k] = [f * x for x in g[k]]
+    return table_to_mjcf(t)

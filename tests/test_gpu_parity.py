@@ -608,3 +608,42 @@ def test_smplx_imitation_env_on_gpu():
         want_obs = mo.imitation_obs(xpos, quat, bv[..., :3], bv[..., 3:], fut["rg_pos"], fut["rb_rot"], fut["body_vel"], fut["body_ang_vel"])
         want_rew, _ = mo.imitation_reward(xpos, quat, bv[..., :3], bv[..., 3:], ref["rg_pos"], ref["rb_rot"], ref["body_vel"], ref["body_ang_vel"])
         assert np.abs(_np(obs)[:, env.base.obs_size:] - want_obs).max() < 1e-3 and np.abs(_np(rew) - want_rew).max() < 1e-4
+
+
+def test_shape_varied_env_groups_match_their_oracles_and_standalone_envs(vec):
+    """Two body shapes in one shard: every group against the oracle built from ITS MJCF, and bit-identical
+    to the same group stepped as a standalone env (the grouping / streams change nothing)."""
+    from helpers import FEET, pd_tables
+    from smplsim_amd.batch import ShardModel
+    from smplsim_amd.mjcf import compile_mjcf
+    from smplsim_amd.mjcf_writer import scaled_xml_str
+    from smplsim_amd.shapes import ShapeVariedVecEnv
+    xmls = [scaled_xml_str("smpl_humanoid", 1.0), scaled_xml_str("smpl_humanoid", 0.85, {"L_Knee": 1.15, "R_Knee": 1.15, "Chest": 0.9})]
+    env = ShapeVariedVecEnv(xmls, 4, autoreset=False, seed=0)
+    solo = [vec(4, model=ShardModel(xml=x), autoreset=False, seed=1000 * g) for g, x in enumerate(xmls)]
+    obs, _ = env.reset()
+    for s in solo:
+        s.reset()
+    oenvs = []
+    for x in xmls:
+        mc = compile_mjcf(x)
+        om = O.OracleModel(x, *pd_tables(mc), legal_bodies=FEET, timestep=1.0 / 450)
+        oe = O.OracleEnv(om)
+        oenvs.append(oe)
+    torch.cuda.synchronize()
+    assert np.abs(oenvs[0].reset() - _np(obs)[0]).max() < 1e-5 and np.abs(oenvs[1].reset() - _np(obs)[4]).max() < 1e-5
+    assert np.abs(_np(obs)[0] - _np(obs)[4]).max() > 1e-3                 # the shapes really differ
+    rs = np.random.default_rng(4)
+    for k in range(6):
+        a = rs.uniform(-0.3, 0.3, (2, 69))
+        act = torch.tensor(np.repeat(a, 4, axis=0), device=env.device, dtype=torch.float32)
+        obs, rew, term, trunc, info = env.step(act)
+        for g, s in enumerate(solo):
+            s.step(act[4 * g:4 * g + 4])
+        torch.cuda.synchronize()
+        qpos, qvel = env.state()
+        for g in range(2):
+            o_ref, r, te, tu = oenvs[g].step(a[g])
+            assert np.abs(_np(qpos)[4 * g] - oenvs[g].data.qpos).max() < 2 * TOL_QPOS and np.abs(_np(obs)[4 * g] - o_ref).max() < TOL_OBS, (k, g)
+            assert torch.equal(qpos[4 * g:4 * g + 4], solo[g].qpos) and torch.equal(obs[4 * g:4 * g + 4], solo[g].obs_buf)
+    assert obs.shape == (8, env.obs_size) and rew.shape == (8,)

@@ -272,7 +272,7 @@ struct EmuBackend {
     for (int wv = 0; wv * per < a.N; wv++) { ImCtx c{&a, wv, machine()}; run_wave(machine(), lpe == 32 ? im_entry<32> : im_entry<64>, &c); }
     return nullptr;
   }
-  static const char *launch(const ss::KArgs &k, int nenv, int envs_per_wg, size_t lds_bytes, void *) {
+  static const char *launch(const ss::KArgs &k, int nenv, int envs_per_wg, size_t lds_bytes, void *, int, int) {
     (void)envs_per_wg; (void)lds_bytes;
     static thread_local Machine *m = new Machine();
     std::vector<float> L(k.h.env_floats);
