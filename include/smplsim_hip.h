@@ -98,6 +98,9 @@ typedef struct {
   float *pid_integral;   /* [N,nu] */
   float *pid_last_error; /* [N,nu] */
   int32_t *pid_started;  /* [N]    0 until the controller ran once (its first derivative term is zero) */
+  /* models made by ss_model_create_shapes only (NULL otherwise): body shape of every env, 0 .. num_shapes-1; read by every
+   * launch, so it may be rewritten between launches (e.g. a new body at reset) */
+  const int32_t *shape_id; /* [N] */
 } ss_state;
 
 typedef struct ss_model ss_model;
@@ -105,6 +108,11 @@ typedef struct ss_batch ss_batch;
 
 /* mujoco.MjModel.from_xml_string + setup_humanoid_properties + setup_controller */
 int ss_model_create(const ss_model_desc *desc, int device_id, ss_model **out);
+/* Per-env body shapes (reference cfg.robot.has_shape_variation, humanoid_env.py:205: every env process builds its own MJCF from
+ * its betas): num_shapes descriptions of the SAME humanoid — tree, joints, limits, gains, actuators, geom types and options
+ * must agree; body offsets, inertias, geom sizes / positions and the inverse weights may differ.  The geometry tables are
+ * stored per shape and every env reads those of ss_state.shape_id[env]; one launch steps all shapes together. */
+int ss_model_create_shapes(const ss_model_desc *descs, int32_t num_shapes, int device_id, ss_model **out);
 void ss_model_destroy(ss_model *m);
 /* nq, nv, nu, nbody, obs size for (self_obs_v, task, root_height_obs) — humanoid_env.py:293-299 */
 int ss_model_dims(const ss_model *m, int32_t *nq, int32_t *nv, int32_t *nu, int32_t *nbody);

@@ -50,7 +50,7 @@ class State(C.Structure):
         ("num_envs", C.c_int32), ("qpos", C.c_void_p), ("qvel", C.c_void_p), ("qpos_prev", C.c_void_p),
         ("qvel_prev", C.c_void_p), ("qacc_warm", C.c_void_p), ("body_vel", C.c_void_p), ("touch", C.c_void_p),
         ("cur_t", C.c_void_p), ("task", C.c_void_p), ("nwarn", C.c_void_p), ("solver_iters", C.c_void_p),
-        ("pid_integral", C.c_void_p), ("pid_last_error", C.c_void_p), ("pid_started", C.c_void_p),
+        ("pid_integral", C.c_void_p), ("pid_last_error", C.c_void_p), ("pid_started", C.c_void_p), ("shape_id", C.c_void_p),
     ]
 
 
@@ -83,6 +83,7 @@ class ImitationCfg(C.Structure):
 def bind(lib):
     vp = C.c_void_p
     lib.ss_model_create.argtypes = [C.POINTER(ModelDesc), C.c_int, C.POINTER(vp)]
+    lib.ss_model_create_shapes.argtypes = [C.POINTER(ModelDesc), C.c_int32, C.c_int, C.POINTER(vp)]
     lib.ss_model_destroy.argtypes = [vp]; lib.ss_model_destroy.restype = None
     lib.ss_model_dims.argtypes = [vp] + [C.POINTER(C.c_int32)] * 4
     lib.ss_obs_size.argtypes = [vp, C.POINTER(EnvCfg)]
@@ -110,7 +111,7 @@ def bind(lib):
     return lib
 
 
-EXPORTS = ["ss_model_create", "ss_model_destroy", "ss_model_dims", "ss_obs_size", "ss_batch_create",
+EXPORTS = ["ss_model_create", "ss_model_create_shapes", "ss_model_destroy", "ss_model_dims", "ss_obs_size", "ss_batch_create",
            "ss_batch_destroy", "ss_reset", "ss_step", "ss_step_autoreset", "ss_substep", "ss_kinematics", "ss_debug_forward",
            "ss_gae", "ss_debug_prof", "ss_set_order", "ss_set_body_outputs", "ss_set_launch_geometry", "ss_schedule_longest_first", "ss_launch_info", "ss_last_error",
            "ss_motion_cook", "ss_motion_state_at", "ss_motion_resample", "ss_imitation_step"]

@@ -33,20 +33,26 @@ class ShardModel:
     """Compiled model + device tables (ss_model) for one device."""
 
     def __init__(self, xml=None, humanoid="smpl_humanoid", device=0, contact_bodies=DEFAULT_CONTACT_BODIES,
-                 control_mode="uhc_pd", clip_actions=True, pdp_scale=1.0, pdd_scale=1.0, sim_timestep_inv=450, tables=None):
+                 control_mode="uhc_pd", clip_actions=True, pdp_scale=1.0, pdd_scale=1.0, sim_timestep_inv=450, tables=None, xmls=None):
         """tables: optional (kp, kd, torque_lim, act_scale, act_offset) per actuator for models whose bodies are not in
-        the reference's gain table (humanoid_env.py:62-84)."""
-        self.xml = xml if xml is not None else default_xml_str(humanoid)
-        self.mc = compile_mjcf(self.xml)
+        the reference's gain table (humanoid_env.py:62-84).
+        xmls: a list of MJCF strings = body shapes of the same humanoid (cfg.robot.has_shape_variation): one model whose
+        geometry tables have an entry per shape; the envs pick theirs through SMPLSimVecEnv(shape_id=...)."""
+        self.xmls = list(xmls) if xmls is not None else [xml if xml is not None else default_xml_str(humanoid)]
+        self.xml = self.xmls[0]
+        self.mcs = [compile_mjcf(x) for x in self.xmls]
+        self.mc, self.num_shapes = self.mcs[0], len(self.xmls)
         rng = {n: self.mc.jnt_range[6 + i] for i, n in enumerate(self.mc.joint_names)}
         self.tables = tables if tables is not None else build_pd_tables(
             self.mc.actuator_names, lambda n: rng[n], clip_actions=clip_actions, control_mode=control_mode,
             pdp_scale=pdp_scale, pdd_scale=pdd_scale)
         self.device = int(device)
-        desc, self._keep = _cabi.make_model_desc(self.mc, *self.tables, legal_bodies=tuple(contact_bodies),
-                                                 timestep=1.0 / sim_timestep_inv)
+        descs, self._keep = (_cabi.ModelDesc * self.num_shapes)(), []
+        for i, mc in enumerate(self.mcs):
+            descs[i], keep = _cabi.make_model_desc(mc, *self.tables, legal_bodies=tuple(contact_bodies), timestep=1.0 / sim_timestep_inv)
+            self._keep.append(keep)
         self.handle = C.c_void_p()
-        _check(lib().ss_model_create(C.byref(desc), self.device, C.byref(self.handle)))
+        _check(lib().ss_model_create_shapes(descs, self.num_shapes, self.device, C.byref(self.handle)))
 
     def __del__(self):
         h = getattr(self, "handle", None)
@@ -64,7 +70,7 @@ class SMPLSimVecEnv:
                  control_mode="uhc_pd", episode_length=300, control_freq_inv=15, root_height_obs=True,
                  power_scale=1.0, tar_speed=(0.0, 5.0), speed_change=(100, 200), tar_height=(0.5, 1.2),
                  height_change=(100, 200), recovery_steps=60, tar_dist_max=1.0, reach_body="R_Hand", newton_iters=8, fused_autoreset=True,
-                 autoreset=True, seed=0, lpt_order=True,
+                 autoreset=True, seed=0, lpt_order=True, shape_id=None,
                  **model_kw):
         if not torch.cuda.is_available():
             raise RuntimeError("SMPLSimVecEnv needs a ROCm GPU (MI355X); there is no CPU fallback")
@@ -96,10 +102,19 @@ class SMPLSimVecEnv:
         self.pid_integral = torch.zeros(N, self.nu, **f32); self.pid_last_error = torch.zeros(N, self.nu, **f32)
         self.pid_started = torch.zeros(N, **i32)
         self.qpos[:, 3] = 1; self.qpos_prev[:, 3] = 1
+        # per-env body shape (models built from several MJCFs): read by every launch, may be rewritten between launches
+        self.shape_id = None
+        if self.model.num_shapes > 1:
+            sid = torch.arange(N, device=dev) % self.model.num_shapes if shape_id is None else torch.as_tensor(shape_id, device=dev)
+            if sid.shape != (N,) or int(sid.min()) < 0 or int(sid.max()) >= self.model.num_shapes:
+                raise ValueError("shape_id must hold one shape index in [0, num_shapes) per env")
+            self.shape_id = sid.to(torch.int32).contiguous()
+        elif shape_id is not None:
+            raise ValueError("shape_id given but the model has a single shape (build it with ShardModel(xmls=[...]))")
         st = _cabi.State(N, *[_ptr(t) for t in (self.qpos, self.qvel, self.qpos_prev, self.qvel_prev, self.qacc_warm,
                                                self.body_vel, self.touch, self.cur_t, self.task_state, self.nwarn,
                                                self.solver_iters, self.pid_integral, self.pid_last_error,
-                                               self.pid_started)])
+                                               self.pid_started, self.shape_id)])
         self.handle = C.c_void_p()
         _check(lib().ss_batch_create(self.model.handle, C.byref(self.cfg), C.byref(st), C.byref(self.handle)))
         self.obs_size = lib().ss_obs_size(self.model.handle, C.byref(self.cfg))

@@ -74,7 +74,7 @@ struct WaveGpu {
   }
 };
 
-template <int DOFP, int CANDP, int SLOTP, int NPASS, int MAXT, bool BODYOUT>
+template <int DOFP, int CANDP, int SLOTP, int NPASS, int MAXT, bool BODYOUT, bool SHAPED>
 __global__ void __launch_bounds__(MAXT) ss_env_kernel(const ss::KArgs k) {
   extern __shared__ __align__(16) uint32_t lds[];
   for (int i = threadIdx.x; i < k.h.shared_words; i += blockDim.x) lds[i] = k.shared_g[i];
@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(MAXT) ss_env_kernel(const ss::KArgs k) {
     if (k.order) env = __builtin_amdgcn_readfirstlane(k.order[env]);   // longest-processing-time-first hand-out
     int mode = k.mode;
     for (int rep = 0; rep < 2; rep++) {                       // second trip = fused Default reset of an env whose episode ended
-      const bool again = ss::run_env<WaveGpu, DOFP, CANDP, SLOTP, NPASS, BODYOUT>(&w, &k, lds, L, env, mode);
+      const bool again = ss::run_env<WaveGpu, DOFP, CANDP, SLOTP, NPASS, BODYOUT, SHAPED>(&w, &k, lds, L, env, mode);
       w.sync();
       if (!again) break;
       mode = ss::MODE_RESET;
@@ -173,9 +173,18 @@ __global__ void __launch_bounds__(256) ss_imitation_kernel(const ss::mo::ImArgs 
 }
 
 typedef void (*kern_t)(const ss::KArgs);
-kern_t pick_kernel(int variant, bool bodyout) {
-  if (variant == 0) return bodyout ? ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true> : ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, false>;        // SMPL layout (24 bodies)
-  if (variant == 1) return bodyout ? ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, true> : ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, false>;    // SMPL-X/H layout (52 bodies)
+// instantiations per model size: plain (the headline), +body-frame outputs, +per-env body shapes (which includes the outputs)
+kern_t pick_kernel(int variant, int flavour) {
+  if (variant == 0) {                                        // SMPL layout (24 bodies)
+    if (flavour == 0) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, false, false>;
+    if (flavour == 1) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, false>;
+    return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, true>;
+  }
+  if (variant == 1) {                                        // SMPL-X/H layout (52 bodies)
+    if (flavour == 0) return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, false, false>;
+    if (flavour == 1) return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, true, false>;
+    return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, true, true>;
+  }
   return nullptr;
 }
 
@@ -227,11 +236,12 @@ struct HipBackend {
   static int kernel_regs() { return regs_ref(); }
   static const char *launch(const ss::KArgs &k, int nenv, int envs_per_wg, size_t lds_bytes, void *stream, int fixed_epw, int max_wgs) {
     const bool bodyout = k.out0 && (k.mode == ss::MODE_STEP || k.mode == ss::MODE_RESET);
-    kern_t kern = pick_kernel(ss::kernel_variant(k.h), bodyout);
+    const int flavour = k.shape_id ? 2 : (bodyout ? 1 : 0);
+    kern_t kern = pick_kernel(ss::kernel_variant(k.h), flavour);
     if (!kern) return "no kernel variant for this model size";
-    static thread_local kern_t configured[4] = {nullptr, nullptr, nullptr, nullptr};
-    static thread_local size_t configured_lds[4] = {0, 0, 0, 0};
-    const int slot = 2 * ss::kernel_variant(k.h) + (bodyout ? 1 : 0);
+    static thread_local kern_t configured[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    static thread_local size_t configured_lds[6] = {0, 0, 0, 0, 0, 0};
+    const int slot = 3 * ss::kernel_variant(k.h) + flavour;
     if (configured[slot] != kern || configured_lds[slot] < lds_bytes) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
       if (e != hipSuccess) return hipGetErrorString(e);

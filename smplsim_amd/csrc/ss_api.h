@@ -21,6 +21,8 @@ struct ss_model {
   uint32_t *d_shared = nullptr;
   float *d_bodyc = nullptr, *d_candc = nullptr;
   int32_t *d_candb = nullptr;
+  int num_shapes = 1;                     // ss_model_create_shapes: d_bodyc / d_candc hold num_shapes consecutive tables
+  float *d_dinvw = nullptr;               // [num_shapes][nv] dof_invweight0 (shaped models only)
 };
 struct ss_batch {
   const ss_model *m = nullptr;
@@ -61,9 +63,54 @@ struct ss_api {
     *out = m;
     return SS_OK;
   }
+  // S descriptions of the same humanoid with different body shapes -> one model whose geometry tables have S entries
+  static int model_create_shapes(const ss_model_desc *d, int num_shapes, int device, ss_model **out) {
+    if (!d || !out || num_shapes < 1) return fail(SS_ERR_INVALID, "null argument or num_shapes < 1");
+    if (num_shapes == 1) return model_create(d, device, out);
+    ss_model *m = new (std::nothrow) ss_model();
+    if (!m) return fail(SS_ERR_NOMEM, "out of host memory");
+    std::vector<float> bodyc, candc, dinvw;
+    for (int s = 0; s < num_shapes; s++) {
+      ss::HostModel hm;
+      if (!ss::build_host_model(d[s], hm)) { std::string e = "shape " + std::to_string(s) + ": " + hm.error; delete m; return fail(SS_ERR_INVALID, e); }
+      const ss::Hdr &h = hm.h;
+      std::vector<float> iw(h.nv);
+      for (int i = 0; i < h.nv; i++) { iw[i] = ss::bits2f_host(hm.shared[h.o_dofc + i * ss::kDofC + 4]); hm.shared[h.o_dofc + i * ss::kDofC + 4] = 0u; }
+      for (int i = 0; i < 3 * h.nb; i++) hm.shared[h.o_boff + i] = 0u;      // the two shape-dependent parts of the shared blob
+      if (s == 0) m->hm = hm;
+      else {
+        const ss::Hdr &g = m->hm.h;
+        // everything but the geometry must agree: tree, joints, limits, gains, actuators, geom types, contact set, options
+        const bool same = h.nb == g.nb && h.nv == g.nv && h.nu == g.nu && h.ncand == g.ncand && h.nbox == g.nbox && h.nslot == g.nslot &&
+                          h.shared_words == g.shared_words && h.env_floats == g.env_floats && hm.shared == m->hm.shared &&
+                          hm.candb == m->hm.candb && hm.illegal_mask == m->hm.illegal_mask && h.dt == g.dt && h.grav == g.grav &&
+                          h.margin == g.margin && h.mu == g.mu && h.K == g.K && h.B == g.B;
+        if (!same) { delete m; return fail(SS_ERR_INVALID, "shape " + std::to_string(s) + " differs from shape 0 in more than its geometry"); }
+      }
+      bodyc.insert(bodyc.end(), hm.bodyc.begin(), hm.bodyc.end());
+      candc.insert(candc.end(), hm.candc.begin(), hm.candc.end());
+      dinvw.insert(dinvw.end(), iw.begin(), iw.end());
+    }
+    if (12 * m->hm.h.nb > m->hm.h.l_Wst - m->hm.h.l_IA) { delete m; return fail(SS_ERR_LDS, "no room for the per-env body offsets"); }
+    m->device = device; m->num_shapes = num_shapes;
+    if (!BE::set_device(device)) { delete m; return fail(SS_ERR_HIP, "cannot select device"); }
+    auto up = [&](const void *src, size_t bytes) -> void * {
+      void *p = BE::alloc(bytes ? bytes : 4);
+      if (p && bytes && !BE::upload(p, src, bytes)) { BE::free_(p); p = nullptr; }
+      return p;
+    };
+    m->d_shared = (uint32_t *)up(m->hm.shared.data(), m->hm.shared.size() * 4);
+    m->d_bodyc = (float *)up(bodyc.data(), bodyc.size() * 4);
+    m->d_candc = (float *)up(candc.data(), candc.size() * 4);
+    m->d_candb = (int32_t *)up(m->hm.candb.data(), m->hm.candb.size() * 4);
+    m->d_dinvw = (float *)up(dinvw.data(), dinvw.size() * 4);
+    if (!m->d_shared || !m->d_bodyc || !m->d_candc || !m->d_candb || !m->d_dinvw) { model_destroy(m); return fail(SS_ERR_HIP, "device table upload failed"); }
+    *out = m;
+    return SS_OK;
+  }
   static void model_destroy(ss_model *m) {
     if (!m) return;
-    BE::free_(m->d_shared); BE::free_(m->d_bodyc); BE::free_(m->d_candc); BE::free_(m->d_candb);
+    BE::free_(m->d_shared); BE::free_(m->d_bodyc); BE::free_(m->d_candc); BE::free_(m->d_candb); BE::free_(m->d_dinvw);
     delete m;
   }
   static int batch_create(const ss_model *m, const ss_env_cfg *cfg, const ss_state *st, ss_batch **out) {
@@ -77,6 +124,8 @@ struct ss_api {
       return fail(SS_ERR_INVALID, "control_mode simple_pid needs the pid_* state buffers");
     if (cfg->self_obs_v != 1 && cfg->self_obs_v != 2) return fail(SS_ERR_INVALID, "self_obs_v must be 1 or 2");
     if (cfg->control_freq_inv < 1) return fail(SS_ERR_INVALID, "control_freq_inv must be >= 1");
+    if (m->num_shapes > 1 && !st->shape_id) return fail(SS_ERR_INVALID, "a model with several shapes needs ss_state.shape_id");
+    if (m->num_shapes == 1 && st->shape_id) return fail(SS_ERR_INVALID, "ss_state.shape_id given for a single-shape model");
     if (cfg->task == SS_TASK_REACH && (cfg->reach_body < 0 || cfg->reach_body >= m->hm.h.nb)) return fail(SS_ERR_INVALID, "reach_body out of range");
     const ss::Hdr &h = m->hm.h;
     if (ss::kernel_variant(h) < 0) return fail(SS_ERR_INVALID, "model too large for the compiled kernel variants");
@@ -113,6 +162,7 @@ struct ss_api {
     k.prof = b->d_prof;
     k.order = b->order;
     if (mode == ss::MODE_STEP || mode == ss::MODE_RESET) { k.out0 = b->body_xpos; k.out1 = b->body_xmat; }
+    if (m->num_shapes > 1) { k.shape_id = b->st.shape_id; k.dinvw = m->d_dinvw; }
     return k;
   }
   static int run(const ss_batch *b, const ss::KArgs &k, void *stream) {
@@ -169,6 +219,7 @@ struct ss_api {
 #define SS_DEFINE_C_API(BE)                                                                                          \
   extern "C" {                                                                                                       \
   int ss_model_create(const ss_model_desc *d, int dev, ss_model **out) { return ss_api<BE>::model_create(d, dev, out); } \
+  int ss_model_create_shapes(const ss_model_desc *d, int32_t n, int dev, ss_model **out) { return ss_api<BE>::model_create_shapes(d, n, dev, out); } \
   void ss_model_destroy(ss_model *m) { ss_api<BE>::model_destroy(m); }                                               \
   int ss_model_dims(const ss_model *m, int32_t *nq, int32_t *nv, int32_t *nu, int32_t *nb) {                          \
     if (!m) return ss_api<BE>::fail(SS_ERR_INVALID, "null model");                                                   \

@@ -64,6 +64,11 @@ struct KArgs {
   const float *task_rand2;
   uint8_t *terminated, *truncated;
   float *out0, *out1, *out2;  // kinematics: xpos, xmat ; debug forward: M [N,nv,nv], bias [N,nv], qacc [N,nv]
+  // per-env body shapes (ss_model_create_shapes): bodyc / candc hold num_shapes consecutive tables, dinvw [num_shapes][nv] the
+  // shape-dependent dof constant (dof_invweight0), shape_id [N] selects per env; null = single-shape model.  At the end of
+  // the struct so that the kernarg offsets of everything above are those of the single-shape build.
+  const int32_t *shape_id;
+  const float *dinvw;
 };
 
 }  // namespace ss

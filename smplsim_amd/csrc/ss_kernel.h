@@ -89,10 +89,15 @@ SS_DEV void sincos_small(float x, float *sn, float *cs) {
 }
 SS_DEV bool is_bad(float x) { return !(x <= 1e10f && x >= -1e10f); }
 
-template <class W, int DOFP, int CANDP, int SLOTP, int NPASS>
+// SHAPED: per-env body shapes — the geometry-dependent constants (body table, contact candidates, dof inverse weights) are
+// indexed by the env's shape id, and the body offsets of the kinematic chain walk come from the env's own body table (staged
+// through the env's LDS slice) instead of the workgroup's shared table.  A separate instantiation: the single-shape code
+// is textually what it was.
+template <class W, int DOFP, int CANDP, int SLOTP, int NPASS, bool SHAPED = false>
 struct Sim {
   W *w;
   const KArgs *k;
+  const float *bodyc_s, *candc_s, *dinvw_s;   // SHAPED only: this env's tables
   const uint32_t *T;      // shared tables in LDS
   int lane, env;
   // per-env LDS arrays
@@ -113,6 +118,9 @@ struct Sim {
   SS_DEV int ti(int off, int i) const { return (int)T[off + i]; }
   SS_DEV float tf(int off, int i) const { return bits2f(T[off + i]); }
   SS_DEV float dc(int dof, int f) const { return tf(k->h.o_dofc, dof * kDofC + f); }
+  SS_DEV const float *bodyc() const { if constexpr (SHAPED) return bodyc_s; else return k->bodyc; }
+  SS_DEV const float *candc() const { if constexpr (SHAPED) return candc_s; else return k->candc; }
+  SS_DEV float dof_invweight(int dof) const { if constexpr (SHAPED) return dinvw_s[dof]; else return dc(dof, 4); }
   // body of a contact slot: box b owns slots 4b'..4b'+3 (b' = box order), capsule ends follow
   SS_DEV int h_box_body(int sl) const { return k->candb[8 * (sl >> 2)] & 255; }
   SS_DEV int h_caps_body(int sl) const { int e = sl - 4 * k->h.nbox; int ci = 8 * k->h.nbox + e; return ci < k->h.ncand ? (k->candb[ci] & 255) : 0; }
@@ -120,6 +128,11 @@ struct Sim {
   SS_DEV void init(W *w_, const KArgs *k_, const uint32_t *T_, float *L, int env_) {
     w = w_; k = k_; T = T_; lane = w->lane(); env = env_;
     const Hdr &h = k->h;
+    bodyc_s = candc_s = dinvw_s = nullptr;
+    if constexpr (SHAPED) {
+      const size_t sid = (size_t)k->shape_id[env];
+      bodyc_s = k->bodyc + sid * h.nb * kBodyC; candc_s = k->candc + sid * h.ncand * kCandC; dinvw_s = k->dinvw + sid * h.nv;
+    }
     S = L + h.l_S; R = L + h.l_R; r = L + h.l_r; V = L + h.l_V; Ab = L + h.l_Ab; An = L + h.l_An; Ad = An;
     Gb = L + h.l_Gb; tmpb = L + h.l_tmp; Aown = L + h.l_Aown; IA = L + h.l_IA; Ubuf = L + h.l_Ubuf; Wst = L + h.l_Wst;
     q = L + h.l_q; v = L + h.l_v; a = L + h.l_a; tau = L + h.l_tau; Pb = L + h.l_Pb;
@@ -245,7 +258,7 @@ struct Sim {
     float Rb[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, rb[3] = {0, 0, 0};
     float bc[kBodyC];                                       // this lane's body constants (L1/L2-resident table)
     {
-      const float4_t *src = reinterpret_cast<const float4_t *>(k->bodyc + (lane < h.nb ? lane : 0) * kBodyC);
+      const float4_t *src = reinterpret_cast<const float4_t *>(bodyc() + (lane < h.nb ? lane : 0) * kBodyC);
       const float4_t b0 = src[0], b1 = src[1], b2 = src[2], b3 = src[3];
       bc[0] = b0.x; bc[1] = b0.y; bc[2] = b0.z; bc[3] = b0.w; bc[4] = b1.x; bc[5] = b1.y; bc[6] = b1.z; bc[7] = b1.w;
       bc[8] = b2.x; bc[9] = b2.y; bc[10] = b2.z; bc[11] = b2.w; bc[12] = b3.x; bc[13] = b3.y; bc[14] = b3.z; bc[15] = b3.w;
@@ -285,6 +298,7 @@ struct Sim {
     if (lane >= 1 && lane < h.nb) {
 #pragma unroll
       for (int i = 0; i < 9; i++) Rloc[9 * lane + i] = Rl[i];
+      if constexpr (SHAPED) { Rloc[9 * h.nb + 3 * lane] = bc[0]; Rloc[9 * h.nb + 3 * lane + 1] = bc[1]; Rloc[9 * h.nb + 3 * lane + 2] = bc[2]; }
     }
     w->sync();
     SS_FTICK(PF_K_PRO);
@@ -296,7 +310,9 @@ struct Sim {
       rb[0] = rb[1] = rb[2] = 0.f;
       for (int kq = 2; kq <= dn; kq++) {                      // bodies on the chain below the root, ending with this one
         const int a_ = ti(row, kq) - 1;
-        const float o0 = tf(h.o_boff, 3 * a_), o1 = tf(h.o_boff, 3 * a_ + 1), o2 = tf(h.o_boff, 3 * a_ + 2);
+        float o0, o1, o2;
+        if constexpr (SHAPED) { const float *bo = Rloc + 9 * h.nb + 3 * a_; o0 = bo[0]; o1 = bo[1]; o2 = bo[2]; }
+        else { o0 = tf(h.o_boff, 3 * a_); o1 = tf(h.o_boff, 3 * a_ + 1); o2 = tf(h.o_boff, 3 * a_ + 2); }
         float La[9];
 #pragma unroll
         for (int i = 0; i < 9; i++) La[i] = Rloc[9 * a_ + i];
@@ -518,7 +534,7 @@ struct Sim {
       const bool caps = valid && (cbp & 256);
       float cv[kCandC];
       {
-        const float4_t *src = reinterpret_cast<const float4_t *>(k->candc + (valid ? cidx : 0) * kCandC);
+        const float4_t *src = reinterpret_cast<const float4_t *>(candc() + (valid ? cidx : 0) * kCandC);
         const float4_t c0 = src[0], c1 = src[1];
         cv[0] = c0.x; cv[1] = c0.y; cv[2] = c0.z; cv[3] = c0.w; cv[4] = c1.x; cv[5] = c1.y; cv[6] = c1.z; cv[7] = c1.w;
       }
@@ -602,7 +618,7 @@ struct Sim {
         else if (hi - qi < 0.f) { l.sign = -1.f; pos = hi - qi; }
         if (l.sign != 0.f) {
           float imp = impedance(pos, 0.f);
-          float Rr = (1.f - imp) / imp * dc(i, 4);
+          float Rr = (1.f - imp) / imp * dof_invweight(i);
           if (Rr < 1e-15f) Rr = 1e-15f;
           l.D = 1.f / Rr;
           l.aref = -h.B * (l.sign * v[i]) - h.K * imp * pos;
@@ -1315,14 +1331,14 @@ enum { SOLVE_NEWTON = 1, SOLVE_SPD = 2 };
 // BODYOUT: the instantiation whose step / reset passes also write the body frames (ss_set_body_outputs).  A separate
 // instantiation because the extra epilogue costs the headline step kernel 3.7% (register allocation of the hot loops
 // shifts) even when the pointer is null — callers that do not ask for it keep the plain one.
-template <class W, int DOFP, int CANDP, int SLOTP, int NPASS, bool BODYOUT = false>
+template <class W, int DOFP, int CANDP, int SLOTP, int NPASS, bool BODYOUT = false, bool SHAPED = false>
 SS_DEV bool run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env, int mode) {
   const Hdr &h = k->h;
   const ss_env_cfg &cf = k->cfg;
   const ss_state &st = k->st;
   const bool fused_pass = mode != k->mode;                    // the in-launch reset of an env that just finished
   if (!fused_pass && k->mask && !k->mask[env]) return false;
-  Sim<W, DOFP, CANDP, SLOTP, NPASS> sim;
+  Sim<W, DOFP, CANDP, SLOTP, NPASS, SHAPED> sim;
   sim.init(w, k, T, L, env);
   int lane = sim.lane;
   float *qg = st.qpos + (size_t)env * h.nq, *vg = st.qvel + (size_t)env * h.nv;

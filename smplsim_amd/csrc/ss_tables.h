@@ -33,6 +33,7 @@ struct HostModel {
 };
 
 inline uint32_t f2u(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+inline float bits2f_host(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 
 inline void quat2mat(const double *q, double *m) {
   double w = q[0], x = q[1], y = q[2], z = q[3];

@@ -1,11 +1,16 @@
 """Body-shape variation across the envs of one GPU shard (the part that touches the hot path).
 
 The reference gives every env process its own MJCF when `cfg.robot.has_shape_variation` is set (SMPL_Robot writes one per
-betas draw; smpl_sim/envs/humanoid_env.py:205,218-247).  The stepper's model constants are per `ss_batch`, so here the envs
-are grouped by shape: one compiled model + one `ss_batch` per shape, all groups stepped concurrently on their own HIP streams
-and joined at the end of the step — the per-step barrier over all envs of the reference's vector env is kept.  State,
-observation, reward and flag tensors are single [N, ...] tensors; every group's buffers are row ranges of them, so nothing
-is concatenated or copied per step.
+betas draw; smpl_sim/envs/humanoid_env.py:205,218-247).  Two ways here:
+
+  * per-env shapes in ONE launch (the default): `ShardModel(xmls=[...])` -> `ss_model_create_shapes`, the geometry tables
+    (body offsets / inertias, contact candidates, inverse weights) have one entry per shape and every env reads those of
+    `shape_id[env]`; `SMPLSimVecEnv(N, model, shape_id=...)`.  Any number of shapes, up to one per env; the shapes must
+    differ in geometry only.  `ShapeVariedVecEnv(xmls, envs_per_shape)` is a convenience constructor for it.
+  * shape groups on streams (`single_launch=False`): one compiled model + one `ss_batch` per shape, all groups stepped
+    concurrently on their own HIP streams and joined at the end of the step — for variants that differ in more than
+    geometry (gains, limits).  State, observation, reward and flag tensors are single [N, ...] tensors; every group's buffers
+    are row ranges of them, so nothing is concatenated or copied per step.
 
 Concurrency needs one hardware queue per group: ROCm maps streams onto GPU_MAX_HW_QUEUES (default 4) queues, so export
 GPU_MAX_HW_QUEUES >= number of shapes + 1 before the process touches the GPU (measured, 4096 envs: 2 groups 2.15 ms per step
@@ -24,11 +29,21 @@ from .batch import ShardModel, SMPLSimVecEnv
 
 
 class ShapeVariedVecEnv:
-    def __init__(self, xmls, envs_per_shape, device=0, seed=0, shape_params=None, **env_kw):
+    def __init__(self, xmls, envs_per_shape, device=0, seed=0, shape_params=None, single_launch=True, **env_kw):
         """xmls: one MJCF string per body shape (same tree / actuators, different geometry); envs_per_shape: int or list."""
         K = len(xmls)
         counts = [int(envs_per_shape)] * K if isinstance(envs_per_shape, int) else [int(c) for c in envs_per_shape]
         assert len(counts) == K and all(c > 0 for c in counts)
+        self.single = None
+        if single_launch:
+            sid = torch.repeat_interleave(torch.arange(K), torch.tensor(counts))
+            e = self.single = SMPLSimVecEnv(sum(counts), model=ShardModel(xmls=xmls, device=device), device=device, seed=seed, shape_id=sid if K > 1 else None, **env_kw)
+            self.envs, self.models, self.num_envs, self.num_shapes = [e], [e.model], e.num_envs, K
+            self.device, self.nq, self.nv, self.nu, self.nbody, self.obs_size, self.action_size = e.device, e.nq, e.nv, e.nu, e.nbody, e.obs_size, e.nu
+            self.shape_id = e.shape_id
+            self.obs_buf, self.rew_buf = e.obs_buf, e.rew_buf
+            self.reset, self.step, self.state = e.reset, e.step, (lambda: (e.qpos, e.qvel))
+            return
         self.models = [ShardModel(xml=x, device=device) for x in xmls]
         self.envs = [SMPLSimVecEnv(c, model=m, device=device, seed=seed + 1000 * g, **env_kw) for g, (c, m) in enumerate(zip(counts, self.models))]
         e0 = self.envs[0]

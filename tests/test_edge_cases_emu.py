@@ -164,3 +164,71 @@ def test_step_autoreset_error_paths():
     ok = _batch(2)
     rc = emu.lib().ss_step_autoreset(ok.batch, p(a), None, None, p(ok.obs), None, p(ok.reward), p(ok.terminated), p(ok.truncated), None)
     assert rc != 0                                            # obs_next is mandatory
+
+
+def test_per_env_body_shapes_equal_single_shape_batches_and_track_their_oracles():
+    """ss_model_create_shapes: 3 body shapes, 7 envs with mixed shape ids, one launch.  Every env must be bit-identical to
+    the same env in a single-shape batch of its shape (the shape tables are the only thing that changes), and follow the
+    oracle compiled from ITS MJCF."""
+    from smplsim_amd.mjcf import compile_mjcf
+    from smplsim_amd.mjcf_writer import scaled_xml_str
+    xmls = [scaled_xml_str("smpl_humanoid", 1.0), scaled_xml_str("smpl_humanoid", 0.9, {"L_Knee": 1.1, "R_Knee": 1.1}),
+            scaled_xml_str("smpl_humanoid", 1.08, {"Chest": 0.9, "L_Elbow": 1.2})]
+    mcs = [compile_mjcf(x) for x in xmls]
+    tabs = pd_tables(mcs[0])
+    sid = np.array([0, 1, 2, 2, 1, 0, 1], np.int32)
+    n = len(sid)
+    eb = emu.EmuBatch(mcs[0], tabs, n, legal_bodies=FEET, shape_mcs=mcs, shape_id=sid, task=_cabi.TASK_SPEED, episode_length=3)
+    rs = np.random.default_rng(8)
+    tr = rs.uniform(size=(n, 4))
+    obs0 = eb.reset(task_rand=tr)
+    solos = []
+    for s in range(3):
+        idx = np.nonzero(sid == s)[0]
+        so = emu.EmuBatch(mcs[s], tabs, len(idx), legal_bodies=FEET, task=_cabi.TASK_SPEED, episode_length=3)
+        assert np.array_equal(so.reset(task_rand=tr[idx]), obs0[idx])
+        solos.append((idx, so))
+    oenvs = []
+    for i in range(n):
+        om = O.OracleModel(xmls[sid[i]], *tabs, legal_bodies=FEET, timestep=1.0 / 450)
+        oe = O.OracleEnv(om, task=O.TASK_SPEED, episode_length=3)
+        assert np.abs(oe.reset(task_rand=tr[i]) - obs0[i]).max() < 1e-5
+        oenvs.append(oe)
+    assert np.abs(obs0[0] - obs0[1]).max() > 1e-3                       # the shapes really differ
+    for k in range(3):
+        act = rs.uniform(-0.4, 0.4, (n, 69))
+        tr = rs.uniform(size=(n, 4))
+        obs, rew, term, trunc = eb.step(act, task_rand=tr)
+        for idx, so in solos:
+            o2, r2, t2, u2 = so.step(act[idx], task_rand=tr[idx])
+            assert np.array_equal(o2, obs[idx]) and np.array_equal(so.qpos, eb.qpos[idx]) and np.array_equal(r2, rew[idx])
+        for i, oe in enumerate(oenvs):
+            o_ref, r, te, tu = oe.step(act[i], task_rand=tr[i])
+            assert np.abs(oe.data.qpos - eb.qpos[i]).max() < 2e-4 and np.abs(o_ref - obs[i]).max() < 5e-3, (k, i)
+            assert (te, tu) == (bool(term[i]), bool(trunc[i]))
+    # the shape of an env may change between launches (a new body at reset): swap two envs' shapes and reset them
+    sid2 = sid.copy(); sid2[0], sid2[1] = sid[1], sid[0]
+    eb.shape_id[:] = sid2
+    m = np.zeros(n, np.uint8); m[:2] = 1
+    ob = eb.reset(mask=m, task_rand=tr)
+    assert np.array_equal(ob[0, 1:70], obs0[1, 1:70]) and np.array_equal(ob[1, 1:70], obs0[0, 1:70])   # body positions of the other shape
+
+
+def test_shaped_model_error_paths():
+    from smplsim_amd.mjcf import compile_mjcf
+    from smplsim_amd.mjcf_writer import scaled_xml_str
+    mc0, mc1 = compile_mjcf(scaled_xml_str("smpl_humanoid", 1.0)), compile_mjcf(scaled_xml_str("smpl_humanoid", 0.9))
+    tabs = pd_tables(mc0)
+    with pytest.raises(RuntimeError, match="shape_id"):
+        emu.EmuBatch(mc0, tabs, 2, legal_bodies=FEET, shape_mcs=[mc0, mc1], shape_id=None)
+    mcx = model_const("smplx_humanoid")
+    descs = (_cabi.ModelDesc * 2)()
+    descs[0], k0 = _cabi.make_model_desc(mc0, *tabs, legal_bodies=FEET)
+    descs[1], k1 = _cabi.make_model_desc(mcx, *pd_tables(mcx), legal_bodies=FEET)
+    h = C.c_void_p()
+    assert emu.lib().ss_model_create_shapes(descs, 2, 0, C.byref(h)) == -1
+    assert b"differs from shape 0" in emu.lib().ss_last_error()
+    t2 = [np.array(t, dtype=np.float64).copy() for t in tabs]
+    t2[0][3] *= 2.0                                                     # a different gain is not a body shape
+    descs[1], k2 = _cabi.make_model_desc(mc1, *t2, legal_bodies=FEET)
+    assert emu.lib().ss_model_create_shapes(descs, 2, 0, C.byref(h)) == -1

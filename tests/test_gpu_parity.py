@@ -619,9 +619,11 @@ def test_shape_varied_env_groups_match_their_oracles_and_standalone_envs(vec):
     from smplsim_amd.mjcf_writer import scaled_xml_str
     from smplsim_amd.shapes import ShapeVariedVecEnv
     xmls = [scaled_xml_str("smpl_humanoid", 1.0), scaled_xml_str("smpl_humanoid", 0.85, {"L_Knee": 1.15, "R_Knee": 1.15, "Chest": 0.9})]
-    env = ShapeVariedVecEnv(xmls, 4, autoreset=False, seed=0)
+    env = ShapeVariedVecEnv(xmls, 4, autoreset=False, seed=0, single_launch=False)
+    one = ShapeVariedVecEnv(xmls, 4, autoreset=False, seed=0)              # per-env shapes in one launch
     solo = [vec(4, model=ShardModel(xml=x), autoreset=False, seed=1000 * g) for g, x in enumerate(xmls)]
     obs, _ = env.reset()
+    assert torch.equal(one.reset()[0], obs)
     for s in solo:
         s.reset()
     oenvs = []
@@ -638,6 +640,8 @@ def test_shape_varied_env_groups_match_their_oracles_and_standalone_envs(vec):
         a = rs.uniform(-0.3, 0.3, (2, 69))
         act = torch.tensor(np.repeat(a, 4, axis=0), device=env.device, dtype=torch.float32)
         obs, rew, term, trunc, info = env.step(act)
+        obs1, rew1 = one.step(act)[:2]
+        assert torch.equal(obs1, obs) and torch.equal(rew1, rew) and torch.equal(one.state()[0], env.state()[0])
         for g, s in enumerate(solo):
             s.step(act[4 * g:4 * g + 4])
         torch.cuda.synchronize()

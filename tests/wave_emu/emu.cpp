@@ -193,13 +193,13 @@ struct WaveEmu {
 
 struct LaunchCtx { const ss::KArgs *k; const uint32_t *T; float *L; int env; Machine *m; };
 
-template <int DOFP, int CANDP, int SLOTP, int NPASS>
+template <int DOFP, int CANDP, int SLOTP, int NPASS, bool SHAPED>
 void lane_entry(int lane, void *arg) {
   LaunchCtx *c = (LaunchCtx *)arg;
   WaveEmu w{c->m, lane};
   int mode = c->k->mode;
   for (int rep = 0; rep < 2; rep++) {
-    const bool again = ss::run_env<WaveEmu, DOFP, CANDP, SLOTP, NPASS, true>(&w, c->k, c->T, c->L, c->env, mode);
+    const bool again = ss::run_env<WaveEmu, DOFP, CANDP, SLOTP, NPASS, true, SHAPED>(&w, c->k, c->T, c->L, c->env, mode);
     w.sync();
     if (!again) break;
     mode = ss::MODE_RESET;
@@ -283,8 +283,8 @@ struct EmuBackend {
       LaunchCtx c{&k, k.shared_g, L.data(), k.order ? k.order[env] : env, m};
       void (*entry)(int, void *) = nullptr;
       const int variant = ss::kernel_variant(k.h);
-      if (variant == 0) entry = lane_entry<2, 2, 1, 1>;
-      else if (variant == 1) entry = lane_entry<3, 3, 2, 2>;
+      if (variant == 0) entry = k.shape_id ? lane_entry<2, 2, 1, 1, true> : lane_entry<2, 2, 1, 1, false>;
+      else if (variant == 1) entry = k.shape_id ? lane_entry<3, 3, 2, 2, true> : lane_entry<3, 3, 2, 2, false>;
       else return "no kernel variant for this model size";
       run_wave(m, entry, &c);
     }

@@ -38,12 +38,22 @@ def _rand4(tr, n):
 
 
 class EmuBatch:
-    def __init__(self, mc, tables, num_envs, legal_bodies=(), timestep=1.0 / 450, **cfg):
+    def __init__(self, mc, tables, num_envs, legal_bodies=(), timestep=1.0 / 450, shape_mcs=None, shape_id=None, **cfg):
+        """shape_mcs: list of ModelConst = body shapes of one humanoid (ss_model_create_shapes), shape_id [N] picks per env."""
         L = lib()
         self.mc = mc
-        desc, self._keep = _cabi.make_model_desc(mc, *tables, legal_bodies=legal_bodies, timestep=timestep)
         self.model = C.c_void_p()
-        self._chk(L.ss_model_create(C.byref(desc), 0, C.byref(self.model)))
+        self.shape_id = None
+        if shape_mcs is None:
+            desc, self._keep = _cabi.make_model_desc(mc, *tables, legal_bodies=legal_bodies, timestep=timestep)
+            self._chk(L.ss_model_create(C.byref(desc), 0, C.byref(self.model)))
+        else:
+            descs, self._keep = (_cabi.ModelDesc * len(shape_mcs))(), []
+            for i, m in enumerate(shape_mcs):
+                descs[i], keep = _cabi.make_model_desc(m, *tables, legal_bodies=legal_bodies, timestep=timestep)
+                self._keep.append(keep)
+            self._chk(L.ss_model_create_shapes(descs, len(shape_mcs), 0, C.byref(self.model)))
+            self.shape_id = None if shape_id is None else np.ascontiguousarray(shape_id, np.int32)
         self.cfg = _cabi.make_env_cfg(**cfg)
         N, nq, nv, nb = num_envs, mc.nq, mc.nv, mc.nbody
         self.N = N
@@ -59,7 +69,7 @@ class EmuBatch:
         st = _cabi.State(N, *[_p(x) for x in (self.qpos, self.qvel, self.qpos_prev, self.qvel_prev, self.qacc_warm,
                                              self.body_vel, self.touch, self.cur_t, self.task, self.nwarn,
                                              self.solver_iters, self.pid_integral, self.pid_last_error,
-                                             self.pid_started)])
+                                             self.pid_started, self.shape_id)])
         self.batch = C.c_void_p()
         self._chk(L.ss_batch_create(self.model, C.byref(self.cfg), C.byref(st), C.byref(self.batch)))
         self.obs_size = L.ss_obs_size(self.model, C.byref(self.cfg))

@@ -13,11 +13,12 @@ from smplsim_amd.mjcf_writer import scaled_xml_str
 from smplsim_amd.shapes import ShapeVariedVecEnv
 
 N, STEPS = 4096, int(os.environ.get("STEPS", 200))
-for K in (1, 2, 4, 8, 16, 32):
+SINGLE = os.environ.get("SINGLE_LAUNCH", "1") == "1"
+for K in ((1, 2, 16, 256, 4096) if SINGLE else (1, 2, 4, 8, 16, 32)):
     # identical geometry in every group (but K separately compiled models / batches / streams): isolates the cost of grouping —
     # really different shapes change the workload itself (a scaled body starts above or inside the floor at the fixed reset height)
     xmls = [scaled_xml_str("smpl_humanoid", 1.0) for g in range(K)]
-    env = ShapeVariedVecEnv(xmls, N // K, seed=0)
+    env = ShapeVariedVecEnv(xmls, N // K, seed=0, single_launch=SINGLE)
     g = torch.Generator(device=env.device); g.manual_seed(1)
     env.reset()
     for _ in range(10):
@@ -26,6 +27,7 @@ for K in (1, 2, 4, 8, 16, 32):
     for _ in range(STEPS):
         env.step(torch.rand(N, env.nu, generator=g, device=env.device) * 2 - 1)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(json.dumps({"shapes": K, "envs_per_shape": N // K, "env_steps_per_s": round(N * STEPS / dt), "ms_per_step": round(1e3 * dt / STEPS, 3),
+    print(json.dumps({"single_launch": SINGLE, "shapes": K, "envs_per_shape": N // K, "env_steps_per_s": round(N * STEPS / dt), "ms_per_step": round(1e3 * dt / STEPS, 3),
                       "obs_finite": bool(torch.isfinite(env.obs_buf).all())}))
-    env.close()
+    for e in env.envs:
+        e.close()
