@@ -236,7 +236,7 @@ struct HipBackend {
   static int kernel_regs() { return regs_ref(); }
   static const char *launch(const ss::KArgs &k, int nenv, int envs_per_wg, size_t lds_bytes, void *stream, int fixed_epw, int max_wgs) {
     const bool bodyout = k.out0 && (k.mode == ss::MODE_STEP || k.mode == ss::MODE_RESET);
-    const int flavour = k.shape_id ? 2 : (bodyout ? 1 : 0);
+    const int flavour = k.st.shape_id ? 2 : (bodyout ? 1 : 0);
     kern_t kern = pick_kernel(ss::kernel_variant(k.h), flavour);
     if (!kern) return "no kernel variant for this model size";
     static thread_local kern_t configured[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -21,8 +21,7 @@ struct ss_model {
   uint32_t *d_shared = nullptr;
   float *d_bodyc = nullptr, *d_candc = nullptr;
   int32_t *d_candb = nullptr;
-  int num_shapes = 1;                     // ss_model_create_shapes: d_bodyc / d_candc hold num_shapes consecutive tables
-  float *d_dinvw = nullptr;               // [num_shapes][nv] dof_invweight0 (shaped models only)
+  int num_shapes = 1;                     // ss_model_create_shapes: d_bodyc / d_candc hold num_shapes consecutive tables (ss_hdr.h)
 };
 struct ss_batch {
   const ss_model *m = nullptr;
@@ -69,7 +68,7 @@ struct ss_api {
     if (num_shapes == 1) return model_create(d, device, out);
     ss_model *m = new (std::nothrow) ss_model();
     if (!m) return fail(SS_ERR_NOMEM, "out of host memory");
-    std::vector<float> bodyc, candc, dinvw;
+    std::vector<float> bodyc, candc;
     for (int s = 0; s < num_shapes; s++) {
       ss::HostModel hm;
       if (!ss::build_host_model(d[s], hm)) { std::string e = "shape " + std::to_string(s) + ": " + hm.error; delete m; return fail(SS_ERR_INVALID, e); }
@@ -88,8 +87,9 @@ struct ss_api {
         if (!same) { delete m; return fail(SS_ERR_INVALID, "shape " + std::to_string(s) + " differs from shape 0 in more than its geometry"); }
       }
       bodyc.insert(bodyc.end(), hm.bodyc.begin(), hm.bodyc.end());
+      iw.resize((h.nv + 3) & ~3, 0.f);
+      bodyc.insert(bodyc.end(), iw.begin(), iw.end());        // block = body constants, then the dof inverse weights
       candc.insert(candc.end(), hm.candc.begin(), hm.candc.end());
-      dinvw.insert(dinvw.end(), iw.begin(), iw.end());
     }
     if (12 * m->hm.h.nb > m->hm.h.l_Wst - m->hm.h.l_IA) { delete m; return fail(SS_ERR_LDS, "no room for the per-env body offsets"); }
     m->device = device; m->num_shapes = num_shapes;
@@ -103,14 +103,13 @@ struct ss_api {
     m->d_bodyc = (float *)up(bodyc.data(), bodyc.size() * 4);
     m->d_candc = (float *)up(candc.data(), candc.size() * 4);
     m->d_candb = (int32_t *)up(m->hm.candb.data(), m->hm.candb.size() * 4);
-    m->d_dinvw = (float *)up(dinvw.data(), dinvw.size() * 4);
-    if (!m->d_shared || !m->d_bodyc || !m->d_candc || !m->d_candb || !m->d_dinvw) { model_destroy(m); return fail(SS_ERR_HIP, "device table upload failed"); }
+    if (!m->d_shared || !m->d_bodyc || !m->d_candc || !m->d_candb) { model_destroy(m); return fail(SS_ERR_HIP, "device table upload failed"); }
     *out = m;
     return SS_OK;
   }
   static void model_destroy(ss_model *m) {
     if (!m) return;
-    BE::free_(m->d_shared); BE::free_(m->d_bodyc); BE::free_(m->d_candc); BE::free_(m->d_candb); BE::free_(m->d_dinvw);
+    BE::free_(m->d_shared); BE::free_(m->d_bodyc); BE::free_(m->d_candc); BE::free_(m->d_candb);
     delete m;
   }
   static int batch_create(const ss_model *m, const ss_env_cfg *cfg, const ss_state *st, ss_batch **out) {
@@ -162,7 +161,6 @@ struct ss_api {
     k.prof = b->d_prof;
     k.order = b->order;
     if (mode == ss::MODE_STEP || mode == ss::MODE_RESET) { k.out0 = b->body_xpos; k.out1 = b->body_xmat; }
-    if (m->num_shapes > 1) { k.shape_id = b->st.shape_id; k.dinvw = m->d_dinvw; }
     return k;
   }
   static int run(const ss_batch *b, const ss::KArgs &k, void *stream) {

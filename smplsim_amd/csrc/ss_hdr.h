@@ -35,6 +35,8 @@ inline int kernel_variant(const Hdr &h) {
   return -1;
 }
 
+constexpr int shape_stride(const Hdr &h) { return h.nb * kBodyC + ((h.nv + 3) & ~3); }   // floats per shape in the shaped bodyc array
+
 enum { MODE_STEP = 0, MODE_SUBSTEP = 1, MODE_RESET = 2, MODE_KINEMATICS = 3, MODE_DEBUG_FORWARD = 4 };
 
 // Everything a launch needs, passed to the kernel by value.
@@ -64,11 +66,9 @@ struct KArgs {
   const float *task_rand2;
   uint8_t *terminated, *truncated;
   float *out0, *out1, *out2;  // kinematics: xpos, xmat ; debug forward: M [N,nv,nv], bias [N,nv], qacc [N,nv]
-  // per-env body shapes (ss_model_create_shapes): bodyc / candc hold num_shapes consecutive tables, dinvw [num_shapes][nv] the
-  // shape-dependent dof constant (dof_invweight0), shape_id [N] selects per env; null = single-shape model.  At the end of
-  // the struct so that the kernarg offsets of everything above are those of the single-shape build.
-  const int32_t *shape_id;
-  const float *dinvw;
+  // per-env body shapes (ss_model_create_shapes): bodyc holds num_shapes consecutive blocks of [nb][kBodyC] body constants
+  // followed by [nv] dof inverse weights (block stride shape_stride(h) floats), candc num_shapes consecutive tables;
+  // st.shape_id [N] selects per env (null = single-shape model)
 };
 
 }  // namespace ss

@@ -93,11 +93,13 @@ SS_DEV bool is_bad(float x) { return !(x <= 1e10f && x >= -1e10f); }
 // indexed by the env's shape id, and the body offsets of the kinematic chain walk come from the env's own body table (staged
 // through the env's LDS slice) instead of the workgroup's shared table.  A separate instantiation: the single-shape code
 // is textually what it was.
+template <bool SHAPED> struct ShapeTables {};
+template <> struct ShapeTables<true> { const float *bodyc_s, *candc_s, *dinvw_s; };   // this env's tables
+
 template <class W, int DOFP, int CANDP, int SLOTP, int NPASS, bool SHAPED = false>
-struct Sim {
+struct Sim : ShapeTables<SHAPED> {
   W *w;
   const KArgs *k;
-  const float *bodyc_s, *candc_s, *dinvw_s;   // SHAPED only: this env's tables
   const uint32_t *T;      // shared tables in LDS
   int lane, env;
   // per-env LDS arrays
@@ -118,9 +120,9 @@ struct Sim {
   SS_DEV int ti(int off, int i) const { return (int)T[off + i]; }
   SS_DEV float tf(int off, int i) const { return bits2f(T[off + i]); }
   SS_DEV float dc(int dof, int f) const { return tf(k->h.o_dofc, dof * kDofC + f); }
-  SS_DEV const float *bodyc() const { if constexpr (SHAPED) return bodyc_s; else return k->bodyc; }
-  SS_DEV const float *candc() const { if constexpr (SHAPED) return candc_s; else return k->candc; }
-  SS_DEV float dof_invweight(int dof) const { if constexpr (SHAPED) return dinvw_s[dof]; else return dc(dof, 4); }
+  SS_DEV const float *bodyc() const { if constexpr (SHAPED) return this->bodyc_s; else return k->bodyc; }
+  SS_DEV const float *candc() const { if constexpr (SHAPED) return this->candc_s; else return k->candc; }
+  SS_DEV float dof_invweight(int dof) const { if constexpr (SHAPED) return this->dinvw_s[dof]; else return dc(dof, 4); }
   // body of a contact slot: box b owns slots 4b'..4b'+3 (b' = box order), capsule ends follow
   SS_DEV int h_box_body(int sl) const { return k->candb[8 * (sl >> 2)] & 255; }
   SS_DEV int h_caps_body(int sl) const { int e = sl - 4 * k->h.nbox; int ci = 8 * k->h.nbox + e; return ci < k->h.ncand ? (k->candb[ci] & 255) : 0; }
@@ -128,10 +130,10 @@ struct Sim {
   SS_DEV void init(W *w_, const KArgs *k_, const uint32_t *T_, float *L, int env_) {
     w = w_; k = k_; T = T_; lane = w->lane(); env = env_;
     const Hdr &h = k->h;
-    bodyc_s = candc_s = dinvw_s = nullptr;
     if constexpr (SHAPED) {
-      const size_t sid = (size_t)k->shape_id[env];
-      bodyc_s = k->bodyc + sid * h.nb * kBodyC; candc_s = k->candc + sid * h.ncand * kCandC; dinvw_s = k->dinvw + sid * h.nv;
+      const size_t sid = (size_t)k->st.shape_id[env];
+      this->bodyc_s = k->bodyc + sid * shape_stride(h); this->candc_s = k->candc + sid * h.ncand * kCandC;
+      this->dinvw_s = this->bodyc_s + h.nb * kBodyC;
     }
     S = L + h.l_S; R = L + h.l_R; r = L + h.l_r; V = L + h.l_V; Ab = L + h.l_Ab; An = L + h.l_An; Ad = An;
     Gb = L + h.l_Gb; tmpb = L + h.l_tmp; Aown = L + h.l_Aown; IA = L + h.l_IA; Ubuf = L + h.l_Ubuf; Wst = L + h.l_Wst;

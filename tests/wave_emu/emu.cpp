@@ -283,8 +283,8 @@ struct EmuBackend {
       LaunchCtx c{&k, k.shared_g, L.data(), k.order ? k.order[env] : env, m};
       void (*entry)(int, void *) = nullptr;
       const int variant = ss::kernel_variant(k.h);
-      if (variant == 0) entry = k.shape_id ? lane_entry<2, 2, 1, 1, true> : lane_entry<2, 2, 1, 1, false>;
-      else if (variant == 1) entry = k.shape_id ? lane_entry<3, 3, 2, 2, true> : lane_entry<3, 3, 2, 2, false>;
+      if (variant == 0) entry = k.st.shape_id ? lane_entry<2, 2, 1, 1, true> : lane_entry<2, 2, 1, 1, false>;
+      else if (variant == 1) entry = k.st.shape_id ? lane_entry<3, 3, 2, 2, true> : lane_entry<3, 3, 2, 2, false>;
       else return "no kernel variant for this model size";
       run_wave(m, entry, &c);
     }
