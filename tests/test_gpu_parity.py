@@ -651,3 +651,38 @@ def test_shape_varied_env_groups_match_their_oracles_and_standalone_envs(vec):
             assert np.abs(_np(qpos)[4 * g] - oenvs[g].data.qpos).max() < 2 * TOL_QPOS and np.abs(_np(obs)[4 * g] - o_ref).max() < TOL_OBS, (k, g)
             assert torch.equal(qpos[4 * g:4 * g + 4], solo[g].qpos) and torch.equal(obs[4 * g:4 * g + 4], solo[g].obs_buf)
     assert obs.shape == (8, env.obs_size) and rew.shape == (8,)
+
+
+def test_imitation_with_per_env_shapes_and_per_clip_offsets():
+    """PHC-style setup: every env has its own body shape and tracks a clip cooked with THAT shape's joint offsets.  After the
+    reference-state init the simulator's body positions (kinematics of the shaped model) must coincide with the clip's
+    (forward kinematics of the motion library with per-clip offsets) — two independent FK implementations, two tables."""
+    import test_motion_lib as T
+    from smplsim_amd.batch import ShardModel
+    from smplsim_amd.imitation import SMPLSimImitationVecEnv
+    from smplsim_amd.mjcf_writer import scaled_xml_str
+    from smplsim_amd.motion_lib import MotionLibSMPL, Skeleton
+    xmls = [scaled_xml_str("smpl_humanoid", 1.0), scaled_xml_str("smpl_humanoid", 0.9, {"L_Knee": 1.1, "R_Knee": 1.1}),
+            scaled_xml_str("smpl_humanoid", 1.1, {"Chest": 0.9})]
+    model = ShardModel(xmls=xmls, device=0)
+    sks = [Skeleton.from_model_const(mc) for mc in model.mcs]
+    lib = MotionLibSMPL(T.clip_dict(), sks[0], device=0)
+    lib.load_motions(random_sample=False, offsets=np.stack([sk.offsets for sk in sks]))       # clip m <-> shape m
+    n = 9
+    ids = np.arange(n, dtype=np.int32) % 3
+    env = SMPLSimImitationVecEnv(n, lib, model=model, shape_id=ids, autoreset=False, seed=0)
+    env.offset[:, 2] = 0.3
+    # on exact frames (blend 0): between frames the clip's qpos (Euler angles interpolated linearly) and its body positions
+    # (interpolated linearly themselves) are not the same pose, in the reference as here
+    frame = np.array([3, 6, 9, 4, 7, 10, 5, 8, 11])
+    t0 = (frame / np.asarray(T.G["fps"])[ids]).astype(np.float32)
+    env.reset(motion_ids=ids, start_times=t0)
+    ref = lib.get_motion_state(ids, t0, offset=env.offset)
+    torch.cuda.synchronize()
+    # 5e-4: the motion library rounds the joint offsets to 5 decimals like the reference's update_model, the model does not
+    assert np.abs(_np(env.xpos) - _np(ref["rg_pos"])).max() < 5e-4
+    d01 = np.abs(_np(lib.gts)[0] - _np(lib.gts)[int(lib.length_starts[1])]).max()
+    assert d01 > 1e-2                                        # the shapes / clips really differ
+    obs, rew, term, trunc, _ = env.step(env.reference_actions())
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+    assert (rew[torch.as_tensor(ids == 0, device=rew.device)] > 0.5).all()                       # the gentle clip: one PD step from its own state stays close to it
