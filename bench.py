@@ -109,7 +109,7 @@ def run_imitation(args, rank, local_rank, world, dist, dev):
     import torch
     from smplsim_amd import shard
     from smplsim_amd._lib import lib
-    from smplsim_amd.batch import ShardModel, _ptr
+    from smplsim_amd.batch import ShardModel
     from smplsim_amd.imitation import SMPLSimImitationVecEnv
     from smplsim_amd.motion_lib import MotionLibSMPL, Skeleton
     N = args.envs_per_gpu

@@ -26,7 +26,7 @@ from __future__ import annotations
 import dataclasses
 import math
 import xml.etree.ElementTree as ET
-from typing import List, Optional
+from typing import List
 
 import numpy as np
 

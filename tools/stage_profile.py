@@ -9,7 +9,6 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import numpy as np
 import torch
 
 from smplsim_amd import _cabi, _lib
