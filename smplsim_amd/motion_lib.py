@@ -11,8 +11,9 @@ all on purpose:
     is three HIP launches over every frame of every selected clip (ss_motion_cook); the arrays are torch tensors in HBM;
   * joint offsets come from the compiled MJCF (body positions) instead of SMPL_Parser + betas — the SMPL model files
     are not redistributable; per-clip offsets ([M,J,3], e.g. from the user's own SMPL_Parser) can be passed in;
-  * fix_trans_height (motion_lib_smpl.py:66-90) needs the SMPL mesh: FixHeightMode.no_fix is native, the other two
-    modes need a `height_fix` callable supplied by the user (called per clip on the host).
+  * fix_trans_height (motion_lib_smpl.py:66-90) needs the SMPL mesh: FixHeightMode.no_fix is native, full_fix / ankle_fix
+    need a `height_fix` callable supplied by the user (called per clip on the host); FixHeightMode.geom_fix (not in the
+    reference) does full_fix on the device with the MJCF's collision geoms standing in for the mesh vertices.
 
 There is no CPU path: without a GPU (and libsmplsim_hip.so) construction fails.
 """
@@ -34,14 +35,16 @@ class FixHeightMode(Enum):          # motion_lib_base.py:28-31
     no_fix = 0
     full_fix = 1
     ankle_fix = 2
+    geom_fix = 3                    # not in the reference: full_fix with the MJCF's collision geoms in place of the SMPL mesh
 
 
 class Skeleton:
     """Body tree in MuJoCo (MJCF depth-first) order + the SMPL joint order permutation (Humanoid_Batch.__init__,
     torch_smpl_humanoid_batch.py:38-78)."""
 
-    def __init__(self, body_names, parents, offsets, smpl_order_names=None):
+    def __init__(self, body_names, parents, offsets, smpl_order_names=None, geoms=None):
         self.body_names = list(body_names)
+        self.geoms = geoms          # (type [J], size [J,3], pos [J,3], quat [J,4]) of the collision geoms, for FixHeightMode.geom_fix
         self.parents = np.asarray(parents, np.int32)
         self.offsets = np.round(np.asarray(offsets, np.float32), decimals=5)        # update_model rounds to 5 decimals (:113)
         order = list(smpl_order_names) if smpl_order_names is not None else (
@@ -53,7 +56,9 @@ class Skeleton:
     @classmethod
     def from_model_const(cls, mc, smpl_order_names=None):
         """From a compiled MJCF (smplsim_amd.mjcf.compile_mjcf): offsets = body positions in the parent frame."""
-        return cls(mc.body_names, mc.body_parent, mc.body_pos, smpl_order_names)
+        return cls(mc.body_names, mc.body_parent, mc.body_pos, smpl_order_names,
+                   geoms=(np.asarray(mc.geom_type), np.asarray(mc.geom_size, np.float32), np.asarray(mc.geom_pos, np.float32),
+                          np.asarray(mc.geom_quat, np.float32)))
 
 
 def _ptr(t):
@@ -75,8 +80,10 @@ class MotionLibSMPL:
             self._lib, self.device = _clib, torch.device("cpu")
         self.skeleton = skeleton
         self.fix_height, self.height_fix = fix_height, height_fix
-        if fix_height != FixHeightMode.no_fix and height_fix is None:
-            raise ValueError("fix_height modes other than no_fix need the SMPL mesh: pass a height_fix(pose_aa, trans) callable")
+        if fix_height in (FixHeightMode.full_fix, FixHeightMode.ankle_fix) and height_fix is None:
+            raise ValueError("full_fix / ankle_fix need the SMPL mesh: pass a height_fix(pose_aa, trans) callable, or use geom_fix")
+        if fix_height == FixHeightMode.geom_fix and skeleton.geoms is None:
+            raise ValueError("geom_fix needs the skeleton's collision geoms (Skeleton.from_model_const)")
         self.max_length, self.randomrize_heading, self.filter_vel = max_length, randomrize_heading, bool(filter_vel)
         self.rng = np.random.default_rng(seed)
         self.dtype = np.float32
@@ -155,7 +162,7 @@ class MotionLibSMPL:
                 rot = sRot.from_euler("xyz", [0.0, 0.0, np.pi * (2 * self.rng.random() - 1.0)])
                 pose[:, 0] = (rot * sRot.from_rotvec(pose[:, 0])).as_rotvec().astype(np.float32)
                 trans = (trans @ rot.as_matrix().T.astype(np.float32)).astype(np.float32)
-            if self.fix_height != FixHeightMode.no_fix:
+            if self.fix_height in (FixHeightMode.full_fix, FixHeightMode.ankle_fix):
                 trans = np.asarray(self.height_fix(pose, trans), np.float32)
             poses.append(pose); transs.append(trans); nfs.append(pose.shape[0]); fpss.append(fps)
 
@@ -198,6 +205,8 @@ class MotionLibSMPL:
         self._sk_keep = (np.ascontiguousarray(sk.parents, np.int32), np.ascontiguousarray(sk.smpl_2_mujoco, np.int32))
         skel = _cabi.Skeleton(J, self._sk_keep[0].ctypes.data_as(C.c_void_p), self._sk_keep[1].ctypes.data_as(C.c_void_p))
         self._check(self._lib.ss_motion_cook(C.byref(skel), C.byref(self.data), int(self.filter_vel), self._stream()))
+        if self.fix_height == FixHeightMode.geom_fix:
+            self._geom_height_fix()
         self.motion_lengths_t, self.motion_num_frames_t = self._d["motion_lengths"], self._d["motion_num_frames"]
         cdf = np.cumsum(self._sampling_batch_prob)
         cdf[-1] = 1.0 + 1e-6                                        # rand < 1 always lands in a clip
@@ -206,6 +215,36 @@ class MotionLibSMPL:
             print(f"###### Sampling {M:d} motions:", idx[:5], self.curr_motion_keys[:5],
                   f"total length of {self.get_total_length():.3f}s and {F} frames.")
         return M
+
+    def _geom_height_fix(self, frame_check=30):
+        """fix_trans_height's full_fix (motion_lib_smpl.py:66-90: lower / raise every clip so that the lowest point of its first
+        30 frames touches z = 0) with the model's collision geoms standing in for the SMPL mesh vertices.  A pure translation:
+        applied to the cooked positions in place (velocities and rotations do not change), on the device."""
+        gtype, gsize, gpos, gquat = self.skeleton.geoms
+        dev, J = self.device, self.skeleton.num_joints
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)  # noqa: E731
+        q = self.grs                                                               # [F,J,4] wxyz body rotations
+        w, x, y, z = q.unbind(-1)
+        row2 = torch.stack([2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1)   # third row of R_body
+        gq = t(gquat)
+        gw, gx, gy, gz = gq.unbind(-1)
+        G = torch.stack([torch.stack([1 - 2 * (gy * gy + gz * gz), 2 * (gx * gy - gw * gz), 2 * (gx * gz + gw * gy)], -1),
+                         torch.stack([2 * (gx * gy + gw * gz), 1 - 2 * (gx * gx + gz * gz), 2 * (gy * gz - gw * gx)], -1),
+                         torch.stack([2 * (gx * gz - gw * gy), 2 * (gy * gz + gw * gx), 1 - 2 * (gx * gx + gy * gy)], -1)], -2)  # [J,3,3]
+        zrow = torch.einsum("fjk,jkc->fjc", row2, G)                               # third row of R_body R_geom
+        centre = self.gts[..., 2] + (row2 * t(gpos)).sum(-1)
+        size = t(gsize)
+        is_box = torch.as_tensor(np.asarray(gtype) == 0, device=dev)
+        low_box = centre - (zrow.abs() * size).sum(-1)
+        low_caps = centre - zrow[..., 2].abs() * size[:, 1] - size[:, 0]           # lower end sphere of the capsule
+        low = torch.where(is_box, low_box, low_caps).min(dim=1).values             # [F] lowest geom point per frame
+        fm = self._d["frame_motion"].long()
+        t_in = torch.arange(low.shape[0], device=dev) - self._d["length_starts"].long()[fm]
+        low = torch.where(t_in < frame_check, low, torch.full_like(low, float("inf")))
+        diff = torch.full((self._num_motions,), float("inf"), device=dev).scatter_reduce(0, fm, low, reduce="amin")
+        self.height_offsets = diff
+        self.gts[..., 2] -= diff[fm][:, None]
+        self.qpos[:, 2] -= diff[fm]
 
     def _check(self, rc):
         if rc != 0:

@@ -428,3 +428,34 @@ def test_tracking_metrics_match_reference_smpl_eval():
         assert np.abs(m[k].numpy() - ref).max() < 1e-8 * max(1.0, np.abs(ref).max()), k
     m32 = metrics.compute_metrics_lite([t(G["ev_in_pred0"]).float()], [t(G["ev_in_gt0"]).float()])
     assert np.abs(m32["mpjpe_pa"].numpy() - G["ev_mpjpe_pa"][:17]).max() < 1e-2      # millimetres, float32
+
+
+def test_geom_height_fix_puts_the_first_frames_on_the_floor(emu_lib):
+    from smplsim_amd.motion_lib import FixHeightMode
+    raw = make_lib(emu_lib)
+    lib = make_lib(emu_lib, fix_height=FixHeightMode.geom_fix)
+    # lowest geom point per frame from the oracle-side restatement of the geoms (numpy, independent of the torch code)
+    from helpers import model_const
+    mc = model_const()
+    gts, grs = lib.gts.numpy().astype(np.float64), lib.grs.numpy().astype(np.float64)
+    R = mo.quaternion_to_matrix(grs)
+    G = mo.quaternion_to_matrix(np.asarray(mc.geom_quat, np.float64))
+    lows = np.full(gts.shape[:2], np.inf)
+    for j in range(24):
+        Rg = R[:, j] @ G[j]
+        c = gts[:, j] + R[:, j] @ np.asarray(mc.geom_pos[j], np.float64)
+        if mc.geom_type[j] == 0:
+            corners = np.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)]) * np.asarray(mc.geom_size[j])
+            lows[:, j] = (c[:, None, 2] + np.einsum("fk,ck->fc", Rg[:, 2], corners)).min(1)
+        else:
+            r, hl = mc.geom_size[j][0], mc.geom_size[j][1]
+            lows[:, j] = np.minimum(c[:, 2] + Rg[:, 2, 2] * hl, c[:, 2] - Rg[:, 2, 2] * hl) - r
+    st = np.concatenate([[0], np.cumsum(np.asarray(lib._motion_num_frames))])
+    for m in range(3):
+        first = lows[st[m]:st[m] + 30].min()
+        assert abs(first) < 2e-5, (m, first)
+    # a pure z translation of positions; everything else untouched
+    d = raw.gts.numpy() - lib.gts.numpy()
+    assert np.abs(d[..., :2]).max() == 0 and np.abs(d[..., 2] - d[:, :1, 2]).max() < 1e-6
+    assert np.array_equal(raw.gvs.numpy(), lib.gvs.numpy()) and np.array_equal(raw.grs.numpy(), lib.grs.numpy())
+    assert np.abs((raw.qpos.numpy() - lib.qpos.numpy())[:, 2] - d[:, 0, 2]).max() < 1e-6
