@@ -18,7 +18,12 @@ _LIB = None
 # with v_mov shuffles; packed FP32 issues at half rate on gfx950 (profiles/r01n_valu_ubench.txt), so that is slower
 # (-7 %) and costs 45 more spilled VGPRs.  iterative-ilp: the GCN scheduler variant that schedules for ILP — the kernel
 # is a dependent-instruction chain per wavefront with a fixed occupancy (launch bounds), not occupancy-limited (-3 %).
-DEFAULT_OPT = "-O3 -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-ilp"
+# -Os (was -O3): the stepper is one big state machine per wavefront; optimised for size it spills more (47 instead of 16
+# VGPRs) and is still faster — 2.04 vs 2.08 ms per 4096-env SMPL step, 4.80 vs 5.22 ms SMPL-X (same-box A/B; -O2 is in
+# between, -Oz and -O3 -fno-unroll-loops are slower).  The small arithmetic kernels of the motion library are twice as slow at
+# -Os, so that translation unit keeps -O3 (MOTION_OPT).
+DEFAULT_OPT = "-Os -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-ilp"
+MOTION_OPT = "-O3"
 
 
 class ExtensionMissing(RuntimeError):
@@ -27,21 +32,32 @@ class ExtensionMissing(RuntimeError):
 
 def build(verbose=False, force=False):
     """hipcc --offload-arch=gfx950 build of the kernels + C ABI (cross-compiles without a GPU)."""
-    srcs = [os.path.join(SRC_DIR, f) for f in ("smplsim_hip.hip", "ss_kernel.h", "ss_api.h", "ss_tables.h", "ss_hdr.h", "ss_motion.h",
-                                                  "ss_motion_api.h")]
+    srcs = [os.path.join(SRC_DIR, f) for f in ("smplsim_hip.hip", "smplsim_motion.hip", "ss_kernel.h", "ss_api.h", "ss_tables.h", "ss_hdr.h",
+                                                  "ss_motion.h", "ss_motion_api.h", "ss_wave_gpu.h")]
     srcs += [os.path.join(os.path.dirname(_PKG), "include", h) for h in ("smplsim_hip.h", "smplsim_motion.h")]
     opt = os.environ.get("SS_HIPCC_OPT", DEFAULT_OPT).split()
+    mopt = os.environ.get("SS_HIPCC_MOTION_OPT", MOTION_OPT).split()
     stamp = LIB_PATH + ".flags"                              # rebuild when the flags change, not only the sources
-    same_flags = os.path.exists(stamp) and open(stamp).read() == " ".join(opt)
+    same_flags = os.path.exists(stamp) and open(stamp).read() == " ".join(opt + ["|"] + mopt)
     if not force and same_flags and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", *opt, "-std=c++17", "-shared", "-fPIC", srcs[0], "-o", LIB_PATH]
+    objs = []
+    for src, flags in ((srcs[0], opt), (srcs[1], mopt)):      # stepper and motion library: one object each, their own flags
+        obj = os.path.join(_PKG, os.path.basename(src).replace(".hip", ".o"))
+        cmd = [hipcc, "--offload-arch=gfx950", *flags, "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    for o in objs:
+        os.remove(o)
     with open(stamp, "w") as f:
-        f.write(" ".join(opt))
+        f.write(" ".join(opt + ["|"] + mopt))
     return LIB_PATH
 
 

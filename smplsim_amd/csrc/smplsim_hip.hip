@@ -8,10 +8,10 @@
 
 #include "ss_api.h"
 #include "ss_kernel.h"
-#include "ss_motion_api.h"
+#include "ss_wave_gpu.h"
 
 // launch bounds per kernel variant = the number of envs whose LDS slices fit one CU, rounded up to whole waves per
-// SIMD.  SMPL: 12 envs -> 3 waves/SIMD -> 168-VGPR cap (~12 spilled dwords).  SMPL-X: 5 envs -> 2 waves/SIMD, 256 VGPRs,
+// SIMD.  SMPL: 12 envs -> 3 waves/SIMD -> 168-VGPR cap (16 spilled dwords at -O3, 47 at the shipped -Os, which is faster all the same).  SMPL-X: 5 envs -> 2 waves/SIMD, 256 VGPRs,
 // no spills.  (History of the trade-off: profiles/r01i_ab_launch_bounds.txt.)
 #ifndef SS_MAX_THREADS
 #define SS_MAX_THREADS 768
@@ -22,57 +22,6 @@
 
 namespace {
 
-struct WaveGpu {
-  int ln;
-  __device__ __forceinline__ int lane() const { return ln; }
-  // wave-level LDS hand-off: the DS instructions of one wavefront are issued and executed in program order, so a
-  // read that follows a write in the instruction stream sees it without draining lgkmcnt; what is needed is only
-  // that the compiler keeps LDS accesses on their side of the hand-off (memory clobber + scheduling barrier)
-  __device__ __forceinline__ void sync() const {
-#ifdef SS_SYNC_DRAIN
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
-    asm volatile("" ::: "memory");
-#endif
-    __builtin_amdgcn_wave_barrier();
-  }
-  // cross-lane moves as DPP modifiers of VALU instructions (no LDS-crossbar ds_bpermute round trips):
-  // quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140
-  template <int CTRL> static __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
-  template <int CTRL> static __device__ __forceinline__ float dpp_f(float v) { return __builtin_bit_cast(float, dpp_i<CTRL>(__builtin_bit_cast(int, v))); }
-  static __device__ __forceinline__ float rl(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
-  // wave-wide sum, result in every lane: 4 DPP steps give every 16-lane row its sum, then 4 readlanes
-  __device__ __forceinline__ float sum(float v) const {
-    v += dpp_f<0xB1>(v); v += dpp_f<0x4E>(v); v += dpp_f<0x141>(v); v += dpp_f<0x140>(v);
-    return (rl(v, 0) + rl(v, 16)) + (rl(v, 32) + rl(v, 48));
-  }
-  // sum over the lane's aligned group of 8 lanes: xor 1, xor 2, then the mirrored half row
-  __device__ __forceinline__ float sum8(float v) const { v += dpp_f<0xB1>(v); v += dpp_f<0x4E>(v); v += dpp_f<0x141>(v); return v; }
-  __device__ __forceinline__ float quad_xor1(float v) const { return dpp_f<0xB1>(v); }
-  __device__ __forceinline__ float quad_xor2(float v) const { return dpp_f<0x4E>(v); }
-  __device__ __forceinline__ int quad_xor1_i(int v) const { return dpp_i<0xB1>(v); }
-  __device__ __forceinline__ int quad_xor2_i(int v) const { return dpp_i<0x4E>(v); }
-  __device__ __forceinline__ void mem_fence() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); }
-  __device__ __forceinline__ unsigned long long clock() const { return __builtin_readcyclecounter(); }
-  __device__ __forceinline__ void atomic_add_u64(unsigned long long *p, unsigned long long v) const { atomicAdd(p, v); }
-  __device__ __forceinline__ int opaque(int x) const { return __builtin_amdgcn_readfirstlane(x); }   // wave-uniform, optimizer-opaque
-  __device__ __forceinline__ int opaque_v(int x) const { asm volatile("" : "+v"(x)); return x; }   // per-lane value, optimizer-opaque
-  __device__ __forceinline__ float shfl_xor(float v, int m) const { return __shfl_xor(v, m, 64); }
-  __device__ __forceinline__ int shfl_xor_i(int v, int m) const { return __shfl_xor(v, m, 64); }
-  __device__ __forceinline__ unsigned long long ballot(int p) const { return __ballot(p); }
-  __device__ __forceinline__ bool any(int p) const { return __any(p) != 0; }
-  __device__ __forceinline__ unsigned long long bor(unsigned long long v) const {
-    int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
-    lo |= dpp_i<0xB1>(lo); lo |= dpp_i<0x4E>(lo); lo |= dpp_i<0x141>(lo); lo |= dpp_i<0x140>(lo);
-    hi |= dpp_i<0xB1>(hi); hi |= dpp_i<0x4E>(hi); hi |= dpp_i<0x141>(hi); hi |= dpp_i<0x140>(hi);
-    const unsigned l = (unsigned)(__builtin_amdgcn_readlane(lo, 0) | __builtin_amdgcn_readlane(lo, 16) | __builtin_amdgcn_readlane(lo, 32) | __builtin_amdgcn_readlane(lo, 48));
-    const unsigned h = (unsigned)(__builtin_amdgcn_readlane(hi, 0) | __builtin_amdgcn_readlane(hi, 16) | __builtin_amdgcn_readlane(hi, 32) | __builtin_amdgcn_readlane(hi, 48));
-    return ((unsigned long long)h << 32) | l;
-  }
-  __device__ __forceinline__ void atomic_add(float *p, float v) const {
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-  }
-};
 
 template <int DOFP, int CANDP, int SLOTP, int NPASS, int MAXT, bool BODYOUT, bool SHAPED>
 __global__ void __launch_bounds__(MAXT) ss_env_kernel(const ss::KArgs k) {
@@ -136,42 +85,6 @@ __global__ void __launch_bounds__(1024) ss_order_kernel(const int32_t *iters, in
 }
 
 
-// ---- motion library (include/smplsim_motion.h; element / wave functions in ss_motion.h).  All HBM-bound gathers: the
-// grids are one lane per (frame, body) for FK (tree levels in sequence through a small LDS tile), one wave per clip (the
-// sequential Euler-angle fix), one thread per (frame, body) and per (env, body).
-template <int LPE>
-__global__ void __launch_bounds__(256) ss_motion_fk_kernel(const ss::mo::CookArgs a) {
-  __shared__ float xf[4 * 64 * ss::mo::kXformStride];
-  WaveGpu w{(int)(threadIdx.x & 63)};
-  const int wave = threadIdx.x >> 6;
-  ss::mo::fk_wave<WaveGpu, LPE>(&w, a, (int)(blockIdx.x * 4 + wave), xf + wave * 64 * ss::mo::kXformStride);
-}
-__global__ void __launch_bounds__(64) ss_motion_fix_kernel(const ss::mo::CookArgs a) {
-  WaveGpu w{(int)threadIdx.x};
-  ss::mo::dof_fix_clip(&w, a, (int)blockIdx.x);
-}
-__global__ void __launch_bounds__(128) ss_motion_vel_kernel(const ss::mo::CookArgs a) {
-  extern __shared__ float raw[];                             // per wave: (tile + 16) frames x J bodies x 6 floats
-  WaveGpu w{(int)(threadIdx.x & 63)};
-  const int wave = threadIdx.x >> 6, per = (ss::mo::kVelTile + 2 * ss::mo::kGaussRadius) * a.sk.nb * 6;
-  const int wave_id = (int)(blockIdx.x * (blockDim.x >> 6)) + wave;
-  if (wave_id * ss::mo::kVelTile < a.d.num_frames) ss::mo::vel_wave(&w, a, wave_id, raw + (size_t)wave * per);
-}
-__global__ void __launch_bounds__(256) ss_motion_state_kernel(const ss::mo::StateArgs a) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int J = a.d.nbody;
-  if (idx < (long long)a.N * J) ss::mo::state_elem(a, (int)(idx / J), (int)(idx % J));
-}
-__global__ void __launch_bounds__(256) ss_motion_resample_kernel(const ss::mo::ResampleArgs a) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n < a.N) ss::mo::resample_elem(a, n);
-}
-template <int LPE>
-__global__ void __launch_bounds__(256) ss_imitation_kernel(const ss::mo::ImArgs a) {
-  WaveGpu w{(int)(threadIdx.x & 63)};
-  ss::mo::imitation_wave<WaveGpu, LPE>(&w, a, (int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-}
-
 typedef void (*kern_t)(const ss::KArgs);
 // instantiations per model size: plain (the headline), +body-frame outputs, +per-env body shapes (which includes the outputs)
 kern_t pick_kernel(int variant, int flavour) {
@@ -207,30 +120,6 @@ struct HipBackend {
     hipLaunchKernelGGL(ss_gae_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, rew, nd, ndead, val, boot, T, N, gamma, tau, adv, ret);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? nullptr : hipGetErrorString(e);
-  }
-  static const char *hip_err() { hipError_t e = hipGetLastError(); return e == hipSuccess ? nullptr : hipGetErrorString(e); }
-  static const char *motion_cook(const ss::mo::CookArgs &a, void *stream) {
-    const int F = a.d.num_frames, J = a.sk.nb;
-    if (J <= 32) hipLaunchKernelGGL(ss_motion_fk_kernel<32>, dim3((F + 7) / 8), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(ss_motion_fk_kernel<64>, dim3((F + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
-    hipLaunchKernelGGL(ss_motion_fix_kernel, dim3(a.d.num_motions), dim3(64), 0, (hipStream_t)stream, a);
-    const int vwaves = J <= 32 ? 2 : 1, tiles = (F + ss::mo::kVelTile - 1) / ss::mo::kVelTile;      // <= 40 KiB of LDS per workgroup
-    const size_t vlds = (size_t)vwaves * (ss::mo::kVelTile + 2 * ss::mo::kGaussRadius) * J * 6 * sizeof(float);
-    hipLaunchKernelGGL(ss_motion_vel_kernel, dim3((tiles + vwaves - 1) / vwaves), dim3(64 * vwaves), vlds, (hipStream_t)stream, a);
-    return hip_err();
-  }
-  static const char *motion_state(const ss::mo::StateArgs &a, void *stream) {
-    hipLaunchKernelGGL(ss_motion_state_kernel, dim3((unsigned)(((long long)a.N * a.d.nbody + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
-    return hip_err();
-  }
-  static const char *motion_resample(const ss::mo::ResampleArgs &a, void *stream) {
-    hipLaunchKernelGGL(ss_motion_resample_kernel, dim3((a.N + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
-    return hip_err();
-  }
-  static const char *imitation(const ss::mo::ImArgs &a, void *stream) {
-    if (a.d.nbody <= 32) hipLaunchKernelGGL(ss_imitation_kernel<32>, dim3((a.N + 7) / 8), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(ss_imitation_kernel<64>, dim3((a.N + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
-    return hip_err();
   }
   static int &regs_ref() { static int r = 0; return r; }
   static int kernel_regs() { return regs_ref(); }
@@ -275,4 +164,3 @@ struct HipBackend {
 }  // namespace
 
 SS_DEFINE_C_API(HipBackend)
-SS_DEFINE_MOTION_API(HipBackend)
