@@ -124,3 +124,17 @@ def test_world_size_2_gloo_shards(tmp_path):
     import json
     res = json.loads(outs[0][0].strip().splitlines()[-1])
     assert res["units"] == 64 and res["elapsed"] >= 0.1 and abs(res["value"] - 64 / res["elapsed"]) < 1e-6
+
+
+def test_import_shim_lets_the_rest_of_the_reference_resolve_behind_it():
+    """With this repo before a SMPLSim checkout on sys.path, smpl_sim.envs is ours and smpl_sim.learning is the reference's."""
+    ref = "/root/reference"
+    if not os.path.isdir(os.path.join(ref, "smpl_sim", "learning")):
+        pytest.skip("no reference checkout in this environment")
+    code = ("import smpl_sim.envs.tasks as t, smpl_sim.learning.mlp as m, smpl_sim.smpllib.motion_lib_smpl as ml, sys;"
+            "print(t.HumanoidEnv.__module__, m.__file__, ml.MotionLibSMPL.__module__)")
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + ref, PYTHONDONTWRITEBYTECODE="1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd="/tmp")
+    assert out.returncode == 0, out.stderr[-2000:]
+    mod, mlp_file, ml_mod = out.stdout.split()
+    assert mod.startswith("smplsim_amd.") and mlp_file.startswith(ref) and ml_mod == "smplsim_amd.motion_lib"
