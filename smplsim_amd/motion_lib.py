@@ -65,6 +65,29 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def qpos_to_pose_aa(qpos, skeleton):
+    """Simulator state -> SMPL pose: the inverse of the qpos the motion library cooks (Humanoid_Batch.qpos_to_pose_aa_torch /
+    _numpy, torch_smpl_humanoid_batch.py:239-265).  qpos [B, 7+3(J-1)] (root pos, root quat wxyz, XYZ Euler hinges, MuJoCo body
+    order) -> (root translation [B,3] without the root joint offset, pose_aa [B,J,3] in SMPL joint order).  Plain torch ops on
+    whatever device qpos lives on."""
+    B, J = qpos.shape[0], skeleton.num_joints
+    e = qpos[:, 7:].reshape(B, J - 1, 3)
+    # R = Rx Ry Rz (intrinsic XYZ), as a quaternion product qx * qy * qz
+    hx, hy, hz = e[..., 0] / 2, e[..., 1] / 2, e[..., 2] / 2
+    cx, sx, cy, sy, cz, sz = hx.cos(), hx.sin(), hy.cos(), hy.sin(), hz.cos(), hz.sin()
+    qb = torch.stack([cx * cy * cz - sx * sy * sz, sx * cy * cz + cx * sy * sz, cx * sy * cz - sx * cy * sz, cx * cy * sz + sx * sy * cz], -1)
+    quat = torch.cat([qpos[:, None, 3:7], qb], 1)                                   # [B,J,4] wxyz, MuJoCo order
+    quat = quat / quat.norm(dim=-1, keepdim=True)
+    quat = torch.where(quat[..., :1] < 0, -quat, quat)
+    v = quat[..., 1:]
+    n = v.norm(dim=-1, keepdim=True)
+    ang = 2 * torch.atan2(n, quat[..., :1])
+    aa = torch.where(n > 1e-8, v / n.clamp(min=1e-12) * ang, 2 * v)
+    m2s = torch.as_tensor(skeleton.mujoco_2_smpl, device=qpos.device, dtype=torch.long)
+    root = qpos[:, :3] - torch.as_tensor(skeleton.offsets[0], device=qpos.device, dtype=qpos.dtype)
+    return root, aa[:, m2s]
+
+
 class MotionLibSMPL:
     def __init__(self, motion_file, skeleton, device=0, fix_height=FixHeightMode.no_fix, min_length=-1, max_length=-1,
                  randomrize_heading=False, filter_vel=True, height_fix=None, seed=0, _clib=None):

@@ -459,3 +459,14 @@ def test_geom_height_fix_puts_the_first_frames_on_the_floor(emu_lib):
     assert np.abs(d[..., :2]).max() == 0 and np.abs(d[..., 2] - d[:, :1, 2]).max() < 1e-6
     assert np.array_equal(raw.gvs.numpy(), lib.gvs.numpy()) and np.array_equal(raw.grs.numpy(), lib.grs.numpy())
     assert np.abs((raw.qpos.numpy() - lib.qpos.numpy())[:, 2] - d[:, 0, 2]).max() < 1e-6
+
+
+def test_qpos_to_pose_aa_inverts_the_cooked_qpos(emu_lib):
+    from smplsim_amd.motion_lib import qpos_to_pose_aa
+    lib = make_lib(emu_lib)
+    root, aa = qpos_to_pose_aa(lib.qpos.double(), lib.skeleton)
+    assert np.abs(root.numpy() - G["trans"]).max() < 1e-5
+    # same rotations as the clips' pose_aa (compare as matrices: axis-angle is not unique beyond pi)
+    want = mo.quaternion_to_matrix(mo.axis_angle_to_quaternion(G["pose_aa"].astype(np.float64)))
+    got = mo.quaternion_to_matrix(mo.axis_angle_to_quaternion(aa.numpy()))
+    assert np.abs(got - want).max() < 2e-5
