@@ -68,5 +68,8 @@ def lib():
             raise ExtensionMissing(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). smplsim_amd has no CPU fallback.")
+        # torch first: it brings its own libamdhip64; loaded after ours (which links /opt/rocm's) the process would hold two HIP
+        # runtimes and the first hipSetDevice fails ("cannot select device")
+        import torch  # noqa: F401
         _LIB = _cabi.bind(ctypes.CDLL(LIB_PATH))
     return _LIB

@@ -13,6 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_library_builds_loads_and_exports_every_declared_symbol():
+    import torch  # noqa: F401  (always before the library: one HIP runtime per process)
     from smplsim_amd import _cabi, _lib
     path = _lib.build()
     lib = ctypes.CDLL(path)
