@@ -374,10 +374,19 @@ class MotionLibSMPL:
                                                  C.byref(st), self._stream()))
         return out, ids
 
+    def _frame0(self, ids, times):
+        """Global index of the frame at or before `times` (f0l of the reference), float32 like the kernel."""
+        idl = ids.long()
+        nf = self.motion_num_frames_t[idl]
+        phase = (times / self.motion_lengths_t[idl]).clamp(0.0, 1.0)
+        i0 = (phase * (nf - 1).to(torch.float32)).to(torch.int64)
+        return torch.where(nf < 2, torch.zeros_like(i0), i0) + self._d["length_starts"][idl].long()
+
     def get_motion_state(self, motion_ids, motion_times, offset=None, with_qpos=False):
         fields = ["root_pos", "root_rot", "dof_pos", "root_vel", "root_ang_vel", "dof_vel", "rg_pos", "rb_rot", "body_vel", "body_ang_vel"]
         out, ids = self._lookup(motion_ids, motion_times, offset, False, fields + (["qpos", "qvel"] if with_qpos else []))
         out["motion_bodies"] = torch.as_tensor(self._motion_bodies, device=self.device)[ids.long()]
+        out["motion_aa"] = self._d["pose_aa"][self._frame0(ids, self._keep[1])]      # raw clip pose of frame f0, as in the reference
         return out
 
     def get_motion_state_intervaled(self, motion_ids, motion_times, offset=None):

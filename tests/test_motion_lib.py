@@ -147,6 +147,9 @@ def check_blended(lib, rs, n=200):
             err = np.abs(g - v.reshape(g.shape)).max()
         # float32 blend weight (error ~1e-5) times the frame-to-frame change, which is 100s of rad/s for the velocities here
         assert err < (2e-4 if k.endswith("rot") else 5e-3 if "vel" in k else 1e-4), (k, err)
+    i0, _, _ = mo.calc_frame_blend(times, lib._motion_lengths[ids], lib._motion_num_frames[ids], lib._motion_dt[ids])
+    sel = np.abs(times / lib._motion_dt[ids] - np.round(times / lib._motion_dt[ids])) > 1e-3      # away from frame boundaries
+    assert np.array_equal(got["motion_aa"].cpu().numpy()[sel], lib._motion_aa[(i0 + lib.length_starts[ids])[sel]])
     # qpos/qvel of the blended state: root pose + Euler dofs, body-frame root angular velocity
     qp, qv = got["qpos"].cpu().numpy(), got["qvel"].cpu().numpy()
     assert np.abs(qp[:, :3] - want["root_pos"]).max() < 1e-4 and np.abs(qp[:, 7:] - want["dof_pos"]).max() < 1e-4
