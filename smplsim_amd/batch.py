@@ -82,6 +82,9 @@ class SMPLSimVecEnv:
         if self.task_id == _cabi.TASK_REACH and isinstance(reach_body, str) and reach_body not in mc.body_names:
             raise ValueError(f"reach_body {reach_body!r} is not a body of this model")
         self.state_init = _cabi.STATE_INITS[state_init] if isinstance(state_init, str) else int(state_init)
+        if self.state_init == _cabi.INIT_EXTERNAL and autoreset:
+            raise ValueError("StateInit External keeps the state the caller wrote: pass autoreset=False and reset finished envs "
+                             "yourself (write qpos / qvel, then reset(mask)), as SMPLSimImitationVecEnv does")
         self.cfg = _cabi.make_env_cfg(
             task=self.task_id, state_init=self.state_init, self_obs_v=self_obs_v,
             control_mode=_cabi.CONTROL_MODES[control_mode], episode_length=episode_length,

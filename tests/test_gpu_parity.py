@@ -686,3 +686,13 @@ def test_imitation_with_per_env_shapes_and_per_clip_offsets():
     obs, rew, term, trunc, _ = env.step(env.reference_actions())
     assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
     assert (rew[torch.as_tensor(ids == 0, device=rew.device)] > 0.5).all()                       # the gentle clip: one PD step from its own state stays close to it
+
+
+def test_external_init_refuses_autoreset(vec):
+    with pytest.raises(ValueError, match="External"):
+        vec(4, state_init="External")
+    env = vec(4, state_init="External", autoreset=False)
+    env.set_state(np.tile(default_qpos(76), (4, 1)), np.zeros((4, 75)))
+    obs, _ = env.reset()
+    ref = vec(4, autoreset=False)
+    assert torch.equal(ref.reset()[0], obs)              # the Default pose written by hand == StateInit Default
