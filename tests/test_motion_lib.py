@@ -473,3 +473,34 @@ def test_qpos_to_pose_aa_inverts_the_cooked_qpos(emu_lib):
     want = mo.quaternion_to_matrix(mo.axis_angle_to_quaternion(G["pose_aa"].astype(np.float64)))
     got = mo.quaternion_to_matrix(mo.axis_angle_to_quaternion(aa.numpy()))
     assert np.abs(got - want).max() < 2e-5
+
+
+def test_emu_very_short_clips_match_oracle(emu_lib):
+    """2- and 3-frame clips between longer ones: every tap of the velocity filter is an edge sample."""
+    from smplsim_amd.motion_lib import MotionLibSMPL, Skeleton
+    from smplsim_amd.mjcf import compile_mjcf
+    from smplsim_amd.mjcf_writer import default_xml_str
+    sk = Skeleton.from_model_const(compile_mjcf(default_xml_str("smpl_humanoid")))
+    rs = np.random.default_rng(3)
+    clips = {}
+    for c, T in enumerate((2, 19, 3, 2, 17)):
+        pose = (rs.normal(size=(1, 24, 3)) * 0.3 + 0.2 * np.arange(T)[:, None, None] * rs.normal(size=(1, 24, 3))).astype(np.float32)
+        trans = np.cumsum(rs.normal(size=(T, 3)) * 0.02, 0).astype(np.float32) + np.array([0, 0, 0.9], np.float32)
+        clips[f"s{c}"] = dict(pose_aa=pose.reshape(T, 72), trans=trans, fps=30)
+    lib = MotionLibSMPL(clips, sk, _clib=emu_lib)
+    lib.load_motions(random_sample=False)
+    st = 0
+    for c in clips.values():
+        T = c["pose_aa"].shape[0]
+        r = mo.cook(c["pose_aa"].reshape(T, 24, 3), c["trans"], sk.offsets, sk.parents, sk.smpl_2_mujoco, 1 / 30, True)
+        for k, attr in NAMES.items():
+            got = getattr(lib, attr).numpy()[st:st + T]
+            ref = r[k].reshape(got.shape)
+            err = np.minimum(np.abs(got - ref).max(-1), np.abs(got + ref).max(-1)).max() if k.endswith("rotation") else np.abs(got - ref).max()
+            assert err < TOL[k], (T, k, err)
+        st += T
+    # lookups at and beyond both ends of a 2-frame clip
+    s = lib.get_motion_state(np.array([0, 0, 0, 3]), np.array([-1.0, 0.0, 5.0, 1 / 60], np.float32))
+    assert np.allclose(s["rg_pos"][0].numpy(), lib.gts[0].numpy()) and np.allclose(s["rg_pos"][2].numpy(), lib.gts[1].numpy())
+    f3 = int(lib.length_starts[3])
+    assert np.allclose(s["rg_pos"][3].numpy(), 0.5 * (lib.gts[f3].numpy() + lib.gts[f3 + 1].numpy()), atol=1e-5)
