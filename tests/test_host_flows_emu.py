@@ -1,0 +1,97 @@
+"""The Python host logic of the batched envs (smplsim_amd/batch.py, imitation.py, shapes.py) run end to end in the GPU-less
+container: the package is pointed at the CPU emulator build of the same C ABI through its unit-test hook
+(smplsim_amd._lib.use_test_backend) and works on host tensors.  The GPU twins are in test_gpu_parity.py."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import oracle_model
+from oracle import oracle as O
+
+
+@pytest.fixture()
+def emu_backend():
+    from smplsim_amd import _lib
+    from wave_emu import emu
+    _lib.use_test_backend(emu.lib())
+    yield emu.lib()
+    _lib.use_test_backend(None)
+
+
+def test_vec_env_autoreset_flows_on_the_emulator(emu_backend):
+    from smplsim_amd.batch import SMPLSimVecEnv
+    n = 5
+    fused = SMPLSimVecEnv(n, task="HumanoidSpeed", episode_length=2, seed=3)                       # in-launch Default autoreset
+    plain = SMPLSimVecEnv(n, task="HumanoidSpeed", episode_length=2, seed=3, fused_autoreset=False)  # step + masked reset
+    assert fused.device.type == "cpu" and fused._fused_autoreset and not plain._fused_autoreset
+    o1, _ = fused.reset(); o2, _ = plain.reset()
+    assert torch.equal(o1, o2)
+    oenv = O.OracleEnv(oracle_model(), task=O.TASK_SPEED, episode_length=2)
+    rs = np.random.default_rng(0)
+    for k in range(4):
+        a = torch.tensor(rs.uniform(-0.3, 0.3, (n, 69)), dtype=torch.float32)
+        tr = torch.rand(n, 4, generator=torch.Generator().manual_seed(k))
+        ob1, r1, t1, u1, i1 = fused.step(a, task_rand=tr)
+        ob2, r2, t2, u2, i2 = plain.step(a, task_rand=tr)
+        assert torch.equal(r1, r2) and torch.equal(t1, t2) and torch.equal(u1, u2)
+        assert torch.equal(i1["final_observation"], i2["final_observation"])
+        assert bool(u1.all()) == (k % 3 == 2)                   # cur_t > 2 on every third step, then the envs start over
+    assert int(fused.cur_t.max()) <= 3
+
+
+def test_imitation_env_end_to_end_on_the_emulator(emu_backend):
+    import test_motion_lib as T
+    from oracle import motion_oracle as mo
+    from smplsim_amd.imitation import SMPLSimImitationVecEnv
+    lib = T.make_lib(emu_backend)
+    n, J = 4, 24
+    env = SMPLSimImitationVecEnv(n, lib, seed=2)
+    env.offset[:, 2] = 0.05
+    ids = np.array([0, 1, 2, 0], np.int32)
+    t0 = np.array([0.1, 0.2, 0.3, 1.25], np.float32)           # env 3 starts one step before the end of its 1.3 s clip
+    obs, _ = env.reset(motion_ids=ids, start_times=t0)
+    assert obs.shape == (n, env.base.obs_size + 24 * J)
+    arr = T.lib_arrays(lib)
+    act = env.reference_actions()
+    pre_ids = env.motion_ids.clone()
+    obs, rew, term, trunc, info = env.step(act)
+    # reward / flags of the step against the oracle on the body state the step launch wrote (before the re-initialisation)
+    times = t0 + np.float32(env.dt)
+    ref = mo.motion_state(arr, ids, times.astype(np.float64), env.offset.numpy().astype(np.float64))
+    assert trunc.tolist() == [False, False, False, True] and "final_observation" in info
+    assert np.isfinite(rew.numpy()).all() and (rew.numpy() > 0).all()
+    done = (term | trunc).numpy()
+    assert (env.base.cur_t.numpy()[done] == 0).all() and (env.base.cur_t.numpy()[~done] == 1).all()
+    # finished envs were re-initialised on a (new) clip: their simulator state is that clip's state at the new start time
+    st = lib.get_motion_state(env.motion_ids, env.start_times, offset=env.offset, with_qpos=True)
+    assert np.allclose(env.base.qpos.numpy()[done], st["qpos"].numpy()[done], atol=1e-6)
+    assert torch.equal(env.motion_ids[torch.as_tensor(~done)], pre_ids[torch.as_tensor(~done)])
+    # envs that continue still hold the step's body state: their reward must be the oracle's on that state
+    xpos, bv = env.xpos.numpy().astype(np.float64), env.base.body_vel.numpy().astype(np.float64)
+    quat = mo.matrix_to_quaternion(env.xmat.numpy().astype(np.float64).reshape(n, J, 3, 3))
+    want, _ = mo.imitation_reward(xpos, quat, bv[..., :3], bv[..., 3:], ref["rg_pos"], ref["rb_rot"], ref["body_vel"], ref["body_ang_vel"])
+    assert np.abs(rew.numpy() - want)[~done].max() < 5e-5
+    # the observation handed to the policy has the self part of the base env and the task part written in place
+    assert torch.equal(obs[:, :env.self_obs_size], env.base.obs_buf) and torch.isfinite(obs).all()
+
+
+def test_per_env_shapes_through_the_python_api_on_the_emulator(emu_backend):
+    from smplsim_amd.batch import ShardModel, SMPLSimVecEnv
+    from smplsim_amd.mjcf_writer import scaled_xml_str
+    from smplsim_amd.shapes import ShapeVariedVecEnv
+    xmls = [scaled_xml_str("smpl_humanoid", 1.0), scaled_xml_str("smpl_humanoid", 0.9, {"L_Knee": 1.1})]
+    env = ShapeVariedVecEnv(xmls, [2, 1], autoreset=False, seed=0)
+    assert env.num_envs == 3 and env.shape_id.tolist() == [0, 0, 1]
+    obs, _ = env.reset()
+    solo = SMPLSimVecEnv(1, model=ShardModel(xml=xmls[1]), autoreset=False)
+    assert torch.equal(solo.reset()[0][0], obs[2]) and not torch.equal(obs[0], obs[2])
+    a = torch.zeros(3, 69)
+    o2 = env.step(a)[0]
+    assert torch.equal(solo.step(a[:1])[0][0], o2[2])
+    with pytest.raises(ValueError, match="shape_id"):
+        SMPLSimVecEnv(2, model=ShardModel(xmls=xmls), shape_id=[0, 5])
+
+
+def test_hook_is_off_by_default():
+    from smplsim_amd import _lib
+    assert _lib.test_device() is None
