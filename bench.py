@@ -223,7 +223,8 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=None, help="default 4096 (imitation: 1024 = 8192 envs on 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="smpl", choices=["smpl", "getup", "smplx", "imitation"],
-                    help="smpl = BASELINE config 2 (the metric); getup = config 3 shard (Fall init, getup task); smplx = config 4")
+                    help="smpl = BASELINE config 2 (the metric); getup = config 3 shard (Fall init, getup task); smplx = config 4; "
+                         "imitation = config 5 shard (motion clips, tracking reward)")
     args = ap.parse_args()
 
     import torch
