@@ -225,6 +225,8 @@ class OracleData:
     angvel = property(lambda s: s.get(D_ANGVEL).reshape(-1, 3))
     touch = property(lambda s: s.get(D_TOUCH))
     ncon = property(lambda s: int(s.get(D_NCON)[0]))
+    solver_iter = property(lambda s: int(s.get(D_SOLVER_ITER)[0]))
+    nwarn = property(lambda s: int(s.get(D_SOLVER_ITER)[1]))     # mj_checkPos/Vel/Acc autoresets so far
 
     def kinematics(self):
         lib().om_kinematics(self.m.h, self.h)

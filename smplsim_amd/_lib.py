@@ -61,22 +61,6 @@ def build(verbose=False, force=False):
     return LIB_PATH
 
 
-_TEST_DEVICE = None
-
-
-def use_test_backend(clib):
-    """UNIT-TEST HOOK (tests/wave_emu only): bind the CPU emulator build of the same C ABI, so that the Python host logic
-    (env wrappers, autoreset flows, imitation / shape plumbing) is exercised in the GPU-less container with host tensors.
-    Never called by the package; without it every entry point needs the HIP library and a GPU."""
-    global _LIB, _TEST_DEVICE
-    import torch
-    _LIB, _TEST_DEVICE = clib, (torch.device("cpu") if clib is not None else None)
-
-
-def test_device():
-    return _TEST_DEVICE
-
-
 def lib():
     global _LIB
     if _LIB is None:

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _cabi
-from ._lib import lib, test_device
+from ._lib import lib
 from .gains import build_pd_tables
 from .mjcf import compile_mjcf
 from .mjcf_writer import default_xml_str
@@ -27,6 +27,17 @@ def _check(rc):
 
 def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _shard_device(index):
+    """The device the shard's tensors live on: always a ROCm GPU (there is no CPU path in this package)."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("SMPLSimVecEnv needs a ROCm GPU (MI355X); there is no CPU fallback")
+    return torch.device("cuda", int(index))
+
+
+def _launch_stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 class ShardModel:
@@ -72,11 +83,10 @@ class SMPLSimVecEnv:
                  height_change=(100, 200), recovery_steps=60, tar_dist_max=1.0, reach_body="R_Hand", newton_iters=8, fused_autoreset=True,
                  autoreset=True, seed=0, lpt_order=True, shape_id=None,
                  **model_kw):
-        if test_device() is None and not torch.cuda.is_available():
-            raise RuntimeError("SMPLSimVecEnv needs a ROCm GPU (MI355X); there is no CPU fallback")
+        self.device = _shard_device(device if model is None else model.device)   # raises before any table is built without a GPU
         self.model = model if model is not None else ShardModel(device=device, control_mode=control_mode, **model_kw)
         mc = self.model.mc
-        self.num_envs, self.device = int(num_envs), (test_device() or torch.device("cuda", self.model.device))
+        self.num_envs = int(num_envs)
         self.nq, self.nv, self.nu, self.nbody = mc.nq, mc.nv, mc.nu, mc.nbody
         self.task_id = _cabi.TASKS[task] if isinstance(task, str) else int(task)
         if self.task_id == _cabi.TASK_REACH and isinstance(reach_body, str) and reach_body not in mc.body_names:
@@ -159,9 +169,7 @@ class SMPLSimVecEnv:
         return torch.rand(self.num_envs, 3, self.nu, generator=self.gen, device=self.device)
 
     def _stream(self):
-        if self.device.type != "cuda":
-            return None                                        # unit-test backend (CPU emulator): no streams
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return _launch_stream(self.device)
 
     def reset(self, mask=None, fall_actions=None, task_rand=None):
         """Reset all envs (mask None) or those with mask != 0.  Returns (obs, info)."""

@@ -19,7 +19,7 @@ struct ss_model {
   ss::HostModel hm;
   int device = 0;
   uint32_t *d_shared = nullptr;
-  float *d_bodyc = nullptr, *d_candc = nullptr;
+  ss::real *d_bodyc = nullptr, *d_candc = nullptr;
   int32_t *d_candb = nullptr;
   int num_shapes = 1;                     // ss_model_create_shapes: d_bodyc / d_candc hold num_shapes consecutive tables (ss_hdr.h)
 };
@@ -35,6 +35,8 @@ struct ss_batch {
   const int32_t *order = nullptr;         // caller-owned device array or null
   int32_t *d_sched = nullptr;             // library-owned [N] hand-out order written by ss_schedule_longest_first
   float *body_xpos = nullptr, *body_xmat = nullptr;   // caller-owned, optional: written by every step / reset (ss_set_body_outputs)
+  static ss::real *R(float *p) { return reinterpret_cast<ss::real *>(p); }               // C-ABI arrays as the kernel's scalar type
+  static const ss::real *R(const float *p) { return reinterpret_cast<const ss::real *>(p); }
   int fixed_envs_per_wg = 0, max_wgs = 0; // ss_set_launch_geometry: 0 = automatic (small batches are spread over all CUs)
 };
 
@@ -55,8 +57,8 @@ struct ss_api {
       return p;
     };
     m->d_shared = (uint32_t *)up(m->hm.shared.data(), m->hm.shared.size() * 4);
-    m->d_bodyc = (float *)up(m->hm.bodyc.data(), m->hm.bodyc.size() * 4);
-    m->d_candc = (float *)up(m->hm.candc.data(), m->hm.candc.size() * 4);
+    m->d_bodyc = (ss::real *)up(m->hm.bodyc.data(), m->hm.bodyc.size() * sizeof(ss::real));
+    m->d_candc = (ss::real *)up(m->hm.candc.data(), m->hm.candc.size() * sizeof(ss::real));
     m->d_candb = (int32_t *)up(m->hm.candb.data(), m->hm.candb.size() * 4);
     if (!m->d_shared || !m->d_bodyc || !m->d_candc || !m->d_candb) { model_destroy(m); return fail(SS_ERR_HIP, "device table upload failed"); }
     *out = m;
@@ -68,14 +70,15 @@ struct ss_api {
     if (num_shapes == 1) return model_create(d, device, out);
     ss_model *m = new (std::nothrow) ss_model();
     if (!m) return fail(SS_ERR_NOMEM, "out of host memory");
-    std::vector<float> bodyc, candc;
+    std::vector<ss::real> bodyc, candc;
     for (int s = 0; s < num_shapes; s++) {
       ss::HostModel hm;
       if (!ss::build_host_model(d[s], hm)) { std::string e = "shape " + std::to_string(s) + ": " + hm.error; delete m; return fail(SS_ERR_INVALID, e); }
       const ss::Hdr &h = hm.h;
-      std::vector<float> iw(h.nv);
-      for (int i = 0; i < h.nv; i++) { iw[i] = ss::bits2f_host(hm.shared[h.o_dofc + i * ss::kDofC + 4]); hm.shared[h.o_dofc + i * ss::kDofC + 4] = 0u; }
-      for (int i = 0; i < 3 * h.nb; i++) hm.shared[h.o_boff + i] = 0u;      // the two shape-dependent parts of the shared blob
+      std::vector<ss::real> iw(h.nv);
+      ss::real *sf = ss::shared_reals(hm);
+      for (int i = 0; i < h.nv; i++) { iw[i] = sf[h.o_dofc + i * ss::kDofC + 4]; sf[h.o_dofc + i * ss::kDofC + 4] = 0; }
+      for (int i = 0; i < 3 * h.nb; i++) sf[h.o_boff + i] = 0;              // the two shape-dependent parts of the shared blob
       if (s == 0) m->hm = hm;
       else {
         const ss::Hdr &g = m->hm.h;
@@ -87,7 +90,7 @@ struct ss_api {
         if (!same) { delete m; return fail(SS_ERR_INVALID, "shape " + std::to_string(s) + " differs from shape 0 in more than its geometry"); }
       }
       bodyc.insert(bodyc.end(), hm.bodyc.begin(), hm.bodyc.end());
-      iw.resize((h.nv + 3) & ~3, 0.f);
+      iw.resize((h.nv + 3) & ~3, ss::real(0));
       bodyc.insert(bodyc.end(), iw.begin(), iw.end());        // block = body constants, then the dof inverse weights
       candc.insert(candc.end(), hm.candc.begin(), hm.candc.end());
     }
@@ -100,8 +103,8 @@ struct ss_api {
       return p;
     };
     m->d_shared = (uint32_t *)up(m->hm.shared.data(), m->hm.shared.size() * 4);
-    m->d_bodyc = (float *)up(bodyc.data(), bodyc.size() * 4);
-    m->d_candc = (float *)up(candc.data(), candc.size() * 4);
+    m->d_bodyc = (ss::real *)up(bodyc.data(), bodyc.size() * sizeof(ss::real));
+    m->d_candc = (ss::real *)up(candc.data(), candc.size() * sizeof(ss::real));
     m->d_candb = (int32_t *)up(m->hm.candb.data(), m->hm.candb.size() * 4);
     if (!m->d_shared || !m->d_bodyc || !m->d_candc || !m->d_candb) { model_destroy(m); return fail(SS_ERR_HIP, "device table upload failed"); }
     *out = m;
@@ -133,7 +136,7 @@ struct ss_api {
     b->m = m; b->cfg = *cfg; b->st = *st;
     if (b->cfg.newton_iters <= 0) b->cfg.newton_iters = 8;
     b->obs_size = ss::obs_size(h, *cfg);
-    size_t shared_b = (size_t)((h.shared_words + 3) & ~3) * 4, env_b = (size_t)h.env_floats * 4;
+    size_t shared_b = (size_t)((h.shared_words + 3) & ~3) * 4, env_b = (size_t)h.env_floats * sizeof(ss::real);
     int cap = BE::lds_capacity();
     int e = (int)((cap - (long)shared_b) / (long)env_b);
     if (e < 1) { delete b; return fail(SS_ERR_LDS, "model does not fit in LDS"); }
@@ -145,6 +148,7 @@ struct ss_api {
     b->d_prof = (unsigned long long *)BE::alloc(64 * sizeof(unsigned long long));
     if (b->d_prof) { unsigned long long z[64] = {0}; BE::upload(b->d_prof, z, sizeof z); }
 #endif
+    if (!BE::set_device(m->device)) { delete b; return fail(SS_ERR_HIP, "cannot select device"); }   // the counter must live on the batch's GPU
     b->d_counter = (int32_t *)BE::alloc(sizeof(int32_t));
     if (!b->d_counter) { delete b; return fail(SS_ERR_NOMEM, "device allocation failed"); }
     *out = b;
@@ -160,7 +164,7 @@ struct ss_api {
     k.work_counter = b->d_counter;
     k.prof = b->d_prof;
     k.order = b->order;
-    if (mode == ss::MODE_STEP || mode == ss::MODE_RESET) { k.out0 = b->body_xpos; k.out1 = b->body_xmat; }
+    if (mode == ss::MODE_STEP || mode == ss::MODE_RESET) { k.out0 = ss_batch::R(b->body_xpos); k.out1 = ss_batch::R(b->body_xmat); }
     return k;
   }
   static int run(const ss_batch *b, const ss::KArgs &k, void *stream) {
@@ -173,14 +177,15 @@ struct ss_api {
     if (!b || !obs) return fail(SS_ERR_INVALID, "null argument");
     if (b->cfg.state_init == SS_INIT_FALL && !fall_actions) return fail(SS_ERR_INVALID, "StateInit.Fall needs fall_actions");
     ss::KArgs k = base_args(b, ss::MODE_RESET);
-    k.mask = mask; k.fall_actions = fall_actions; k.task_rand = task_rand; k.obs = obs;
+    k.mask = mask; k.fall_actions = ss_batch::R(fall_actions); k.task_rand = ss_batch::R(task_rand); k.obs = ss_batch::R(obs);
     return run(b, k, stream);
   }
   static int step(ss_batch *b, const float *actions, const float *task_rand, float *obs, float *reward, uint8_t *term,
                   uint8_t *trunc, void *stream) {
     if (!b || !actions || !obs || !reward || !term || !trunc) return fail(SS_ERR_INVALID, "null argument");
     ss::KArgs k = base_args(b, ss::MODE_STEP);
-    k.actions = actions; k.task_rand = task_rand; k.obs = obs; k.reward = reward; k.terminated = term; k.truncated = trunc;
+    k.actions = ss_batch::R(actions); k.task_rand = ss_batch::R(task_rand); k.obs = ss_batch::R(obs); k.reward = ss_batch::R(reward);
+    k.terminated = term; k.truncated = trunc;
     return run(b, k, stream);
   }
   static int step_autoreset(ss_batch *b, const float *actions, const float *task_rand, const float *reset_task_rand, float *obs,
@@ -189,26 +194,27 @@ struct ss_api {
     if (b->cfg.state_init != SS_INIT_DEFAULT)
       return fail(SS_ERR_INVALID, "in-launch autoreset is for StateInit.Default; use ss_step + a masked ss_reset for Fall");
     ss::KArgs k = base_args(b, ss::MODE_STEP);
-    k.actions = actions; k.task_rand = task_rand; k.obs = obs; k.reward = reward; k.terminated = term; k.truncated = trunc;
-    k.fused_reset = 1; k.obs2 = obs_next; k.task_rand2 = reset_task_rand;
+    k.actions = ss_batch::R(actions); k.task_rand = ss_batch::R(task_rand); k.obs = ss_batch::R(obs); k.reward = ss_batch::R(reward);
+    k.terminated = term; k.truncated = trunc;
+    k.fused_reset = 1; k.obs2 = ss_batch::R(obs_next); k.task_rand2 = ss_batch::R(reset_task_rand);
     return run(b, k, stream);
   }
   static int substep(ss_batch *b, const float *actions, int n, void *stream) {
     if (!b || !actions || n < 1) return fail(SS_ERR_INVALID, "bad argument");
     ss::KArgs k = base_args(b, ss::MODE_SUBSTEP);
-    k.actions = actions; k.nsub = n;
+    k.actions = ss_batch::R(actions); k.nsub = n;
     return run(b, k, stream);
   }
   static int kinematics(ss_batch *b, float *xpos, float *xmat, void *stream) {
     if (!b || !xpos || !xmat) return fail(SS_ERR_INVALID, "null argument");
     ss::KArgs k = base_args(b, ss::MODE_KINEMATICS);
-    k.out0 = xpos; k.out1 = xmat;
+    k.out0 = ss_batch::R(xpos); k.out1 = ss_batch::R(xmat);
     return run(b, k, stream);
   }
   static int debug_forward(ss_batch *b, const float *torques, float *M, float *bias, float *qacc, void *stream) {
     if (!b || !M || !bias || !qacc) return fail(SS_ERR_INVALID, "null argument");
     ss::KArgs k = base_args(b, ss::MODE_DEBUG_FORWARD);
-    k.actions = torques; k.out0 = M; k.out1 = bias; k.out2 = qacc;
+    k.actions = ss_batch::R(torques); k.out0 = ss_batch::R(M); k.out1 = ss_batch::R(bias); k.out2 = ss_batch::R(qacc);
     return run(b, k, stream);
   }
 };
@@ -245,6 +251,7 @@ struct ss_api {
   }                                                                                                                  \
   int ss_schedule_longest_first(ss_batch *b, void *stream) {                                                        \
     if (!b) return ss_api<BE>::fail(SS_ERR_INVALID, "null batch");                                                  \
+    if (!BE::set_device(b->m->device)) return ss_api<BE>::fail(SS_ERR_HIP, "cannot select device");                  \
     if (!b->d_sched) b->d_sched = (int32_t *)BE::alloc(sizeof(int32_t) * (size_t)b->st.num_envs);                      \
     if (!b->d_sched) return ss_api<BE>::fail(SS_ERR_NOMEM, "device allocation failed");                              \
     const char *err = BE::order_by_iters(b->st.solver_iters, b->d_sched, b->st.num_envs, stream);                     \

@@ -46,6 +46,7 @@
 #define SS_LS_TOL 1e-2f
 #endif
 
+
 namespace ss {
 
 enum { PF_FWD = 0, PF_CONS, PF_NBEGIN, PF_NPREP, PF_ASM, PF_FACTOR, PF_SOLVE, PF_NFIN, PF_SPDPREP, PF_SPDFIN, PF_INTEG, PF_MISC,
@@ -59,57 +60,65 @@ enum { PF_FWD = 0, PF_CONS, PF_NBEGIN, PF_NPREP, PF_ASM, PF_FACTOR, PF_SOLVE, PF
 #define SS_FTICK(id) do {} while (0)
 #endif
 
-struct alignas(16) float4_t { float x, y, z, w; };
+struct alignas(16) float4_t { real x, y, z, w; };   // 4 reals: one 16-byte LDS access in the product (float) build
 
 struct Contact {
-  float rx, ry, rz;      // contact point relative to the root origin
-  float t1x, t1y;        // first tangent (unit, in the floor plane); second = (-t1y, t1x)
-  float D;               // 1/R of the 4 pyramid rows
-  float aref[4], jar[4], jd[4];
+  real rx, ry, rz;      // contact point relative to the root origin
+  real t1x, t1y;        // first tangent (unit, in the floor plane); second = (-t1y, t1x)
+  real D;               // 1/R of the 4 pyramid rows
+  real aref[4], jar[4], jd[4];
   int body, active;
 };
-struct Limit { float sign, D, aref, jar, jd; };
+struct Limit { real sign, D, aref, jar, jd; };
 
-SS_DEV float bits2f(uint32_t u) { union { uint32_t u; float f; } c; c.u = u; return c.f; }
-SS_DEV float4_t ld4(const float *p) { return *reinterpret_cast<const float4_t *>(p); }      // 16-byte aligned LDS row
+// caller-owned HBM arrays are declared float* in the C ABI (include/smplsim_hip.h); the kernel reads them as `real`
+// (identity in the product build; the float64 triage build of tests/wave_emu is handed double arrays)
+SS_DEV real *gptr(float *p) { return reinterpret_cast<real *>(p); }
+SS_DEV const real *gptr(const float *p) { return reinterpret_cast<const real *>(p); }
+SS_DEV float4_t ld4(const real *p) { return *reinterpret_cast<const float4_t *>(p); }      // 16-byte aligned LDS row
 // sin and cos of an angle of at most a few hundred radians (joint angles, half rotation angles): Cody-Waite reduction
 // by pi/2 and the single-precision minimax polynomials on [-pi/4, pi/4] (abs. error ~1e-7).  libm's sincosf carries a
 // Payne-Hanek path for huge arguments (private scratch array, ~600 instructions per inlined call site).
-SS_DEV void sincos_small(float x, float *sn, float *cs) {
-  const float kf = rintf(x * 0.636619772367581343f);
+SS_DEV void sincos_small(real x, real *sn, real *cs) {
+#ifdef SS_F64
+  *sn = sin(x); *cs = cos(x);
+  return;
+#endif
+  const real kf = SS_M(rint)(x * 0.636619772367581343f);
   const int ki = (int)kf;
-  float r = fmaf(-kf, 1.5707962512969971f, x);
-  r = fmaf(-kf, 7.5497894158615964e-08f, r);
-  const float z = r * r;
-  const float sp = r + r * z * (-1.6666654611e-1f + z * (8.3321608736e-3f + z * -1.9515295891e-4f));
-  const float cp = 1.0f - 0.5f * z + z * z * (4.166664568298827e-2f + z * (-1.388731625493765e-3f + z * 2.443315711809948e-5f));
-  const float a = (ki & 1) ? cp : sp, b = (ki & 1) ? sp : cp;
+  real r = SS_M(fma)(-kf, 1.5707962512969971f, x);
+  r = SS_M(fma)(-kf, 7.5497894158615964e-08f, r);
+  const real z = r * r;
+  const real sp = r + r * z * (-1.6666654611e-1f + z * (8.3321608736e-3f + z * -1.9515295891e-4f));
+  const real cp = 1.0f - 0.5f * z + z * z * (4.166664568298827e-2f + z * (-1.388731625493765e-3f + z * 2.443315711809948e-5f));
+  const real a = (ki & 1) ? cp : sp, b = (ki & 1) ? sp : cp;
   *sn = (ki & 2) ? -a : a;
   *cs = ((ki + 1) & 2) ? -b : b;
 }
-SS_DEV bool is_bad(float x) { return !(x <= 1e10f && x >= -1e10f); }
+SS_DEV bool is_bad(real x) { return !(x <= real(1e10) && x >= -real(1e10)); }
 
 // SHAPED: per-env body shapes — the geometry-dependent constants (body table, contact candidates, dof inverse weights) are
 // indexed by the env's shape id, and the body offsets of the kinematic chain walk come from the env's own body table (staged
 // through the env's LDS slice) instead of the workgroup's shared table.  A separate instantiation: the single-shape code
 // is textually what it was.
 template <bool SHAPED> struct ShapeTables {};
-template <> struct ShapeTables<true> { const float *bodyc_s, *candc_s, *dinvw_s; };   // this env's tables
+template <> struct ShapeTables<true> { const real *bodyc_s, *candc_s, *dinvw_s; };   // this env's tables
 
 template <class W, int DOFP, int CANDP, int SLOTP, int NPASS, bool SHAPED = false>
 struct Sim : ShapeTables<SHAPED> {
   W *w;
   const KArgs *k;
-  const uint32_t *T;      // shared tables in LDS
+  const uint32_t *T;      // shared tables in LDS: integer part
+  const real *Tf;         // ... and real-valued part (dof constants, body offsets), behind the integers
   int lane, env;
   // per-env LDS arrays
-  float *S, *R, *r, *V, *Ab, *An, *Ad, *Gb, *tmpb, *Aown, *IA, *Ubuf, *Wst, *q, *v, *a, *tau, *Pb, *delta, *C, *diag, *Iown;
+  real *S, *R, *r, *V, *Ab, *An, *Ad, *Gb, *tmpb, *Aown, *IA, *Ubuf, *Wst, *q, *v, *a, *tau, *Pb, *delta, *C, *diag, *Iown;
   // per-lane constants
   int bpar, bdep;
   // per-lane state
   Contact con[SLOTP];
   Limit lim[DOFP];
-  float perr[DOFP];
+  real perr[DOFP];
   int iters, nwarn_add, pid_on;
   int slot_body[SLOTP];    // body of this lane's contact slot(s): constant for the launch, read once from HBM
 #ifdef SS_PROFILE
@@ -118,18 +127,19 @@ struct Sim : ShapeTables<SHAPED> {
   unsigned long long touchmask;
 
   SS_DEV int ti(int off, int i) const { return (int)T[off + i]; }
-  SS_DEV float tf(int off, int i) const { return bits2f(T[off + i]); }
-  SS_DEV float dc(int dof, int f) const { return tf(k->h.o_dofc, dof * kDofC + f); }
-  SS_DEV const float *bodyc() const { if constexpr (SHAPED) return this->bodyc_s; else return k->bodyc; }
-  SS_DEV const float *candc() const { if constexpr (SHAPED) return this->candc_s; else return k->candc; }
-  SS_DEV float dof_invweight(int dof) const { if constexpr (SHAPED) return this->dinvw_s[dof]; else return dc(dof, 4); }
+  SS_DEV real tf(int off, int i) const { return Tf[off + i]; }
+  SS_DEV real dc(int dof, int f) const { return tf(k->h.o_dofc, dof * kDofC + f); }
+  SS_DEV const real *bodyc() const { if constexpr (SHAPED) return this->bodyc_s; else return k->bodyc; }
+  SS_DEV const real *candc() const { if constexpr (SHAPED) return this->candc_s; else return k->candc; }
+  SS_DEV real dof_invweight(int dof) const { if constexpr (SHAPED) return this->dinvw_s[dof]; else return dc(dof, 4); }
   // body of a contact slot: box b owns slots 4b'..4b'+3 (b' = box order), capsule ends follow
   SS_DEV int h_box_body(int sl) const { return k->candb[8 * (sl >> 2)] & 255; }
   SS_DEV int h_caps_body(int sl) const { int e = sl - 4 * k->h.nbox; int ci = 8 * k->h.nbox + e; return ci < k->h.ncand ? (k->candb[ci] & 255) : 0; }
 
-  SS_DEV void init(W *w_, const KArgs *k_, const uint32_t *T_, float *L, int env_) {
+  SS_DEV void init(W *w_, const KArgs *k_, const uint32_t *T_, real *L, int env_) {
     w = w_; k = k_; T = T_; lane = w->lane(); env = env_;
     const Hdr &h = k->h;
+    Tf = reinterpret_cast<const real *>(T_ + h.o_real);
     if constexpr (SHAPED) {
       const size_t sid = (size_t)k->st.shape_id[env];
       this->bodyc_s = k->bodyc + sid * shape_stride(h); this->candc_s = k->candc + sid * h.ncand * kCandC;
@@ -171,8 +181,8 @@ struct Sim : ShapeTables<SHAPED> {
   }
 
   // ------------------------------------------------------------------ HBM <-> LDS
-  SS_DEV void load(float *dst, const float *src, int n) { for (int i = lane; i < n; i += 64) dst[i] = src[i]; }
-  SS_DEV void store(float *dst, const float *src, int n) { for (int i = lane; i < n; i += 64) dst[i] = src[i]; }
+  SS_DEV void load(real *dst, const real *src, int n) { for (int i = lane; i < n; i += 64) dst[i] = src[i]; }
+  SS_DEV void store(real *dst, const real *src, int n) { for (int i = lane; i < n; i += 64) dst[i] = src[i]; }
 
   // ------------------------------------------------------------------ tree helpers
   // out[b][c] = sum of in[d][c] over the subtree of b = the contiguous index range [b, b + size_b) (depth-first
@@ -183,12 +193,12 @@ struct Sim : ShapeTables<SHAPED> {
   // full LDS round trip per element and sat on every Newton iteration's critical path (profiles/r01r_*).
   // Must be called between hand-offs; it contains one.
   template <int NC>
-  SS_DEV void subtree_sum(const float *in, float *out) {
+  SS_DEV void subtree_sum(const real *in, real *out) {
     const Hdr &h = k->h;
     for (int idx = lane; idx < NC * h.n_sumsmall; idx += 64) {
       const int o = idx / NC, c = idx - o * NC, e = ti(h.o_sumsmall, o), b = e & 255, n = e >> 8;
-      const float *p = in + b * NC + c;
-      float part[8];
+      const real *p = in + b * NC + c;
+      real part[8];
 #pragma unroll
       for (int u = 0; u < 8; u++) part[u] = p[(u < n ? u : 0) * NC];
 #pragma unroll
@@ -199,9 +209,9 @@ struct Sim : ShapeTables<SHAPED> {
     w->sync();
     for (int idx = lane; idx < NC * h.n_sumbig; idx += 64) {
       const int o = idx / NC, c = idx - o * NC, e = ti(h.o_sumbig, o), b = e & 255, start = (e >> 8) & 4095, cnt = e >> 20;
-      float acc = 0.f;
+      real acc = 0.f;
       for (int j = 0; j < cnt; j += 4) {
-        float part[4];
+        real part[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
           const int t = ti(h.o_sumcover, start + (j + u < cnt ? j + u : j));
@@ -218,7 +228,7 @@ struct Sim : ShapeTables<SHAPED> {
   // A[b] = sum over the dofs d on the chain of body b of S[d] * x[d]   (spatial accel without bias).
   // Two stages: per-node contributions c_n = S[3n..3n+2] x[3n..3n+2] (into `tmp`, 6 floats per node),
   // then each (body, component) adds the <= depth+1 node contributions along its chain.
-  SS_DEV void body_accel(const float *x, float *A, float *tmp) {
+  SS_DEV void body_accel(const real *x, real *A, real *tmp) {
     const Hdr &h = k->h;
     for (int idx = lane; idx < 6 * h.nn; idx += 64) {
       int n = idx / 6, c = idx - 6 * n, d = 3 * n;
@@ -229,19 +239,19 @@ struct Sim : ShapeTables<SHAPED> {
   }
   // A[b] = sum of the node contributions tmp[n] (6 floats each) over the chain root .. node(b); optionally a second
   // (tmp2 -> A2) pair in the same pass over the chain table
-  SS_DEV void chain_sum(const float *tmp, float *A, const float *tmp2 = nullptr, float *A2 = nullptr) {
+  SS_DEV void chain_sum(const real *tmp, real *A, const real *tmp2 = nullptr, real *A2 = nullptr) {
     const Hdr &h = k->h;
     for (int idx = lane; idx < 6 * h.nb; idx += 64) {
       int b = idx / 6, c = idx - 6 * b, n = b + 1;
       const int dn = ti(h.o_ndepth, n), row = h.o_chainnode + n * h.nlev;
-      float s = 0.f, s2 = 0.f;
+      real s = 0.f, s2 = 0.f;
       for (int kk = 0; kk <= dn; kk += 4) {                  // 4 independent (table, data) read pairs per trip
         const int k1 = kk + 1 <= dn ? kk + 1 : kk, k2 = kk + 2 <= dn ? kk + 2 : kk, k3 = kk + 3 <= dn ? kk + 3 : kk;
         const int n0 = ti(row, kk), n1 = ti(row, k1), n2 = ti(row, k2), n3 = ti(row, k3);
-        const float a0 = tmp[6 * n0 + c], a1 = tmp[6 * n1 + c], a2 = tmp[6 * n2 + c], a3 = tmp[6 * n3 + c];
+        const real a0 = tmp[6 * n0 + c], a1 = tmp[6 * n1 + c], a2 = tmp[6 * n2 + c], a3 = tmp[6 * n3 + c];
         s += (a0 + (kk + 1 <= dn ? a1 : 0.f)) + ((kk + 2 <= dn ? a2 : 0.f) + (kk + 3 <= dn ? a3 : 0.f));
         if (tmp2) {
-          const float e0 = tmp2[6 * n0 + c], e1 = tmp2[6 * n1 + c], e2 = tmp2[6 * n2 + c], e3 = tmp2[6 * n3 + c];
+          const real e0 = tmp2[6 * n0 + c], e1 = tmp2[6 * n1 + c], e2 = tmp2[6 * n2 + c], e3 = tmp2[6 * n3 + c];
           s2 += (e0 + (kk + 1 <= dn ? e1 : 0.f)) + ((kk + 2 <= dn ? e2 : 0.f) + (kk + 3 <= dn ? e3 : 0.f));
         }
       }
@@ -256,9 +266,9 @@ struct Sim : ShapeTables<SHAPED> {
     fresh();
     const Hdr &h = k->h;
     SS_FT0();
-    float vb[6] = {0, 0, 0, 0, 0, 0}, ab[6] = {0, 0, 0, 0, 0, 0};
-    float Rb[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, rb[3] = {0, 0, 0};
-    float bc[kBodyC];                                       // this lane's body constants (L1/L2-resident table)
+    real vb[6] = {0, 0, 0, 0, 0, 0}, ab[6] = {0, 0, 0, 0, 0, 0};
+    real Rb[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, rb[3] = {0, 0, 0};
+    real bc[kBodyC];                                       // this lane's body constants (L1/L2-resident table)
     {
       const float4_t *src = reinterpret_cast<const float4_t *>(bodyc() + (lane < h.nb ? lane : 0) * kBodyC);
       const float4_t b0 = src[0], b1 = src[1], b2 = src[2], b3 = src[3];
@@ -266,9 +276,9 @@ struct Sim : ShapeTables<SHAPED> {
       bc[8] = b2.x; bc[9] = b2.y; bc[10] = b2.z; bc[11] = b2.w; bc[12] = b3.x; bc[13] = b3.y; bc[14] = b3.z; bc[15] = b3.w;
     }
     if (lane == 0) {
-      float qw = q[3], qx = q[4], qy = q[5], qz = q[6];
-      float n = sqrtf(qw * qw + qx * qx + qy * qy + qz * qz);
-      if (n < 1e-15f) { qw = 1; qx = qy = qz = 0; } else { float in = 1.f / n; qw *= in; qx *= in; qy *= in; qz *= in; }
+      real qw = q[3], qx = q[4], qy = q[5], qz = q[6];
+      real n = SS_M(sqrt)(qw * qw + qx * qx + qy * qy + qz * qz);
+      if (n < real(1e-15)) { qw = 1; qx = qy = qz = 0; } else { real in = 1.f / n; qw *= in; qx *= in; qy *= in; qz *= in; }
       Rb[0] = 1 - 2 * (qy * qy + qz * qz); Rb[1] = 2 * (qx * qy - qw * qz); Rb[2] = 2 * (qx * qz + qw * qy);
       Rb[3] = 2 * (qx * qy + qw * qz); Rb[4] = 1 - 2 * (qx * qx + qz * qz); Rb[5] = 2 * (qy * qz - qw * qx);
       Rb[6] = 2 * (qx * qz - qw * qy); Rb[7] = 2 * (qy * qz + qw * qx); Rb[8] = 1 - 2 * (qx * qx + qy * qy);
@@ -282,9 +292,9 @@ struct Sim : ShapeTables<SHAPED> {
       for (int d = 0; d < 3; d++) { S[6 * (3 + d) + 0] = Rb[d]; S[6 * (3 + d) + 1] = Rb[3 + d]; S[6 * (3 + d) + 2] = Rb[6 + d]; }
     }
     // local rotation Rl = Rx Ry Rz and the hinge axes in the parent frame, once per body (not per level)
-    float Rl[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, ayl[3] = {0, 1, 0}, azl[3] = {0, 0, 1};
+    real Rl[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, ayl[3] = {0, 1, 0}, azl[3] = {0, 0, 1};
     if (lane >= 1 && lane < h.nb) {
-      float sx, cx, sy, cy, sz, cz;
+      real sx, cx, sy, cy, sz, cz;
       sincos_small(q[3 * lane + 4], &sx, &cx); sincos_small(q[3 * lane + 5], &sy, &cy); sincos_small(q[3 * lane + 6], &sz, &cz);
       // Rx Ry = [[cy,0,sy],[sx sy,cx,-sx cy],[-cx sy,sx,cx cy]] ; times Rz
       Rl[0] = cy * cz;                 Rl[1] = -cy * sz;                Rl[2] = sy;
@@ -296,7 +306,7 @@ struct Sim : ShapeTables<SHAPED> {
     // The local rotations go through LDS (level-buffer region, free here) and every body walks its own chain of
     // ancestors from the root: redundant arithmetic across lanes is free, a level-by-level sweep costs one LDS
     // hand-off per tree level on every pass.
-    float *Rloc = IA;
+    real *Rloc = IA;
     if (lane >= 1 && lane < h.nb) {
 #pragma unroll
       for (int i = 0; i < 9; i++) Rloc[9 * lane + i] = Rl[i];
@@ -306,16 +316,16 @@ struct Sim : ShapeTables<SHAPED> {
     SS_FTICK(PF_K_PRO);
     if (lane >= 1 && lane < h.nb) {
       const int n = lane + 1, dn = ti(h.o_ndepth, n), row = h.o_chainnode + n * h.nlev;
-      float Rw[9], Rp[9];
+      real Rw[9], Rp[9];
 #pragma unroll
       for (int i = 0; i < 9; i++) { Rw[i] = R[i]; Rp[i] = Rw[i]; }
       rb[0] = rb[1] = rb[2] = 0.f;
       for (int kq = 2; kq <= dn; kq++) {                      // bodies on the chain below the root, ending with this one
         const int a_ = ti(row, kq) - 1;
-        float o0, o1, o2;
-        if constexpr (SHAPED) { const float *bo = Rloc + 9 * h.nb + 3 * a_; o0 = bo[0]; o1 = bo[1]; o2 = bo[2]; }
+        real o0, o1, o2;
+        if constexpr (SHAPED) { const real *bo = Rloc + 9 * h.nb + 3 * a_; o0 = bo[0]; o1 = bo[1]; o2 = bo[2]; }
         else { o0 = tf(h.o_boff, 3 * a_); o1 = tf(h.o_boff, 3 * a_ + 1); o2 = tf(h.o_boff, 3 * a_ + 2); }
-        float La[9];
+        real La[9];
 #pragma unroll
         for (int i = 0; i < 9; i++) La[i] = Rloc[9 * a_ + i];
 #pragma unroll
@@ -324,7 +334,7 @@ struct Sim : ShapeTables<SHAPED> {
         for (int i = 0; i < 9; i++) Rp[i] = Rw[i];
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-          const float p0 = Rp[3 * i], p1 = Rp[3 * i + 1], p2 = Rp[3 * i + 2];
+          const real p0 = Rp[3 * i], p1 = Rp[3 * i + 1], p2 = Rp[3 * i + 2];
           Rw[3 * i] = p0 * La[0] + p1 * La[3] + p2 * La[6];
           Rw[3 * i + 1] = p0 * La[1] + p1 * La[4] + p2 * La[7];
           Rw[3 * i + 2] = p0 * La[2] + p1 * La[5] + p2 * La[8];
@@ -332,10 +342,10 @@ struct Sim : ShapeTables<SHAPED> {
       }
 #pragma unroll
       for (int i = 0; i < 9; i++) Rb[i] = Rw[i];
-      float sd[3][6];
+      real sd[3][6];
 #pragma unroll
       for (int i = 0; i < 3; i++) {
-        const float p0 = Rp[3 * i], p1 = Rp[3 * i + 1], p2 = Rp[3 * i + 2];
+        const real p0 = Rp[3 * i], p1 = Rp[3 * i + 1], p2 = Rp[3 * i + 2];
         sd[0][i] = p0;                                             // world axes of the x, y, z hinges
         sd[1][i] = p1 * ayl[1] + p2 * ayl[2];
         sd[2][i] = p0 * azl[0] + p1 * azl[1] + p2 * azl[2];
@@ -353,9 +363,9 @@ struct Sim : ShapeTables<SHAPED> {
         for (int c = 0; c < 6; c++) S[6 * (3 * n + j) + c] = sd[j][c];
       }
       if (with_dyn) {                                          // this node's terms of the body velocities S_n qd_n and of the
-        const float q0 = v[3 * n], q1 = v[3 * n + 1], q2 = v[3 * n + 2];      // body accelerations of the warm start S_n a_n
-        const float g0 = a[3 * n], g1 = a[3 * n + 1], g2 = a[3 * n + 2];
-        float *w2 = Wst + 12 * h.nb;                           // free part of the (W, y) region behind R, r
+        const real q0 = v[3 * n], q1 = v[3 * n + 1], q2 = v[3 * n + 2];      // body accelerations of the warm start S_n a_n
+        const real g0 = a[3 * n], g1 = a[3 * n + 1], g2 = a[3 * n + 2];
+        real *w2 = Wst + 12 * h.nb;                           // free part of the (W, y) region behind R, r
 #pragma unroll
         for (int c = 0; c < 6; c++) {
           Ad[6 * n + c] = sd[0][c] * q0 + sd[1][c] * q1 + sd[2][c] * q2;
@@ -363,14 +373,14 @@ struct Sim : ShapeTables<SHAPED> {
         }
       }
     } else if (lane == 0 && with_dyn) {                        // root: translation node (0 ; v_lin), rotation node (R w_local ; 0)
-      const float wl0 = v[3], wl1 = v[4], wl2 = v[5];
+      const real wl0 = v[3], wl1 = v[4], wl2 = v[5];
       Ad[0] = Ad[1] = Ad[2] = 0.f; Ad[3] = v[0]; Ad[4] = v[1]; Ad[5] = v[2];
       Ad[6] = Rb[0] * wl0 + Rb[1] * wl1 + Rb[2] * wl2;
       Ad[7] = Rb[3] * wl0 + Rb[4] * wl1 + Rb[5] * wl2;
       Ad[8] = Rb[6] * wl0 + Rb[7] * wl1 + Rb[8] * wl2;
       Ad[9] = Ad[10] = Ad[11] = 0.f;
-      float *w2 = Wst + 12 * h.nb;
-      const float g0 = a[3], g1 = a[4], g2 = a[5];
+      real *w2 = Wst + 12 * h.nb;
+      const real g0 = a[3], g1 = a[4], g2 = a[5];
       w2[0] = w2[1] = w2[2] = 0.f; w2[3] = a[0]; w2[4] = a[1]; w2[5] = a[2];
       w2[6] = Rb[0] * g0 + Rb[1] * g1 + Rb[2] * g2;
       w2[7] = Rb[3] * g0 + Rb[4] * g1 + Rb[5] * g2;
@@ -386,20 +396,20 @@ struct Sim : ShapeTables<SHAPED> {
     w->sync();
     if (lane < h.nn) {
       const int n = lane;
-      float d[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      real d[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       if (n == 1) {                                          // free joint: (0 ; u x w)
         d[3] = V[4] * V[2] - V[5] * V[1];
         d[4] = V[5] * V[0] - V[3] * V[2];
         d[5] = V[3] * V[1] - V[4] * V[0];
       } else if (n >= 2) {
-        const float *vp = V + 6 * ti(h.o_bparent, n - 1);
-        float u[6];
+        const real *vp = V + 6 * ti(h.o_bparent, n - 1);
+        real u[6];
 #pragma unroll
         for (int c = 0; c < 6; c++) u[c] = vp[c];
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-          const float qd = v[3 * n + j];
-          float sj[6];
+          const real qd = v[3 * n + j];
+          real sj[6];
 #pragma unroll
           for (int c = 0; c < 6; c++) sj[c] = S[6 * (3 * n + j) + c];
           // (w;u) x_m (sw;su) = (w x sw ; w x su + u x sw)
@@ -424,29 +434,29 @@ struct Sim : ShapeTables<SHAPED> {
     // ---- body spatial inertia about the root origin (world axes), bias force, sensor velocities
     if (lane < h.nb) {
       const int b = lane;
-      float cx_ = rb[0] + Rb[0] * bc[3] + Rb[1] * bc[4] + Rb[2] * bc[5];
-      float cy_ = rb[1] + Rb[3] * bc[3] + Rb[4] * bc[4] + Rb[5] * bc[5];
-      float cz_ = rb[2] + Rb[6] * bc[3] + Rb[7] * bc[4] + Rb[8] * bc[5];
-      float m = bc[6];
+      real cx_ = rb[0] + Rb[0] * bc[3] + Rb[1] * bc[4] + Rb[2] * bc[5];
+      real cy_ = rb[1] + Rb[3] * bc[3] + Rb[4] * bc[4] + Rb[5] * bc[5];
+      real cz_ = rb[2] + Rb[6] * bc[3] + Rb[7] * bc[4] + Rb[8] * bc[5];
+      real m = bc[6];
       // Ibar = Rb Ibody Rb^T
-      float Bm[9] = {bc[7], bc[8], bc[9], bc[8], bc[10], bc[11], bc[9], bc[11], bc[12]};
-      float RB[9];
+      real Bm[9] = {bc[7], bc[8], bc[9], bc[8], bc[10], bc[11], bc[9], bc[11], bc[12]};
+      real RB[9];
 #pragma unroll
       for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
         RB[3 * i + j] = Rb[3 * i] * Bm[j] + Rb[3 * i + 1] * Bm[3 + j] + Rb[3 * i + 2] * Bm[6 + j];
-      float Ixx = RB[0] * Rb[0] + RB[1] * Rb[1] + RB[2] * Rb[2];
-      float Ixy = RB[0] * Rb[3] + RB[1] * Rb[4] + RB[2] * Rb[5];
-      float Ixz = RB[0] * Rb[6] + RB[1] * Rb[7] + RB[2] * Rb[8];
-      float Iyy = RB[3] * Rb[3] + RB[4] * Rb[4] + RB[5] * Rb[5];
-      float Iyz = RB[3] * Rb[6] + RB[4] * Rb[7] + RB[5] * Rb[8];
-      float Izz = RB[6] * Rb[6] + RB[7] * Rb[7] + RB[8] * Rb[8];
-      float Ib[10];
+      real Ixx = RB[0] * Rb[0] + RB[1] * Rb[1] + RB[2] * Rb[2];
+      real Ixy = RB[0] * Rb[3] + RB[1] * Rb[4] + RB[2] * Rb[5];
+      real Ixz = RB[0] * Rb[6] + RB[1] * Rb[7] + RB[2] * Rb[8];
+      real Iyy = RB[3] * Rb[3] + RB[4] * Rb[4] + RB[5] * Rb[5];
+      real Iyz = RB[3] * Rb[6] + RB[4] * Rb[7] + RB[5] * Rb[8];
+      real Izz = RB[6] * Rb[6] + RB[7] * Rb[7] + RB[8] * Rb[8];
+      real Ib[10];
       Ib[0] = m; Ib[1] = m * cx_; Ib[2] = m * cy_; Ib[3] = m * cz_;
       Ib[4] = Ixx + m * (cy_ * cy_ + cz_ * cz_); Ib[5] = Ixy - m * cx_ * cy_; Ib[6] = Ixz - m * cx_ * cz_;
       Ib[7] = Iyy + m * (cx_ * cx_ + cz_ * cz_); Ib[8] = Iyz - m * cy_ * cz_; Ib[9] = Izz + m * (cx_ * cx_ + cy_ * cy_);
       // f = I (a - a_grav) + v x* (I v)
-      float ag[6] = {ab[0], ab[1], ab[2], ab[3], ab[4], ab[5] - h.grav};
-      float Ia[6], Iv[6], fb[6];
+      real ag[6] = {ab[0], ab[1], ab[2], ab[3], ab[4], ab[5] - h.grav};
+      real Ia[6], Iv[6], fb[6];
       imul(Ib, ag, Ia); imul(Ib, vb, Iv);
 #pragma unroll
       for (int i = 0; i < 10; i++) Iown[10 * b + i] = Ib[i];   // the body's own inertia stays in LDS for the solves of this pass
@@ -460,7 +470,7 @@ struct Sim : ShapeTables<SHAPED> {
       for (int c = 0; c < 6; c++) Ad[6 * b + c] = fb[c];     // Ad (bias-accel scratch of the sweep) is free again
       // framelinvel / frameangvel of the body frame origin (the env reads the LAST forward's values)
       if (write_sensors) {
-        float *svo = k->st.body_vel + ((size_t)env * h.nb + b) * 6;
+        real *svo = gptr(k->st.body_vel) + ((size_t)env * h.nb + b) * 6;
         svo[0] = vb[3] + vb[1] * rb[2] - vb[2] * rb[1];
         svo[1] = vb[4] + vb[2] * rb[0] - vb[0] * rb[2];
         svo[2] = vb[5] + vb[0] * rb[1] - vb[1] * rb[0];
@@ -477,7 +487,7 @@ struct Sim : ShapeTables<SHAPED> {
       int i = p * 64 + lane;
       if (i < h.nv) {
         int n = i / 3, b = n > 0 ? n - 1 : 0;
-        float s = 0.f;
+        real s = 0.f;
 #pragma unroll
         for (int c = 0; c < 6; c++) s += S[6 * i + c] * Gb[6 * b + c];
         C[i] = s;
@@ -488,8 +498,8 @@ struct Sim : ShapeTables<SHAPED> {
   }
 
   // spatial inertia (10 params, about the origin) times motion vector (w;u) -> force (n;f)
-  SS_DEV static void imul(const float *I, const float *x, float *y) {
-    float m = I[0], cx = I[1], cy = I[2], cz = I[3];
+  SS_DEV static void imul(const real *I, const real *x, real *y) {
+    real m = I[0], cx = I[1], cy = I[2], cz = I[3];
     y[0] = I[4] * x[0] + I[5] * x[1] + I[6] * x[2] + cy * x[5] - cz * x[4];
     y[1] = I[5] * x[0] + I[7] * x[1] + I[8] * x[2] + cz * x[3] - cx * x[5];
     y[2] = I[6] * x[0] + I[8] * x[1] + I[9] * x[2] + cx * x[4] - cy * x[3];
@@ -499,17 +509,17 @@ struct Sim : ShapeTables<SHAPED> {
   }
 
   // ------------------------------------------------------------------ MuJoCo impedance d(r)
-  SS_DEV float impedance(float pos, float margin) const {
-    const float *si = k->h.solimp;
-    float x = (pos - margin) / si[2];
+  SS_DEV real impedance(real pos, real margin) const {
+    const real *si = k->h.solimp;
+    real x = (pos - margin) / si[2];
     if (x < 0) x = -x;
     if (x >= 1.f) return si[1];
     if (x <= 0.f) return si[0];
-    float y;
+    real y;
     if (si[4] == 1.f) y = x;
     else if (si[4] == 2.f) y = x <= si[3] ? x * x / si[3] : 1.f - (1.f - x) * (1.f - x) / (1.f - si[3]);   // MuJoCo default
-    else if (x <= si[3]) y = powf(x, si[4]) / powf(si[3], si[4] - 1.f);
-    else y = 1.f - powf(1.f - x, si[4]) / powf(1.f - si[3], si[4] - 1.f);
+    else if (x <= si[3]) y = SS_M(pow)(x, si[4]) / SS_M(pow)(si[3], si[4] - 1.f);
+    else y = 1.f - SS_M(pow)(1.f - x, si[4]) / SS_M(pow)(1.f - si[3], si[4] - 1.f);
     return si[0] + y * (si[1] - si[0]);
   }
 
@@ -517,51 +527,51 @@ struct Sim : ShapeTables<SHAPED> {
   SS_DEV void make_constraints() {
     fresh();
     const Hdr &h = k->h;
-    const float pz = q[2], mu = h.mu;
+    const real pz = q[2], mu = h.mu;
     touchmask = 0ull;
     // contact records are compacted through LDS (the solver region is free here) into one slot per lane:
     // box b keeps at most 4 corners -> slots 4b..4b+3, capsule end e -> slot 4*nbox + e
-    float *rec = Aown;
+    real *rec = Aown;
 #pragma unroll
     for (int p = 0; p < SLOTP; p++) { int sl = p * 64 + lane; if (sl < h.nslot) rec[13 * sl] = 0.f; }
     w->sync();
 #pragma unroll
     for (int p = 0; p < CANDP; p++) {
       int qual = 0;
-      float dist = 0.f, px = 0, py = 0, pzr = 0, t1x = 0.f, t1y = 1.f;
+      real dist = 0.f, px = 0, py = 0, pzr = 0, t1x = 0.f, t1y = 1.f;
       const int cidx = p * 64 + lane;
       const bool valid = cidx < h.ncand;
       const int cbp = valid ? k->candb[cidx] : 0;
       const int b = cbp & 255;
       const bool caps = valid && (cbp & 256);
-      float cv[kCandC];
+      real cv[kCandC];
       {
         const float4_t *src = reinterpret_cast<const float4_t *>(candc() + (valid ? cidx : 0) * kCandC);
         const float4_t c0 = src[0], c1 = src[1];
         cv[0] = c0.x; cv[1] = c0.y; cv[2] = c0.z; cv[3] = c0.w; cv[4] = c1.x; cv[5] = c1.y; cv[6] = c1.z; cv[7] = c1.w;
       }
       if (valid) {
-        const float *Rb = R + 9 * b, *rb = r + 3 * b;
+        const real *Rb = R + 9 * b, *rb = r + 3 * b;
         if (!caps) {
-          float ldist = Rb[6] * cv[0] + Rb[7] * cv[1] + Rb[8] * cv[2];
-          float dcen = pz + rb[2] + Rb[6] * cv[3] + Rb[7] * cv[4] + Rb[8] * cv[5];
+          real ldist = Rb[6] * cv[0] + Rb[7] * cv[1] + Rb[8] * cv[2];
+          real dcen = pz + rb[2] + Rb[6] * cv[3] + Rb[7] * cv[4] + Rb[8] * cv[5];
           qual = !(dcen + ldist > h.margin || ldist > 0.f);
           dist = dcen + ldist;
-          float lx = cv[0] + cv[3], ly = cv[1] + cv[4], lz = cv[2] + cv[5];
+          real lx = cv[0] + cv[3], ly = cv[1] + cv[4], lz = cv[2] + cv[5];
           px = rb[0] + Rb[0] * lx + Rb[1] * ly + Rb[2] * lz;
           py = rb[1] + Rb[3] * lx + Rb[4] * ly + Rb[5] * lz;
           pzr = rb[2] + Rb[6] * lx + Rb[7] * ly + Rb[8] * lz - 0.5f * dist;
         } else {
-          float czw = pz + rb[2] + Rb[6] * cv[0] + Rb[7] * cv[1] + Rb[8] * cv[2];
+          real czw = pz + rb[2] + Rb[6] * cv[0] + Rb[7] * cv[1] + Rb[8] * cv[2];
           dist = czw - cv[6];
           qual = !(dist > h.margin);
           px = rb[0] + Rb[0] * cv[0] + Rb[1] * cv[1] + Rb[2] * cv[2];
           py = rb[1] + Rb[3] * cv[0] + Rb[4] * cv[1] + Rb[5] * cv[2];
           pzr = rb[2] + Rb[6] * cv[0] + Rb[7] * cv[1] + Rb[8] * cv[2] - (cv[6] + 0.5f * dist);
-          float axx = Rb[0] * cv[3] + Rb[1] * cv[4] + Rb[2] * cv[5];
-          float axy = Rb[3] * cv[3] + Rb[4] * cv[4] + Rb[5] * cv[5];
-          float nn = sqrtf(axx * axx + axy * axy);
-          if (nn < 1e-15f) { t1x = 1.f; t1y = 0.f; } else { t1x = axx / nn; t1y = axy / nn; }
+          real axx = Rb[0] * cv[3] + Rb[1] * cv[4] + Rb[2] * cv[5];
+          real axy = Rb[3] * cv[3] + Rb[4] * cv[4] + Rb[5] * cv[5];
+          real nn = SS_M(sqrt)(axx * axx + axy * axy);
+          if (nn < real(1e-15)) { t1x = 1.f; t1y = 0.f; } else { t1x = axx / nn; t1y = axy / nn; }
         }
       }
       unsigned long long bal = w->ballot(qual && !caps);
@@ -575,18 +585,18 @@ struct Sim : ShapeTables<SHAPED> {
         slot = 4 * (cidx >> 3) + rank;
       } else if (valid) slot = 4 * h.nbox + (cidx - 8 * h.nbox);
       if (act) {
-        const float *vb = V + 6 * b;
-        float vx = vb[3] + vb[1] * pzr - vb[2] * py;
-        float vy = vb[4] + vb[2] * px - vb[0] * pzr;
-        float vz = vb[5] + vb[0] * py - vb[1] * px;
-        float vt1 = t1x * vx + t1y * vy, vt2 = -t1y * vx + t1x * vy;
-        float imp = impedance(dist, h.margin);
-        float R0 = (1.f - imp) / imp * cv[7] * (1.f + mu * mu);
-        if (R0 < 1e-15f) R0 = 1e-15f;
-        float Rpy = 2.f * mu * mu * R0;
-        float kterm = h.K * imp * (dist - h.margin);
-        float *o = rec + 13 * slot;
-        o[0] = 1.f; o[1] = (float)b; o[2] = px; o[3] = py; o[4] = pzr; o[5] = t1x; o[6] = t1y; o[7] = 1.f / Rpy;
+        const real *vb = V + 6 * b;
+        real vx = vb[3] + vb[1] * pzr - vb[2] * py;
+        real vy = vb[4] + vb[2] * px - vb[0] * pzr;
+        real vz = vb[5] + vb[0] * py - vb[1] * px;
+        real vt1 = t1x * vx + t1y * vy, vt2 = -t1y * vx + t1x * vy;
+        real imp = impedance(dist, h.margin);
+        real R0 = (1.f - imp) / imp * cv[7] * (1.f + mu * mu);
+        if (R0 < real(1e-15)) R0 = real(1e-15);
+        real Rpy = 2.f * mu * mu * R0;
+        real kterm = h.K * imp * (dist - h.margin);
+        real *o = rec + 13 * slot;
+        o[0] = 1.f; o[1] = (real)b; o[2] = px; o[3] = py; o[4] = pzr; o[5] = t1x; o[6] = t1y; o[7] = 1.f / Rpy;
         o[8] = -h.B * (vz + mu * vt1) - kterm;
         o[9] = -h.B * (vz - mu * vt1) - kterm;
         o[10] = -h.B * (vz + mu * vt2) - kterm;
@@ -601,7 +611,7 @@ struct Sim : ShapeTables<SHAPED> {
       const int sl = p * 64 + lane;
       c.active = 0;
       if (sl < h.nslot) {
-        const float *o = rec + 13 * sl;
+        const real *o = rec + 13 * sl;
         if (o[0] != 0.f) {
           c.active = 1; c.body = (int)o[1]; c.rx = o[2]; c.ry = o[3]; c.rz = o[4]; c.t1x = o[5]; c.t1y = o[6]; c.D = o[7];
           c.aref[0] = o[8]; c.aref[1] = o[9]; c.aref[2] = o[10]; c.aref[3] = o[11];
@@ -615,13 +625,13 @@ struct Sim : ShapeTables<SHAPED> {
       Limit &l = lim[p];
       l.sign = 0.f; l.D = 0.f; l.aref = 0.f; l.jar = 0.f; l.jd = 0.f;
       if (i >= 6 && i < h.nv && dc(i, 3) != 0.f) {
-        float qi = q[i + 1], lo = dc(i, 1), hi = dc(i, 2), pos = 0.f;
+        real qi = q[i + 1], lo = dc(i, 1), hi = dc(i, 2), pos = 0.f;
         if (qi - lo < 0.f) { l.sign = 1.f; pos = qi - lo; }
         else if (hi - qi < 0.f) { l.sign = -1.f; pos = hi - qi; }
         if (l.sign != 0.f) {
-          float imp = impedance(pos, 0.f);
-          float Rr = (1.f - imp) / imp * dof_invweight(i);
-          if (Rr < 1e-15f) Rr = 1e-15f;
+          real imp = impedance(pos, 0.f);
+          real Rr = (1.f - imp) / imp * dof_invweight(i);
+          if (Rr < real(1e-15)) Rr = real(1e-15);
           l.D = 1.f / Rr;
           l.aref = -h.B * (l.sign * v[i]) - h.K * imp * pos;
         }
@@ -631,17 +641,17 @@ struct Sim : ShapeTables<SHAPED> {
 
   // rows: jar (from A = Ab, x = a) or jd (from A = Ad, x = delta)
   // A: spatial accelerations, body b at A + stride * b
-  SS_DEV void eval_rows(const float *A, int stride, const float *x, bool is_delta) {
-    const float mu = k->h.mu;
+  SS_DEV void eval_rows(const real *A, int stride, const real *x, bool is_delta) {
+    const real mu = k->h.mu;
 #pragma unroll
     for (int p = 0; p < SLOTP; p++) {
       Contact &c = con[p];
       if (!c.active) continue;
-      const float *Ab_ = A + stride * c.body;
-      float ax = Ab_[3] + Ab_[1] * c.rz - Ab_[2] * c.ry;
-      float ay = Ab_[4] + Ab_[2] * c.rx - Ab_[0] * c.rz;
-      float az = Ab_[5] + Ab_[0] * c.ry - Ab_[1] * c.rx;
-      float t1 = mu * (c.t1x * ax + c.t1y * ay), t2 = mu * (-c.t1y * ax + c.t1x * ay);
+      const real *Ab_ = A + stride * c.body;
+      real ax = Ab_[3] + Ab_[1] * c.rz - Ab_[2] * c.ry;
+      real ay = Ab_[4] + Ab_[2] * c.rx - Ab_[0] * c.rz;
+      real az = Ab_[5] + Ab_[0] * c.ry - Ab_[1] * c.rx;
+      real t1 = mu * (c.t1x * ax + c.t1y * ay), t2 = mu * (-c.t1y * ax + c.t1x * ay);
       if (is_delta) { c.jd[0] = az + t1; c.jd[1] = az - t1; c.jd[2] = az + t2; c.jd[3] = az - t2; }
       else { c.jar[0] = az + t1 - c.aref[0]; c.jar[1] = az - t1 - c.aref[1]; c.jar[2] = az + t2 - c.aref[2]; c.jar[3] = az - t2 - c.aref[3]; }
     }
@@ -668,13 +678,13 @@ struct Sim : ShapeTables<SHAPED> {
   // quantities; the 3x3 joint-space algebra is redundant per lane.  Two wave syncs per level going up, one going
   // down.  Rows of the level's IA', pA' go through a two-level LDS buffer; (W_r, y_r) are kept per node.
   // On return x holds the solution and An[8 n ..] the node accelerations a_n (= the body accelerations J_b x).
-  SS_DEV static void st4w(float *p, float a, float b, float c, float d) { float4_t v; v.x = a; v.y = b; v.z = c; v.w = d; *reinterpret_cast<float4_t *>(p) = v; }
+  SS_DEV static void st4w(real *p, real a, real b, real c, real d) { float4_t v; v.x = a; v.y = b; v.z = c; v.w = d; *reinterpret_cast<float4_t *>(p) = v; }
 
   SS_DEV void write_own_inertia() {                          // Aown[b] = expand(Ib), packed upper triangle (ang;lin)
     if (lane < k->h.nb) {
-      float *o = Aown + 21 * lane;
-      const float *Ib = Iown + 10 * lane;
-      const float m = Ib[0], cx = Ib[1], cy = Ib[2], cz = Ib[3];
+      real *o = Aown + 21 * lane;
+      const real *Ib = Iown + 10 * lane;
+      const real m = Ib[0], cx = Ib[1], cy = Ib[2], cz = Ib[3];
       o[0] = Ib[4]; o[1] = Ib[5]; o[2] = Ib[6]; o[3] = 0.f; o[4] = -cz; o[5] = cy;
       o[6] = Ib[7]; o[7] = Ib[8]; o[8] = cz; o[9] = 0.f; o[10] = -cx;
       o[11] = Ib[9]; o[12] = -cy; o[13] = cx; o[14] = 0.f;
@@ -683,7 +693,7 @@ struct Sim : ShapeTables<SHAPED> {
   }
 
   // pb: optional per-body bias force (6 per body): the system solved is  H x = b - sum_b J_b^T pb_b
-  SS_DEV void aba_solve(float *x, const float *pb) {
+  SS_DEV void aba_solve(real *x, const real *pb) {
     fresh();
     const Hdr &h = k->h;
     const int r_ = lane & 7, g = lane >> 3;
@@ -696,9 +706,9 @@ struct Sim : ShapeTables<SHAPED> {
     for (int L = h.nlev - 1; L >= 2; --L) {                    // the two root nodes are solved together below
       const int nk = (int)(((L < 16 ? nk0 : nk1) >> (4 * (L & 15))) & 15ull) + 1;
       s0 -= nk;
-      float *cur = IA + (L & 1) * h.ia_stride;
-      const float *prev = IA + ((L + 1) & 1) * h.ia_stride;
-      float row[NPASS][6], pa[NPASS], Ur[NPASS][3], red[NPASS][9];
+      real *cur = IA + (L & 1) * h.ia_stride;
+      const real *prev = IA + ((L + 1) & 1) * h.ia_stride;
+      real row[NPASS][6], pa[NPASS], Ur[NPASS][3], red[NPASS][9];
       int nod[NPASS];
 #pragma unroll
       for (int ps = 0; ps < NPASS; ps++) {                    // ---- part 1: articulated row, U_r = IA_r S, partial S^T U
@@ -709,25 +719,25 @@ struct Sim : ShapeTables<SHAPED> {
         if (r_ < 6 && kk < nk) {
           const int e = ti(h.o_lev, s0 + kk), n = e & 255, cfirst = (e >> 16) & 255, cc = (e >> 24) & 255;
           nod[ps] = n;
-          float rw[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, pv = (pb && n > 0) ? pb[6 * (n - 1) + r_] : 0.f;
+          real rw[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, pv = (pb && n > 0) ? pb[6 * (n - 1) + r_] : 0.f;
           if (n > 0) {
-            const float *ao = Aown + 21 * (n - 1);
+            const real *ao = Aown + 21 * (n - 1);
 #pragma unroll
             for (int c = 0; c < 6; c++) rw[c] = ao[off[c]];
           }
-          float sv[18];                                       // S_n: issued before the child loop, consumed after it
-          const float *sn = S + 18 * n;
+          real sv[18];                                       // S_n: issued before the child loop, consumed after it
+          const real *sn = S + 18 * n;
 #pragma unroll
           for (int t = 0; t < 18; t++) sv[t] = sn[t];
-          const float sr0 = sn[r_], sr1 = sn[6 + r_], sr2 = sn[12 + r_];   // row r of S_n
+          const real sr0 = sn[r_], sr1 = sn[6 + r_], sr2 = sn[12 + r_];   // row r of S_n
           for (int j = 0; j < cc; j++) {
-            const float *src = prev + ((cfirst + j) * 6 + r_) * 8;
+            const real *src = prev + ((cfirst + j) * 6 + r_) * 8;
             const float4_t v0 = ld4(src), v1 = ld4(src + 4);
             rw[0] += v0.x; rw[1] += v0.y; rw[2] += v0.z; rw[3] += v0.w; rw[4] += v1.x; rw[5] += v1.y; pv += v1.z;
           }
 #pragma unroll
           for (int j = 0; j < 3; j++) {
-            float acc = 0.f;
+            real acc = 0.f;
 #pragma unroll
             for (int c = 0; c < 6; c++) acc += rw[c] * sv[6 * j + c];
             Ur[ps][j] = acc;
@@ -755,21 +765,21 @@ struct Sim : ShapeTables<SHAPED> {
           float4_t U[6];
 #pragma unroll
           for (int c = 0; c < 6; c++) U[c] = ld4(Ubuf + (kk * 6 + c) * 4);
-          const float d00 = red[ps][0] + diag[3 * n], d10 = red[ps][1], d11 = red[ps][2] + diag[3 * n + 1];
-          const float d20 = red[ps][3], d21 = red[ps][4], d22 = red[ps][5] + diag[3 * n + 2];
-          const float u0 = x[3 * n] - red[ps][6], u1 = x[3 * n + 1] - red[ps][7], u2 = x[3 * n + 2] - red[ps][8];
-          const float c00 = d11 * d22 - d21 * d21, c01 = d21 * d20 - d10 * d22, c02 = d10 * d21 - d11 * d20;
-          const float id = rcp_nr(d00 * c00 + d10 * c01 + d20 * c02);
-          const float i00 = c00 * id, i01 = c01 * id, i02 = c02 * id;
-          const float i11 = (d00 * d22 - d20 * d20) * id, i12 = (d10 * d20 - d00 * d21) * id, i22 = (d00 * d11 - d10 * d10) * id;
-          const float y0 = i00 * u0 + i01 * u1 + i02 * u2, y1 = i01 * u0 + i11 * u1 + i12 * u2, y2 = i02 * u0 + i12 * u1 + i22 * u2;
-          const float a0 = Ur[ps][0], a1 = Ur[ps][1], a2 = Ur[ps][2];
-          const float w0 = a0 * i00 + a1 * i01 + a2 * i02, w1 = a0 * i01 + a1 * i11 + a2 * i12, w2 = a0 * i02 + a1 * i12 + a2 * i22;
-          float rn[6];
+          const real d00 = red[ps][0] + diag[3 * n], d10 = red[ps][1], d11 = red[ps][2] + diag[3 * n + 1];
+          const real d20 = red[ps][3], d21 = red[ps][4], d22 = red[ps][5] + diag[3 * n + 2];
+          const real u0 = x[3 * n] - red[ps][6], u1 = x[3 * n + 1] - red[ps][7], u2 = x[3 * n + 2] - red[ps][8];
+          const real c00 = d11 * d22 - d21 * d21, c01 = d21 * d20 - d10 * d22, c02 = d10 * d21 - d11 * d20;
+          const real id = rcp_nr(d00 * c00 + d10 * c01 + d20 * c02);
+          const real i00 = c00 * id, i01 = c01 * id, i02 = c02 * id;
+          const real i11 = (d00 * d22 - d20 * d20) * id, i12 = (d10 * d20 - d00 * d21) * id, i22 = (d00 * d11 - d10 * d10) * id;
+          const real y0 = i00 * u0 + i01 * u1 + i02 * u2, y1 = i01 * u0 + i11 * u1 + i12 * u2, y2 = i02 * u0 + i12 * u1 + i22 * u2;
+          const real a0 = Ur[ps][0], a1 = Ur[ps][1], a2 = Ur[ps][2];
+          const real w0 = a0 * i00 + a1 * i01 + a2 * i02, w1 = a0 * i01 + a1 * i11 + a2 * i12, w2 = a0 * i02 + a1 * i12 + a2 * i22;
+          real rn[6];
 #pragma unroll
           for (int c = 0; c < 6; c++) rn[c] = row[ps][c] - (w0 * U[c].x + w1 * U[c].y + w2 * U[c].z);
-          const float pn = pa[ps] + a0 * y0 + a1 * y1 + a2 * y2;
-          float *dst = cur + (kk * 6 + r_) * 8;
+          const real pn = pa[ps] + a0 * y0 + a1 * y1 + a2 * y2;
+          real *dst = cur + (kk * 6 + r_) * 8;
           st4w(dst, rn[0], rn[1], rn[2], rn[3]); st4w(dst + 4, rn[4], rn[5], pn, 0.f);
           st4w(Wst + (n * 6 + r_) * 4, w0, w1, w2, r_ == 0 ? y0 : (r_ == 1 ? y1 : y2));
         }
@@ -781,24 +791,24 @@ struct Sim : ShapeTables<SHAPED> {
     // and the free joint has neither armature nor limits nor gains, so  S^T (IA a + pA) = b  is the 6x6 system
     // IA a = S b - pA  in world coordinates: no transform of the matrix, no hand-up, two tree levels less per sweep.
     {
-      float *rows = IA + h.ia_stride;                          // the level buffer that level 2 did not use
-      const float *prev = IA;                                  // rows handed up by level 2
+      real *rows = IA + h.ia_stride;                          // the level buffer that level 2 did not use
+      const real *prev = IA;                                  // rows handed up by level 2
       if (lane < 6) {
         const int e = ti(h.o_lev, 1), cfirst = (e >> 16) & 255, cc = (e >> 24) & 255;
-        float rw[6], pv = pb ? pb[lane] : 0.f;
+        real rw[6], pv = pb ? pb[lane] : 0.f;
 #pragma unroll
         for (int c = 0; c < 6; c++) rw[c] = Aown[off[c]];
         for (int j = 0; j < cc; j++) {
-          const float *src = prev + ((cfirst + j) * 6 + lane) * 8;
+          const real *src = prev + ((cfirst + j) * 6 + lane) * 8;
           const float4_t v0 = ld4(src), v1 = ld4(src + 4);
           rw[0] += v0.x; rw[1] += v0.y; rw[2] += v0.z; rw[3] += v0.w; rw[4] += v1.x; rw[5] += v1.y; pv += v1.z;
         }
         // (S b)_r: angular part R b_rot (S of node 1 holds the columns of R), linear part b_trans
-        const float sb = lane < 3 ? S[18 + lane] * x[3] + S[24 + lane] * x[4] + S[30 + lane] * x[5] : x[lane - 3];
+        const real sb = lane < 3 ? S[18 + lane] * x[3] + S[24 + lane] * x[4] + S[30 + lane] * x[5] : x[lane - 3];
         st4w(rows + 8 * lane, rw[0], rw[1], rw[2], rw[3]); st4w(rows + 8 * lane + 4, rw[4], rw[5], sb - pv, 0.f);
       }
       w->sync();
-      float A6[6][6], f6[6];                                   // every lane solves the same 6x6 system (L D L^T)
+      real A6[6][6], f6[6];                                   // every lane solves the same 6x6 system (L D L^T)
 #pragma unroll
       for (int i = 0; i < 6; i++) {
         const float4_t v0 = ld4(rows + 8 * i), v1 = ld4(rows + 8 * i + 4);
@@ -807,17 +817,17 @@ struct Sim : ShapeTables<SHAPED> {
       // 2x2 block elimination with closed-form 3x3 inverses (shallow dependency chains; an L D L^T over 6 pivots is
       // a 60-deep chain for a lone wave):  A = [P Q; Q^T T],  a_ang = (P - Q T^-1 Q^T)^-1 (f_a - Q T^-1 f_l),
       // a_lin = T^-1 (f_l - Q^T a_ang)
-      float Ti[6], Si[6];                                      // symmetric inverses: 00 01 02 11 12 22
+      real Ti[6], Si[6];                                      // symmetric inverses: 00 01 02 11 12 22
       sym3_inverse(A6[3][3], A6[4][3], A6[4][4], A6[5][3], A6[5][4], A6[5][5], Ti);
-      float QT[3][3];                                          // Q T^-1
+      real QT[3][3];                                          // Q T^-1
 #pragma unroll
       for (int i = 0; i < 3; i++) {
-        const float q0 = A6[i][3], q1 = A6[i][4], q2 = A6[i][5];
+        const real q0 = A6[i][3], q1 = A6[i][4], q2 = A6[i][5];
         QT[i][0] = q0 * Ti[0] + q1 * Ti[1] + q2 * Ti[2];
         QT[i][1] = q0 * Ti[1] + q1 * Ti[3] + q2 * Ti[4];
         QT[i][2] = q0 * Ti[2] + q1 * Ti[4] + q2 * Ti[5];
       }
-      float Sc[3][3], ga[3];                                   // Schur complement P - Q T^-1 Q^T and its right-hand side
+      real Sc[3][3], ga[3];                                   // Schur complement P - Q T^-1 Q^T and its right-hand side
 #pragma unroll
       for (int i = 0; i < 3; i++) {
 #pragma unroll
@@ -825,12 +835,12 @@ struct Sim : ShapeTables<SHAPED> {
         ga[i] = f6[i] - (QT[i][0] * f6[3] + QT[i][1] * f6[4] + QT[i][2] * f6[5]);
       }
       sym3_inverse(Sc[0][0], Sc[1][0], Sc[1][1], Sc[2][0], Sc[2][1], Sc[2][2], Si);
-      const float aa0 = Si[0] * ga[0] + Si[1] * ga[1] + Si[2] * ga[2];
-      const float aa1 = Si[1] * ga[0] + Si[3] * ga[1] + Si[4] * ga[2];
-      const float aa2 = Si[2] * ga[0] + Si[4] * ga[1] + Si[5] * ga[2];
-      const float gl0 = f6[3] - (A6[0][3] * aa0 + A6[1][3] * aa1 + A6[2][3] * aa2);
-      const float gl1 = f6[4] - (A6[0][4] * aa0 + A6[1][4] * aa1 + A6[2][4] * aa2);
-      const float gl2 = f6[5] - (A6[0][5] * aa0 + A6[1][5] * aa1 + A6[2][5] * aa2);
+      const real aa0 = Si[0] * ga[0] + Si[1] * ga[1] + Si[2] * ga[2];
+      const real aa1 = Si[1] * ga[0] + Si[3] * ga[1] + Si[4] * ga[2];
+      const real aa2 = Si[2] * ga[0] + Si[4] * ga[1] + Si[5] * ga[2];
+      const real gl0 = f6[3] - (A6[0][3] * aa0 + A6[1][3] * aa1 + A6[2][3] * aa2);
+      const real gl1 = f6[4] - (A6[0][4] * aa0 + A6[1][4] * aa1 + A6[2][4] * aa2);
+      const real gl2 = f6[5] - (A6[0][5] * aa0 + A6[1][5] * aa1 + A6[2][5] * aa2);
       f6[0] = aa0; f6[1] = aa1; f6[2] = aa2;
       f6[3] = Ti[0] * gl0 + Ti[1] * gl1 + Ti[2] * gl2;
       f6[4] = Ti[1] * gl0 + Ti[3] * gl1 + Ti[4] * gl2;
@@ -851,16 +861,16 @@ struct Sim : ShapeTables<SHAPED> {
         if (r_ < 6 && kk < nk) {
           const int e = ti(h.o_lev, s0 + kk), n = e & 255, pn = (e >> 8) & 255;
           float4_t p0, p1; p0.x = p0.y = p0.z = p0.w = 0.f; p1 = p0;
-          float apr = 0.f;
+          real apr = 0.f;
           if (n > 0) { p0 = ld4(An + 8 * pn); p1 = ld4(An + 8 * pn + 4); apr = An[8 * pn + r_]; }
           float4_t Wn[6];
 #pragma unroll
           for (int c = 0; c < 6; c++) Wn[c] = ld4(Wst + (n * 6 + c) * 4);
-          const float ap[6] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y};
-          float x0 = Wn[0].w, x1 = Wn[1].w, x2 = Wn[2].w;
+          const real ap[6] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y};
+          real x0 = Wn[0].w, x1 = Wn[1].w, x2 = Wn[2].w;
 #pragma unroll
           for (int c = 0; c < 6; c++) { x0 -= Wn[c].x * ap[c]; x1 -= Wn[c].y * ap[c]; x2 -= Wn[c].z * ap[c]; }
-          const float *sn = S + 18 * n + r_;
+          const real *sn = S + 18 * n + r_;
           An[8 * n + r_] = apr + sn[0] * x0 + sn[6] * x1 + sn[12] * x2;
           if (r_ < 3) x[3 * n + r_] = r_ == 0 ? x0 : (r_ == 1 ? x1 : x2);
         }
@@ -872,25 +882,25 @@ struct Sim : ShapeTables<SHAPED> {
   }
 
   // inverse of the symmetric 3x3 [d00 d10 d20; d10 d11 d21; d20 d21 d22] -> (i00 i01 i02 i11 i12 i22)
-  SS_DEV static void sym3_inverse(float d00, float d10, float d11, float d20, float d21, float d22, float *o) {
-    const float c00 = d11 * d22 - d21 * d21, c01 = d21 * d20 - d10 * d22, c02 = d10 * d21 - d11 * d20;
-    const float id = rcp_nr(d00 * c00 + d10 * c01 + d20 * c02);
+  SS_DEV static void sym3_inverse(real d00, real d10, real d11, real d20, real d21, real d22, real *o) {
+    const real c00 = d11 * d22 - d21 * d21, c01 = d21 * d20 - d10 * d22, c02 = d10 * d21 - d11 * d20;
+    const real id = rcp_nr(d00 * c00 + d10 * c01 + d20 * c02);
     o[0] = c00 * id; o[1] = c01 * id; o[2] = c02 * id;
     o[3] = (d00 * d22 - d20 * d20) * id; o[4] = (d10 * d20 - d00 * d21) * id; o[5] = (d00 * d11 - d10 * d10) * id;
   }
 
   // 1/x: hardware reciprocal + one Newton step
-  SS_DEV static float rcp_nr(float x) {
+  SS_DEV static real rcp_nr(real x) {
 #if defined(__HIPCC__)
-    float r = __builtin_amdgcn_rcpf(x);
+    real r = __builtin_amdgcn_rcpf(x);
 #else
-    float r = 1.0f / x;
+    real r = 1.0f / x;
 #endif
     return r * (2.0f - x * r);
   }
 
   // joint-space matrix column j = M e_j by a body-level pass (diagnostics only: ss_debug_forward)
-  SS_DEV void dump_mass_matrix(float *out) {
+  SS_DEV void dump_mass_matrix(real *out) {
     const Hdr &h = k->h;
     for (int j = 0; j < h.nv; j++) {
       for (int i = lane; i < h.nv; i += 64) delta[i] = i == j ? 1.f : 0.f;
@@ -898,7 +908,7 @@ struct Sim : ShapeTables<SHAPED> {
       body_accel(delta, Ab, tmpb);
       w->sync();
       if (lane < h.nb) {
-        float Ia[6];
+        real Ia[6];
         imul(Iown + 10 * lane, Ab + 6 * lane, Ia);
 #pragma unroll
         for (int c = 0; c < 6; c++) Ad[6 * lane + c] = Ia[c];
@@ -908,7 +918,7 @@ struct Sim : ShapeTables<SHAPED> {
       w->sync();
       for (int i = lane; i < h.nv; i += 64) {
         const int n = i / 3, b = n > 0 ? n - 1 : 0;
-        float s_ = i == j ? dc(i, 0) : 0.f;
+        real s_ = i == j ? dc(i, 0) : 0.f;
 #pragma unroll
         for (int c = 0; c < 6; c++) s_ += S[6 * i + c] * Gb[6 * b + c];
         out[(size_t)j * h.nv + i] = s_;
@@ -918,15 +928,15 @@ struct Sim : ShapeTables<SHAPED> {
   }
 
   // ------------------------------------------------------------------ Newton solve of the constrained acceleration
-  SS_DEV void ls_eval(float al, float c1, float c2, float &d1, float &d2) {
-    float s1 = 0.f, s2 = 0.f;
+  SS_DEV void ls_eval(real al, real c1, real c2, real &d1, real &d2) {
+    real s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int p = 0; p < SLOTP; p++) {
       const Contact &c = con[p];
       if (!c.active) continue;
 #pragma unroll
       for (int r_ = 0; r_ < 4; r_++) {
-        float x = c.jar[r_] + al * c.jd[r_];
+        real x = c.jar[r_] + al * c.jd[r_];
         if (x < 0.f) { s1 += c.D * x * c.jd[r_]; s2 += c.D * c.jd[r_] * c.jd[r_]; }
       }
     }
@@ -934,7 +944,7 @@ struct Sim : ShapeTables<SHAPED> {
     for (int p = 0; p < DOFP; p++) {
       const Limit &l = lim[p];
       if (l.sign == 0.f) continue;
-      float x = l.jar + al * l.jd;
+      real x = l.jar + al * l.jd;
       if (x < 0.f) { s1 += l.D * x * l.jd; s2 += l.D * l.jd * l.jd; }
     }
     d1 = c1 + al * c2 + w->sum(s1);
@@ -953,7 +963,7 @@ struct Sim : ShapeTables<SHAPED> {
   SS_DEV void newton_prepare() {
     fresh();
     const Hdr &h = k->h;
-    const float mu = h.mu;
+    const real mu = h.mu;
     iters++;
     SS_FT0();
     // ---- contact forces and K_b = sum_rows D u u^T, u = (rho x w ; w).  The (<= 4) contacts of a box sit in
@@ -966,19 +976,19 @@ struct Sim : ShapeTables<SHAPED> {
       const Contact &c = con[p];
       const int sl = p * 64 + lane;
       const bool boxlane = sl < 4 * h.nbox;
-      float vals[27];
+      real vals[27];
 #pragma unroll
       for (int t = 0; t < 27; t++) vals[t] = 0.f;
       if (c.active) {
-        float fx = 0, fy = 0, fz = 0;
-        float Wxx = 0, Wxy = 0, Wxz = 0, Wyy = 0, Wyz = 0, Wzz = 0;
+        real fx = 0, fy = 0, fz = 0;
+        real Wxx = 0, Wxy = 0, Wxz = 0, Wyy = 0, Wyz = 0, Wzz = 0;
 #pragma unroll
         for (int r_ = 0; r_ < 4; r_++) {
-          const float sgn = (r_ & 1) ? -mu : mu;
-          const float wx = r_ < 2 ? sgn * c.t1x : -sgn * c.t1y;
-          const float wy = r_ < 2 ? sgn * c.t1y : sgn * c.t1x;
+          const real sgn = (r_ & 1) ? -mu : mu;
+          const real wx = r_ < 2 ? sgn * c.t1x : -sgn * c.t1y;
+          const real wy = r_ < 2 ? sgn * c.t1y : sgn * c.t1x;
           if (c.jar[r_] < 0.f) {
-            const float f = -c.D * c.jar[r_];
+            const real f = -c.D * c.jar[r_];
             fx += f * wx; fy += f * wy; fz += f;
             Wxx += c.D * wx * wx; Wxy += c.D * wx * wy; Wxz += c.D * wx;
             Wyy += c.D * wy * wy; Wyz += c.D * wy; Wzz += c.D;
@@ -988,9 +998,9 @@ struct Sim : ShapeTables<SHAPED> {
         vals[0] = -(c.ry * fz - c.rz * fy); vals[1] = -(c.rz * fx - c.rx * fz); vals[2] = -(c.rx * fy - c.ry * fx);
         vals[3] = -fx; vals[4] = -fy; vals[5] = -fz;
         // Y = [rho]x W (ang-lin block), Z = rows rho x Y[i,:] (ang-ang block)
-        const float Y0 = c.ry * Wxz - c.rz * Wxy, Y1 = c.ry * Wyz - c.rz * Wyy, Y2 = c.ry * Wzz - c.rz * Wyz;
-        const float Y3 = c.rz * Wxx - c.rx * Wxz, Y4 = c.rz * Wxy - c.rx * Wyz, Y5 = c.rz * Wxz - c.rx * Wzz;
-        const float Y6 = c.rx * Wxy - c.ry * Wxx, Y7 = c.rx * Wyy - c.ry * Wxy, Y8 = c.rx * Wyz - c.ry * Wxz;
+        const real Y0 = c.ry * Wxz - c.rz * Wxy, Y1 = c.ry * Wyz - c.rz * Wyy, Y2 = c.ry * Wzz - c.rz * Wyz;
+        const real Y3 = c.rz * Wxx - c.rx * Wxz, Y4 = c.rz * Wxy - c.rx * Wyz, Y5 = c.rz * Wxz - c.rx * Wzz;
+        const real Y6 = c.rx * Wxy - c.ry * Wxx, Y7 = c.rx * Wyy - c.ry * Wxy, Y8 = c.rx * Wyz - c.ry * Wxz;
         vals[6] = c.ry * Y2 - c.rz * Y1; vals[7] = c.rz * Y0 - c.rx * Y2; vals[8] = c.rx * Y1 - c.ry * Y0;
         vals[9] = Y0; vals[10] = Y1; vals[11] = Y2;
         vals[12] = c.rz * Y3 - c.rx * Y5; vals[13] = c.rx * Y4 - c.ry * Y3;
@@ -1002,20 +1012,20 @@ struct Sim : ShapeTables<SHAPED> {
       // group sums: xor 1 (pairs), then xor 2 for box quads
 #pragma unroll
       for (int t = 0; t < 27; t++) {
-        float v1 = vals[t] + w->quad_xor1(vals[t]);
-        float v2 = w->quad_xor2(v1);
+        real v1 = vals[t] + w->quad_xor1(vals[t]);
+        real v2 = w->quad_xor2(v1);
         vals[t] = boxlane ? v1 + v2 : v1;
       }
       const bool leader = (boxlane ? (sl & 3) == 0 : (sl & 1) == 0) && sl < h.nslot;
       if (leader) {
         const int b = slot_body[p];
-        const float *I = Iown + 10 * b;
-        float Ia[6];
+        const real *I = Iown + 10 * b;
+        real Ia[6];
         imul(I, Ab + 6 * b, Ia);
-        float *g = Pb + 6 * b, *o = Aown + 21 * b;
+        real *g = Pb + 6 * b, *o = Aown + 21 * b;
 #pragma unroll
         for (int t = 0; t < 6; t++) g[t] = Ia[t] + vals[t];
-        const float m = I[0], cx = I[1], cy = I[2], cz = I[3];
+        const real m = I[0], cx = I[1], cy = I[2], cz = I[3];
         o[0] = I[4] + vals[6]; o[1] = I[5] + vals[7]; o[2] = I[6] + vals[8]; o[3] = vals[9]; o[4] = vals[10] - cz; o[5] = vals[11] + cy;
         o[6] = I[7] + vals[12]; o[7] = I[8] + vals[13]; o[8] = vals[14] + cz; o[9] = vals[15]; o[10] = vals[16] - cx;
         o[11] = I[9] + vals[17]; o[12] = vals[18] - cy; o[13] = vals[19] + cx; o[14] = vals[20];
@@ -1029,8 +1039,8 @@ struct Sim : ShapeTables<SHAPED> {
     for (int p = 0; p < DOFP; p++) {
       int i = p * 64 + lane;
       if (i < h.nv) {
-        float s_ = C[i] + dc(i, 0) * a[i] - tau[i];
-        float dg = dc(i, 0);
+        real s_ = C[i] + dc(i, 0) * a[i] - tau[i];
+        real dg = dc(i, 0);
         const Limit &l = lim[p];
         if (l.sign != 0.f && l.jar < 0.f) { s_ += l.sign * l.D * l.jar; dg += l.D; }
         diag[i] = dg; delta[i] = -s_;
@@ -1045,19 +1055,19 @@ struct Sim : ShapeTables<SHAPED> {
     fresh();
     const Hdr &h = k->h;
     eval_rows(An + 8, 8, delta, true);                       // aba_solve left the body accelerations of delta in An
-    float dg_ = 0.f, s_a = 0.f, s_b = 0.f;
+    real dg_ = 0.f, s_a = 0.f, s_b = 0.f;
 #pragma unroll
     for (int p = 0; p < DOFP; p++) {                          // delta . gradient, joint-space part (same terms as newton_prepare)
       int i = p * 64 + lane;
       if (i < h.nv) {
-        float s_ = C[i] + dc(i, 0) * a[i] - tau[i];
+        real s_ = C[i] + dc(i, 0) * a[i] - tau[i];
         const Limit &l = lim[p];
         if (l.sign != 0.f && l.jar < 0.f) s_ += l.sign * l.D * l.jar;
         dg_ += delta[i] * s_;
       }
     }
     if (lane < h.nb) {                                        // body part: (J_b delta) . Pb_b
-      const float *ab_ = An + 8 * (lane + 1), *pb_ = Pb + 6 * lane;
+      const real *ab_ = An + 8 * (lane + 1), *pb_ = Pb + 6 * lane;
 #pragma unroll
       for (int c = 0; c < 6; c++) dg_ += ab_[c] * pb_[c];
     }
@@ -1074,18 +1084,18 @@ struct Sim : ShapeTables<SHAPED> {
       if (l.sign != 0.f && l.jar < 0.f) { s_a += l.D * l.jar * l.jd; s_b += l.D * l.jd * l.jd; }
     }
     dg_ = w->sum(dg_); s_a = w->sum(s_a); s_b = w->sum(s_b);
-    const float c1 = dg_ - s_a, c2 = -dg_ - s_b;            // phi'(al) = c1 + al c2 + sum_active(al) D (jar + al jd) jd
-    float al = 1.f, d1, d2;
+    const real c1 = dg_ - s_a, c2 = -dg_ - s_b;            // phi'(al) = c1 + al c2 + sum_active(al) D (jar + al jd) jd
+    real al = 1.f, d1, d2;
     ls_eval(1.f, c1, c2, d1, d2);
     // accept when |phi'| is SS_LS_TOL of phi'(0) = delta.grad, or at the rounding level of its terms
-    const float tol = SS_LS_TOL * fabsf(dg_) + 2e-6f * (fabsf(dg_) + fabsf(s_a) + fabsf(s_b));
+    const real tol = SS_LS_TOL_EFF * SS_M(fabs)(dg_) + SS_ROUND_REL * (SS_M(fabs)(dg_) + SS_M(fabs)(s_a) + SS_M(fabs)(s_b));
     bool exact = true;
-    if (!(fabsf(d1) <= tol)) {
+    if (!(SS_M(fabs)(d1) <= tol)) {
       exact = false;
-      float lo = 0.f, hi = 1.f;
-      for (int ls = 0; ls < 16; ls++) {                     // one ls_eval site: expand while phi' < 0 at hi, then safeguarded Newton
-        if (fabsf(d1) <= tol) break;
-        float nx;
+      real lo = 0.f, hi = 1.f;
+      for (int ls = 0; ls < SS_LS_MAXIT; ls++) {                     // one ls_eval site: expand while phi' < 0 at hi, then safeguarded Newton
+        if (SS_M(fabs)(d1) <= tol) break;
+        real nx;
         if (d1 < 0.f && al >= hi) { lo = al; hi = 2.f * al; nx = hi; }
         else {
           if (d1 < 0.f) lo = al; else hi = al;
@@ -1101,10 +1111,10 @@ struct Sim : ShapeTables<SHAPED> {
     for (int p = 0; p < DOFP; p++) {
       int i = p * 64 + lane;
       if (i < h.nv) {
-        const float st_ = al * delta[i], an = a[i] + st_;
+        const real st_ = al * delta[i], an = a[i] + st_;
         a[i] = an;
         // still moving: the step is above float32 resolution of the iterate (false for NaN/inf too)
-        moving |= fabsf(st_) > 4e-7f * fabsf(an) + 1e-12f && fabsf(an) <= 1e10f;
+        moving |= SS_M(fabs)(st_) > SS_MOVE_REL * SS_M(fabs)(an) + SS_MOVE_ABS && SS_M(fabs)(an) <= real(1e10);
       }
     }
     for (int idx = lane; idx < 6 * h.nb; idx += 64) { const int b = idx / 6; Ab[idx] += al * An[8 + 2 * b + idx]; }
@@ -1114,7 +1124,7 @@ struct Sim : ShapeTables<SHAPED> {
       if (!c.active) continue;
 #pragma unroll
       for (int r_ = 0; r_ < 4; r_++) {
-        float nj = c.jar[r_] + al * c.jd[r_];
+        real nj = c.jar[r_] + al * c.jd[r_];
         changed |= (nj < 0.f) != (c.jar[r_] < 0.f);
         c.jar[r_] = nj;
       }
@@ -1123,7 +1133,7 @@ struct Sim : ShapeTables<SHAPED> {
     for (int p = 0; p < DOFP; p++) {
       Limit &l = lim[p];
       if (l.sign == 0.f) continue;
-      float nj = l.jar + al * l.jd;
+      real nj = l.jar + al * l.jd;
       changed |= (nj < 0.f) != (l.jar < 0.f);
       l.jar = nj;
     }
@@ -1140,31 +1150,31 @@ struct Sim : ShapeTables<SHAPED> {
   // ------------------------------------------------------------------ controllers (torque for the NEXT mj_step)
   // `pd` (PIDController with zero integral gain, reference controllers.py:335-346) and `torque`
   // (SimpleTorqueController :45-46)
-  SS_DEV void simple_controller(const float *action, float abias) {
+  SS_DEV void simple_controller(const real *action, real abias) {
     const Hdr &h = k->h;
     const int mode = k->cfg.control_mode;
-    const float dtp = h.dt * (float)k->cfg.control_freq_inv;   // the dt SimplePID is constructed with (humanoid_env.py:319)
+    const real dtp = h.dt * (real)k->cfg.control_freq_inv;   // the dt SimplePID is constructed with (humanoid_env.py:319)
 #pragma unroll
     for (int p = 0; p < DOFP; p++) {
       int i = p * 64 + lane;
       if (i < h.nv) {
-        float t = 0.f;
+        real t = 0.f;
         if (dc(i, 10) != 0.f) {
           const int ai = (int)dc(i, 11);
-          float act = action[ai] + abias, lim_ = dc(i, 7);
+          real act = action[ai] + abias, lim_ = dc(i, 7);
           if (mode == SS_CTRL_DEFAULT) t = act;                // ctrl = action, unscaled and unclipped (humanoid_env.py:409-410)
           else {
             if (mode == SS_CTRL_PD) t = -dc(i, 5) * (q[i + 1] - (act * dc(i, 8) + dc(i, 9))) - dc(i, 6) * v[i];
             else if (mode == SS_CTRL_SIMPLE_PID) {             // SimplePID (controllers.py:224-262), ki = 1, state in HBM
-              float *ip = k->st.pid_integral + (size_t)env * h.nu + ai, *ep = k->st.pid_last_error + (size_t)env * h.nu + ai;
-              const float err = act * dc(i, 8) + dc(i, 9) - q[i + 1];
-              const float derr = pid_on ? err - *ep : 0.f;
-              float in = *ip + err * dtp;
-              in = fminf(fmaxf(in, -lim_), lim_);
+              real *ip = gptr(k->st.pid_integral) + (size_t)env * h.nu + ai, *ep = gptr(k->st.pid_last_error) + (size_t)env * h.nu + ai;
+              const real err = act * dc(i, 8) + dc(i, 9) - q[i + 1];
+              const real derr = pid_on ? err - *ep : 0.f;
+              real in = *ip + err * dtp;
+              in = SS_M(fmin)(SS_M(fmax)(in, -lim_), lim_);
               t = dc(i, 5) * err + in + dc(i, 6) * derr / dtp;
               *ip = in; *ep = err;
             } else t = act * k->cfg.power_scale * lim_;
-            t = fminf(fmaxf(t, -lim_), lim_);
+            t = SS_M(fmin)(SS_M(fmax)(t, -lim_), lim_);
           }
         }
         tau[i] = t;
@@ -1176,7 +1186,7 @@ struct Sim : ShapeTables<SHAPED> {
 
   // Stable PD (reference controllers.py:116-190): (M + Kd dt) qdd = -C - Kp e - Kd v on the M, C of the
   // forward pass that is in LDS (the "stale" qM / qfrc_bias) with the current q, v
-  SS_DEV void spd_prepare(const float *action, float abias) {
+  SS_DEV void spd_prepare(const real *action, real abias) {
     fresh();
     const Hdr &h = k->h;
     write_own_inertia();
@@ -1185,7 +1195,7 @@ struct Sim : ShapeTables<SHAPED> {
       int i = p * 64 + lane;
       perr[p] = 0.f;
       if (i < h.nv) {
-        float kp = dc(i, 5), kd = dc(i, 6);
+        real kp = dc(i, 5), kd = dc(i, 6);
         if (dc(i, 10) != 0.f) perr[p] = q[i + 1] + v[i] * h.dt - ((action[(int)dc(i, 11)] + abias) * dc(i, 8) + dc(i, 9));
         diag[i] = dc(i, 0) + kd * h.dt;
         delta[i] = -C[i] - kp * perr[p] - kd * v[i];
@@ -1200,11 +1210,11 @@ struct Sim : ShapeTables<SHAPED> {
     for (int p = 0; p < DOFP; p++) {
       int i = p * 64 + lane;
       if (i < h.nv) {
-        float t = 0.f;
+        real t = 0.f;
         if (dc(i, 10) != 0.f) {
-          float lim_ = dc(i, 7);
+          real lim_ = dc(i, 7);
           t = -dc(i, 5) * perr[p] - dc(i, 6) * (v[i] + delta[i] * h.dt);
-          t = fminf(fmaxf(t, -lim_), lim_);
+          t = SS_M(fmin)(SS_M(fmax)(t, -lim_), lim_);
         }
         tau[i] = t;
       }
@@ -1216,17 +1226,17 @@ struct Sim : ShapeTables<SHAPED> {
   SS_DEV void integrate() {
     fresh();
     const Hdr &h = k->h;
-    const float dt = h.dt;
+    const real dt = h.dt;
     if (lane == 0) {
-      float wx = v[3] + dt * a[3], wy = v[4] + dt * a[4], wz = v[5] + dt * a[5];
-      float nw = sqrtf(wx * wx + wy * wy + wz * wz);
-      float ang = dt * nw, ax, ay, az;
-      if (nw < 1e-15f) { ax = 1; ay = 0; az = 0; ang = 0; } else { ax = wx / nw; ay = wy / nw; az = wz / nw; }
-      float sh, ch; sincos_small(0.5f * ang, &sh, &ch);
-      float qw = q[3], qx = q[4], qy = q[5], qz = q[6];
-      float n = sqrtf(qw * qw + qx * qx + qy * qy + qz * qz);
-      if (n < 1e-15f) { qw = 1; qx = qy = qz = 0; } else { float in = 1.f / n; qw *= in; qx *= in; qy *= in; qz *= in; }
-      float rw = ch, rx = ax * sh, ry = ay * sh, rz = az * sh;
+      real wx = v[3] + dt * a[3], wy = v[4] + dt * a[4], wz = v[5] + dt * a[5];
+      real nw = SS_M(sqrt)(wx * wx + wy * wy + wz * wz);
+      real ang = dt * nw, ax, ay, az;
+      if (nw < real(1e-15)) { ax = 1; ay = 0; az = 0; ang = 0; } else { ax = wx / nw; ay = wy / nw; az = wz / nw; }
+      real sh, ch; sincos_small(0.5f * ang, &sh, &ch);
+      real qw = q[3], qx = q[4], qy = q[5], qz = q[6];
+      real n = SS_M(sqrt)(qw * qw + qx * qx + qy * qy + qz * qz);
+      if (n < real(1e-15)) { qw = 1; qx = qy = qz = 0; } else { real in = 1.f / n; qw *= in; qx *= in; qy *= in; qz *= in; }
+      real rw = ch, rx = ax * sh, ry = ay * sh, rz = az * sh;
       q[3] = qw * rw - qx * rx - qy * ry - qz * rz;
       q[4] = qw * rx + qx * rw + qy * rz - qz * ry;
       q[5] = qw * ry - qx * rz + qy * rw + qz * rx;
@@ -1237,7 +1247,7 @@ struct Sim : ShapeTables<SHAPED> {
     for (int p = 0; p < DOFP; p++) {
       int i = p * 64 + lane;
       if (i < h.nv) {
-        float vn = v[i] + dt * a[i];
+        real vn = v[i] + dt * a[i];
         v[i] = vn;
         if (i < 3) q[i] += dt * vn;
         else if (i >= 6) q[i + 1] += dt * vn;
@@ -1246,7 +1256,7 @@ struct Sim : ShapeTables<SHAPED> {
     w->sync();
   }
 
-  SS_DEV bool any_bad(const float *x, int n) {
+  SS_DEV bool any_bad(const real *x, int n) {
     int bad = 0;
     for (int i = lane; i < n; i += 64) bad |= is_bad(x[i]);
     return w->any(bad);
@@ -1264,35 +1274,35 @@ struct Sim : ShapeTables<SHAPED> {
   }
 
   // ------------------------------------------------------------------ observations (self_obs_v 1 / 2) + task tail
-  SS_DEV void write_obs(float *obs, float tar, float tar_y, float tar_z) {
+  SS_DEV void write_obs(real *obs, real tar, real tar_y, real tar_z) {
     fresh();
     const Hdr &h = k->h;
     const ss_env_cfg &cf = k->cfg;
     // heading from remove_base_rot(root quat): rotated x axis = third column of the root rotation
-    float hx = R[2], hy = R[5];
-    float hn = sqrtf(hx * hx + hy * hy);
-    float ch = 1.f, sh = 0.f;
+    real hx = R[2], hy = R[5];
+    real hn = SS_M(sqrt)(hx * hx + hy * hy);
+    real ch = 1.f, sh = 0.f;
     if (hn > 0.f) { ch = hx / hn; sh = hy / hn; }
     int o = 0;
     if (cf.root_height_obs) { if (lane == 0) obs[0] = q[2]; o = 1; }
     const int nb = h.nb, nd = 3 * (nb - 1);
     if (lane >= 1 && lane < nb) {
-      const float *rb = r + 3 * lane;
-      float *dst = obs + o + 3 * (lane - 1);
+      const real *rb = r + 3 * lane;
+      real *dst = obs + o + 3 * (lane - 1);
       dst[0] = ch * rb[0] + sh * rb[1]; dst[1] = -sh * rb[0] + ch * rb[1]; dst[2] = rb[2];
     }
     o += nd;
     if (lane < nb) {
-      const float *Rb = R + 9 * lane;
-      float *dst = obs + o + 6 * lane;
+      const real *Rb = R + 9 * lane;
+      real *dst = obs + o + 6 * lane;
       dst[0] = ch * Rb[0] + sh * Rb[3]; dst[1] = -sh * Rb[0] + ch * Rb[3]; dst[2] = Rb[6];
       dst[3] = ch * Rb[2] + sh * Rb[5]; dst[4] = -sh * Rb[2] + ch * Rb[5]; dst[5] = Rb[8];
     }
     o += 6 * nb;
     if (cf.self_obs_v == 1) {
       if (lane < 2) {
-        const float *x = v + 3 * lane;
-        float *dst = obs + o + 3 * lane;
+        const real *x = v + 3 * lane;
+        real *dst = obs + o + 3 * lane;
         dst[0] = ch * x[0] + sh * x[1]; dst[1] = -sh * x[0] + ch * x[1]; dst[2] = x[2];
       }
       o += 6;
@@ -1300,8 +1310,8 @@ struct Sim : ShapeTables<SHAPED> {
       o += nd;
     } else {
       if (lane < nb) {
-        const float *sv = k->st.body_vel + ((size_t)env * nb + lane) * 6;   // written by this lane in forward_kin
-        float *d0 = obs + o + 3 * lane, *d1 = obs + o + 3 * nb + 3 * lane;
+        const real *sv = gptr(k->st.body_vel) + ((size_t)env * nb + lane) * 6;   // written by this lane in forward_kin
+        real *d0 = obs + o + 3 * lane, *d1 = obs + o + 3 * nb + 3 * lane;
         d0[0] = ch * sv[0] + sh * sv[1]; d0[1] = -sh * sv[0] + ch * sv[1]; d0[2] = sv[2];
         d1[0] = ch * sv[3] + sh * sv[4]; d1[1] = -sh * sv[3] + ch * sv[4]; d1[2] = sv[5];
       }
@@ -1311,7 +1321,7 @@ struct Sim : ShapeTables<SHAPED> {
       if (cf.task == SS_TASK_SPEED) { obs[o] = ch; obs[o + 1] = -sh; obs[o + 2] = tar; }
       else if (cf.task == SS_TASK_GETUP) obs[o] = tar;
       else if (cf.task == SS_TASK_REACH) {                  // heading^-1 (tar_pos - root_pos), humanoid_reach.py:21-30
-        const float dx = tar - q[0], dy = tar_y - q[1];
+        const real dx = tar - q[0], dy = tar_y - q[1];
         obs[o] = ch * dx + sh * dy; obs[o + 1] = -sh * dx + ch * dy; obs[o + 2] = tar_z - q[2];
       }
     }
@@ -1334,7 +1344,7 @@ enum { SOLVE_NEWTON = 1, SOLVE_SPD = 2 };
 // instantiation because the extra epilogue costs the headline step kernel 3.7% (register allocation of the hot loops
 // shifts) even when the pointer is null — callers that do not ask for it keep the plain one.
 template <class W, int DOFP, int CANDP, int SLOTP, int NPASS, bool BODYOUT = false, bool SHAPED = false>
-SS_DEV bool run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env, int mode) {
+SS_DEV bool run_env(W *w, const KArgs *k, const uint32_t *T, real *L, int env, int mode) {
   const Hdr &h = k->h;
   const ss_env_cfg &cf = k->cfg;
   const ss_state &st = k->st;
@@ -1343,46 +1353,46 @@ SS_DEV bool run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env, 
   Sim<W, DOFP, CANDP, SLOTP, NPASS, SHAPED> sim;
   sim.init(w, k, T, L, env);
   int lane = sim.lane;
-  float *qg = st.qpos + (size_t)env * h.nq, *vg = st.qvel + (size_t)env * h.nv;
-  float *qpg = st.qpos_prev + (size_t)env * h.nq, *vpg = st.qvel_prev + (size_t)env * h.nv;
-  float *wg = st.qacc_warm + (size_t)env * h.nv;
-  float *tk = st.task + (size_t)env * 4;
-  const float *act = k->actions ? k->actions + (size_t)env * h.nu : nullptr;
-  const float *trand_base = fused_pass ? k->task_rand2 : k->task_rand;
-  const float *trand = trand_base ? trand_base + (size_t)env * 4 : nullptr;
-  const float *fa = (k->fall_actions && !fused_pass) ? k->fall_actions + (size_t)env * 3 * h.nu : nullptr;
-  float *obs_base = fused_pass ? k->obs2 : k->obs;
-  float *obs = obs_base ? obs_base + (size_t)env * k->obs_size : nullptr;
+  real *qg = gptr(st.qpos) + (size_t)env * h.nq, *vg = gptr(st.qvel) + (size_t)env * h.nv;
+  real *qpg = gptr(st.qpos_prev) + (size_t)env * h.nq, *vpg = gptr(st.qvel_prev) + (size_t)env * h.nv;
+  real *wg = gptr(st.qacc_warm) + (size_t)env * h.nv;
+  real *tk = gptr(st.task) + (size_t)env * 4;
+  const real *act = k->actions ? k->actions + (size_t)env * h.nu : nullptr;
+  const real *trand_base = fused_pass ? k->task_rand2 : k->task_rand;
+  const real *trand = trand_base ? trand_base + (size_t)env * 4 : nullptr;
+  const real *fa = (k->fall_actions && !fused_pass) ? k->fall_actions + (size_t)env * 3 * h.nu : nullptr;
+  real *obs_base = fused_pass ? k->obs2 : k->obs;
+  real *obs = obs_base ? obs_base + (size_t)env * k->obs_size : nullptr;
   // step pass of a fused launch: the post-step observation also goes to obs2 (envs that do not reset keep it)
-  float *obs_also = (!fused_pass && k->fused_reset && k->obs2) ? k->obs2 + (size_t)env * k->obs_size : nullptr;
+  real *obs_also = (!fused_pass && k->fused_reset && k->obs2) ? k->obs2 + (size_t)env * k->obs_size : nullptr;
   const int maxit = cf.newton_iters > 0 ? cf.newton_iters : 8;
 
   int cur_t = st.cur_t[env];
   // task scalars: speed/getup [target, change_steps, recovery, -] ; reach [tx, ty, tz, change_steps]
   const bool is_reach = cf.task == SS_TASK_REACH;
-  float tar = tk[0], tar_y = tk[1], tar_z = tk[2];
-  float change = is_reach ? tk[3] : tk[1], recov = is_reach ? 0.f : tk[2];
+  real tar = tk[0], tar_y = tk[1], tar_z = tk[2];
+  real change = is_reach ? tk[3] : tk[1], recov = is_reach ? 0.f : tk[2];
   int nsub = k->nsub;
   // StateInit.Fall draws action = U[0,1) - 0.5 (humanoid_env.py:487): the -0.5 is applied in the controller
-  const float abias = (mode == MODE_RESET) ? -0.5f : 0.f;
+  const real abias = (mode == MODE_RESET) ? -0.5f : 0.f;
   const bool is_debug = mode == MODE_DEBUG_FORWARD;
 
   // ---- task bookkeeping that precedes the physics (HumanoidTask.reset / pre_physics_step: update_task)
   const bool resample = (mode == MODE_RESET && cf.task != SS_TASK_BASE) ||
-                        (mode == MODE_STEP && cf.task != SS_TASK_BASE && (float)cur_t >= change);
-  if (mode == MODE_RESET && cf.task == SS_TASK_GETUP) recov = (float)cf.recovery_steps;
+                        (mode == MODE_STEP && cf.task != SS_TASK_BASE && (real)cur_t >= change);
+  if (mode == MODE_RESET && cf.task == SS_TASK_GETUP) recov = (real)cf.recovery_steps;
   if (resample) {                                            // uses the OLD cur_t on reset (reference quirk)
-    const float u0 = trand ? trand[0] : 0.f, u1 = trand ? trand[1] : 0.f, u2 = trand ? trand[2] : 0.f, u3 = trand ? trand[3] : 0.f;
+    const real u0 = trand ? trand[0] : 0.f, u1 = trand ? trand[1] : 0.f, u2 = trand ? trand[2] : 0.f, u3 = trand ? trand[3] : 0.f;
     if (cf.task == SS_TASK_SPEED) {
       tar = (cf.tar_speed_max - cf.tar_speed_min) * u0 + cf.tar_speed_min;
-      change = (float)(cur_t + cf.speed_change_min + (int)floorf(u1 * (float)(cf.speed_change_max - cf.speed_change_min)));
+      change = (real)(cur_t + cf.speed_change_min + (int)SS_M(floor)(u1 * (real)(cf.speed_change_max - cf.speed_change_min)));
     } else if (cf.task == SS_TASK_GETUP) {
       tar = (cf.tar_height_max - cf.tar_height_min) * u0 + cf.tar_height_min;
-      change = (float)(cur_t + cf.height_change_min + (int)floorf(u1 * (float)(cf.height_change_max - cf.height_change_min)));
+      change = (real)(cur_t + cf.height_change_min + (int)SS_M(floor)(u1 * (real)(cf.height_change_max - cf.height_change_min)));
     } else {                                                 // reach (humanoid_reach.py:81-92)
       tar = cf.tar_dist_max * (2.f * u0 - 1.f); tar_y = cf.tar_dist_max * (2.f * u1 - 1.f);
       tar_z = (cf.tar_height_max - cf.tar_height_min) * u2 + cf.tar_height_min;
-      change = (float)(cur_t + cf.height_change_min + (int)floorf(u3 * (float)(cf.height_change_max - cf.height_change_min)));
+      change = (real)(cur_t + cf.height_change_min + (int)SS_M(floor)(u3 * (real)(cf.height_change_max - cf.height_change_min)));
     }
   }
 
@@ -1396,8 +1406,8 @@ SS_DEV bool run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env, 
       for (int i = lane; i < h.nv; i += 64) sim.v[i] = 0.f;
       w->sync();
       if (lane == 0) {
-        if (cf.state_init == SS_INIT_DEFAULT) { sim.q[2] = 0.94f; sim.q[3] = sim.q[4] = sim.q[5] = sim.q[6] = 0.5f; }
-        else { sim.q[2] = 0.3f; sim.q[3] = 1.f; }
+        if (cf.state_init == SS_INIT_DEFAULT) { sim.q[2] = real(0.94); sim.q[3] = sim.q[4] = sim.q[5] = sim.q[6] = 0.5f; }
+        else { sim.q[2] = real(0.3); sim.q[3] = 1.f; }
       }
     }
     nsub = cf.state_init == SS_INIT_FALL ? 3 * cf.control_freq_inv : 0;
@@ -1410,7 +1420,7 @@ SS_DEV bool run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env, 
   }
   w->sync();
 
-  float prev_x = 0.f, prev_y = 0.f;
+  real prev_x = 0.f, prev_y = 0.f;
   // pass sequence: [PROLOGUE] SUBSTEP*nsub [RESETFWD | FINAL]
   int s = (nsub > 0 && !is_debug) ? -1 : 0;
   const int last_kind = mode == MODE_RESET ? K_RESETFWD : ((mode == MODE_STEP || mode == MODE_KINEMATICS) ? K_FINAL : -1);
@@ -1436,7 +1446,7 @@ SS_DEV bool run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env, 
     SS_TICK(PF_CONS);
     if (kind == K_RESETFWD) break;
     int solve = SOLVE_SPD;
-    const float *next_action = nullptr;
+    const real *next_action = nullptr;
     if (kind == K_PROLOGUE) {
       if (mode != MODE_RESET) { sim.load(sim.q, qg, h.nq); sim.load(sim.v, vg, h.nv); w->sync(); }
       prev_x = sim.q[0]; prev_y = sim.q[1];
@@ -1512,24 +1522,24 @@ SS_DEV bool run_env(W *w, const KArgs *k, const uint32_t *T, float *L, int env, 
   int term = 0, trunc = 0;                                   // wave-uniform (all inputs are)
   {
     if (mode == MODE_STEP) {
-      float rew = 0.f;
+      real rew = 0.f;
       trunc = cur_t > cf.episode_length;
       const int illegal = (touch & k->illegal_mask) != 0ull;
       if (cf.task == SS_TASK_SPEED) {
-        float dtc = (float)cf.control_freq_inv * h.dt;
-        float vx = (sim.q[0] - prev_x) / dtc, vy = (sim.q[1] - prev_y) / dtc;
-        float err = tar - vx;
-        rew = expf(-0.25f * (err * err + 0.1f * vy * vy));
+        real dtc = (real)cf.control_freq_inv * h.dt;
+        real vx = (sim.q[0] - prev_x) / dtc, vy = (sim.q[1] - prev_y) / dtc;
+        real err = tar - vx;
+        rew = SS_M(exp)(-0.25f * (err * err + real(0.1) * vy * vy));
         term = illegal;
       } else if (cf.task == SS_TASK_GETUP) {
-        float diff = tar - sim.q[2];
-        rew = expf(-4.f * diff * diff);
+        real diff = tar - sim.q[2];
+        rew = SS_M(exp)(-4.f * diff * diff);
         if (recov > 0.f) { recov -= 1.f; term = 0; trunc = 0; }
         else term = illegal;
       } else if (cf.task == SS_TASK_REACH) {                 // reach_reward on the reach body's world position
-        const float *rb = sim.r + 3 * cf.reach_body;
-        const float dx = tar - (sim.q[0] + rb[0]), dy = tar_y - (sim.q[1] + rb[1]), dz = tar_z - (sim.q[2] + rb[2]);
-        rew = expf(-4.f * (dx * dx + dy * dy + dz * dz));
+        const real *rb = sim.r + 3 * cf.reach_body;
+        const real dx = tar - (sim.q[0] + rb[0]), dy = tar_y - (sim.q[1] + rb[1]), dz = tar_z - (sim.q[2] + rb[2]);
+        rew = SS_M(exp)(-4.f * (dx * dx + dy * dy + dz * dz));
         term = illegal;
       }
       if (lane == 0) {

@@ -21,9 +21,9 @@ namespace ss {
 
 struct HostModel {
   Hdr h{};
-  std::vector<uint32_t> shared;   // tables copied into LDS once per workgroup
-  std::vector<float> bodyc;       // [nb][kBodyC]: off3 ipos3 mass Ibody6 invw_tr  (loaded into registers)
-  std::vector<float> candc;       // [ncand][kCandC]
+  std::vector<uint32_t> shared;   // tables copied into LDS once per workgroup: integer tables, then the real-valued ones
+  std::vector<real> bodyc;        // [nb][kBodyC]: off3 ipos3 mass Ibody6 invw_tr  (loaded into registers)
+  std::vector<real> candc;        // [ncand][kCandC]
   std::vector<int32_t> candb;     // [ncand] body of each candidate, bit 8: capsule
   std::vector<float> actc;        // [nv][4]: kp kd tlim (per dof, 0 for unactuated), [nv][2] scale offset -> in dofc
   std::vector<int32_t> dof_act;   // [nv] actuator index of a dof or -1
@@ -32,8 +32,8 @@ struct HostModel {
   std::string error;
 };
 
-inline uint32_t f2u(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
-inline float bits2f_host(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+// real-valued part of the shared blob (HostModel::shared from word h.o_real on)
+inline real *shared_reals(HostModel &m) { return reinterpret_cast<real *>(m.shared.data() + m.h.o_real); }
 
 inline void quat2mat(const double *q, double *m) {
   double w = q[0], x = q[1], y = q[2], z = q[3];
@@ -88,7 +88,7 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   for (int i = 0; i < 6; i++)                              // the root solve treats the free joint as a plain 6x6 system
     if (d.dof_armature[i] != 0.0) { out.error = "armature on the free joint is not supported"; return false; }
   // ---- dof constants: arm, lo, hi, limited, invw, kp, kd, tlim, ascale, aoffset, actuated, pad
-  std::vector<float> dofc(nv * kDofC, 0.f);
+  std::vector<real> dofc(nv * kDofC, real(0));
   out.dof_act.assign(nv, -1);
   for (int i = 0; i < d.nu; i++) {
     int dof = d.actuator_dof[i];
@@ -96,32 +96,32 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
     out.dof_act[dof] = i;
   }
   for (int i = 0; i < nv; i++) {
-    float *c = &dofc[i * kDofC];
-    c[0] = (float)d.dof_armature[i];
-    c[1] = (float)d.jnt_range[2 * i]; c[2] = (float)d.jnt_range[2 * i + 1];
+    real *c = &dofc[i * kDofC];
+    c[0] = (real)d.dof_armature[i];
+    c[1] = (real)d.jnt_range[2 * i]; c[2] = (real)d.jnt_range[2 * i + 1];
     c[3] = (i >= 6 && d.jnt_limited[i]) ? 1.f : 0.f;
-    c[4] = (float)d.dof_invweight0[i];
+    c[4] = (real)d.dof_invweight0[i];
     int a = out.dof_act[i];
     if (a >= 0) {
-      c[5] = (float)d.kp[a]; c[6] = (float)d.kd[a]; c[7] = (float)d.torque_lim[a];
-      c[8] = (float)d.act_scale[a]; c[9] = (float)d.act_offset[a]; c[10] = 1.f; c[11] = (float)a;
+      c[5] = (real)d.kp[a]; c[6] = (real)d.kd[a]; c[7] = (real)d.torque_lim[a];
+      c[8] = (real)d.act_scale[a]; c[9] = (real)d.act_offset[a]; c[10] = 1.f; c[11] = (real)a;
     } else c[11] = -1.f;
   }
 
   // ---- body constants (registers): off3 ipos3 mass Ibody(xx xy xz yy yz zz) invw_tr
-  out.bodyc.assign(nb * kBodyC, 0.f);
+  out.bodyc.assign(nb * kBodyC, real(0));
   for (int b = 0; b < nb; b++) {
-    float *c = &out.bodyc[b * kBodyC];
-    for (int k = 0; k < 3; k++) { c[k] = (float)d.body_pos[3 * b + k]; c[3 + k] = (float)d.body_ipos[3 * b + k]; }
-    c[6] = (float)d.body_mass[b];
+    real *c = &out.bodyc[b * kBodyC];
+    for (int k = 0; k < 3; k++) { c[k] = (real)d.body_pos[3 * b + k]; c[3 + k] = (real)d.body_ipos[3 * b + k]; }
+    c[6] = (real)d.body_mass[b];
     double R[9]; quat2mat(d.body_iquat + 4 * b, R);
     double I[9];
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
       double s = 0; for (int k = 0; k < 3; k++) s += R[3 * i + k] * d.body_inertia[3 * b + k] * R[3 * j + k];
       I[3 * i + j] = s;
     }
-    c[7] = (float)I[0]; c[8] = (float)I[1]; c[9] = (float)I[2]; c[10] = (float)I[4]; c[11] = (float)I[5]; c[12] = (float)I[8];
-    c[13] = (float)d.body_invweight0[2 * b];
+    c[7] = (real)I[0]; c[8] = (real)I[1]; c[9] = (real)I[2]; c[10] = (real)I[4]; c[11] = (real)I[5]; c[12] = (real)I[8];
+    c[13] = (real)d.body_invweight0[2 * b];
   }
   // root offset is the initial position, not a parent-frame offset
   out.bodyc[0] = out.bodyc[1] = out.bodyc[2] = 0.f;
@@ -134,12 +134,12 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
     for (int i = 0; i < 8; i++) {
       double v[3] = {(i & 1) ? d.geom_size[3 * b] : -d.geom_size[3 * b], (i & 2) ? d.geom_size[3 * b + 1] : -d.geom_size[3 * b + 1],
                      (i & 4) ? d.geom_size[3 * b + 2] : -d.geom_size[3 * b + 2]};
-      float c[kCandC] = {0};
+      real c[kCandC] = {0};
       for (int r = 0; r < 3; r++) {
-        c[r] = (float)(G[3 * r] * v[0] + G[3 * r + 1] * v[1] + G[3 * r + 2] * v[2]);   // corner vector (body frame)
-        c[3 + r] = (float)d.geom_pos[3 * b + r];                                        // box centre (body frame)
+        c[r] = (real)(G[3 * r] * v[0] + G[3 * r + 1] * v[1] + G[3 * r + 2] * v[2]);    // corner vector (body frame)
+        c[3 + r] = (real)d.geom_pos[3 * b + r];                                         // box centre (body frame)
       }
-      c[7] = (float)d.body_invweight0[2 * b];
+      c[7] = (real)d.body_invweight0[2 * b];
       out.candc.insert(out.candc.end(), c, c + kCandC); out.candb.push_back(b);
     }
   }
@@ -148,13 +148,13 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
     double G[9]; quat2mat(d.geom_quat + 4 * b, G);
     for (int s = 0; s < 2; s++) {
       double sg = s ? -1.0 : 1.0;
-      float c[kCandC] = {0};
+      real c[kCandC] = {0};
       for (int r = 0; r < 3; r++) {
-        c[r] = (float)(d.geom_pos[3 * b + r] + sg * G[3 * r + 2] * d.geom_size[3 * b + 1]);  // end-sphere centre (body frame)
-        c[3 + r] = (float)G[3 * r + 2];                                                      // capsule axis (body frame)
+        c[r] = (real)(d.geom_pos[3 * b + r] + sg * G[3 * r + 2] * d.geom_size[3 * b + 1]);   // end-sphere centre (body frame)
+        c[3 + r] = (real)G[3 * r + 2];                                                       // capsule axis (body frame)
       }
-      c[6] = (float)d.geom_size[3 * b];                                                      // radius
-      c[7] = (float)d.body_invweight0[2 * b];
+      c[6] = (real)d.geom_size[3 * b];                                                       // radius
+      c[7] = (real)d.body_invweight0[2 * b];
       out.candc.insert(out.candc.end(), c, c + kCandC); out.candb.push_back(b | 256);
     }
   }
@@ -198,9 +198,10 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   for (int L = 0; L < nlev; L++) h.nkpack[L >> 4] |= (unsigned long long)(levstart[L + 1] - levstart[L] - 1) << (4 * (L & 15));
   auto &S = out.shared; S.clear();
   auto push_i = [&](const std::vector<int> &v) { int o = (int)S.size(); for (int x : v) S.push_back((uint32_t)x); return o; };
-  h.o_dofc = (int)S.size(); for (float f : dofc) S.push_back(f2u(f));
-  h.o_boff = (int)S.size();                                // body frame offsets in the parent frame (chain walk of forward_kin)
-  for (int b = 0; b < nb; b++) for (int k = 0; k < 3; k++) S.push_back(f2u(b == 0 ? 0.f : (float)d.body_pos[3 * b + k]));
+  std::vector<real> Sf;                                    // real-valued tables, appended behind the integer ones below
+  h.o_dofc = (int)Sf.size(); Sf.insert(Sf.end(), dofc.begin(), dofc.end());
+  h.o_boff = (int)Sf.size();                               // body frame offsets in the parent frame (chain walk of forward_kin)
+  for (int b = 0; b < nb; b++) for (int k = 0; k < 3; k++) Sf.push_back(b == 0 ? real(0) : (real)d.body_pos[3 * b + k]);
   h.o_chainnode = push_i(chainnode);
   h.o_ndepth = push_i(ndepth);
   h.o_lev = push_i(lev);
@@ -245,6 +246,10 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
     h.n_sumsmall = (int)small_l.size(); h.n_sumbig = (int)big_l.size();
     h.o_sumsmall = push_i(small_l); h.o_sumbig = push_i(big_l); h.o_sumcover = push_i(cover);
   }
+  while (S.size() % 4) S.push_back(0u);                     // reals start 16-byte aligned
+  h.o_real = (int)S.size();
+  S.resize(S.size() + Sf.size() * (sizeof(real) / 4));
+  std::memcpy(S.data() + h.o_real, Sf.data(), Sf.size() * sizeof(real));
   h.shared_words = (int)S.size();
   (void)blevstart; (void)blevbodies;
 
@@ -275,13 +280,13 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   h.l_R = h.l_Wst; h.l_r = h.l_Wst + 9 * nb;               // R, r: forward kinematics .. constraints / observations
   h.env_floats = o;
 
-  h.dt = (float)d.timestep; h.grav = (float)d.gravity; h.margin = (float)d.margin; h.mu = (float)d.friction;
-  for (int k = 0; k < 5; k++) h.solimp[k] = (float)d.solimp[k];
+  h.dt = (real)d.timestep; h.grav = (real)d.gravity; h.margin = (real)d.margin; h.mu = (real)d.friction;
+  for (int k = 0; k < 5; k++) h.solimp[k] = (real)d.solimp[k];
   double dmax = d.solimp[1];
   double tc = d.solref[0] < 2 * d.timestep ? 2 * d.timestep : d.solref[0];
-  h.K = (float)(1.0 / (dmax * dmax * tc * tc * d.solref[1] * d.solref[1]));
-  h.B = (float)(2.0 / (dmax * tc));
-  for (int k = 0; k < 3; k++) h.qpos0_root[k] = (float)d.qpos0[k];
+  h.K = (real)(1.0 / (dmax * dmax * tc * tc * d.solref[1] * d.solref[1]));
+  h.B = (real)(2.0 / (dmax * tc));
+  for (int k = 0; k < 3; k++) h.qpos0_root[k] = (real)d.qpos0[k];
   if (d.impratio != 1.0) { out.error = "impratio != 1 is not supported"; return false; }
   return true;
 }

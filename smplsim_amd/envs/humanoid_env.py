@@ -126,21 +126,27 @@ class HumanoidEnv:
     def seed(self, seed=None):
         self.np_random = np.random.default_rng(seed)
 
-    def _rands(self):
+    def _fall_rand(self):
+        """StateInit.Fall draws action = np_random.random(nu) - 0.5 three times, in init_humanoid only (humanoid_env.py:485-488):
+        self.np_random advances on resets and never between them."""
         import torch
         v = self._vec
-        fa = tr = None
-        if v.state_init == 1:   # Fall: action = np_random.random(nu) - 0.5, three times (humanoid_env.py:485-488)
-            fa = torch.as_tensor(self.np_random.random((v.num_envs, 3, v.nu)), dtype=torch.float32, device=v.device)
-        if v.task_id != 0:      # task targets use the global numpy RNG in the reference (humanoid_speed.py:97-103)
-            tr = torch.as_tensor(np.random.random((v.num_envs, 4)), dtype=torch.float32, device=v.device)
-        return fa, tr
+        if v.state_init != 1:
+            return None
+        return torch.as_tensor(self.np_random.random((v.num_envs, 3, v.nu)), dtype=torch.float32, device=v.device)
+
+    def _task_rand(self):
+        """Task targets use the global numpy RNG in the reference (humanoid_speed.py:97-103), on reset and on target changes."""
+        import torch
+        v = self._vec
+        if v.task_id == 0:
+            return None
+        return torch.as_tensor(np.random.random((v.num_envs, 4)), dtype=torch.float32, device=v.device)
 
     def reset(self, seed=None, options=None):
         if seed is not None:
             self.seed(seed)
-        fa, tr = self._rands()
-        obs, _ = self._vec.reset(fall_actions=fa, task_rand=tr)
+        obs, _ = self._vec.reset(fall_actions=self._fall_rand(), task_rand=self._task_rand())
         self.cur_t = 0
         o = obs[0].cpu().numpy().astype(self.dtype)
         return o, {"critic_state": o}
@@ -149,8 +155,7 @@ class HumanoidEnv:
         import torch
         v = self._vec
         a = torch.as_tensor(np.asarray(action, dtype=np.float32)[None, : v.nu], device=v.device)
-        _, tr = self._rands() if v.task_id != 0 else (None, None)
-        obs, rew, term, trunc, _ = v.step(a, task_rand=tr)
+        obs, rew, term, trunc, _ = v.step(a, task_rand=self._task_rand())
         self.cur_t += 1
         o = obs[0].cpu().numpy().astype(self.dtype)
         info = dict(self.reward_info)

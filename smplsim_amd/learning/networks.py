@@ -61,15 +61,16 @@ class RunningNorm(nn.Module):
     def forward(self, x):
         if self.training:
             self.update(x)
-        if int(self.n) == 0:
-            return x
+        y = x
         if self.demean:
-            x = x - self.mean
+            y = y - self.mean
         if self.destd:
-            x = x / (self.std + 1e-8)
+            y = y / (self.std + 1e-8)
         if self.clip:
-            x = x.clamp(-self.clip, self.clip)
-        return x
+            y = y.clamp(-self.clip, self.clip)
+        # identity until the first update (reference running_norm.py) — selected on the device: reading `n` on the host
+        # would synchronise the stream once per policy forward, i.e. once per env step of the sampler
+        return torch.where(self.n > 0, y, x)
 
 
 class PolicyGaussian(nn.Module):

@@ -1,0 +1,177 @@
+"""Per-sample parity triage on the benchmark's own state distribution (test infrastructure).
+
+One *sample* = one control step (15 mj_steps) of one env: the pre-step state the stepper holds in HBM
+(qpos, qvel, the stale qpos_prev/qvel_prev the Stable-PD controller's M and C come from, the solver warm start),
+the action, and the float32 post-step state some implementation of the kernel produced (the GPU, or the wavefront
+emulator).  Every sample is replayed from exactly that pre-step state by
+
+  oracle        oracle/oracle.c, float64, different formulation, Newton run to its own tolerance
+  f64           the kernel source instantiated in float64 on the emulator (tests/wave_emu, -DSS_F64), Newton to convergence
+  f64 cap       the same with the product's Newton cap (8 iterations per mj_step)
+  f64 perturbed f64 again from inputs perturbed by half a float32 ulp (relative 2^-24, random signs): the response of the
+                one-control-step map to float32-sized input noise = the sample's conditioning
+
+which separates the three things a float32-vs-oracle difference can be made of:
+  formulation   f64 vs oracle        (must be at the float64 rounding level times the conditioning)
+  precision     float32 vs f64 cap   (must be at the float32 rounding level times the conditioning)
+  Newton cap    f64 cap vs f64       (reported; a property of the product's iteration cap, not of the arithmetic)
+Errors are relative to the sample's velocity scale max(1, |qvel|_max) like in test_gpu_parity.py.
+"""
+import concurrent.futures as cf
+import os
+
+import numpy as np
+
+from helpers import FEET, model_const, oracle_model, pd_tables
+from oracle import oracle as O
+from wave_emu import emu
+
+EPS32, EPS64 = 2.0 ** -24, 2.0 ** -53
+FIELDS = ("qpos", "qvel", "qpos_prev", "qvel_prev", "qacc_warm")
+
+
+def n_threads():
+    return max(1, min(16, len(os.sched_getaffinity(0))))
+
+
+def _chunks(n, k):
+    k = max(1, min(k, n))
+    b = [n * i // k for i in range(k + 1)]
+    return [(b[i], b[i + 1]) for i in range(k) if b[i + 1] > b[i]]
+
+
+def emu_step(pre, actions, f64, newton_iters, humanoid="smpl_humanoid", task="HumanoidEnv", task_state=None, cur_t=None,
+             task_rand=None, **cfg):
+    """One control step of len(actions) independent envs on the emulator from the given pre-step arrays (threaded).
+    Returns dict(qpos, qvel, obs, reward, terminated, truncated, nwarn, iters)."""
+    from smplsim_amd import _cabi
+    n = len(actions)
+    mc = model_const(humanoid)
+    out = {}
+
+    def run(lo_hi):
+        lo, hi = lo_hi
+        eb = emu.EmuBatch(mc, pd_tables(mc), hi - lo, legal_bodies=FEET, f64=f64, newton_iters=newton_iters,
+                          task=_cabi.TASKS[task], **cfg)
+        eb.set_state(pre["qpos"][lo:hi], pre["qvel"][lo:hi], pre["qpos_prev"][lo:hi], pre["qvel_prev"][lo:hi], pre["qacc_warm"][lo:hi])
+        if task_state is not None:
+            eb.task[:] = task_state[lo:hi]
+        if cur_t is not None:
+            eb.cur_t[:] = cur_t[lo:hi]
+        obs, rew, term, trunc = eb.step(actions[lo:hi], None if task_rand is None else task_rand[lo:hi])
+        return lo, hi, dict(qpos=eb.qpos.astype(np.float64), qvel=eb.qvel.astype(np.float64), obs=obs.astype(np.float64),
+                            reward=rew.astype(np.float64), terminated=term, truncated=trunc, nwarn=eb.nwarn.copy(),
+                            iters=eb.solver_iters.copy())
+
+    with cf.ThreadPoolExecutor(n_threads()) as ex:
+        for lo, hi, r in ex.map(run, _chunks(n, n_threads())):
+            for k, v in r.items():
+                out.setdefault(k, np.zeros((n,) + v.shape[1:], v.dtype))[lo:hi] = v
+    return out
+
+
+def oracle_step(pre, actions, humanoid="smpl_humanoid"):
+    """The same control step by the float64 oracle (base task: state only), threaded."""
+    om = oracle_model(humanoid)
+    n = len(actions)
+    q, v, nw = np.zeros((n, om.nq)), np.zeros((n, om.nv)), np.zeros(n, np.int32)
+
+    def run(lo_hi):
+        for i in range(*lo_hi):
+            d = O.OracleData(om)
+            d.qpos = pre["qpos_prev"][i]; d.qvel = pre["qvel_prev"][i]; d.forward()      # stale M, C of the last mj_forward
+            d.qpos = pre["qpos"][i]; d.qvel = pre["qvel"][i]; d.warm = pre["qacc_warm"][i]
+            for _ in range(15):
+                d.ctrl = d.spd_torque(actions[i]); d.step()
+            q[i], v[i], nw[i] = d.qpos, d.qvel, d.nwarn
+
+    with cf.ThreadPoolExecutor(n_threads()) as ex:
+        list(ex.map(run, _chunks(n, n_threads())))
+    return dict(qpos=q, qvel=v, nwarn=nw)
+
+
+def rollout_samples_emu(n_envs, n_steps, seed, skip=8, humanoid="smpl_humanoid", amp=1.0, task="HumanoidEnv", state_init="Default",
+                        **cfg):
+    """Benchmark-distribution samples made on the float32 emulator: n_envs envs under fresh uniform(-amp, amp) actions with
+    the vector env's autoreset (Fall resets draw their own actions); every (env, step >= skip) whose episode did not end in
+    that step is a sample.  Returns (pre dict of [S, ...] float64 arrays, actions [S, nu], float32 post dict)."""
+    from smplsim_amd import _cabi
+    mc = model_const(humanoid)
+    rs = np.random.default_rng(seed)
+    acts = rs.uniform(-amp, amp, (n_steps, n_envs, mc.nu))
+    trand = rs.uniform(size=(n_steps, 2, n_envs, 4))
+    falls = rs.uniform(size=(n_steps + 1, n_envs, 3, mc.nu))
+    pres, posts, A = [], [], []
+
+    def run(lo_hi):
+        lo, hi = lo_hi
+        eb = emu.EmuBatch(mc, pd_tables(mc), hi - lo, legal_bodies=FEET, task=_cabi.TASKS[task], state_init=_cabi.STATE_INITS[state_init], **cfg)
+        eb.reset(fall_actions=falls[n_steps, lo:hi], task_rand=trand[0, 1, lo:hi])
+        recs = []
+        for t in range(n_steps):
+            pre = {k: getattr(eb, k).astype(np.float64) for k in FIELDS}
+            pre["task"], pre["cur_t"], pre["task_rand"] = eb.task.astype(np.float64), eb.cur_t.copy(), trand[t, 0, lo:hi]
+            nw0 = eb.nwarn.copy()
+            obs, rew, term, trunc = eb.step(acts[t, lo:hi], trand[t, 0, lo:hi])
+            keep = ~(term | trunc)
+            if t >= skip and keep.any():
+                recs.append(({k: v[keep] for k, v in pre.items()}, acts[t, lo:hi][keep],
+                             dict(qpos=eb.qpos.astype(np.float64)[keep], qvel=eb.qvel.astype(np.float64)[keep], obs=obs.astype(np.float64)[keep],
+                                  reward=rew.astype(np.float64)[keep], nwarn=(eb.nwarn - nw0)[keep], iters=eb.solver_iters.copy()[keep])))
+            if (~keep).any():
+                eb.reset(mask=~keep, fall_actions=falls[t, lo:hi], task_rand=trand[t, 1, lo:hi])
+        return recs
+
+    with cf.ThreadPoolExecutor(n_threads()) as ex:
+        for recs in ex.map(run, _chunks(n_envs, n_threads())):
+            for pre, a, post in recs:
+                pres.append(pre); A.append(a); posts.append(post)
+    pre = {k: np.concatenate([p[k] for p in pres]) for k in pres[0]}
+    post = {k: np.concatenate([p[k] for p in posts]) for k in posts[0]}
+    return pre, np.concatenate(A), post
+
+
+def perturb(pre, seed, rel=EPS32):
+    """Inputs moved by `rel` times the magnitude of their field in that sample (random signs): one float32 rounding at the
+    scale of the vector's largest entry — what a float32 sum over the vector carries — not of each entry."""
+    rs = np.random.default_rng(seed)
+    out = {}
+    for k in FIELDS:
+        x = pre[k]
+        mag = np.maximum(np.abs(x).max(axis=1, keepdims=True), 1.0 if k.startswith("qpos") else 0.0)
+        out[k] = x + rel * mag * rs.choice([-1.0, 1.0], size=x.shape)
+    return out
+
+
+def rel_err(a, b):
+    """[S, 2]: max |dqpos|, max |dqvel| per sample, relative to the sample's velocity scale."""
+    scale = np.maximum(1.0, np.abs(b["qvel"]).max(axis=1))
+    return np.stack([np.abs(a["qpos"] - b["qpos"]).max(axis=1) / scale, np.abs(a["qvel"] - b["qvel"]).max(axis=1) / scale], 1)
+
+
+def triage(pre, actions, post32, humanoid="smpl_humanoid", cap=8, n_perturb=4, task="HumanoidEnv", **cfg):
+    """Replays of every sample (module docstring).  Returns a dict of [S, 2] relative error arrays + bookkeeping."""
+    kw = dict(humanoid=humanoid, task=task, task_state=pre.get("task"), cur_t=pre.get("cur_t"), task_rand=pre.get("task_rand"), **cfg)
+    orc = oracle_step(pre, actions, humanoid)
+    f64 = emu_step(pre, actions, True, 100, **kw)
+    f64cap = emu_step(pre, actions, True, cap, **kw)
+    cond = np.zeros((len(actions), 2))
+    for s in range(n_perturb):
+        p = emu_step(perturb(pre, 100 + s), actions, True, 100, **kw)
+        cond = np.maximum(cond, rel_err(p, f64) / EPS32)        # output error per unit of relative input error
+    # a sample is "reset" when any implementation hit MuJoCo's bad-state autoreset inside the step (|x| > 1e10): the state
+    # was replaced by qpos0 then, which is a discontinuity of the map — compared only through the reset flags
+    reset = (orc["nwarn"] > 0) | (f64["nwarn"] > 0) | (f64cap["nwarn"] > 0) | (post32["nwarn"] > 0)
+    extra = {}
+    if "obs" in post32:                                          # observation / reward of the float32 kernel vs its float64 twin
+        vs = np.maximum(1.0, np.abs(f64cap["qvel"]).max(axis=1))
+        extra = dict(obs=np.abs(post32["obs"] - f64cap["obs"]).max(axis=1) / vs, reward=np.abs(post32["reward"] - f64cap["reward"]), vscale=vs)
+    return dict(**extra, formulation=rel_err(f64, orc), precision=rel_err(post32, f64cap), cap_gap=rel_err(f64cap, f64),
+                f32_vs_oracle=rel_err(post32, orc), cond=cond, reset=reset,
+                resets_agree=(orc["nwarn"] > 0) == (f64["nwarn"] > 0), iters=f64["iters"], iters_cap=f64cap["iters"])
+
+
+def summarize(name, e, mask):
+    e = e[mask]
+    q = lambda p: np.quantile(e, p, axis=0)
+    return f"{name:14s} n={len(e):4d}  median {q(0.5)}  p90 {q(0.9)}  p99 {q(0.99)}  max {e.max(axis=0)}"

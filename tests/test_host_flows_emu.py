@@ -1,21 +1,13 @@
 """The Python host logic of the batched envs (smplsim_amd/batch.py, imitation.py, shapes.py) run end to end in the GPU-less
-container: the package is pointed at the CPU emulator build of the same C ABI through its unit-test hook
-(smplsim_amd._lib.use_test_backend) and works on host tensors.  The GPU twins are in test_gpu_parity.py."""
+container: the `emu_backend` fixture (tests/conftest.py) monkeypatches the package's library handle, device choice and
+stream lookup onto the CPU emulator build of the same C ABI and host tensors — the package itself has no backend switch.
+The GPU twins are in test_gpu_parity.py."""
 import numpy as np
 import pytest
 import torch
 
 from helpers import oracle_model
 from oracle import oracle as O
-
-
-@pytest.fixture()
-def emu_backend():
-    from smplsim_amd import _lib
-    from wave_emu import emu
-    _lib.use_test_backend(emu.lib())
-    yield emu.lib()
-    _lib.use_test_backend(None)
 
 
 def test_vec_env_autoreset_flows_on_the_emulator(emu_backend):
@@ -92,6 +84,11 @@ def test_per_env_shapes_through_the_python_api_on_the_emulator(emu_backend):
         SMPLSimVecEnv(2, model=ShardModel(xmls=xmls), shape_id=[0, 5])
 
 
-def test_hook_is_off_by_default():
-    from smplsim_amd import _lib
-    assert _lib.test_device() is None
+def test_package_has_no_backend_switch():
+    """The emulator is reachable only through the monkeypatches of the fixture: outside it the package holds no CPU device
+    or alternative library, and its loader exposes nothing to bind one."""
+    from smplsim_amd import _lib, batch
+    assert not hasattr(_lib, "use_test_backend") and not hasattr(_lib, "test_device")
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            batch._shard_device(0)

@@ -44,6 +44,7 @@ emu_switch:
 
 namespace {
 
+using ss::real;
 constexpr int kLanes = 64;
 constexpr size_t kStack = 256 * 1024;
 
@@ -55,8 +56,8 @@ struct Machine {
   void *main_sp = nullptr;
   int cur = -1;
   int done[kLanes];
-  // collective scratch
-  float fx[kLanes];
+  // collective scratch (double holds both builds' values exactly)
+  double fx[kLanes];
   unsigned long long ux[kLanes];
   int siteh[4][kLanes];
   unsigned narr[kLanes];
@@ -126,17 +127,17 @@ struct WaveEmu {
     yield_to_next(m);
   }
   void sync() { arrive(1); }
-  float sum(float v) {
+  real sum(real v) {
     m->fx[ln] = v;
     arrive(2);
-    float t[kLanes];
+    real t[kLanes];
     for (int i = 0; i < kLanes; i++) t[i] = m->fx[i];
     for (int mask = 32; mask >= 1; mask >>= 1) {            // same butterfly order as the GPU's __shfl_xor ladder
-      float n[kLanes];
+      real n[kLanes];
       for (int i = 0; i < kLanes; i++) n[i] = t[i] + t[i ^ mask];
       memcpy(t, n, sizeof t);
     }
-    float r = t[ln];
+    real r = t[ln];
     arrive(3);                                              // nobody overwrites fx before everyone has read it
     return r;
   }
@@ -156,10 +157,10 @@ struct WaveEmu {
     arrive(7);
     return r;
   }
-  float shfl_xor(float v, int mask) {
+  real shfl_xor(real v, int mask) {
     m->fx[ln] = v;
     arrive(8);
-    float r = m->fx[ln ^ mask];
+    real r = m->fx[ln ^ mask];
     arrive(9);
     return r;
   }
@@ -170,16 +171,16 @@ struct WaveEmu {
     arrive(11);
     return r;
   }
-  float sum8(float v) {                                      // sum over the lane's aligned group of 8
+  real sum8(real v) {                                        // sum over the lane's aligned group of 8
     m->fx[ln] = v;
     arrive(12);
-    float r = 0.f;
+    real r = 0;
     for (int i = 0; i < 8; i++) r += m->fx[(ln & ~7) + i];
     arrive(13);
     return r;
   }
-  float quad_xor1(float v) { return shfl_xor(v, 1); }
-  float quad_xor2(float v) { return shfl_xor(v, 2); }
+  real quad_xor1(real v) { return shfl_xor(v, 1); }
+  real quad_xor2(real v) { return shfl_xor(v, 2); }
   int quad_xor1_i(int v) { return shfl_xor_i(v, 1); }
   int quad_xor2_i(int v) { return shfl_xor_i(v, 2); }
   bool any(int p) { return ballot(p) != 0ull; }
@@ -188,10 +189,10 @@ struct WaveEmu {
   void mem_fence() { sync(); }                               // all lanes' stores done before anyone reads them back
   unsigned long long clock() { return 0; }
   void atomic_add_u64(unsigned long long *p, unsigned long long v) { *p += v; }
-  void atomic_add(float *p, float v) { *p += v; }
+  void atomic_add(real *p, real v) { *p += v; }
 };
 
-struct LaunchCtx { const ss::KArgs *k; const uint32_t *T; float *L; int env; Machine *m; };
+struct LaunchCtx { const ss::KArgs *k; const uint32_t *T; ss::real *L; int env; Machine *m; };
 
 template <int DOFP, int CANDP, int SLOTP, int NPASS, bool SHAPED>
 void lane_entry(int lane, void *arg) {
@@ -275,7 +276,7 @@ struct EmuBackend {
   static const char *launch(const ss::KArgs &k, int nenv, int envs_per_wg, size_t lds_bytes, void *, int, int) {
     (void)envs_per_wg; (void)lds_bytes;
     static thread_local Machine *m = new Machine();
-    std::vector<float> L(k.h.env_floats);
+    std::vector<ss::real> L(k.h.env_floats);
     *k.work_counter = 0;
     for (int env = 0; env < nenv; env++) {
       // poison LDS so that reads of never-written locations are visible

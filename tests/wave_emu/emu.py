@@ -13,34 +13,38 @@ import numpy as np
 from smplsim_amd import _cabi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = None
+_LIBS = {}
 
 
-def lib():
-    global _LIB
-    if _LIB is None:
-        subprocess.check_call(["make", "-s", "-C", _HERE, "libss_emu.so"])
-        _LIB = _cabi.bind(C.CDLL(os.path.join(_HERE, "libss_emu.so")))
-    return _LIB
+def lib(f64=False):
+    """f64=True: the float64 instantiation of the same kernel source (-DSS_F64, Newton run to convergence): every array of
+    the C ABI declared float* is then a float64 array."""
+    name = "libss_emu64.so" if f64 else "libss_emu.so"
+    if name not in _LIBS:
+        subprocess.check_call(["make", "-s", "-C", _HERE, name])
+        _LIBS[name] = _cabi.bind(C.CDLL(os.path.join(_HERE, name)))
+    return _LIBS[name]
 
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-def _rand4(tr, n):
+def _rand4(tr, n, ft=np.float32):
     if tr is None:
         return None
-    t = np.zeros((n, 4), np.float32)
-    a = np.asarray(tr, np.float32).reshape(n, -1)
+    t = np.zeros((n, 4), ft)
+    a = np.asarray(tr, ft).reshape(n, -1)
     t[:, :a.shape[1]] = a
     return t
 
 
 class EmuBatch:
-    def __init__(self, mc, tables, num_envs, legal_bodies=(), timestep=1.0 / 450, shape_mcs=None, shape_id=None, **cfg):
-        """shape_mcs: list of ModelConst = body shapes of one humanoid (ss_model_create_shapes), shape_id [N] picks per env."""
-        L = lib()
+    def __init__(self, mc, tables, num_envs, legal_bodies=(), timestep=1.0 / 450, shape_mcs=None, shape_id=None, f64=False, **cfg):
+        """shape_mcs: list of ModelConst = body shapes of one humanoid (ss_model_create_shapes), shape_id [N] picks per env.
+        f64: run the float64 instantiation of the kernel (state / action / observation arrays are float64 then)."""
+        L = self.L = lib(f64)
+        ft = self.ft = np.float64 if f64 else np.float32
         self.mc = mc
         self.model = C.c_void_p()
         self.shape_id = None
@@ -57,13 +61,13 @@ class EmuBatch:
         self.cfg = _cabi.make_env_cfg(**cfg)
         N, nq, nv, nb = num_envs, mc.nq, mc.nv, mc.nbody
         self.N = N
-        self.qpos = np.zeros((N, nq), np.float32); self.qvel = np.zeros((N, nv), np.float32)
-        self.qpos_prev = np.zeros((N, nq), np.float32); self.qvel_prev = np.zeros((N, nv), np.float32)
-        self.qacc_warm = np.zeros((N, nv), np.float32); self.body_vel = np.zeros((N, nb, 6), np.float32)
+        self.qpos = np.zeros((N, nq), ft); self.qvel = np.zeros((N, nv), ft)
+        self.qpos_prev = np.zeros((N, nq), ft); self.qvel_prev = np.zeros((N, nv), ft)
+        self.qacc_warm = np.zeros((N, nv), ft); self.body_vel = np.zeros((N, nb, 6), ft)
         self.touch = np.zeros((N, 2), np.int32); self.cur_t = np.zeros(N, np.int32)
-        self.task = np.zeros((N, 4), np.float32); self.nwarn = np.zeros(N, np.int32)
+        self.task = np.zeros((N, 4), ft); self.nwarn = np.zeros(N, np.int32)
         self.solver_iters = np.zeros(N, np.int32)
-        self.pid_integral = np.zeros((N, mc.nu), np.float32); self.pid_last_error = np.zeros((N, mc.nu), np.float32)
+        self.pid_integral = np.zeros((N, mc.nu), ft); self.pid_last_error = np.zeros((N, mc.nu), ft)
         self.pid_started = np.zeros(N, np.int32)
         self.qpos[:, 3] = 1; self.qpos_prev[:, 3] = 1
         st = _cabi.State(N, *[_p(x) for x in (self.qpos, self.qvel, self.qpos_prev, self.qvel_prev, self.qacc_warm,
@@ -73,13 +77,13 @@ class EmuBatch:
         self.batch = C.c_void_p()
         self._chk(L.ss_batch_create(self.model, C.byref(self.cfg), C.byref(st), C.byref(self.batch)))
         self.obs_size = L.ss_obs_size(self.model, C.byref(self.cfg))
-        self.obs = np.zeros((N, self.obs_size), np.float32)
-        self.reward = np.zeros(N, np.float32)
+        self.obs = np.zeros((N, self.obs_size), ft)
+        self.reward = np.zeros(N, ft)
         self.terminated = np.zeros(N, np.uint8); self.truncated = np.zeros(N, np.uint8)
 
     def _chk(self, rc):
         if rc != 0:
-            raise RuntimeError(f"ss error {rc}: {lib().ss_last_error().decode()}")
+            raise RuntimeError(f"ss error {rc}: {self.L.ss_last_error().decode()}")
 
     def set_state(self, qpos, qvel, qpos_prev=None, qvel_prev=None, warm=None):
         self.qpos[:] = qpos; self.qvel[:] = qvel
@@ -90,43 +94,43 @@ class EmuBatch:
 
     def reset(self, mask=None, fall_actions=None, task_rand=None):
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
-        fa = None if fall_actions is None else np.ascontiguousarray(fall_actions, np.float32)
-        tr = _rand4(task_rand, self.N)
-        self._chk(lib().ss_reset(self.batch, _p(m), _p(fa), _p(tr), _p(self.obs), None))
+        fa = None if fall_actions is None else np.ascontiguousarray(fall_actions, self.ft)
+        tr = _rand4(task_rand, self.N, self.ft)
+        self._chk(self.L.ss_reset(self.batch, _p(m), _p(fa), _p(tr), _p(self.obs), None))
         return self.obs.copy()
 
     def step(self, actions, task_rand=None):
-        a = np.ascontiguousarray(actions, np.float32)
-        tr = _rand4(task_rand, self.N)
-        self._chk(lib().ss_step(self.batch, _p(a), _p(tr), _p(self.obs), _p(self.reward), _p(self.terminated),
+        a = np.ascontiguousarray(actions, self.ft)
+        tr = _rand4(task_rand, self.N, self.ft)
+        self._chk(self.L.ss_step(self.batch, _p(a), _p(tr), _p(self.obs), _p(self.reward), _p(self.terminated),
                                 _p(self.truncated), None))
         return self.obs.copy(), self.reward.copy(), self.terminated.copy().astype(bool), self.truncated.copy().astype(bool)
 
     def step_autoreset(self, actions, task_rand=None, reset_task_rand=None):
-        a = np.ascontiguousarray(actions, np.float32)
-        tr, tr2 = _rand4(task_rand, self.N), _rand4(reset_task_rand, self.N)
+        a = np.ascontiguousarray(actions, self.ft)
+        tr, tr2 = _rand4(task_rand, self.N, self.ft), _rand4(reset_task_rand, self.N, self.ft)
         self.obs_next = np.zeros_like(self.obs)
-        self._chk(lib().ss_step_autoreset(self.batch, _p(a), _p(tr), _p(tr2), _p(self.obs), _p(self.obs_next), _p(self.reward),
+        self._chk(self.L.ss_step_autoreset(self.batch, _p(a), _p(tr), _p(tr2), _p(self.obs), _p(self.obs_next), _p(self.reward),
                                           _p(self.terminated), _p(self.truncated), None))
         return self.obs.copy(), self.obs_next.copy(), self.reward.copy(), self.terminated.copy().astype(bool), self.truncated.copy().astype(bool)
 
     def substep(self, actions, n):
-        a = np.ascontiguousarray(actions, np.float32)
-        self._chk(lib().ss_substep(self.batch, _p(a), n, None))
+        a = np.ascontiguousarray(actions, self.ft)
+        self._chk(self.L.ss_substep(self.batch, _p(a), n, None))
 
     def set_body_outputs(self):
-        self.xpos_out = np.zeros((self.N, self.mc.nbody, 3), np.float32); self.xmat_out = np.zeros((self.N, self.mc.nbody, 9), np.float32)
-        self._chk(lib().ss_set_body_outputs(self.batch, _p(self.xpos_out), _p(self.xmat_out)))
+        self.xpos_out = np.zeros((self.N, self.mc.nbody, 3), self.ft); self.xmat_out = np.zeros((self.N, self.mc.nbody, 9), self.ft)
+        self._chk(self.L.ss_set_body_outputs(self.batch, _p(self.xpos_out), _p(self.xmat_out)))
 
     def kinematics(self):
-        xpos = np.zeros((self.N, self.mc.nbody, 3), np.float32); xmat = np.zeros((self.N, self.mc.nbody, 9), np.float32)
-        self._chk(lib().ss_kinematics(self.batch, _p(xpos), _p(xmat), None))
+        xpos = np.zeros((self.N, self.mc.nbody, 3), self.ft); xmat = np.zeros((self.N, self.mc.nbody, 9), self.ft)
+        self._chk(self.L.ss_kinematics(self.batch, _p(xpos), _p(xmat), None))
         return xpos, xmat
 
     def debug_forward(self, torques=None):
         nv = self.mc.nv
-        M = np.zeros((self.N, nv, nv), np.float32)
-        bias = np.zeros((self.N, nv), np.float32); qacc = np.zeros((self.N, nv), np.float32)
-        tq = None if torques is None else np.ascontiguousarray(torques, np.float32)
-        self._chk(lib().ss_debug_forward(self.batch, _p(tq), _p(M), _p(bias), _p(qacc), None))
+        M = np.zeros((self.N, nv, nv), self.ft)
+        bias = np.zeros((self.N, nv), self.ft); qacc = np.zeros((self.N, nv), self.ft)
+        tq = None if torques is None else np.ascontiguousarray(torques, self.ft)
+        self._chk(self.L.ss_debug_forward(self.batch, _p(tq), _p(M), _p(bias), _p(qacc), None))
         return M, bias, qacc
