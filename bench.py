@@ -35,6 +35,66 @@ WORKLOADS = {
     "smplx": "BASELINE config 4: {N} SMPL-X/H-layout humanoids (52 bodies, nv=159, nu=153), base env, obs v1 (625 f32), uniform(-1,1) actions",
 }
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP32_VECTOR_PEAK = 157.3e12     # MI355X_MICROARCH.md: FP32 vector peak (256 CUs x 4 SIMD-32 x 2 flop x 2.4 GHz, packed)
+PARITY_PIN = ("none (mujoco absent): the oracle's mj_step restates MuJoCo's documented pipeline and is pinned to nothing; "
+              "controllers / observations / rewards / gains are pinned to the reference's own code (tests/golden)")
+
+
+class Gpu:
+    """torch.cuda plumbing of this script in one place.  (The CPU test of the multi-process path, tests/test_multi_gpu_cpu.py,
+    swaps it for host stand-ins and runs the same main() under gloo on the kernel emulator.)"""
+    backend = "nccl"
+
+    @staticmethod
+    def device(index):
+        import torch
+        torch.cuda.set_device(index)
+        return torch.device("cuda", index)
+
+    @staticmethod
+    def sync():
+        import torch
+        torch.cuda.synchronize()
+
+    @staticmethod
+    def event():
+        import torch
+        return torch.cuda.Event(enable_timing=True)
+
+    @staticmethod
+    def stream_ptr(dev):
+        import ctypes as C
+        import torch
+        return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def flops_per_env_step(nb, nv, ncand, newton_iters_per_step, nsub=15):
+    """Algorithmic float32 operations of one env-step as the kernel's formulation does them (FMA = 2), DESIGN.md §4 "Flop
+    model": per mj_step one forward pass (kinematics, velocities, inertias, bias force), the contact candidates, one
+    articulated-body solve for Stable PD and one per Newton iteration with its right-hand side and line search."""
+    nn = nb + 1
+    fk = 700 * nb + 12 * nv
+    aba = 840 * nn + 500
+    cons = 60 * ncand
+    newton_other = 70 * nb + 10 * nv + 1600
+    per_sub = fk + cons + aba + 8 * nv + 6 * nv
+    return nsub * per_sub + newton_iters_per_step * (aba + newton_other) + 60 * nb
+
+
+def pmc_summary(workload, n_envs):
+    """Limiter figures of the dominant kernel from the committed PMC passes of this same command (tools/gpu_prof.sh ->
+    profiles/pmc_summary_<workload>.json); PMC counters cannot be read from inside the process."""
+    path = os.path.join(ROOT, "profiles", f"pmc_summary_{workload}.json")
+    if not os.path.exists(path):
+        return {}
+    j = json.load(open(path))
+    if j.get("envs_per_gpu") != n_envs:
+        return {}
+    keys = ("traffic", "valu_issue_frac", "lds_wait_frac", "lds_bank_conflict_frac", "wave_active_frac", "scratch_bytes_per_lane",
+            "vgprs", "lds_bytes_per_workgroup", "waves_per_cu")
+    out = {k: j[k] for k in keys if k in j}
+    out["pmc_source"] = "profiles/" + os.path.basename(path) + " (" + j.get("profile", "?") + ")"
+    return out
 
 
 def algorithmic_bytes(nq, nv, nu, nobs):
@@ -56,10 +116,12 @@ def usable_cores():
 
 def cpu_baseline(seconds=12.0):
     """The CPU oracle (float64 C restatement; 'port', NOT MuJoCo — MuJoCo is not installable here) on the
-    host cores, same workload shape, bounded sample."""
+    host cores, same workload shape, bounded sample.  Built here, on the box it is timed on, with -O3 -march=native
+    (BASELINE.md §3); the tests use the portable -O2 build."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from helpers import oracle_model
     from oracle import oracle as O
+    flags = O.use_native_build()
+    from helpers import oracle_model
     cores = usable_cores()
     om = oracle_model()
     rs = np.random.default_rng(1234)
@@ -80,8 +142,9 @@ def cpu_baseline(seconds=12.0):
     dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "single_thread_value": rate1,
+            "build": flags,
             "sample": f"{nenv} envs x {steps2} control steps, uniform(-1,1) actions, float64 C oracle "
-                      f"(oracle/oracle.c; NOT MuJoCo), {cores} threads (cgroup/affinity-usable cores), {dt:.1f}s"}
+                      f"(oracle/oracle.c; NOT MuJoCo; dense Cholesky per Newton iteration), {cores} threads (cgroup/affinity-usable cores), {dt:.1f}s"}
 
 
 def synthetic_clips(num, frames, seed):
@@ -114,13 +177,13 @@ def run_imitation(args, rank, local_rank, world, dist, dev):
     from smplsim_amd.motion_lib import MotionLibSMPL, Skeleton
     N = args.envs_per_gpu
     model = ShardModel(device=local_rank)
-    clips = synthetic_clips(256, 300, shard.shard_seed(77, rank))
+    clips = synthetic_clips(args.clips, args.clip_frames, shard.shard_seed(77, rank))
     ml = MotionLibSMPL(clips, Skeleton.from_model_const(model.mc), device=local_rank, seed=shard.shard_seed(5, rank))
     ml.load_motions()                                           # warm-up (module load), then timed
-    torch.cuda.synchronize()
+    Gpu.sync()
     t0 = time.perf_counter()
     ml.load_motions()
-    torch.cuda.synchronize()
+    Gpu.sync()
     load_s = time.perf_counter() - t0
     F, J = ml.data.num_frames, 24
     env = SMPLSimImitationVecEnv(N, ml, model=model, device=local_rank, seed=shard.shard_seed(1234, rank))
@@ -131,8 +194,8 @@ def run_imitation(args, rank, local_rank, world, dist, dev):
 
     for _ in range(args.warmup):
         one_step()
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev0 = [Gpu.event() for _ in range(args.steps)]
+    ev1 = [Gpu.event() for _ in range(args.steps)]
     shard.barrier(dist, world, dev)
     t0 = time.perf_counter()
     rew_sum, ended = torch.zeros((), device=dev), torch.zeros((), device=dev)
@@ -151,19 +214,19 @@ def run_imitation(args, rank, local_rank, world, dist, dev):
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
     # the row's own kernels, timed alone on this stream: imitation step (per launch) and the three cooking launches
     reps = 200
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    e0, e1 = Gpu.event(), Gpu.event()
+    st = Gpu.stream_ptr(dev)
     e0.record()
     for _ in range(reps):
         env._imitation(None, env.rew_buf, env.reward_parts, env.terminated, env.truncated)
-    e1.record(); torch.cuda.synchronize()
+    e1.record(); Gpu.sync()
     im_ms = e0.elapsed_time(e1) / reps
     from smplsim_amd import _cabi
     sk = _cabi.Skeleton(J, ml._sk_keep[0].ctypes.data_as(C.c_void_p), ml._sk_keep[1].ctypes.data_as(C.c_void_p))
     e0.record()
     for _ in range(20):
         lib().ss_motion_cook(C.byref(sk), C.byref(ml.data), 1, st)
-    e1.record(); torch.cuda.synchronize()
+    e1.record(); Gpu.sync()
     cook_ms = e0.elapsed_time(e1) / 20
     if rank == 0:
         traffic, traffic_src = None, None
@@ -180,7 +243,7 @@ def run_imitation(args, rank, local_rank, world, dist, dev):
             "config": {"workload": WORKLOADS["imitation"].format(N=N), "envs_per_gpu": N, "clips": ml.num_current_motions(), "frames": F,
                        "parallelism": f"independent shards x{world} (no collective)", "launch": env.base.launch_info(),
                        "mean_reward": float(rew_sum.item()) / args.steps, "episodes_ended": int(ended.item()),
-                       "obs_finite": bool(torch.isfinite(env.obs_buf).all().item()),
+                       "obs_finite": bool(torch.isfinite(env.obs_buf).all().item()), "parity_pin": PARITY_PIN,
                        "step_kernel_ms": kern_ms, "load_motions_s (upload + cook)": load_s,
                        "cook": {"ms": cook_ms, "frames_per_s": F / (cook_ms * 1e-3), "GB/s": F * cook_bytes / (cook_ms * 1e-3) / 1e9,
                                 "algorithmic_bytes_per_frame": cook_bytes}},
@@ -215,24 +278,25 @@ def cpu_baseline_motion():
                       "compare with config.cook.frames_per_s"}
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs-per-gpu", type=int, default=None, help="default 4096 (imitation: 1024 = 8192 envs on 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--clips", type=int, default=256, help="imitation: synthetic clips per shard")
+    ap.add_argument("--clip-frames", type=int, default=300, help="imitation: frames per synthetic clip (30 fps)")
     ap.add_argument("--workload", default="smpl", choices=["smpl", "getup", "smplx", "imitation"],
                     help="smpl = BASELINE config 2 (the metric); getup = config 3 shard (Fall init, getup task); smplx = config 4; "
                          "imitation = config 5 shard (motion clips, tracking reward)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     import torch
     from smplsim_amd import shard
     rank, local_rank, world = shard.rank_info()
-    dist = shard.init_process_group("nccl", local_rank) if world > 1 else None
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dist = shard.init_process_group(Gpu.backend, local_rank) if world > 1 else None
+    dev = Gpu.device(local_rank)
 
     from smplsim_amd.batch import SMPLSimVecEnv
     if args.envs_per_gpu is None:
@@ -265,8 +329,8 @@ def main():
         shard.barrier(dist, world, dev)
 
     # per-launch duration of the dominant kernel (the fused step), HIP events on the launch stream
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev0 = [Gpu.event() for _ in range(args.steps)]
+    ev1 = [Gpu.event() for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -284,30 +348,32 @@ def main():
     it_p50, it_p99, it_max = (float(it_sorted[int(q * (N - 1))].item()) for q in (0.5, 0.99, 1.0))
 
     if rank == 0:
-        # HBM bytes per step launch from the committed PMC passes of this same command (tools/gpu_prof.sh);
-        # PMC counters cannot be read from inside the process, so the figure is the profiled one or null
-        traffic, traffic_src = None, None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"hbm_traffic_{args.workload}.json")
-        if os.path.exists(tpath) and N == 4096:
-            tj = json.load(open(tpath))
-            traffic, traffic_src = tj["bytes_per_step_launch"], "profiles/" + os.path.basename(tpath)
         total_envs = N * world
         value = shard.whole_job_throughput(total_envs * args.steps, elapsed)
         bstep = algorithmic_bytes(env.nq, env.nv, env.nu, env.obs_size)
         ach = N * bstep / (kern_ms * 1e-3) / 1e9
+        launch = env.launch_info()
+        flops = flops_per_env_step(env.nbody, env.nv, launch.get("contact_candidates", 4 * env.nbody), iters)
+        roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": None, "traffic_unit": "bytes per step launch",
+                "kernel": "ss_env_kernel (MODE_STEP)", "kernel_ms": kern_ms,
+                "algorithmic_bytes_per_env_step": bstep,
+                # the real limiter beside the designated one: FP32 work of the formulation against the vector peak,
+                # measured live; issue / LDS / residency figures from the committed PMC passes of this command
+                "fp32_useful_frac": N * flops / (kern_ms * 1e-3) / FP32_VECTOR_PEAK, "flops_per_env_step_model": flops,
+                "waves_per_cu": launch["envs_per_workgroup"],
+                "note": "path is LDS-latency/VALU bound, not HBM bound (DESIGN.md §roofline)"}
+        roof.update(pmc_summary(args.workload, N))
         out = {
             "metric": "env-steps/sec (whole node), 4096-env SMPL rollout at 1/2/4/8 MI355X", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload].format(N=N),
                        "envs_per_gpu": N, "parallelism": f"independent shards x{world} (no collective)",
-                       "launch": env.launch_info(), "mean_newton_iters_per_step": iters, "newton_iters_p50_p99_max": [it_p50, it_p99, it_max], "autoresets_total": nwarn,
-                       "obs_finite": finite},
-            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_unit": "bytes per step launch", "traffic_source": traffic_src,
-                         "kernel": "ss_env_kernel (MODE_STEP)", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_env_step": bstep,
-                         "note": "path is LDS-latency/VALU bound, not HBM bound (DESIGN.md §roofline)"},
+                       "launch": launch, "mean_newton_iters_per_step": iters, "newton_iters_p50_p99_max": [it_p50, it_p99, it_max],
+                       "bad_state_resets_total": nwarn, "self_collision": bool(getattr(env, "self_collision", False)),
+                       "obs_finite": finite, "parity_pin": PARITY_PIN},
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -49,6 +49,9 @@ class _EnvCfg(C.Structure):
     ]
 
 
+_NATIVE = False
+
+
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
     src = [os.path.join(_HERE, f) for f in ("oracle.c", "oracle.h")]
@@ -57,10 +60,21 @@ def build(force=False):
     return so
 
 
+def use_native_build():
+    """bench.py's cpu_baseline leg: compile the oracle for THIS host (-O3 -march=native) and use that build
+    from now on.  Always rebuilt: the file must never travel to a machine with another CPU.  Returns the flags."""
+    global _NATIVE, _LIB
+    if _LIB is not None and not _NATIVE:
+        raise RuntimeError("use_native_build() must come before the first use of the oracle in this process")
+    subprocess.check_call(["make", "-s", "-B", "-C", _HERE, "liboracle_native.so"])
+    _NATIVE = True
+    return subprocess.check_output(["make", "-s", "-C", _HERE, "print-native-flags"], text=True).strip()
+
+
 def lib():
     global _LIB
     if _LIB is None:
-        L = C.CDLL(build())
+        L = C.CDLL(os.path.join(_HERE, "liboracle_native.so") if _NATIVE else build())
         L.om_model_create.restype = C.c_void_p
         L.om_model_create.argtypes = [C.POINTER(_Desc)]
         L.om_data_create.restype = C.c_void_p

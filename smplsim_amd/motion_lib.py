@@ -90,17 +90,12 @@ def qpos_to_pose_aa(qpos, skeleton):
 
 class MotionLibSMPL:
     def __init__(self, motion_file, skeleton, device=0, fix_height=FixHeightMode.no_fix, min_length=-1, max_length=-1,
-                 randomrize_heading=False, filter_vel=True, height_fix=None, seed=0, _clib=None):
-        """motion_file: path of a joblib/pickle file, a directory of *.pkl files, or the dict itself.
-        `_clib` is a unit-test hook (the CPU emulator build of the same C ABI, host tensors)."""
-        if _clib is None:
-            if not torch.cuda.is_available():
-                raise RuntimeError("MotionLibSMPL needs a ROCm GPU (MI355X); there is no CPU fallback")
-            from ._lib import lib
-            self._lib = lib()
-            self.device = torch.device("cuda", int(device)) if not isinstance(device, torch.device) else device
-        else:
-            self._lib, self.device = _clib, torch.device("cpu")
+                 randomrize_heading=False, filter_vel=True, height_fix=None, seed=0):
+        """motion_file: path of a joblib/pickle file, a directory of *.pkl files, or the dict itself."""
+        from . import batch
+        from ._lib import lib
+        self.device = batch._shard_device(device.index if isinstance(device, torch.device) else device)   # raises without a GPU
+        self._lib = lib()
         self.skeleton = skeleton
         self.fix_height, self.height_fix = fix_height, height_fix
         if fix_height in (FixHeightMode.full_fix, FixHeightMode.ankle_fix) and height_fix is None:
@@ -274,9 +269,8 @@ class MotionLibSMPL:
             raise RuntimeError(f"libsmplsim_hip error {rc}: {self._lib.ss_last_error().decode()}")
 
     def _stream(self):
-        if self.device.type != "cuda":
-            return None
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        from . import batch
+        return batch._launch_stream(self.device)
 
     # ---- bookkeeping (motion_lib_base.py:210-276)
     def num_current_motions(self):

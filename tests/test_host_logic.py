@@ -1,5 +1,5 @@
 """CPU-side tests (-m "not gpu"): host logic, the C-ABI library's exported symbols (no compute calls without
-a GPU), loud failure without a GPU, config/space shims and the multi-process (gloo, world_size 2) shard path."""
+a GPU), loud failure without a GPU, config/space shims.  The multi-process (gloo, world_size 2) shard path: test_multi_gpu_cpu.py."""
 import ctypes
 import os
 import re
@@ -89,42 +89,6 @@ def test_shard_ranges_partition_the_batch():
             seen.extend(range(lo, hi))
         assert seen == list(range(total))
     assert shard_seed(1234, 3) == 1237
-
-
-_WORKER = r'''
-import os, sys, time, json
-sys.path.insert(0, %r)
-import torch
-from smplsim_amd import shard
-rank, local_rank, world = shard.rank_info()
-dist = shard.init_process_group("gloo")
-lo, hi = shard.shard_range(64, world, rank)
-shard.barrier(dist, world)
-t0 = time.perf_counter()
-time.sleep(0.05 * (rank + 1))            # the "step" of this shard: rank 1 is slower
-shard.barrier(dist, world)
-el = shard.max_over_ranks(dist, world, time.perf_counter() - t0)
-n = shard.sum_over_ranks(dist, world, hi - lo)
-if rank == 0:
-    print(json.dumps({"elapsed": el, "units": n, "value": shard.whole_job_throughput(n, el)}))
-dist.destroy_process_group()
-'''
-
-
-def test_world_size_2_gloo_shards(tmp_path):
-    """The N>1 bench path on CPU: one process per shard, barrier + max-over-ranks timing, whole-job value."""
-    script = tmp_path / "w.py"
-    script.write_text(_WORKER % ROOT)
-    port = 29600 + os.getpid() % 200
-    procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    outs = [p.communicate(timeout=120) for p in procs]
-    assert all(p.returncode == 0 for p in procs), outs
-    import json
-    res = json.loads(outs[0][0].strip().splitlines()[-1])
-    assert res["units"] == 64 and res["elapsed"] >= 0.1 and abs(res["value"] - 64 / res["elapsed"]) < 1e-6
 
 
 def test_import_shim_lets_the_rest_of_the_reference_resolve_behind_it():

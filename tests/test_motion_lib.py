@@ -40,8 +40,8 @@ def make_lib(clib, filter_vel=True, device="cpu", **kw):
     sk = Skeleton.from_model_const(mc)
     assert (sk.smpl_2_mujoco == G["smpl_2_mujoco"]).all() and (sk.parents == G["parents"]).all()
     assert np.abs(sk.offsets - G["offsets"]).max() < 1e-6        # fixture MJCF == what the golden generator parsed
-    lib = MotionLibSMPL(clip_dict(), sk, filter_vel=filter_vel, _clib=clib, **kw) if clib is not None else \
-        MotionLibSMPL(clip_dict(), sk, filter_vel=filter_vel, device=device, **kw)
+    # clib given = the caller holds the emu_backend fixture (tests/conftest.py): the package is patched onto the emulator
+    lib = MotionLibSMPL(clip_dict(), sk, filter_vel=filter_vel, device=0 if clib is not None else device, **kw)
     lib.load_motions(random_sample=False)
     return lib
 
@@ -92,10 +92,9 @@ def test_oracle_frame_lookup_and_slerp_match_reference():
 
 
 # ------------------------------------------------------------------ kernel source on the CPU emulator
-@pytest.fixture(scope="module")
-def emu_lib():
-    from wave_emu import emu
-    return emu.lib()
+@pytest.fixture()
+def emu_lib(emu_backend):
+    return emu_backend
 
 
 @pytest.mark.parametrize("filt", [True, False])
@@ -370,8 +369,7 @@ def smplx_lib(clib, device="cpu"):
         pose = rs.normal(size=(1, 52, 3)) * 0.4 + 0.5 * np.sin(2 * np.pi * rs.uniform(0.5, 2, size=(1, 52, 3)) * t)
         trans = np.stack([0.5 * t[:, 0, 0], 0 * t[:, 0, 0], 0.95 + 0 * t[:, 0, 0]], -1)
         clips[f"x{c}"] = dict(pose_aa=pose.reshape(T, -1).astype(np.float32), trans=trans.astype(np.float32), fps=30)
-    kw = dict(_clib=clib) if clib is not None else dict(device=device)
-    lib = MotionLibSMPL(clips, sk, **kw)
+    lib = MotionLibSMPL(clips, sk, device=0 if clib is not None else device)
     lib.load_motions(random_sample=False)
     return lib, sk, clips
 
@@ -487,7 +485,7 @@ def test_emu_very_short_clips_match_oracle(emu_lib):
         pose = (rs.normal(size=(1, 24, 3)) * 0.3 + 0.2 * np.arange(T)[:, None, None] * rs.normal(size=(1, 24, 3))).astype(np.float32)
         trans = np.cumsum(rs.normal(size=(T, 3)) * 0.02, 0).astype(np.float32) + np.array([0, 0, 0.9], np.float32)
         clips[f"s{c}"] = dict(pose_aa=pose.reshape(T, 72), trans=trans, fps=30)
-    lib = MotionLibSMPL(clips, sk, _clib=emu_lib)
+    lib = MotionLibSMPL(clips, sk, device=0)
     lib.load_motions(random_sample=False)
     st = 0
     for c in clips.values():
