@@ -38,9 +38,9 @@ struct Hdr {
   int nb, nn, nv, nq, nu, ncand, nlev, nblev, nbox, nslot, maxlev;
   unsigned long long nkpack[2];      // (nodes in level L) - 1, 4 bits per level: level bounds by SALU shifts, no table/kernarg loads
   // shared-blob word offsets
-  int o_real;                        // word offset of the real-valued tables (dof constants, body offsets) behind the integer ones
-  int o_dofc, o_boff;                // ... offsets into that part, in reals
-  int o_chainnode, o_ndepth, o_lev, o_bparent, o_sumsmall, o_sumbig, o_sumcover, n_sumsmall, n_sumbig, shared_words;
+  // (o_dofc, o_boff: real-valued tables, offsets in reals from the start of the blob; the layout of this struct is part of
+  // the kernel's register allocation — one more field here cost 850 SGPR reloads in the step kernel)
+  int o_dofc, o_boff, o_chainnode, o_ndepth, o_lev, o_bparent, o_sumsmall, o_sumbig, o_sumcover, n_sumsmall, n_sumbig, shared_words;
   // per-env LDS float offsets.  Z = solver region: Aown | IA (2 level buffers) | Ubuf | Wst ; aliases: contact records
   // at Z, R/r inside Wst, Gb and the body_accel scratch inside IA, Ad = Ubuf = An, V = Pb
   int l_q, l_v, l_a, l_tau, l_C, l_Pb, l_delta, l_diag, l_S, l_Ab, l_An, l_Aown, l_IA, l_Ubuf, l_Wst,

@@ -108,8 +108,7 @@ template <class W, int DOFP, int CANDP, int SLOTP, int NPASS, bool SHAPED = fals
 struct Sim : ShapeTables<SHAPED> {
   W *w;
   const KArgs *k;
-  const uint32_t *T;      // shared tables in LDS: integer part
-  const real *Tf;         // ... and real-valued part (dof constants, body offsets), behind the integers
+  const uint32_t *T;      // shared tables in LDS (integer tables, then the real-valued ones)
   int lane, env;
   // per-env LDS arrays
   real *S, *R, *r, *V, *Ab, *An, *Ad, *Gb, *tmpb, *Aown, *IA, *Ubuf, *Wst, *q, *v, *a, *tau, *Pb, *delta, *C, *diag, *Iown;
@@ -127,7 +126,14 @@ struct Sim : ShapeTables<SHAPED> {
   unsigned long long touchmask;
 
   SS_DEV int ti(int off, int i) const { return (int)T[off + i]; }
-  SS_DEV real tf(int off, int i) const { return Tf[off + i]; }
+  // real-valued table entry; offsets (Hdr::o_dofc, o_boff) count reals from the start of the blob.  The float build reads the
+  // word and bit-casts it: an integer-typed LDS load cannot alias the float arrays of the env slice, so the compiler keeps
+  // table values across the kernel's stores (a float-typed read here cost 16% more instructions)
+#ifdef SS_F64
+  SS_DEV real tf(int off, int i) const { return reinterpret_cast<const real *>(T)[off + i]; }
+#else
+  SS_DEV real tf(int off, int i) const { union { uint32_t u; float f; } c; c.u = T[off + i]; return c.f; }
+#endif
   SS_DEV real dc(int dof, int f) const { return tf(k->h.o_dofc, dof * kDofC + f); }
   SS_DEV const real *bodyc() const { if constexpr (SHAPED) return this->bodyc_s; else return k->bodyc; }
   SS_DEV const real *candc() const { if constexpr (SHAPED) return this->candc_s; else return k->candc; }
@@ -139,7 +145,6 @@ struct Sim : ShapeTables<SHAPED> {
   SS_DEV void init(W *w_, const KArgs *k_, const uint32_t *T_, real *L, int env_) {
     w = w_; k = k_; T = T_; lane = w->lane(); env = env_;
     const Hdr &h = k->h;
-    Tf = reinterpret_cast<const real *>(T_ + h.o_real);
     if constexpr (SHAPED) {
       const size_t sid = (size_t)k->st.shape_id[env];
       this->bodyc_s = k->bodyc + sid * shape_stride(h); this->candc_s = k->candc + sid * h.ncand * kCandC;

@@ -29,11 +29,12 @@ struct HostModel {
   std::vector<int32_t> dof_act;   // [nv] actuator index of a dof or -1
   std::vector<uint8_t> legal;     // [nb]
   uint64_t illegal_mask = 0;      // bodies whose floor contact terminates the episode
+  int o_real = 0;                 // word offset of the real-valued part of `shared`
   std::string error;
 };
 
 // real-valued part of the shared blob (HostModel::shared from word h.o_real on)
-inline real *shared_reals(HostModel &m) { return reinterpret_cast<real *>(m.shared.data() + m.h.o_real); }
+inline real *shared_reals(HostModel &m) { return reinterpret_cast<real *>(m.shared.data()); }   // index with Hdr::o_dofc / o_boff
 
 inline void quat2mat(const double *q, double *m) {
   double w = q[0], x = q[1], y = q[2], z = q[3];
@@ -247,10 +248,12 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
     h.o_sumsmall = push_i(small_l); h.o_sumbig = push_i(big_l); h.o_sumcover = push_i(cover);
   }
   while (S.size() % 4) S.push_back(0u);                     // reals start 16-byte aligned
-  h.o_real = (int)S.size();
+  out.o_real = (int)S.size();
   S.resize(S.size() + Sf.size() * (sizeof(real) / 4));
-  std::memcpy(S.data() + h.o_real, Sf.data(), Sf.size() * sizeof(real));
+  std::memcpy(S.data() + out.o_real, Sf.data(), Sf.size() * sizeof(real));
   h.shared_words = (int)S.size();
+  const int real0 = out.o_real / (int)(sizeof(real) / 4);   // kernel-side offsets count reals from the start of the blob
+  h.o_dofc += real0; h.o_boff += real0;
   (void)blevstart; (void)blevbodies;
 
   // ---- per-env LDS layout (floats); arrays with disjoint lifetimes share storage (LDS capacity sets the number
