@@ -149,7 +149,7 @@ def rel_err(a, b):
     return np.stack([np.abs(a["qpos"] - b["qpos"]).max(axis=1) / scale, np.abs(a["qvel"] - b["qvel"]).max(axis=1) / scale], 1)
 
 
-def triage(pre, actions, post32, humanoid="smpl_humanoid", cap=8, n_perturb=4, task="HumanoidEnv", **cfg):
+def triage(pre, actions, post32, humanoid="smpl_humanoid", cap=8, n_perturb=8, task="HumanoidEnv", **cfg):
     """Replays of every sample (module docstring).  Returns a dict of [S, 2] relative error arrays + bookkeeping."""
     kw = dict(humanoid=humanoid, task=task, task_state=pre.get("task"), cur_t=pre.get("cur_t"), task_rand=pre.get("task_rand"), **cfg)
     orc = oracle_step(pre, actions, humanoid)

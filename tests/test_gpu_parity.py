@@ -10,8 +10,13 @@ torch = pytest.importorskip("torch")
 from helpers import FEET, default_qpos, model_const, oracle_model  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
-# Stated tolerances (float32 kernel vs float64 oracle), per control step = 15 mj_steps:
-TOL_QPOS, TOL_QVEL, TOL_OBS, TOL_REW = 1e-4, 5e-3, 5e-3, 1e-4
+# Stated tolerances (float32 kernel vs float64 oracle), per control step = 15 mj_steps, for the gentle-action tests (the
+# benchmark's violent states have their own, conditioning-scaled per-sample test below).  Kept at <= 2-3x the maxima measured
+# on the MI355X (gpurun_out/parity_measured.json): teacher-forced qpos 3.4e-6, qvel 8.5e-4, obs 8.5e-4 (the
+# observation carries qvel entries unscaled, so it inherits the velocity tolerance), reward 2.6e-7; SURVEY §8d's budget was
+# 1e-5 / 2e-3 / 1e-4 (positions) / 1e-5.  Free-running rollouts accumulate: 40 control steps with floor impacts measured 4.4e-5.
+TOL_QPOS, TOL_QVEL, TOL_OBS, TOL_REW = 1e-5, 2e-3, 2e-3, 1e-6
+TOL_QPOS_FREE = 1e-4
 
 
 @pytest.fixture(scope="module")
@@ -87,7 +92,7 @@ def test_free_running_rollout_tracks_oracle(vec):
         assert (te, tu) == (bool(term[0]), bool(trunc[0]))
     assert torch.equal(env.qpos[0], env.qpos[7])             # identical inputs -> bit-identical envs
     _record("free_running_40_steps_smpl", qpos=worst[0], qvel=worst[1], obs=worst[2])
-    assert worst[0] < TOL_QPOS and worst[1] < TOL_QVEL and worst[2] < TOL_OBS, worst
+    assert worst[0] < TOL_QPOS_FREE and worst[1] < TOL_QVEL and worst[2] < TOL_OBS, worst
 
 
 @pytest.mark.parametrize("task,init", [("HumanoidSpeed", "Default"), ("HumanoidGetup", "Fall"), ("HumanoidReach", "Default")])
@@ -150,7 +155,7 @@ def test_smplx_free_running_with_floor_contact(vec):
         worst = np.maximum(worst, [np.abs(_np(env.qpos)[0] - oenv.data.qpos).max(), np.abs(o_ref - _np(obs)[0]).max()])
     assert int(env.touch[0, 0].item()) != 0 or int(env.touch[0, 1].item()) != 0     # it does stand on the floor
     _record("free_running_20_steps_smplx", qpos=worst[0], obs=worst[1])
-    assert worst[0] < TOL_QPOS and worst[1] < TOL_OBS, worst
+    assert worst[0] < TOL_QPOS_FREE and worst[1] < TOL_OBS, worst
 
 
 def test_obs_v2_on_gpu(vec):
@@ -402,8 +407,10 @@ def test_per_sample_parity_on_the_benchmark_distribution(vec, which):
             reward_max=r["reward"][ok].max())
     assert ok.sum() >= {"smpl": 400, "getup": 100, "smplx": 80}[which], ok.sum()
     assert r["resets_agree"].all()
-    assert (r["formulation"][ok] <= 1e-9).all(), r["formulation"][ok].max(axis=0)
+    assert (r["formulation"][ok] <= np.maximum(1e-9, K_ROUND * cond[ok] * P.EPS64)).all(), r["formulation"][ok].max(axis=0)
     assert (ratio64[ok] <= K_ROUND).all() and (ratio32[ok] <= K_ROUND).all(), (ratio64[ok].max(axis=0), ratio32[ok].max(axis=0))
+    med, p90 = np.median(r["precision"][ok], axis=0), np.quantile(r["precision"][ok], 0.9, axis=0)
+    assert med[0] < 5e-7 and med[1] < 5e-5 and p90[0] < 5e-6 and p90[1] < 5e-4, (med, p90)
     worst = r["precision"].max(axis=1)
     assert (r["obs"][ok] <= 4 * worst[ok] + 1e-5).all()
     assert (r["reward"][ok] <= 2 * r["precision"][ok, 0] * r["vscale"][ok] + 1e-6).all()
@@ -710,7 +717,7 @@ def test_shape_varied_env_groups_match_their_oracles_and_standalone_envs(vec):
         qpos, qvel = env.state()
         for g in range(2):
             o_ref, r, te, tu = oenvs[g].step(a[g])
-            assert np.abs(_np(qpos)[4 * g] - oenvs[g].data.qpos).max() < 2 * TOL_QPOS and np.abs(_np(obs)[4 * g] - o_ref).max() < TOL_OBS, (k, g)
+            assert np.abs(_np(qpos)[4 * g] - oenvs[g].data.qpos).max() < TOL_QPOS_FREE and np.abs(_np(obs)[4 * g] - o_ref).max() < TOL_OBS, (k, g)
             assert torch.equal(qpos[4 * g:4 * g + 4], solo[g].qpos) and torch.equal(obs[4 * g:4 * g + 4], solo[g].obs_buf)
     assert obs.shape == (8, env.obs_size) and rew.shape == (8,)
 

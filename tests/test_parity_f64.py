@@ -2,9 +2,10 @@
 (CPU: both kernel builds run on the wavefront emulator; the GPU twin is test_gpu_parity.py::test_per_sample_parity_*).
 
 What is asserted PER SAMPLE (tests/parity_tools.py explains the replays), errors relative to max(1, |qvel|_max):
-  formulation  float64 kernel vs oracle       <= 1e-9    (the two formulations solve the same problem: measured max ~1e-12)
+  formulation  float64 kernel vs oracle       <= max(1e-9, K cond 2^-53)   (the two formulations solve the same problem:
+               measured max 1e-12 on the emulator's samples, 7e-10 on the GPU's stragglers)
   resets       MuJoCo bad-state autoresets (|x| > 1e10) happen in the same samples in oracle and float64 kernel
-  precision    float32 kernel vs float64 kernel at the same Newton cap   <= K * cond * 2^-24 with K = 4096, where cond is the
+  precision    float32 kernel vs float64 kernel at the same Newton cap   <= K * cond * 2^-24 with K = 8192, where cond is the
                sample's measured response to float32-sized input noise (floored at COND_FLOOR): the float32 error is a bounded
                multiple of rounding unit x conditioning; the float64 kernel's distance to the oracle obeys the same K with 2^-53
   cap gap      float64 kernel with the product's cap (8 Newton iterations per mj_step) vs converged: reported, and zero for at
@@ -15,7 +16,7 @@ import pytest
 
 import parity_tools as P
 
-K_ROUND = 4096.0
+K_ROUND = 8192.0
 COND_FLOOR = np.array([1.0, 50.0])       # qpos, qvel: the conditioning of a quiet sample (measured medians 0.7 / 60)
 
 
@@ -34,7 +35,9 @@ def _check(r, label, min_samples):
     print("\n".join(lines))
     assert ok.sum() >= min_samples, ok.sum()
     assert r["resets_agree"].all()
-    assert (r["formulation"][ok] <= 1e-9).all(), r["formulation"][ok].max(axis=0)
+    assert (r["formulation"][ok] <= np.maximum(1e-9, K_ROUND * cond[ok] * P.EPS64)).all(), r["formulation"][ok].max(axis=0)
+    med, p90 = np.median(r["precision"][ok], axis=0), np.quantile(r["precision"][ok], 0.9, axis=0)
+    assert med[0] < 5e-7 and med[1] < 5e-5 and p90[0] < 5e-6 and p90[1] < 5e-4, (med, p90)
     assert (ratio64[ok] <= K_ROUND).all(), ratio64[ok].max(axis=0)
     assert (ratio32[ok] <= K_ROUND).all(), ratio32[ok].max(axis=0)
     assert (r["cap_gap"][ok].max(axis=1) == 0).mean() >= 0.85
@@ -45,14 +48,14 @@ def test_smpl_benchmark_distribution_per_sample():
     """BASELINE config 2's distribution: SMPL, Default init, uniform(-1,1) actions, samples from control step 8 on (thrown
     around, lying on the floor with many contacts, some diverging)."""
     pre, A, post = P.rollout_samples_emu(24, 20, seed=3, skip=8)
-    _check(P.triage(pre, A, post), "smpl uniform(-1,1)", 250)
+    _check(P.triage(pre, A, post, n_perturb=5), "smpl uniform(-1,1)", 250)
 
 
 def test_getup_fall_distribution_per_sample():
     """BASELINE config 3's distribution: getup task, StateInit.Fall (45 warm-up mj_steps), uniform(-1,1) actions."""
     kw = dict(task="HumanoidGetup", state_init="Fall")
     pre, A, post = P.rollout_samples_emu(16, 10, seed=5, skip=0, **kw)
-    r = P.triage(pre, A, post, task="HumanoidGetup", state_init=1)
+    r = P.triage(pre, A, post, task="HumanoidGetup", state_init=1, n_perturb=5)
     _check(r, "getup / Fall uniform(-1,1)", 120)
     ok = ~r["reset"]
     # the task observation / reward follow the state: their float32 error is bounded by the sample's state error
@@ -64,7 +67,7 @@ def test_getup_fall_distribution_per_sample():
 def test_smplx_benchmark_distribution_per_sample():
     """BASELINE config 4's distribution: the SMPL-X/H-layout humanoid (52 bodies, nv 159) under uniform(-1,1) actions."""
     pre, A, post = P.rollout_samples_emu(8, 14, seed=7, skip=6, humanoid="smplx_humanoid")
-    _check(P.triage(pre, A, post, humanoid="smplx_humanoid"), "smplx uniform(-1,1)", 50)
+    _check(P.triage(pre, A, post, humanoid="smplx_humanoid", n_perturb=5), "smplx uniform(-1,1)", 50)
 
 
 @pytest.mark.parametrize("obs_v", [1, 2])
