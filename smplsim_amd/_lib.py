@@ -11,7 +11,8 @@ import subprocess
 from . import _cabi
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libsmplsim_hip.so")
+# SMPLSIM_HIP_LIB: another build of the same library (A/B of compiler flags or kernel variants, tools/build_variant.sh)
+LIB_PATH = os.environ.get("SMPLSIM_HIP_LIB") or os.path.join(_PKG, "libsmplsim_hip.so")
 SRC_DIR = os.path.join(_PKG, "csrc")
 _LIB = None
 # -fno-slp-vectorize: the SLP vectorizer turns the scalar FMA chains of the kernel into v_pk_* FP32 ops glued together

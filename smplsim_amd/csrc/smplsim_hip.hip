@@ -23,13 +23,13 @@
 namespace {
 
 
-template <int DOFP, int CANDP, int SLOTP, int NPASS, int MAXT, bool BODYOUT, bool SHAPED>
+template <int DOFP, int CANDP, int SLOTP, int NPASS, int MAXT, bool BODYOUT, bool SHAPED, class HT = ss::HdrRuntime>
 __global__ void __launch_bounds__(MAXT) ss_env_kernel(const ss::KArgs k) {
   extern __shared__ __align__(16) uint32_t lds[];
   for (int i = threadIdx.x; i < k.h.shared_words; i += blockDim.x) lds[i] = k.shared_g[i];
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> LDS bases stay in SGPRs
-  float *L = reinterpret_cast<float *>(lds + ((k.h.shared_words + 3) & ~3)) + (size_t)wave * k.h.env_floats;
+  float *L = reinterpret_cast<float *>(lds + ((k.h.shared_words + 3) & ~3)) + (size_t)wave * HT::view(k.h).env_floats;
   WaveGpu w{(int)(threadIdx.x & 63)};
   // persistent wavefronts: env-steps have heavy-tailed cost (Newton iterations), so every wave pulls the
   // next env id from a device counter instead of owning a fixed slice of the batch.  The first env of every wave is
@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(MAXT) ss_env_kernel(const ss::KArgs k) {
     if (k.order) env = __builtin_amdgcn_readfirstlane(k.order[env]);   // longest-processing-time-first hand-out
     int mode = k.mode;
     for (int rep = 0; rep < 2; rep++) {                       // second trip = fused Default reset of an env whose episode ended
-      const bool again = ss::run_env<WaveGpu, DOFP, CANDP, SLOTP, NPASS, BODYOUT, SHAPED>(&w, &k, lds, L, env, mode);
+      const bool again = ss::run_env<WaveGpu, DOFP, CANDP, SLOTP, NPASS, BODYOUT, SHAPED, HT>(&w, &k, lds, L, env, mode);
       w.sync();
       if (!again) break;
       mode = ss::MODE_RESET;
@@ -87,9 +87,21 @@ __global__ void __launch_bounds__(1024) ss_order_kernel(const int32_t *iters, in
 
 typedef void (*kern_t)(const ss::KArgs);
 // instantiations per model size: plain (the headline), +body-frame outputs, +per-env body shapes (which includes the outputs)
-kern_t pick_kernel(int variant, int flavour) {
+// The two fixtures' sizes get instantiations with compile-time dimensions and LDS layout (HdrFixedT, ss_hdr.h): -2.4% per step
+// launch on the SMPL headline (profiles/r02b_variants.txt); any other model of a variant's size class runs the generic one.
+typedef ss::HdrFixedT<24, 5> HdrSmpl;                        // SMPL: 24 bodies, at most 5 nodes in a tree level
+typedef ss::HdrFixedT<52, 10> HdrSmplx;                      // SMPL-X/H: 52 bodies, 10 finger nodes per level
+kern_t pick_kernel(int variant, int flavour, const ss::Hdr &h) {
+#ifndef SS_NO_FIXED_LAYOUT
+  if (variant == 0 && flavour == 0 && HdrSmpl::matches(h)) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, false, false, HdrSmpl>;
+#ifndef SS_ONLY_HEADLINE
+  if (variant == 0 && flavour == 1 && HdrSmpl::matches(h)) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, false, HdrSmpl>;
+  if (variant == 1 && flavour == 0 && HdrSmplx::matches(h)) return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, false, false, HdrSmplx>;
+#endif
+#endif
+  if (variant == 0 && flavour == 0) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, false, false>;
+#ifndef SS_ONLY_HEADLINE                                     // (experiment builds, tools/build_variant.sh, keep the headline kernel alone)
   if (variant == 0) {                                        // SMPL layout (24 bodies)
-    if (flavour == 0) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, false, false>;
     if (flavour == 1) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, false>;
     return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, true>;
   }
@@ -98,6 +110,7 @@ kern_t pick_kernel(int variant, int flavour) {
     if (flavour == 1) return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, true, false>;
     return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, true, true>;
   }
+#endif
   return nullptr;
 }
 
@@ -126,7 +139,7 @@ struct HipBackend {
   static const char *launch(const ss::KArgs &k, int nenv, int envs_per_wg, size_t lds_bytes, void *stream, int fixed_epw, int max_wgs) {
     const bool bodyout = k.out0 && (k.mode == ss::MODE_STEP || k.mode == ss::MODE_RESET);
     const int flavour = k.st.shape_id ? 2 : (bodyout ? 1 : 0);
-    kern_t kern = pick_kernel(ss::kernel_variant(k.h), flavour);
+    kern_t kern = pick_kernel(ss::kernel_variant(k.h), flavour, k.h);
     if (!kern) return "no kernel variant for this model size";
     static thread_local kern_t configured[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     static thread_local size_t configured_lds[6] = {0, 0, 0, 0, 0, 0};

@@ -49,6 +49,87 @@ struct Hdr {
   real qpos0_root[3];
 };
 
+// Per-env LDS layout (float offsets) as a function of the body count and the widest tree level.  constexpr: the host fills
+// Hdr with it, and the kernel instantiations specialised for one model size (HdrFixed below) fold it into instruction
+// immediates.  Arrays with disjoint lifetimes share storage (LDS capacity sets the number of resident envs per CU).
+struct Layout {
+  int l_q, l_v, l_a, l_tau, l_C, l_Pb, l_delta, l_diag, l_S, l_Ab, l_An, l_Aown, l_IA, l_Ubuf, l_Wst, l_R, l_r, l_Gb, l_tmp, l_V, l_Iown,
+      ia_stride, env_floats;
+};
+constexpr Layout make_layout(int nb, int maxlev) {
+  const int nn = nb + 1, nv = 6 + 3 * (nb - 1);
+  Layout y{};
+  int o = 0;
+  auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
+  y.l_q = take(nv + 1); y.l_v = take(nv); y.l_a = take(nv); y.l_tau = take(nv); y.l_C = take(nv);
+  y.l_delta = take(nv);
+  y.l_Pb = take(6 * nb);                                   // per-body force I a - f of the Newton iterate (bias of the sweeps)
+  y.l_V = y.l_Pb;                                          // V (body velocities): dead after make_constraints
+  y.l_diag = take(nv);
+  y.l_S = take(6 * nv);
+  y.l_Ab = take(6 * nb);
+  y.l_Iown = take(10 * nb);                                // own spatial inertia of every body (10 parameters)
+  y.l_An = take(8 * nn);                                   // node accelerations of the last solve; Ad (6 nb) aliases it
+  // solver region Z
+  y.l_Aown = take(21 * nb);                                // per-body generalized inertia I_b + K_b, packed symmetric
+  y.ia_stride = 48 * maxlev;
+  const int gb = (6 * nb + 3) & ~3;
+  const int ia_need = 2 * y.ia_stride > gb + 6 * nn ? 2 * y.ia_stride : gb + 6 * nn;
+  y.l_IA = take(ia_need);                                  // articulated rows of the current / previous level
+  y.l_Gb = y.l_IA; y.l_tmp = y.l_IA + gb;                  // subtree sums and body_accel scratch live outside solves
+  // U rows of the level in flight: only live in the upward sweep, An only from the downward sweep on
+  y.l_Ubuf = 24 * maxlev <= 8 * nn ? y.l_An : take(24 * maxlev);
+  y.l_Wst = take(24 * nn);                                 // (W_r, y_r) per node row, kept for the downward sweep
+  y.l_R = y.l_Wst; y.l_r = y.l_Wst + 9 * nb;               // R, r: forward kinematics .. constraints / observations
+  y.env_floats = o;
+  return y;
+}
+
+// The header as the kernel sees it.  HdrRuntime: the Hdr itself (any model that fits a variant).  HdrFixedT<NB, MAXLEV>: body
+// count, dof counts and the whole LDS layout are compile-time constants — LDS addresses become one base register plus an
+// instruction immediate and ~30 wave-uniform values leave the SGPR file (the generic kernel reloads spilled SGPRs with
+// ~1300 v_readlane per instantiation) — everything else is still read from the runtime header.
+#if defined(__HIPCC__)
+#define SS_HD __host__ __device__ inline __attribute__((always_inline))
+#else
+#define SS_HD inline __attribute__((always_inline))
+#endif
+struct HdrRuntime {
+  typedef const Hdr &type;
+  static constexpr bool fixed = false;
+  static SS_HD type view(const Hdr &h) { return h; }
+};
+template <int NB, int MAXLEV>
+struct HdrFixed {
+  static constexpr Layout LY = make_layout(NB, MAXLEV);
+  static constexpr int nb = NB, nn = NB + 1, nv = 6 + 3 * (NB - 1), nq = 7 + 3 * (NB - 1), maxlev = MAXLEV;
+  static constexpr int l_q = LY.l_q, l_v = LY.l_v, l_a = LY.l_a, l_tau = LY.l_tau, l_C = LY.l_C, l_Pb = LY.l_Pb, l_delta = LY.l_delta,
+                       l_diag = LY.l_diag, l_S = LY.l_S, l_Ab = LY.l_Ab, l_An = LY.l_An, l_Aown = LY.l_Aown, l_IA = LY.l_IA,
+                       l_Ubuf = LY.l_Ubuf, l_Wst = LY.l_Wst, l_R = LY.l_R, l_r = LY.l_r, l_Gb = LY.l_Gb, l_tmp = LY.l_tmp, l_V = LY.l_V,
+                       l_Iown = LY.l_Iown, ia_stride = LY.ia_stride, env_floats = LY.env_floats;
+  const int &nu, &ncand, &nlev, &nblev, &nbox, &nslot;
+  const unsigned long long (&nkpack)[2];
+  const int &o_dofc, &o_boff, &o_chainnode, &o_ndepth, &o_lev, &o_bparent, &o_sumsmall, &o_sumbig, &o_sumcover, &n_sumsmall, &n_sumbig,
+      &shared_words;
+  const real &dt, &grav, &margin, &mu;
+  const real (&solimp)[5];
+  const real &K, &B;
+  const real (&qpos0_root)[3];
+  SS_HD explicit HdrFixed(const Hdr &h)
+      : nu(h.nu), ncand(h.ncand), nlev(h.nlev), nblev(h.nblev), nbox(h.nbox), nslot(h.nslot), nkpack(h.nkpack), o_dofc(h.o_dofc),
+        o_boff(h.o_boff), o_chainnode(h.o_chainnode), o_ndepth(h.o_ndepth), o_lev(h.o_lev), o_bparent(h.o_bparent),
+        o_sumsmall(h.o_sumsmall), o_sumbig(h.o_sumbig), o_sumcover(h.o_sumcover), n_sumsmall(h.n_sumsmall), n_sumbig(h.n_sumbig),
+        shared_words(h.shared_words), dt(h.dt), grav(h.grav), margin(h.margin), mu(h.mu), solimp(h.solimp), K(h.K), B(h.B),
+        qpos0_root(h.qpos0_root) {}
+};
+template <int NB, int MAXLEV>
+struct HdrFixedT {
+  typedef const HdrFixed<NB, MAXLEV> type;
+  static constexpr bool fixed = true;
+  static SS_HD HdrFixed<NB, MAXLEV> view(const Hdr &h) { return HdrFixed<NB, MAXLEV>(h); }
+  static bool matches(const Hdr &h) { return h.nb == NB && h.maxlev == MAXLEV; }
+};
+
 // compiled kernel variants: 0 = SMPL-sized (<= 128 dofs / candidates, <= 64 contact slots, <= 8 nodes per tree level),
 // 1 = SMPL-X/H-sized (<= 192 dofs / candidates, <= 128 slots, <= 16 nodes per level); -1 = none fits
 inline int kernel_variant(const Hdr &h) {
@@ -58,7 +139,7 @@ inline int kernel_variant(const Hdr &h) {
   return -1;
 }
 
-constexpr int shape_stride(const Hdr &h) { return h.nb * kBodyC + ((h.nv + 3) & ~3); }   // floats per shape in the shaped bodyc array
+template <class H> constexpr int shape_stride(const H &h) { return h.nb * kBodyC + ((h.nv + 3) & ~3); }   // floats per shape in the shaped bodyc array
 
 enum { MODE_STEP = 0, MODE_SUBSTEP = 1, MODE_RESET = 2, MODE_KINEMATICS = 3, MODE_DEBUG_FORWARD = 4 };
 

@@ -104,7 +104,7 @@ SS_DEV bool is_bad(real x) { return !(x <= real(1e10) && x >= -real(1e10)); }
 template <bool SHAPED> struct ShapeTables {};
 template <> struct ShapeTables<true> { const real *bodyc_s, *candc_s, *dinvw_s; };   // this env's tables
 
-template <class W, int DOFP, int CANDP, int SLOTP, int NPASS, bool SHAPED = false>
+template <class W, int DOFP, int CANDP, int SLOTP, int NPASS, bool SHAPED = false, class HT = HdrRuntime>
 struct Sim : ShapeTables<SHAPED> {
   W *w;
   const KArgs *k;
@@ -135,6 +135,7 @@ struct Sim : ShapeTables<SHAPED> {
   SS_DEV real tf(int off, int i) const { union { uint32_t u; float f; } c; c.u = T[off + i]; return c.f; }
 #endif
   SS_DEV real dc(int dof, int f) const { return tf(k->h.o_dofc, dof * kDofC + f); }
+  SS_DEV typename HT::type hdr() const { return HT::view(k->h); }
   SS_DEV const real *bodyc() const { if constexpr (SHAPED) return this->bodyc_s; else return k->bodyc; }
   SS_DEV const real *candc() const { if constexpr (SHAPED) return this->candc_s; else return k->candc; }
   SS_DEV real dof_invweight(int dof) const { if constexpr (SHAPED) return this->dinvw_s[dof]; else return dc(dof, 4); }
@@ -144,7 +145,7 @@ struct Sim : ShapeTables<SHAPED> {
 
   SS_DEV void init(W *w_, const KArgs *k_, const uint32_t *T_, real *L, int env_) {
     w = w_; k = k_; T = T_; lane = w->lane(); env = env_;
-    const Hdr &h = k->h;
+    typename HT::type h = HT::view(k->h);
     if constexpr (SHAPED) {
       const size_t sid = (size_t)k->st.shape_id[env];
       this->bodyc_s = k->bodyc + sid * shape_stride(h); this->candc_s = k->candc + sid * h.ncand * kCandC;
@@ -199,7 +200,7 @@ struct Sim : ShapeTables<SHAPED> {
   // Must be called between hand-offs; it contains one.
   template <int NC>
   SS_DEV void subtree_sum(const real *in, real *out) {
-    const Hdr &h = k->h;
+    typename HT::type h = HT::view(k->h);
     for (int idx = lane; idx < NC * h.n_sumsmall; idx += 64) {
       const int o = idx / NC, c = idx - o * NC, e = ti(h.o_sumsmall, o), b = e & 255, n = e >> 8;
       const real *p = in + b * NC + c;
@@ -234,7 +235,7 @@ struct Sim : ShapeTables<SHAPED> {
   // Two stages: per-node contributions c_n = S[3n..3n+2] x[3n..3n+2] (into `tmp`, 6 floats per node),
   // then each (body, component) adds the <= depth+1 node contributions along its chain.
   SS_DEV void body_accel(const real *x, real *A, real *tmp) {
-    const Hdr &h = k->h;
+    typename HT::type h = HT::view(k->h);
     for (int idx = lane; idx < 6 * h.nn; idx += 64) {
       int n = idx / 6, c = idx - 6 * n, d = 3 * n;
       tmp[idx] = S[6 * d + c] * x[d] + S[6 * d + 6 + c] * x[d + 1] + S[6 * d + 12 + c] * x[d + 2];
@@ -245,7 +246,7 @@ struct Sim : ShapeTables<SHAPED> {
   // A[b] = sum of the node contributions tmp[n] (6 floats each) over the chain root .. node(b); optionally a second
   // (tmp2 -> A2) pair in the same pass over the chain table
   SS_DEV void chain_sum(const real *tmp, real *A, const real *tmp2 = nullptr, real *A2 = nullptr) {
-    const Hdr &h = k->h;
+    typename HT::type h = HT::view(k->h);
     for (int idx = lane; idx < 6 * h.nb; idx += 64) {
       int b = idx / 6, c = idx - 6 * b, n = b + 1;
       const int dn = ti(h.o_ndepth, n), row = h.o_chainnode + n * h.nlev;
@@ -269,7 +270,7 @@ struct Sim : ShapeTables<SHAPED> {
   // with_dyn = false: positions/orientations only (observation FK)
   SS_DEV void forward_kin(bool with_dyn, bool write_sensors) {
     fresh();
-    const Hdr &h = k->h;
+    typename HT::type h = HT::view(k->h);
     SS_FT0();
     real vb[6] = {0, 0, 0, 0, 0, 0}, ab[6] = {0, 0, 0, 0, 0, 0};
     real Rb[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, rb[3] = {0, 0, 0};
@@ -531,7 +532,7 @@ struct Sim : ShapeTables<SHAPED> {
   // ------------------------------------------------------------------ floor contacts + joint limits
   SS_DEV void make_constraints() {
     fresh();
-    const Hdr &h = k->h;
+    typename HT::type h = HT::view(k->h);
     const real pz = q[2], mu = h.mu;
     touchmask = 0ull;
     // contact records are compacted through LDS (the solver region is free here) into one slot per lane:
@@ -686,7 +687,7 @@ struct Sim : ShapeTables<SHAPED> {
   SS_DEV static void st4w(real *p, real a, real b, real c, real d) { float4_t v; v.x = a; v.y = b; v.z = c; v.w = d; *reinterpret_cast<float4_t *>(p) = v; }
 
   SS_DEV void write_own_inertia() {                          // Aown[b] = expand(Ib), packed upper triangle (ang;lin)
-    if (lane < k->h.nb) {
+    if (lane < hdr().nb) {
       real *o = Aown + 21 * lane;
       const real *Ib = Iown + 10 * lane;
       const real m = Ib[0], cx = Ib[1], cy = Ib[2], cz = Ib[3];
@@ -700,7 +701,7 @@ struct Sim : ShapeTables<SHAPED> {
   // pb: optional per-body bias force (6 per body): the system solved is  H x = b - sum_b J_b^T pb_b
   SS_DEV void aba_solve(real *x, const real *pb) {
     fresh();
-    const Hdr &h = k->h;
+    typename HT::type h = HT::view(k->h);
     const int r_ = lane & 7, g = lane >> 3;
     int off[6];                                              // packed-symmetric offsets of row r_
 #pragma unroll
@@ -906,7 +907,7 @@ struct Sim : ShapeTables<SHAPED> {
 
   // joint-space matrix column j = M e_j by a body-level pass (diagnostics only: ss_debug_forward)
   SS_DEV void dump_mass_matrix(real *out) {
-    const Hdr &h = k->h;
+    typename HT::type h = HT::view(k->h);
     for (int j = 0; j < h.nv; j++) {
       for (int i = lane; i < h.nv; i += 64) delta[i] = i == j ? 1.f : 0.f;
       w->sync();
@@ -967,7 +968,7 @@ struct Sim : ShapeTables<SHAPED> {
   // and the per-body generalized inertias Aown = I_b + K_b
   SS_DEV void newton_prepare() {
     fresh();
-    const Hdr &h = k->h;
+    typename HT::type h = HT::view(k->h);
     const real mu = h.mu;
     iters++;
     SS_FT0();
@@ -1058,7 +1059,7 @@ struct Sim : ShapeTables<SHAPED> {
   // exact line search along delta, step, active-set change detection; returns true when converged
   SS_DEV bool newton_finish() {
     fresh();
-    const Hdr &h = k->h;
+    typename HT::type h = HT::view(k->h);
     eval_rows(An + 8, 8, delta, true);                       // aba_solve left the body accelerations of delta in An
     real dg_ = 0.f, s_a = 0.f, s_b = 0.f;
 #pragma unroll
@@ -1156,7 +1157,7 @@ struct Sim : ShapeTables<SHAPED> {
   // `pd` (PIDController with zero integral gain, reference controllers.py:335-346) and `torque`
   // (SimpleTorqueController :45-46)
   SS_DEV void simple_controller(const real *action, real abias) {
-    const Hdr &h = k->h;
+    typename HT::type h = HT::view(k->h);
     const int mode = k->cfg.control_mode;
     const real dtp = h.dt * (real)k->cfg.control_freq_inv;   // the dt SimplePID is constructed with (humanoid_env.py:319)
 #pragma unroll
@@ -1193,7 +1194,7 @@ struct Sim : ShapeTables<SHAPED> {
   // forward pass that is in LDS (the "stale" qM / qfrc_bias) with the current q, v
   SS_DEV void spd_prepare(const real *action, real abias) {
     fresh();
-    const Hdr &h = k->h;
+    typename HT::type h = HT::view(k->h);
     write_own_inertia();
 #pragma unroll
     for (int p = 0; p < DOFP; p++) {
@@ -1210,7 +1211,7 @@ struct Sim : ShapeTables<SHAPED> {
   }
   SS_DEV void spd_finish() {
     fresh();
-    const Hdr &h = k->h;
+    typename HT::type h = HT::view(k->h);
 #pragma unroll
     for (int p = 0; p < DOFP; p++) {
       int i = p * 64 + lane;
@@ -1230,7 +1231,7 @@ struct Sim : ShapeTables<SHAPED> {
   // ------------------------------------------------------------------ semi-implicit Euler
   SS_DEV void integrate() {
     fresh();
-    const Hdr &h = k->h;
+    typename HT::type h = HT::view(k->h);
     const real dt = h.dt;
     if (lane == 0) {
       real wx = v[3] + dt * a[3], wy = v[4] + dt * a[4], wz = v[5] + dt * a[5];
@@ -1269,7 +1270,7 @@ struct Sim : ShapeTables<SHAPED> {
 
   // mj_resetData after a bad qpos / qvel / qacc (MuJoCo autoreset)
   SS_DEV void reset_data() {
-    const Hdr &h = k->h;
+    typename HT::type h = HT::view(k->h);
     for (int i = lane; i < h.nq; i += 64) q[i] = 0.f;
     for (int i = lane; i < h.nv; i += 64) { v[i] = 0.f; a[i] = 0.f; tau[i] = 0.f; }
     w->sync();
@@ -1281,7 +1282,7 @@ struct Sim : ShapeTables<SHAPED> {
   // ------------------------------------------------------------------ observations (self_obs_v 1 / 2) + task tail
   SS_DEV void write_obs(real *obs, real tar, real tar_y, real tar_z) {
     fresh();
-    const Hdr &h = k->h;
+    typename HT::type h = HT::view(k->h);
     const ss_env_cfg &cf = k->cfg;
     // heading from remove_base_rot(root quat): rotated x axis = third column of the root rotation
     real hx = R[2], hy = R[5];
@@ -1348,14 +1349,14 @@ enum { SOLVE_NEWTON = 1, SOLVE_SPD = 2 };
 // BODYOUT: the instantiation whose step / reset passes also write the body frames (ss_set_body_outputs).  A separate
 // instantiation because the extra epilogue costs the headline step kernel 3.7% (register allocation of the hot loops
 // shifts) even when the pointer is null — callers that do not ask for it keep the plain one.
-template <class W, int DOFP, int CANDP, int SLOTP, int NPASS, bool BODYOUT = false, bool SHAPED = false>
+template <class W, int DOFP, int CANDP, int SLOTP, int NPASS, bool BODYOUT = false, bool SHAPED = false, class HT = HdrRuntime>
 SS_DEV bool run_env(W *w, const KArgs *k, const uint32_t *T, real *L, int env, int mode) {
-  const Hdr &h = k->h;
+  typename HT::type h = HT::view(k->h);
   const ss_env_cfg &cf = k->cfg;
   const ss_state &st = k->st;
   const bool fused_pass = mode != k->mode;                    // the in-launch reset of an env that just finished
   if (!fused_pass && k->mask && !k->mask[env]) return false;
-  Sim<W, DOFP, CANDP, SLOTP, NPASS, SHAPED> sim;
+  Sim<W, DOFP, CANDP, SLOTP, NPASS, SHAPED, HT> sim;
   sim.init(w, k, T, L, env);
   int lane = sim.lane;
   real *qg = gptr(st.qpos) + (size_t)env * h.nq, *vg = gptr(st.qvel) + (size_t)env * h.nv;

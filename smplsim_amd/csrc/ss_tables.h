@@ -259,29 +259,14 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   // ---- per-env LDS layout (floats); arrays with disjoint lifetimes share storage (LDS capacity sets the number
   // of resident envs per CU)
   if (nn > 64) { out.error = "too many nodes"; return false; }
-  int o = 0;
-  auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
-  h.l_q = take(nv + 1); h.l_v = take(nv); h.l_a = take(nv); h.l_tau = take(nv); h.l_C = take(nv);
-  h.l_delta = take(nv);
-  h.l_Pb = take(6 * nb);                                   // per-body force I a - f of the Newton iterate (bias of the sweeps)
-  h.l_V = h.l_Pb;                                          // V (body velocities): dead after make_constraints
-  h.l_diag = take(nv);
-  h.l_S = take(6 * nv);
-  h.l_Ab = take(6 * nb);
-  h.l_Iown = take(10 * nb);                                // own spatial inertia of every body (10 parameters)
-  h.l_An = take(8 * nn);                                   // node accelerations of the last solve; Ad (6 nb) aliases it
-  // solver region Z
-  h.l_Aown = take(21 * nb);                                // per-body generalized inertia I_b + K_b, packed symmetric
-  h.ia_stride = 48 * maxlev;
-  const int ia_need = std::max(2 * h.ia_stride, ((6 * nb + 3) & ~3) + 6 * nn);
-  h.l_IA = take(ia_need);                                  // articulated rows of the current / previous level
-  h.l_Gb = h.l_IA; h.l_tmp = h.l_IA + ((6 * nb + 3) & ~3);  // subtree sums and body_accel scratch live outside solves
-  // U rows of the level in flight: only live in the upward sweep, An only from the downward sweep on
-  h.l_Ubuf = 24 * maxlev <= 8 * nn ? h.l_An : take(24 * maxlev);
-  if (13 * h.nslot > o - h.l_Aown) { out.error = "contact record buffer does not fit"; return false; }
-  h.l_Wst = take(24 * nn);                                 // (W_r, y_r) per node row, kept for the downward sweep
-  h.l_R = h.l_Wst; h.l_r = h.l_Wst + 9 * nb;               // R, r: forward kinematics .. constraints / observations
-  h.env_floats = o;
+  {
+    const Layout y = make_layout(nb, maxlev);
+    h.l_q = y.l_q; h.l_v = y.l_v; h.l_a = y.l_a; h.l_tau = y.l_tau; h.l_C = y.l_C; h.l_delta = y.l_delta; h.l_Pb = y.l_Pb; h.l_V = y.l_V;
+    h.l_diag = y.l_diag; h.l_S = y.l_S; h.l_Ab = y.l_Ab; h.l_Iown = y.l_Iown; h.l_An = y.l_An; h.l_Aown = y.l_Aown; h.ia_stride = y.ia_stride;
+    h.l_IA = y.l_IA; h.l_Gb = y.l_Gb; h.l_tmp = y.l_tmp; h.l_Ubuf = y.l_Ubuf; h.l_Wst = y.l_Wst; h.l_R = y.l_R; h.l_r = y.l_r;
+    h.env_floats = y.env_floats;
+    if (13 * h.nslot > h.l_Wst - h.l_Aown) { out.error = "contact record buffer does not fit"; return false; }
+  }
 
   h.dt = (real)d.timestep; h.grav = (real)d.gravity; h.margin = (real)d.margin; h.mu = (real)d.friction;
   for (int k = 0; k < 5; k++) h.solimp[k] = (real)d.solimp[k];

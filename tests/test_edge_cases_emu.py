@@ -232,3 +232,27 @@ def test_shaped_model_error_paths():
     t2[0][3] *= 2.0                                                     # a different gain is not a body shape
     descs[1], k2 = _cabi.make_model_desc(mc1, *t2, legal_bodies=FEET)
     assert emu.lib().ss_model_create_shapes(descs, 2, 0, C.byref(h)) == -1
+
+
+@pytest.mark.parametrize("humanoid", ["smpl_humanoid", "smplx_humanoid"])
+def test_fixed_layout_instantiation_is_bit_identical_to_the_generic_one(humanoid, monkeypatch):
+    """The instantiations with compile-time dimensions / LDS layout (HdrFixedT<24,5>, <52,10>, ss_hdr.h) against the generic kernel
+    (the emulator's launcher mirrors the GPU's choice; SS_EMU_GENERIC forces the generic one): same bits after contact-rich steps."""
+    from helpers import FEET, model_const, pd_tables
+    mc = model_const(humanoid)
+    rs = np.random.default_rng(4)
+    acts = rs.uniform(-1, 1, (3, 4, mc.nu))
+    outs = []
+    for generic in (False, True):
+        if generic:
+            monkeypatch.setenv("SS_EMU_GENERIC", "1")
+        eb = emu.EmuBatch(mc, pd_tables(mc), 4, legal_bodies=FEET, task=1)
+        eb.reset(task_rand=np.full((4, 4), 0.5))
+        q = eb.qpos.copy(); q[:, 2] = 0.5                     # dropped onto the floor: contacts, limits, many Newton iterations
+        eb.set_state(q, eb.qvel.copy())
+        for a in acts:
+            obs, rew, term, trunc = eb.step(a, np.full((4, 4), 0.25))
+        outs.append((eb.qpos.copy(), eb.qvel.copy(), obs, rew, eb.solver_iters.copy()))
+    for x, y in zip(*outs):
+        assert np.array_equal(x, y)
+    assert outs[0][4].max() > 15                            # contacts were active (one Newton iteration per mj_step otherwise)

@@ -194,13 +194,13 @@ struct WaveEmu {
 
 struct LaunchCtx { const ss::KArgs *k; const uint32_t *T; ss::real *L; int env; Machine *m; };
 
-template <int DOFP, int CANDP, int SLOTP, int NPASS, bool SHAPED>
+template <int DOFP, int CANDP, int SLOTP, int NPASS, bool SHAPED, class HT = ss::HdrRuntime>
 void lane_entry(int lane, void *arg) {
   LaunchCtx *c = (LaunchCtx *)arg;
   WaveEmu w{c->m, lane};
   int mode = c->k->mode;
   for (int rep = 0; rep < 2; rep++) {
-    const bool again = ss::run_env<WaveEmu, DOFP, CANDP, SLOTP, NPASS, true, SHAPED>(&w, c->k, c->T, c->L, c->env, mode);
+    const bool again = ss::run_env<WaveEmu, DOFP, CANDP, SLOTP, NPASS, true, SHAPED, HT>(&w, c->k, c->T, c->L, c->env, mode);
     w.sync();
     if (!again) break;
     mode = ss::MODE_RESET;
@@ -284,7 +284,10 @@ struct EmuBackend {
       LaunchCtx c{&k, k.shared_g, L.data(), k.order ? k.order[env] : env, m};
       void (*entry)(int, void *) = nullptr;
       const int variant = ss::kernel_variant(k.h);
-      if (variant == 0) entry = k.st.shape_id ? lane_entry<2, 2, 1, 1, true> : lane_entry<2, 2, 1, 1, false>;
+      // like the GPU launcher: the SMPL-sized model without per-env shapes runs the compile-time-layout instantiation
+      if (variant == 0 && !k.st.shape_id && ss::HdrFixedT<24, 5>::matches(k.h) && !getenv("SS_EMU_GENERIC")) entry = lane_entry<2, 2, 1, 1, false, ss::HdrFixedT<24, 5>>;
+      else if (variant == 0) entry = k.st.shape_id ? lane_entry<2, 2, 1, 1, true> : lane_entry<2, 2, 1, 1, false>;
+      else if (variant == 1 && !k.st.shape_id && ss::HdrFixedT<52, 10>::matches(k.h) && !getenv("SS_EMU_GENERIC")) entry = lane_entry<3, 3, 2, 2, false, ss::HdrFixedT<52, 10>>;
       else if (variant == 1) entry = k.st.shape_id ? lane_entry<3, 3, 2, 2, true> : lane_entry<3, 3, 2, 2, false>;
       else return "no kernel variant for this model size";
       run_wave(m, entry, &c);

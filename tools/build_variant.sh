@@ -1,0 +1,13 @@
+#!/bin/bash
+# Build a named variant of libsmplsim_hip.so for same-box A/B runs (selected at run time with SMPLSIM_HIP_LIB=...).
+# usage: tools/build_variant.sh NAME [extra hipcc flags for the stepper translation unit...]
+set -e
+cd "$(dirname "$0")/.."
+NAME=$1; shift
+OPT=${SS_HIPCC_OPT:--Os -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-ilp}
+mkdir -p build/variants
+/opt/rocm/bin/hipcc --offload-arch=gfx950 $OPT "$@" -std=c++17 -fPIC -c smplsim_amd/csrc/smplsim_hip.hip -o build/variants/hip_$NAME.o
+[ -f build/variants/motion.o ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c smplsim_amd/csrc/smplsim_motion.hip -o build/variants/motion.o
+mkdir -p smplsim_amd/variants
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/variants/hip_$NAME.o build/variants/motion.o -o smplsim_amd/variants/libsmplsim_hip_$NAME.so
+echo built smplsim_amd/variants/libsmplsim_hip_$NAME.so
