@@ -25,7 +25,9 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define MAXCON (4 * OM_MAXB)
+#define MAXSELF 256                     /* body-body contacts */
+#define MAXCON (4 * OM_MAXB + MAXSELF)
+#define MAXPAIR (OM_MAXB * (OM_MAXB - 1) / 2)
 #define MINVAL 1e-15
 
 /* ------------------------------------------------------------------ small math */
@@ -131,6 +133,11 @@ struct om_model {
   double dt, grav, solref[2], solimp[5], margin, mu, impratio;
   int chain_len[OM_MAXB];
   int chain[OM_MAXB][OM_MAXV];
+  /* body-body collision: candidate pairs after the contype/conaffinity test, the parent-child filter and the excludes;
+   * b1 is the geom MuJoCo hands to the pair function first (lower geom type, then lower id): normals point b1 -> b2 */
+  int self_collision, npair, max_self;
+  int pair_b1[MAXPAIR], pair_b2[MAXPAIR];
+  double brad[OM_MAXB];                       /* bounding-sphere radius of the body's geom about its centre */
 };
 
 struct om_data {
@@ -140,7 +147,8 @@ struct om_data {
   double xpos[OM_MAXB][3], xquat[OM_MAXB][4], xmat[OM_MAXB][9], xipos[OM_MAXB][3], Iw[OM_MAXB][9];
   double axis[OM_MAXB][3][3];
   double linvel[OM_MAXB][3], angvel[OM_MAXB][3];
-  int ncon, con_body[MAXCON];
+  int ncon, con_body[MAXCON], con_body1[MAXCON];   /* con_body1 = -1: floor contact */
+  int nself, nself_dropped;
   double con_pos[MAXCON][3], con_frame[MAXCON][9], con_dist[MAXCON];
   int touch[OM_MAXB];
   int nefc, maxrow;
@@ -230,6 +238,25 @@ om_model *om_model_create(const om_desc *ds) {
     m->kp[i] = ds->kp[i]; m->kd[i] = ds->kd[i]; m->tlim[i] = ds->torque_lim[i];
     m->ascale[i] = ds->act_scale[i]; m->aoffset[i] = ds->act_offset[i];
   }
+  /* candidate body pairs (mj_collision's static filters) */
+  m->self_collision = ds->self_collision; m->max_self = ds->max_self_contacts; m->npair = 0;
+  for (int b = 0; b < nb; b++) {
+    const double *sz = m->gsize[b];
+    m->brad[b] = m->gtype[b] == OM_GEOM_BOX ? sqrt(sz[0] * sz[0] + sz[1] * sz[1] + sz[2] * sz[2]) : sz[0] + sz[1];
+  }
+  if (ds->self_collision)
+    for (int i = 0; i < nb; i++) for (int j = i + 1; j < nb; j++) {
+      int ct1 = ds->contype ? ds->contype[i] : 1, ca1 = ds->conaffinity ? ds->conaffinity[i] : 1;
+      int ct2 = ds->contype ? ds->contype[j] : 1, ca2 = ds->conaffinity ? ds->conaffinity[j] : 1;
+      if (!((ct1 & ca2) || (ct2 & ca1))) continue;
+      if (m->parent[j] == i || m->parent[i] == j) continue;             /* filterparent (the world is nobody's geom parent here) */
+      int ex = 0;
+      for (int e = 0; e < ds->nexclude; e++)
+        if ((ds->exclude[2 * e] == i && ds->exclude[2 * e + 1] == j) || (ds->exclude[2 * e] == j && ds->exclude[2 * e + 1] == i)) ex = 1;
+      if (ex) continue;
+      int first = (m->gtype[i] == OM_GEOM_BOX && m->gtype[j] == OM_GEOM_CAPSULE) ? j : i;   /* capsule (type 3) before box (6) */
+      m->pair_b1[m->npair] = first; m->pair_b2[m->npair] = first == i ? j : i; m->npair++;
+    }
   m->dt = ds->timestep; m->grav = ds->gravity;
   memcpy(m->solref, ds->solref, sizeof m->solref); memcpy(m->solimp, ds->solimp, sizeof m->solimp);
   m->margin = ds->margin; m->mu = ds->mu; m->impratio = ds->impratio;
@@ -303,7 +330,7 @@ int om_model_get(const om_model *m, int field, double *out) {
 om_data *om_data_create(const om_model *m) {
   om_data *d = (om_data *)calloc(1, sizeof *d);
   int nv = m->nv;
-  d->maxrow = 4 * 4 * m->nbody + 2 * nv;
+  d->maxrow = 4 * MAXCON + 2 * nv;
   d->M = (double *)calloc((size_t)nv * nv, sizeof(double));
   d->H = (double *)calloc((size_t)nv * nv, sizeof(double));
   d->work = (double *)calloc((size_t)nv * nv, sizeof(double));
@@ -445,6 +472,7 @@ static void collide(const om_model *m, om_data *d) {
         double ldist = corner[2];
         if (gp[2] + ldist > m->margin || ldist > 0) continue;
         int c = d->ncon++;
+        d->con_body1[c] = -1;
         d->con_body[c] = b; d->con_dist[c] = gp[2] + ldist;
         v3set(d->con_pos[c], gp[0] + corner[0], gp[1] + corner[1], gp[2] + corner[2] - 0.5 * d->con_dist[c]);
         memset(d->con_frame[c], 0, 9 * sizeof(double)); d->con_frame[c][2] = 1;
@@ -460,6 +488,7 @@ static void collide(const om_model *m, om_data *d) {
         double dist = c3[2] - m->gsize[b][0];
         if (dist > m->margin) continue;
         int c = d->ncon++;
+        d->con_body1[c] = -1;
         d->con_body[c] = b; d->con_dist[c] = dist;
         v3set(d->con_pos[c], c3[0], c3[1], c3[2] - (m->gsize[b][0] + 0.5 * dist));
         memset(d->con_frame[c], 0, 9 * sizeof(double)); d->con_frame[c][2] = 1;
@@ -468,6 +497,284 @@ static void collide(const om_model *m, om_data *d) {
         d->touch[b] = 1;
       }
     }
+  }
+}
+
+/* ------------------------------------------------------------------ body-body narrow phases
+ * MuJoCo's pair functions for the geom types of the reference's humanoids (capsule, box), restated: [MJ-doc]
+ *   capsule-capsule  mjc_CapsuleCapsule: closest points of the two segments, then a sphere-sphere test (two tests when the
+ *                    axes are parallel)
+ *   capsule-box      the point of the capsule's segment closest to the box (exact minimiser of the convex, piecewise
+ *                    quadratic squared distance), a sphere-box test there (mjc_SphereBox) and one at the far end of the
+ *                    segment: at most 2 contacts like mjc_CapsuleBox
+ *   box-box          separating-axis test over the 15 axes; face axis: the vertices of either box within the margin of the
+ *                    other's face and inside its rectangle (at most 8 contacts like mjc_BoxBox); edge-edge axis: one
+ *                    contact at the closest points of the two supporting edges
+ * "parity unpinned" like the rest of mj_step (oracle.h): the contact-selection details of mjc_CapsuleBox / mjc_BoxBox are
+ * restated as rules, not line by line.  Normals point from the pair's first geom to its second. */
+typedef struct { double pos[3], normal[3], dist; } ncon;
+
+static int sphere_sphere(const double *p1, double r1, const double *p2, double r2, double margin, ncon *o) {
+  double d[3]; v3sub(d, p2, p1);
+  double len = v3norm(d), dist = len - (r1 + r2);
+  if (dist > margin) return 0;
+  if (len < MINVAL) v3set(o->normal, 1, 0, 0); else v3set(o->normal, d[0] / len, d[1] / len, d[2] / len);
+  for (int k = 0; k < 3; k++) o->pos[k] = p1[k] + o->normal[k] * (r1 + 0.5 * dist);
+  o->dist = dist;
+  return 1;
+}
+
+static double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+/* geom = centre p, unit axis a (capsule z axis), radius r, half length h */
+static int capsule_capsule(const double *p1, const double *a1, double r1, double h1, const double *p2, const double *a2, double r2,
+                           double h2, double margin, ncon *o) {
+  double dif[3]; v3sub(dif, p1, p2);
+  double ma = v3dot(a1, a1), mb = -v3dot(a1, a2), mc = v3dot(a2, a2), u = -v3dot(a1, dif), v = v3dot(a2, dif);
+  double det = ma * mc - mb * mb;
+  double c1[3], c2[3];
+  if (fabs(det) >= MINVAL) {                                 /* general configuration */
+    double x1 = (mc * u - mb * v) / det, x2 = (ma * v - mb * u) / det;
+    if (x1 > h1) { x1 = h1; x2 = (v - mb * h1) / mc; }
+    else if (x1 < -h1) { x1 = -h1; x2 = (v + mb * h1) / mc; }
+    if (x2 > h2) { x2 = h2; x1 = clampd((u - mb * h2) / ma, -h1, h1); }
+    else if (x2 < -h2) { x2 = -h2; x1 = clampd((u + mb * h2) / ma, -h1, h1); }
+    for (int k = 0; k < 3; k++) { c1[k] = p1[k] + a1[k] * x1; c2[k] = p2[k] + a2[k] * x2; }
+    return sphere_sphere(c1, r1, c2, r2, margin, o);
+  }
+  /* parallel axes: the ends of each segment against the other segment, at most two contacts */
+  int n = 0;
+  for (int e = 0; e < 4 && n < 2; e++) {
+    double x1, x2;
+    if (e < 2) { x1 = e == 0 ? h1 : -h1; x2 = (v - mb * x1) / mc; if (x2 > h2 || x2 < -h2) continue; }
+    else { x2 = e == 2 ? h2 : -h2; x1 = (u - mb * x2) / ma; if (x1 > h1 || x1 < -h1) continue; }
+    for (int k = 0; k < 3; k++) { c1[k] = p1[k] + a1[k] * x1; c2[k] = p2[k] + a2[k] * x2; }
+    n += sphere_sphere(c1, r1, c2, r2, margin, o + n);
+  }
+  return n;
+}
+
+/* sphere (geom 1) against box (geom 2: centre bp, rotation bm row-major with the box axes as columns, half sizes bs) */
+static int sphere_box(const double *c, double r, const double *bp, const double *bm, const double *bs, double margin, ncon *o) {
+  double d[3], l[3], cl[3];
+  v3sub(d, c, bp);
+  for (int i = 0; i < 3; i++) { l[i] = bm[i] * d[0] + bm[3 + i] * d[1] + bm[6 + i] * d[2]; cl[i] = clampd(l[i], -bs[i], bs[i]); }
+  double v[3] = {l[0] - cl[0], l[1] - cl[1], l[2] - cl[2]}, len = v3norm(v), nl[3], dist;
+  if (len >= MINVAL) {                                       /* centre outside the box */
+    dist = len - r;
+    if (dist > margin) return 0;
+    v3set(nl, v[0] / len, v[1] / len, v[2] / len);
+  } else {                                                   /* centre inside: push out through the nearest face */
+    int k = 0; double best = bs[0] - fabs(l[0]);
+    for (int i = 1; i < 3; i++) if (bs[i] - fabs(l[i]) < best) { best = bs[i] - fabs(l[i]); k = i; }
+    double sg = l[k] >= 0 ? 1.0 : -1.0;
+    v3set(nl, 0, 0, 0); nl[k] = sg; cl[k] = sg * bs[k];
+    dist = -best - r;
+  }
+  double nw[3], pw[3];                                       /* box -> sphere direction and closest box point, world */
+  for (int i = 0; i < 3; i++) {
+    nw[i] = bm[3 * i] * nl[0] + bm[3 * i + 1] * nl[1] + bm[3 * i + 2] * nl[2];
+    pw[i] = bp[i] + bm[3 * i] * cl[0] + bm[3 * i + 1] * cl[1] + bm[3 * i + 2] * cl[2];
+  }
+  for (int i = 0; i < 3; i++) { o->normal[i] = -nw[i]; o->pos[i] = pw[i] + nw[i] * 0.5 * dist; }
+  o->dist = dist;
+  return 1;
+}
+
+/* derivative of the squared distance between the box [-s, s]^3 and the point p + t a (box frame), over 2 */
+static double seg_box_dslope(const double *p, const double *a, const double *s, double t) {
+  double g = 0;
+  for (int i = 0; i < 3; i++) {
+    double x = p[i] + t * a[i], e = fabs(x) - s[i];
+    if (e > 0) g += a[i] * (x > 0 ? e : -e);
+  }
+  return g;
+}
+
+static int capsule_box(const double *cp, const double *ca, double r, double h, const double *bp, const double *bm, const double *bs,
+                       double margin, ncon *o) {
+  double d[3], p[3], a[3];
+  v3sub(d, cp, bp);
+  for (int i = 0; i < 3; i++) {
+    p[i] = bm[i] * d[0] + bm[3 + i] * d[1] + bm[6 + i] * d[2];
+    a[i] = bm[i] * ca[0] + bm[3 + i] * ca[1] + bm[6 + i] * ca[2];
+  }
+  /* breakpoints of the piecewise-linear slope: the segment crossing the six face planes; sorted with the two ends */
+  double T[8]; int nt = 0;
+  T[nt++] = -h;
+  for (int i = 0; i < 3; i++) {
+    if (fabs(a[i]) < MINVAL) continue;
+    for (int sg = -1; sg <= 1; sg += 2) { double t = (sg * bs[i] - p[i]) / a[i]; if (t > -h && t < h) T[nt++] = t; }
+  }
+  T[nt++] = h;
+  for (int i = 1; i < nt; i++) { double x = T[i]; int j = i; while (j > 0 && T[j - 1] > x) { T[j] = T[j - 1]; j--; } T[j] = x; }
+  /* the slope g is continuous, piecewise linear and non-decreasing: the minimiser is where it crosses zero; when it is
+   * zero over a range (segment inside the box, or parallel to its nearest face) the middle of the range is taken */
+  double G[8], ts;
+  for (int k = 0; k < nt; k++) G[k] = seg_box_dslope(p, a, bs, T[k]);
+  if (G[0] > 0) ts = T[0];
+  else if (G[nt - 1] < 0) ts = T[nt - 1];
+  else {
+    int i = 0;
+    while (G[i] < 0) i++;
+    if (G[i] > 0) ts = T[i - 1] - G[i - 1] * (T[i] - T[i - 1]) / (G[i] - G[i - 1]);
+    else { int e = i; while (e + 1 < nt && G[e + 1] <= 0) e++; ts = 0.5 * (T[i] + T[e]); }
+  }
+  int n = 0;
+  double c[3];
+  for (int i = 0; i < 3; i++) c[i] = cp[i] + ts * ca[i];
+  n += sphere_box(c, r, bp, bm, bs, margin, o + n);
+  double t2 = ts >= 0 ? -h : h;                              /* the far end of the segment */
+  if (fabs(t2 - ts) > 1e-6 * (h > MINVAL ? h : 1.0)) {
+    for (int i = 0; i < 3; i++) c[i] = cp[i] + t2 * ca[i];
+    n += sphere_box(c, r, bp, bm, bs, margin, o + n);
+  }
+  return n;
+}
+
+/* signed distance of point x (world) to the box and the outward direction of the nearest surface point (world) */
+static double point_box_sdf(const double *x, const double *bp, const double *bm, const double *bs, double *cl_w, double *n_w) {
+  ncon t;
+  /* a zero-radius sphere; a point farther than any margin still needs its distance, so the margin is infinite here */
+  sphere_box(x, 0.0, bp, bm, bs, 1e300, &t);
+  for (int i = 0; i < 3; i++) { n_w[i] = -t.normal[i]; cl_w[i] = t.pos[i] - n_w[i] * 0.5 * t.dist; }
+  return t.dist;
+}
+
+static int box_box(const double *pa, const double *ma, const double *sa, const double *pb, const double *mb, const double *sb,
+                   double margin, ncon *o) {
+  double A[3][3], B[3][3], t[3], R[3][3], AR[3][3];
+  for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) { A[i][k] = ma[3 * k + i]; B[i][k] = mb[3 * k + i]; }   /* axes */
+  v3sub(t, pb, pa);
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { R[i][j] = v3dot(A[i], B[j]); AR[i][j] = fabs(R[i][j]); }
+  double best = -1e300; int bcode = -1; double bn[3] = {0, 0, 0};
+  /* face axes of A (code 0-2) and B (3-5) */
+  for (int i = 0; i < 3; i++) {
+    double tl = v3dot(t, A[i]);
+    double sep = fabs(tl) - (sa[i] + sb[0] * AR[i][0] + sb[1] * AR[i][1] + sb[2] * AR[i][2]);
+    if (sep > best) { best = sep; bcode = i; for (int k = 0; k < 3; k++) bn[k] = (tl >= 0 ? 1.0 : -1.0) * A[i][k]; }
+  }
+  for (int j = 0; j < 3; j++) {
+    double tl = v3dot(t, B[j]);
+    double sep = fabs(tl) - (sa[0] * AR[0][j] + sa[1] * AR[1][j] + sa[2] * AR[2][j] + sb[j]);
+    if (sep > best) { best = sep; bcode = 3 + j; for (int k = 0; k < 3; k++) bn[k] = (tl >= 0 ? 1.0 : -1.0) * B[j][k]; }
+  }
+  /* edge-edge axes A_i x B_j (code 6 + 3 i + j): chosen only when clearly less penetrating than the best face axis */
+  double ebest = -1e300; int ecode = -1; double en[3] = {0, 0, 0};
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+    double L[3]; v3cross(L, A[i], B[j]);
+    double ln = v3norm(L);
+    if (ln < 1e-6) continue;
+    v3set(L, L[0] / ln, L[1] / ln, L[2] / ln);
+    double tl = v3dot(t, L), ra = 0, rb = 0;
+    for (int k = 0; k < 3; k++) { ra += sa[k] * fabs(v3dot(A[k], L)); rb += sb[k] * fabs(v3dot(B[k], L)); }
+    double sep = fabs(tl) - (ra + rb);
+    if (sep > ebest) { ebest = sep; ecode = 6 + 3 * i + j; for (int k = 0; k < 3; k++) en[k] = (tl >= 0 ? 1.0 : -1.0) * L[k]; }
+  }
+  if (best > margin || ebest > margin) return 0;             /* a separating axis */
+  int n = 0;
+  if (ecode >= 0 && ebest > best + 1e-4 + 0.05 * fabs(best)) {
+    /* edge-edge: the supporting edge of A (direction A_i, through its vertex farthest along +n) and of B (along -n) */
+    int i = (ecode - 6) / 3, j = (ecode - 6) % 3;
+    double qa[3], qb[3];
+    v3cpy(qa, pa); v3cpy(qb, pb);
+    for (int k = 0; k < 3; k++) {
+      if (k != i) v3addscl(qa, A[k], (v3dot(en, A[k]) > 0 ? 1.0 : -1.0) * sa[k]);
+      if (k != j) v3addscl(qb, B[k], (v3dot(en, B[k]) > 0 ? -1.0 : 1.0) * sb[k]);
+    }
+    /* closest points of the two lines qa + x A_i, qb + y B_j */
+    double w[3]; v3sub(w, qa, qb);
+    double b_ = R[i][j], d_ = v3dot(A[i], w), e_ = v3dot(B[j], w), den = 1.0 - b_ * b_;
+    double x = den > 1e-12 ? (b_ * e_ - d_) / den : 0.0, y = den > 1e-12 ? (e_ - b_ * d_) / den : 0.0;
+    x = clampd(x, -sa[i], sa[i]); y = clampd(y, -sb[j], sb[j]);
+    for (int k = 0; k < 3; k++) {
+      double ca_ = qa[k] + x * A[i][k], cb_ = qb[k] + y * B[j][k];
+      o[0].pos[k] = 0.5 * (ca_ + cb_); o[0].normal[k] = en[k];
+    }
+    o[0].dist = ebest;
+    return 1;
+  }
+  /* face contact: vertices of either box within the margin of the other box's surface whose nearest surface point lies on
+   * the face the separating axis selects (normal within 45 degrees of the axis) */
+  for (int which = 0; which < 2 && n < 8; which++) {
+    const double *pv = which ? pa : pb, *sv = which ? sa : sb;         /* box providing the vertices */
+    const double (*V)[3] = which ? A : B;
+    const double *po = which ? pb : pa, *mo = which ? mb : ma, *so = which ? sb : sa;   /* box providing the surface */
+    for (int c = 0; c < 8 && n < 8; c++) {
+      double x[3]; v3cpy(x, pv);
+      for (int k = 0; k < 3; k++) v3addscl(x, V[k], ((c >> k) & 1 ? 1.0 : -1.0) * sv[k]);
+      double cl[3], nw[3];
+      double dist = point_box_sdf(x, po, mo, so, cl, nw);
+      if (dist > margin) continue;
+      /* nw: outward normal of the surface box at the nearest point; towards the vertex box it is +bn (surface = A) or -bn */
+      double al = v3dot(nw, bn) * (which ? -1.0 : 1.0);
+      if (al < 0.70710678) continue;
+      for (int k = 0; k < 3; k++) { o[n].pos[k] = 0.5 * (x[k] + cl[k]); o[n].normal[k] = bn[k]; }
+      o[n].dist = dist;
+      n++;
+    }
+  }
+  (void)bcode;
+  return n;
+}
+
+/* test hook: one pair function on raw geometry.  kind 0 capsule-capsule, 1 capsule-box, 2 box-box.  in: geom 1 then geom 2
+ * (capsule: centre3 axis3 radius halflength; box: centre3 rowmajor-rotation9 halfsizes3), then the margin.
+ * out: [n, then n x (pos3 normal3 dist)] */
+int om_narrow_phase(int kind, const double *in, double *out) {
+  ncon c[8]; int n = 0;
+  if (kind == 0) n = capsule_capsule(in, in + 3, in[6], in[7], in + 8, in + 11, in[14], in[15], in[16], c);
+  else if (kind == 1) n = capsule_box(in, in + 3, in[6], in[7], in + 8, in + 11, in + 20, in[23], c);
+  else n = box_box(in, in + 3, in + 12, in + 15, in + 18, in + 27, in[30], c);
+  out[0] = n;
+  for (int i = 0; i < n; i++) { memcpy(out + 1 + 7 * i, c[i].pos, 24); memcpy(out + 4 + 7 * i, c[i].normal, 24); out[7 + 7 * i] = c[i].dist; }
+  return n;
+}
+
+static void geom_world(const om_model *m, const om_data *d, int b, double *gp, double *gm) {
+  double t[3]; m3mulv(t, d->xmat[b], m->gpos[b]); v3add(gp, d->xpos[b], t);
+  m3mul(gm, d->xmat[b], m->gmat[b]);
+}
+
+/* body-body contacts appended behind the floor contacts; touch[] (the env's termination rule) stays floor-only */
+static void collide_bodies(const om_model *m, om_data *d) {
+  d->nself = 0; d->nself_dropped = 0;
+  if (!m->self_collision) return;
+  int first = d->ncon;
+  for (int q = 0; q < m->npair; q++) {
+    int b1 = m->pair_b1[q], b2 = m->pair_b2[q];
+    double p1[3], m1[9], p2[3], m2[9], dc[3];
+    geom_world(m, d, b1, p1, m1); geom_world(m, d, b2, p2, m2);
+    v3sub(dc, p2, p1);
+    if (v3norm(dc) > m->brad[b1] + m->brad[b2] + m->margin) continue;     /* bounding spheres */
+    ncon out[8]; int n = 0;
+    double a1[3] = {m1[2], m1[5], m1[8]}, a2[3] = {m2[2], m2[5], m2[8]};
+    if (m->gtype[b1] == OM_GEOM_CAPSULE && m->gtype[b2] == OM_GEOM_CAPSULE)
+      n = capsule_capsule(p1, a1, m->gsize[b1][0], m->gsize[b1][1], p2, a2, m->gsize[b2][0], m->gsize[b2][1], m->margin, out);
+    else if (m->gtype[b1] == OM_GEOM_CAPSULE)
+      n = capsule_box(p1, a1, m->gsize[b1][0], m->gsize[b1][1], p2, m2, m->gsize[b2], m->margin, out);
+    else
+      n = box_box(p1, m1, m->gsize[b1], p2, m2, m->gsize[b2], m->margin, out);
+    for (int i = 0; i < n && d->ncon < MAXCON; i++) {
+      int c = d->ncon++;
+      d->con_body1[c] = b1; d->con_body[c] = b2; d->con_dist[c] = out[i].dist;
+      v3cpy(d->con_pos[c], out[i].pos);
+      memset(d->con_frame[c], 0, 9 * sizeof(double)); v3cpy(d->con_frame[c], out[i].normal);
+      make_frame(d->con_frame[c]);
+    }
+  }
+  d->nself = d->ncon - first;
+  if (m->max_self > 0 && d->nself > m->max_self) {           /* keep the deepest max_self (stable: ties keep pair order) */
+    int keep = m->max_self, idx[MAXCON], ns = d->nself;
+    for (int i = 0; i < ns; i++) idx[i] = first + i;
+    for (int i = 1; i < ns; i++) { int x = idx[i], j = i; while (j > 0 && d->con_dist[idx[j - 1]] > d->con_dist[x]) { idx[j] = idx[j - 1]; j--; } idx[j] = x; }
+    for (int i = 1; i < keep; i++) { int x = idx[i], j = i; while (j > 0 && idx[j - 1] > x) { idx[j] = idx[j - 1]; j--; } idx[j] = x; }   /* back in pair order */
+    for (int i = 0; i < keep; i++) {
+      int sidx = idx[i], c = first + i;
+      d->con_body1[c] = d->con_body1[sidx]; d->con_body[c] = d->con_body[sidx]; d->con_dist[c] = d->con_dist[sidx];
+      v3cpy(d->con_pos[c], d->con_pos[sidx]); memcpy(d->con_frame[c], d->con_frame[sidx], 9 * sizeof(double));
+    }
+    d->nself_dropped = ns - keep; d->nself = keep; d->ncon = first + keep;
   }
 }
 
@@ -502,21 +809,28 @@ static void make_constraints(const om_model *m, om_data *d) {
   }
   int first_contact_row = r;
   for (int c = 0; c < d->ncon; c++) {
-    int b = d->con_body[c];
-    double jn[OM_MAXV], jt1[OM_MAXV], jt2[OM_MAXV];
-    int n = m->chain_len[b];
-    for (int a = 0; a < n; a++) {
-      double jv[3], jw[3]; dof_jac(m, d, m->chain[b][a], d->con_pos[c], jv, jw);
-      jn[a] = v3dot(d->con_frame[c], jv); jt1[a] = v3dot(d->con_frame[c] + 3, jv); jt2[a] = v3dot(d->con_frame[c] + 6, jv);
+    /* relative velocity of the contact point: body 2 minus body 1 (floor contacts: body 1 = world, no Jacobian, weight 0) */
+    double fn[OM_MAXV], ft1[OM_MAXV], ft2[OM_MAXV];
+    memset(fn, 0, sizeof(double) * nv); memset(ft1, 0, sizeof(double) * nv); memset(ft2, 0, sizeof(double) * nv);
+    double w = 0;
+    for (int side = 0; side < 2; side++) {
+      int b = side ? d->con_body[c] : d->con_body1[c];
+      if (b < 0) continue;
+      double sgn = side ? 1.0 : -1.0;
+      for (int a = 0; a < m->chain_len[b]; a++) {
+        double jv[3], jw[3]; dof_jac(m, d, m->chain[b][a], d->con_pos[c], jv, jw);
+        int dof = m->chain[b][a];
+        fn[dof] += sgn * v3dot(d->con_frame[c], jv); ft1[dof] += sgn * v3dot(d->con_frame[c] + 3, jv); ft2[dof] += sgn * v3dot(d->con_frame[c] + 6, jv);
+      }
+      w += m->body_invw[b][0];
     }
     for (int k = 0; k < 4; k++) {
       double *row = d->J + (size_t)r * nv;
-      memset(row, 0, sizeof(double) * nv);
-      const double *jt = k < 2 ? jt1 : jt2;
+      const double *jt = k < 2 ? ft1 : ft2;
       double sg = (k & 1) ? -m->mu : m->mu;
-      for (int a = 0; a < n; a++) row[m->chain[b][a]] = jn[a] + sg * jt[a];
+      for (int a = 0; a < nv; a++) row[a] = fn[a] + sg * jt[a];
       d->epos[r] = d->con_dist[c]; d->emargin[r] = m->margin;
-      d->ediag[r] = m->body_invw[b][0] * (1 + m->mu * m->mu);   /* world body weight = 0 */
+      d->ediag[r] = w * (1 + m->mu * m->mu);
       r++;
     }
   }
@@ -669,6 +983,7 @@ void om_forward(const om_model *m, om_data *d) {
   om_kinematics(m, d);
   compute_M(m, d);
   collide(m, d);
+  collide_bodies(m, d);
   compute_bias(m, d);                                       /* velocity stage: sensors + bias */
   make_constraints(m, d);
   memset(d->qfrc_act, 0, sizeof(double) * nv);
@@ -1008,6 +1323,8 @@ int om_get(const om_model *m, const om_data *d, int f, double *out) {
     case OM_D_CON_FRAME: memcpy(out, d->con_frame, sizeof(double) * 9 * d->ncon); return 9 * d->ncon;
     case OM_D_CON_DIST: memcpy(out, d->con_dist, sizeof(double) * d->ncon); return d->ncon;
     case OM_D_CON_BODY: for (int c = 0; c < d->ncon; c++) out[c] = d->con_body[c]; return d->ncon;
+    case OM_D_CON_BODY1: for (int c = 0; c < d->ncon; c++) out[c] = d->con_body1[c]; return d->ncon;
+    case OM_D_NSELF: out[0] = d->nself; out[1] = m->npair; out[2] = d->nself_dropped; return 3;
     case OM_D_QACC_SMOOTH: memcpy(out, d->qacc_smooth, sizeof(double) * nv); return nv;
     case OM_D_QFRC_CONSTRAINT: memcpy(out, d->qfrc_constraint, sizeof(double) * nv); return nv;
     case OM_D_NEFC: out[0] = d->nefc; return 1;

@@ -39,6 +39,13 @@ typedef struct {
   const double *kp, *kd, *torque_lim, *act_scale, *act_offset; /* [nu] */
   const int32_t *legal_contact; /* [nbody] bodies allowed to touch the floor (contact_bodies) */
   double timestep, gravity, solref[2], solimp[5], margin, mu, impratio;
+  /* body-body contacts (reference smpl_humanoid.xml:5,24,231-242): geom contype / conaffinity bit masks, <contact><exclude>
+   * body pairs; parent-child pairs are filtered like MuJoCo's filterparent.  self_collision 0 = floor contacts only. */
+  int self_collision;
+  const int32_t *contype, *conaffinity; /* [nbody] or NULL (= 1, 1) */
+  int nexclude;
+  const int32_t *exclude;     /* [nexclude,2] body indices */
+  int max_self_contacts;      /* 0 = all; otherwise the deepest N body-body contacts are kept (the HIP kernel's capacity) */
 } om_desc;
 
 typedef struct om_model om_model;
@@ -57,7 +64,8 @@ void om_data_destroy(om_data *d);
 enum { OM_D_QPOS = 0, OM_D_QVEL, OM_D_QACC, OM_D_WARM, OM_D_CTRL, OM_D_M, OM_D_BIAS, OM_D_XPOS, OM_D_XQUAT,
        OM_D_LINVEL, OM_D_ANGVEL, OM_D_TOUCH, OM_D_NCON, OM_D_CON_POS, OM_D_CON_DIST, OM_D_CON_BODY,
        OM_D_QACC_SMOOTH, OM_D_NEFC, OM_D_EFC_FORCE, OM_D_SOLVER_ITER, OM_D_ENERGY, OM_D_XIPOS,
-       OM_D_QFRC_CONSTRAINT, OM_D_CON_FRAME };
+       OM_D_QFRC_CONSTRAINT, OM_D_CON_FRAME, OM_D_CON_BODY1 /* first body of every contact, -1 = floor */,
+       OM_D_NSELF /* [contacts between two bodies, candidate pairs of the model, contacts dropped by max_self_contacts] */ };
 int om_get(const om_model *m, const om_data *d, int field, double *out);
 int om_set(const om_model *m, om_data *d, int field, const double *in);
 
@@ -95,6 +103,7 @@ void om_env_step(om_env *e, const double *action, const double *task_rand, float
                  int *terminated, int *truncated);
 void om_env_obs(om_env *e, float *obs);   /* compute_observations() on the current state */
 void om_quat_op(int op, const double *a, const double *b, double *out);
+int om_narrow_phase(int kind, const double *in, double *out);   /* pair functions on raw geometry (test hook, see oracle.c) */
 /* task scalars: [cur_t, tar_speed|tar_height|tar_x, change_steps, recovery_counter, prev_root_pos xyz, tar_y, tar_z] */
 void om_env_get_task(const om_env *e, double *out9);
 void om_env_set_task(om_env *e, const double *in9);

@@ -22,7 +22,7 @@ INIT_DEFAULT, INIT_FALL, INIT_EXTERNAL = 0, 1, 2
 M_MASS, M_IPOS, M_IQUAT, M_INERTIA, M_GPOS, M_GQUAT, M_GSIZE, M_BODY_INVW, M_DOF_INVW, M_RANGE = range(10)
 (D_QPOS, D_QVEL, D_QACC, D_WARM, D_CTRL, D_M, D_BIAS, D_XPOS, D_XQUAT, D_LINVEL, D_ANGVEL, D_TOUCH, D_NCON,
  D_CON_POS, D_CON_DIST, D_CON_BODY, D_QACC_SMOOTH, D_NEFC, D_EFC_FORCE, D_SOLVER_ITER, D_ENERGY, D_XIPOS,
- D_QFRC_CONSTRAINT, D_CON_FRAME) = range(24)
+ D_QFRC_CONSTRAINT, D_CON_FRAME, D_CON_BODY1, D_NSELF) = range(26)
 
 
 class _Desc(C.Structure):
@@ -34,6 +34,8 @@ class _Desc(C.Structure):
         ("legal_contact", C.c_void_p), ("timestep", C.c_double), ("gravity", C.c_double),
         ("solref", C.c_double * 2), ("solimp", C.c_double * 5), ("margin", C.c_double), ("mu", C.c_double),
         ("impratio", C.c_double),
+        ("self_collision", C.c_int), ("contype", C.c_void_p), ("conaffinity", C.c_void_p), ("nexclude", C.c_int), ("exclude", C.c_void_p),
+        ("max_self_contacts", C.c_int),
     ]
 
 
@@ -112,6 +114,7 @@ def lib():
         L.om_env_set_task.argtypes = [C.c_void_p, C.c_void_p]
         L.om_obs_v1.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p]
         L.om_obs_v2.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p]
+        L.om_narrow_phase.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
         L.om_batch_rollout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.om_batch_rollout.restype = C.c_long
         _LIB = L
@@ -129,7 +132,7 @@ def read_mjcf_primitives(xml):
     dj = dict(dflt.find("joint").attrib) if dflt is not None and dflt.find("joint") is not None else {}
     dg = dict(dflt.find("geom").attrib) if dflt is not None and dflt.find("geom") is not None else {}
     P = dict(names=[], parent=[], pos=[], gtype=[], gparams=[], density=[], armature=[0.0] * 6,
-             range_deg=[[0.0, 0.0]] * 6, limited=[0] * 6, jnames=[])
+             range_deg=[[0.0, 0.0]] * 6, limited=[0] * 6, jnames=[], contype=[], conaffinity=[])
     f = lambda s: [float(x) for x in s.split()]
 
     def walk(el, par):
@@ -151,16 +154,22 @@ def read_mjcf_primitives(xml):
                 P["gtype"].append(1)
                 P["gparams"].append(f(g["fromto"]) + [f(g["size"])[0], 0.0, 0.0, 0.0])
             P["density"].append(float(g.get("density", 1000)))
+            P["contype"].append(int(g.get("contype", 1))); P["conaffinity"].append(int(g.get("conaffinity", 1)))
             walk(b, i)
 
     walk(root.find("worldbody"), -1)
     P["motors"] = [(m.get("name"), m.get("joint")) for m in root.find("actuator").findall("motor")]
     P["margin"] = float(dg.get("margin", 0))
+    con = root.find("contact")
+    P["exclude"] = [(P["names"].index(e.get("body1")), P["names"].index(e.get("body2"))) for e in con.findall("exclude")] if con is not None else []
     return P
 
 
 class OracleModel:
-    def __init__(self, xml, kp, kd, torque_lim, act_scale, act_offset, legal_bodies=(), timestep=1.0 / 450):
+    def __init__(self, xml, kp, kd, torque_lim, act_scale, act_offset, legal_bodies=(), timestep=1.0 / 450, self_collision=False,
+                 max_self_contacts=0):
+        """self_collision: body-body contacts per the MJCF's contype / conaffinity / excludes (False = floor only);
+        max_self_contacts: keep only the deepest N of them (0 = all)."""
         P = read_mjcf_primitives(xml)
         self.prim = P
         self.nbody = len(P["names"])
@@ -178,6 +187,8 @@ class OracleModel:
             tl=np.ascontiguousarray(torque_lim, dtype=np.float64), sc=np.ascontiguousarray(act_scale, dtype=np.float64),
             of=np.ascontiguousarray(act_offset, dtype=np.float64),
             legal=np.array([int(n in legal_bodies) for n in P["names"]], dtype=np.int32),
+            contype=np.array(P["contype"], dtype=np.int32), conaffinity=np.array(P["conaffinity"], dtype=np.int32),
+            exclude=np.array(P["exclude"], dtype=np.int32).reshape(-1, 2),
         )
         k = self._keep
         d = _Desc(nbody=self.nbody, parent=_p(k["parent"]), body_pos=_p(k["pos"]), geom_type=_p(k["gtype"]),
@@ -186,7 +197,9 @@ class OracleModel:
                   kp=_p(k["kp"]), kd=_p(k["kd"]), torque_lim=_p(k["tl"]), act_scale=_p(k["sc"]),
                   act_offset=_p(k["of"]), legal_contact=_p(k["legal"]), timestep=timestep, gravity=-9.81,
                   solref=(C.c_double * 2)(0.02, 1.0), solimp=(C.c_double * 5)(0.9, 0.95, 0.001, 0.5, 2.0),
-                  margin=P["margin"], mu=1.0, impratio=1.0)
+                  margin=P["margin"], mu=1.0, impratio=1.0, self_collision=int(bool(self_collision)), contype=_p(k["contype"]),
+                  conaffinity=_p(k["conaffinity"]), nexclude=len(P["exclude"]), exclude=_p(k["exclude"]) if len(P["exclude"]) else None,
+                  max_self_contacts=int(max_self_contacts))
         self.h = lib().om_model_create(C.byref(d))
         if not self.h:
             raise RuntimeError("om_model_create failed")
@@ -239,6 +252,12 @@ class OracleData:
     angvel = property(lambda s: s.get(D_ANGVEL).reshape(-1, 3))
     touch = property(lambda s: s.get(D_TOUCH))
     ncon = property(lambda s: int(s.get(D_NCON)[0]))
+    con_body = property(lambda s: s.get(D_CON_BODY).astype(int))
+    con_body1 = property(lambda s: s.get(D_CON_BODY1).astype(int))          # -1 = floor
+    con_pos = property(lambda s: s.get(D_CON_POS).reshape(-1, 3))
+    con_dist = property(lambda s: s.get(D_CON_DIST))
+    con_frame = property(lambda s: s.get(D_CON_FRAME).reshape(-1, 3, 3))
+    nself = property(lambda s: int(s.get(D_NSELF)[0]))                      # contacts between two bodies
     solver_iter = property(lambda s: int(s.get(D_SOLVER_ITER)[0]))
     nwarn = property(lambda s: int(s.get(D_SOLVER_ITER)[1]))     # mj_checkPos/Vel/Acc autoresets so far
 
@@ -272,6 +291,16 @@ class OracleData:
                 lib().om_data_destroy(self.h)
             except Exception:
                 pass
+
+
+def narrow_phase(kind, g1, g2, margin=0.001):
+    """Pair function on raw geometry.  kind: "cc" | "cb" | "bb"; capsule = (centre, axis, radius, half length), box = (centre,
+    rotation 3x3 with the box axes as columns, half sizes).  Returns a list of (pos, normal geom1->geom2, dist)."""
+    flat = lambda g: np.concatenate([np.ravel(np.asarray(x, dtype=np.float64)) for x in g])
+    inp = np.ascontiguousarray(np.concatenate([flat(g1), flat(g2), [margin]]))
+    out = np.zeros(1 + 7 * 8)
+    n = lib().om_narrow_phase({"cc": 0, "cb": 1, "bb": 2}[kind], _p(inp), _p(out))
+    return [(out[1 + 7 * i:4 + 7 * i].copy(), out[4 + 7 * i:7 + 7 * i].copy(), float(out[7 + 7 * i])) for i in range(n)]
 
 
 def _rand4(u):
