@@ -63,6 +63,13 @@ typedef struct {
   const double *kp, *kd, *torque_lim, *act_scale, *act_offset;   /* [nu] */
   const uint8_t *legal_contact;  /* [nbody] bodies allowed to touch the floor (cfg.env.contact_bodies) */
   double timestep, gravity, solref[2], solimp[5], margin, friction, impratio;
+  /* body-body contacts (reference smpl_humanoid.xml:5,24 contype / conaffinity, :231-242 <exclude> pairs; parent-child pairs
+   * are filtered like MuJoCo's filterparent): the candidate pair table is built from these; ss_env_cfg.self_collision turns
+   * the pair functions on.  contype / conaffinity may be NULL (= 1) */
+  const int32_t *geom_contype;   /* [nbody] */
+  const int32_t *geom_conaffinity; /* [nbody] */
+  int32_t nexclude;
+  const int32_t *exclude;        /* [nexclude,2] body indices */
 } ss_model_desc;
 
 /* Environment configuration (the keys of the reference's smpl_sim/data/cfg/env yaml files). */
@@ -76,7 +83,11 @@ typedef struct {
   /* reach task (tasks/humanoid_reach.py): target x,y in +-tar_dist_max, z in [tar_height_min, tar_height_max], resampled
    * every [height_change_min, height_change_max) steps; reward on the world position of body `reach_body` */
   float tar_dist_max; int32_t reach_body;
+  /* 1: contacts between the humanoid's own bodies (capsule-capsule, capsule-box, box-box) as mj_step makes
+   * them for the reference MJCF; 0: floor contacts and joint limits only.  At most SS_MAX_SELF_CONTACTS (the deepest) per env */
+  int32_t self_collision;
 } ss_env_cfg;
+enum { SS_MAX_SELF_CONTACTS = 8 };
 
 /* Device buffers of one shard of environments (all caller-owned, float32 unless noted). */
 typedef struct {
@@ -101,6 +112,8 @@ typedef struct {
   /* models made by ss_model_create_shapes only (NULL otherwise): body shape of every env, 0 .. num_shapes-1; read by every
    * launch, so it may be rewritten between launches (e.g. a new body at reset) */
   const int32_t *shape_id; /* [N] */
+  /* optional (may be NULL): body-body contacts of every env at its last forward pass [N] (self_collision envs) */
+  int32_t *self_contacts;
 } ss_state;
 
 typedef struct ss_model ss_model;

@@ -608,17 +608,21 @@ static int capsule_box(const double *cp, const double *ca, double r, double h, c
   }
   T[nt++] = h;
   for (int i = 1; i < nt; i++) { double x = T[i]; int j = i; while (j > 0 && T[j - 1] > x) { T[j] = T[j - 1]; j--; } T[j] = x; }
-  /* the slope g is continuous, piecewise linear and non-decreasing: the minimiser is where it crosses zero; when it is
-   * zero over a range (segment inside the box, or parallel to its nearest face) the middle of the range is taken */
+  /* the slope g is continuous, piecewise linear and non-decreasing: the minimiser is where it crosses zero.  When it is zero
+   * over a range (segment inside the box, or parallel to its nearest face) the middle of the range is taken; "zero" is
+   * |g| <= tol with tol far above float32 rounding of g, so that the float32 kernel and this code take the same branch when
+   * the exact slope at a breakpoint is zero (a segment entering the box has g = 0 at the entry breakpoint up to rounding) */
   double G[8], ts;
+  const double bmax = bs[0] > bs[1] ? (bs[0] > bs[2] ? bs[0] : bs[2]) : (bs[1] > bs[2] ? bs[1] : bs[2]);
+  const double tol = 1e-5 * (h + bmax);
   for (int k = 0; k < nt; k++) G[k] = seg_box_dslope(p, a, bs, T[k]);
-  if (G[0] > 0) ts = T[0];
-  else if (G[nt - 1] < 0) ts = T[nt - 1];
+  if (G[0] > tol) ts = T[0];
+  else if (G[nt - 1] < -tol) ts = T[nt - 1];
   else {
     int i = 0;
-    while (G[i] < 0) i++;
-    if (G[i] > 0) ts = T[i - 1] - G[i - 1] * (T[i] - T[i - 1]) / (G[i] - G[i - 1]);
-    else { int e = i; while (e + 1 < nt && G[e + 1] <= 0) e++; ts = 0.5 * (T[i] + T[e]); }
+    while (G[i] < -tol) i++;
+    if (G[i] > tol) ts = T[i - 1] - G[i - 1] * (T[i] - T[i - 1]) / (G[i] - G[i - 1]);
+    else { int e = i; while (e + 1 < nt && G[e + 1] <= tol) e++; ts = 0.5 * (T[i] + T[e]); }
   }
   int n = 0;
   double c[3];

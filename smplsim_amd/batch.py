@@ -81,7 +81,7 @@ class SMPLSimVecEnv:
                  control_mode="uhc_pd", episode_length=300, control_freq_inv=15, root_height_obs=True,
                  power_scale=1.0, tar_speed=(0.0, 5.0), speed_change=(100, 200), tar_height=(0.5, 1.2),
                  height_change=(100, 200), recovery_steps=60, tar_dist_max=1.0, reach_body="R_Hand", newton_iters=8, fused_autoreset=True,
-                 autoreset=True, seed=0, lpt_order=True, shape_id=None,
+                 autoreset=True, seed=0, lpt_order=True, shape_id=None, self_collision=False,
                  **model_kw):
         self.device = _shard_device(device if model is None else model.device)   # raises before any table is built without a GPU
         self.model = model if model is not None else ShardModel(device=device, control_mode=control_mode, **model_kw)
@@ -101,7 +101,8 @@ class SMPLSimVecEnv:
             control_freq_inv=control_freq_inv, root_height_obs=root_height_obs, power_scale=power_scale,
             tar_speed=tar_speed, speed_change=speed_change, tar_height=tar_height, height_change=height_change,
             recovery_steps=recovery_steps, newton_iters=newton_iters, tar_dist_max=tar_dist_max,
-            reach_body=self._body_index(mc, reach_body))
+            reach_body=self._body_index(mc, reach_body), self_collision=self_collision)
+        self.self_collision = bool(self_collision)
         N, dev = self.num_envs, self.device
         f32 = dict(dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
@@ -114,6 +115,7 @@ class SMPLSimVecEnv:
         # SimplePID controller state (control_mode simple_pid; lives as long as the env, like the reference's object)
         self.pid_integral = torch.zeros(N, self.nu, **f32); self.pid_last_error = torch.zeros(N, self.nu, **f32)
         self.pid_started = torch.zeros(N, **i32)
+        self.self_contacts = torch.zeros(N, **i32)           # body-body contacts of every env at its last forward (self_collision)
         self.qpos[:, 3] = 1; self.qpos_prev[:, 3] = 1
         # per-env body shape (models built from several MJCFs): read by every launch, may be rewritten between launches
         self.shape_id = None
@@ -127,7 +129,7 @@ class SMPLSimVecEnv:
         st = _cabi.State(N, *[_ptr(t) for t in (self.qpos, self.qvel, self.qpos_prev, self.qvel_prev, self.qacc_warm,
                                                self.body_vel, self.touch, self.cur_t, self.task_state, self.nwarn,
                                                self.solver_iters, self.pid_integral, self.pid_last_error,
-                                               self.pid_started, self.shape_id)])
+                                               self.pid_started, self.shape_id, self.self_contacts)])
         self.handle = C.c_void_p()
         _check(lib().ss_batch_create(self.model.handle, C.byref(self.cfg), C.byref(st), C.byref(self.handle)))
         self.obs_size = lib().ss_obs_size(self.model.handle, C.byref(self.cfg))

@@ -19,17 +19,22 @@
 #ifndef SS_MAX_THREADS_X
 #define SS_MAX_THREADS_X 384
 #endif
+// self-collision instantiation of the SMPL size: its LDS slice (18.2 KB) lets 8 envs share a CU -> 2 waves/SIMD, 256 VGPRs
+#ifndef SS_MAX_THREADS_SC
+#define SS_MAX_THREADS_SC 512
+#endif
 
 namespace {
 
 
-template <int DOFP, int CANDP, int SLOTP, int NPASS, int MAXT, bool BODYOUT, bool SHAPED, class HT = ss::HdrRuntime>
+template <int DOFP, int CANDP, int SLOTP, int NPASS, int MAXT, bool BODYOUT, bool SHAPED, class HT = ss::HdrRuntime, bool SELFCOL = false>
 __global__ void __launch_bounds__(MAXT) ss_env_kernel(const ss::KArgs k) {
   extern __shared__ __align__(16) uint32_t lds[];
   for (int i = threadIdx.x; i < k.h.shared_words; i += blockDim.x) lds[i] = k.shared_g[i];
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> LDS bases stay in SGPRs
-  float *L = reinterpret_cast<float *>(lds + ((k.h.shared_words + 3) & ~3)) + (size_t)wave * HT::view(k.h).env_floats;
+  const int slice = SELFCOL ? k.sc.env_floats : HT::view(k.h).env_floats;
+  float *L = reinterpret_cast<float *>(lds + ((k.h.shared_words + 3) & ~3)) + (size_t)wave * slice;
   WaveGpu w{(int)(threadIdx.x & 63)};
   // persistent wavefronts: env-steps have heavy-tailed cost (Newton iterations), so every wave pulls the
   // next env id from a device counter instead of owning a fixed slice of the batch.  The first env of every wave is
@@ -47,7 +52,7 @@ __global__ void __launch_bounds__(MAXT) ss_env_kernel(const ss::KArgs k) {
     if (k.order) env = __builtin_amdgcn_readfirstlane(k.order[env]);   // longest-processing-time-first hand-out
     int mode = k.mode;
     for (int rep = 0; rep < 2; rep++) {                       // second trip = fused Default reset of an env whose episode ended
-      const bool again = ss::run_env<WaveGpu, DOFP, CANDP, SLOTP, NPASS, BODYOUT, SHAPED, HT>(&w, &k, lds, L, env, mode);
+      const bool again = ss::run_env<WaveGpu, DOFP, CANDP, SLOTP, NPASS, BODYOUT, SHAPED, HT, SELFCOL>(&w, &k, lds, L, env, mode);
       w.sync();
       if (!again) break;
       mode = ss::MODE_RESET;
@@ -101,6 +106,11 @@ kern_t pick_kernel(int variant, int flavour, const ss::Hdr &h) {
 #endif
   if (variant == 0 && flavour == 0) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, false, false>;
 #ifndef SS_ONLY_HEADLINE                                     // (experiment builds, tools/build_variant.sh, keep the headline kernel alone)
+  if (flavour == 3) {                                        // body-body contacts (ss_env_cfg.self_collision); also writes the body frames
+    if (variant == 0) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS_SC, true, false, ss::HdrRuntime, true>;
+    if (variant == 1) return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, true, false, ss::HdrRuntime, true>;
+    return nullptr;
+  }
   if (variant == 0) {                                        // SMPL layout (24 bodies)
     if (flavour == 1) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, false>;
     return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, true>;
@@ -122,7 +132,7 @@ struct HipBackend {
   static bool download(void *dst, const void *src, size_t n) { return hipMemcpy(dst, src, n, hipMemcpyDeviceToHost) == hipSuccess; }
   static int lds_capacity() { return 160 * 1024; }
   static int num_cus() { int d = 0, n = 256; if (hipGetDevice(&d) == hipSuccess) { hipDeviceProp_t p; if (hipGetDeviceProperties(&p, d) == hipSuccess) n = p.multiProcessorCount; } return n; }
-  static int max_waves(int variant) { return (variant == 0 ? SS_MAX_THREADS : SS_MAX_THREADS_X) / 64; }
+  static int max_waves(int variant, int selfcol) { return (variant == 0 ? (selfcol ? SS_MAX_THREADS_SC : SS_MAX_THREADS) : SS_MAX_THREADS_X) / 64; }
   static const char *order_by_iters(const int32_t *iters, int32_t *order, int n, void *stream) {
     hipLaunchKernelGGL(ss_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, iters, order, n);
     hipError_t e = hipGetLastError();
@@ -138,12 +148,12 @@ struct HipBackend {
   static int kernel_regs() { return regs_ref(); }
   static const char *launch(const ss::KArgs &k, int nenv, int envs_per_wg, size_t lds_bytes, void *stream, int fixed_epw, int max_wgs) {
     const bool bodyout = k.out0 && (k.mode == ss::MODE_STEP || k.mode == ss::MODE_RESET);
-    const int flavour = k.st.shape_id ? 2 : (bodyout ? 1 : 0);
+    const int flavour = k.cfg.self_collision ? 3 : (k.st.shape_id ? 2 : (bodyout ? 1 : 0));
     kern_t kern = pick_kernel(ss::kernel_variant(k.h), flavour, k.h);
     if (!kern) return "no kernel variant for this model size";
-    static thread_local kern_t configured[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    static thread_local size_t configured_lds[6] = {0, 0, 0, 0, 0, 0};
-    const int slot = 3 * ss::kernel_variant(k.h) + flavour;
+    static thread_local kern_t configured[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    static thread_local size_t configured_lds[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int slot = 4 * ss::kernel_variant(k.h) + flavour;
     if (configured[slot] != kern || configured_lds[slot] < lds_bytes) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
       if (e != hipSuccess) return hipGetErrorString(e);
@@ -157,10 +167,10 @@ struct HipBackend {
     const int per_cu = (nenv + cus - 1) / cus;
     if (fixed_epw > 0) {                                      // fixed by the caller (ss_set_launch_geometry)
       envs_per_wg = fixed_epw;
-      lds_bytes = (size_t)((k.h.shared_words + 3) & ~3) * 4 + (size_t)envs_per_wg * k.h.env_floats * 4;
+      lds_bytes = (size_t)((k.h.shared_words + 3) & ~3) * 4 + (size_t)envs_per_wg * ss::env_slice_floats(k) * 4;
     } else if (per_cu < envs_per_wg) {
       envs_per_wg = per_cu < 1 ? 1 : per_cu;
-      lds_bytes = (size_t)((k.h.shared_words + 3) & ~3) * 4 + (size_t)envs_per_wg * k.h.env_floats * 4;
+      lds_bytes = (size_t)((k.h.shared_words + 3) & ~3) * 4 + (size_t)envs_per_wg * ss::env_slice_floats(k) * 4;
     }
     int wgs = (nenv + envs_per_wg - 1) / envs_per_wg;
     const int resident = cus * (int)(lds_capacity() / lds_bytes > 0 ? lds_capacity() / lds_bytes : 1);

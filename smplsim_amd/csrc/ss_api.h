@@ -21,6 +21,8 @@ struct ss_model {
   uint32_t *d_shared = nullptr;
   ss::real *d_bodyc = nullptr, *d_candc = nullptr;
   int32_t *d_candb = nullptr;
+  int32_t *d_pairs = nullptr;             // body-body candidate pairs, geom table (self_collision batches)
+  ss::real *d_geomc = nullptr;
   int num_shapes = 1;                     // ss_model_create_shapes: d_bodyc / d_candc hold num_shapes consecutive tables (ss_hdr.h)
 };
 struct ss_batch {
@@ -60,7 +62,9 @@ struct ss_api {
     m->d_bodyc = (ss::real *)up(m->hm.bodyc.data(), m->hm.bodyc.size() * sizeof(ss::real));
     m->d_candc = (ss::real *)up(m->hm.candc.data(), m->hm.candc.size() * sizeof(ss::real));
     m->d_candb = (int32_t *)up(m->hm.candb.data(), m->hm.candb.size() * 4);
-    if (!m->d_shared || !m->d_bodyc || !m->d_candc || !m->d_candb) { model_destroy(m); return fail(SS_ERR_HIP, "device table upload failed"); }
+    m->d_pairs = (int32_t *)up(m->hm.pairs.data(), m->hm.pairs.size() * 4);
+    m->d_geomc = (ss::real *)up(m->hm.geomc.data(), m->hm.geomc.size() * sizeof(ss::real));
+    if (!m->d_shared || !m->d_bodyc || !m->d_candc || !m->d_candb || !m->d_pairs || !m->d_geomc) { model_destroy(m); return fail(SS_ERR_HIP, "device table upload failed"); }
     *out = m;
     return SS_OK;
   }
@@ -112,7 +116,7 @@ struct ss_api {
   }
   static void model_destroy(ss_model *m) {
     if (!m) return;
-    BE::free_(m->d_shared); BE::free_(m->d_bodyc); BE::free_(m->d_candc); BE::free_(m->d_candb);
+    BE::free_(m->d_shared); BE::free_(m->d_bodyc); BE::free_(m->d_candc); BE::free_(m->d_candb); BE::free_(m->d_pairs); BE::free_(m->d_geomc);
     delete m;
   }
   static int batch_create(const ss_model *m, const ss_env_cfg *cfg, const ss_state *st, ss_batch **out) {
@@ -128,6 +132,8 @@ struct ss_api {
     if (cfg->control_freq_inv < 1) return fail(SS_ERR_INVALID, "control_freq_inv must be >= 1");
     if (m->num_shapes > 1 && !st->shape_id) return fail(SS_ERR_INVALID, "a model with several shapes needs ss_state.shape_id");
     if (m->num_shapes == 1 && st->shape_id) return fail(SS_ERR_INVALID, "ss_state.shape_id given for a single-shape model");
+    if (cfg->self_collision && m->num_shapes > 1) return fail(SS_ERR_INVALID, "self_collision with per-env body shapes is not supported yet");
+    if (cfg->self_collision && !m->d_pairs) return fail(SS_ERR_INVALID, "model has no pair table");
     if (cfg->task == SS_TASK_REACH && (cfg->reach_body < 0 || cfg->reach_body >= m->hm.h.nb)) return fail(SS_ERR_INVALID, "reach_body out of range");
     const ss::Hdr &h = m->hm.h;
     if (ss::kernel_variant(h) < 0) return fail(SS_ERR_INVALID, "model too large for the compiled kernel variants");
@@ -136,11 +142,12 @@ struct ss_api {
     b->m = m; b->cfg = *cfg; b->st = *st;
     if (b->cfg.newton_iters <= 0) b->cfg.newton_iters = 8;
     b->obs_size = ss::obs_size(h, *cfg);
-    size_t shared_b = (size_t)((h.shared_words + 3) & ~3) * 4, env_b = (size_t)h.env_floats * sizeof(ss::real);
+    size_t shared_b = (size_t)((h.shared_words + 3) & ~3) * 4;
+    const size_t env_b = (size_t)(cfg->self_collision ? m->hm.sc.env_floats : h.env_floats) * sizeof(ss::real);
     int cap = BE::lds_capacity();
     int e = (int)((cap - (long)shared_b) / (long)env_b);
     if (e < 1) { delete b; return fail(SS_ERR_LDS, "model does not fit in LDS"); }
-    { const int mw = BE::max_waves(ss::kernel_variant(h)); if (e > mw) e = mw; }   // launch bound of the kernel variant
+    { const int mw = BE::max_waves(ss::kernel_variant(h), cfg->self_collision); if (e > mw) e = mw; }   // launch bound of the kernel variant
     { const char *cap = getenv("SS_ENVS_PER_WG"); if (cap && atoi(cap) > 0 && atoi(cap) < e) e = atoi(cap); }
     b->envs_per_wg = e;
     b->lds_bytes = shared_b + (size_t)e * env_b;
@@ -160,6 +167,7 @@ struct ss_api {
     k.h = m->hm.h; k.cfg = b->cfg; k.st = b->st;
     k.shared_g = m->d_shared; k.bodyc = m->d_bodyc; k.candc = m->d_candc; k.candb = m->d_candb;
     k.illegal_mask = m->hm.illegal_mask;
+    k.sc = m->hm.sc; k.pairs = m->d_pairs; k.geomc = m->d_geomc;
     k.mode = mode; k.nsub = b->cfg.control_freq_inv; k.obs_size = b->obs_size;
     k.work_counter = b->d_counter;
     k.prof = b->d_prof;

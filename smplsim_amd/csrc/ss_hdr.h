@@ -85,6 +85,30 @@ constexpr Layout make_layout(int nb, int maxlev) {
   return y;
 }
 
+// Body-body contacts (SELFCOL instantiations, ss_env_cfg.self_collision): extra per-env LDS arrays behind the base layout and the
+// static pair table.  Kept out of Hdr: Hdr's layout is part of the plain kernels' register allocation.
+constexpr int kMaxSelf = SS_MAX_SELF_CONTACTS;   // body-body contacts kept per env (the deepest)
+constexpr int kSelfRec = 24;                     // floats per contact record: b1 b2 | pos3 | n3 | t13 | D | aref4 | jar4 | jd4 | pad
+constexpr int kSelfCand = 32;                    // narrow-phase candidates before the deepest kMaxSelf are kept
+constexpr int kGeomC = 16;                       // floats per body in the geom table: gpos3 gsize3 gmat9 (row-major) type
+struct HdrSC {
+  int npair;                                     // candidate body pairs of the model (b1 | b2 << 8 each)
+  int l_rec, l_G, l_u, l_lam, l_Pb2, l_delta2, l_gc;   // float offsets in the env slice
+  int env_floats;                                // slice size of a SELFCOL env
+};
+constexpr HdrSC make_layout_sc(int nb, int base_floats) {
+  const int nv = 6 + 3 * (nb - 1);
+  HdrSC y{};
+  int o = base_floats;
+  auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
+  y.l_rec = take(kSelfRec * kMaxSelf);
+  y.l_G = take(9 * kMaxSelf * kMaxSelf > 10 * kSelfCand ? 9 * kMaxSelf * kMaxSelf : 10 * kSelfCand);   // (3c)^2 Delassus block; narrow-phase candidates before that
+  y.l_u = take(3 * kMaxSelf); y.l_lam = take(3 * kMaxSelf);
+  y.l_Pb2 = take(6 * nb); y.l_delta2 = take(nv + 1); y.l_gc = take(3 * nb);
+  y.env_floats = o;
+  return y;
+}
+
 // The header as the kernel sees it.  HdrRuntime: the Hdr itself (any model that fits a variant).  HdrFixedT<NB, MAXLEV>: body
 // count, dof counts and the whole LDS layout are compile-time constants — LDS addresses become one base register plus an
 // instruction immediate and ~30 wave-uniform values leave the SGPR file (the generic kernel reloads spilled SGPRs with
@@ -170,9 +194,16 @@ struct KArgs {
   const real *task_rand2;
   uint8_t *terminated, *truncated;
   real *out0, *out1, *out2;  // kinematics: xpos, xmat ; debug forward: M [N,nv,nv], bias [N,nv], qacc [N,nv]
+  // body-body contacts (SELFCOL instantiations only; appended so that the plain kernels' argument layout is what it was)
+  HdrSC sc;
+  const int32_t *pairs;       // [sc.npair] b1 | b2 << 8
+  const real *geomc;          // [nb][kGeomC]
   // per-env body shapes (ss_model_create_shapes): bodyc holds num_shapes consecutive blocks of [nb][kBodyC] body constants
   // followed by [nv] dof inverse weights (block stride shape_stride(h) floats), candc num_shapes consecutive tables;
   // st.shape_id [N] selects per env (null = single-shape model)
 };
+
+// floats of one env's LDS slice for this launch
+inline int env_slice_floats(const KArgs &k) { return k.cfg.self_collision ? k.sc.env_floats : k.h.env_floats; }
 
 }  // namespace ss

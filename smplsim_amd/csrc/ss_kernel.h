@@ -24,6 +24,7 @@
 #include <stdint.h>
 
 #include "ss_hdr.h"
+#include "ss_selfcol.h"
 
 #if defined(__HIPCC__)
 #define SS_DEV __device__ __forceinline__
@@ -104,8 +105,20 @@ SS_DEV bool is_bad(real x) { return !(x <= real(1e10) && x >= -real(1e10)); }
 template <bool SHAPED> struct ShapeTables {};
 template <> struct ShapeTables<true> { const real *bodyc_s, *candc_s, *dinvw_s; };   // this env's tables
 
-template <class W, int DOFP, int CANDP, int SLOTP, int NPASS, bool SHAPED = false, class HT = HdrRuntime>
-struct Sim : ShapeTables<SHAPED> {
+// SELFCOL: contacts between the humanoid's own bodies (ss_env_cfg.self_collision).  Their rows couple two bodies, which the
+// per-body generalized inertias of the articulated-body solve cannot express; the Newton system H = H_tree + E^T W E (E: relative
+// contact-point velocity of the <= kMaxSelf contacts in their frames, 3 rows each; W: 3x3 blocks of the active pyramid rows) is
+// solved by the Woodbury identity on top of the tree solve:  delta = H_tree^-1 (b_tree - E^T lam),  (I + W G) lam = q + W E y,
+// y = H_tree^-1 b_tree, G = E H_tree^-1 E^T (one tree solve per column), q = the rows' gradient in frame coordinates.
+// Written so that no two large vectors are subtracted: the final step is ONE tree solve with the combined right-hand side.
+template <bool SELFCOL> struct SelfColState {};
+template <> struct SelfColState<true> {
+  real *rec, *G, *uvec, *lam, *Pb2, *delta2, *gc;          // per-env LDS arrays (HdrSC)
+  int nself;                                               // wave-uniform count of body-body contacts of this pass
+};
+
+template <class W, int DOFP, int CANDP, int SLOTP, int NPASS, bool SHAPED = false, class HT = HdrRuntime, bool SELFCOL = false>
+struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
   W *w;
   const KArgs *k;
   const uint32_t *T;      // shared tables in LDS (integer tables, then the real-valued ones)
@@ -157,6 +170,11 @@ struct Sim : ShapeTables<SHAPED> {
     delta = L + h.l_delta; C = L + h.l_C; diag = L + h.l_diag; Iown = L + h.l_Iown;
     bpar = -1; bdep = -1;
     if (lane < h.nb) { bpar = ti(h.o_bparent, lane); bdep = ti(h.o_ndepth, lane + 1) - 1; }
+    if constexpr (SELFCOL) {
+      const HdrSC &y = k->sc;
+      this->rec = L + y.l_rec; this->G = L + y.l_G; this->uvec = L + y.l_u; this->lam = L + y.l_lam; this->Pb2 = L + y.l_Pb2;
+      this->delta2 = L + y.l_delta2; this->gc = L + y.l_gc; this->nself = 0;
+    }
 #pragma unroll
     for (int p = 0; p < SLOTP; p++) con[p].active = 0;
 #pragma unroll
@@ -645,9 +663,303 @@ struct Sim : ShapeTables<SHAPED> {
     }
   }
 
+  // ------------------------------------------------------------------ body-body contacts (SELFCOL)
+  // world frame of geom b relative to the root origin: centre gp, rotation gm (row-major), from the body frames in LDS
+  SS_DEV void geom_frame(int b, const real *gcst, real *gp, real *gm) const {
+    const real *Rb = R + 9 * b, *rb = r + 3 * b;
+    for (int i = 0; i < 3; i++) {
+      gp[i] = rb[i] + Rb[3 * i] * gcst[0] + Rb[3 * i + 1] * gcst[1] + Rb[3 * i + 2] * gcst[2];
+      for (int j = 0; j < 3; j++) gm[3 * i + j] = Rb[3 * i] * gcst[6 + j] + Rb[3 * i + 1] * gcst[9 + j] + Rb[3 * i + 2] * gcst[12 + j];
+    }
+  }
+  // contact record fields
+  enum { RC_B1 = 0, RC_B2 = 1, RC_POS = 2, RC_N = 5, RC_T1 = 8, RC_D = 11, RC_AREF = 12, RC_JAR = 16, RC_JD = 20 };
+
+  // Collision of the candidate body pairs (static table) at the pose of this pass; keeps the deepest kMaxSelf contacts, in
+  // pair order, as records in LDS.  Must run right after make_constraints(): it reads R, r (not yet overwritten by a solve)
+  // and the body velocities V.
+  SS_DEV void make_self_contacts(bool write_count) {
+    if constexpr (SELFCOL) {
+      fresh();
+      typename HT::type h = HT::view(k->h);
+      const int npair = k->sc.npair;
+      real *cand = this->G;                                  // candidates [kSelfCand][10]: pos3 n3 dist id b1 b2 (the Delassus block is not live yet)
+      real *plist = this->Pb2;                               // pairs that passed the bounding-sphere test (<= 64 per round)
+      if (lane < h.nb) {
+        const real *gcst = k->geomc + lane * kGeomC;
+        const real *Rb = R + 9 * lane, *rb = r + 3 * lane;
+        for (int i = 0; i < 3; i++) this->gc[3 * lane + i] = rb[i] + Rb[3 * i] * gcst[0] + Rb[3 * i + 1] * gcst[1] + Rb[3 * i + 2] * gcst[2];
+      }
+      w->sync();
+      int ncand = 0, nlist = 0;
+      const int npass = (npair + 63) >> 6;
+      for (int p = 0; p <= npass; p++) {
+        // ---- broad phase of 64 pairs: bounding spheres about the geom centres
+        int pass_ = 0, q = p * 64 + lane;
+        if (p < npass && q < npair) {
+          const int pr = k->pairs[q], b1 = pr & 255, b2 = pr >> 8;
+          const real *g1 = k->geomc + b1 * kGeomC, *g2 = k->geomc + b2 * kGeomC;
+          const real r1 = g1[15] == real(SS_GEOM_BOX) ? SS_M(sqrt)(g1[3] * g1[3] + g1[4] * g1[4] + g1[5] * g1[5]) : g1[3] + g1[4];
+          const real r2 = g2[15] == real(SS_GEOM_BOX) ? SS_M(sqrt)(g2[3] * g2[3] + g2[4] * g2[4] + g2[5] * g2[5]) : g2[3] + g2[4];
+          const real dx = this->gc[3 * b2] - this->gc[3 * b1], dy = this->gc[3 * b2 + 1] - this->gc[3 * b1 + 1], dz = this->gc[3 * b2 + 2] - this->gc[3 * b1 + 2];
+          pass_ = !(SS_M(sqrt)(dx * dx + dy * dy + dz * dz) > r1 + r2 + h.margin);
+        }
+        const unsigned long long bal = w->ballot(pass_);
+        int cnt = 0;
+        for (unsigned long long t_ = bal; t_; t_ &= t_ - 1) cnt++;
+        const bool flush = p == npass || nlist + cnt > 64;
+        if (flush && nlist > 0) {
+          // ---- narrow phase: one listed pair per lane, up to 8 contacts each, appended to the candidate list
+          w->sync();
+          sc::NCon out[8];
+          int n = 0, pid = 0, b1 = 0, b2 = 0;
+          if (lane < nlist) {
+            pid = (int)plist[lane];
+            const int pr = k->pairs[pid];
+            b1 = pr & 255; b2 = pr >> 8;
+            const real *g1 = k->geomc + b1 * kGeomC, *g2 = k->geomc + b2 * kGeomC;
+            real p1[3], m1[9], p2[3], m2[9];
+            geom_frame(b1, g1, p1, m1); geom_frame(b2, g2, p2, m2);
+            const real a1[3] = {m1[2], m1[5], m1[8]}, a2[3] = {m2[2], m2[5], m2[8]};
+            const bool c1 = g1[15] != real(SS_GEOM_BOX), c2 = g2[15] != real(SS_GEOM_BOX);
+            if (c1 && c2) n = sc::capsule_capsule(p1, a1, g1[3], g1[4], p2, a2, g2[3], g2[4], h.margin, out);
+            else if (c1) n = sc::capsule_box(p1, a1, g1[3], g1[4], p2, m2, g2 + 3, h.margin, out);
+            else n = sc::box_box(p1, m1, g1 + 3, p2, m2, g2 + 3, h.margin, out);
+          }
+          for (int kq = 0; kq < 8; kq++) {
+            const int has = n > kq;
+            const unsigned long long m_ = w->ballot(has);
+            if (!m_) break;
+            int rank = 0, tot = 0;
+            for (unsigned long long t_ = m_; t_; t_ &= t_ - 1) tot++;
+            for (unsigned long long t_ = m_ & ((1ull << lane) - 1ull); t_; t_ &= t_ - 1) rank++;
+            const int idx = ncand + rank;
+            if (has && idx < kSelfCand) {
+              real *o = cand + 10 * idx;
+              const sc::NCon &c = out[kq];
+              o[0] = c.pos[0]; o[1] = c.pos[1]; o[2] = c.pos[2]; o[3] = c.n[0]; o[4] = c.n[1]; o[5] = c.n[2]; o[6] = c.dist;
+              o[7] = (real)(pid * 8 + kq); o[8] = (real)b1; o[9] = (real)b2;
+            }
+            ncand += tot;
+          }
+          if (ncand > kSelfCand) ncand = kSelfCand;
+          nlist = 0;
+          w->sync();
+        }
+        if (pass_) {
+          int rank = 0;
+          for (unsigned long long t_ = bal & ((1ull << lane) - 1ull); t_; t_ &= t_ - 1) rank++;
+          plist[nlist + rank] = (real)q;
+        }
+        nlist += cnt;
+      }
+      w->sync();
+      // ---- keep the deepest kMaxSelf (ties: pair order), in pair order
+      int keep = 0; real mydist = 0, myid = 0;
+      if (lane < ncand) {
+        mydist = cand[10 * lane + 6]; myid = cand[10 * lane + 7];
+        int rk = 0;
+        for (int j = 0; j < ncand; j++) { const real dj = cand[10 * j + 6], ij = cand[10 * j + 7]; rk += dj < mydist || (dj == mydist && ij < myid); }
+        keep = rk < kMaxSelf;
+      }
+      const unsigned long long km = w->ballot(keep);
+      int nk = 0;
+      for (unsigned long long t_ = km; t_; t_ &= t_ - 1) nk++;
+      this->nself = nk;
+      real rcd[kSelfRec];
+      int slot = -1;
+      if (keep) {
+        slot = 0;
+        for (int j = 0; j < ncand; j++) if (((km >> j) & 1ull) && cand[10 * j + 7] < myid) slot++;
+        const real *o = cand + 10 * lane;
+        const int b1 = (int)o[8], b2 = (int)o[9];
+        const real px = o[0], py = o[1], pz_ = o[2], nx = o[3], ny = o[4], nz = o[5], dist = o[6];
+        // frame: first tangent from e_y (|n_y| < 0.5) or e_z, orthogonalised against the normal (mj_makeFrame with no hint)
+        real t1x = 0, t1y = 0, t1z = 0;
+        if (ny < real(0.5) && ny > real(-0.5)) t1y = 1; else t1z = 1;
+        const real dp = nx * t1x + ny * t1y + nz * t1z;
+        t1x -= nx * dp; t1y -= ny * dp; t1z -= nz * dp;
+        const real tn = SS_M(sqrt)(t1x * t1x + t1y * t1y + t1z * t1z);
+        if (tn < sc::kMin) { t1x = 1; t1y = 0; t1z = 0; } else { const real it = real(1) / tn; t1x *= it; t1y *= it; t1z *= it; }
+        const real t2x = ny * t1z - nz * t1y, t2y = nz * t1x - nx * t1z, t2z = nx * t1y - ny * t1x;
+        // relative velocity of the contact point (body 2 minus body 1), body velocities V = (omega ; v at the root origin)
+        const real *v1 = V + 6 * b1, *v2 = V + 6 * b2;
+        const real wx = v2[0] - v1[0], wy = v2[1] - v1[1], wz = v2[2] - v1[2];
+        const real vx = v2[3] - v1[3] + wy * pz_ - wz * py, vy = v2[4] - v1[4] + wz * px - wx * pz_, vz = v2[5] - v1[5] + wx * py - wy * px;
+        const real vn = nx * vx + ny * vy + nz * vz, vt1 = t1x * vx + t1y * vy + t1z * vz, vt2 = t2x * vx + t2y * vy + t2z * vz;
+        const real mu = h.mu, imp = impedance(dist, h.margin);
+        const real wsum = bodyc()[b1 * kBodyC + 13] + bodyc()[b2 * kBodyC + 13];
+        real R0 = (real(1) - imp) / imp * wsum * (real(1) + mu * mu);
+        if (R0 < real(1e-15)) R0 = real(1e-15);
+        const real kterm = h.K * imp * (dist - h.margin);
+        rcd[RC_B1] = (real)b1; rcd[RC_B2] = (real)b2;
+        rcd[RC_POS] = px; rcd[RC_POS + 1] = py; rcd[RC_POS + 2] = pz_;
+        rcd[RC_N] = nx; rcd[RC_N + 1] = ny; rcd[RC_N + 2] = nz; rcd[RC_T1] = t1x; rcd[RC_T1 + 1] = t1y; rcd[RC_T1 + 2] = t1z;
+        rcd[RC_D] = real(1) / (real(2) * mu * mu * R0);
+        rcd[RC_AREF] = -h.B * (vn + mu * vt1) - kterm; rcd[RC_AREF + 1] = -h.B * (vn - mu * vt1) - kterm;
+        rcd[RC_AREF + 2] = -h.B * (vn + mu * vt2) - kterm; rcd[RC_AREF + 3] = -h.B * (vn - mu * vt2) - kterm;
+        for (int i = RC_JAR; i < kSelfRec; i++) rcd[i] = 0;
+      }
+      w->sync();                                             // candidates consumed (the records may not overlap them, but keep it simple)
+      if (slot >= 0) for (int i = 0; i < kSelfRec; i++) this->rec[kSelfRec * slot + i] = rcd[i];
+      if (write_count && lane == 0 && k->st.self_contacts) k->st.self_contacts[env] = nk;
+      w->sync();
+    }
+  }
+
+  // relative acceleration of a self-contact's point in its frame (normal, t1, t2) from per-body spatial accelerations
+  SS_DEV void self_rel(const real *rc, const real *A, int stride, real *an, real *at1, real *at2) const {
+    const int b1 = (int)rc[RC_B1], b2 = (int)rc[RC_B2];
+    const real *a1 = A + stride * b1, *a2 = A + stride * b2;
+    const real px = rc[RC_POS], py = rc[RC_POS + 1], pz_ = rc[RC_POS + 2];
+    const real wx = a2[0] - a1[0], wy = a2[1] - a1[1], wz = a2[2] - a1[2];
+    const real ax = a2[3] - a1[3] + wy * pz_ - wz * py, ay = a2[4] - a1[4] + wz * px - wx * pz_, az = a2[5] - a1[5] + wx * py - wy * px;
+    const real nx = rc[RC_N], ny = rc[RC_N + 1], nz = rc[RC_N + 2], t1x = rc[RC_T1], t1y = rc[RC_T1 + 1], t1z = rc[RC_T1 + 2];
+    const real t2x = ny * t1z - nz * t1y, t2y = nz * t1x - nx * t1z, t2z = nx * t1y - ny * t1x;
+    *an = nx * ax + ny * ay + nz * az; *at1 = t1x * ax + t1y * ay + t1z * az; *at2 = t2x * ax + t2y * ay + t2z * az;
+  }
+  // rows of the self-contacts (lane = contact): jar from the iterate's body accelerations or jd from the direction's
+  SS_DEV void eval_self_rows(const real *A, int stride, bool is_delta) {
+    if constexpr (SELFCOL) {
+      if (lane < this->nself) {
+        real *rc = this->rec + kSelfRec * lane;
+        const real mu = hdr().mu;
+        real an, at1, at2;
+        self_rel(rc, A, stride, &an, &at1, &at2);
+        const real v[4] = {an + mu * at1, an - mu * at1, an + mu * at2, an - mu * at2};
+        for (int i = 0; i < 4; i++) { if (is_delta) rc[RC_JD + i] = v[i]; else rc[RC_JAR + i] = v[i] - rc[RC_AREF + i]; }
+      }
+    }
+  }
+  // sum over this lane's self-contact rows of D x jd (x < 0 only) and D jd^2, at x = jar + al jd
+  SS_DEV void self_ls_terms(real al, real &s1, real &s2) const {
+    if constexpr (SELFCOL) {
+      if (lane < this->nself) {
+        const real *rc = this->rec + kSelfRec * lane;
+        for (int i = 0; i < 4; i++) {
+          const real x = rc[RC_JAR + i] + al * rc[RC_JD + i];
+          if (x < 0) { s1 += rc[RC_D] * x * rc[RC_JD + i]; s2 += rc[RC_D] * rc[RC_JD + i] * rc[RC_JD + i]; }
+        }
+      }
+    }
+  }
+  // wrench (moment about the root origin ; force) of the frame-coordinate force (fn, f1, f2) of record rc, component t
+  SS_DEV static real self_wrench(const real *rc, real fn, real f1, real f2, int t) {
+    const real nx = rc[RC_N], ny = rc[RC_N + 1], nz = rc[RC_N + 2], t1x = rc[RC_T1], t1y = rc[RC_T1 + 1], t1z = rc[RC_T1 + 2];
+    const real t2x = ny * t1z - nz * t1y, t2y = nz * t1x - nx * t1z, t2z = nx * t1y - ny * t1x;
+    const real fx = fn * nx + f1 * t1x + f2 * t2x, fy = fn * ny + f1 * t1y + f2 * t2y, fz = fn * nz + f1 * t1z + f2 * t2z;
+    const real px = rc[RC_POS], py = rc[RC_POS + 1], pz_ = rc[RC_POS + 2];
+    return t == 0 ? py * fz - pz_ * fy : t == 1 ? pz_ * fx - px * fz : t == 2 ? px * fy - py * fx : t == 3 ? fx : t == 4 ? fy : fz;
+  }
+
+  // The Newton direction with body-body contacts (see SelfColState): replaces the plain aba_solve(delta, Pb) of the solver loop
+  SS_DEV void solve_with_self_contacts() {
+    if constexpr (SELFCOL) {
+      typename HT::type h = HT::view(k->h);
+      const int ns = this->nself, m = 3 * ns;
+      const real mu = h.mu;
+      real *G = this->G, *uvec = this->uvec, *lam = this->lam, *Pb2 = this->Pb2, *d2 = this->delta2;
+      // ---- columns of G = E H_tree^-1 E^T: one tree solve per unit relative force
+      for (int col = 0; col < m; col++) {
+        fresh();
+        const int cc = col / 3, cj = col - 3 * cc;
+        const real *rc = this->rec + kSelfRec * cc;
+        for (int i = lane; i < h.nv; i += 64) d2[i] = 0;
+        for (int i = lane; i < 6 * h.nb; i += 64) Pb2[i] = 0;
+        w->sync();
+        if (lane < 12) {                                     // H x = - sum_b J_b^T pb: pb = -wrench on body 2, +wrench on body 1
+          const int t = lane < 6 ? lane : lane - 6;
+          const real wv = self_wrench(rc, cj == 0 ? real(1) : real(0), cj == 1 ? real(1) : real(0), cj == 2 ? real(1) : real(0), t);
+          const int b = (int)(lane < 6 ? rc[RC_B2] : rc[RC_B1]);
+          Pb2[6 * b + t] = lane < 6 ? -wv : wv;
+        }
+        w->sync();
+        aba_solve(d2, Pb2);
+        if (lane < ns) {
+          real an, at1, at2;
+          self_rel(this->rec + kSelfRec * lane, An + 8, 8, &an, &at1, &at2);
+          G[(3 * lane) * m + col] = an; G[(3 * lane + 1) * m + col] = at1; G[(3 * lane + 2) * m + col] = at2;
+        }
+        w->sync();
+      }
+      // ---- y = H_tree^-1 b_tree (b_tree: joint-space right-hand side in delta, tree per-body forces in Pb)
+      fresh();
+      for (int i = lane; i < h.nv; i += 64) d2[i] = delta[i];
+      w->sync();
+      aba_solve(delta, Pb);
+      if (lane < ns) {
+        real an, at1, at2;
+        self_rel(this->rec + kSelfRec * lane, An + 8, 8, &an, &at1, &at2);
+        uvec[3 * lane] = an; uvec[3 * lane + 1] = at1; uvec[3 * lane + 2] = at2;
+      }
+      w->sync();
+      // ---- (I + W G) lam = q + W (E y), Gaussian elimination with partial pivoting by one lane (m <= 3 kMaxSelf)
+      if (lane == 0) {
+        for (int c = 0; c < ns; c++) {
+          const real *rc = this->rec + kSelfRec * c;
+          // active pyramid rows r: directions (1, +-mu, 0), (1, 0, +-mu) in the frame; W = sum D d d^T, q = sum D jar d
+          real Wm[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, qv[3] = {0, 0, 0};
+          for (int r_ = 0; r_ < 4; r_++) {
+            if (!(rc[RC_JAR + r_] < 0)) continue;
+            const real dv[3] = {real(1), r_ < 2 ? (r_ == 0 ? mu : -mu) : real(0), r_ < 2 ? real(0) : (r_ == 2 ? mu : -mu)};
+            for (int i = 0; i < 3; i++) { qv[i] += rc[RC_D] * rc[RC_JAR + r_] * dv[i]; for (int j = 0; j < 3; j++) Wm[i][j] += rc[RC_D] * dv[i] * dv[j]; }
+          }
+          // rows 3c..3c+2 of (I + W G) overwrite G's rows in place (row i of W G only needs rows 3c..3c+2 of G)
+          real g3[3][3 * kMaxSelf];
+          for (int i = 0; i < 3; i++) for (int j = 0; j < m; j++) g3[i][j] = G[(3 * c + i) * m + j];
+          for (int i = 0; i < 3; i++) {
+            real rhs = qv[i];
+            for (int j2 = 0; j2 < 3; j2++) rhs += Wm[i][j2] * uvec[3 * c + j2];
+            lam[3 * c + i] = rhs;
+            for (int j = 0; j < m; j++) {
+              real s_ = (j == 3 * c + i) ? real(1) : real(0);
+              for (int j2 = 0; j2 < 3; j2++) s_ += Wm[i][j2] * g3[j2][j];
+              G[(3 * c + i) * m + j] = s_;
+            }
+          }
+        }
+        for (int p_ = 0; p_ < m; p_++) {                      // elimination
+          int piv = p_; real best = SS_M(fabs)(G[p_ * m + p_]);
+          for (int i = p_ + 1; i < m; i++) { const real v_ = SS_M(fabs)(G[i * m + p_]); if (v_ > best) { best = v_; piv = i; } }
+          if (piv != p_) {
+            for (int j = 0; j < m; j++) { const real t_ = G[p_ * m + j]; G[p_ * m + j] = G[piv * m + j]; G[piv * m + j] = t_; }
+            const real t_ = lam[p_]; lam[p_] = lam[piv]; lam[piv] = t_;
+          }
+          const real ip = real(1) / G[p_ * m + p_];
+          for (int i = p_ + 1; i < m; i++) {
+            const real f_ = G[i * m + p_] * ip;
+            if (f_ == 0) continue;
+            for (int j = p_ + 1; j < m; j++) G[i * m + j] -= f_ * G[p_ * m + j];
+            lam[i] -= f_ * lam[p_];
+          }
+        }
+        for (int i = m - 1; i >= 0; i--) {
+          real s_ = lam[i];
+          for (int j = i + 1; j < m; j++) s_ -= G[i * m + j] * lam[j];
+          lam[i] = s_ / G[i * m + i];
+        }
+      }
+      w->sync();
+      // ---- delta = H_tree^-1 (b_tree - E^T lam): one tree solve with the combined right-hand side
+      fresh();
+      for (int i = lane; i < h.nv; i += 64) delta[i] = d2[i];
+      for (int i = lane; i < 6 * h.nb; i += 64) Pb2[i] = Pb[i];
+      w->sync();
+      if (lane < 6)
+        for (int c = 0; c < ns; c++) {                       // the same lane owns component `lane` of every body: no hand-off needed
+          const real *rc = this->rec + kSelfRec * c;
+          const real wv = self_wrench(rc, lam[3 * c], lam[3 * c + 1], lam[3 * c + 2], lane);
+          Pb2[6 * (int)rc[RC_B2] + lane] += wv; Pb2[6 * (int)rc[RC_B1] + lane] -= wv;
+        }
+      w->sync();
+      aba_solve(delta, Pb2);
+    }
+  }
+
   // rows: jar (from A = Ab, x = a) or jd (from A = Ad, x = delta)
   // A: spatial accelerations, body b at A + stride * b
   SS_DEV void eval_rows(const real *A, int stride, const real *x, bool is_delta) {
+    eval_self_rows(A, stride, is_delta);
     const real mu = k->h.mu;
 #pragma unroll
     for (int p = 0; p < SLOTP; p++) {
@@ -953,6 +1265,7 @@ struct Sim : ShapeTables<SHAPED> {
       real x = l.jar + al * l.jd;
       if (x < 0.f) { s1 += l.D * x * l.jd; s2 += l.D * l.jd * l.jd; }
     }
+    self_ls_terms(al, s1, s2);
     d1 = c1 + al * c2 + w->sum(s1);
     d2 = c2 + w->sum(s2);
   }
@@ -1089,7 +1402,18 @@ struct Sim : ShapeTables<SHAPED> {
       const Limit &l = lim[p];
       if (l.sign != 0.f && l.jar < 0.f) { s_a += l.D * l.jar * l.jd; s_b += l.D * l.jd * l.jd; }
     }
+    // body-body rows (SELFCOL): their forces are not part of Pb, so dg_ above is the tree part of delta . gradient; the rows'
+    // own part is sum_active D jar jd = what they add to s_a
+    real ss_a = 0.f, ss_b = 0.f;
+    if constexpr (SELFCOL) {
+      if (lane < this->nself) {
+        const real *rc = this->rec + kSelfRec * lane;
+        for (int i = 0; i < 4; i++) if (rc[RC_JAR + i] < 0) { ss_a += rc[RC_D] * rc[RC_JAR + i] * rc[RC_JD + i]; ss_b += rc[RC_D] * rc[RC_JD + i] * rc[RC_JD + i]; }
+      }
+      if (this->nself > 0) { ss_a = w->sum(ss_a); ss_b = w->sum(ss_b); }
+    }
     dg_ = w->sum(dg_); s_a = w->sum(s_a); s_b = w->sum(s_b);
+    dg_ += ss_a; s_a += ss_a; s_b += ss_b;
     const real c1 = dg_ - s_a, c2 = -dg_ - s_b;            // phi'(al) = c1 + al c2 + sum_active(al) D (jar + al jd) jd
     real al = 1.f, d1, d2;
     ls_eval(1.f, c1, c2, d1, d2);
@@ -1142,6 +1466,16 @@ struct Sim : ShapeTables<SHAPED> {
       real nj = l.jar + al * l.jd;
       changed |= (nj < 0.f) != (l.jar < 0.f);
       l.jar = nj;
+    }
+    if constexpr (SELFCOL) {
+      if (lane < this->nself) {
+        real *rc = this->rec + kSelfRec * lane;
+        for (int i = 0; i < 4; i++) {
+          const real nj = rc[RC_JAR + i] + al * rc[RC_JD + i];
+          changed |= (nj < 0) != (rc[RC_JAR + i] < 0);
+          rc[RC_JAR + i] = nj;
+        }
+      }
     }
     w->sync();
     // converged: full Newton step with an unchanged active set, or no representable progress any more
@@ -1349,14 +1683,14 @@ enum { SOLVE_NEWTON = 1, SOLVE_SPD = 2 };
 // BODYOUT: the instantiation whose step / reset passes also write the body frames (ss_set_body_outputs).  A separate
 // instantiation because the extra epilogue costs the headline step kernel 3.7% (register allocation of the hot loops
 // shifts) even when the pointer is null — callers that do not ask for it keep the plain one.
-template <class W, int DOFP, int CANDP, int SLOTP, int NPASS, bool BODYOUT = false, bool SHAPED = false, class HT = HdrRuntime>
+template <class W, int DOFP, int CANDP, int SLOTP, int NPASS, bool BODYOUT = false, bool SHAPED = false, class HT = HdrRuntime, bool SELFCOL = false>
 SS_DEV bool run_env(W *w, const KArgs *k, const uint32_t *T, real *L, int env, int mode) {
   typename HT::type h = HT::view(k->h);
   const ss_env_cfg &cf = k->cfg;
   const ss_state &st = k->st;
   const bool fused_pass = mode != k->mode;                    // the in-launch reset of an env that just finished
   if (!fused_pass && k->mask && !k->mask[env]) return false;
-  Sim<W, DOFP, CANDP, SLOTP, NPASS, SHAPED, HT> sim;
+  Sim<W, DOFP, CANDP, SLOTP, NPASS, SHAPED, HT, SELFCOL> sim;
   sim.init(w, k, T, L, env);
   int lane = sim.lane;
   real *qg = gptr(st.qpos) + (size_t)env * h.nq, *vg = gptr(st.qvel) + (size_t)env * h.nv;
@@ -1448,7 +1782,10 @@ SS_DEV bool run_env(W *w, const KArgs *k, const uint32_t *T, real *L, int env, i
     sim.forward_kin(kind != K_FINAL, kind == K_RESETFWD || (kind == K_SUBSTEP && s == nsub - 1));
     SS_TICK(PF_FWD);
     if (kind == K_FINAL) break;
-    if (kind == K_SUBSTEP || kind == K_RESETFWD) sim.make_constraints();
+    if (kind == K_SUBSTEP || kind == K_RESETFWD) {
+      sim.make_constraints();
+      sim.make_self_contacts(kind == K_RESETFWD || s == nsub - 1);
+    }
     SS_TICK(PF_CONS);
     if (kind == K_RESETFWD) break;
     int solve = SOLVE_SPD;
@@ -1480,7 +1817,10 @@ SS_DEV bool run_env(W *w, const KArgs *k, const uint32_t *T, real *L, int env, i
         sim.spd_prepare(next_action, abias);
         SS_TICK(PF_SPDPREP);
       }
-      sim.aba_solve(sim.delta, solve == SOLVE_NEWTON ? sim.Pb : nullptr);
+      bool plain_solve = true;
+      if constexpr (SELFCOL) plain_solve = !(solve == SOLVE_NEWTON && sim.nself > 0);
+      if (plain_solve) sim.aba_solve(sim.delta, solve == SOLVE_NEWTON ? sim.Pb : nullptr);
+      else sim.solve_with_self_contacts();
       SS_TICK(PF_FACTOR);
       if (solve == SOLVE_SPD) { sim.spd_finish(); SS_TICK(PF_SPDFIN); break; }
       const bool conv = sim.newton_finish();

@@ -30,6 +30,9 @@ struct HostModel {
   std::vector<uint8_t> legal;     // [nb]
   uint64_t illegal_mask = 0;      // bodies whose floor contact terminates the episode
   int o_real = 0;                 // word offset of the real-valued part of `shared`
+  std::vector<int32_t> pairs;     // body-body candidate pairs after MuJoCo's static filters: b1 | b2 << 8 (normal points b1 -> b2)
+  std::vector<real> geomc;        // [nb][kGeomC] geoms in their body frames (pair functions of the SELFCOL kernels)
+  HdrSC sc{};
   std::string error;
 };
 
@@ -267,6 +270,33 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
     h.env_floats = y.env_floats;
     if (13 * h.nslot > h.l_Wst - h.l_Aown) { out.error = "contact record buffer does not fit"; return false; }
   }
+
+  // ---- body-body collision: candidate pairs (mj_collision's static filters: contype / conaffinity masks, parent-child
+  // filter, <exclude> pairs) and the geom table of the pair functions.  The pair's first geom is the one MuJoCo hands to the
+  // pair function first (capsule before box, then the lower id); contact normals point from it to the second.
+  out.pairs.clear();
+  for (int i = 0; i < nb; i++) for (int j = i + 1; j < nb; j++) {
+    const int ct1 = d.geom_contype ? d.geom_contype[i] : 1, ca1 = d.geom_conaffinity ? d.geom_conaffinity[i] : 1;
+    const int ct2 = d.geom_contype ? d.geom_contype[j] : 1, ca2 = d.geom_conaffinity ? d.geom_conaffinity[j] : 1;
+    if (!((ct1 & ca2) || (ct2 & ca1))) continue;
+    if (d.body_parent[j] == i || d.body_parent[i] == j) continue;
+    bool ex = false;
+    for (int e = 0; e < d.nexclude; e++)
+      ex |= (d.exclude[2 * e] == i && d.exclude[2 * e + 1] == j) || (d.exclude[2 * e] == j && d.exclude[2 * e + 1] == i);
+    if (ex) continue;
+    const int first = (d.geom_type[i] == SS_GEOM_BOX && d.geom_type[j] == SS_GEOM_CAPSULE) ? j : i;
+    out.pairs.push_back(first | ((first == i ? j : i) << 8));
+  }
+  out.geomc.assign((size_t)nb * kGeomC, real(0));
+  for (int b = 0; b < nb; b++) {
+    real *c = &out.geomc[(size_t)b * kGeomC];
+    double G[9]; quat2mat(d.geom_quat + 4 * b, G);
+    for (int k = 0; k < 3; k++) { c[k] = (real)d.geom_pos[3 * b + k]; c[3 + k] = (real)d.geom_size[3 * b + k]; }
+    for (int k = 0; k < 9; k++) c[6 + k] = (real)G[k];
+    c[15] = (real)d.geom_type[b];
+  }
+  out.sc = make_layout_sc(nb, h.env_floats);
+  out.sc.npair = (int)out.pairs.size();
 
   h.dt = (real)d.timestep; h.grav = (real)d.gravity; h.margin = (real)d.margin; h.mu = (real)d.friction;
   for (int k = 0; k < 5; k++) h.solimp[k] = (real)d.solimp[k];

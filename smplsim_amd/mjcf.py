@@ -73,8 +73,10 @@ class ModelConst:
     body_invweight0: np.ndarray    # [nbody,2]
     dof_invweight0: np.ndarray     # [nv]
     qpos0: np.ndarray              # [nq]
-    excludes: List[tuple]
+    excludes: List[tuple]          # <contact><exclude> body-name pairs
     has_vel_sensors: bool
+    geom_contype: np.ndarray = None      # [nbody] int32 collision bit masks (MuJoCo default 1 / 1); two geoms collide when
+    geom_conaffinity: np.ndarray = None  # (contype1 & conaffinity2) | (contype2 & conaffinity1) != 0
     # options (MuJoCo defaults unless the env overrides; timestep is set by the env,
     # reference base_env.py:142)
     timestep: float = 0.002
@@ -179,6 +181,7 @@ def compile_mjcf(xml: str) -> ModelConst:
     names, parent, pos = [], [], []
     mass, ipos, iquat, inertia = [], [], [], []
     gtype, gsize, gpos, gquat, gnames, gmargin, gfric = [], [], [], [], [], [], []
+    gcontype, gconaff = [], []
     armature, jrange, jlimited, jnames = [], [], [], []
 
     def add_body(b, par):
@@ -250,6 +253,7 @@ def compile_mjcf(xml: str) -> ModelConst:
         gtype.append(t); gsize.append(size); gpos.append(p); gquat.append(q)
         gnames.append(g.get("name")); gmargin.append(float(g.get("margin", 0)))
         gfric.append(_floats(g.get("friction", "1 0.005 0.0001"))[0])
+        gcontype.append(int(g.get("contype", 1))); gconaff.append(int(g.get("conaffinity", 1)))
         mass.append(m); ipos.append(p); iquat.append(q); inertia.append(inert)
         for c in b.findall("body"):
             add_body(c, idx)
@@ -297,6 +301,7 @@ def compile_mjcf(xml: str) -> ModelConst:
         actuator_gear=np.array(agear), body_invweight0=np.zeros((nbody, 2)), dof_invweight0=np.zeros(nv),
         qpos0=qpos0, excludes=excludes, has_vel_sensors=bool(has_sens),
         geom_margin=margin, friction=mu,
+        geom_contype=np.array(gcontype, dtype=np.int32), geom_conaffinity=np.array(gconaff, dtype=np.int32),
     )
     _set_invweight0(mc)
     return mc

@@ -61,7 +61,7 @@ def emu_step(pre, actions, f64, newton_iters, humanoid="smpl_humanoid", task="Hu
         obs, rew, term, trunc = eb.step(actions[lo:hi], None if task_rand is None else task_rand[lo:hi])
         return lo, hi, dict(qpos=eb.qpos.astype(np.float64), qvel=eb.qvel.astype(np.float64), obs=obs.astype(np.float64),
                             reward=rew.astype(np.float64), terminated=term, truncated=trunc, nwarn=eb.nwarn.copy(),
-                            iters=eb.solver_iters.copy())
+                            iters=eb.solver_iters.copy(), nself=eb.self_contacts.copy())
 
     with cf.ThreadPoolExecutor(n_threads()) as ex:
         for lo, hi, r in ex.map(run, _chunks(n, n_threads())):
@@ -70,9 +70,9 @@ def emu_step(pre, actions, f64, newton_iters, humanoid="smpl_humanoid", task="Hu
     return out
 
 
-def oracle_step(pre, actions, humanoid="smpl_humanoid"):
+def oracle_step(pre, actions, humanoid="smpl_humanoid", self_collision=False):
     """The same control step by the float64 oracle (base task: state only), threaded."""
-    om = oracle_model(humanoid)
+    om = oracle_model(humanoid, self_collision=bool(self_collision), max_self_contacts=8 if self_collision else 0)
     n = len(actions)
     q, v, nw = np.zeros((n, om.nq)), np.zeros((n, om.nv)), np.zeros(n, np.int32)
 
@@ -117,7 +117,8 @@ def rollout_samples_emu(n_envs, n_steps, seed, skip=8, humanoid="smpl_humanoid",
             if t >= skip and keep.any():
                 recs.append(({k: v[keep] for k, v in pre.items()}, acts[t, lo:hi][keep],
                              dict(qpos=eb.qpos.astype(np.float64)[keep], qvel=eb.qvel.astype(np.float64)[keep], obs=obs.astype(np.float64)[keep],
-                                  reward=rew.astype(np.float64)[keep], nwarn=(eb.nwarn - nw0)[keep], iters=eb.solver_iters.copy()[keep])))
+                                  reward=rew.astype(np.float64)[keep], nwarn=(eb.nwarn - nw0)[keep], iters=eb.solver_iters.copy()[keep],
+                                  nself=eb.self_contacts.copy()[keep])))
             if (~keep).any():
                 eb.reset(mask=~keep, fall_actions=falls[t, lo:hi], task_rand=trand[t, 1, lo:hi])
         return recs
@@ -152,7 +153,7 @@ def rel_err(a, b):
 def triage(pre, actions, post32, humanoid="smpl_humanoid", cap=8, n_perturb=8, task="HumanoidEnv", **cfg):
     """Replays of every sample (module docstring).  Returns a dict of [S, 2] relative error arrays + bookkeeping."""
     kw = dict(humanoid=humanoid, task=task, task_state=pre.get("task"), cur_t=pre.get("cur_t"), task_rand=pre.get("task_rand"), **cfg)
-    orc = oracle_step(pre, actions, humanoid)
+    orc = oracle_step(pre, actions, humanoid, self_collision=cfg.get("self_collision", False))
     f64 = emu_step(pre, actions, True, 100, **kw)
     f64cap = emu_step(pre, actions, True, cap, **kw)
     cond = np.zeros((len(actions), 2))
@@ -168,7 +169,7 @@ def triage(pre, actions, post32, humanoid="smpl_humanoid", cap=8, n_perturb=8, t
         extra = dict(obs=np.abs(post32["obs"] - f64cap["obs"]).max(axis=1) / vs, reward=np.abs(post32["reward"] - f64cap["reward"]), vscale=vs)
     return dict(**extra, formulation=rel_err(f64, orc), precision=rel_err(post32, f64cap), cap_gap=rel_err(f64cap, f64),
                 f32_vs_oracle=rel_err(post32, orc), cond=cond, reset=reset,
-                resets_agree=(orc["nwarn"] > 0) == (f64["nwarn"] > 0), iters=f64["iters"], iters_cap=f64cap["iters"])
+                resets_agree=(orc["nwarn"] > 0) == (f64["nwarn"] > 0), iters=f64["iters"], iters_cap=f64cap["iters"], nself=f64["nself"])
 
 
 def summarize(name, e, mask):

@@ -347,7 +347,7 @@ def test_fused_autoreset_equals_two_launch_path(vec):
     assert ended > 64
 
 
-@pytest.mark.parametrize("which", ["smpl", "getup", "smplx"])
+@pytest.mark.parametrize("which", ["smpl", "getup", "smplx", "smpl_selfcol"])
 def test_per_sample_parity_on_the_benchmark_distribution(vec, which):
     """The benchmark's own states, per sample (GPU twin of test_parity_f64.py): envs driven by full-range uniform(-1,1)
     actions (thrown around, lying on the floor with ~10 bodies in contact, some diverging).  At several control steps the
@@ -359,9 +359,11 @@ def test_per_sample_parity_on_the_benchmark_distribution(vec, which):
     import parity_tools as P
     from test_parity_f64 import COND_FLOOR, K_ROUND
     from smplsim_amd.batch import ShardModel
-    N, steps, every, per_step = {"smpl": (4096, 36, 5, (24, 60)), "getup": (1024, 12, 4, (12, 40)), "smplx": (1024, 24, 6, (8, 20))}[which]
+    N, steps, every, per_step = {"smpl": (4096, 36, 5, (24, 60)), "getup": (1024, 12, 4, (12, 40)), "smplx": (1024, 24, 6, (8, 20)),
+                                 "smpl_selfcol": (2048, 24, 4, (16, 40))}[which]
     humanoid = "smplx_humanoid" if which == "smplx" else "smpl_humanoid"
-    kw = dict(task="HumanoidGetup", state_init="Fall") if which == "getup" else {}
+    kw = dict(task="HumanoidGetup", state_init="Fall") if which == "getup" else (dict(self_collision=True) if which == "smpl_selfcol" else {})
+    tkw = {"task": "HumanoidGetup", "state_init": 1} if which == "getup" else ({"self_collision": True} if which == "smpl_selfcol" else {})
     env = vec(N, model=ShardModel(humanoid=humanoid), autoreset=True, seed=11, **kw)
     g = torch.Generator(device=env.device); g.manual_seed(11)
     env.reset()
@@ -393,7 +395,7 @@ def test_per_sample_parity_on_the_benchmark_distribution(vec, which):
     pre = {k: np.concatenate([p[k] for p in pres]) for k in pres[0]}
     post = {k: np.concatenate([p[k] for p in posts]) for k in posts[0]}
     A = np.concatenate(acts)
-    r = P.triage(pre, A, post, humanoid=humanoid, **({"task": "HumanoidGetup", "state_init": 1} if which == "getup" else {}))
+    r = P.triage(pre, A, post, humanoid=humanoid, **tkw)
     ok = ~r["reset"]
     cond = np.maximum(r["cond"], COND_FLOOR)
     ratio32, ratio64 = r["precision"] / (cond * P.EPS32), r["formulation"] / (cond * P.EPS64)
@@ -405,7 +407,9 @@ def test_per_sample_parity_on_the_benchmark_distribution(vec, which):
             precision_over_cond_eps_max=ratio32[ok].max(axis=0), cap_gap_nonzero_frac=float((r["cap_gap"][ok].max(axis=1) > 0).mean()),
             cap_gap_max=r["cap_gap"][ok].max(axis=0), f32_vs_oracle_max=r["f32_vs_oracle"][ok].max(axis=0), obs_max=r["obs"][ok].max(),
             reward_max=r["reward"][ok].max())
-    assert ok.sum() >= {"smpl": 400, "getup": 100, "smplx": 80}[which], ok.sum()
+    assert ok.sum() >= {"smpl": 400, "getup": 100, "smplx": 80, "smpl_selfcol": 200}[which], ok.sum()
+    if which == "smpl_selfcol":
+        assert (r["nself"][ok] > 0).mean() > 0.3                 # most of these samples do have body-body contacts
     assert r["resets_agree"].all()
     assert (r["formulation"][ok] <= np.maximum(1e-9, K_ROUND * cond[ok] * P.EPS64)).all(), r["formulation"][ok].max(axis=0)
     assert (ratio64[ok] <= K_ROUND).all() and (ratio32[ok] <= K_ROUND).all(), (ratio64[ok].max(axis=0), ratio32[ok].max(axis=0))
@@ -415,6 +419,45 @@ def test_per_sample_parity_on_the_benchmark_distribution(vec, which):
     assert (r["obs"][ok] <= 4 * worst[ok] + 1e-5).all()
     assert (r["reward"][ok] <= 2 * r["precision"][ok, 0] * r["vscale"][ok] + 1e-6).all()
     assert (r["cap_gap"][ok].max(axis=1) == 0).mean() >= 0.85
+
+
+def test_self_collision_on_gpu(vec):
+    """Body-body contacts (ss_env_cfg.self_collision) on the GPU: contact counts and constrained accelerations of
+    folded-up states against the oracle, then teacher-forced control steps under full-range actions; the flag off is the old path."""
+    from test_selfcol_emu import _states
+    om, Q, V, T = _states(16, 2)
+    env = vec(16, autoreset=False, self_collision=True)
+    env.set_state(Q, V)
+    M, bias, qacc = env.debug_forward(torch.tensor(T, device=env.device))
+    torch.cuda.synchronize()
+    d = O.OracleData(om)
+    worst = 0.0
+    for i in range(16):
+        d.qpos = Q[i]; d.qvel = V[i]; d.ctrl = T[i]; d.warm = np.zeros(75); d.forward()
+        assert int(env.self_contacts[i]) == d.nself
+        e = np.abs(_np(qacc)[i] - d.qacc).max() / np.abs(d.qacc).max()
+        worst = max(worst, e)
+        assert e < 5e-5, (i, d.ncon, d.nself, e)
+    env0 = vec(16, autoreset=False)
+    env0.set_state(Q, V)
+    assert (env0.debug_forward(torch.tensor(T, device=env.device))[2] - qacc).abs().max() > 1e-2 and int(env0.self_contacts.sum()) == 0
+    oenv = O.OracleEnv(om)
+    env = vec(2, autoreset=False, self_collision=True)
+    obs, _ = env.reset(); oenv.reset()
+    rs = np.random.default_rng(5)
+    w2, with_self = np.zeros(3), 0
+    for i in range(12):
+        env.set_state(np.tile(oenv.data.qpos, (2, 1)), np.tile(oenv.data.qvel, (2, 1)), env.qpos_prev, env.qvel_prev)
+        a = rs.uniform(-1, 1, 69)
+        o_ref, r, te, tu = oenv.step(a)
+        obs, rew, term, trunc, _ = env.step(torch.tensor(np.tile(a, (2, 1)), device=env.device, dtype=torch.float32))
+        with_self += oenv.data.nself > 0
+        assert int(env.self_contacts[0]) == oenv.data.nself
+        scale = max(1.0, np.abs(oenv.data.qvel).max())
+        w2 = np.maximum(w2, [np.abs(_np(env.qpos)[0] - oenv.data.qpos).max() / scale, np.abs(_np(env.qvel)[0] - oenv.data.qvel).max() / scale,
+                             np.abs(_np(obs)[0] - o_ref).max() / scale])
+    _record("self_collision", qacc_rel=worst, qpos=w2[0], qvel=w2[1], obs=w2[2], steps_with_body_body_contact=with_self)
+    assert with_self >= 5 and w2[0] < 2e-5 and w2[1] < 2e-3 and w2[2] < 2e-3, w2
 
 
 def test_pipelined_sub_batches_equal_their_standalone_envs(vec):

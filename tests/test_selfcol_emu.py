@@ -1,0 +1,123 @@
+"""Body-body contacts in the kernel (SELFCOL instantiation, ss_env_cfg.self_collision) on the wavefront
+emulator against the float64 oracle: contact counts, the constrained acceleration of states with arms folded into the
+torso / legs crossed / lying on the floor (float64 build: 1e-10 — pair functions, record building and the Woodbury solve
+on top of the tree recursion are the oracle's problem exactly; float32 build: 2e-5), teacher-forced control steps, the
+capacity rule (deepest 8 contacts) and the benchmark distribution per sample.  GPU twins: test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+import parity_tools as P
+from helpers import FEET, default_qpos, model_const, oracle_model, pd_tables
+from oracle import oracle as O
+from wave_emu import emu
+
+
+def _states(n, seed, min_self=1, humanoid="smpl_humanoid"):
+    """Random large joint angles in the air or just above the floor, kept when the oracle reports body-body contacts."""
+    om = oracle_model(humanoid, self_collision=True, max_self_contacts=8)
+    mc = model_const(humanoid)
+    rs = np.random.default_rng(seed)
+    d = O.OracleData(om)
+    Q, V, T = [], [], []
+    while len(Q) < n:
+        q = default_qpos(mc.nq); q[2] = rs.choice([5.0, 0.35]); q[7:] = rs.uniform(-1.5, 1.5, mc.nq - 7)
+        v, t = rs.normal(size=mc.nv) * 0.5, rs.normal(size=mc.nu) * 5
+        d.qpos = q; d.qvel = v; d.ctrl = t; d.forward()
+        if d.nself >= min_self:
+            Q.append(q); V.append(v); T.append(t)
+    return om, np.array(Q), np.array(V), np.array(T)
+
+
+@pytest.mark.parametrize("f64,tol", [(True, 1e-10), (False, 2e-5)])
+def test_constrained_acceleration_with_body_body_contacts(f64, tol):
+    mc = model_const()
+    om, Q, V, T = _states(10, 2)
+    eb = emu.EmuBatch(mc, pd_tables(mc), len(Q), legal_bodies=FEET, f64=f64, newton_iters=100 if f64 else 8, self_collision=True)
+    eb.set_state(Q, V)
+    M, bias, qacc = eb.debug_forward(T)
+    d = O.OracleData(om)
+    seen = set()
+    for i in range(len(Q)):
+        d.qpos = Q[i]; d.qvel = V[i]; d.ctrl = T[i]; d.warm = np.zeros(75); d.forward()
+        assert eb.self_contacts[i] == d.nself
+        assert np.abs(qacc[i] - d.qacc).max() < tol * np.abs(d.qacc).max(), (i, d.ncon, d.nself)
+        seen.add((d.nself > 0, d.ncon > d.nself))
+    assert (True, True) in seen and (True, False) in seen      # with and without simultaneous floor contacts
+    # without the flag the same states take the floor-only path: the acceleration differs
+    eb0 = emu.EmuBatch(mc, pd_tables(mc), len(Q), legal_bodies=FEET, f64=f64, newton_iters=100 if f64 else 8)
+    eb0.set_state(Q, V)
+    assert np.abs(eb0.debug_forward(T)[2] - qacc).max() > 1e-2 and (eb0.self_contacts == 0).all()
+
+
+def test_capacity_rule_keeps_the_deepest_eight():
+    """More than SS_MAX_SELF_CONTACTS body-body contacts: the kernel keeps the deepest 8 (ties in pair order) like the oracle
+    built with max_self_contacts=8, and differs from the uncapped oracle."""
+    mc = model_const()
+    om8 = oracle_model(self_collision=True, max_self_contacts=8)
+    om_all = oracle_model(self_collision=True)
+    rs = np.random.default_rng(9)
+    d8, da = O.OracleData(om8), O.OracleData(om_all)
+    found = None
+    for _ in range(3000):
+        q = default_qpos(76); q[2] = 5.0; q[7:] = rs.uniform(-2.2, 2.2, 69)
+        da.qpos = q; da.qvel = np.zeros(75); da.ctrl = np.zeros(69); da.forward()
+        if da.nself > 8:
+            found = q
+            break
+    assert found is not None
+    d8.qpos = found; d8.qvel = np.zeros(75); d8.ctrl = np.zeros(69); d8.forward()
+    assert d8.nself == 8 and int(d8.get(O.D_NSELF)[2]) == da.nself - 8
+    eb = emu.EmuBatch(mc, pd_tables(mc), 1, legal_bodies=FEET, f64=True, newton_iters=100, self_collision=True)
+    eb.set_state(found[None], np.zeros((1, 75)))
+    qacc = eb.debug_forward(np.zeros((1, 69)))[2][0]
+    assert eb.self_contacts[0] == 8
+    assert np.abs(qacc - d8.qacc).max() < 1e-9 * np.abs(d8.qacc).max()
+    assert np.abs(qacc - da.qacc).max() > 1e-6 * np.abs(da.qacc).max()
+
+
+def test_teacher_forced_control_steps_with_self_collision():
+    """Actions that fold the arms through the torso and cross the legs (uniform(-1,1) targets up to +-pi): 10 control steps
+    of the float32 kernel, each from the oracle's state, against the oracle with the same contact set."""
+    mc = model_const()
+    om = oracle_model(self_collision=True, max_self_contacts=8)
+    oenv = O.OracleEnv(om)
+    eb = emu.EmuBatch(mc, pd_tables(mc), 1, legal_bodies=FEET, self_collision=True)
+    assert np.abs(oenv.reset() - eb.reset()[0]).max() < 1e-6
+    rs = np.random.default_rng(5)
+    worst, with_self = np.zeros(3), 0
+    for i in range(10):
+        eb.set_state(oenv.data.qpos[None], oenv.data.qvel[None], eb.qpos_prev, eb.qvel_prev)
+        a = rs.uniform(-1, 1, 69)
+        o_ref, r, te, tu = oenv.step(a)
+        obs, rew, term, trunc = eb.step(a[None])
+        with_self += oenv.data.nself > 0
+        assert eb.self_contacts[0] == oenv.data.nself
+        scale = max(1.0, np.abs(oenv.data.qvel).max())
+        worst = np.maximum(worst, [np.abs(eb.qpos[0] - oenv.data.qpos).max() / scale, np.abs(eb.qvel[0] - oenv.data.qvel).max() / scale,
+                                   np.abs(obs[0] - o_ref).max() / scale])
+    assert with_self >= 5
+    assert worst[0] < 2e-5 and worst[1] < 2e-3 and worst[2] < 2e-3, worst
+
+
+def test_benchmark_distribution_per_sample_with_self_collision():
+    """The per-sample triage of test_parity_f64.py with body-body contacts on (69% of the benchmark's control steps end with
+    at least one): formulation, resets, precision and cap gap under the same bounds."""
+    from test_parity_f64 import _check
+    pre, A, post = P.rollout_samples_emu(12, 16, seed=3, skip=6, self_collision=True)
+    r = P.triage(pre, A, post, n_perturb=4, self_collision=True)
+    _check(r, "smpl uniform(-1,1), self-collision", 90)
+    assert (r["nself"] > 0).mean() > 0.3
+
+
+def test_smplx_with_self_collision():
+    """52 bodies, 1265 candidate pairs (20 broad-phase rounds of 64 lanes)."""
+    mc = model_const("smplx_humanoid")
+    om, Q, V, T = _states(3, 4, humanoid="smplx_humanoid")
+    eb = emu.EmuBatch(mc, pd_tables(mc), len(Q), legal_bodies=FEET, f64=True, newton_iters=100, self_collision=True)
+    eb.set_state(Q, V)
+    qacc = eb.debug_forward(T)[2]
+    d = O.OracleData(om)
+    for i in range(len(Q)):
+        d.qpos = Q[i]; d.qvel = V[i]; d.ctrl = T[i]; d.warm = np.zeros(mc.nv); d.forward()
+        assert eb.self_contacts[i] == d.nself
+        assert np.abs(qacc[i] - d.qacc).max() < 1e-9 * np.abs(d.qacc).max()

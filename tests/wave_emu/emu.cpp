@@ -194,13 +194,13 @@ struct WaveEmu {
 
 struct LaunchCtx { const ss::KArgs *k; const uint32_t *T; ss::real *L; int env; Machine *m; };
 
-template <int DOFP, int CANDP, int SLOTP, int NPASS, bool SHAPED, class HT = ss::HdrRuntime>
+template <int DOFP, int CANDP, int SLOTP, int NPASS, bool SHAPED, class HT = ss::HdrRuntime, bool SELFCOL = false>
 void lane_entry(int lane, void *arg) {
   LaunchCtx *c = (LaunchCtx *)arg;
   WaveEmu w{c->m, lane};
   int mode = c->k->mode;
   for (int rep = 0; rep < 2; rep++) {
-    const bool again = ss::run_env<WaveEmu, DOFP, CANDP, SLOTP, NPASS, true, SHAPED, HT>(&w, c->k, c->T, c->L, c->env, mode);
+    const bool again = ss::run_env<WaveEmu, DOFP, CANDP, SLOTP, NPASS, true, SHAPED, HT, SELFCOL>(&w, c->k, c->T, c->L, c->env, mode);
     w.sync();
     if (!again) break;
     mode = ss::MODE_RESET;
@@ -215,7 +215,7 @@ struct EmuBackend {
   static bool download(void *dst, const void *src, size_t n) { memcpy(dst, src, n); return true; }
   static int lds_capacity() { return 160 * 1024; }
   static int kernel_regs() { return 0; }
-  static int max_waves(int) { return 16; }
+  static int max_waves(int, int) { return 16; }
   static const char *order_by_iters(const int32_t *iters, int32_t *order, int n, void *) {
     std::vector<int> idx(n);
     for (int i = 0; i < n; i++) idx[i] = i;
@@ -276,7 +276,7 @@ struct EmuBackend {
   static const char *launch(const ss::KArgs &k, int nenv, int envs_per_wg, size_t lds_bytes, void *, int, int) {
     (void)envs_per_wg; (void)lds_bytes;
     static thread_local Machine *m = new Machine();
-    std::vector<ss::real> L(k.h.env_floats);
+    std::vector<ss::real> L(ss::env_slice_floats(k));
     *k.work_counter = 0;
     for (int env = 0; env < nenv; env++) {
       // poison LDS so that reads of never-written locations are visible
@@ -284,6 +284,13 @@ struct EmuBackend {
       LaunchCtx c{&k, k.shared_g, L.data(), k.order ? k.order[env] : env, m};
       void (*entry)(int, void *) = nullptr;
       const int variant = ss::kernel_variant(k.h);
+      if (k.cfg.self_collision) {
+        if (variant == 0) entry = lane_entry<2, 2, 1, 1, false, ss::HdrRuntime, true>;
+        else if (variant == 1) entry = lane_entry<3, 3, 2, 2, false, ss::HdrRuntime, true>;
+        else return "no kernel variant for this model size";
+        run_wave(m, entry, &c);
+        continue;
+      }
       // like the GPU launcher: the SMPL-sized model without per-env shapes runs the compile-time-layout instantiation
       if (variant == 0 && !k.st.shape_id && ss::HdrFixedT<24, 5>::matches(k.h) && !getenv("SS_EMU_GENERIC")) entry = lane_entry<2, 2, 1, 1, false, ss::HdrFixedT<24, 5>>;
       else if (variant == 0) entry = k.st.shape_id ? lane_entry<2, 2, 1, 1, true> : lane_entry<2, 2, 1, 1, false>;
@@ -297,6 +304,21 @@ struct EmuBackend {
 };
 
 }  // namespace
+
+// test hook: the kernel's pair functions (ss_selfcol.h) on raw geometry, same calling convention as the oracle's
+// om_narrow_phase (oracle/oracle.c); always float64 in / out
+extern "C" int ss_emu_narrow_phase(int kind, const double *in, double *out) {
+  using namespace ss;
+  real v[32];
+  for (int i = 0; i < 31; i++) v[i] = (real)in[i];
+  sc::NCon c[8]; int n = 0;
+  if (kind == 0) n = sc::capsule_capsule(v, v + 3, v[6], v[7], v + 8, v + 11, v[14], v[15], v[16], c);
+  else if (kind == 1) n = sc::capsule_box(v, v + 3, v[6], v[7], v + 8, v + 11, v + 20, v[23], c);
+  else n = sc::box_box(v, v + 3, v + 12, v + 15, v + 18, v + 27, v[30], c);
+  out[0] = n;
+  for (int i = 0; i < n; i++) { for (int k = 0; k < 3; k++) { out[1 + 7 * i + k] = c[i].pos[k]; out[4 + 7 * i + k] = c[i].n[k]; } out[7 + 7 * i] = c[i].dist; }
+  return n;
+}
 
 SS_DEFINE_C_API(EmuBackend)
 SS_DEFINE_MOTION_API(EmuBackend)

@@ -69,11 +69,12 @@ class EmuBatch:
         self.solver_iters = np.zeros(N, np.int32)
         self.pid_integral = np.zeros((N, mc.nu), ft); self.pid_last_error = np.zeros((N, mc.nu), ft)
         self.pid_started = np.zeros(N, np.int32)
+        self.self_contacts = np.zeros(N, np.int32)
         self.qpos[:, 3] = 1; self.qpos_prev[:, 3] = 1
         st = _cabi.State(N, *[_p(x) for x in (self.qpos, self.qvel, self.qpos_prev, self.qvel_prev, self.qacc_warm,
                                              self.body_vel, self.touch, self.cur_t, self.task, self.nwarn,
                                              self.solver_iters, self.pid_integral, self.pid_last_error,
-                                             self.pid_started, self.shape_id)])
+                                             self.pid_started, self.shape_id, self.self_contacts)])
         self.batch = C.c_void_p()
         self._chk(L.ss_batch_create(self.model, C.byref(self.cfg), C.byref(st), C.byref(self.batch)))
         self.obs_size = L.ss_obs_size(self.model, C.byref(self.cfg))
