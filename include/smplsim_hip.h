@@ -180,6 +180,10 @@ int ss_set_body_outputs(ss_batch *b, float *xpos, float *xmat);
  * writes the dense joint-space mass matrix [N,nv,nv] (what mj_fullM returns; the stepping path itself never forms
  * it), qfrc_bias [N,nv] and the constrained qacc [N,nv]. */
 int ss_debug_forward(ss_batch *b, const float *torques, float *M, float *bias, float *qacc, void *stream);
+/* Diagnostics (self_collision batches): a caller-owned buffer [N, SS_MAX_SELF_CONTACTS, 24] that every launch fills with the
+ * body-body contact records of each env's last forward pass (mjData.contact of the body pairs): body1 body2 | world position 3 |
+ * normal body1->body2 3 | first tangent 3 | 1/R of the pyramid rows | aref 4 | jar 4 | jd 4 ; NULL turns it off. */
+int ss_debug_self_contacts(ss_batch *b, float *records);
 /* ---- caller side of the path: device-side generalised advantage estimation for the PPO sampler that
  * feeds ss_step.  The rollout is stored time-major [T,N]; one recursion per env column, exactly the loop of the
  * reference's estimate_advantages (smpl_sim/learning/learning_utils.py:198-218):

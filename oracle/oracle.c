@@ -514,11 +514,15 @@ static void collide(const om_model *m, om_data *d) {
  * restated as rules, not line by line.  Normals point from the pair's first geom to its second. */
 typedef struct { double pos[3], normal[3], dist; } ncon;
 
-static int sphere_sphere(const double *p1, double r1, const double *p2, double r2, double margin, ncon *o) {
+/* fb: direction to use when the centres (nearly) coincide — the separation vector is rounding noise then.  NULL = (1,0,0).
+ * "Nearly" = closer than 1e-5 of the radii, far above float32 rounding of the positions: the float32 kernel and this code
+ * take the same branch */
+static int sphere_sphere(const double *p1, double r1, const double *p2, double r2, double margin, const double *fb, ncon *o) {
   double d[3]; v3sub(d, p2, p1);
   double len = v3norm(d), dist = len - (r1 + r2);
   if (dist > margin) return 0;
-  if (len < MINVAL) v3set(o->normal, 1, 0, 0); else v3set(o->normal, d[0] / len, d[1] / len, d[2] / len);
+  if (len < 1e-5 * (r1 + r2)) { if (fb) v3cpy(o->normal, fb); else v3set(o->normal, 1, 0, 0); }
+  else v3set(o->normal, d[0] / len, d[1] / len, d[2] / len);
   for (int k = 0; k < 3; k++) o->pos[k] = p1[k] + o->normal[k] * (r1 + 0.5 * dist);
   o->dist = dist;
   return 1;
@@ -540,7 +544,10 @@ static int capsule_capsule(const double *p1, const double *a1, double r1, double
     if (x2 > h2) { x2 = h2; x1 = clampd((u - mb * h2) / ma, -h1, h1); }
     else if (x2 < -h2) { x2 = -h2; x1 = clampd((u + mb * h2) / ma, -h1, h1); }
     for (int k = 0; k < 3; k++) { c1[k] = p1[k] + a1[k] * x1; c2[k] = p2[k] + a2[k] * x2; }
-    return sphere_sphere(c1, r1, c2, r2, margin, o);
+    /* axes that (nearly) intersect: push apart along their common perpendicular, on the side of geom 2's centre */
+    double fb[3]; v3cross(fb, a1, a2); v3normalize(fb);
+    if (v3dot(fb, dif) > 0) v3set(fb, -fb[0], -fb[1], -fb[2]);
+    return sphere_sphere(c1, r1, c2, r2, margin, fb, o);
   }
   /* parallel axes: the ends of each segment against the other segment, at most two contacts */
   int n = 0;
@@ -549,13 +556,16 @@ static int capsule_capsule(const double *p1, const double *a1, double r1, double
     if (e < 2) { x1 = e == 0 ? h1 : -h1; x2 = (v - mb * x1) / mc; if (x2 > h2 || x2 < -h2) continue; }
     else { x2 = e == 2 ? h2 : -h2; x1 = (u - mb * x2) / ma; if (x1 > h1 || x1 < -h1) continue; }
     for (int k = 0; k < 3; k++) { c1[k] = p1[k] + a1[k] * x1; c2[k] = p2[k] + a2[k] * x2; }
-    n += sphere_sphere(c1, r1, c2, r2, margin, o + n);
+    n += sphere_sphere(c1, r1, c2, r2, margin, NULL, o + n);
   }
   return n;
 }
 
 /* sphere (geom 1) against box (geom 2: centre bp, rotation bm row-major with the box axes as columns, half sizes bs) */
-static int sphere_box(const double *c, double r, const double *bp, const double *bm, const double *bs, double margin, ncon *o) {
+/* hint (box frame, may be NULL): which of two opposite faces a centre lying on the box's mid-plane is pushed out through
+ * (capsule_box passes the capsule's centre: its mid-range rule puts the sphere exactly there when the axis skewers a thin box) */
+static int sphere_box(const double *c, double r, const double *bp, const double *bm, const double *bs, double margin, const double *hint,
+                      ncon *o) {
   double d[3], l[3], cl[3];
   v3sub(d, c, bp);
   for (int i = 0; i < 3; i++) { l[i] = bm[i] * d[0] + bm[3 + i] * d[1] + bm[6 + i] * d[2]; cl[i] = clampd(l[i], -bs[i], bs[i]); }
@@ -568,6 +578,7 @@ static int sphere_box(const double *c, double r, const double *bp, const double 
     int k = 0; double best = bs[0] - fabs(l[0]);
     for (int i = 1; i < 3; i++) if (bs[i] - fabs(l[i]) < best) { best = bs[i] - fabs(l[i]); k = i; }
     double sg = l[k] >= 0 ? 1.0 : -1.0;
+    if (hint && fabs(l[k]) < 1e-5 * bs[k]) sg = hint[k] >= 0 ? 1.0 : -1.0;
     v3set(nl, 0, 0, 0); nl[k] = sg; cl[k] = sg * bs[k];
     dist = -best - r;
   }
@@ -627,11 +638,11 @@ static int capsule_box(const double *cp, const double *ca, double r, double h, c
   int n = 0;
   double c[3];
   for (int i = 0; i < 3; i++) c[i] = cp[i] + ts * ca[i];
-  n += sphere_box(c, r, bp, bm, bs, margin, o + n);
+  n += sphere_box(c, r, bp, bm, bs, margin, p, o + n);
   double t2 = ts >= 0 ? -h : h;                              /* the far end of the segment */
   if (fabs(t2 - ts) > 1e-6 * (h > MINVAL ? h : 1.0)) {
     for (int i = 0; i < 3; i++) c[i] = cp[i] + t2 * ca[i];
-    n += sphere_box(c, r, bp, bm, bs, margin, o + n);
+    n += sphere_box(c, r, bp, bm, bs, margin, p, o + n);
   }
   return n;
 }
@@ -640,7 +651,7 @@ static int capsule_box(const double *cp, const double *ca, double r, double h, c
 static double point_box_sdf(const double *x, const double *bp, const double *bm, const double *bs, double *cl_w, double *n_w) {
   ncon t;
   /* a zero-radius sphere; a point farther than any margin still needs its distance, so the margin is infinite here */
-  sphere_box(x, 0.0, bp, bm, bs, 1e300, &t);
+  sphere_box(x, 0.0, bp, bm, bs, 1e300, NULL, &t);
   for (int i = 0; i < 3; i++) { n_w[i] = -t.normal[i]; cl_w[i] = t.pos[i] - n_w[i] * 0.5 * t.dist; }
   return t.dist;
 }

@@ -39,6 +39,7 @@ struct ss_batch {
   float *body_xpos = nullptr, *body_xmat = nullptr;   // caller-owned, optional: written by every step / reset (ss_set_body_outputs)
   static ss::real *R(float *p) { return reinterpret_cast<ss::real *>(p); }               // C-ABI arrays as the kernel's scalar type
   static const ss::real *R(const float *p) { return reinterpret_cast<const ss::real *>(p); }
+  float *dbg_self = nullptr;              // caller-owned, optional (ss_debug_self_contacts)
   int fixed_envs_per_wg = 0, max_wgs = 0; // ss_set_launch_geometry: 0 = automatic (small batches are spread over all CUs)
 };
 
@@ -167,7 +168,7 @@ struct ss_api {
     k.h = m->hm.h; k.cfg = b->cfg; k.st = b->st;
     k.shared_g = m->d_shared; k.bodyc = m->d_bodyc; k.candc = m->d_candc; k.candb = m->d_candb;
     k.illegal_mask = m->hm.illegal_mask;
-    k.sc = m->hm.sc; k.pairs = m->d_pairs; k.geomc = m->d_geomc;
+    k.sc = m->hm.sc; k.pairs = m->d_pairs; k.geomc = m->d_geomc; k.dbg_self = ss_batch::R(b->dbg_self);
     k.mode = mode; k.nsub = b->cfg.control_freq_inv; k.obs_size = b->obs_size;
     k.work_counter = b->d_counter;
     k.prof = b->d_prof;
@@ -256,6 +257,10 @@ struct ss_api {
   int ss_set_body_outputs(ss_batch *b, float *xpos, float *xmat) {                                                    \
     if (!b || (!xpos) != (!xmat)) return ss_api<BE>::fail(SS_ERR_INVALID, "pass both buffers or neither");           \
     b->body_xpos = xpos; b->body_xmat = xmat; return SS_OK;                                                          \
+  }                                                                                                                  \
+  int ss_debug_self_contacts(ss_batch *b, float *records) {                                                           \
+    if (!b) return ss_api<BE>::fail(SS_ERR_INVALID, "null batch");                                                  \
+    b->dbg_self = records; return SS_OK;                                                                             \
   }                                                                                                                  \
   int ss_schedule_longest_first(ss_batch *b, void *stream) {                                                        \
     if (!b) return ss_api<BE>::fail(SS_ERR_INVALID, "null batch");                                                  \

@@ -198,6 +198,7 @@ struct KArgs {
   HdrSC sc;
   const int32_t *pairs;       // [sc.npair] b1 | b2 << 8
   const real *geomc;          // [nb][kGeomC]
+  real *dbg_self;             // optional [N][kMaxSelf][kSelfRec]: the contact records of the last forward (ss_debug_self_contacts)
   // per-env body shapes (ss_model_create_shapes): bodyc holds num_shapes consecutive blocks of [nb][kBodyC] body constants
   // followed by [nv] dof inverse weights (block stride shape_stride(h) floats), candc num_shapes consecutive tables;
   // st.shape_id [N] selects per env (null = single-shape model)

@@ -803,6 +803,8 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       w->sync();                                             // candidates consumed (the records may not overlap them, but keep it simple)
       if (slot >= 0) for (int i = 0; i < kSelfRec; i++) this->rec[kSelfRec * slot + i] = rcd[i];
       if (write_count && lane == 0 && k->st.self_contacts) k->st.self_contacts[env] = nk;
+      if (write_count && k->dbg_self && slot >= 0)           // diagnostics: positions made absolute
+        for (int i = 0; i < kSelfRec; i++) k->dbg_self[((size_t)env * kMaxSelf + slot) * kSelfRec + i] = rcd[i] + (i >= RC_POS && i < RC_POS + 3 ? q[i - RC_POS] : real(0));
       w->sync();
     }
   }

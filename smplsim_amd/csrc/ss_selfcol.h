@@ -32,11 +32,13 @@ constexpr real kMin = real(1e-15);
 SS_DEV real dot3(const real *a, const real *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 SS_DEV real clampr(real x, real lo, real hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
-SS_DEV int sphere_sphere(const real *p1, real r1, const real *p2, real r2, real margin, NCon *o) {
+// fb: direction used when the centres (nearly) coincide — closer than 1e-5 of the radii, where the separation vector is rounding
+// noise (far above float32 rounding of the positions, so the float64 twin takes the same branch); null = (1,0,0)
+SS_DEV int sphere_sphere(const real *p1, real r1, const real *p2, real r2, real margin, const real *fb, NCon *o) {
   const real d[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
   const real len = SS_M(sqrt)(dot3(d, d)), dist = len - (r1 + r2);
   if (dist > margin) return 0;
-  if (len < kMin) { o->n[0] = 1; o->n[1] = 0; o->n[2] = 0; }
+  if (len < real(1e-5) * (r1 + r2)) { o->n[0] = fb ? fb[0] : real(1); o->n[1] = fb ? fb[1] : real(0); o->n[2] = fb ? fb[2] : real(0); }
   else { const real il = real(1) / len; o->n[0] = d[0] * il; o->n[1] = d[1] * il; o->n[2] = d[2] * il; }
   for (int k = 0; k < 3; k++) o->pos[k] = p1[k] + o->n[k] * (r1 + real(0.5) * dist);
   o->dist = dist;
@@ -57,7 +59,12 @@ SS_DEV int capsule_capsule(const real *p1, const real *a1, real r1, real h1, con
     if (x2 > h2) { x2 = h2; x1 = clampr((u - mb * h2) / ma, -h1, h1); }
     else if (x2 < -h2) { x2 = -h2; x1 = clampr((u + mb * h2) / ma, -h1, h1); }
     for (int k = 0; k < 3; k++) { c1[k] = p1[k] + a1[k] * x1; c2[k] = p2[k] + a2[k] * x2; }
-    return sphere_sphere(c1, r1, c2, r2, margin, o);
+    // axes that (nearly) intersect: push apart along their common perpendicular, on the side of geom 2's centre
+    real fb[3] = {a1[1] * a2[2] - a1[2] * a2[1], a1[2] * a2[0] - a1[0] * a2[2], a1[0] * a2[1] - a1[1] * a2[0]};
+    const real fl = SS_M(sqrt)(dot3(fb, fb));
+    if (fl < kMin) { fb[0] = 1; fb[1] = 0; fb[2] = 0; } else { const real il = real(1) / fl; fb[0] *= il; fb[1] *= il; fb[2] *= il; }
+    if (dot3(fb, dif) > 0) { fb[0] = -fb[0]; fb[1] = -fb[1]; fb[2] = -fb[2]; }
+    return sphere_sphere(c1, r1, c2, r2, margin, fb, o);
   }
   int n = 0;                                                 // parallel axes: segment ends against the other segment
   for (int e = 0; e < 4 && n < 2; e++) {
@@ -65,13 +72,15 @@ SS_DEV int capsule_capsule(const real *p1, const real *a1, real r1, real h1, con
     if (e < 2) { x1 = e == 0 ? h1 : -h1; x2 = (v - mb * x1) / mc; if (x2 > h2 || x2 < -h2) continue; }
     else { x2 = e == 2 ? h2 : -h2; x1 = (u - mb * x2) / ma; if (x1 > h1 || x1 < -h1) continue; }
     for (int k = 0; k < 3; k++) { c1[k] = p1[k] + a1[k] * x1; c2[k] = p2[k] + a2[k] * x2; }
-    n += sphere_sphere(c1, r1, c2, r2, margin, o + n);
+    n += sphere_sphere(c1, r1, c2, r2, margin, nullptr, o + n);
   }
   return n;
 }
 
 // sphere (first geom) against box (second geom: centre bp, rotation bm row-major with the box axes as columns, half sizes bs)
-SS_DEV int sphere_box(const real *c, real r, const real *bp, const real *bm, const real *bs, real margin, NCon *o) {
+// hint (box frame, may be null): which of two opposite faces a centre lying on the box's mid-plane is pushed out through
+// (capsule_box passes the capsule's centre: its mid-range rule puts the sphere exactly there when the axis skewers a thin box)
+SS_DEV int sphere_box(const real *c, real r, const real *bp, const real *bm, const real *bs, real margin, const real *hint, NCon *o) {
   const real d[3] = {c[0] - bp[0], c[1] - bp[1], c[2] - bp[2]};
   real l[3], cl[3];
   for (int i = 0; i < 3; i++) { l[i] = bm[i] * d[0] + bm[3 + i] * d[1] + bm[6 + i] * d[2]; cl[i] = clampr(l[i], -bs[i], bs[i]); }
@@ -86,7 +95,8 @@ SS_DEV int sphere_box(const real *c, real r, const real *bp, const real *bm, con
   } else {                                                   // centre inside the box: out through the nearest face
     int k = 0; real best = bs[0] - SS_M(fabs)(l[0]);
     for (int i = 1; i < 3; i++) { const real e = bs[i] - SS_M(fabs)(l[i]); if (e < best) { best = e; k = i; } }
-    const real sg = l[k] >= 0 ? real(1) : real(-1);
+    real sg = l[k] >= 0 ? real(1) : real(-1);
+    if (hint && SS_M(fabs)(l[k]) < real(1e-5) * bs[k]) sg = hint[k] >= 0 ? real(1) : real(-1);
     nl[0] = nl[1] = nl[2] = 0;
     if (k == 0) { nl[0] = sg; cl[0] = sg * bs[0]; } else if (k == 1) { nl[1] = sg; cl[1] = sg * bs[1]; } else { nl[2] = sg; cl[2] = sg * bs[2]; }
     dist = -best - r;
@@ -143,11 +153,11 @@ SS_DEV int capsule_box(const real *cp, const real *ca, real r, real h, const rea
   int n = 0;
   real c[3];
   for (int i = 0; i < 3; i++) c[i] = cp[i] + ts * ca[i];
-  n += sphere_box(c, r, bp, bm, bs, margin, o + n);
+  n += sphere_box(c, r, bp, bm, bs, margin, p, o + n);
   const real t2 = ts >= 0 ? -h : h;
   if (SS_M(fabs)(t2 - ts) > real(1e-6) * (h > kMin ? h : real(1))) {
     for (int i = 0; i < 3; i++) c[i] = cp[i] + t2 * ca[i];
-    n += sphere_box(c, r, bp, bm, bs, margin, o + n);
+    n += sphere_box(c, r, bp, bm, bs, margin, p, o + n);
   }
   return n;
 }
@@ -209,7 +219,7 @@ SS_DEV int box_box(const real *pa, const real *ma, const real *sa, const real *p
         x[0] += ax[0] * s_; x[1] += ax[1] * s_; x[2] += ax[2] * s_;
       }
       NCon tcon;
-      sphere_box(x, real(0), po, mo, so, real(1e30), &tcon);  // zero-radius sphere: signed distance and nearest surface point
+      sphere_box(x, real(0), po, mo, so, real(1e30), nullptr, &tcon);  // zero-radius sphere: signed distance and nearest surface point
       if (tcon.dist > margin) continue;
       // -tcon.n: outward normal of the surface box at the nearest point; towards the vertex box it is +bn (surface = A) or -bn
       const real al = -(tcon.n[0] * bn[0] + tcon.n[1] * bn[1] + tcon.n[2] * bn[2]) * (which ? real(-1) : real(1));

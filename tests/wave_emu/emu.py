@@ -128,6 +128,12 @@ class EmuBatch:
         self._chk(self.L.ss_kinematics(self.batch, _p(xpos), _p(xmat), None))
         return xpos, xmat
 
+    def debug_self_contacts(self):
+        """Turn on the record dump of the body-body contacts: self.self_records [N, 8, 24] after every launch."""
+        self.self_records = np.zeros((self.N, 8, 24), self.ft)
+        self._chk(self.L.ss_debug_self_contacts(self.batch, _p(self.self_records)))
+        return self.self_records
+
     def debug_forward(self, torques=None):
         nv = self.mc.nv
         M = np.zeros((self.N, nv, nv), self.ft)
