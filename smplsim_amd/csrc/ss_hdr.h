@@ -94,6 +94,7 @@ constexpr int kGeomC = 16;                       // floats per body in the geom 
 struct HdrSC {
   int npair;                                     // candidate body pairs of the model (b1 | b2 << 8 each)
   int l_rec, l_G, l_u, l_lam, l_Pb2, l_delta2, l_gc;   // float offsets in the env slice
+  int l_Dinv, l_rootf, l_ysave, l_An3;                 // factor pieces kept for re-solves, and the 3-right-hand-side sweep's buffers
   int env_floats;                                // slice size of a SELFCOL env
 };
 constexpr HdrSC make_layout_sc(int nb, int base_floats) {
@@ -105,6 +106,7 @@ constexpr HdrSC make_layout_sc(int nb, int base_floats) {
   y.l_G = take(9 * kMaxSelf * kMaxSelf > 10 * kSelfCand ? 9 * kMaxSelf * kMaxSelf : 10 * kSelfCand);   // (3c)^2 Delassus block; narrow-phase candidates before that
   y.l_u = take(3 * kMaxSelf); y.l_lam = take(3 * kMaxSelf);
   y.l_Pb2 = take(6 * nb); y.l_delta2 = take(nv + 1); y.l_gc = take(3 * nb);
+  y.l_Dinv = take(8 * (nb + 1)); y.l_rootf = take(32); y.l_ysave = take(12 * (nb + 1)); y.l_An3 = take(24 * (nb + 1));
   y.env_floats = o;
   return y;
 }

@@ -114,6 +114,7 @@ template <> struct ShapeTables<true> { const real *bodyc_s, *candc_s, *dinvw_s; 
 template <bool SELFCOL> struct SelfColState {};
 template <> struct SelfColState<true> {
   real *rec, *G, *uvec, *lam, *Pb2, *delta2, *gc;          // per-env LDS arrays (HdrSC)
+  real *Dinv, *rootf, *ysave, *An3;                        // D^-1 per node and the root's block inverses of the last aba_solve; re-solve buffers
   int nself;                                               // wave-uniform count of body-body contacts of this pass
 };
 
@@ -174,6 +175,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       const HdrSC &y = k->sc;
       this->rec = L + y.l_rec; this->G = L + y.l_G; this->uvec = L + y.l_u; this->lam = L + y.l_lam; this->Pb2 = L + y.l_Pb2;
       this->delta2 = L + y.l_delta2; this->gc = L + y.l_gc; this->nself = 0;
+      this->Dinv = L + y.l_Dinv; this->rootf = L + y.l_rootf; this->ysave = L + y.l_ysave; this->An3 = L + y.l_An3;
     }
 #pragma unroll
     for (int p = 0; p < SLOTP; p++) con[p].active = 0;
@@ -861,30 +863,8 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       const int ns = this->nself, m = 3 * ns;
       const real mu = h.mu;
       real *G = this->G, *uvec = this->uvec, *lam = this->lam, *Pb2 = this->Pb2, *d2 = this->delta2;
-      // ---- columns of G = E H_tree^-1 E^T: one tree solve per unit relative force
-      for (int col = 0; col < m; col++) {
-        fresh();
-        const int cc = col / 3, cj = col - 3 * cc;
-        const real *rc = this->rec + kSelfRec * cc;
-        for (int i = lane; i < h.nv; i += 64) d2[i] = 0;
-        for (int i = lane; i < 6 * h.nb; i += 64) Pb2[i] = 0;
-        w->sync();
-        if (lane < 12) {                                     // H x = - sum_b J_b^T pb: pb = -wrench on body 2, +wrench on body 1
-          const int t = lane < 6 ? lane : lane - 6;
-          const real wv = self_wrench(rc, cj == 0 ? real(1) : real(0), cj == 1 ? real(1) : real(0), cj == 2 ? real(1) : real(0), t);
-          const int b = (int)(lane < 6 ? rc[RC_B2] : rc[RC_B1]);
-          Pb2[6 * b + t] = lane < 6 ? -wv : wv;
-        }
-        w->sync();
-        aba_solve(d2, Pb2);
-        if (lane < ns) {
-          real an, at1, at2;
-          self_rel(this->rec + kSelfRec * lane, An + 8, 8, &an, &at1, &at2);
-          G[(3 * lane) * m + col] = an; G[(3 * lane + 1) * m + col] = at1; G[(3 * lane + 2) * m + col] = at2;
-        }
-        w->sync();
-      }
-      // ---- y = H_tree^-1 b_tree (b_tree: joint-space right-hand side in delta, tree per-body forces in Pb)
+      // ---- y = H_tree^-1 b_tree (b_tree: joint-space right-hand side in delta, tree per-body forces in Pb): the one full solve
+      // of this Newton iteration — everything below re-uses its factorization (aba_resolve)
       fresh();
       for (int i = lane; i < h.nv; i += 64) d2[i] = delta[i];
       w->sync();
@@ -895,6 +875,26 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
         uvec[3 * lane] = an; uvec[3 * lane + 1] = at1; uvec[3 * lane + 2] = at2;
       }
       w->sync();
+      // ---- columns of G = E H_tree^-1 E^T: per contact, the responses to a unit relative force along its normal and two
+      // tangents in one 3-right-hand-side sweep (H x = - sum_b J_b^T pb with pb = -wrench on body 2, +wrench on body 1)
+      for (int cc = 0; cc < ns; cc++) {
+        const real *rc = this->rec + kSelfRec * cc;
+        const int cb1 = (int)rc[RC_B1], cb2 = (int)rc[RC_B2];
+        const int r_ = lane & 7;
+        real wr[3] = {0, 0, 0};
+        if (r_ < 6) { wr[0] = self_wrench(rc, real(1), real(0), real(0), r_); wr[1] = self_wrench(rc, real(0), real(1), real(0), r_); wr[2] = self_wrench(rc, real(0), real(0), real(1), r_); }
+        aba_resolve<3>([](int, int) { return real(0); },
+                       [&](int b, int, int q_) { return b == cb2 ? -wr[q_] : (b == cb1 ? wr[q_] : real(0)); }, this->An3, nullptr);
+        if (lane < ns) {
+          const real *rl = this->rec + kSelfRec * lane;
+          for (int q_ = 0; q_ < 3; q_++) {
+            real an, at1, at2;
+            self_rel(rl, this->An3 + 24 + 8 * q_, 24, &an, &at1, &at2);   // body b = node b + 1: An3[((b + 1) * 3 + q) * 8]
+            G[(3 * lane) * m + 3 * cc + q_] = an; G[(3 * lane + 1) * m + 3 * cc + q_] = at1; G[(3 * lane + 2) * m + 3 * cc + q_] = at2;
+          }
+        }
+        w->sync();
+      }
       // ---- (I + W G) lam = q + W (E y), Gaussian elimination with partial pivoting by one lane (m <= 3 kMaxSelf)
       if (lane == 0) {
         for (int c = 0; c < ns; c++) {
@@ -942,9 +942,8 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
         }
       }
       w->sync();
-      // ---- delta = H_tree^-1 (b_tree - E^T lam): one tree solve with the combined right-hand side
+      // ---- delta = H_tree^-1 (b_tree - E^T lam): a single-right-hand-side re-solve with the combined bias forces
       fresh();
-      for (int i = lane; i < h.nv; i += 64) delta[i] = d2[i];
       for (int i = lane; i < 6 * h.nb; i += 64) Pb2[i] = Pb[i];
       w->sync();
       if (lane < 6)
@@ -954,7 +953,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
           Pb2[6 * (int)rc[RC_B2] + lane] += wv; Pb2[6 * (int)rc[RC_B1] + lane] -= wv;
         }
       w->sync();
-      aba_solve(delta, Pb2);
+      aba_resolve<1>([&](int dof, int) { return d2[dof]; }, [&](int b, int row, int) { return Pb2[6 * b + row]; }, An, delta);
     }
   }
 
@@ -1102,6 +1101,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
           real *dst = cur + (kk * 6 + r_) * 8;
           st4w(dst, rn[0], rn[1], rn[2], rn[3]); st4w(dst + 4, rn[4], rn[5], pn, 0.f);
           st4w(Wst + (n * 6 + r_) * 4, w0, w1, w2, r_ == 0 ? y0 : (r_ == 1 ? y1 : y2));
+          if constexpr (SELFCOL) if (r_ == 0) { st4w(this->Dinv + 8 * n, i00, i01, i02, i11); st4w(this->Dinv + 8 * n + 4, i12, i22, 0.f, 0.f); }
         }
       }
       SS_FTICK(PF_F_P2);
@@ -1165,6 +1165,12 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       f6[3] = Ti[0] * gl0 + Ti[1] * gl1 + Ti[2] * gl2;
       f6[4] = Ti[1] * gl0 + Ti[3] * gl1 + Ti[4] * gl2;
       f6[5] = Ti[2] * gl0 + Ti[4] * gl1 + Ti[5] * gl2;
+      if constexpr (SELFCOL)
+        if (lane == 0) {                                       // the root's block inverses, for aba_resolve
+          real *rf = this->rootf;
+          for (int i = 0; i < 6; i++) { rf[i] = Ti[i]; rf[6 + i] = Si[i]; }
+          for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { rf[12 + 3 * i + j] = QT[i][j]; rf[21 + 3 * i + j] = A6[i][3 + j]; }
+        }
       // f6 = spatial acceleration of body 0; joint solution: x_trans = a_lin, x_rot = R^T a_ang
       if (lane < 6) An[8 + lane] = lane == 0 ? f6[0] : lane == 1 ? f6[1] : lane == 2 ? f6[2] : lane == 3 ? f6[3] : lane == 4 ? f6[4] : f6[5];
       if (lane < 3) x[lane] = lane == 0 ? f6[3] : (lane == 1 ? f6[4] : f6[5]);
@@ -1199,6 +1205,141 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       w->sync();
     }
     SS_FTICK(PF_F_BSOL);
+  }
+
+  // Re-solve with the factorization the last aba_solve left in LDS (W per node in Wst, D^-1 per node, the root's block inverses):
+  // H X = B - sum_b J_b^T PB_b for K right-hand sides in the same sweeps.  Only the bias quantities travel: one hand-off per level
+  // going up (no U rows), one going down — about a third of a full solve for K = 1, and K = 3 costs little more.
+  //   bf(dof, k)        joint-space right-hand side of system k
+  //   pf(body, row, k)  row of the per-body bias force of system k
+  //   Aout              body accelerations of the solutions, Aout[(node * K + k) * 8 + row]
+  //   xout              (K = 1, or null) joint-space solution
+  template <int K, class BF, class PF>
+  SS_DEV void aba_resolve(BF bf, PF pf, real *Aout, real *xout) {
+    if constexpr (SELFCOL) {
+      fresh();
+      typename HT::type h = HT::view(k->h);
+      const int r_ = lane & 7, g = lane >> 3;
+      const unsigned long long nk0 = h.nkpack[0], nk1 = h.nkpack[1];
+      real *ysave = this->ysave;
+      int s0 = h.nn;
+      for (int L = h.nlev - 1; L >= 2; --L) {
+        const int nk = (int)(((L < 16 ? nk0 : nk1) >> (4 * (L & 15))) & 15ull) + 1;
+        s0 -= nk;
+        real *cur = IA + (L & 1) * h.ia_stride;
+        const real *prev = IA + ((L + 1) & 1) * h.ia_stride;
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ps++) {
+          const int kk = ps * 8 + g;
+          int n = -1;
+          real pa[K], red[K][3], wr0 = 0, wr1 = 0, wr2 = 0;
+#pragma unroll
+          for (int q_ = 0; q_ < K; q_++) { pa[q_] = 0; red[q_][0] = red[q_][1] = red[q_][2] = 0; }
+          if (r_ < 6 && kk < nk) {
+            const int e = ti(h.o_lev, s0 + kk), cfirst = (e >> 16) & 255, cc = (e >> 24) & 255;
+            n = e & 255;
+#pragma unroll
+            for (int q_ = 0; q_ < K; q_++) pa[q_] = pf(n - 1, r_, q_);
+            for (int j = 0; j < cc; j++) {
+              const real *src = prev + ((cfirst + j) * 6 + r_) * 8;
+#pragma unroll
+              for (int q_ = 0; q_ < K; q_++) pa[q_] += src[q_];
+            }
+            const real *sn = S + 18 * n;
+            const real sr0 = sn[r_], sr1 = sn[6 + r_], sr2 = sn[12 + r_];
+#pragma unroll
+            for (int q_ = 0; q_ < K; q_++) { red[q_][0] = sr0 * pa[q_]; red[q_][1] = sr1 * pa[q_]; red[q_][2] = sr2 * pa[q_]; }
+            const float4_t wv = ld4(Wst + (n * 6 + r_) * 4);
+            wr0 = wv.x; wr1 = wv.y; wr2 = wv.z;
+          }
+#pragma unroll
+          for (int q_ = 0; q_ < K; q_++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) red[q_][j] = w->sum8(red[q_][j]);
+          if (n >= 0) {
+            const float4_t d0 = ld4(this->Dinv + 8 * n), d1 = ld4(this->Dinv + 8 * n + 4);
+            real *dst = cur + (kk * 6 + r_) * 8;
+#pragma unroll
+            for (int q_ = 0; q_ < K; q_++) {
+              const real u0 = bf(3 * n, q_) - red[q_][0], u1 = bf(3 * n + 1, q_) - red[q_][1], u2 = bf(3 * n + 2, q_) - red[q_][2];
+              dst[q_] = pa[q_] + wr0 * u0 + wr1 * u1 + wr2 * u2;
+              if (r_ < 3) {
+                const real yv = r_ == 0 ? d0.x * u0 + d0.y * u1 + d0.z * u2 : (r_ == 1 ? d0.y * u0 + d0.w * u1 + d1.x * u2 : d0.z * u0 + d1.x * u1 + d1.y * u2);
+                ysave[(n * K + q_) * 4 + r_] = yv;
+              }
+            }
+          }
+        }
+        w->sync();
+      }
+      {                                                      // ---- root (nodes 0 and 1 as one 6-dof joint)
+        real *rows = IA + h.ia_stride;
+        const real *prev = IA;
+        if (lane < 6) {
+          const int e = ti(h.o_lev, 1), cfirst = (e >> 16) & 255, cc = (e >> 24) & 255;
+#pragma unroll
+          for (int q_ = 0; q_ < K; q_++) {
+            real pv = pf(0, lane, q_);
+            for (int j = 0; j < cc; j++) pv += prev[((cfirst + j) * 6 + lane) * 8 + q_];
+            const real sb = lane < 3 ? S[18 + lane] * bf(3, q_) + S[24 + lane] * bf(4, q_) + S[30 + lane] * bf(5, q_) : bf(lane - 3, q_);
+            rows[8 * q_ + lane] = sb - pv;
+          }
+        }
+        w->sync();
+        const real *rf = this->rootf;
+#pragma unroll
+        for (int q_ = 0; q_ < K; q_++) {
+          real f6[6];
+          for (int i = 0; i < 6; i++) f6[i] = rows[8 * q_ + i];
+          real ga[3], aa[3], gl[3], al_[3];
+          for (int i = 0; i < 3; i++) ga[i] = f6[i] - (rf[12 + 3 * i] * f6[3] + rf[12 + 3 * i + 1] * f6[4] + rf[12 + 3 * i + 2] * f6[5]);
+          aa[0] = rf[6] * ga[0] + rf[7] * ga[1] + rf[8] * ga[2];
+          aa[1] = rf[7] * ga[0] + rf[9] * ga[1] + rf[10] * ga[2];
+          aa[2] = rf[8] * ga[0] + rf[10] * ga[1] + rf[11] * ga[2];
+          for (int j = 0; j < 3; j++) gl[j] = f6[3 + j] - (rf[21 + j] * aa[0] + rf[24 + j] * aa[1] + rf[27 + j] * aa[2]);
+          al_[0] = rf[0] * gl[0] + rf[1] * gl[1] + rf[2] * gl[2];
+          al_[1] = rf[1] * gl[0] + rf[3] * gl[1] + rf[4] * gl[2];
+          al_[2] = rf[2] * gl[0] + rf[4] * gl[1] + rf[5] * gl[2];
+          if (lane < 6) Aout[(1 * K + q_) * 8 + lane] = lane < 3 ? (lane == 0 ? aa[0] : lane == 1 ? aa[1] : aa[2]) : (lane == 3 ? al_[0] : lane == 4 ? al_[1] : al_[2]);
+          if (xout && q_ == 0) {
+            if (lane < 3) xout[lane] = lane == 0 ? al_[0] : (lane == 1 ? al_[1] : al_[2]);
+            else if (lane < 6) { const int j = lane - 3; xout[lane] = S[18 + 6 * j] * aa[0] + S[18 + 6 * j + 1] * aa[1] + S[18 + 6 * j + 2] * aa[2]; }
+          }
+        }
+        w->sync();
+        s0 = 2;
+      }
+      for (int L = 2; L < h.nlev; L++) {                      // ---- downward sweep
+        const int nk = (int)(((L < 16 ? nk0 : nk1) >> (4 * (L & 15))) & 15ull) + 1;
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ps++) {
+          const int kk = ps * 8 + g;
+          if (r_ < 6 && kk < nk) {
+            const int e = ti(h.o_lev, s0 + kk), n = e & 255, pn = (e >> 8) & 255;
+            float4_t Wn[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) Wn[c] = ld4(Wst + (n * 6 + c) * 4);
+            const real *sn = S + 18 * n + r_;
+            const real s_0 = sn[0], s_1 = sn[6], s_2 = sn[12];
+#pragma unroll
+            for (int q_ = 0; q_ < K; q_++) {
+              const real *apk = Aout + (pn * K + q_) * 8;
+              const float4_t p0 = ld4(apk), p1 = ld4(apk + 4);
+              const real ap[6] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y};
+              const real apr = apk[r_];
+              const real *ys = ysave + (n * K + q_) * 4;
+              real x0 = ys[0], x1 = ys[1], x2 = ys[2];
+#pragma unroll
+              for (int c = 0; c < 6; c++) { x0 -= Wn[c].x * ap[c]; x1 -= Wn[c].y * ap[c]; x2 -= Wn[c].z * ap[c]; }
+              Aout[(n * K + q_) * 8 + r_] = apr + s_0 * x0 + s_1 * x1 + s_2 * x2;
+              if (xout && q_ == 0 && r_ < 3) xout[3 * n + r_] = r_ == 0 ? x0 : (r_ == 1 ? x1 : x2);
+            }
+          }
+        }
+        s0 += nk;
+        w->sync();
+      }
+    }
   }
 
   // inverse of the symmetric 3x3 [d00 d10 d20; d10 d11 d21; d20 d21 d22] -> (i00 i01 i02 i11 i12 i22)
