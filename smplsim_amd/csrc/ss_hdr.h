@@ -104,7 +104,7 @@ constexpr HdrSC make_layout_sc(int nb, int base_floats) {
   auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
   y.l_rec = take(kSelfRec * kMaxSelf);
   y.l_G = take(9 * kMaxSelf * kMaxSelf > 10 * kSelfCand ? 9 * kMaxSelf * kMaxSelf : 10 * kSelfCand);   // (3c)^2 Delassus block; narrow-phase candidates before that
-  y.l_u = take(3 * kMaxSelf); y.l_lam = take(3 * kMaxSelf);
+  y.l_u = take(3 * kMaxSelf); y.l_lam = take(4 * kMaxSelf);   // lam doubles as the 4c-row exchange buffer of the dense solve
   y.l_Pb2 = take(6 * nb); y.l_delta2 = take(nv + 1); y.l_gc = take(3 * nb);
   y.l_Dinv = take(8 * (nb + 1)); y.l_rootf = take(32); y.l_ysave = take(12 * (nb + 1)); y.l_An3 = take(24 * (nb + 1));
   y.env_floats = o;

@@ -895,51 +895,74 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
         }
         w->sync();
       }
-      // ---- (I + W G) lam = q + W (E y), Gaussian elimination with partial pivoting by one lane (m <= 3 kMaxSelf)
-      if (lane == 0) {
-        for (int c = 0; c < ns; c++) {
-          const real *rc = this->rec + kSelfRec * c;
-          // active pyramid rows r: directions (1, +-mu, 0), (1, 0, +-mu) in the frame; W = sum D d d^T, q = sum D jar d
-          real Wm[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, qv[3] = {0, 0, 0};
-          for (int r_ = 0; r_ < 4; r_++) {
-            if (!(rc[RC_JAR + r_] < 0)) continue;
-            const real dv[3] = {real(1), r_ < 2 ? (r_ == 0 ? mu : -mu) : real(0), r_ < 2 ? real(0) : (r_ == 2 ? mu : -mu)};
-            for (int i = 0; i < 3; i++) { qv[i] += rc[RC_D] * rc[RC_JAR + r_] * dv[i]; for (int j = 0; j < 3; j++) Wm[i][j] += rc[RC_D] * dv[i] * dv[j]; }
-          }
-          // rows 3c..3c+2 of (I + W G) overwrite G's rows in place (row i of W G only needs rows 3c..3c+2 of G)
-          real g3[3][3 * kMaxSelf];
-          for (int i = 0; i < 3; i++) for (int j = 0; j < m; j++) g3[i][j] = G[(3 * c + i) * m + j];
-          for (int i = 0; i < 3; i++) {
-            real rhs = qv[i];
-            for (int j2 = 0; j2 < 3; j2++) rhs += Wm[i][j2] * uvec[3 * c + j2];
-            lam[3 * c + i] = rhs;
-            for (int j = 0; j < m; j++) {
-              real s_ = (j == 3 * c + i) ? real(1) : real(0);
-              for (int j2 = 0; j2 < 3; j2++) s_ += Wm[i][j2] * g3[j2][j];
-              G[(3 * c + i) * m + j] = s_;
+      // ---- the small dense system, in the space of the pyramid rows (4 per contact, lane = row): with A the active rows
+      // (jar < 0), d_r their frame directions (1, +-mu, 0) / (1, 0, +-mu) and u = E y,
+      //     (D_A^-1 + B_A G B_A^T) nu = jar_A + B_A u ,    lam = B_A^T nu .
+      // Symmetric positive definite (a positive diagonal plus a Gram matrix), so plain elimination without pivoting is stable;
+      // inactive rows are kept as identity rows (nu = 0).  The lane holds its row in registers; the pivot column travels through
+      // LDS once per step (by symmetry it is also the pivot row).
+      {
+        fresh();
+        const int n4 = 4 * ns;
+        real *cbuf = lam;                                    // [<= 4 kMaxSelf] pivot column / solution exchange (lam is written last)
+        real *rbuf = this->ysave;                            // right-hand-side exchange (the re-solve buffers are idle here)
+        real arow[4 * kMaxSelf], rhs = 0, dinv_own = 1;
+        const int ci = lane >> 2, ri = lane & 3;
+        int act_i = 0;
+        real di1 = 0, di2 = 0;                               // d_i = (1, di1, di2)
+        if (lane < n4) {
+          const real *rc = this->rec + kSelfRec * ci;
+          act_i = rc[RC_JAR + ri] < 0;
+          di1 = ri < 2 ? (ri == 0 ? mu : -mu) : real(0); di2 = ri < 2 ? real(0) : (ri == 2 ? mu : -mu);
+          if (act_i) { rhs = rc[RC_JAR + ri] + uvec[3 * ci] + di1 * uvec[3 * ci + 1] + di2 * uvec[3 * ci + 2]; dinv_own = real(1) / rc[RC_D]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4 * kMaxSelf; j++) {
+          real v_ = 0;
+          if (lane < n4 && j < n4) {
+            const int cj = j >> 2, rj = j & 3;
+            const int act_j = this->rec[kSelfRec * cj + RC_JAR + rj] < 0;
+            if (act_i && act_j) {
+              const real dj1 = rj < 2 ? (rj == 0 ? mu : -mu) : real(0), dj2 = rj < 2 ? real(0) : (rj == 2 ? mu : -mu);
+              const real *g = G + (3 * ci) * m + 3 * cj;
+              const real t0 = g[0] + dj1 * g[1] + dj2 * g[2], t1 = g[m] + dj1 * g[m + 1] + dj2 * g[m + 2], t2 = g[2 * m] + dj1 * g[2 * m + 1] + dj2 * g[2 * m + 2];
+              v_ = t0 + di1 * t1 + di2 * t2;
             }
+            if (j == lane) v_ += dinv_own;
+          }
+          arow[j] = v_;
+        }
+#pragma unroll
+        for (int p_ = 0; p_ < 4 * kMaxSelf; p_++) {           // forward elimination
+          if (p_ < n4) {
+            if (lane < n4) { cbuf[lane] = arow[p_]; rbuf[lane] = rhs; }
+            w->sync();
+            if (lane < n4 && lane > p_) {
+              const real f_ = arow[p_] / cbuf[p_];
+#pragma unroll
+              for (int j = 0; j < 4 * kMaxSelf; j++) if (j > p_ && j < n4) arow[j] -= f_ * cbuf[j];
+              rhs -= f_ * rbuf[p_];
+            }
+            w->sync();
           }
         }
-        for (int p_ = 0; p_ < m; p_++) {                      // elimination
-          int piv = p_; real best = SS_M(fabs)(G[p_ * m + p_]);
-          for (int i = p_ + 1; i < m; i++) { const real v_ = SS_M(fabs)(G[i * m + p_]); if (v_ > best) { best = v_; piv = i; } }
-          if (piv != p_) {
-            for (int j = 0; j < m; j++) { const real t_ = G[p_ * m + j]; G[p_ * m + j] = G[piv * m + j]; G[piv * m + j] = t_; }
-            const real t_ = lam[p_]; lam[p_] = lam[piv]; lam[piv] = t_;
-          }
-          const real ip = real(1) / G[p_ * m + p_];
-          for (int i = p_ + 1; i < m; i++) {
-            const real f_ = G[i * m + p_] * ip;
-            if (f_ == 0) continue;
-            for (int j = p_ + 1; j < m; j++) G[i * m + j] -= f_ * G[p_ * m + j];
-            lam[i] -= f_ * lam[p_];
+#pragma unroll
+        for (int p_ = 4 * kMaxSelf - 1; p_ >= 0; p_--) {      // back substitution
+          if (p_ < n4) {
+            if (lane == p_) cbuf[p_] = rhs / arow[p_];
+            w->sync();
+            if (lane < p_) rhs -= arow[p_] * cbuf[p_];
+            w->sync();
           }
         }
-        for (int i = m - 1; i >= 0; i--) {
-          real s_ = lam[i];
-          for (int j = i + 1; j < m; j++) s_ -= G[i * m + j] * lam[j];
-          lam[i] = s_ / G[i * m + i];
+        // cbuf = nu; lam = B^T nu (written after every lane has read its nu's: cbuf aliases lam)
+        real l0 = 0, l1 = 0, l2 = 0;
+        if (lane < ns) {
+          const real n0 = cbuf[4 * lane], n1 = cbuf[4 * lane + 1], n2 = cbuf[4 * lane + 2], n3 = cbuf[4 * lane + 3];
+          l0 = n0 + n1 + n2 + n3; l1 = mu * (n0 - n1); l2 = mu * (n2 - n3);
         }
+        w->sync();
+        if (lane < ns) { lam[3 * lane] = l0; lam[3 * lane + 1] = l1; lam[3 * lane + 2] = l2; }
       }
       w->sync();
       // ---- delta = H_tree^-1 (b_tree - E^T lam): a single-right-hand-side re-solve with the combined bias forces
