@@ -52,7 +52,8 @@ namespace ss {
 
 enum { PF_FWD = 0, PF_CONS, PF_NBEGIN, PF_NPREP, PF_ASM, PF_FACTOR, PF_SOLVE, PF_NFIN, PF_SPDPREP, PF_SPDFIN, PF_INTEG, PF_MISC,
        PF_F_P13, PF_F_SYNC1, PF_F_P2, PF_F_BSOL, PF_F_SYNC2,
-       PF_K_PRO, PF_K_LEV, PF_K_INERTIA, PF_K_SUMS, PF_P_BASE, PF_P_CONTACT, PF_P_SUMS, PF_P_GRAD, PF_COUNT };
+       PF_K_PRO, PF_K_LEV, PF_K_INERTIA, PF_K_SUMS, PF_P_BASE, PF_P_CONTACT, PF_P_SUMS, PF_P_GRAD,
+       PF_SC_NARROW, PF_SC_BASE, PF_SC_COLS, PF_SC_DENSE, PF_SC_FINAL, PF_COUNT };
 #ifdef SS_PROFILE
 #define SS_FT0() unsigned long long ft__ = w->clock()
 #define SS_FTICK(id) do { unsigned long long n__ = w->clock(); prof[id] += n__ - ft__; ft__ = n__; } while (0)
@@ -683,6 +684,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
   SS_DEV void make_self_contacts(bool write_count) {
     if constexpr (SELFCOL) {
       fresh();
+      SS_FT0();
       typename HT::type h = HT::view(k->h);
       const int npair = k->sc.npair;
       real *cand = this->G;                                  // candidates [kSelfCand][10]: pos3 n3 dist id b1 b2 (the Delassus block is not live yet)
@@ -804,6 +806,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       }
       w->sync();                                             // candidates consumed (the records may not overlap them, but keep it simple)
       if (slot >= 0) for (int i = 0; i < kSelfRec; i++) this->rec[kSelfRec * slot + i] = rcd[i];
+      SS_FTICK(PF_SC_NARROW);
       if (write_count && lane == 0 && k->st.self_contacts) k->st.self_contacts[env] = nk;
       if (write_count && k->dbg_self && slot >= 0)           // diagnostics: positions made absolute
         for (int i = 0; i < kSelfRec; i++) k->dbg_self[((size_t)env * kMaxSelf + slot) * kSelfRec + i] = rcd[i] + (i >= RC_POS && i < RC_POS + 3 ? q[i - RC_POS] : real(0));
@@ -863,9 +866,15 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       const int ns = this->nself, m = 3 * ns;
       const real mu = h.mu;
       real *G = this->G, *uvec = this->uvec, *lam = this->lam, *Pb2 = this->Pb2, *d2 = this->delta2;
+      {                                                      // no active body-body row (contacts inside the margin but separating):
+        int act = 0;                                         // the Hessian is the tree's
+        if (lane < ns) { const real *rc = this->rec + kSelfRec * lane; act = rc[RC_JAR] < 0 || rc[RC_JAR + 1] < 0 || rc[RC_JAR + 2] < 0 || rc[RC_JAR + 3] < 0; }
+        if (!w->any(act)) { aba_solve(delta, Pb); return; }
+      }
       // ---- y = H_tree^-1 b_tree (b_tree: joint-space right-hand side in delta, tree per-body forces in Pb): the one full solve
       // of this Newton iteration — everything below re-uses its factorization (aba_resolve)
       fresh();
+      SS_FT0();
       for (int i = lane; i < h.nv; i += 64) d2[i] = delta[i];
       w->sync();
       aba_solve(delta, Pb);
@@ -875,6 +884,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
         uvec[3 * lane] = an; uvec[3 * lane + 1] = at1; uvec[3 * lane + 2] = at2;
       }
       w->sync();
+      SS_FTICK(PF_SC_BASE);
       // ---- columns of G = E H_tree^-1 E^T: per contact, the responses to a unit relative force along its normal and two
       // tangents in one 3-right-hand-side sweep (H x = - sum_b J_b^T pb with pb = -wrench on body 2, +wrench on body 1)
       for (int cc = 0; cc < ns; cc++) {
@@ -895,6 +905,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
         }
         w->sync();
       }
+      SS_FTICK(PF_SC_COLS);
       // ---- the small dense system, in the space of the pyramid rows (4 per contact, lane = row): with A the active rows
       // (jar < 0), d_r their frame directions (1, +-mu, 0) / (1, 0, +-mu) and u = E y,
       //     (D_A^-1 + B_A G B_A^T) nu = jar_A + B_A u ,    lam = B_A^T nu .
@@ -965,6 +976,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
         if (lane < ns) { lam[3 * lane] = l0; lam[3 * lane + 1] = l1; lam[3 * lane + 2] = l2; }
       }
       w->sync();
+      SS_FTICK(PF_SC_DENSE);
       // ---- delta = H_tree^-1 (b_tree - E^T lam): a single-right-hand-side re-solve with the combined bias forces
       fresh();
       for (int i = lane; i < 6 * h.nb; i += 64) Pb2[i] = Pb[i];
@@ -977,6 +989,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
         }
       w->sync();
       aba_resolve<1>([&](int dof, int) { return d2[dof]; }, [&](int b, int row, int) { return Pb2[6 * b + row]; }, An, delta);
+      SS_FTICK(PF_SC_FINAL);
     }
   }
 

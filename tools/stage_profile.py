@@ -13,25 +13,28 @@ import torch
 
 from smplsim_amd import _cabi, _lib
 
-prof_so = os.path.join(ROOT, "gpurun_out", "libsmplsim_hip_prof.so")
-os.makedirs(os.path.dirname(prof_so), exist_ok=True)
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", *_lib.DEFAULT_OPT.split(), "-std=c++17", "-shared", "-fPIC", "-DSS_PROFILE", *os.environ.get("SS_EXTRA", "").split(),
+prof_so = os.environ.get("SS_PROF_LIB") or os.path.join(ROOT, "gpurun_out", "libsmplsim_hip_prof.so")
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+if not os.environ.get("SS_PROF_LIB"):                        # or a prebuilt -DSS_PROFILE variant (tools/build_variant.sh prof -DSS_PROFILE)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", *_lib.DEFAULT_OPT.split(), "-std=c++17", "-shared", "-fPIC", "-DSS_PROFILE", *os.environ.get("SS_EXTRA", "").split(),
                        os.path.join(_lib.SRC_DIR, "smplsim_hip.hip"), "-o", prof_so])
 _lib._LIB = _cabi.bind(C.CDLL(prof_so))
 from smplsim_amd.batch import SMPLSimVecEnv
 
 N, steps = int(os.environ.get("NENV", "4096")), int(os.environ.get("STEPS", "30"))
-env = SMPLSimVecEnv(N, autoreset=True, seed=1234)
+SELF = bool(int(os.environ.get("SELFCOL", "0")))
+env = SMPLSimVecEnv(N, autoreset=True, seed=1234, self_collision=SELF)
 g = torch.Generator(device=env.device); g.manual_seed(1234)
 env.reset()
 for _ in range(steps):
     env.step(torch.rand(N, 69, generator=g, device=env.device) * 2 - 1)
 torch.cuda.synchronize()
 out = (C.c_ulonglong * 64)()
-rc = _lib.lib().ss_debug_prof(env.handle, out, 32)
+rc = _lib.lib().ss_debug_prof(env.handle, out, 40)
 names = ["fwd_kin", "constraints", "newton_begin", "newton_prepare", "(unused)", "aba_solve", "(unused)", "newton_finish",
          "spd_prepare", "spd_finish", "integrate", "misc", "aba:up_phase1", "aba:up_last_sync", "aba:up_phase2", "aba:down", "(unused)",
-         "fk:prologue", "fk:level_sweep", "fk:inertia_bias", "fk:subtree_C", "prep:base", "prep:contactK", "prep:subtree", "prep:grad"]
+         "fk:prologue", "fk:level_sweep", "fk:inertia_bias", "fk:subtree_C", "prep:base", "prep:contactK", "prep:subtree", "prep:grad",
+         "selfcol:pair functions", "selfcol:factor+base solve", "selfcol:Delassus columns", "selfcol:dense solve", "selfcol:final re-solve"]
 tot = sum(out[i] for i in range(12))
 iters = float(env.solver_iters.float().mean().item())
 res = {"rc": rc, "total_ticks": tot, "mean_newton_iters": iters, "stages": {}}
