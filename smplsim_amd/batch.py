@@ -7,6 +7,7 @@ wxyz / qpos / qvel packing.  PyTorch is only the owner of device
 streams here; all arithmetic happens in libsmplsim_hip.so.
 """
 import ctypes as C
+import warnings
 
 import numpy as np
 import torch
@@ -38,6 +39,20 @@ def _shard_device(index):
 
 def _launch_stream(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+_WARNED = False
+
+
+def _warn_floor_only():
+    """Once per process: the default of the batched env is the floor-contact path of BASELINE.json's north_star; the reference's
+    MuJoCo model also collides the humanoid's bodies with each other."""
+    global _WARNED
+    if not _WARNED:
+        _WARNED = True
+        warnings.warn("SMPLSimVecEnv(self_collision=False): floor contacts and joint limits only — bodies of the humanoid pass through "
+                      "each other, unlike mj_step on the reference MJCF (contype/conaffinity, smpl_humanoid.xml:5,24). Pass "
+                      "self_collision=True for the reference's contact set (about 3x the step time under violent actions).", stacklevel=3)
 
 
 class ShardModel:
@@ -103,6 +118,8 @@ class SMPLSimVecEnv:
             recovery_steps=recovery_steps, newton_iters=newton_iters, tar_dist_max=tar_dist_max,
             reach_body=self._body_index(mc, reach_body), self_collision=self_collision)
         self.self_collision = bool(self_collision)
+        if not self.self_collision:
+            _warn_floor_only()
         N, dev = self.num_envs, self.device
         f32 = dict(dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)

@@ -76,6 +76,9 @@ class HumanoidEnv:
             print("SMPL files found, but SMPL_Robot generation is not part of this package; using the mean neutral body")
         self.default_xml_str = default_xml_str("smpl_humanoid" if self.humanoid_type == "smpl" else "smplx_humanoid")
         self.contact_bodies = list(e.contact_bodies)
+        # body-body contacts: on like in the reference's MuJoCo model (smpl_humanoid.xml:5,24,231-242) unless the cfg says otherwise
+        # (`env.self_collision: False` = floor contacts and joint limits only, the faster path; not a key of the reference's yaml)
+        self.self_collision = bool(e.get("self_collision", True) if hasattr(e, "get") else getattr(e, "self_collision", True))
         kw = self._task_kwargs(e)
         self._model = ShardModel(xml=self.default_xml_str, device=device, contact_bodies=self.contact_bodies,
                                  control_mode=self.control_mode, clip_actions=self.clip_actions,
@@ -84,7 +87,7 @@ class HumanoidEnv:
                                   self_obs_v=self.self_obs_v, control_mode=self.control_mode,
                                   episode_length=self.max_episode_length, control_freq_inv=self.control_freq_inv,
                                   root_height_obs=self._root_height_obs, power_scale=float(self.power_scale),
-                                  autoreset=False, **kw)
+                                  autoreset=False, self_collision=self.self_collision, **kw)
         mc = self._model.mc
         self.mj_body_names = ["world"] + list(mc.body_names)
         self.body_names_orig = list(mc.body_names)

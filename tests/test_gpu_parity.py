@@ -487,7 +487,8 @@ def test_gym_style_single_env_matches_oracle():
     import smpl_sim.envs.tasks as tasks                       # the reference's import path
     from smplsim_amd.config import default_cfg
     env = tasks.HumanoidEnv(default_cfg("HumanoidEnv"))
-    oenv = O.OracleEnv(oracle_model())
+    assert env.self_collision                                  # body-body contacts on, like the reference's MuJoCo model
+    oenv = O.OracleEnv(oracle_model(self_collision=True, max_self_contacts=8))
     obs, info = env.reset(seed=54)
     assert obs.dtype == np.float32 and obs.shape == (289,) and info["critic_state"] is obs
     assert env.observation_space.shape == (289,) and env.action_space.shape == (69,) and env.actuator_names[0] == "L_Hip_x"
