@@ -59,15 +59,21 @@ class ShardModel:
     """Compiled model + device tables (ss_model) for one device."""
 
     def __init__(self, xml=None, humanoid="smpl_humanoid", device=0, contact_bodies=DEFAULT_CONTACT_BODIES,
-                 control_mode="uhc_pd", clip_actions=True, pdp_scale=1.0, pdd_scale=1.0, sim_timestep_inv=450, tables=None, xmls=None):
+                 control_mode="uhc_pd", clip_actions=True, pdp_scale=1.0, pdd_scale=1.0, sim_timestep_inv=450, tables=None, xmls=None, mcs=None):
         """tables: optional (kp, kd, torque_lim, act_scale, act_offset) per actuator for models whose bodies are not in
         the reference's gain table (humanoid_env.py:62-84).
         xmls: a list of MJCF strings = body shapes of the same humanoid (cfg.robot.has_shape_variation): one model whose
-        geometry tables have an entry per shape; the envs pick theirs through SMPLSimVecEnv(shape_id=...)."""
-        self.xmls = list(xmls) if xmls is not None else [xml if xml is not None else default_xml_str(humanoid)]
-        self.xml = self.xmls[0]
-        self.mcs = [compile_mjcf(x) for x in self.xmls]
-        self.mc, self.num_shapes = self.mcs[0], len(self.xmls)
+        geometry tables have an entry per shape; the envs pick theirs through SMPLSimVecEnv(shape_id=...).
+        mcs: the same as already compiled ModelConsts (smplsim_amd.robot.compile_tables / models_from_mesh: body shapes built from
+        SMPL meshes by the reference's geometry rules, thousands per vectorised pass)."""
+        if mcs is not None:
+            self.mcs, self.xmls = list(mcs), []
+            self.xml = None
+        else:
+            self.xmls = list(xmls) if xmls is not None else [xml if xml is not None else default_xml_str(humanoid)]
+            self.xml = self.xmls[0]
+            self.mcs = [compile_mjcf(x) for x in self.xmls]
+        self.mc, self.num_shapes = self.mcs[0], len(self.mcs)
         rng = {n: self.mc.jnt_range[6 + i] for i, n in enumerate(self.mc.joint_names)}
         self.tables = tables if tables is not None else build_pd_tables(
             self.mc.actuator_names, lambda n: rng[n], clip_actions=clip_actions, control_mode=control_mode,

@@ -46,7 +46,11 @@ class HumanoidEnv:
     metadata = {"render_modes": ["human", "rgb_array"], "render_fps": 30}
     _TASK = "HumanoidEnv"
 
-    def __init__(self, cfg, device=0, num_envs=1):
+    def __init__(self, cfg, device=0, num_envs=1, bodies=None):
+        """bodies (cfg.robot.has_shape_variation): one posed body per env — a dict with `verts` [S, V, 3], `joints` [S, J, 3],
+        `skin_weights` [V, J], `joint_names`, `parents` (and optionally `joint_range`), i.e. what the reference's SMPL parser
+        hands to SMPL_Robot for a betas draw (smpl_local_robot.py:1345-1368); S = 1 or num_envs.  The SMPL model files that turn
+        betas into these arrays are licensed and stay with the caller; the geometry rules that follow them are in ..robot."""
         self.cfg = cfg
         e, r = cfg.env, cfg.robot
         self.clip_actions = e.clip_actions
@@ -69,20 +73,42 @@ class HumanoidEnv:
             raise NotImplementedError(f"control_mode {self.control_mode!r} is not supported by the HIP stepper")
         if self.self_obs_v == 2 and not r.create_vel_sensors:
             raise AssertionError("self_obs_v=2 needs robot.create_vel_sensors (reference humanoid_env.py:297)")
-        if r.has_shape_variation:
-            raise NotImplementedError("shape variation needs the licensed SMPL files (SURVEY.md §8f-3)")
+        self.has_shape_variation = bool(r.has_shape_variation)
+        if self.has_shape_variation and bodies is None:
+            raise ValueError("robot.has_shape_variation: pass bodies=dict(verts, joints, skin_weights, joint_names, parents) — the posed "
+                             "SMPL mesh of every env's betas draw; this package holds the reference's geometry rules (smplsim_amd.robot), "
+                             "not the licensed SMPL model files that produce the mesh")
         smpl_dir = r.get("smpl_data_dir", "data/smpl") if hasattr(r, "get") else "data/smpl"
-        if os.path.exists(smpl_dir):
-            print("SMPL files found, but SMPL_Robot generation is not part of this package; using the mean neutral body")
+        if os.path.exists(smpl_dir) and bodies is None:
+            print("SMPL files found, but the SMPL parser is not part of this package; using the mean neutral body (pass bodies=...)")
         self.default_xml_str = default_xml_str("smpl_humanoid" if self.humanoid_type == "smpl" else "smplx_humanoid")
+        shape_mcs = None
+        if bodies is not None:
+            from .. import robot as _robot
+            from ..mjcf_writer import table_to_mjcf
+            g = (lambda k, d=None: r.get(k, d)) if hasattr(r, "get") else (lambda k, d=None: getattr(r, k, d))
+            flags = dict(smpl_model=self.humanoid_type, upright_start=bool(g("has_upright_start", False)), remove_toe=bool(g("remove_toe", False)),
+                         big_ankle=bool(g("big_ankle", True)), box_body=bool(g("box_body", True)), freeze_hand=bool(g("freeze_hand", False)),
+                         real_weight=bool(g("real_weight", True)), real_weight_porpotion_capsules=bool(g("real_weight_porpotion_capsules", True)),
+                         real_weight_porpotion_boxes=bool(g("real_weight_porpotion_boxes", True)), create_vel_sensors=bool(r.create_vel_sensors))
+            shape_mcs = _robot.models_from_mesh(bodies["verts"], bodies["joints"], bodies["skin_weights"], bodies["joint_names"],
+                                                bodies["parents"], joint_range=bodies.get("joint_range"), **flags)
+            if len(shape_mcs) not in (1, num_envs):
+                raise ValueError("bodies must hold one shape, or one per env")
         self.contact_bodies = list(e.contact_bodies)
         # body-body contacts: on like in the reference's MuJoCo model (smpl_humanoid.xml:5,24,231-242) unless the cfg says otherwise
         # (`env.self_collision: False` = floor contacts and joint limits only, the faster path; not a key of the reference's yaml)
         self.self_collision = bool(e.get("self_collision", True) if hasattr(e, "get") else getattr(e, "self_collision", True))
         kw = self._task_kwargs(e)
-        self._model = ShardModel(xml=self.default_xml_str, device=device, contact_bodies=self.contact_bodies,
+        self._model = ShardModel(xml=self.default_xml_str, mcs=shape_mcs, device=device, contact_bodies=self.contact_bodies,
                                  control_mode=self.control_mode, clip_actions=self.clip_actions,
                                  pdp_scale=e.pdp_scale, pdd_scale=e.pdd_scale, sim_timestep_inv=self.sim_timestep_inv)
+        if shape_mcs is not None and len(shape_mcs) > 1:
+            kw["shape_id"] = list(range(num_envs))
+            if self.self_collision:                          # the pair functions read one geom table per model so far
+                import warnings
+                warnings.warn("per-env body shapes run with floor contacts only (self_collision is not combined with shape tables yet)")
+                self.self_collision = False
         self._vec = SMPLSimVecEnv(num_envs, model=self._model, task=self._TASK, state_init=e.state_init,
                                   self_obs_v=self.self_obs_v, control_mode=self.control_mode,
                                   episode_length=self.max_episode_length, control_freq_inv=self.control_freq_inv,
@@ -228,11 +254,11 @@ class SMPLSimGymVecEnv:
     `gym.vector` env (`num_envs`, `action_space.sample()`, `reset(seed=)`, `step(actions=)`), backed by one
     HIP launch for all envs instead of one OS process per env (reference benchmark.py:78-81)."""
 
-    def __init__(self, cfg, num_envs, device=0, autoreset=True):
+    def __init__(self, cfg, num_envs, device=0, autoreset=True, bodies=None):
         import torch
         cls = {"HumanoidEnv": HumanoidEnv, "HumanoidSpeed": HumanoidSpeed, "HumanoidGetup": HumanoidGetup,
                "HumanoidReach": HumanoidReach}[cfg.env.task]
-        self._single = cls(cfg, device=device, num_envs=num_envs)
+        self._single = cls(cfg, device=device, num_envs=num_envs, bodies=bodies)   # bodies: see HumanoidEnv (has_shape_variation)
         self._vec = self._single._vec
         self._vec.autoreset = autoreset
         self.num_envs = num_envs

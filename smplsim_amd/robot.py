@@ -1,0 +1,273 @@
+"""Body shape -> humanoid model: the geometry rules of the reference's SMPL_Robot / Skeleton, restated.
+
+The reference builds one MJCF per body shape: `SMPL_Robot.load_from_skeleton` (smpl_sim/smpllib/smpl_local_robot.py:1280-1505)
+poses the SMPL mesh at zero pose for a betas draw, assigns every vertex to the joint with the largest skinning weight and
+takes the convex hull of each joint's vertices (`get_geom_dict`, :146-173); `Skeleton.write_xml_bodynode`
+(smpl_sim/smpllib/skeleton_local.py:460-684) then turns (joint offsets, hull volume, hull bounding box) into one capsule or
+box per body with the density rules below, and `HumanoidEnv` loads that MJCF (humanoid_env.py:205,304-305).
+
+The SMPL model files are licensed and not part of this package (nor of the reference): this module starts where they end —
+at `(vertices, joints, skinning weights)` of a posed mesh, or directly at per-body vertex sets — and produces the body
+table that `mjcf_writer.table_to_mjcf` / `compile_tables` turn into `ModelConst`s for `ShardModel(models=...)`: thousands of
+shapes compile in one vectorised pass (the inverse weights need one 75 x 75 inverse per shape) instead of one MJCF parse each.
+
+Rules (flag names are the reference's; defaults = smpl_sim/data/cfg/robot/smpl_humanoid.yaml, which made the packaged fixture):
+  bone end        mean of the children's offsets; leaves: own offset + 0.002                       (skeleton_local.py:387-391)
+  capsule         from 20 % to 80 % of the bone end (45 % / 55 % for Torso, Spine, Chest); radius = the positive real root of
+                  4/3 pi r^3 + pi L r^2 = hull volume, shrunk x0.7 (Torso, Spine, Chest, L/R_Hip) or x0.9 (L/R_Knee) with the
+                  density raised by 1 / shrink^2 (real_weight_porpotion_capsules)                     (:560-596)
+  box (big_ankle) centre and half sizes of the hull's bounding box; toes are moved to their parent's sole height and sideways
+                  position; Pelvis / 1.75, Head / 1.5 in x and z (y-up), SMPL-X wrists shrunk; density = hull volume / box
+                  volume x base (real_weight_porpotion_boxes)                                       (:598-668)
+  geom types      boxes: ankles, toes; with box_body: Pelvis, Head; hands unless freeze_hand; SMPL-X wrists; all else capsules
+  base density    1000 (real_weight) or 500; capsules contype 1 / conaffinity 1, boxes the template default (7 / 1)
+"""
+import math
+
+import numpy as np
+
+from .mjcf import GEOM_BOX, GEOM_CAPSULE, ModelConst, geom_mass_inertia, z_to_quat
+
+EXCLUDES = (("Torso", "Chest"), ("Head", "Chest"), ("R_Knee", "R_Toe"), ("R_Knee", "L_Ankle"), ("R_Knee", "L_Toe"), ("L_Knee", "L_Toe"),
+            ("L_Knee", "R_Ankle"), ("L_Knee", "R_Toe"), ("L_Shoulder", "Chest"), ("R_Shoulder", "Chest"))   # smpl_local_robot.py:1459-1470
+
+
+def geom_type(name, smpl_model="smpl", box_body=True, freeze_hand=False):
+    """GEOM_TYPES of skeleton_local.py:19-74 after the flag overrides of :537-547, as a rule."""
+    if name in ("L_Ankle", "R_Ankle", "L_Toe", "R_Toe"):
+        return "box"
+    if name in ("Pelvis", "Head"):
+        return "box" if box_body else "sphere"
+    if name in ("L_Hand", "R_Hand"):
+        return "sphere" if freeze_hand else "box"
+    if smpl_model == "smplx" and name in ("L_Wrist", "R_Wrist"):
+        return "box"
+    return "capsule"
+
+
+def body_hulls(verts, joints, skin_weights, joint_names, scale_dict=None):
+    """Per-body vertex sets and hull volumes of a posed mesh (`get_geom_dict`, smpl_local_robot.py:146-173): every vertex
+    belongs to the joint with its largest skinning weight; vertices are expressed relative to that joint."""
+    from scipy.spatial import ConvexHull
+    verts, joints = np.asarray(verts, np.float64), np.asarray(joints, np.float64)
+    owner = np.asarray(skin_weights).argmax(axis=1)
+    out = {}
+    for j, name in enumerate(joint_names):
+        idx = np.nonzero(owner == j)[0]
+        if len(idx) == 0:
+            continue
+        nv = (verts[idx] - joints[j]) * (scale_dict or {}).get(name, 1)
+        out[name] = {"norm_verts": nv, "volume": float(ConvexHull(nv).volume)}
+    return out
+
+
+def hulls_from_vertex_sets(vertex_sets):
+    """{body: vertices relative to its joint [n, 3]} -> hull dict (volume from the convex hull)."""
+    from scipy.spatial import ConvexHull
+    return {k: {"norm_verts": np.asarray(v, np.float64), "volume": float(ConvexHull(np.asarray(v, np.float64)).volume)} for k, v in vertex_sets.items()}
+
+
+def capsule_radius(volume, length):
+    """Positive real root of 4/3 pi r^3 + pi L r^2 - V = 0 (skeleton_local.py:566-569)."""
+    roots = np.polynomial.polynomial.Polynomial([-volume, 0.0, length * math.pi, 4.0 / 3.0 * math.pi]).roots()
+    real = roots.real[np.abs(roots.imag) < 1e-5]
+    real = real[real > 0]
+    return float(real[0])
+
+
+def skeleton_table(joint_names, parents, offsets, hulls, joint_range=None, smpl_model="smpl", upright_start=False, remove_toe=False,
+                   big_ankle=True, box_body=True, freeze_hand=False, real_weight=True, real_weight_porpotion_capsules=True,
+                   real_weight_porpotion_boxes=True, create_vel_sensors=False, root_offset=(0.0, 0.0, 0.0), decimals=4):
+    """(joint tree, hulls) -> body table in the format of smplsim_amd/data/*.json (what `Skeleton.construct_tree` writes as MJCF).
+
+    joint_names [J] in depth-first order (root first), parents {name: parent name} or [J] indices, offsets {name: xyz} or [J, 3]
+    (each joint relative to its parent; the root's is its world position), hulls {name: {"norm_verts", "volume"}},
+    joint_range {name: [3, 2] radians} or None (= +-180 degrees like the packaged fixture).  `decimals`: the reference prints
+    4 decimals into the XML (`"{0:.4f}"`); None keeps full precision."""
+    if not big_ankle or remove_toe:
+        raise NotImplementedError("only the big_ankle=True, remove_toe=False geometry of the reference's robot cfgs is restated")
+    names = list(joint_names)
+    par = [parents[n] for n in names] if isinstance(parents, dict) else [None if p < 0 else names[p] for p in parents]
+    off = {n: np.asarray(offsets[n] if isinstance(offsets, dict) else offsets[i], np.float64) for i, n in enumerate(names)}
+    rnd = (lambda x: np.round(np.asarray(x, np.float64), decimals)) if decimals is not None else (lambda x: np.asarray(x, np.float64))
+    children = {n: [c for c, p in zip(names, par) if p == n] for n in names}
+    end = {n: (np.mean([off[c] for c in children[n]], axis=0) if children[n] else off[n] + 0.002) for n in names}
+    base = 1000.0 if real_weight else 500.0
+    bodies, aabb = [], {}
+    for n, p in zip(names, par):
+        is_root = p is None
+        pos = off[n] + (np.asarray(root_offset, np.float64) if is_root else 0.0)
+        body = {"name": n, "parent": p, "pos": rnd(pos).tolist(), "freejoint": is_root, "joints": [], "geoms": []}
+        if not is_root:
+            for i, ax in enumerate("xyz"):
+                rng = [-180.0, 180.0] if joint_range is None else np.rad2deg(np.asarray(joint_range[n])[i]).tolist()
+                axis = [0.0, 0.0, 0.0]; axis[i] = 1.0
+                body["joints"].append({"name": f"{n}_{ax}", "axis": axis, "range": rnd(rng).tolist(), "armature": "0.01", "damping": "0",
+                                       "stiffness": "0", "type": "hinge", "pos": "0 0 0"})
+        gt = geom_type(n, smpl_model, box_body, freeze_hand)
+        hp = hulls[n]
+        sep = 0.45 if n in ("Torso", "Chest", "Spine") else 0.2
+        e2 = end[n] + (np.asarray(root_offset, np.float64) if is_root else 0.0)
+        e1 = e2 * sep
+        e2 = e2 - e2 * sep
+        if gt == "capsule":
+            r = capsule_radius(hp["volume"], float(np.linalg.norm(e2 - e1)))
+            dens = base
+            shrink = 0.7 if n in ("Torso", "Spine", "Chest", "L_Hip", "R_Hip") else (0.9 if n in ("L_Knee", "R_Knee") else 1.0)
+            r *= shrink
+            if shrink != 1.0 and real_weight_porpotion_capsules:
+                dens = base / shrink ** 2
+            body["geoms"].append({"name": n, "type": "capsule", "size": [float(rnd(r))], "fromto": rnd(np.concatenate([e1, e2])).tolist(),
+                                  "density": f"{dens:.6f}".rstrip("0").rstrip("."), "contype": "1", "conaffinity": "1"})
+        elif gt == "box":
+            nv = np.asarray(hp["norm_verts"], np.float64)
+            lo, hi = nv.min(axis=0), nv.max(axis=0)
+            size, gpos = (hi - lo) / 2, (hi + lo) / 2
+            aabb[n] = (lo, hi)
+            if n in ("L_Toe", "R_Toe"):                       # sole at the parent's sole, sideways at the parent's centre
+                plo, phi = aabb[p]
+                up, side = (2, 1) if upright_start else (1, 0)
+                gpos[up] = plo[up] - off[n][up] + size[up]
+                gpos[side] = (plo[side] + phi[side]) / 2 - off[n][side]
+            if n == "Pelvis":
+                size = size / 1.75
+            if n == "Head":
+                size[0] /= 1.5; size[1 if upright_start else 2] /= 1.5
+            if smpl_model == "smplx" and n in ("L_Wrist", "R_Wrist"):
+                size[0] /= 1.15
+                if upright_start:
+                    size[1] /= 1.3; size[2] /= 1.7
+                else:
+                    size[1] /= 1.3 * 1.7
+            g = {"name": n, "type": "box", "pos": rnd(gpos).tolist(), "size": rnd(size).tolist(), "quat": [1.0, 0.0, 0.0, 0.0]}
+            if real_weight_porpotion_boxes:
+                g["density"] = f"{hp['volume'] / float(size[0] * size[1] * size[2] * 8) * base:.6f}"
+            body["geoms"].append(g)
+        else:
+            raise NotImplementedError(f"{n}: sphere geoms (box_body=False / freeze_hand) are not supported by the stepper")
+        bodies.append(body)
+    motors = [{"name": j["name"], "joint": j["name"], "gear": "1"} for b in bodies for j in b["joints"]]
+    return {"model": "humanoid", "default_joint": {"damping": "0.0", "armature": "0.01", "stiffness": "0.0", "limited": "true"},
+            "default_geom": {"conaffinity": "1", "condim": "3", "contype": "7", "margin": "0.001"},
+            "floor": {"name": "floor", "pos": [0.0, 0.0, 0.0], "size": [100.0, 100.0, 0.2], "conaffinity": "1", "condim": "3"},
+            "bodies": bodies, "excludes": [list(e) for e in EXCLUDES if e[0] in names and e[1] in names], "vel_sensors": bool(create_vel_sensors),
+            "motors": motors}
+
+
+def hulls_of_table(table):
+    """Inverse of the geometry rules for a table made by them (e.g. the packaged fixtures): the hull volume and bounding box per
+    body that reproduce its geoms.  Used to re-derive a model after changing the joints only, and by the round-trip test."""
+    names = [b["name"] for b in table["bodies"]]
+    byname = {b["name"]: b for b in table["bodies"]}
+    out = {}
+    for b in table["bodies"]:
+        n, g = b["name"], b["geoms"][0]
+        dens = float(g.get("density", 1000))
+        if g["type"] == "capsule":
+            ft = np.asarray(g["fromto"], np.float64)
+            L, r = float(np.linalg.norm(ft[3:] - ft[:3])), float(g["size"][0])
+            shrink = 0.7 if n in ("Torso", "Spine", "Chest", "L_Hip", "R_Hip") else (0.9 if n in ("L_Knee", "R_Knee") else 1.0)
+            r0 = r / shrink
+            out[n] = {"volume": 4.0 / 3.0 * math.pi * r0 ** 3 + math.pi * L * r0 ** 2, "norm_verts": None}
+        else:
+            size, gpos = np.asarray(g["size"], np.float64).copy(), np.asarray(g["pos"], np.float64).copy()
+            vol = dens / 1000.0 * float(size.prod() * 8)
+            if n == "Pelvis":
+                size = size * 1.75
+            if n == "Head":
+                size[0] *= 1.5; size[2] *= 1.5
+            if n in ("L_Toe", "R_Toe"):                       # undo the sole / sideways alignment: keep the box where the rules put it
+                pg = byname[b["parent"]]["geoms"][0]
+                plo = np.asarray(pg["pos"]) - np.asarray(pg["size"])
+                pc = np.asarray(pg["pos"])
+                off = np.asarray(b["pos"], np.float64)
+                # the rule overwrites pos[1] and pos[0]; any hull whose bounding box has this size and whose z centre is gpos[2] works
+                gpos = np.array([pc[0] - off[0], plo[1] - off[1] + size[1], gpos[2]])
+            lo, hi = gpos - size, gpos + size
+            corners = np.array([[(lo, hi)[(c >> k) & 1][k] for k in range(3)] for c in range(8)])
+            out[n] = {"volume": vol, "norm_verts": corners}
+    return out
+
+
+# ---------------------------------------------------------------- vectorised compile of many shapes of one skeleton
+def compile_tables(tables):
+    """[body table] -> [ModelConst] without an MJCF round trip; the joint-space inverse at qpos0 (body / dof inverse weights) is
+    one batched numpy inverse for all shapes.  Same numbers as compile_mjcf(table_to_mjcf(t)) (tests/test_robot.py)."""
+    from .mjcf import body_com_jacobians_qpos0, quat_to_mat
+    mcs = []
+    for t in tables:
+        names = [b["name"] for b in t["bodies"]]
+        nb = len(names)
+        nv = 6 + 3 * (nb - 1)
+        parent = np.array([-1 if b["parent"] is None else names.index(b["parent"]) for b in t["bodies"]], np.int32)
+        if any(parent[i] >= i for i in range(1, nb)):
+            raise ValueError("bodies must be listed parents first")
+        dj, dg = t["default_joint"], t["default_geom"]
+        gtype, gsize, gpos, gquat, mass, inertia, ct, ca = [], [], [], [], [], [], [], []
+        arm, rng, lim, jn = [0.0] * 6, [[-np.inf, np.inf]] * 6, [False] * 6, []
+        for b in t["bodies"]:
+            g = {**dg, **b["geoms"][0]}
+            if g["type"] == "box":
+                ty, size, p, q = GEOM_BOX, np.asarray(g["size"], np.float64), np.asarray(g["pos"], np.float64), np.asarray(g.get("quat", [1, 0, 0, 0]), np.float64)
+                q = q / np.linalg.norm(q)
+            else:
+                ft = np.asarray(g["fromto"], np.float64)
+                vec = ft[3:] - ft[:3]
+                ty, size, p, q = GEOM_CAPSULE, np.array([float(g["size"][0]), 0.5 * np.linalg.norm(vec), 0.0]), 0.5 * (ft[:3] + ft[3:]), z_to_quat(vec)
+            m, inert = geom_mass_inertia(ty, size, float(g.get("density", 1000)))
+            gtype.append(ty); gsize.append(size); gpos.append(p); gquat.append(q); mass.append(m); inertia.append(inert)
+            ct.append(int(g.get("contype", 1))); ca.append(int(g.get("conaffinity", 1)))
+            for j in b["joints"]:
+                a = {**dj, **{k: v for k, v in j.items() if k in ("armature", "limited")}}
+                arm.append(float(a.get("armature", 0)))
+                r = j.get("range")
+                limited = a.get("limited", "auto")
+                lim.append(limited == "true" or (limited == "auto" and r is not None))
+                rng.append(list(np.deg2rad(r)) if r is not None else [0.0, 0.0])
+                jn.append(j["name"])
+        anames = [m_["name"] for m_ in t["motors"]]
+        qpos0 = np.zeros(nv + 1); qpos0[:3] = t["bodies"][0]["pos"]; qpos0[3] = 1.0
+        mcs.append(ModelConst(
+            nbody=nb, nq=nv + 1, nv=nv, nu=len(anames), body_names=names, body_parent=parent,
+            body_pos=np.array([b["pos"] for b in t["bodies"]], np.float64), body_mass=np.array(mass), body_ipos=np.array(gpos),
+            body_iquat=np.array(gquat), body_inertia=np.array(inertia), geom_type=np.array(gtype, np.int32), geom_size=np.array(gsize),
+            geom_pos=np.array(gpos), geom_quat=np.array(gquat), geom_names=list(names), dof_armature=np.array(arm), jnt_range=np.array(rng),
+            jnt_limited=np.array(lim), joint_names=jn, actuator_names=anames,
+            actuator_dof=np.array([6 + jn.index(m_["joint"]) for m_ in t["motors"]], np.int32), actuator_gear=np.ones(len(anames)),
+            body_invweight0=np.zeros((nb, 2)), dof_invweight0=np.zeros(nv), qpos0=qpos0, excludes=[tuple(e) for e in t["excludes"]],
+            has_vel_sensors=bool(t.get("vel_sensors", False)), geom_margin=float(dg.get("margin", 0)), friction=1.0,
+            geom_contype=np.array(ct, np.int32), geom_conaffinity=np.array(ca, np.int32)))
+    # inverse weights at qpos0, all shapes at once: M = sum_b m Jp^T Jp + Jr^T Iw Jr + armature
+    B = len(mcs)
+    if B == 0:
+        return mcs
+    nb, nv = mcs[0].nbody, mcs[0].nv
+    J = np.stack([body_com_jacobians_qpos0(mc)[0] for mc in mcs])                     # [B, nb, 6, nv]
+    Rm = np.stack([[quat_to_mat(q) for q in mc.body_iquat] for mc in mcs])            # [B, nb, 3, 3]
+    Iw = np.einsum("sbij,sbj,sbkj->sbik", Rm, np.stack([mc.body_inertia for mc in mcs]), Rm)
+    m = np.stack([mc.body_mass for mc in mcs])
+    M = np.einsum("sb,sbki,sbkj->sij", m, J[:, :, 0:3], J[:, :, 0:3]) + np.einsum("sbki,sbkl,sblj->sij", J[:, :, 3:6], Iw, J[:, :, 3:6])
+    M[:, np.arange(nv), np.arange(nv)] += np.stack([mc.dof_armature for mc in mcs])
+    Minv = np.linalg.inv(M)
+    A = np.einsum("sbki,sij,sblj->sbkl", J, Minv, J)
+    for s, mc in enumerate(mcs):
+        mc.body_invweight0[:, 0] = np.trace(A[s][:, 0:3, 0:3], axis1=1, axis2=2) / 3
+        mc.body_invweight0[:, 1] = np.trace(A[s][:, 3:6, 3:6], axis1=1, axis2=2) / 3
+        d = np.diag(Minv[s]).copy()
+        d[0:3] = d[0:3].mean(); d[3:6] = d[3:6].mean()
+        mc.dof_invweight0[:] = d
+    return mcs
+
+
+def models_from_mesh(verts, joints, skin_weights, joint_names, parents, offsets=None, joint_range=None, **flags):
+    """One posed mesh per shape -> [ModelConst]: `body_hulls` + `skeleton_table` + `compile_tables`.  verts [S, V, 3] (or a list),
+    joints [S, J, 3]; offsets default to joints[j] - joints[parent] (the root's: its joint position)."""
+    tables = []
+    names = list(joint_names)
+    pidx = [(-1 if parents[n] is None else names.index(parents[n])) if isinstance(parents, dict) else int(parents[i]) for i, n in enumerate(names)]
+    for s in range(len(verts)):
+        jt = np.asarray(joints[s], np.float64)
+        off = offsets[s] if offsets is not None else np.array([jt[j] - (jt[pidx[j]] if pidx[j] >= 0 else 0.0) for j in range(len(names))])
+        hulls = body_hulls(verts[s], jt, skin_weights, names)
+        tables.append(skeleton_table(names, pidx, off, hulls, joint_range, **flags))
+    return compile_tables(tables)

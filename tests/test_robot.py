@@ -1,0 +1,145 @@
+"""Body shape -> model (smplsim_amd/robot.py): the reference's geometry rules restated
+(skeleton_local.py:460-684, smpl_local_robot.py:146-173,1280-1505).  The SMPL model files are absent, so the rules are pinned
+on the one artefact of theirs that IS here — the packaged mean-body MJCF they produced: feeding its own joints and the hull
+volumes / bounding boxes its geoms imply back through the rules must reproduce it, number for number."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from smplsim_amd import robot
+from smplsim_amd.mjcf import compile_mjcf
+from smplsim_amd.mjcf_writer import default_xml_str, table_to_mjcf
+
+DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "smplsim_amd", "data")
+
+
+def _table(name):
+    return json.load(open(os.path.join(DATA, name + ".json")))
+
+
+def test_rules_reproduce_the_packaged_mean_body():
+    t = _table("smpl_humanoid")
+    names = [b["name"] for b in t["bodies"]]
+    parents = {b["name"]: b["parent"] for b in t["bodies"]}
+    offsets = {b["name"]: b["pos"] for b in t["bodies"]}
+    hulls = robot.hulls_of_table(t)
+    # the capsule end points need nothing but the joints: 20 % .. 80 % of the mean child offset (45 % .. 55 % for the trunk)
+    jrange = {b["name"]: np.deg2rad([j["range"] for j in b["joints"]]) for b in t["bodies"] if b["joints"]}   # the SMPL parser's ranges
+    made = robot.skeleton_table(names, parents, offsets, hulls, joint_range=jrange, create_vel_sensors=True)
+    for a, b in zip(made["bodies"], t["bodies"]):
+        assert a["name"] == b["name"] and a["parent"] == b["parent"] and a["freejoint"] == b["freejoint"]
+        assert np.abs(np.array(a["pos"]) - b["pos"]).max() < 1e-12
+        assert [j["name"] for j in a["joints"]] == [j["name"] for j in b["joints"]] and all(x["range"] == y["range"] for x, y in zip(a["joints"], b["joints"]))
+        ga, gb = a["geoms"][0], b["geoms"][0]
+        assert ga["type"] == gb["type"], a["name"]
+        if ga["type"] == "capsule":
+            # the XML's end points were printed from unrounded joints: 1.5e-4 = one unit of the 4th decimal through the 0.8 factor
+            assert np.abs(np.array(ga["fromto"]) - gb["fromto"]).max() < 1.5e-4, (a["name"], ga["fromto"], gb["fromto"])
+            assert abs(ga["size"][0] - gb["size"][0]) < 1e-4 and ga["contype"] == gb["contype"] == "1"
+            assert abs(float(ga["density"]) - float(gb["density"])) < 1e-3 * float(gb["density"])
+        else:
+            assert np.abs(np.array(ga["size"]) - gb["size"]).max() < 1e-4 and np.abs(np.array(ga["pos"]) - gb["pos"]).max() < 1.5e-4, a["name"]
+            assert abs(float(ga["density"]) - float(gb["density"])) < 2e-3 * float(gb["density"]) and "contype" not in ga
+    assert made["excludes"] == t["excludes"] and [m["name"] for m in made["motors"]] == [m["name"] for m in t["motors"]]
+    # and the model compiled from the re-derived table is the fixture's model (masses within the 4-decimal printing of the sizes)
+    mc0, mc1 = compile_mjcf(table_to_mjcf(t)), robot.compile_tables([made])[0]
+    assert abs(mc1.total_mass - mc0.total_mass) < 2e-3 * mc0.total_mass and abs(mc0.total_mass - 71.805) < 1e-3
+    assert np.abs(mc1.body_mass - mc0.body_mass).max() < 0.02 and np.abs(mc1.body_ipos - mc0.body_ipos).max() < 2e-4
+
+
+def test_capsule_radius_is_the_root_of_the_volume_polynomial():
+    for r, L in ((0.06, 0.25), (0.03, 0.05), (0.1, 0.0)):
+        V = 4 / 3 * np.pi * r ** 3 + np.pi * L * r ** 2
+        assert abs(robot.capsule_radius(V, L) - r) < 1e-12
+
+
+@pytest.mark.parametrize("name", ["smpl_humanoid", "smplx_humanoid"])
+def test_vectorised_compile_equals_the_mjcf_compiler(name):
+    t = _table(name)
+    a, b = compile_mjcf(table_to_mjcf(t)), robot.compile_tables([t, t])[1]
+    for f in ("body_parent", "body_pos", "body_mass", "body_ipos", "body_iquat", "body_inertia", "geom_type", "geom_size", "geom_pos", "geom_quat",
+              "dof_armature", "jnt_range", "jnt_limited", "actuator_dof", "body_invweight0", "dof_invweight0", "qpos0", "geom_contype", "geom_conaffinity"):
+        x, y = np.asarray(getattr(a, f), np.float64), np.asarray(getattr(b, f), np.float64)
+        assert x.shape == y.shape and np.allclose(x, y, rtol=1e-10, atol=1e-12, equal_nan=True), f
+    assert a.body_names == b.body_names and a.joint_names == b.joint_names and a.actuator_names == b.actuator_names and a.excludes == b.excludes
+
+
+def _synthetic_meshes(t, n_shapes, seed):
+    """Point clouds around every body of the packaged skeleton, limbs scaled per shape: stand-ins for posed SMPL meshes."""
+    rs = np.random.default_rng(seed)
+    names = [b["name"] for b in t["bodies"]]
+    parents = {b["name"]: b["parent"] for b in t["bodies"]}
+    hulls = robot.hulls_of_table(t)
+    V, J, W = [], [], None
+    for s in range(n_shapes):
+        scale = rs.uniform(0.85, 1.15)
+        joints, verts, owner = {}, [], []
+        for j, b in enumerate(t["bodies"]):
+            off = np.array(b["pos"]) * scale
+            joints[b["name"]] = off + (joints[b["parent"]] if b["parent"] else 0.0)
+            g = b["geoms"][0]
+            if g["type"] == "box":
+                c, h = np.array(g["pos"]) * scale, np.array(g["size"]) * scale * (1.75 if b["name"] == "Pelvis" else 1.0)
+            else:
+                ft = np.array(g["fromto"]) * scale
+                c, h = 0.5 * (ft[:3] + ft[3:]), np.abs(ft[3:] - ft[:3]) / 2 + g["size"][0] * scale
+            pts = c + rs.uniform(-1, 1, (40, 3)) * h
+            verts.append(joints[b["name"]] + pts); owner += [j] * 40
+        V.append(np.concatenate(verts)); J.append(np.array([joints[n] for n in names]))
+        W = np.eye(len(names))[owner]
+    return names, parents, np.array(V), np.array(J), W
+
+
+def test_models_from_meshes_step_on_the_emulator(emu_backend):
+    """16 body shapes from (vertices, joints, skinning weights) through the rules into ONE model with per-env shapes, stepped by
+    the kernel (emulator) and checked against the oracle compiled from each shape's own MJCF."""
+    import torch
+    from helpers import FEET, pd_tables
+    from oracle import oracle as O
+    from smplsim_amd.batch import ShardModel, SMPLSimVecEnv
+    t = _table("smpl_humanoid")
+    names, parents, V, J, W = _synthetic_meshes(t, 4, 3)
+    hulls0 = robot.body_hulls(V[0], J[0], W, names)
+    assert set(hulls0) == set(names) and all(h["volume"] > 0 for h in hulls0.values())
+    mcs = robot.models_from_mesh(V, J, W, names, parents)
+    assert len(mcs) == 4 and len({round(m.total_mass, 3) for m in mcs}) == 4            # the shapes differ
+    model = ShardModel(mcs=mcs)
+    env = SMPLSimVecEnv(4, model=model, shape_id=[0, 1, 2, 3], autoreset=False)
+    obs, _ = env.reset()
+    rs = np.random.default_rng(0)
+    acts = rs.uniform(-0.3, 0.3, (3, 69))
+    for a in acts:
+        env.step(torch.tensor(np.tile(a, (4, 1)), dtype=torch.float32))
+    for s in range(4):
+        tab = robot.skeleton_table(names, [-1 if parents[n] is None else names.index(parents[n]) for n in names],
+                                   np.array([J[s][j] - (J[s][names.index(parents[n])] if parents[n] else 0.0) for j, n in enumerate(names)]),
+                                   robot.body_hulls(V[s], J[s], W, names))
+        xml = table_to_mjcf(tab)
+        om = O.OracleModel(xml, *pd_tables(mcs[s]), legal_bodies=FEET)
+        oe = O.OracleEnv(om); oe.reset()
+        for a in acts:
+            oe.step(a)
+        assert np.abs(env.qpos[s].numpy() - oe.data.qpos).max() < 1e-4, s
+
+
+def test_gym_env_with_shape_variation(emu_backend):
+    """cfg.robot.has_shape_variation (reference humanoid_env.py:205): refused without bodies, one model per env with them."""
+    from smplsim_amd.config import default_cfg
+    from smplsim_amd.envs import SMPLSimGymVecEnv
+    from smplsim_amd.envs.humanoid_env import HumanoidEnv
+    cfg = default_cfg("HumanoidEnv")
+    cfg.robot.has_shape_variation = True
+    with pytest.raises(ValueError, match="bodies"):
+        HumanoidEnv(cfg)
+    names, parents, V, J, W = _synthetic_meshes(_table("smpl_humanoid"), 3, 5)
+    bodies = dict(verts=V, joints=J, skin_weights=W, joint_names=names, parents=parents)
+    with pytest.warns(UserWarning):
+        env = SMPLSimGymVecEnv(cfg, 3, bodies=bodies)
+    assert env._single._model.num_shapes == 3 and env.single_observation_space.shape == (289,)
+    obs, _ = env.reset(seed=1)
+    o2 = env.step(np.zeros((3, 69), np.float32))[0]
+    assert o2.shape == (3, 289) and np.isfinite(o2).all() and np.abs(o2[0] - o2[1]).max() > 1e-4     # different bodies move differently
+    one = HumanoidEnv(cfg, bodies={**bodies, "verts": V[:1], "joints": J[:1]})      # a single shape: no shape table needed
+    assert one._model.num_shapes == 1 and one.self_collision
