@@ -193,7 +193,6 @@ def hulls_of_table(table):
 def compile_tables(tables):
     """[body table] -> [ModelConst] without an MJCF round trip; the joint-space inverse at qpos0 (body / dof inverse weights) is
     one batched numpy inverse for all shapes.  Same numbers as compile_mjcf(table_to_mjcf(t)) (tests/test_robot.py)."""
-    from .mjcf import body_com_jacobians_qpos0, quat_to_mat
     mcs = []
     for t in tables:
         names = [b["name"] for b in t["bodies"]]
@@ -237,19 +236,45 @@ def compile_tables(tables):
             body_invweight0=np.zeros((nb, 2)), dof_invweight0=np.zeros(nv), qpos0=qpos0, excludes=[tuple(e) for e in t["excludes"]],
             has_vel_sensors=bool(t.get("vel_sensors", False)), geom_margin=float(dg.get("margin", 0)), friction=1.0,
             geom_contype=np.array(ct, np.int32), geom_conaffinity=np.array(ca, np.int32)))
-    # inverse weights at qpos0, all shapes at once: M = sum_b m Jp^T Jp + Jr^T Iw Jr + armature
+    # inverse weights at qpos0, all shapes at once: M = sum_b m Jp^T Jp + Jr^T Iw Jr + armature.  The tree is the same for every
+    # shape, so the COM Jacobians are filled per (body, ancestor, axis) for all shapes in one numpy statement each.
     B = len(mcs)
     if B == 0:
         return mcs
     nb, nv = mcs[0].nbody, mcs[0].nv
-    J = np.stack([body_com_jacobians_qpos0(mc)[0] for mc in mcs])                     # [B, nb, 6, nv]
-    Rm = np.stack([[quat_to_mat(q) for q in mc.body_iquat] for mc in mcs])            # [B, nb, 3, 3]
-    Iw = np.einsum("sbij,sbj,sbkj->sbik", Rm, np.stack([mc.body_inertia for mc in mcs]), Rm)
+    par = mcs[0].body_parent
+    bpos = np.stack([mc.body_pos for mc in mcs])                                       # [B, nb, 3]
+    xpos = np.zeros((B, nb, 3))
+    for b_ in range(nb):
+        xpos[:, b_] = bpos[:, b_] + (xpos[:, par[b_]] if par[b_] >= 0 else 0.0)       # all frames are identity at qpos0
+    com = xpos + np.stack([mc.body_ipos for mc in mcs])
+    J = np.zeros((B, nb, 6, nv))
+    eye = np.eye(3)
+    for b_ in range(nb):
+        J[:, b_, 0:3, 0:3] = eye
+        a_ = b_
+        while a_ >= 0:
+            base = 3 if a_ == 0 else 6 + 3 * (a_ - 1)
+            rel = com[:, b_] - xpos[:, a_]
+            for k_ in range(3):
+                J[:, b_, 3 + k_, base + k_] = 1.0
+                J[:, b_, 0:3, base + k_] = np.cross(eye[k_], rel)
+            a_ = par[a_]
+    iq = np.stack([mc.body_iquat for mc in mcs])                                        # [B, nb, 4] -> rotation matrices
+    w_, x_, y_, z_ = iq[..., 0], iq[..., 1], iq[..., 2], iq[..., 3]
+    Rm = np.stack([np.stack([1 - 2 * (y_ * y_ + z_ * z_), 2 * (x_ * y_ - w_ * z_), 2 * (x_ * z_ + w_ * y_)], -1),
+                   np.stack([2 * (x_ * y_ + w_ * z_), 1 - 2 * (x_ * x_ + z_ * z_), 2 * (y_ * z_ - w_ * x_)], -1),
+                   np.stack([2 * (x_ * z_ - w_ * y_), 2 * (y_ * z_ + w_ * x_), 1 - 2 * (x_ * x_ + y_ * y_)], -1)], -2)
+    inert = np.stack([mc.body_inertia for mc in mcs])                                  # [B, nb, 3]
+    Iw = np.matmul(Rm * inert[:, :, None, :], np.swapaxes(Rm, -1, -2))                  # R diag(I) R^T
     m = np.stack([mc.body_mass for mc in mcs])
-    M = np.einsum("sb,sbki,sbkj->sij", m, J[:, :, 0:3], J[:, :, 0:3]) + np.einsum("sbki,sbkl,sblj->sij", J[:, :, 3:6], Iw, J[:, :, 3:6])
+    Jp, Jr = J[:, :, 0:3], J[:, :, 3:6]
+    Jpm = (Jp * np.sqrt(m)[:, :, None, None]).reshape(B, nb * 3, nv)
+    IJ = np.matmul(Iw, Jr).reshape(B, nb * 3, nv)
+    M = np.matmul(np.swapaxes(Jpm, 1, 2), Jpm) + np.matmul(np.swapaxes(Jr.reshape(B, nb * 3, nv), 1, 2), IJ)
     M[:, np.arange(nv), np.arange(nv)] += np.stack([mc.dof_armature for mc in mcs])
     Minv = np.linalg.inv(M)
-    A = np.einsum("sbki,sij,sblj->sbkl", J, Minv, J)
+    A = np.matmul(np.matmul(J, Minv[:, None]), np.swapaxes(J, -1, -2))                   # [B, nb, 6, 6]
     for s, mc in enumerate(mcs):
         mc.body_invweight0[:, 0] = np.trace(A[s][:, 0:3, 0:3], axis1=1, axis2=2) / 3
         mc.body_invweight0[:, 1] = np.trace(A[s][:, 3:6, 3:6], axis1=1, axis2=2) / 3
