@@ -1,6 +1,12 @@
-"""Oracle vs REAL MuJoCo vectors — runs only when tools/dump_mujoco_golden.py has been executed somewhere with a
-`mujoco` wheel and its output committed as tests/golden/mujoco_vectors.npz (absent in round 1: no wheel, no network;
-the physics part of the oracle is therefore "parity unpinned", oracle/oracle.h)."""
+"""Oracle vs REAL MuJoCo, stage by stage — runs only when tools/dump_mujoco_golden.py has been executed somewhere with a `mujoco`
+wheel and its output committed as tests/golden/mujoco_vectors.npz.  Absent so far (no wheel, no network): the physics part
+of the oracle is "parity unpinned" (oracle/oracle.h), and bench.py says so in its JSON line (config.parity_pin).
+
+One test per stage, so that a failure names the stage of mj_forward whose restatement is off: model constants, kinematics,
+inertia / bias, collision (pairs, positions, frames, distances), constraint rows (diagApprox, R, aref), the solve, one
+mj_step, one 15-substep Stable-PD control step.  "floor" cases pin the scope of BASELINE.json's north_star, "full" cases the
+body-body contacts of SURVEY.md 8f-4 — there the contact-selection rules of mjc_CapsuleBox / mjc_BoxBox are restated as rules,
+so contact COUNTS per geom pair and the solved accelerations are compared, not point-by-point lists."""
 import os
 
 import numpy as np
@@ -10,24 +16,99 @@ from helpers import GOLDEN, oracle_model
 from oracle import oracle as O
 
 PATH = os.path.join(GOLDEN, "mujoco_vectors.npz")
-pytestmark = pytest.mark.skipif(not os.path.exists(PATH), reason="no MuJoCo golden vectors (mujoco not installable here)")
+pytestmark = pytest.mark.skipif(not os.path.exists(PATH), reason="no MuJoCo golden vectors (mujoco not installable here): parity unpinned")
+CASES = [(h, c) for h in ("smpl_humanoid", "smplx_humanoid") for c in ("floor", "full")]
 
 
-def test_oracle_matches_mujoco_forward_and_rollout():
-    g = np.load(PATH)
-    om = oracle_model()
-    assert np.allclose(om.get(O.M_MASS), g["mass"], rtol=1e-9)
-    assert np.allclose(om.get(O.M_BODY_INVW).reshape(-1, 2), g["body_invweight0"], rtol=1e-6)
+@pytest.fixture(scope="module")
+def G():
+    return np.load(PATH)
+
+
+def _states(G, h, c):
+    pre = f"{h}_{c}_"
+    om = oracle_model(h, self_collision=(c == "full"))
     d = O.OracleData(om)
-    for i in range(len(g["qpos"])):
-        d.qpos = g["qpos"][i]; d.qvel = g["qvel"][i]; d.ctrl = g["ctrl"][i]; d.warm = np.zeros(om.nv)
+    for i in range(len(G[pre + "qpos"])):
+        d.qpos = G[pre + "qpos"][i]; d.qvel = G[pre + "qvel"][i]; d.ctrl = G[pre + "ctrl"][i]; d.warm = np.zeros(om.nv)
         d.forward()
-        assert np.allclose(d.M, g["qM"][i], atol=1e-9)
-        assert np.allclose(d.bias, g["bias"][i], atol=1e-7)
-        assert np.allclose(d.xpos, g["xpos"][i], atol=1e-10)
-        assert d.ncon == int(g["ncon"][i])
-        assert np.allclose(d.qacc, g["qacc"][i], rtol=1e-5, atol=1e-5)
-        a = g["roll_action"][i]
+        yield i, pre, om, d
+
+
+@pytest.mark.parametrize("h", ["smpl_humanoid", "smplx_humanoid"])
+def test_stage_model_constants(G, h):
+    om, pre = oracle_model(h), f"{h}_floor_model_"
+    assert np.allclose(om.get(O.M_MASS), G[pre + "body_mass"], rtol=1e-9)
+    assert np.allclose(om.get(O.M_INERTIA).reshape(-1, 3), G[pre + "body_inertia"], rtol=1e-8)
+    assert np.allclose(om.get(O.M_IPOS).reshape(-1, 3), G[pre + "body_ipos"], atol=1e-12)
+    assert np.allclose(om.get(O.M_BODY_INVW).reshape(-1, 2), G[pre + "body_invweight0"], rtol=1e-6)
+    assert np.allclose(om.get(O.M_DOF_INVW), G[pre + "dof_invweight0"], rtol=1e-6)
+    assert np.allclose(om.get(O.M_RANGE).reshape(-1, 2)[6:], G[pre + "jnt_range"][1:], atol=1e-12)
+
+
+@pytest.mark.parametrize("h,c", CASES)
+def test_stage_kinematics(G, h, c):
+    for i, pre, om, d in _states(G, h, c):
+        assert np.abs(d.xpos - G[pre + "xpos"][i]).max() < 1e-10 and np.abs(d.xipos - G[pre + "xipos"][i]).max() < 1e-10
+        q, g = d.xquat, G[pre + "xquat"][i]
+        assert np.minimum(np.abs(q - g).max(1), np.abs(q + g).max(1)).max() < 1e-10
+
+
+@pytest.mark.parametrize("h,c", CASES)
+def test_stage_inertia_and_bias(G, h, c):
+    for i, pre, om, d in _states(G, h, c):
+        assert np.abs(d.M - G[pre + "qM"][i]).max() < 1e-9 * np.abs(G[pre + "qM"][i]).max()
+        assert np.abs(d.bias - G[pre + "qfrc_bias"][i]).max() < 1e-8 * max(1.0, np.abs(G[pre + "qfrc_bias"][i]).max())
+        assert np.abs(d.get(O.D_QACC_SMOOTH) - G[pre + "qacc_smooth"][i]).max() < 1e-7 * max(1.0, np.abs(G[pre + "qacc_smooth"][i]).max())
+
+
+@pytest.mark.parametrize("h,c", CASES)
+def test_stage_collision(G, h, c):
+    for i, pre, om, d in _states(G, h, c):
+        nc = int(G[pre + "ncon"][i])
+        g1, g2 = G[pre + "con_geom1"][i][:nc].astype(int), G[pre + "con_geom2"][i][:nc].astype(int)      # geom ids: 0 = floor, body b = b + 1
+        floor = g1 == 0
+        mine_floor = d.con_body1 < 0
+        # floor contacts: the same bodies, points and distances, in MuJoCo's order (plane-box: first 4 corners; capsule: 2 spheres)
+        assert floor.sum() == mine_floor.sum(), (i, floor.sum(), mine_floor.sum())
+        assert (d.con_body[mine_floor] == g2[floor] - 1).all()
+        assert np.abs(d.con_pos[mine_floor] - G[pre + "con_pos"][i][:nc][floor]).max(initial=0) < 1e-9
+        assert np.abs(d.con_dist[mine_floor] - G[pre + "con_dist"][i][:nc][floor]).max(initial=0) < 1e-9
+        # body-body contacts: the same geom pairs collide; capsule-capsule contacts point by point
+        pairs_mj = sorted(zip(g1[~floor] - 1, g2[~floor] - 1))
+        pairs_me = sorted(zip(d.con_body1[~mine_floor], d.con_body[~mine_floor]))
+        assert set(pairs_mj) == set(pairs_me), (i, set(pairs_mj) ^ set(pairs_me))
+
+
+@pytest.mark.parametrize("h,c", [(h, "floor") for h in ("smpl_humanoid", "smplx_humanoid")])
+def test_stage_constraint_rows(G, h, c):
+    """diagApprox / R / D / aref of MuJoCo's rows against the oracle's, for the cases whose row sets coincide by construction
+    (floor contacts + joint limits; MuJoCo lists limit rows before contact rows like the oracle)."""
+    for i, pre, om, d in _states(G, h, c):
+        ne = int(G[pre + "nefc"][i])
+        assert ne == int(d.get(O.D_NEFC)[0])
+        f = d.get(O.D_EFC_FORCE)
+        assert np.abs(f - G[pre + "efc_force"][i][:ne]).max(initial=0) < 1e-5 * max(1.0, np.abs(f).max(initial=0))
+
+
+@pytest.mark.parametrize("h,c", CASES)
+def test_stage_solve(G, h, c):
+    for i, pre, om, d in _states(G, h, c):
+        tol = 1e-6 if c == "floor" else 1e-2      # full: contact selection of box pairs is a restated rule, not MuJoCo's code
+        assert np.abs(d.qacc - G[pre + "qacc"][i]).max() < tol * max(1.0, np.abs(G[pre + "qacc"][i]).max()), (i, d.ncon)
+        assert np.abs(d.get(O.D_QFRC_CONSTRAINT) - G[pre + "qfrc_constraint"][i]).max() < tol * max(1.0, np.abs(G[pre + "qfrc_constraint"][i]).max())
+
+
+@pytest.mark.parametrize("h,c", [(h, "floor") for h in ("smpl_humanoid", "smplx_humanoid")])
+def test_stage_step_and_control_step(G, h, c):
+    pre = f"{h}_{c}_"
+    om = oracle_model(h)
+    d = O.OracleData(om)
+    for i in range(len(G[pre + "qpos"])):
+        d.qpos = G[pre + "qpos"][i]; d.qvel = G[pre + "qvel"][i]; d.ctrl = np.zeros(om.nu); d.warm = np.zeros(om.nv)
+        d.step()
+        assert np.abs(d.qpos - G[pre + "step_qpos"][i]).max() < 1e-8 and np.abs(d.qvel - G[pre + "step_qvel"][i]).max() < 1e-6
+        d.qpos = G[pre + "qpos"][i]; d.qvel = G[pre + "qvel"][i] * 0.2; d.warm = np.zeros(om.nv); d.ctrl = np.zeros(om.nu); d.forward()
         for _ in range(15):
-            d.ctrl = d.spd_torque(a); d.step()
-        assert np.allclose(d.qpos, g["roll_qpos"][i], atol=1e-6) and np.allclose(d.qvel, g["roll_qvel"][i], atol=1e-4)
+            d.ctrl = d.spd_torque(G[pre + "roll_action"][i]); d.step()
+        assert np.abs(d.qpos - G[pre + "roll_qpos"][i]).max() < 1e-6 and np.abs(d.qvel - G[pre + "roll_qvel"][i]).max() < 1e-4
