@@ -90,16 +90,22 @@ def qpos_to_pose_aa(qpos, skeleton):
 
 class MotionLibSMPL:
     def __init__(self, motion_file, skeleton, device=0, fix_height=FixHeightMode.no_fix, min_length=-1, max_length=-1,
-                 randomrize_heading=False, filter_vel=True, height_fix=None, seed=0):
-        """motion_file: path of a joblib/pickle file, a directory of *.pkl files, or the dict itself."""
+                 randomrize_heading=False, filter_vel=True, height_fix=None, seed=0, mesh_parsers=None):
+        """motion_file: path of a joblib/pickle file, a directory of *.pkl files, or the dict itself.
+        mesh_parsers: what the reference builds from the SMPL model files (motion_lib_smpl.py:48-64): {"0" | "1" | "2": parser} by
+        gender with `get_joints_verts(pose_aa, betas, trans) -> (vertices, joints)`, `lbs_weights`, `joint_names`; with it
+        FixHeightMode.full_fix / ankle_fix run `fix_trans_height` on the mesh like the reference (shape_params of load_motions give
+        gender + betas per clip).  The parsers need the licensed SMPL files, so they are the caller's; `height_fix` (a plain
+        callable) and FixHeightMode.geom_fix (collision geoms instead of the mesh, on the device) remain as alternatives."""
         from . import batch
         from ._lib import lib
         self.device = batch._shard_device(device.index if isinstance(device, torch.device) else device)   # raises without a GPU
         self._lib = lib()
         self.skeleton = skeleton
-        self.fix_height, self.height_fix = fix_height, height_fix
-        if fix_height in (FixHeightMode.full_fix, FixHeightMode.ankle_fix) and height_fix is None:
-            raise ValueError("full_fix / ankle_fix need the SMPL mesh: pass a height_fix(pose_aa, trans) callable, or use geom_fix")
+        self.fix_height, self.height_fix, self.mesh_parsers = fix_height, height_fix, mesh_parsers
+        if fix_height in (FixHeightMode.full_fix, FixHeightMode.ankle_fix) and height_fix is None and mesh_parsers is None:
+            raise ValueError("full_fix / ankle_fix need the SMPL mesh: pass mesh_parsers (the reference's SMPL parsers), a "
+                             "height_fix(pose_aa, trans) callable, or use geom_fix")
         if fix_height == FixHeightMode.geom_fix and skeleton.geoms is None:
             raise ValueError("geom_fix needs the skeleton's collision geoms (Skeleton.from_model_const)")
         self.max_length, self.randomrize_heading, self.filter_vel = max_length, randomrize_heading, bool(filter_vel)
@@ -157,7 +163,7 @@ class MotionLibSMPL:
         self._sampling_batch_prob = self._sampling_prob[idx] / self._sampling_prob[idx].sum()
 
         poses, transs, nfs, fpss = [], [], [], []
-        for i in idx:
+        for f_, i in enumerate(idx):                             # f_: position in the loaded batch (shape_params[f_], like the reference)
             clip = self._motion_data_list[i]
             fps = float(clip.get("fps", 30))
             pose = np.asarray(clip["pose_aa"], np.float32)
@@ -181,7 +187,11 @@ class MotionLibSMPL:
                 pose[:, 0] = (rot * sRot.from_rotvec(pose[:, 0])).as_rotvec().astype(np.float32)
                 trans = (trans @ rot.as_matrix().T.astype(np.float32)).astype(np.float32)
             if self.fix_height in (FixHeightMode.full_fix, FixHeightMode.ankle_fix):
-                trans = np.asarray(self.height_fix(pose, trans), np.float32)
+                if self.mesh_parsers is not None:
+                    gb = np.zeros(17, np.float32) if shape_params is None else np.asarray(shape_params[f_], np.float32)
+                    trans, _ = self.fix_trans_height(pose, trans, gb, self.mesh_parsers, self.fix_height)
+                else:
+                    trans = np.asarray(self.height_fix(pose, trans), np.float32)
             poses.append(pose); transs.append(trans); nfs.append(pose.shape[0]); fpss.append(fps)
 
         nf = np.array(nfs, np.int64)
@@ -263,6 +273,35 @@ class MotionLibSMPL:
         self.height_offsets = diff
         self.gts[..., 2] -= diff[fm][:, None]
         self.qpos[:, 2] -= diff[fm]
+
+    @staticmethod
+    def fix_trans_height(pose_aa, trans, curr_gender_betas, mesh_parsers, fix_height_mode, frame_check=30):
+        """The reference's mesh height fix (motion_lib_smpl.py:67-92): pose the SMPL mesh of the clip's shape for the first 30
+        frames (usually a calibration phase) and shift the whole clip so that its lowest vertex (full_fix) — or its lowest vertex
+        not skinned to the toes / hands, minus 2.5 cm (ankle_fix) — touches z = 0.  Returns (trans, shift)."""
+        if fix_height_mode == FixHeightMode.no_fix:
+            return trans, 0.0
+        gb = np.asarray(curr_gender_betas, np.float32)
+        parser = mesh_parsers[str(int(gb[0]))]
+        pose = torch.as_tensor(np.asarray(pose_aa, np.float32))[:frame_check]
+        tr = torch.as_tensor(np.asarray(trans, np.float32))
+        with torch.no_grad():
+            verts, _ = parser.get_joints_verts(pose, torch.as_tensor(gb[1:])[None], tr[:frame_check])
+            verts = torch.as_tensor(verts)
+            if fix_height_mode == FixHeightMode.ankle_fix:
+                tol = -0.025
+                owner = torch.as_tensor(np.asarray(parser.lbs_weights)).argmax(dim=1)
+                names = list(parser.joint_names)
+                keep = torch.ones_like(owner, dtype=torch.bool)
+                for n in ("L_Toe", "R_Toe", "R_Hand", "L_Hand"):
+                    keep &= owner != names.index(n)
+                verts = verts[:, keep]
+            else:
+                tol = 0.0
+            diff = float((verts[..., -1].min(dim=-1).values - tol).min())
+        out = np.asarray(trans, np.float32).copy()
+        out[..., -1] -= diff
+        return out, diff
 
     def _check(self, rc):
         if rc != 0:

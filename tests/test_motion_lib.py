@@ -502,3 +502,53 @@ def test_emu_very_short_clips_match_oracle(emu_lib):
     assert np.allclose(s["rg_pos"][0].numpy(), lib.gts[0].numpy()) and np.allclose(s["rg_pos"][2].numpy(), lib.gts[1].numpy())
     f3 = int(lib.length_starts[3])
     assert np.allclose(s["rg_pos"][3].numpy(), 0.5 * (lib.gts[f3].numpy() + lib.gts[f3 + 1].numpy()), atol=1e-5)
+
+
+class _FakeMeshParser:
+    """Stand-in for the reference's SMPL_Parser (needs the licensed model files): a "mesh" of 4 vertices per joint, posed by the
+    oracle's forward kinematics.  Only the interface fix_trans_height uses: get_joints_verts, lbs_weights, joint_names."""
+
+    def __init__(self, sk):
+        self.sk = sk
+        self.joint_names = list(sk.smpl_order_names) if hasattr(sk, "smpl_order_names") else None
+        J = len(sk.parents)
+        self.lbs_weights = np.repeat(np.eye(J, dtype=np.float32), 4, axis=0)            # vertex 4 j .. 4 j + 3 belongs to joint j
+        rs = np.random.default_rng(0)
+        self.local = rs.uniform(-0.05, 0.05, (J, 4, 3))
+
+    def get_joints_verts(self, pose_aa, betas, trans):
+        pose, tr = np.asarray(pose_aa, np.float64), np.asarray(trans, np.float64)
+        r = mo.cook(pose, tr, self.sk.offsets, self.sk.parents, self.sk.smpl_2_mujoco, 1 / 30, False)
+        gt = r["global_translation"].reshape(len(pose), -1, 3)                            # MuJoCo body order
+        verts = (gt[:, :, None, :] + self.local[None]).reshape(len(pose), -1, 3)
+        return torch.as_tensor(verts, dtype=torch.float32), torch.as_tensor(gt, dtype=torch.float32)
+
+
+def test_fix_trans_height_on_the_mesh(emu_lib):
+    """FixHeightMode.full_fix / ankle_fix with mesh parsers (reference motion_lib_smpl.py:67-92): the first 30 frames' lowest
+    vertex ends on the floor; ankle_fix ignores the vertices skinned to toes and hands and leaves 2.5 cm."""
+    from smplsim_amd.motion_lib import FixHeightMode, MotionLibSMPL, Skeleton
+    from smplsim_amd.mjcf import compile_mjcf
+    from smplsim_amd.mjcf_writer import default_xml_str
+    mc = compile_mjcf(default_xml_str("smpl_humanoid"))
+    sk = Skeleton.from_model_const(mc)
+    parser = _FakeMeshParser(sk)
+    parser.joint_names = list(mc.body_names)                                              # vertex owner index = MuJoCo body index here
+    parsers = {"0": parser}
+    clips = clip_dict()
+    for mode, tol in ((FixHeightMode.full_fix, 0.0), (FixHeightMode.ankle_fix, -0.025)):
+        lib = MotionLibSMPL(clips, sk, device=0, fix_height=mode, mesh_parsers=parsers)
+        lib.load_motions(random_sample=False)
+        st = 0
+        for m, c in enumerate(clips.values()):
+            T = c["pose_aa"].shape[0]
+            tr = lib.qpos[st:st + T, :3].numpy()                                          # the fixed root translation (+ root offset)
+            verts, _ = parser.get_joints_verts(c["pose_aa"].reshape(T, 24, 3)[:30], None, tr[:30] - sk.offsets[0])
+            v = verts.numpy().reshape(min(T, 30), 24, 4, 3)
+            if mode == FixHeightMode.ankle_fix:
+                keep = [i for i, n in enumerate(mc.body_names) if n not in ("L_Toe", "R_Toe", "L_Hand", "R_Hand")]
+                v = v[:, keep]
+            assert abs(v[..., 2].min() - tol) < 2e-5, (mode, m, v[..., 2].min())
+            st += T
+    with pytest.raises(ValueError, match="mesh_parsers"):
+        MotionLibSMPL(clips, sk, device=0, fix_height=FixHeightMode.full_fix)
