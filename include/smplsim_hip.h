@@ -126,6 +126,21 @@ int ss_model_create(const ss_model_desc *desc, int device_id, ss_model **out);
  * must agree; body offsets, inertias, geom sizes / positions and the inverse weights may differ.  The geometry tables are
  * stored per shape and every env reads those of ss_state.shape_id[env]; one launch steps all shapes together. */
 int ss_model_create_shapes(const ss_model_desc *descs, int32_t num_shapes, int device_id, ss_model **out);
+
+/* The same from MJCF text, for hosts without the Python compiler: mujoco.MjModel.from_xml_string (reference
+ * smpl_sim/envs/base_env.py:139-142) for the MJCF subset the reference's humanoids use (smplsim_amd/csrc/ss_mjcf.h lists it;
+ * anything outside is SS_ERR_INVALID with the offending element in the message), plus the per-actuator tables of
+ * HumanoidEnv.setup_controller / build_pd_action_scale (humanoid_env.py:312-370) from the reference's gain table by body name
+ * (humanoid_env.py:62-84).  opts NULL = the reference defaults below.  len 0 = strlen(xml). */
+typedef struct {
+  int32_t control_mode;          /* SS_CTRL_*; default SS_CTRL_UHC_PD (cfg.robot.control_mode) */
+  int32_t clip_actions;          /* default 1 (cfg.env.clip_actions): action scale = min(1.2 * max|range|, pi) */
+  double pdp_scale, pdd_scale;   /* <= 0 = 1 (cfg.env.pdp_scale / pdd_scale) */
+  double timestep;               /* <= 0 = 1/450 (cfg.env.sim_timestep_inv) */
+  int32_t num_contact_bodies;    /* with contact_bodies: names of the bodies allowed to touch the floor */
+  const char *const *contact_bodies; /* NULL = R_Ankle, L_Ankle, R_Toe, L_Toe (cfg.env.contact_bodies) */
+} ss_mjcf_options;
+int ss_model_create_from_mjcf(const char *xml, size_t len, const ss_mjcf_options *opts, int device_id, ss_model **out);
 void ss_model_destroy(ss_model *m);
 /* nq, nv, nu, nbody, obs size for (self_obs_v, task, root_height_obs) — humanoid_env.py:293-299 */
 int ss_model_dims(const ss_model *m, int32_t *nq, int32_t *nv, int32_t *nu, int32_t *nbody);
@@ -206,7 +221,11 @@ int ss_launch_info(const ss_batch *b, int32_t *envs_per_wg, int32_t *lds_bytes, 
  * persistent workgroups of a launch (0 = one per CU), so that K concurrent batches can each own 1/K of the CUs. */
 int ss_set_launch_geometry(ss_batch *b, int32_t envs_per_wg, int32_t max_workgroups);
 
+/* Message of the calling thread's last failed call; and of the last failed call that took this handle (valid until the next
+ * failing call on the handle or its destruction) — for hosts that call from pooled threads and cannot rely on thread identity. */
 const char *ss_last_error(void);
+const char *ss_model_last_error(const ss_model *m);
+const char *ss_batch_last_error(const ss_batch *b);
 
 #ifdef __cplusplus
 }

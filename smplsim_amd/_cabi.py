@@ -82,8 +82,16 @@ class ImitationCfg(C.Structure):
                                          "termination_distance", "obs_dt")]
 
 
+class MjcfOptions(C.Structure):
+    _fields_ = [("control_mode", C.c_int32), ("clip_actions", C.c_int32), ("pdp_scale", C.c_double), ("pdd_scale", C.c_double),
+                ("timestep", C.c_double), ("num_contact_bodies", C.c_int32), ("contact_bodies", C.POINTER(C.c_char_p))]
+
+
 def bind(lib):
     vp = C.c_void_p
+    lib.ss_model_create_from_mjcf.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(MjcfOptions), C.c_int, C.POINTER(vp)]
+    lib.ss_model_last_error.argtypes = [vp]; lib.ss_model_last_error.restype = C.c_char_p
+    lib.ss_batch_last_error.argtypes = [vp]; lib.ss_batch_last_error.restype = C.c_char_p
     lib.ss_model_create.argtypes = [C.POINTER(ModelDesc), C.c_int, C.POINTER(vp)]
     lib.ss_model_create_shapes.argtypes = [C.POINTER(ModelDesc), C.c_int32, C.c_int, C.POINTER(vp)]
     lib.ss_model_destroy.argtypes = [vp]; lib.ss_model_destroy.restype = None
@@ -117,6 +125,7 @@ def bind(lib):
 EXPORTS = ["ss_model_create", "ss_model_create_shapes", "ss_model_destroy", "ss_model_dims", "ss_obs_size", "ss_batch_create",
            "ss_batch_destroy", "ss_reset", "ss_step", "ss_step_autoreset", "ss_substep", "ss_kinematics", "ss_debug_forward", "ss_debug_self_contacts",
            "ss_gae", "ss_debug_prof", "ss_set_order", "ss_set_body_outputs", "ss_set_launch_geometry", "ss_schedule_longest_first", "ss_launch_info", "ss_last_error",
+           "ss_model_create_from_mjcf", "ss_model_last_error", "ss_batch_last_error",
            "ss_motion_cook", "ss_motion_state_at", "ss_motion_resample", "ss_imitation_step"]
 
 

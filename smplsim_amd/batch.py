@@ -59,8 +59,10 @@ class ShardModel:
     """Compiled model + device tables (ss_model) for one device."""
 
     def __init__(self, xml=None, humanoid="smpl_humanoid", device=0, contact_bodies=DEFAULT_CONTACT_BODIES,
-                 control_mode="uhc_pd", clip_actions=True, pdp_scale=1.0, pdd_scale=1.0, sim_timestep_inv=450, tables=None, xmls=None, mcs=None):
-        """tables: optional (kp, kd, torque_lim, act_scale, act_offset) per actuator for models whose bodies are not in
+                 control_mode="uhc_pd", clip_actions=True, pdp_scale=1.0, pdd_scale=1.0, sim_timestep_inv=450, tables=None, xmls=None, mcs=None, compiler="python"):
+        """compiler: "python" = smplsim_amd.mjcf + gains build the ss_model_desc; "native" = the library compiles the MJCF text and
+        the gain tables itself (ss_model_create_from_mjcf — the entry a non-Python host uses; single shape, reference gain table).
+        tables: optional (kp, kd, torque_lim, act_scale, act_offset) per actuator for models whose bodies are not in
         the reference's gain table (humanoid_env.py:62-84).
         xmls: a list of MJCF strings = body shapes of the same humanoid (cfg.robot.has_shape_variation): one model whose
         geometry tables have an entry per shape; the envs pick theirs through SMPLSimVecEnv(shape_id=...).
@@ -79,11 +81,22 @@ class ShardModel:
             self.mc.actuator_names, lambda n: rng[n], clip_actions=clip_actions, control_mode=control_mode,
             pdp_scale=pdp_scale, pdd_scale=pdd_scale)
         self.device = int(device)
+        self.handle = C.c_void_p()
+        if compiler == "native":
+            if self.num_shapes != 1 or self.xml is None or tables is not None:
+                raise ValueError("compiler='native' takes one MJCF text and the reference's gain table")
+            names = (C.c_char_p * len(contact_bodies))(*[n.encode() for n in contact_bodies])
+            opt = _cabi.MjcfOptions(_cabi.CONTROL_MODES[control_mode], int(bool(clip_actions)), pdp_scale, pdd_scale, 1.0 / sim_timestep_inv,
+                                    len(contact_bodies), names)
+            txt = self.xml.encode()
+            _check(lib().ss_model_create_from_mjcf(txt, len(txt), C.byref(opt), self.device, C.byref(self.handle)))
+            return
+        elif compiler != "python":
+            raise ValueError(f"unknown compiler {compiler!r}")
         descs, self._keep = (_cabi.ModelDesc * self.num_shapes)(), []
         for i, mc in enumerate(self.mcs):
             descs[i], keep = _cabi.make_model_desc(mc, *self.tables, legal_bodies=tuple(contact_bodies), timestep=1.0 / sim_timestep_inv)
             self._keep.append(keep)
-        self.handle = C.c_void_p()
         _check(lib().ss_model_create_shapes(descs, self.num_shapes, self.device, C.byref(self.handle)))
 
     def __del__(self):

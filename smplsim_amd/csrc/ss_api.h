@@ -9,10 +9,16 @@
 #include <new>
 #include <string>
 
+#include "ss_mjcf.h"
 #include "ss_tables.h"
 
 namespace ss {
 inline std::string &last_error() { static thread_local std::string e; return e; }
+inline std::string *&error_slot() { static thread_local std::string *p = nullptr; return p; }   // the handle the running entry works on
+struct HandleScope {                      // entries that take a handle also record their error message in it (ss_batch_last_error)
+  explicit HandleScope(std::string *slot) { error_slot() = slot; }
+  ~HandleScope() { error_slot() = nullptr; }
+};
 }  // namespace ss
 
 struct ss_model {
@@ -24,6 +30,7 @@ struct ss_model {
   int32_t *d_pairs = nullptr;             // body-body candidate pairs, geom table (self_collision batches)
   ss::real *d_geomc = nullptr;
   int num_shapes = 1;                     // ss_model_create_shapes: d_bodyc / d_candc hold num_shapes consecutive tables (ss_hdr.h)
+  mutable std::string err;                // message of the last failed call that took this handle
 };
 struct ss_batch {
   const ss_model *m = nullptr;
@@ -41,11 +48,16 @@ struct ss_batch {
   static const ss::real *R(const float *p) { return reinterpret_cast<const ss::real *>(p); }
   float *dbg_self = nullptr;              // caller-owned, optional (ss_debug_self_contacts)
   int fixed_envs_per_wg = 0, max_wgs = 0; // ss_set_launch_geometry: 0 = automatic (small batches are spread over all CUs)
+  mutable std::string err;                // message of the last failed call that took this handle
 };
 
 template <class BE>
 struct ss_api {
-  static int fail(int code, const std::string &msg) { ss::last_error() = msg; return code; }
+  static int fail(int code, const std::string &msg) {
+    ss::last_error() = msg;
+    if (ss::error_slot()) *ss::error_slot() = msg;
+    return code;
+  }
 
   static int model_create(const ss_model_desc *d, int device, ss_model **out) {
     if (!d || !out) return fail(SS_ERR_INVALID, "null argument");
@@ -235,6 +247,7 @@ struct ss_api {
   int ss_model_create_shapes(const ss_model_desc *d, int32_t n, int dev, ss_model **out) { return ss_api<BE>::model_create_shapes(d, n, dev, out); } \
   void ss_model_destroy(ss_model *m) { ss_api<BE>::model_destroy(m); }                                               \
   int ss_model_dims(const ss_model *m, int32_t *nq, int32_t *nv, int32_t *nu, int32_t *nb) {                          \
+    ss::HandleScope hs_(m ? &m->err : nullptr);                                                                      \
     if (!m) return ss_api<BE>::fail(SS_ERR_INVALID, "null model");                                                   \
     if (nq) *nq = m->hm.h.nq;                                                                                        \
     if (nv) *nv = m->hm.h.nv;                                                                                        \
@@ -243,26 +256,26 @@ struct ss_api {
     return SS_OK;                                                                                                    \
   }                                                                                                                  \
   int ss_obs_size(const ss_model *m, const ss_env_cfg *c) { return (m && c) ? ss::obs_size(m->hm.h, *c) : SS_ERR_INVALID; } \
-  int ss_batch_create(const ss_model *m, const ss_env_cfg *c, const ss_state *s, ss_batch **o) { return ss_api<BE>::batch_create(m, c, s, o); } \
+  int ss_batch_create(const ss_model *m, const ss_env_cfg *c, const ss_state *s, ss_batch **o) { ss::HandleScope hs_(m ? &m->err : nullptr); return ss_api<BE>::batch_create(m, c, s, o); } \
   void ss_batch_destroy(ss_batch *b) { if (b) { BE::free_(b->d_counter); BE::free_(b->d_prof); BE::free_(b->d_sched); delete b; } }          \
-  int ss_set_order(ss_batch *b, const int32_t *order) {                                                              \
+  int ss_set_order(ss_batch *b, const int32_t *order) { ss::HandleScope hs_(b ? &b->err : nullptr);                                                              \
     if (!b) return ss_api<BE>::fail(SS_ERR_INVALID, "null batch");                                                  \
     b->order = order; return SS_OK;                                                                                  \
   }                                                                                                                  \
-  int ss_set_launch_geometry(ss_batch *b, int32_t envs_per_wg, int32_t max_workgroups) {                              \
+  int ss_set_launch_geometry(ss_batch *b, int32_t envs_per_wg, int32_t max_workgroups) { ss::HandleScope hs_(b ? &b->err : nullptr);                              \
     if (!b || envs_per_wg < 0 || envs_per_wg > b->envs_per_wg || max_workgroups < 0)                                   \
       return ss_api<BE>::fail(SS_ERR_INVALID, "envs per workgroup must be in [0, ss_launch_info's value], max_workgroups >= 0"); \
     b->fixed_envs_per_wg = envs_per_wg; b->max_wgs = max_workgroups; return SS_OK;                                     \
   }                                                                                                                  \
-  int ss_set_body_outputs(ss_batch *b, float *xpos, float *xmat) {                                                    \
+  int ss_set_body_outputs(ss_batch *b, float *xpos, float *xmat) { ss::HandleScope hs_(b ? &b->err : nullptr);                                                    \
     if (!b || (!xpos) != (!xmat)) return ss_api<BE>::fail(SS_ERR_INVALID, "pass both buffers or neither");           \
     b->body_xpos = xpos; b->body_xmat = xmat; return SS_OK;                                                          \
   }                                                                                                                  \
-  int ss_debug_self_contacts(ss_batch *b, float *records) {                                                           \
+  int ss_debug_self_contacts(ss_batch *b, float *records) { ss::HandleScope hs_(b ? &b->err : nullptr);                                                           \
     if (!b) return ss_api<BE>::fail(SS_ERR_INVALID, "null batch");                                                  \
     b->dbg_self = records; return SS_OK;                                                                             \
   }                                                                                                                  \
-  int ss_schedule_longest_first(ss_batch *b, void *stream) {                                                        \
+  int ss_schedule_longest_first(ss_batch *b, void *stream) { ss::HandleScope hs_(b ? &b->err : nullptr);                                                        \
     if (!b) return ss_api<BE>::fail(SS_ERR_INVALID, "null batch");                                                  \
     if (!BE::set_device(b->m->device)) return ss_api<BE>::fail(SS_ERR_HIP, "cannot select device");                  \
     if (!b->d_sched) b->d_sched = (int32_t *)BE::alloc(sizeof(int32_t) * (size_t)b->st.num_envs);                      \
@@ -278,18 +291,18 @@ struct ss_api {
     const char *err = BE::gae(rew, nd, ndead, val, boot, T, N, gamma, tau, adv, ret, stream);                         \
     return err ? ss_api<BE>::fail(SS_ERR_HIP, err) : SS_OK;                                                          \
   }                                                                                                                  \
-  int ss_debug_prof(ss_batch *b, unsigned long long *out, int n) {                                                   \
+  int ss_debug_prof(ss_batch *b, unsigned long long *out, int n) { ss::HandleScope hs_(b ? &b->err : nullptr);                                                   \
     if (!b || !out || !b->d_prof) return ss_api<BE>::fail(SS_ERR_INVALID, "not a profiling build");                 \
     return BE::download(out, b->d_prof, (size_t)n * 8) ? SS_OK : SS_ERR_HIP;                                         \
   }                                                                   \
-  int ss_reset(ss_batch *b, const uint8_t *mask, const float *fa, const float *tr, float *obs, void *st) { return ss_api<BE>::reset(b, mask, fa, tr, obs, st); } \
-  int ss_step(ss_batch *b, const float *a, const float *tr, float *obs, float *rew, uint8_t *te, uint8_t *tu, void *st) { return ss_api<BE>::step(b, a, tr, obs, rew, te, tu, st); } \
+  int ss_reset(ss_batch *b, const uint8_t *mask, const float *fa, const float *tr, float *obs, void *st) { ss::HandleScope hs_(b ? &b->err : nullptr); return ss_api<BE>::reset(b, mask, fa, tr, obs, st); } \
+  int ss_step(ss_batch *b, const float *a, const float *tr, float *obs, float *rew, uint8_t *te, uint8_t *tu, void *st) { ss::HandleScope hs_(b ? &b->err : nullptr); return ss_api<BE>::step(b, a, tr, obs, rew, te, tu, st); } \
   int ss_step_autoreset(ss_batch *b, const float *a, const float *tr, const float *tr2, float *obs, float *obs_next, float *rew, \
-                        uint8_t *te, uint8_t *tu, void *st) { return ss_api<BE>::step_autoreset(b, a, tr, tr2, obs, obs_next, rew, te, tu, st); } \
-  int ss_substep(ss_batch *b, const float *a, int n, void *st) { return ss_api<BE>::substep(b, a, n, st); }          \
-  int ss_kinematics(ss_batch *b, float *xpos, float *xmat, void *st) { return ss_api<BE>::kinematics(b, xpos, xmat, st); } \
-  int ss_debug_forward(ss_batch *b, const float *tq, float *M, float *bias, float *qacc, void *st) { return ss_api<BE>::debug_forward(b, tq, M, bias, qacc, st); } \
-  int ss_launch_info(const ss_batch *b, int32_t *epw, int32_t *lds, int32_t *regs) {                                 \
+                        uint8_t *te, uint8_t *tu, void *st) { ss::HandleScope hs_(b ? &b->err : nullptr); return ss_api<BE>::step_autoreset(b, a, tr, tr2, obs, obs_next, rew, te, tu, st); } \
+  int ss_substep(ss_batch *b, const float *a, int n, void *st) { ss::HandleScope hs_(b ? &b->err : nullptr); return ss_api<BE>::substep(b, a, n, st); }          \
+  int ss_kinematics(ss_batch *b, float *xpos, float *xmat, void *st) { ss::HandleScope hs_(b ? &b->err : nullptr); return ss_api<BE>::kinematics(b, xpos, xmat, st); } \
+  int ss_debug_forward(ss_batch *b, const float *tq, float *M, float *bias, float *qacc, void *st) { ss::HandleScope hs_(b ? &b->err : nullptr); return ss_api<BE>::debug_forward(b, tq, M, bias, qacc, st); } \
+  int ss_launch_info(const ss_batch *b, int32_t *epw, int32_t *lds, int32_t *regs) { ss::HandleScope hs_(b ? &b->err : nullptr);                                 \
     if (!b) return ss_api<BE>::fail(SS_ERR_INVALID, "null batch");                                                   \
     if (epw) *epw = b->envs_per_wg;                                                                                  \
     if (lds) *lds = (int32_t)b->lds_bytes;                                                                           \
@@ -297,4 +310,12 @@ struct ss_api {
     return SS_OK;                                                                                                    \
   }                                                                                                                  \
   const char *ss_last_error(void) { return ss::last_error().c_str(); }                                               \
+  const char *ss_model_last_error(const ss_model *m) { return m ? m->err.c_str() : ""; }                               \
+  const char *ss_batch_last_error(const ss_batch *b) { return b ? b->err.c_str() : ""; }                               \
+  int ss_model_create_from_mjcf(const char *xml, size_t len, const ss_mjcf_options *opt, int dev, ss_model **out) {   \
+    if (!xml || !out) return ss_api<BE>::fail(SS_ERR_INVALID, "null argument");                                      \
+    ss::mjcf::Compiled c; std::string e;                                                                             \
+    if (!ss::mjcf::compile(xml, len ? len : std::strlen(xml), opt, c, e)) return ss_api<BE>::fail(SS_ERR_INVALID, "MJCF: " + e); \
+    return ss_api<BE>::model_create(&c.desc, dev, out);                                                              \
+  }                                                                                                                  \
   }

@@ -1,0 +1,392 @@
+// ss_mjcf.h — MJCF text -> ss_model_desc inside the library: ss_model_create_from_mjcf (include/smplsim_hip.h).
+//
+// The C/C++ twin of smplsim_amd/mjcf.py + gains.py for hosts that do not run Python: what the reference gets from
+// mujoco.MjModel.from_xml_string (smpl_sim/envs/base_env.py:139-142) and HumanoidEnv.setup_humanoid_properties /
+// build_pd_action_scale (humanoid_env.py:262-370) for the MJCF subset its humanoids use — one free-floating root body, three
+// x/y/z hinges per further body at the body origin, one box or capsule (fromto) geom per body whose density gives mass and
+// inertia, a z = 0 floor plane, <motor> actuators, <contact><exclude>, compiler defaults (local coordinates, degrees).
+// Everything outside that subset is an error, like in the Python compiler.  Host-only, standard library only.
+#pragma once
+#include <cmath>
+#include <cctype>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/smplsim_hip.h"
+
+namespace ss {
+namespace mjcf {
+
+struct Node {
+  std::string tag;
+  std::vector<std::pair<std::string, std::string>> attrs;
+  std::vector<std::unique_ptr<Node>> kids;
+  const char *get(const char *k) const { for (auto &a : attrs) if (a.first == k) return a.second.c_str(); return nullptr; }
+  std::string gets(const char *k, const char *dflt) const { const char *v = get(k); return v ? v : dflt; }
+  const Node *child(const char *t) const { for (auto &c : kids) if (c->tag == t) return c.get(); return nullptr; }
+  std::vector<const Node *> children(const char *t) const { std::vector<const Node *> o; for (auto &c : kids) if (c->tag == t) o.push_back(c.get()); return o; }
+};
+
+// minimal XML reader: elements, attributes (single / double quotes), comments, <?...?> ; no entities, no text nodes
+struct Parser {
+  const char *p, *end;
+  std::string err;
+  void skip() {
+    for (;;) {
+      while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) p++;
+      if (end - p >= 4 && !std::strncmp(p, "<!--", 4)) { const char *q = p + 4; while (q + 2 < end && std::strncmp(q, "-->", 3)) q++; p = q + 3 <= end ? q + 3 : end; continue; }
+      if (end - p >= 2 && !std::strncmp(p, "<?", 2)) { while (p + 1 < end && std::strncmp(p, "?>", 2)) p++; p = p + 2 <= end ? p + 2 : end; continue; }
+      return;
+    }
+  }
+  static bool namech(char c) { return std::isalnum((unsigned char)c) || c == '_' || c == '-' || c == ':' || c == '.'; }
+  std::unique_ptr<Node> element() {
+    skip();
+    if (p >= end || *p != '<') { err = "XML parse error: expected '<'"; return nullptr; }
+    p++;
+    auto n = std::make_unique<Node>();
+    while (p < end && namech(*p)) n->tag += *p++;
+    if (n->tag.empty()) { err = "XML parse error: empty tag"; return nullptr; }
+    for (;;) {
+      while (p < end && std::isspace((unsigned char)*p)) p++;
+      if (p >= end) { err = "XML parse error: unexpected end"; return nullptr; }
+      if (*p == '/') { if (p + 1 < end && p[1] == '>') { p += 2; return n; } err = "XML parse error: stray '/'"; return nullptr; }
+      if (*p == '>') { p++; break; }
+      std::string k, v;
+      while (p < end && namech(*p)) k += *p++;
+      while (p < end && std::isspace((unsigned char)*p)) p++;
+      if (k.empty() || p >= end || *p != '=') { err = "XML parse error: attribute of <" + n->tag + ">"; return nullptr; }
+      p++;
+      while (p < end && std::isspace((unsigned char)*p)) p++;
+      if (p >= end || (*p != '"' && *p != '\'')) { err = "XML parse error: attribute value of " + k; return nullptr; }
+      const char qc = *p++;
+      while (p < end && *p != qc) v += *p++;
+      if (p >= end) { err = "XML parse error: unterminated attribute value"; return nullptr; }
+      p++;
+      n->attrs.emplace_back(k, v);
+    }
+    for (;;) {                                               // children until the closing tag; text content is skipped
+      skip();
+      while (p < end && *p != '<') p++;
+      if (p >= end) { err = "XML parse error: <" + n->tag + "> not closed"; return nullptr; }
+      if (p + 1 < end && p[1] == '/') {
+        p += 2;
+        std::string t;
+        while (p < end && namech(*p)) t += *p++;
+        while (p < end && *p != '>') p++;
+        if (p < end) p++;
+        if (t != n->tag) { err = "XML parse error: </" + t + "> closes <" + n->tag + ">"; return nullptr; }
+        return n;
+      }
+      if (end - p >= 4 && !std::strncmp(p, "<!--", 4)) { skip(); continue; }
+      auto c = element();
+      if (!c) return nullptr;
+      n->kids.push_back(std::move(c));
+    }
+  }
+};
+
+inline bool floats(const std::string &s, int n, double *out, std::string &err, const char *what) {
+  const char *p = s.c_str();
+  int k = 0;
+  while (*p) {
+    while (*p && std::isspace((unsigned char)*p)) p++;
+    if (!*p) break;
+    char *e;
+    double v = std::strtod(p, &e);
+    if (e == p) { err = std::string("bad number in ") + what; return false; }
+    if (k < n) out[k] = v;
+    k++; p = e;
+  }
+  if (k != n) { err = std::string(what) + ": expected " + std::to_string(n) + " numbers"; return false; }
+  return true;
+}
+
+// everything ss_model_desc points at
+struct Compiled {
+  int nb = 0, nv = 0, nu = 0;
+  std::vector<std::string> names, jnames, anames;
+  std::vector<int32_t> parent, gtype, adof, contype, conaff, excl;
+  std::vector<double> pos, mass, ipos, iquat, inertia, gsize, gpos, gquat, arm, jrange, binvw, dinvw, qpos0, kp, kd, tlim, ascale, aoff;
+  std::vector<uint8_t> jlimited, legal;
+  double margin = 0, friction = 1;
+  ss_model_desc desc{};
+};
+
+inline void z_to_quat(const double *v, double *q) {           // minimal rotation of +z onto v (MuJoCo's fromto convention)
+  const double n = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  const double u[3] = {v[0] / n, v[1] / n, v[2] / n};
+  double ax[3] = {-u[1], u[0], 0.0};                          // z x u
+  const double s = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1]);
+  if (s < 1e-10) { ax[0] = 1; ax[1] = 0; } else { ax[0] /= s; ax[1] /= s; }
+  const double ang = std::atan2(s, u[2]);
+  q[0] = std::cos(ang / 2); q[1] = ax[0] * std::sin(ang / 2); q[2] = ax[1] * std::sin(ang / 2); q[3] = 0;
+}
+
+inline bool body_gain(const std::string &body, double *g) {    // GAINS["stablepd"], humanoid_env.py:62-84 (+ finger rows of GAINS_PHC)
+  static const struct { const char *n; double kp, kd, lim; } T[] = {
+      {"L_Hip", 800, 80, 1000}, {"L_Knee", 800, 80, 1000}, {"L_Ankle", 800, 80, 1000}, {"R_Hip", 800, 80, 1000}, {"R_Knee", 800, 80, 1000},
+      {"R_Ankle", 800, 80, 1000}, {"L_Toe", 500, 50, 500}, {"R_Toe", 500, 50, 500}, {"Torso", 1000, 100, 500}, {"Spine", 1000, 100, 500},
+      {"Chest", 1000, 100, 500}, {"Neck", 500, 50, 250}, {"Head", 500, 50, 250}, {"L_Elbow", 500, 50, 250}, {"R_Elbow", 500, 50, 250},
+      {"L_Thorax", 500, 50, 1000}, {"L_Shoulder", 500, 50, 1000}, {"R_Thorax", 500, 50, 1000}, {"R_Shoulder", 500, 50, 1000},
+      {"L_Wrist", 300, 30, 250}, {"L_Hand", 300, 30, 250}, {"R_Wrist", 300, 30, 250}, {"R_Hand", 300, 30, 250}};
+  for (auto &t : T) if (body == t.n) { g[0] = t.kp; g[1] = t.kd; g[2] = t.lim; return true; }
+  const size_t us = body.find('_');
+  if (us != std::string::npos) {
+    std::string f = body.substr(us + 1);
+    while (!f.empty() && (f.back() == '1' || f.back() == '2' || f.back() == '3')) f.pop_back();
+    for (const char *fn : {"Index", "Middle", "Pinky", "Ring", "Thumb"}) if (f == fn) { g[0] = 100; g[1] = 10; g[2] = 150; return true; }
+  }
+  return false;
+}
+
+inline bool compile(const char *xml, size_t len, const ss_mjcf_options *opt, Compiled &c, std::string &err) {
+  Parser ps{xml, xml + len, ""};
+  auto root = ps.element();
+  if (!root) { err = ps.err; return false; }
+  if (root->tag != "mujoco") { err = "root element must be <mujoco>"; return false; }
+  if (const Node *comp = root->child("compiler")) {
+    if (comp->gets("coordinate", "local") != "local") { err = "only coordinate='local' is supported"; return false; }
+    if (comp->gets("angle", "degree") != "degree") { err = "only angle='degree' (the compiler default) is supported"; return false; }
+  }
+  if (const Node *o = root->child("option")) if (!o->attrs.empty()) { err = "<option> overrides are not supported (the env sets opt.timestep itself)"; return false; }
+  std::map<std::string, std::string> dj, dg;
+  if (const Node *d = root->child("default")) {
+    if (d->child("default")) { err = "nested default classes are not supported"; return false; }
+    if (const Node *j = d->child("joint")) for (auto &a : j->attrs) dj[a.first] = a.second;
+    if (const Node *g = d->child("geom")) for (auto &a : g->attrs) dg[a.first] = a.second;
+  }
+  auto merged = [](const std::map<std::string, std::string> &d, const Node *n) { auto m = d; for (auto &a : n->attrs) m[a.first] = a.second; return m; };
+  auto mget = [](const std::map<std::string, std::string> &m, const char *k, const char *dflt) { auto it = m.find(k); return it == m.end() ? std::string(dflt) : it->second; };
+  const Node *wb = root->child("worldbody");
+  if (!wb) { err = "missing <worldbody>"; return false; }
+  const Node *floor = nullptr;
+  int nplanes = 0;
+  for (auto g : wb->children("geom")) if (g->gets("type", "") == "plane") { floor = g; nplanes++; }
+  if (nplanes != 1) { err = "exactly one floor plane geom is required in <worldbody>"; return false; }
+  { double fp[3]; if (!floats(floor->gets("pos", "0 0 0"), 3, fp, err, "floor pos")) return false;
+    if (fp[0] != 0 || fp[1] != 0 || fp[2] != 0 || floor->get("quat") || floor->get("zaxis")) { err = "floor plane must be z=0 with identity orientation"; return false; } }
+  auto top = wb->children("body");
+  if (top.size() != 1) { err = "exactly one root body is required"; return false; }
+  std::vector<double> gmargin, gfric;
+  bool ok = true;
+  std::function<void(const Node *, int)> add_body = [&](const Node *b, int par) {
+    if (!ok) return;
+    const int idx = (int)c.names.size();
+    const std::string bname = b->gets("name", "");
+    c.names.push_back(bname); c.parent.push_back(par);
+    double v3[3], v4[4];
+    if (!floats(b->gets("pos", "0 0 0"), 3, v3, err, "body pos")) { ok = false; return; }
+    c.pos.insert(c.pos.end(), v3, v3 + 3);
+    if (b->get("quat")) { if (!floats(b->get("quat"), 4, v4, err, "body quat")) { ok = false; return; }
+      if (std::fabs(v4[0] - 1) > 1e-8 || std::fabs(v4[1]) > 1e-8 || std::fabs(v4[2]) > 1e-8 || std::fabs(v4[3]) > 1e-8) { err = "body " + bname + ": non-identity body quat is not supported"; ok = false; return; } }
+    if (b->child("inertial")) { err = "explicit <inertial> is not supported (inertia comes from the geom)"; ok = false; return; }
+    const Node *fj = b->child("freejoint");
+    auto joints = b->children("joint");
+    if (par < 0) {
+      if (!fj || !joints.empty()) { err = "the root body must carry exactly one <freejoint>"; ok = false; return; }
+      for (int k = 0; k < 6; k++) { c.arm.push_back(0); c.jrange.push_back(-INFINITY); c.jrange.push_back(INFINITY); c.jlimited.push_back(0); }
+    } else {
+      if (fj || joints.size() != 3) { err = "body " + bname + ": expected exactly 3 hinge joints"; ok = false; return; }
+      for (int k = 0; k < 3; k++) {
+        auto a = merged(dj, joints[k]);
+        const std::string jn = mget(a, "name", "");
+        if (mget(a, "type", "hinge") != "hinge") { err = "joint " + jn + ": only hinge joints are supported"; ok = false; return; }
+        double jp[3], ax[3];
+        if (!floats(mget(a, "pos", "0 0 0"), 3, jp, err, "joint pos") || !floats(mget(a, "axis", "0 0 1"), 3, ax, err, "joint axis")) { ok = false; return; }
+        if (jp[0] != 0 || jp[1] != 0 || jp[2] != 0) { err = "joint " + jn + ": joint anchor must be the body origin"; ok = false; return; }
+        for (int i = 0; i < 3; i++) if (ax[i] != (i == k ? 1.0 : 0.0)) { err = "joint " + jn + ": hinge axes must be x, y, z in this order"; ok = false; return; }
+        if (std::atof(mget(a, "damping", "0").c_str()) != 0 || std::atof(mget(a, "stiffness", "0").c_str()) != 0 || std::atof(mget(a, "frictionloss", "0").c_str()) != 0) {
+          err = "joint " + jn + ": passive damping/stiffness/frictionloss not supported"; ok = false; return; }
+        c.arm.push_back(std::atof(mget(a, "armature", "0").c_str()));
+        const std::string lim = mget(a, "limited", "auto");
+        const bool has_range = a.count("range") > 0;
+        double r2[2] = {0, 0};
+        if (has_range) { if (!floats(a["range"], 2, r2, err, "joint range")) { ok = false; return; } r2[0] *= M_PI / 180.0; r2[1] *= M_PI / 180.0; }
+        c.jrange.push_back(r2[0]); c.jrange.push_back(r2[1]);
+        c.jlimited.push_back((lim == "true" || (lim == "auto" && has_range)) ? 1 : 0);
+        c.jnames.push_back(jn);
+      }
+    }
+    auto geoms = b->children("geom");
+    if (geoms.size() != 1) { err = "body " + bname + ": exactly one geom per body is supported"; ok = false; return; }
+    auto g = merged(dg, geoms[0]);
+    int t;
+    double size[3] = {0, 0, 0}, gp[3] = {0, 0, 0}, gq[4] = {1, 0, 0, 0};
+    const std::string gt = mget(g, "type", "sphere");
+    if (gt == "box") {
+      t = SS_GEOM_BOX;
+      if (!floats(mget(g, "size", ""), 3, size, err, "box size") || !floats(mget(g, "pos", "0 0 0"), 3, gp, err, "geom pos") ||
+          !floats(mget(g, "quat", "1 0 0 0"), 4, gq, err, "geom quat")) { ok = false; return; }
+      const double n = std::sqrt(gq[0] * gq[0] + gq[1] * gq[1] + gq[2] * gq[2] + gq[3] * gq[3]);
+      for (int i = 0; i < 4; i++) gq[i] /= n;
+    } else if (gt == "capsule") {
+      t = SS_GEOM_CAPSULE;
+      if (!g.count("fromto")) { err = "capsules must be given by fromto"; ok = false; return; }
+      double ft[6], r1[3];
+      { const std::string sz = mget(g, "size", ""); char *e; r1[0] = std::strtod(sz.c_str(), &e); if (e == sz.c_str()) { err = "capsule size"; ok = false; return; } }
+      if (!floats(g["fromto"], 6, ft, err, "fromto")) { ok = false; return; }
+      const double vec[3] = {ft[3] - ft[0], ft[4] - ft[1], ft[5] - ft[2]};
+      size[0] = r1[0]; size[1] = 0.5 * std::sqrt(vec[0] * vec[0] + vec[1] * vec[1] + vec[2] * vec[2]);
+      for (int i = 0; i < 3; i++) gp[i] = 0.5 * (ft[i] + ft[3 + i]);
+      z_to_quat(vec, gq);
+    } else { err = "geom type '" + gt + "' is not supported"; ok = false; return; }
+    if (std::atoi(mget(g, "condim", "3").c_str()) != 3) { err = "only condim=3 is supported"; ok = false; return; }
+    const double dens = std::atof(mget(g, "density", "1000").c_str());
+    double m, in3[3];
+    if (t == SS_GEOM_BOX) {
+      m = dens * 8.0 * size[0] * size[1] * size[2];
+      in3[0] = m / 3 * (size[1] * size[1] + size[2] * size[2]); in3[1] = m / 3 * (size[0] * size[0] + size[2] * size[2]); in3[2] = m / 3 * (size[0] * size[0] + size[1] * size[1]);
+    } else {
+      const double r = size[0], h = 2.0 * size[1], mc = dens * M_PI * r * r * h, ms = dens * 4.0 / 3.0 * M_PI * r * r * r;
+      const double ip = mc * (3 * r * r + h * h) / 12 + 0.4 * ms * r * r + ms * h * (3 * r + 2 * h) / 8;
+      m = mc + ms; in3[0] = in3[1] = ip; in3[2] = mc * r * r / 2 + 0.4 * ms * r * r;
+    }
+    c.gtype.push_back(t); c.gsize.insert(c.gsize.end(), size, size + 3); c.gpos.insert(c.gpos.end(), gp, gp + 3); c.gquat.insert(c.gquat.end(), gq, gq + 4);
+    c.mass.push_back(m); c.ipos.insert(c.ipos.end(), gp, gp + 3); c.iquat.insert(c.iquat.end(), gq, gq + 4); c.inertia.insert(c.inertia.end(), in3, in3 + 3);
+    gmargin.push_back(std::atof(mget(g, "margin", "0").c_str()));
+    { double fr[3] = {1, 0.005, 0.0001}; const std::string fs = mget(g, "friction", "1 0.005 0.0001"); char *e; fr[0] = std::strtod(fs.c_str(), &e); gfric.push_back(fr[0]); }
+    c.contype.push_back(std::atoi(mget(g, "contype", "1").c_str())); c.conaff.push_back(std::atoi(mget(g, "conaffinity", "1").c_str()));
+    for (auto cb : b->children("body")) add_body(cb, idx);
+  };
+  add_body(top[0], -1);
+  if (!ok) return false;
+  const int nb = c.nb = (int)c.names.size(), nv = c.nv = 6 + 3 * (nb - 1);
+  {
+    auto fa = merged(dg, floor);
+    double mmax = std::atof(mget(fa, "margin", "0").c_str()), fmax = 0;
+    { const std::string fs = mget(fa, "friction", "1 0.005 0.0001"); char *e; fmax = std::strtod(fs.c_str(), &e); }
+    for (size_t i = 0; i < gmargin.size(); i++) {
+      if (gmargin[i] != gmargin[0] || gfric[i] != gfric[0]) { err = "per-geom margin/friction variation is not supported"; return false; }
+      mmax = std::max(mmax, gmargin[i]); fmax = std::max(fmax, gfric[i]);
+    }
+    c.margin = mmax; c.friction = fmax;
+  }
+  if (const Node *act = root->child("actuator"))
+    for (auto &m_ : act->kids) {
+      if (m_->tag != "motor") { err = "only <motor> actuators are supported"; return false; }
+      if (m_->get("ctrlrange") || m_->gets("ctrllimited", "") == "true" || m_->get("forcerange")) { err = "actuator ctrl/force ranges are not supported"; return false; }
+      const std::string jn = m_->gets("joint", "");
+      int dof = -1;
+      for (size_t j = 0; j < c.jnames.size(); j++) if (c.jnames[j] == jn) dof = 6 + (int)j;
+      if (dof < 0) { err = "motor " + m_->gets("name", "") + ": unknown joint " + jn; return false; }
+      c.anames.push_back(m_->gets("name", "")); c.adof.push_back(dof);
+    }
+  c.nu = (int)c.anames.size();
+  if (const Node *con = root->child("contact"))
+    for (auto e : con->children("exclude")) {
+      int a = -1, b = -1;
+      for (int i = 0; i < nb; i++) { if (c.names[i] == e->gets("body1", "")) a = i; if (c.names[i] == e->gets("body2", "")) b = i; }
+      if (a < 0 || b < 0) { err = "<exclude>: unknown body"; return false; }
+      c.excl.push_back(a); c.excl.push_back(b);
+    }
+  c.qpos0.assign(nv + 1, 0.0);
+  for (int k = 0; k < 3; k++) c.qpos0[k] = c.pos[k];
+  c.qpos0[3] = 1.0;
+
+  // ---- inverse weights at qpos0 (all frames identity): M = sum_b m Jp^T Jp + Jr^T Iw Jr + armature, then diag blocks of J M^-1 J^T
+  std::vector<double> xpos(3 * nb), com(3 * nb), J((size_t)nb * 6 * nv, 0.0), M((size_t)nv * nv, 0.0);
+  for (int b = 0; b < nb; b++) for (int k = 0; k < 3; k++) { xpos[3 * b + k] = c.pos[3 * b + k] + (c.parent[b] >= 0 ? xpos[3 * c.parent[b] + k] : 0.0); com[3 * b + k] = xpos[3 * b + k] + c.ipos[3 * b + k]; }
+  auto Jat = [&](int b, int r, int col) -> double & { return J[((size_t)b * 6 + r) * nv + col]; };
+  for (int b = 0; b < nb; b++) {
+    for (int k = 0; k < 3; k++) Jat(b, k, k) = 1.0;
+    for (int a = b; a >= 0; a = c.parent[a]) {
+      const int base = a == 0 ? 3 : 6 + 3 * (a - 1);
+      const double r[3] = {com[3 * b] - xpos[3 * a], com[3 * b + 1] - xpos[3 * a + 1], com[3 * b + 2] - xpos[3 * a + 2]};
+      for (int k = 0; k < 3; k++) {
+        Jat(b, 3 + k, base + k) = 1.0;
+        double e[3] = {0, 0, 0}; e[k] = 1.0;                   // e_k x r
+        Jat(b, 0, base + k) = e[1] * r[2] - e[2] * r[1]; Jat(b, 1, base + k) = e[2] * r[0] - e[0] * r[2]; Jat(b, 2, base + k) = e[0] * r[1] - e[1] * r[0];
+      }
+    }
+  }
+  for (int b = 0; b < nb; b++) {
+    const double *q = &c.iquat[4 * b];
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                         2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)};
+    double Iw[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += R[3 * i + k] * c.inertia[3 * b + k] * R[3 * j + k]; Iw[3 * i + j] = s; }
+    for (int i = 0; i < nv; i++) for (int j = 0; j <= i; j++) {
+      double s = 0;
+      for (int k = 0; k < 3; k++) s += c.mass[b] * Jat(b, k, i) * Jat(b, k, j);
+      for (int k = 0; k < 3; k++) { const double ji = Jat(b, 3 + k, i); if (ji == 0) continue; for (int l = 0; l < 3; l++) s += ji * Iw[3 * k + l] * Jat(b, 3 + l, j); }
+      M[(size_t)i * nv + j] += s;
+    }
+  }
+  for (int i = 0; i < nv; i++) { M[(size_t)i * nv + i] += c.arm[i]; for (int j = i + 1; j < nv; j++) M[(size_t)i * nv + j] = M[(size_t)j * nv + i]; }
+  std::vector<double> L = M, Minv((size_t)nv * nv, 0.0);       // Cholesky, then the inverse column by column
+  for (int j = 0; j < nv; j++) {
+    double s = L[(size_t)j * nv + j];
+    for (int k = 0; k < j; k++) s -= L[(size_t)j * nv + k] * L[(size_t)j * nv + k];
+    if (s <= 0) { err = "mass matrix at qpos0 is not positive definite"; return false; }
+    const double l = std::sqrt(s);
+    L[(size_t)j * nv + j] = l;
+    for (int i = j + 1; i < nv; i++) { double t_ = L[(size_t)i * nv + j]; for (int k = 0; k < j; k++) t_ -= L[(size_t)i * nv + k] * L[(size_t)j * nv + k]; L[(size_t)i * nv + j] = t_ / l; }
+  }
+  std::vector<double> col(nv);
+  for (int j = 0; j < nv; j++) {
+    std::fill(col.begin(), col.end(), 0.0); col[j] = 1.0;
+    for (int i = 0; i < nv; i++) { double t_ = col[i]; for (int k = 0; k < i; k++) t_ -= L[(size_t)i * nv + k] * col[k]; col[i] = t_ / L[(size_t)i * nv + i]; }
+    for (int i = nv - 1; i >= 0; i--) { double t_ = col[i]; for (int k = i + 1; k < nv; k++) t_ -= L[(size_t)k * nv + i] * col[k]; col[i] = t_ / L[(size_t)i * nv + i]; }
+    for (int i = 0; i < nv; i++) Minv[(size_t)i * nv + j] = col[i];
+  }
+  c.binvw.assign(2 * nb, 0.0); c.dinvw.assign(nv, 0.0);
+  std::vector<double> JM(nv);
+  for (int b = 0; b < nb; b++)
+    for (int r = 0; r < 6; r++) {
+      for (int j = 0; j < nv; j++) { double s = 0; for (int i = 0; i < nv; i++) { const double ji = Jat(b, r, i); if (ji != 0) s += ji * Minv[(size_t)i * nv + j]; } JM[j] = s; }
+      double d = 0; for (int j = 0; j < nv; j++) d += JM[j] * Jat(b, r, j);
+      c.binvw[2 * b + (r < 3 ? 0 : 1)] += d / 3;
+    }
+  for (int i = 0; i < nv; i++) c.dinvw[i] = Minv[(size_t)i * nv + i];
+  for (int g = 0; g < 2; g++) { const double a = (c.dinvw[3 * g] + c.dinvw[3 * g + 1] + c.dinvw[3 * g + 2]) / 3; c.dinvw[3 * g] = c.dinvw[3 * g + 1] = c.dinvw[3 * g + 2] = a; }
+
+  // ---- gains, torque limits, action scaling (build_pd_action_scale / setup_controller)
+  const int mode = opt ? opt->control_mode : SS_CTRL_UHC_PD;
+  const bool clip = opt ? opt->clip_actions != 0 : true;
+  const double pdp = opt && opt->pdp_scale > 0 ? opt->pdp_scale : 1.0, pdd = opt && opt->pdd_scale > 0 ? opt->pdd_scale : 1.0;
+  c.kp.assign(c.nu, 0); c.kd.assign(c.nu, 0); c.tlim.assign(c.nu, 0); c.ascale.assign(c.nu, 1); c.aoff.assign(c.nu, 0);
+  for (int i = 0; i < c.nu; i++) {
+    const int dof = c.adof[i];
+    const double lo = c.jrange[2 * dof], hi = c.jrange[2 * dof + 1];
+    const double s = std::min(1.2 * std::max(std::fabs(lo), std::fabs(hi)), M_PI);
+    if (clip) { c.ascale[i] = s; c.aoff[i] = 0.0; }
+    if (mode == SS_CTRL_PD || mode == SS_CTRL_UHC_PD || mode == SS_CTRL_SIMPLE_PID) {
+      const std::string &an = c.anames[i];
+      const std::string body = an.substr(0, an.rfind('_'));
+      double g[3];
+      if (!body_gain(body, g)) { err = "no PD gain entry for body '" + body + "'"; return false; }
+      if (mode == SS_CTRL_SIMPLE_PID) { c.kp[i] = g[0] / 10; c.kd[i] = g[1] / 10; } else { c.kp[i] = g[0] / pdp; c.kd[i] = g[1] / pdd; }
+      c.tlim[i] = g[2];
+    }
+  }
+  c.legal.assign(nb, 0);
+  static const char *feet[] = {"R_Ankle", "L_Ankle", "R_Toe", "L_Toe"};
+  const int ncb = opt && opt->contact_bodies ? opt->num_contact_bodies : 4;
+  const char *const *cb = opt && opt->contact_bodies ? opt->contact_bodies : feet;
+  for (int i = 0; i < ncb; i++) for (int b = 0; b < nb; b++) if (c.names[b] == cb[i]) c.legal[b] = 1;
+
+  ss_model_desc &d = c.desc;
+  d.nbody = nb; d.body_parent = c.parent.data(); d.body_pos = c.pos.data(); d.body_mass = c.mass.data(); d.body_ipos = c.ipos.data();
+  d.body_iquat = c.iquat.data(); d.body_inertia = c.inertia.data(); d.geom_type = c.gtype.data(); d.geom_size = c.gsize.data();
+  d.geom_pos = c.gpos.data(); d.geom_quat = c.gquat.data(); d.dof_armature = c.arm.data(); d.jnt_range = c.jrange.data();
+  d.jnt_limited = c.jlimited.data(); d.body_invweight0 = c.binvw.data(); d.dof_invweight0 = c.dinvw.data(); d.qpos0 = c.qpos0.data();
+  d.nu = c.nu; d.actuator_dof = c.adof.data(); d.kp = c.kp.data(); d.kd = c.kd.data(); d.torque_lim = c.tlim.data(); d.act_scale = c.ascale.data();
+  d.act_offset = c.aoff.data(); d.legal_contact = c.legal.data();
+  d.timestep = opt && opt->timestep > 0 ? opt->timestep : 1.0 / 450; d.gravity = -9.81;
+  d.solref[0] = 0.02; d.solref[1] = 1.0;
+  const double si[5] = {0.9, 0.95, 0.001, 0.5, 2.0};
+  for (int k = 0; k < 5; k++) d.solimp[k] = si[k];
+  d.margin = c.margin; d.friction = c.friction; d.impratio = 1.0;
+  d.geom_contype = c.contype.data(); d.geom_conaffinity = c.conaff.data(); d.nexclude = (int)c.excl.size() / 2; d.exclude = c.excl.empty() ? nullptr : c.excl.data();
+  return true;
+}
+
+}  // namespace mjcf
+}  // namespace ss

@@ -124,6 +124,20 @@ def test_task_envs_teacher_forced(vec, task, init):
     _record(f"teacher_forced_{task}_{init}", qpos=worst[0], qvel=worst[1], obs=worst[2], reward=worst[3])
 
 
+def test_native_mjcf_entry_on_gpu(vec):
+    """ss_model_create_from_mjcf (the library's own MJCF compiler + gain tables): the same stepping, bit for bit, as the model
+    the Python host compiler describes."""
+    from smplsim_amd.batch import ShardModel
+    a = vec(3, model=ShardModel(humanoid="smplx_humanoid"), autoreset=False, seed=5)
+    b = vec(3, model=ShardModel(humanoid="smplx_humanoid", compiler="native"), autoreset=False, seed=5)
+    assert torch.equal(a.reset()[0], b.reset()[0])
+    g = torch.Generator().manual_seed(0)
+    for _ in range(3):
+        act = (torch.rand(3, 153, generator=g) - 0.5).to(a.device)
+        ra, rb = a.step(act), b.step(act)
+        assert torch.equal(ra[0], rb[0]) and torch.equal(ra[1], rb[1]) and torch.equal(a.qpos, b.qpos)
+
+
 def test_smplx_layout(vec):
     from smplsim_amd.batch import ShardModel
     env = vec(4, model=ShardModel(humanoid="smplx_humanoid"), autoreset=False)

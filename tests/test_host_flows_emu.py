@@ -84,6 +84,17 @@ def test_per_env_shapes_through_the_python_api_on_the_emulator(emu_backend):
         SMPLSimVecEnv(2, model=ShardModel(xmls=xmls), shape_id=[0, 5])
 
 
+def test_native_mjcf_compiler_through_the_python_api_on_the_emulator(emu_backend):
+    """ShardModel(compiler="native") = ss_model_create_from_mjcf: the same env, bit for bit, as the Python compiler's model."""
+    from smplsim_amd.batch import ShardModel, SMPLSimVecEnv
+    a = SMPLSimVecEnv(2, model=ShardModel(), autoreset=False, seed=3)
+    b = SMPLSimVecEnv(2, model=ShardModel(compiler="native"), autoreset=False, seed=3)
+    assert torch.equal(a.reset()[0], b.reset()[0])
+    act = torch.linspace(-0.4, 0.4, 2 * 69).reshape(2, 69)
+    ra, rb = a.step(act), b.step(act)
+    assert torch.equal(ra[0], rb[0]) and torch.equal(ra[1], rb[1]) and torch.equal(a.qvel, b.qvel)
+
+
 def test_package_has_no_backend_switch():
     """The emulator is reachable only through the monkeypatches of the fixture: outside it the package holds no CPU device
     or alternative library, and its loader exposes nothing to bind one."""

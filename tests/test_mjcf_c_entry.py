@@ -1,0 +1,89 @@
+"""ss_model_create_from_mjcf: the library's own MJCF-subset compiler + gain tables (smplsim_amd/csrc/ss_mjcf.h) against the
+Python host compiler (smplsim_amd.mjcf.compile_mjcf + gains.build_pd_tables) — the models must step bit-identically on the
+emulator; and the per-handle error strings of the C-ABI (ss_model_last_error / ss_batch_last_error)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN  # noqa: F401  (sys.path set-up)
+from smplsim_amd import _cabi
+from smplsim_amd.gains import build_pd_tables
+from smplsim_amd.mjcf import compile_mjcf
+from smplsim_amd.mjcf_writer import default_xml_str
+from wave_emu.emu import EmuBatch, lib
+
+FEET = ("R_Ankle", "L_Ankle", "R_Toe", "L_Toe")
+
+
+def _tables(mc, **kw):
+    rng = {n: mc.jnt_range[6 + i] for i, n in enumerate(mc.joint_names)}
+    return build_pd_tables(mc.actuator_names, lambda n: rng[n], **kw)
+
+
+def _rollout(b, mc, steps, seed):
+    rs = np.random.default_rng(seed)
+    q = np.tile(mc.qpos0, (b.N, 1)); q[:, 7:] = rs.uniform(-0.4, 0.4, (b.N, mc.nv - 6)); q[:, 2] = 0.95
+    b.set_state(q, rs.normal(size=(b.N, mc.nv)) * 0.3)
+    out = [b.reset()]
+    for _ in range(steps):
+        o, r, te, tr = b.step(rs.uniform(-0.5, 0.5, (b.N, mc.nu)))
+        out += [o, r, b.qpos.copy(), b.qvel.copy()]
+    return out
+
+
+@pytest.mark.parametrize("humanoid", ["smpl_humanoid", "smplx_humanoid"])
+def test_c_compiler_matches_python_compiler(humanoid):
+    xml = default_xml_str(humanoid)
+    mc = compile_mjcf(xml)
+    a = EmuBatch(mc, _tables(mc), 2, legal_bodies=FEET)
+    b = EmuBatch(mc, None, 2, mjcf_text=xml)
+    for x, y in zip(_rollout(a, mc, 2, 1), _rollout(b, mc, 2, 1)):
+        assert np.array_equal(x, y)
+
+
+def test_c_compiler_options():
+    xml = default_xml_str("smpl_humanoid")
+    mc = compile_mjcf(xml)
+    names = (C.c_char_p * 2)(b"L_Toe", b"R_Toe")
+    opt = _cabi.MjcfOptions(_cabi.CTRL_PD, 0, 2.0, 4.0, 1.0 / 300, 2, names)
+    a = EmuBatch(mc, _tables(mc, clip_actions=False, control_mode="pd", pdp_scale=2.0, pdd_scale=4.0), 2, legal_bodies=("L_Toe", "R_Toe"),
+                 timestep=1.0 / 300, control_mode=_cabi.CTRL_PD)
+    b = EmuBatch(mc, None, 2, mjcf_text=xml, mjcf_options=opt, control_mode=_cabi.CTRL_PD)
+    for x, y in zip(_rollout(a, mc, 2, 3), _rollout(b, mc, 2, 3)):
+        assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("edit,msg", [
+    (lambda s: s.replace("<freejoint", "<joint type='ball'", 1).replace("</freejoint>", "</joint>", 1), "freejoint"),
+    (lambda s: s.replace('type="capsule"', 'type="ellipsoid"', 1), "not supported"),
+    (lambda s: s.replace("<mujoco", "<mujoc0", 1), "mujoco"),
+    (lambda s: s[: len(s) // 2], "XML parse error"),
+    (lambda s: s.replace('axis="0.0 1.0 0.0"', 'axis="0 0.7 0.7"', 1), "hinge axes"),
+])
+def test_c_compiler_rejects_what_the_python_compiler_rejects(edit, msg):
+    L = lib()
+    bad = edit(default_xml_str("smpl_humanoid")).encode()
+    h = C.c_void_p()
+    rc = L.ss_model_create_from_mjcf(bad, len(bad), None, 0, C.byref(h))
+    assert rc == -1 and not h.value
+    assert msg in L.ss_last_error().decode(), L.ss_last_error().decode()
+
+
+def test_per_handle_error_strings():
+    xml = default_xml_str("smpl_humanoid")
+    mc = compile_mjcf(xml)
+    a = EmuBatch(mc, _tables(mc), 1, legal_bodies=FEET)
+    b = EmuBatch(mc, _tables(mc), 1, legal_bodies=FEET)
+    L = a.L
+    assert L.ss_batch_last_error(a.batch) == b""
+    assert L.ss_step(a.batch, None, None, None, None, None, None, None) == -1          # null actions
+    assert L.ss_batch_last_error(a.batch) == b"null argument" and L.ss_batch_last_error(b.batch) == b""
+    assert L.ss_set_launch_geometry(b.batch, 10 ** 6, 0) == -1
+    assert b"workgroup" in L.ss_batch_last_error(b.batch) and L.ss_batch_last_error(a.batch) == b"null argument"
+    # a failing ss_batch_create is recorded on the MODEL handle
+    cfg = _cabi.make_env_cfg(self_obs_v=7)
+    st = _cabi.State(); st.num_envs = 1
+    out = C.c_void_p()
+    assert L.ss_batch_create(a.model, C.byref(cfg), C.byref(st), C.byref(out)) == -1
+    assert L.ss_model_last_error(a.model) != b"" and L.ss_model_last_error(b.model) == b""

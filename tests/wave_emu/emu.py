@@ -40,7 +40,7 @@ def _rand4(tr, n, ft=np.float32):
 
 
 class EmuBatch:
-    def __init__(self, mc, tables, num_envs, legal_bodies=(), timestep=1.0 / 450, shape_mcs=None, shape_id=None, f64=False, **cfg):
+    def __init__(self, mc, tables, num_envs, legal_bodies=(), timestep=1.0 / 450, shape_mcs=None, shape_id=None, f64=False, mjcf_text=None, mjcf_options=None, **cfg):
         """shape_mcs: list of ModelConst = body shapes of one humanoid (ss_model_create_shapes), shape_id [N] picks per env.
         f64: run the float64 instantiation of the kernel (state / action / observation arrays are float64 then)."""
         L = self.L = lib(f64)
@@ -48,7 +48,10 @@ class EmuBatch:
         self.mc = mc
         self.model = C.c_void_p()
         self.shape_id = None
-        if shape_mcs is None:
+        if mjcf_text is not None:      # the library's own MJCF compiler + gain tables (mc is used for sizes only)
+            txt = mjcf_text.encode()
+            self._chk(L.ss_model_create_from_mjcf(txt, len(txt), None if mjcf_options is None else C.byref(mjcf_options), 0, C.byref(self.model)))
+        elif shape_mcs is None:
             desc, self._keep = _cabi.make_model_desc(mc, *tables, legal_bodies=legal_bodies, timestep=timestep)
             self._chk(L.ss_model_create(C.byref(desc), 0, C.byref(self.model)))
         else:
