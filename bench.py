@@ -29,9 +29,10 @@ WORKLOADS = {
     "getup": "BASELINE config 3 shard: {N} SMPL humanoids, env=getup (obs 290, height reward, contact termination, 60-step "
              "recovery), StateInit.Fall (45 warm-up mj_steps per reset), uniform(-1,1) actions (ms_per_step includes the masked Fall-reset launch, kernel_ms is the step launch)",
     "imitation": "BASELINE config 5 shard: {N} SMPL humanoids tracking motion clips (synthetic smooth clips in the AMASS pickle "
-                 "format; no dataset in the image), reference-state init, PD replay of the clip as the policy, per step: ss_step "
-                 "(obs v2) + ss_kinematics + ss_imitation_step (clip lookup at t and t+dt, 576-float task obs, PHC tracking reward, "
-                 "early termination) + in-place re-initialisation of finished envs",
+                 "format; no dataset in the image), reference-state init, PD replay of the clip as the policy, per step ONE launch "
+                 "(ss_imitation_step_fused): ss_step (obs v2, body frames) + clip lookup at t and t+dt, 576-float task obs, PHC tracking "
+                 "reward, early termination + in-place re-initialisation of finished envs (resample, clip state, reset forward, "
+                 "observations); --unfused = the six-launch sequence it replaces",
     "smplx": "BASELINE config 4: {N} SMPL-X/H-layout humanoids (52 bodies, nv=159, nu=153), base env, obs v1 (625 f32), uniform(-1,1) actions",
 }
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -186,7 +187,7 @@ def run_imitation(args, rank, local_rank, world, dist, dev):
     Gpu.sync()
     load_s = time.perf_counter() - t0
     F, J = ml.data.num_frames, 24
-    env = SMPLSimImitationVecEnv(N, ml, model=model, device=local_rank, seed=shard.shard_seed(1234, rank))
+    env = SMPLSimImitationVecEnv(N, ml, model=model, device=local_rank, seed=shard.shard_seed(1234, rank), fused=not args.unfused)
     env.reset()
 
     def one_step():
@@ -199,16 +200,14 @@ def run_imitation(args, rank, local_rank, world, dist, dev):
     shard.barrier(dist, world, dev)
     t0 = time.perf_counter()
     rew_sum, ended = torch.zeros((), device=dev), torch.zeros((), device=dev)
+    rew_acc = torch.zeros(N, device=dev); end_acc = torch.zeros(N, dtype=torch.int32, device=dev)
     for i in range(args.steps):
-        a = env.reference_actions()
+        a = env.reference_actions()                              # the stand-in policy (one clip lookup launch + two elementwise ones)
         ev0[i].record()
-        env.base.step(a)                                         # the physics launch (dominant kernel), timed per launch
+        env.step(a)                                              # fused: schedule + the one step launch; --unfused: the whole sequence
         ev1[i].record()
-        env._imitation(None, env.rew_buf, env.reward_parts, env.terminated, env.truncated)
-        env.obs_buf[:, :env.self_obs_size] = env.base.obs_buf
-        torch.bitwise_or(env.terminated, env.truncated, out=env.reset_buf)
-        rew_sum += env.rew_buf.mean(); ended += env.reset_buf.sum()
-        env.reset(mask=env.reset_buf)
+        rew_acc.add_(env.rew_buf); end_acc.add_(env.terminated); end_acc.add_(env.truncated)
+    rew_sum, ended = rew_acc.mean(), end_acc.sum()
     shard.barrier(dist, world, dev)
     elapsed = shard.max_over_ranks(dist, world, time.perf_counter() - t0, dev)
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
@@ -244,13 +243,13 @@ def run_imitation(args, rank, local_rank, world, dist, dev):
                        "parallelism": f"independent shards x{world} (no collective)", "launch": env.base.launch_info(),
                        "mean_reward": float(rew_sum.item()) / args.steps, "episodes_ended": int(ended.item()),
                        "obs_finite": bool(torch.isfinite(env.obs_buf).all().item()), "parity_pin": PARITY_PIN,
-                       "step_kernel_ms": kern_ms, "load_motions_s (upload + cook)": load_s,
+                       "env_step_ms (events around env.step)": kern_ms, "fused_step": bool(env.fused), "load_motions_s (upload + cook)": load_s,
                        "cook": {"ms": cook_ms, "frames_per_s": F / (cook_ms * 1e-3), "GB/s": F * cook_bytes / (cook_ms * 1e-3) / 1e9,
                                 "algorithmic_bytes_per_frame": cook_bytes}},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_unit": "bytes per launch", "traffic_source": traffic_src, "kernel": "ss_imitation_kernel<32>", "kernel_ms": im_ms, "algorithmic_bytes_per_env_step": im_bytes,
                          "note": f"{N} envs x {im_bytes} B is far below what fills HBM for the ~us a launch lasts: launch-latency bound at this size; "
-                                 "the step's time is the physics launch (step_kernel_ms)"},
+                                 "the step's time is the physics part of the step launch (env_step_ms)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_motion()
@@ -288,6 +287,7 @@ def main(argv=None):
     ap.add_argument("--self-collision", action="store_true",
                     help="contacts between the humanoid's own bodies like mj_step on the reference MJCF (SURVEY 8f-4); default: floor "
                          "contacts and joint limits only")
+    ap.add_argument("--unfused", action="store_true", help="imitation: the separate launches instead of ss_imitation_step_fused")
     ap.add_argument("--clips", type=int, default=256, help="imitation: synthetic clips per shard")
     ap.add_argument("--clip-frames", type=int, default=300, help="imitation: frames per synthetic clip (30 fps)")
     ap.add_argument("--workload", default="smpl", choices=["smpl", "getup", "smplx", "imitation"],

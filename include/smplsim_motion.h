@@ -114,6 +114,37 @@ int ss_imitation_step(const ss_motion_data *data, const ss_imitation_cfg *cfg, c
                       const float *body_vel, float *task_obs, int32_t obs_stride, float *reward, float *reward_parts,
                       uint8_t *terminated, uint8_t *truncated, void *stream);
 
+/* The whole imitation control step in ONE launch: ss_step (15 x (Stable-PD + mj_step), self observation, body frames) and, in
+ * the wavefront that stepped the env, on what it just wrote: the work of ss_imitation_step (reward, flags, task observation
+ * behind the self observation) and — for the envs that terminated or ran out of clip, when `rand` is given — the reference-state
+ * re-initialisation PHC's HumanoidIm does: ss_motion_resample (clip by inverse CDF from rand[n,0], start time from rand[n,1]),
+ * ss_motion_state_at into the simulator's qpos / qvel, the reset's mj_forward + self observation (ss_reset, StateInit External)
+ * and the task observation of the new state.  Same element functions, same results as that sequence of six launches.
+ *
+ * ss_imitation_bind stores the buffers (device pointers the caller keeps alive and in place) with the batch; the batch must
+ * have task base, StateInit External and ss_set_body_outputs buffers.  Rows of obs_final / obs_next are
+ * [self observation | task observation (24 J)] at a row stride of obs_stride floats: obs_final = after the step (what the
+ * learner stores), obs_next = what the policy acts on next (= obs_final for envs that go on). */
+struct ss_batch;
+typedef struct {
+  const ss_motion_data *data;    /* copied */
+  ss_imitation_cfg cfg;
+  int32_t *motion_ids;           /* [N] clip of every env, rewritten on re-initialisation */
+  float *start_times;            /* [N] clip time at cur_t = 0 */
+  const float *offset;           /* [N,3] world offset of the clips, or NULL */
+  const float *sampling_cdf;     /* [num_motions] inclusive CDF of the clip sampling probabilities (NULL: no re-initialisation) */
+  float truncate_time;           /* sample_time(truncate_time): start times are drawn from [0, length - truncate_time) */
+  int32_t random_start;          /* 0: re-initialised envs start at t = 0 */
+  float *obs_final, *obs_next;   /* [N, obs_stride] */
+  int32_t obs_stride;
+  float *reward;                 /* [N] */
+  float *reward_parts;           /* [N,4] or NULL */
+  uint8_t *terminated, *truncated; /* [N] */
+} ss_imitation_io;
+int ss_imitation_bind(struct ss_batch *b, const ss_imitation_io *io);
+/* actions [N,nu]; rand [N,2] uniform [0,1) draws or NULL (finished envs are then left as they are: evaluation runs) */
+int ss_imitation_step_fused(struct ss_batch *b, const float *actions, const float *rand, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,6 +82,13 @@ class ImitationCfg(C.Structure):
                                          "termination_distance", "obs_dt")]
 
 
+class ImitationIO(C.Structure):
+    _fields_ = [("data", C.POINTER(MotionData)), ("cfg", ImitationCfg), ("motion_ids", C.c_void_p), ("start_times", C.c_void_p),
+                ("offset", C.c_void_p), ("sampling_cdf", C.c_void_p), ("truncate_time", C.c_float), ("random_start", C.c_int32),
+                ("obs_final", C.c_void_p), ("obs_next", C.c_void_p), ("obs_stride", C.c_int32), ("reward", C.c_void_p),
+                ("reward_parts", C.c_void_p), ("terminated", C.c_void_p), ("truncated", C.c_void_p)]
+
+
 class MjcfOptions(C.Structure):
     _fields_ = [("control_mode", C.c_int32), ("clip_actions", C.c_int32), ("pdp_scale", C.c_double), ("pdd_scale", C.c_double),
                 ("timestep", C.c_double), ("num_contact_bodies", C.c_int32), ("contact_bodies", C.POINTER(C.c_char_p))]
@@ -90,6 +97,8 @@ class MjcfOptions(C.Structure):
 def bind(lib):
     vp = C.c_void_p
     lib.ss_model_create_from_mjcf.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(MjcfOptions), C.c_int, C.POINTER(vp)]
+    lib.ss_imitation_bind.argtypes = [vp, C.POINTER(ImitationIO)]
+    lib.ss_imitation_step_fused.argtypes = [vp, vp, vp, vp]
     lib.ss_model_last_error.argtypes = [vp]; lib.ss_model_last_error.restype = C.c_char_p
     lib.ss_batch_last_error.argtypes = [vp]; lib.ss_batch_last_error.restype = C.c_char_p
     lib.ss_model_create.argtypes = [C.POINTER(ModelDesc), C.c_int, C.POINTER(vp)]
@@ -125,7 +134,7 @@ def bind(lib):
 EXPORTS = ["ss_model_create", "ss_model_create_shapes", "ss_model_destroy", "ss_model_dims", "ss_obs_size", "ss_batch_create",
            "ss_batch_destroy", "ss_reset", "ss_step", "ss_step_autoreset", "ss_substep", "ss_kinematics", "ss_debug_forward", "ss_debug_self_contacts",
            "ss_gae", "ss_debug_prof", "ss_set_order", "ss_set_body_outputs", "ss_set_launch_geometry", "ss_schedule_longest_first", "ss_launch_info", "ss_last_error",
-           "ss_model_create_from_mjcf", "ss_model_last_error", "ss_batch_last_error",
+           "ss_model_create_from_mjcf", "ss_model_last_error", "ss_batch_last_error", "ss_imitation_bind", "ss_imitation_step_fused",
            "ss_motion_cook", "ss_motion_state_at", "ss_motion_resample", "ss_imitation_step"]
 
 

@@ -34,7 +34,7 @@ class ExtensionMissing(RuntimeError):
 def build(verbose=False, force=False):
     """hipcc --offload-arch=gfx950 build of the kernels + C ABI (cross-compiles without a GPU)."""
     srcs = [os.path.join(SRC_DIR, f) for f in ("smplsim_hip.hip", "smplsim_motion.hip", "ss_kernel.h", "ss_selfcol.h", "ss_api.h", "ss_tables.h", "ss_hdr.h",
-                                                  "ss_motion.h", "ss_motion_api.h", "ss_wave_gpu.h")]
+                                                  "ss_motion.h", "ss_motion_api.h", "ss_wave_gpu.h", "ss_imfused.h", "ss_mjcf.h")]
     srcs += [os.path.join(os.path.dirname(_PKG), "include", h) for h in ("smplsim_hip.h", "smplsim_motion.h")]
     opt = os.environ.get("SS_HIPCC_OPT", DEFAULT_OPT).split()
     mopt = os.environ.get("SS_HIPCC_MOTION_OPT", MOTION_OPT).split()

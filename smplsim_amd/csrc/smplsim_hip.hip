@@ -27,9 +27,12 @@
 namespace {
 
 
-template <int DOFP, int CANDP, int SLOTP, int NPASS, int MAXT, bool BODYOUT, bool SHAPED, class HT = ss::HdrRuntime, bool SELFCOL = false>
+// IMIT: the instantiation of ss_imitation_step_fused — after the step pass the wave runs the imitation task of its env and, if the
+// env finished, the reference-state re-initialisation (ss_imfused.h) around the stepper's own reset pass.
+template <int DOFP, int CANDP, int SLOTP, int NPASS, int MAXT, bool BODYOUT, bool SHAPED, class HT = ss::HdrRuntime, bool SELFCOL = false, bool IMIT = false>
 __global__ void __launch_bounds__(MAXT) ss_env_kernel(const ss::KArgs k) {
   extern __shared__ __align__(16) uint32_t lds[];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *k.work_counter_next = 0;   // the next launch's counter (this launch uses the other one)
   for (int i = threadIdx.x; i < k.h.shared_words; i += blockDim.x) lds[i] = k.shared_g[i];
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> LDS bases stay in SGPRs
@@ -51,6 +54,17 @@ __global__ void __launch_bounds__(MAXT) ss_env_kernel(const ss::KArgs k) {
     if (env >= k.st.num_envs) break;
     if (k.order) env = __builtin_amdgcn_readfirstlane(k.order[env]);   // longest-processing-time-first hand-out
     int mode = k.mode;
+    if constexpr (IMIT) {
+      const ss::mo::ImFused *f = static_cast<const ss::mo::ImFused *>(k.im);
+      ss::run_env<WaveGpu, DOFP, CANDP, SLOTP, NPASS, BODYOUT, SHAPED, HT, SELFCOL>(&w, &k, lds, L, env, mode);
+      w.sync();
+      if (ss::mo::fused_after_step(&w, f, k.im_rand, env)) {
+        ss::run_env<WaveGpu, DOFP, CANDP, SLOTP, NPASS, BODYOUT, SHAPED, HT, SELFCOL>(&w, &k, lds, L, env, ss::MODE_RESET);
+        w.sync();
+        ss::mo::fused_after_reset(&w, f, env);
+      }
+      continue;
+    }
     for (int rep = 0; rep < 2; rep++) {                       // second trip = fused Default reset of an env whose episode ended
       const bool again = ss::run_env<WaveGpu, DOFP, CANDP, SLOTP, NPASS, BODYOUT, SHAPED, HT, SELFCOL>(&w, &k, lds, L, env, mode);
       w.sync();
@@ -106,6 +120,14 @@ kern_t pick_kernel(int variant, int flavour, const ss::Hdr &h) {
 #endif
   if (variant == 0 && flavour == 0) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, false, false>;
 #ifndef SS_ONLY_HEADLINE                                     // (experiment builds, tools/build_variant.sh, keep the headline kernel alone)
+  if (flavour == 4) {                                        // imitation task folded into the step launch (ss_imitation_step_fused)
+#ifndef SS_NO_FIXED_LAYOUT
+    if (variant == 0 && HdrSmpl::matches(h)) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, false, HdrSmpl, false, true>;
+#endif
+    if (variant == 0) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, false, ss::HdrRuntime, false, true>;
+    if (variant == 1) return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, true, false, ss::HdrRuntime, false, true>;
+    return nullptr;
+  }
   if (flavour == 3) {                                        // body-body contacts (ss_env_cfg.self_collision); also writes the body frames
     if (variant == 0) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS_SC, true, false, ss::HdrRuntime, true>;
     if (variant == 1) return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, true, false, ss::HdrRuntime, true>;
@@ -148,12 +170,12 @@ struct HipBackend {
   static int kernel_regs() { return regs_ref(); }
   static const char *launch(const ss::KArgs &k, int nenv, int envs_per_wg, size_t lds_bytes, void *stream, int fixed_epw, int max_wgs) {
     const bool bodyout = k.out0 && (k.mode == ss::MODE_STEP || k.mode == ss::MODE_RESET);
-    const int flavour = k.cfg.self_collision ? 3 : (k.st.shape_id ? 2 : (bodyout ? 1 : 0));
+    const int flavour = k.im ? 4 : (k.cfg.self_collision ? 3 : (k.st.shape_id ? 2 : (bodyout ? 1 : 0)));
     kern_t kern = pick_kernel(ss::kernel_variant(k.h), flavour, k.h);
     if (!kern) return "no kernel variant for this model size";
-    static thread_local kern_t configured[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    static thread_local size_t configured_lds[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const int slot = 4 * ss::kernel_variant(k.h) + flavour;
+    static thread_local kern_t configured[16] = {};
+    static thread_local size_t configured_lds[16] = {};
+    const int slot = 8 * ss::kernel_variant(k.h) + flavour;
     if (configured[slot] != kern || configured_lds[slot] < lds_bytes) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
       if (e != hipSuccess) return hipGetErrorString(e);
@@ -176,7 +198,6 @@ struct HipBackend {
     const int resident = cus * (int)(lds_capacity() / lds_bytes > 0 ? lds_capacity() / lds_bytes : 1);
     if (wgs > resident) wgs = resident;                      // persistent: one resident set of workgroups
     if (max_wgs > 0 && wgs > max_wgs) wgs = max_wgs;         // the caller shares the GPU between concurrent batches
-    if (hipMemsetAsync(k.work_counter, 0, sizeof(int32_t), (hipStream_t)stream) != hipSuccess) return "hipMemsetAsync failed";
     dim3 grid(wgs), block(64 * envs_per_wg);
     hipLaunchKernelGGL(kern, grid, block, lds_bytes, (hipStream_t)stream, k);
     hipError_t e = hipGetLastError();

@@ -9,6 +9,7 @@
 #include <new>
 #include <string>
 
+#include "ss_imfused.h"
 #include "ss_mjcf.h"
 #include "ss_tables.h"
 
@@ -49,6 +50,9 @@ struct ss_batch {
   float *dbg_self = nullptr;              // caller-owned, optional (ss_debug_self_contacts)
   int fixed_envs_per_wg = 0, max_wgs = 0; // ss_set_launch_geometry: 0 = automatic (small batches are spread over all CUs)
   mutable std::string err;                // message of the last failed call that took this handle
+  mutable int parity = 0;                 // which of the two work counters the next launch uses (it clears the other one)
+  void *d_im = nullptr;                   // ss::mo::ImFused on the device (ss_imitation_bind)
+  ss_imitation_io im_io{};
 };
 
 template <class BE>
@@ -169,8 +173,9 @@ struct ss_api {
     if (b->d_prof) { unsigned long long z[64] = {0}; BE::upload(b->d_prof, z, sizeof z); }
 #endif
     if (!BE::set_device(m->device)) { delete b; return fail(SS_ERR_HIP, "cannot select device"); }   // the counter must live on the batch's GPU
-    b->d_counter = (int32_t *)BE::alloc(sizeof(int32_t));
-    if (!b->d_counter) { delete b; return fail(SS_ERR_NOMEM, "device allocation failed"); }
+    b->d_counter = (int32_t *)BE::alloc(2 * sizeof(int32_t));
+    const int32_t zeros[2] = {0, 0};
+    if (!b->d_counter || !BE::upload(b->d_counter, zeros, sizeof zeros)) { BE::free_(b->d_counter); delete b; return fail(SS_ERR_NOMEM, "device allocation failed"); }
     *out = b;
     return SS_OK;
   }
@@ -182,7 +187,9 @@ struct ss_api {
     k.illegal_mask = m->hm.illegal_mask;
     k.sc = m->hm.sc; k.pairs = m->d_pairs; k.geomc = m->d_geomc; k.dbg_self = ss_batch::R(b->dbg_self);
     k.mode = mode; k.nsub = b->cfg.control_freq_inv; k.obs_size = b->obs_size;
-    k.work_counter = b->d_counter;
+    k.work_counter = b->d_counter + b->parity; k.work_counter_next = b->d_counter + (b->parity ^ 1);
+    b->parity ^= 1;
+    k.obs_stride = b->obs_size;
     k.prof = b->d_prof;
     k.order = b->order;
     if (mode == ss::MODE_STEP || mode == ss::MODE_RESET) { k.out0 = ss_batch::R(b->body_xpos); k.out1 = ss_batch::R(b->body_xmat); }
@@ -218,6 +225,44 @@ struct ss_api {
     k.actions = ss_batch::R(actions); k.task_rand = ss_batch::R(task_rand); k.obs = ss_batch::R(obs); k.reward = ss_batch::R(reward);
     k.terminated = term; k.truncated = trunc;
     k.fused_reset = 1; k.obs2 = ss_batch::R(obs_next); k.task_rand2 = ss_batch::R(reset_task_rand);
+    return run(b, k, stream);
+  }
+  // ---- imitation folded into the step launch (include/smplsim_motion.h)
+  static int imitation_bind(ss_batch *b, const ss_imitation_io *io) {
+    if (!b || !io) return fail(SS_ERR_INVALID, "null argument");
+    if (sizeof(ss::real) != sizeof(float)) return fail(SS_ERR_INVALID, "not available in the float64 build");
+    if (const char *e = ss::mo::check_data(io->data, false)) return fail(SS_ERR_INVALID, e);
+    const ss::Hdr &h = b->m->hm.h;
+    if (io->data->nbody != h.nb) return fail(SS_ERR_INVALID, "motion data and model disagree on nbody");
+    if (b->cfg.state_init != SS_INIT_EXTERNAL || b->cfg.task != SS_TASK_BASE)
+      return fail(SS_ERR_INVALID, "the fused imitation step needs a batch with task base and StateInit External");
+    if (b->cfg.self_collision || b->st.shape_id) return fail(SS_ERR_INVALID, "fused imitation step: self_collision / per-env shapes not supported");
+    if (!b->body_xpos || !b->body_xmat) return fail(SS_ERR_INVALID, "call ss_set_body_outputs first");
+    if (!io->motion_ids || !io->start_times || !io->obs_final || !io->obs_next || !io->reward || !io->terminated || !io->truncated)
+      return fail(SS_ERR_INVALID, "null buffer in ss_imitation_io");
+    if (io->obs_stride < b->obs_size + 24 * h.nb) return fail(SS_ERR_INVALID, "obs_stride smaller than self + task observation");
+    if (io->truncate_time < 0.f) return fail(SS_ERR_INVALID, "truncate_time must be >= 0");
+    ss::mo::ImFused f{};
+    f.im = ss::mo::ImArgs{*io->data, io->cfg, io->motion_ids, io->start_times, b->st.cur_t, io->offset, nullptr, b->st.num_envs,
+                          b->body_xpos, b->body_xmat, b->st.body_vel, io->obs_final + b->obs_size, io->obs_stride, io->reward,
+                          io->reward_parts, io->terminated, io->truncated};
+    f.ids = io->motion_ids; f.start_times = io->start_times; f.cdf = io->sampling_cdf; f.truncate = io->truncate_time;
+    f.random_start = io->random_start; f.obs_final = io->obs_final; f.obs_next = io->obs_next;
+    f.obs_floats = b->obs_size + 24 * h.nb; f.qpos = b->st.qpos; f.qvel = b->st.qvel; f.nq = h.nq; f.nv = h.nv;
+    if (!BE::set_device(b->m->device)) return fail(SS_ERR_HIP, "cannot select device");
+    if (!b->d_im) b->d_im = BE::alloc(sizeof f);
+    if (!b->d_im || !BE::upload(b->d_im, &f, sizeof f)) return fail(SS_ERR_NOMEM, "device allocation failed");
+    b->im_io = *io;
+    return SS_OK;
+  }
+  static int imitation_step_fused(ss_batch *b, const float *actions, const float *rand, void *stream) {
+    if (!b || !actions) return fail(SS_ERR_INVALID, "null argument");
+    if (!b->d_im) return fail(SS_ERR_INVALID, "ss_imitation_bind first");
+    if (rand && !b->im_io.sampling_cdf) return fail(SS_ERR_INVALID, "re-initialisation needs ss_imitation_io.sampling_cdf");
+    ss::KArgs k = base_args(b, ss::MODE_STEP);
+    k.actions = ss_batch::R(actions);
+    k.obs = ss_batch::R(b->im_io.obs_final); k.obs2 = ss_batch::R(b->im_io.obs_next); k.obs_stride = b->im_io.obs_stride;
+    k.im = b->d_im; k.im_rand = rand;                        // reward / flags come from the imitation part
     return run(b, k, stream);
   }
   static int substep(ss_batch *b, const float *actions, int n, void *stream) {
@@ -257,7 +302,7 @@ struct ss_api {
   }                                                                                                                  \
   int ss_obs_size(const ss_model *m, const ss_env_cfg *c) { return (m && c) ? ss::obs_size(m->hm.h, *c) : SS_ERR_INVALID; } \
   int ss_batch_create(const ss_model *m, const ss_env_cfg *c, const ss_state *s, ss_batch **o) { ss::HandleScope hs_(m ? &m->err : nullptr); return ss_api<BE>::batch_create(m, c, s, o); } \
-  void ss_batch_destroy(ss_batch *b) { if (b) { BE::free_(b->d_counter); BE::free_(b->d_prof); BE::free_(b->d_sched); delete b; } }          \
+  void ss_batch_destroy(ss_batch *b) { if (b) { BE::free_(b->d_im); BE::free_(b->d_counter); BE::free_(b->d_prof); BE::free_(b->d_sched); delete b; } }          \
   int ss_set_order(ss_batch *b, const int32_t *order) { ss::HandleScope hs_(b ? &b->err : nullptr);                                                              \
     if (!b) return ss_api<BE>::fail(SS_ERR_INVALID, "null batch");                                                  \
     b->order = order; return SS_OK;                                                                                  \
@@ -299,6 +344,8 @@ struct ss_api {
   int ss_step(ss_batch *b, const float *a, const float *tr, float *obs, float *rew, uint8_t *te, uint8_t *tu, void *st) { ss::HandleScope hs_(b ? &b->err : nullptr); return ss_api<BE>::step(b, a, tr, obs, rew, te, tu, st); } \
   int ss_step_autoreset(ss_batch *b, const float *a, const float *tr, const float *tr2, float *obs, float *obs_next, float *rew, \
                         uint8_t *te, uint8_t *tu, void *st) { ss::HandleScope hs_(b ? &b->err : nullptr); return ss_api<BE>::step_autoreset(b, a, tr, tr2, obs, obs_next, rew, te, tu, st); } \
+  int ss_imitation_bind(ss_batch *b, const ss_imitation_io *io) { ss::HandleScope hs_(b ? &b->err : nullptr); return ss_api<BE>::imitation_bind(b, io); } \
+  int ss_imitation_step_fused(ss_batch *b, const float *a, const float *rand, void *st) { ss::HandleScope hs_(b ? &b->err : nullptr); return ss_api<BE>::imitation_step_fused(b, a, rand, st); } \
   int ss_substep(ss_batch *b, const float *a, int n, void *st) { ss::HandleScope hs_(b ? &b->err : nullptr); return ss_api<BE>::substep(b, a, n, st); }          \
   int ss_kinematics(ss_batch *b, float *xpos, float *xmat, void *st) { ss::HandleScope hs_(b ? &b->err : nullptr); return ss_api<BE>::kinematics(b, xpos, xmat, st); } \
   int ss_debug_forward(ss_batch *b, const float *tq, float *M, float *bias, float *qacc, void *st) { ss::HandleScope hs_(b ? &b->err : nullptr); return ss_api<BE>::debug_forward(b, tq, M, bias, qacc, st); } \

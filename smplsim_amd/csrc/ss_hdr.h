@@ -187,7 +187,7 @@ struct KArgs {
   const uint8_t *mask;        // [N] or null
   unsigned long long *prof;   // optional stage-cycle accumulators (SS_PROFILE builds), else null
   const int32_t *order;       // optional [N] processing order of the envs (heavy first), or null
-  int32_t *work_counter;      // device word, zeroed before each launch: persistent waves pull env ids from it
+  int32_t *work_counter;      // device word, zero at launch (the previous launch cleared it): persistent waves pull env ids from it
   real *obs, *reward;
   // fused autoreset (ss_step_autoreset): envs whose step ends an episode run the Default reset in the same launch;
   // obs2 receives the observation AFTER the (possible) reset for every env, task_rand2 feeds the reset's reset_task
@@ -204,6 +204,10 @@ struct KArgs {
   // per-env body shapes (ss_model_create_shapes): bodyc holds num_shapes consecutive blocks of [nb][kBodyC] body constants
   // followed by [nv] dof inverse weights (block stride shape_stride(h) floats), candc num_shapes consecutive tables;
   // st.shape_id [N] selects per env (null = single-shape model)
+  int obs_stride;             // floats between the observation rows of obs / obs2 (body-output instantiations; = obs_size otherwise)
+  const void *im;             // ss::mo::ImFused on the device (ss_imitation_step_fused), or null
+  const float *im_rand;       // [N,2] uniform draws for the re-initialisation of finished envs, or null = none
+  int32_t *work_counter_next; // the counter of the NEXT launch on this batch: zeroed by this one (no memset between launches)
 };
 
 // floats of one env's LDS slice for this launch

@@ -1881,9 +1881,10 @@ SS_DEV bool run_env(W *w, const KArgs *k, const uint32_t *T, real *L, int env, i
   const real *trand = trand_base ? trand_base + (size_t)env * 4 : nullptr;
   const real *fa = (k->fall_actions && !fused_pass) ? k->fall_actions + (size_t)env * 3 * h.nu : nullptr;
   real *obs_base = fused_pass ? k->obs2 : k->obs;
-  real *obs = obs_base ? obs_base + (size_t)env * k->obs_size : nullptr;
+  const int ostride = BODYOUT ? k->obs_stride : k->obs_size;   // rows wider than the observation: a task part follows (imitation)
+  real *obs = obs_base ? obs_base + (size_t)env * ostride : nullptr;
   // step pass of a fused launch: the post-step observation also goes to obs2 (envs that do not reset keep it)
-  real *obs_also = (!fused_pass && k->fused_reset && k->obs2) ? k->obs2 + (size_t)env * k->obs_size : nullptr;
+  real *obs_also = (!fused_pass && k->fused_reset && k->obs2) ? k->obs2 + (size_t)env * ostride : nullptr;
   const int maxit = cf.newton_iters > 0 ? cf.newton_iters : 8;
 
   int cur_t = st.cur_t[env];

@@ -374,8 +374,9 @@ SS_DEV Q heading_inv(const Q &root) {
 
 // LPE lanes per env (32 for J <= 32, else 64): lane j of an env's group handles body j; the five per-body error terms
 // are summed over the group with a shfl_xor ladder, lane 0 of the group writes reward / termination.
+// Returns, in every lane of an env's group, bit 0 = terminated, bit 1 = truncated (0 for skipped envs).
 template <class W, int LPE>
-SS_DEV void imitation_wave(W *w, const ImArgs &a, int wave_id) {
+SS_DEV int imitation_wave(W *w, const ImArgs &a, int wave_id, float *obs_rows = nullptr, bool obs_only = false) {
   const ss_motion_data &d = a.d;
   const int J = d.nbody, lane = w->lane(), j = lane % LPE, n = wave_id * (64 / LPE) + lane / LPE;
   const bool act = n < a.N && j < J && !(a.mask && !a.mask[n]);
@@ -406,7 +407,7 @@ SS_DEV void imitation_wave(W *w, const ImArgs &a, int wave_id) {
     frame_blend(d, id, time + a.c.obs_dt, &f0, &f1, &b);
     sample_body(d, f0, f1, b, j, off, &r);
     const Q hi = heading_inv(rq), hq = q_conj(hi);
-    float *ob = a.obs + (size_t)n * a.obs_stride;
+    float *ob = (obs_rows ? obs_rows : a.obs) + (size_t)n * a.obs_stride;   // obs_rows: another set of rows than the bound one
     float t3[3], o3[3], o6[6];
     for (int c = 0; c < 3; c++) t3[c] = r.p[c] - sp[c];
     q_rot(hi, t3, o3); for (int c = 0; c < 3; c++) ob[3 * j + c] = o3[c];
@@ -424,15 +425,22 @@ SS_DEV void imitation_wave(W *w, const ImArgs &a, int wave_id) {
     e_pos += w->shfl_xor(e_pos, mask); e_rot += w->shfl_xor(e_rot, mask); e_vel += w->shfl_xor(e_vel, mask);
     e_ang += w->shfl_xor(e_ang, mask); dist += w->shfl_xor(dist, mask);
   }
+  int flags = 0;
+  if (obs_only) return 0;
   if (act && j == 0) {
     const float ij = 1.f / (float)J;
     const float r0 = expf(-a.c.k_pos * e_pos * ij * (1.f / 3.f)), r1 = expf(-a.c.k_rot * e_rot * ij);
     const float r2 = expf(-a.c.k_vel * e_vel * ij * (1.f / 3.f)), r3 = expf(-a.c.k_ang_vel * e_ang * ij * (1.f / 3.f));
     if (a.reward) a.reward[n] = a.c.w_pos * r0 + a.c.w_rot * r1 + a.c.w_vel * r2 + a.c.w_ang_vel * r3;
     if (a.parts) { a.parts[4 * n] = r0; a.parts[4 * n + 1] = r1; a.parts[4 * n + 2] = r2; a.parts[4 * n + 3] = r3; }
-    if (a.terminated) a.terminated[n] = dist * ij > a.c.termination_distance ? 1 : 0;
-    if (a.truncated) a.truncated[n] = time + a.c.obs_dt >= d.motion_lengths[a.ids[n]] ? 1 : 0;   // no later frame to look ahead to
+    const int term = dist * ij > a.c.termination_distance ? 1 : 0;
+    const int trunc = time + a.c.obs_dt >= d.motion_lengths[a.ids[n]] ? 1 : 0;                  // no later frame to look ahead to
+    if (a.terminated) a.terminated[n] = (uint8_t)term;
+    if (a.truncated) a.truncated[n] = (uint8_t)trunc;
+    flags = term | (trunc << 1);
   }
+  for (int mask = 1; mask < LPE; mask <<= 1) flags |= w->shfl_xor_i(flags, mask);
+  return flags;
 }
 
 }  // namespace mo

@@ -45,15 +45,6 @@ inline bool pack_skeleton(const ss_skeleton *s, Skel *out, std::string *err) {
   return true;
 }
 
-inline const char *check_data(const ss_motion_data *d, bool cooking) {
-  if (!d) return "null motion data";
-  if (d->num_motions < 1 || d->num_frames < 1 || d->nbody < 1 || d->nbody > kMaxBodies) return "motion data: bad sizes";
-  if (!d->length_starts || !d->motion_num_frames || !d->motion_dt || !d->motion_lengths) return "motion data: null clip table";
-  if (!d->gts || !d->grs || !d->gvs || !d->gavs || !d->dof_pos || !d->dvs || !d->qpos || !d->qvel) return "motion data: null cooked array";
-  if (cooking && (!d->frame_motion || !d->pose_aa || !d->trans || !d->offsets || !d->lrs)) return "motion data: null raw clip array";
-  return nullptr;
-}
-
 }  // namespace mo
 }  // namespace ss
 

@@ -5,11 +5,13 @@ replica of PHC's", humanoid_env.py:636) but not the task itself; this env wires 
 
   reset   reference-state init: sample a clip and a start time per env, write the clip's qpos/qvel at that time into
           the simulator state (ss_motion_state_at -> ss_reset with StateInit "External")
-  step    ss_step (15 x (Stable-PD + mj_step), self observation, body frames via ss_set_body_outputs)  ->
-          ss_imitation_step (clip lookup at t and t + dt, task observation written behind the self observation, tracking
-          reward, early termination, truncation at the end of the clip)
-          finished envs are re-initialised in place: ss_motion_resample -> ss_motion_state_at (masked, straight into the
-          simulator's qpos / qvel) -> ss_reset (masked) -> ss_imitation_step (masked, observation only).
+  step    ONE launch, ss_imitation_step_fused: ss_step (15 x (Stable-PD + mj_step), self observation, body frames) and, in the
+          wavefront that stepped the env, the imitation task (clip lookup at t and t + dt, task observation written behind the
+          self observation, tracking reward, early termination, truncation at the end of the clip) and the re-initialisation of
+          finished envs (resample -> clip state into qpos / qvel -> reset forward -> observations).  (+ one launch for the
+          longest-first hand-out order, + one torch.rand per 64 steps for the resampling draws.)
+          fused=False keeps the sequence of separate launches the fused one is tested against: ss_step -> ss_imitation_step ->
+          ss_motion_resample -> ss_motion_state_at (masked) -> ss_reset (masked) -> ss_imitation_step (masked, observation only).
 
 All buffers are torch tensors on the shard's device; nothing leaves HBM between launches.
 """
@@ -25,7 +27,7 @@ from ._lib import lib
 class SMPLSimImitationVecEnv:
     def __init__(self, num_envs, motion_lib, model=None, device=0, self_obs_v=2, control_freq_inv=15, sim_timestep_inv=450,
                  termination_distance=0.25, reward_k=(100.0, 10.0, 0.1, 0.1), reward_w=(0.5, 0.3, 0.1, 0.1),
-                 random_start=True, autoreset=True, seed=0, **env_kw):
+                 random_start=True, autoreset=True, seed=0, fused=True, **env_kw):
         self.base = SMPLSimVecEnv(num_envs, model=model, device=device, task="HumanoidEnv", state_init="External",
                                   self_obs_v=self_obs_v, control_freq_inv=control_freq_inv, episode_length=2 ** 30,
                                   autoreset=False, fused_autoreset=False, seed=seed, **env_kw)
@@ -59,6 +61,33 @@ class SMPLSimImitationVecEnv:
         self.gen.manual_seed(int(seed) + 1)
         # every step / reset launch also writes the body frames of its last forward: no separate ss_kinematics launch
         _check(lib().ss_set_body_outputs(b.handle, _ptr(self.xpos), _ptr(self.xmat)))
+        # resampling draws of the re-initialisations: a block of RAND_BLOCK steps per torch.rand launch
+        self._rand_block, self._rand_i = None, self.RAND_BLOCK
+        self.fused = bool(fused) and not b.self_collision and b.shape_id is None
+        self.obs_final = torch.zeros(N, self.obs_size, **f32)
+        self._bound = None
+        self._bind()
+
+    def _bind(self):
+        """Hand the buffers of the fused step to the batch (again after the motion library loaded other clips: its arrays moved)."""
+        ml = self.motion_lib
+        if not self.fused or self._bound == ml.load_count:
+            return
+        io = _cabi.ImitationIO(C.pointer(ml.data), self.cfg, *[_ptr(t) for t in (self.motion_ids, self.start_times, self.offset,
+                               ml.sampling_cdf)], self.dt, int(bool(self.random_start)), _ptr(self.obs_final), _ptr(self.obs_buf),
+                               self.obs_size, _ptr(self.rew_buf), _ptr(self.reward_parts), _ptr(self.terminated), _ptr(self.truncated))
+        _check(lib().ss_imitation_bind(self.base.handle, C.byref(io)))
+        self._bound = ml.load_count
+
+    RAND_BLOCK = 64
+
+    def _draws(self):
+        """[N,2] uniform draws for this step's re-initialisations (a view into a block drawn once per RAND_BLOCK steps)."""
+        if self._rand_i >= self.RAND_BLOCK:
+            self._rand_block = torch.rand(self.RAND_BLOCK, self.num_envs, 2, device=self.device, generator=self.gen)
+            self._rand_i = 0
+        self._rand_i += 1
+        return self._rand_block[self._rand_i - 1]
 
     @property
     def times(self):
@@ -78,13 +107,13 @@ class SMPLSimImitationVecEnv:
                                        _ptr(b.body_vel), task_ptr, self.obs_size, _ptr(rew), _ptr(parts), _ptr(term), _ptr(trunc),
                                        b._stream()))
 
-    def reset(self, mask=None, motion_ids=None, start_times=None):
+    def reset(self, mask=None, motion_ids=None, start_times=None, rand=None):
         """Reference-state init of all envs (mask None) or those with mask != 0: new clip + start time (unless given), the
         clip's qpos / qvel at that time written into the simulator state, mj_forward + observations — 4 launches, in place."""
         b, ml = self.base, self.motion_lib
         m = None if mask is None else mask.to(self.device).to(torch.uint8).contiguous()
         if motion_ids is None:
-            ml.resample(m, self.motion_ids, self.start_times, truncate_time=self.dt, generator=self.gen)
+            ml.resample(m, self.motion_ids, self.start_times, truncate_time=self.dt, rand=self._draws() if rand is None else rand)
             if start_times is None and not self.random_start:
                 self.start_times.zero_() if m is None else self.start_times.masked_fill_(m.bool(), 0.0)
         else:
@@ -101,13 +130,28 @@ class SMPLSimImitationVecEnv:
 
     def step(self, actions):
         b = self.base
+        if self.fused:
+            actions = actions.to(torch.float32).contiguous()
+            assert actions.shape == (self.num_envs, self.nu) and actions.device == self.device
+            rand = self._draws() if self.autoreset else None
+            self._keep = (actions, rand)
+            self._bind()
+            if b.lpt_order:
+                _check(lib().ss_schedule_longest_first(b.handle, b._stream()))
+            _check(lib().ss_imitation_step_fused(b.handle, _ptr(actions), _ptr(rand), b._stream()))
+            if b.lpt_order:
+                _check(lib().ss_set_order(b.handle, None))
+            # the flag bytes are 0 / 1: viewed, not converted (no launch)
+            return self.obs_buf, self.rew_buf, self.terminated.view(torch.bool), self.truncated.view(torch.bool), \
+                {"reward_parts": self.reward_parts, "final_observation": self.obs_final, "critic_state": self.obs_buf}
         b.step(actions)
         self._imitation(None, self.rew_buf, self.reward_parts, self.terminated, self.truncated)
         self.obs_buf[:, :self.self_obs_size] = b.obs_buf
         terminated, truncated = self.terminated.bool(), self.truncated.bool()
         info = {"reward_parts": self.reward_parts}
         if self.autoreset:
-            info["final_observation"] = self.obs_buf.clone()
+            self.obs_final.copy_(self.obs_buf)
+            info["final_observation"] = self.obs_final
             torch.bitwise_or(self.terminated, self.truncated, out=self.reset_buf)
             self.reset(mask=self.reset_buf)
         info["critic_state"] = self.obs_buf

@@ -239,6 +239,7 @@ class MotionLibSMPL:
         cdf = np.cumsum(self._sampling_batch_prob)
         cdf[-1] = 1.0 + 1e-6                                        # rand < 1 always lands in a clip
         self.sampling_cdf = up(cdf, np.float32)
+        self.load_count = getattr(self, "load_count", 0) + 1    # holders of device pointers into this library (fused imitation step) rebind
         if not silent:
             print(f"###### Sampling {M:d} motions:", idx[:5], self.curr_motion_keys[:5],
                   f"total length of {self.get_total_length():.3f}s and {F} frames.")
@@ -376,11 +377,12 @@ class MotionLibSMPL:
         return steps if motion_ids is None else steps[np.asarray(motion_ids.cpu() if torch.is_tensor(motion_ids) else motion_ids)]
 
     # ---- lookup (:311-423)
-    def resample(self, mask, motion_ids, start_times, truncate_time=0.0, generator=None):
+    def resample(self, mask, motion_ids, start_times, truncate_time=0.0, generator=None, rand=None):
         """sample_motions + sample_time for the envs with mask != 0 (None = all), in place, one launch
-        (motion_ids int32 [N], start_times float32 [N], device tensors)."""
+        (motion_ids int32 [N], start_times float32 [N], device tensors).  rand: optional [N,2] uniform draws to use."""
         N = motion_ids.shape[0]
-        rand = torch.rand(N, 2, device=self.device, generator=generator)
+        if rand is None:
+            rand = torch.rand(N, 2, device=self.device, generator=generator)
         self._keep_rs = (rand, mask)
         self._check(self._lib.ss_motion_resample(C.byref(self.data), _ptr(mask), _ptr(rand), _ptr(self.sampling_cdf), float(truncate_time), N,
                                                  _ptr(motion_ids), _ptr(start_times), self._stream()))

@@ -675,6 +675,44 @@ def test_imitation_env_autoreset_and_truncation_on_gpu():
     assert ((env.start_times + env.base.cur_t * env.dt) <= env.motion_len + 1e-5).all()
 
 
+@pytest.mark.parametrize("humanoid", ["smpl_humanoid", "smplx_humanoid"])
+def test_fused_imitation_step_on_gpu_equals_the_launch_sequence(humanoid):
+    """ss_imitation_step_fused (the whole imitation control step in one launch) against the six-launch sequence it replaces, with
+    re-initialisations: identical flags / clip assignments, outputs to float32 round-off (two compilations of the same
+    functions: -Os inside the stepper, -O3 in the motion kernels)."""
+    import test_motion_lib as T
+    from smplsim_amd.batch import ShardModel
+    from smplsim_amd.imitation import SMPLSimImitationVecEnv
+    if humanoid == "smpl_humanoid":
+        lib, nu = T.make_lib(None, device=0), 69
+    else:
+        lib, nu = T.smplx_lib(None, device=0)[0], 153
+    n = 96
+    envs = [SMPLSimImitationVecEnv(n, lib, model=ShardModel(humanoid=humanoid, device=0), seed=5, fused=f, termination_distance=0.15) for f in (True, False)]
+    assert envs[0].fused and not envs[1].fused
+    for e in envs:
+        e.offset[:, 2] = 0.05
+    o = [e.reset()[0].clone() for e in envs]
+    assert torch.equal(envs[0].motion_ids, envs[1].motion_ids) and torch.equal(envs[0].start_times, envs[1].start_times)
+    assert (o[0] - o[1]).abs().max() < 1e-5
+    g = torch.Generator().manual_seed(1)
+    resets = 0
+    for k in range(12):
+        act = envs[0].reference_actions() if k % 3 else ((torch.rand(n, nu, generator=g) - 0.5) * 1.5).to(envs[0].device)
+        (o1, r1, te1, tr1, i1), (o2, r2, te2, tr2, i2) = [e.step(act.clone()) for e in envs]
+        torch.cuda.synchronize()
+        assert torch.equal(te1, te2) and torch.equal(tr1, tr2), k
+        assert torch.equal(envs[0].motion_ids, envs[1].motion_ids) and torch.equal(envs[0].start_times, envs[1].start_times), k
+        assert torch.equal(envs[0].base.cur_t, envs[1].base.cur_t)
+        assert (r1 - r2).abs().max() < 1e-5 and (o1 - o2).abs().max() < 2e-4 and (i1["final_observation"] - i2["final_observation"]).abs().max() < 2e-4, k
+        assert (envs[0].base.qpos - envs[1].base.qpos).abs().max() < 1e-5
+        envs[1].base.qpos.copy_(envs[0].base.qpos); envs[1].base.qvel.copy_(envs[0].base.qvel)      # keep round-off from accumulating into a flag flip
+        envs[1].base.qpos_prev.copy_(envs[0].base.qpos_prev); envs[1].base.qvel_prev.copy_(envs[0].base.qvel_prev)
+        envs[1].base.qacc_warm.copy_(envs[0].base.qacc_warm)
+        resets += int((te1 | tr1).sum())
+    assert resets >= 20
+
+
 def test_motion_lib_52_body_skeleton_on_gpu():
     import test_motion_lib as T
     from smplsim_amd import _lib

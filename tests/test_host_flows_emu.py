@@ -31,13 +31,15 @@ def test_vec_env_autoreset_flows_on_the_emulator(emu_backend):
     assert int(fused.cur_t.max()) <= 3
 
 
-def test_imitation_env_end_to_end_on_the_emulator(emu_backend):
+@pytest.mark.parametrize("fused", [True, False])
+def test_imitation_env_end_to_end_on_the_emulator(emu_backend, fused):
     import test_motion_lib as T
     from oracle import motion_oracle as mo
     from smplsim_amd.imitation import SMPLSimImitationVecEnv
     lib = T.make_lib(emu_backend)
     n, J = 4, 24
-    env = SMPLSimImitationVecEnv(n, lib, seed=2)
+    env = SMPLSimImitationVecEnv(n, lib, seed=2, fused=fused)
+    assert env.fused == fused
     env.offset[:, 2] = 0.05
     ids = np.array([0, 1, 2, 0], np.int32)
     t0 = np.array([0.1, 0.2, 0.3, 1.25], np.float32)           # env 3 starts one step before the end of its 1.3 s clip
@@ -64,7 +66,42 @@ def test_imitation_env_end_to_end_on_the_emulator(emu_backend):
     want, _ = mo.imitation_reward(xpos, quat, bv[..., :3], bv[..., 3:], ref["rg_pos"], ref["rb_rot"], ref["body_vel"], ref["body_ang_vel"])
     assert np.abs(rew.numpy() - want)[~done].max() < 5e-5
     # the observation handed to the policy has the self part of the base env and the task part written in place
-    assert torch.equal(obs[:, :env.self_obs_size], env.base.obs_buf) and torch.isfinite(obs).all()
+    assert torch.isfinite(obs).all() and (fused or torch.equal(obs[:, :env.self_obs_size], env.base.obs_buf))
+
+
+def test_fused_imitation_step_equals_the_launch_sequence_it_replaces(emu_backend):
+    """ss_imitation_step_fused (one launch) against ss_step -> ss_imitation_step -> resample -> state_at -> ss_reset ->
+    ss_imitation_step, over steps in which envs run off their clips and drift away from them: every output identical."""
+    import test_motion_lib as T
+    from smplsim_amd.imitation import SMPLSimImitationVecEnv
+    lib = T.make_lib(emu_backend)
+    n = 5
+    envs = [SMPLSimImitationVecEnv(n, lib, seed=7, fused=f, termination_distance=0.12) for f in (True, False)]
+    ids = np.array([0, 1, 2, 0, 1], np.int32)
+    t0 = np.array([0.1, 0.2, 0.3, 1.2, 0.0], np.float32)
+    outs = [e.reset(motion_ids=ids, start_times=t0)[0].clone() for e in envs]
+    assert torch.equal(*outs)
+    g = torch.Generator().manual_seed(0)
+    resets = 0
+    for k in range(6):
+        act = envs[0].reference_actions() if k % 2 == 0 else (torch.rand(n, 69, generator=g) - 0.5) * 2.0   # wild actions: early termination
+        res = [e.step(act.clone()) for e in envs]
+        (o1, r1, te1, tr1, i1), (o2, r2, te2, tr2, i2) = res
+        assert torch.equal(te1, te2) and torch.equal(tr1, tr2) and torch.equal(r1, r2), k
+        assert torch.equal(i1["reward_parts"], i2["reward_parts"]) and torch.equal(i1["final_observation"], i2["final_observation"]), k
+        assert torch.equal(o1, o2), k
+        for f in ("motion_ids", "start_times"):
+            assert torch.equal(getattr(envs[0], f), getattr(envs[1], f)), (k, f)
+        for f in ("qpos", "qvel", "cur_t", "qacc_warm"):
+            assert torch.equal(getattr(envs[0].base, f), getattr(envs[1].base, f)), (k, f)
+        resets += int((te1 | tr1).sum())
+    assert resets >= 3                                          # clip ends and early terminations both happened
+    # evaluation-style stepping: no re-initialisation, finished envs keep going
+    for e in envs:
+        e.autoreset = False
+    act = envs[0].reference_actions()
+    res = [e.step(act.clone()) for e in envs]
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(envs[0].base.cur_t, envs[1].base.cur_t)
 
 
 def test_per_env_shapes_through_the_python_api_on_the_emulator(emu_backend):

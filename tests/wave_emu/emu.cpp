@@ -199,6 +199,19 @@ void lane_entry(int lane, void *arg) {
   LaunchCtx *c = (LaunchCtx *)arg;
   WaveEmu w{c->m, lane};
   int mode = c->k->mode;
+#ifndef SS_F64
+  if (c->k->im) {                                            // the IMIT instantiation of the GPU kernel (smplsim_hip.hip)
+    const ss::mo::ImFused *f = static_cast<const ss::mo::ImFused *>(c->k->im);
+    ss::run_env<WaveEmu, DOFP, CANDP, SLOTP, NPASS, true, SHAPED, HT, SELFCOL>(&w, c->k, c->T, c->L, c->env, mode);
+    w.sync();
+    if (ss::mo::fused_after_step(&w, f, c->k->im_rand, c->env)) {
+      ss::run_env<WaveEmu, DOFP, CANDP, SLOTP, NPASS, true, SHAPED, HT, SELFCOL>(&w, c->k, c->T, c->L, c->env, ss::MODE_RESET);
+      w.sync();
+      ss::mo::fused_after_reset(&w, f, c->env);
+    }
+    return;
+  }
+#endif
   for (int rep = 0; rep < 2; rep++) {
     const bool again = ss::run_env<WaveEmu, DOFP, CANDP, SLOTP, NPASS, true, SHAPED, HT, SELFCOL>(&w, c->k, c->T, c->L, c->env, mode);
     w.sync();
@@ -277,7 +290,8 @@ struct EmuBackend {
     (void)envs_per_wg; (void)lds_bytes;
     static thread_local Machine *m = new Machine();
     std::vector<ss::real> L(ss::env_slice_floats(k));
-    *k.work_counter = 0;
+    if (*k.work_counter != 0) return "work counter not zero at launch";
+    *k.work_counter_next = 0;
     for (int env = 0; env < nenv; env++) {
       // poison LDS so that reads of never-written locations are visible
       for (auto &x : L) x = __builtin_nanf("");
