@@ -117,6 +117,9 @@ template <> struct SelfColState<true> {
   real *rec, *G, *uvec, *lam, *Pb2, *delta2, *gc;          // per-env LDS arrays (HdrSC)
   real *Dinv, *rootf, *ysave, *An3;                        // D^-1 per node and the root's block inverses of the last aba_solve; re-solve buffers
   int nself;                                               // wave-uniform count of body-body contacts of this pass
+  // the tree Hessian of consecutive Newton iterations of one mj_step differs only when a floor-contact / joint-limit row changes
+  // side: while this lane's rows keep their state (sig) the factorization in LDS and the Delassus columns computed so far stay valid
+  unsigned sig_prev, gvalid;
 };
 
 template <class W, int DOFP, int CANDP, int SLOTP, int NPASS, bool SHAPED = false, class HT = HdrRuntime, bool SELFCOL = false>
@@ -687,6 +690,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       SS_FT0();
       typename HT::type h = HT::view(k->h);
       const int npair = k->sc.npair;
+      this->sig_prev = 0xFFFFFFFFu; this->gvalid = 0u;        // new pose, new rows: nothing of the last mj_step's solves carries over
       real *cand = this->G;                                  // candidates [kSelfCand][10]: pos3 n3 dist id b1 b2 (the Delassus block is not live yet)
       real *plist = this->Pb2;                               // pairs that passed the bounding-sphere test (<= 64 per round)
       if (lane < h.nb) {
@@ -866,18 +870,39 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       const int ns = this->nself, m = 3 * ns;
       const real mu = h.mu;
       real *G = this->G, *uvec = this->uvec, *lam = this->lam, *Pb2 = this->Pb2, *d2 = this->delta2;
-      {                                                      // no active body-body row (contacts inside the margin but separating):
-        int act = 0;                                         // the Hessian is the tree's
-        if (lane < ns) { const real *rc = this->rec + kSelfRec * lane; act = rc[RC_JAR] < 0 || rc[RC_JAR + 1] < 0 || rc[RC_JAR + 2] < 0 || rc[RC_JAR + 3] < 0; }
-        if (!w->any(act)) { aba_solve(delta, Pb); return; }
+      // ---- does the tree Hessian differ from the one factorized by the previous Newton iteration of this mj_step?
+      bool same;
+      {
+        unsigned sig = 0;
+#pragma unroll
+        for (int p = 0; p < SLOTP; p++) {
+          const Contact &c = con[p];
+          if (c.active)
+            for (int r_ = 0; r_ < 4; r_++) if (c.jar[r_] < 0.f) sig |= 1u << (4 * p + r_);
+        }
+#pragma unroll
+        for (int p = 0; p < DOFP; p++) { const Limit &l = lim[p]; if (l.sign != 0.f && l.jar < 0.f) sig |= 1u << (16 + p); }
+        same = !w->any(sig != this->sig_prev);
+        this->sig_prev = sig;
+        if (!same) this->gvalid = 0u;
+#ifdef SS_COUNT_SAME
+        if (lane == 0) { extern long ss_cnt_same, ss_cnt_all; ss_cnt_all++; ss_cnt_same += same; }
+#endif
       }
-      // ---- y = H_tree^-1 b_tree (b_tree: joint-space right-hand side in delta, tree per-body forces in Pb): the one full solve
-      // of this Newton iteration — everything below re-uses its factorization (aba_resolve)
+      int act = 0;
+      if (lane < ns) { const real *rc = this->rec + kSelfRec * lane; act = rc[RC_JAR] < 0 || rc[RC_JAR + 1] < 0 || rc[RC_JAR + 2] < 0 || rc[RC_JAR + 3] < 0; }
+      const unsigned long long amask = w->ballot(act);      // contacts with an active pyramid row
+      // ---- y = H_tree^-1 b_tree (b_tree: joint-space right-hand side in delta, tree per-body forces in Pb): a full solve, which
+      // leaves the factorization in LDS, or — same Hessian as last time — a bias-only re-solve with it
       fresh();
       SS_FT0();
-      for (int i = lane; i < h.nv; i += 64) d2[i] = delta[i];
-      w->sync();
-      aba_solve(delta, Pb);
+      if (same || amask) {
+        for (int i = lane; i < h.nv; i += 64) d2[i] = delta[i];
+        w->sync();
+      }
+      if (same) aba_resolve<1>([&](int dof, int) { return d2[dof]; }, [&](int b, int row, int) { return Pb[6 * b + row]; }, An, delta);
+      else aba_solve(delta, Pb);
+      if (!amask) return;                                    // no active body-body row (contacts inside the margin but separating): the Hessian is the tree's
       if (lane < ns) {
         real an, at1, at2;
         self_rel(this->rec + kSelfRec * lane, An + 8, 8, &an, &at1, &at2);
@@ -886,8 +911,11 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       w->sync();
       SS_FTICK(PF_SC_BASE);
       // ---- columns of G = E H_tree^-1 E^T: per contact, the responses to a unit relative force along its normal and two
-      // tangents in one 3-right-hand-side sweep (H x = - sum_b J_b^T pb with pb = -wrench on body 2, +wrench on body 1)
+      // tangents in one 3-right-hand-side sweep (H x = - sum_b J_b^T pb with pb = -wrench on body 2, +wrench on body 1).
+      // Only contacts with an active row enter the dense system; columns computed for this Hessian earlier are kept.
       for (int cc = 0; cc < ns; cc++) {
+        if (!((amask >> cc) & 1ull) || ((this->gvalid >> cc) & 1u)) continue;
+        this->gvalid |= 1u << cc;
         const real *rc = this->rec + kSelfRec * cc;
         const int cb1 = (int)rc[RC_B1], cb2 = (int)rc[RC_B2];
         const int r_ = lane & 7;

@@ -293,8 +293,18 @@ struct EmuBackend {
     if (*k.work_counter != 0) return "work counter not zero at launch";
     *k.work_counter_next = 0;
     for (int env = 0; env < nenv; env++) {
-      // poison LDS so that reads of never-written locations are visible
-      for (auto &x : L) x = __builtin_nanf("");
+      // poison LDS so that reads of never-written locations are visible: NaN by default; SS_EMU_POISON = neg | pos | rand puts
+      // finite garbage there instead (a NaN hides a read that only feeds a comparison: the comparison is just false)
+      {
+        static const char *pz = getenv("SS_EMU_POISON");
+        static unsigned long long lcg = 88172645463325252ull;
+        for (auto &x : L) {
+          if (!pz) x = __builtin_nanf("");
+          else if (pz[0] == 'n') x = (ss::real)-1e30;
+          else if (pz[0] == 'p') x = (ss::real)1e30;
+          else { lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; x = (ss::real)((double)(long long)(lcg >> 11) * 1e-12 - 4e3); }
+        }
+      }
       LaunchCtx c{&k, k.shared_g, L.data(), k.order ? k.order[env] : env, m};
       void (*entry)(int, void *) = nullptr;
       const int variant = ss::kernel_variant(k.h);
