@@ -913,25 +913,14 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       // ---- columns of G = E H_tree^-1 E^T: per contact, the responses to a unit relative force along its normal and two
       // tangents in one 3-right-hand-side sweep (H x = - sum_b J_b^T pb with pb = -wrench on body 2, +wrench on body 1).
       // Only contacts with an active row enter the dense system; columns computed for this Hessian earlier are kept.
-      for (int cc = 0; cc < ns; cc++) {
-        if (!((amask >> cc) & 1ull) || ((this->gvalid >> cc) & 1u)) continue;
-        this->gvalid |= 1u << cc;
-        const real *rc = this->rec + kSelfRec * cc;
-        const int cb1 = (int)rc[RC_B1], cb2 = (int)rc[RC_B2];
-        const int r_ = lane & 7;
-        real wr[3] = {0, 0, 0};
-        if (r_ < 6) { wr[0] = self_wrench(rc, real(1), real(0), real(0), r_); wr[1] = self_wrench(rc, real(0), real(1), real(0), r_); wr[2] = self_wrench(rc, real(0), real(0), real(1), r_); }
-        aba_resolve<3>([](int, int) { return real(0); },
-                       [&](int b, int, int q_) { return b == cb2 ? -wr[q_] : (b == cb1 ? wr[q_] : real(0)); }, this->An3, nullptr);
-        if (lane < ns) {
-          const real *rl = this->rec + kSelfRec * lane;
-          for (int q_ = 0; q_ < 3; q_++) {
-            real an, at1, at2;
-            self_rel(rl, this->An3 + 24 + 8 * q_, 24, &an, &at1, &at2);   // body b = node b + 1: An3[((b + 1) * 3 + q) * 8]
-            G[(3 * lane) * m + 3 * cc + q_] = an; G[(3 * lane + 1) * m + 3 * cc + q_] = at1; G[(3 * lane + 2) * m + 3 * cc + q_] = at2;
-          }
+      {
+        unsigned need = (unsigned)amask & ~this->gvalid;      // up to four contacts per pair of sweeps
+        this->gvalid |= need;
+        while (need) {
+          unsigned cm = 0;
+          for (int i = 0; i < 4 && need; i++) { const unsigned low = need & (0u - need); cm |= low; need &= ~low; }
+          aba_columns(cm, G, m);
         }
-        w->sync();
       }
       SS_FTICK(PF_SC_COLS);
       // ---- the small dense system, in the space of the pyramid rows (4 per contact, lane = row): with A the active rows
@@ -1398,6 +1387,155 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
               Aout[(n * K + q_) * 8 + r_] = apr + s_0 * x0 + s_1 * x1 + s_2 * x2;
               if (xout && q_ == 0 && r_ < 3) xout[3 * n + r_] = r_ == 0 ? x0 : (r_ == 1 ? x1 : x2);
             }
+          }
+        }
+        s0 += nk;
+        w->sync();
+      }
+    }
+  }
+
+  // Delassus columns of up to 4 body-body contacts (mask cm over the contact records) in ONE pair of sweeps with the
+  // factorization in LDS: the 12 right-hand sides (unit relative force along the normal and the two tangents of each contact)
+  // are spread over the lanes — lane = (node of the tree level, right-hand side), 5 nodes x 12 per pass, the lane carries all six
+  // rows of its node, so there is no cross-lane reduction — instead of one re-solve sweep per contact.  Hand-off rows travel through
+  // two level buffers in the Aown / IA region (dead here), indexed by the node's position in its level, so that a parent finds
+  // its children's rows going up and pushes its acceleration into its children's slots going down.  The accelerations are not
+  // kept: every (body, right-hand side) lane adds its body's share of the relative acceleration of every contact the body is
+  // part of straight into G (two commutative additions per entry at most: one per body of the contact).
+  //     G[(3 i + k) m + 3 c + d] = frame_i[k] . (acceleration of contact i's point, body 2 minus body 1, for unit force d of contact c)
+  SS_DEV void aba_columns(unsigned cm, real *G, int m) {
+    if constexpr (SELFCOL) {
+      fresh();
+      typename HT::type h = HT::view(k->h);
+      const int ns = this->nself;
+      const int q_ = lane % 12, grp = lane / 12;
+      int nsel = 0;
+      for (unsigned t_ = cm; t_; t_ &= t_ - 1) nsel++;
+      const bool on = grp < 5 && q_ < 3 * nsel;
+      int myc = 0;
+      { unsigned t_ = cm; for (int i = 0; i < q_ / 3 && t_; i++) t_ &= t_ - 1; while (t_ && !(t_ & 1u)) { t_ >>= 1; myc++; } }
+      const int dir = q_ % 3, col = 3 * myc + dir;
+      real wrq[6] = {0, 0, 0, 0, 0, 0};
+      int cb1 = -1, cb2 = -1;
+      if (on) {
+        const real *rc = this->rec + kSelfRec * myc;
+        cb1 = (int)rc[RC_B1]; cb2 = (int)rc[RC_B2];
+        for (int r_ = 0; r_ < 6; r_++) wrq[r_] = self_wrench(rc, dir == 0 ? real(1) : real(0), dir == 1 ? real(1) : real(0), dir == 2 ? real(1) : real(0), r_);
+        if (grp == 0) for (int i = 0; i < 3 * ns; i++) G[i * m + col] = 0;
+      }
+      real *buf = Aown;
+      real *ys = this->ysave;
+      const int bstride = 72 * h.maxlev;
+      const unsigned long long nk0 = h.nkpack[0], nk1 = h.nkpack[1];
+      // share of body b (acceleration acc: angular ; linear at the root origin) in the rows of every contact it belongs to
+      auto scatter = [&](int b, const real *acc) {
+        for (int i = 0; i < ns; i++) {
+          const real *rc = this->rec + kSelfRec * i;
+          const int sg = ((int)rc[RC_B2] == b) - ((int)rc[RC_B1] == b);
+          if (sg == 0) continue;
+          const real px = rc[RC_POS], py = rc[RC_POS + 1], pz_ = rc[RC_POS + 2];
+          const real ax = acc[3] + acc[1] * pz_ - acc[2] * py, ay = acc[4] + acc[2] * px - acc[0] * pz_, az = acc[5] + acc[0] * py - acc[1] * px;
+          const real nx = rc[RC_N], ny = rc[RC_N + 1], nz = rc[RC_N + 2], t1x = rc[RC_T1], t1y = rc[RC_T1 + 1], t1z = rc[RC_T1 + 2];
+          const real t2x = ny * t1z - nz * t1y, t2y = nz * t1x - nx * t1z, t2z = nx * t1y - ny * t1x;
+          const real sgn = (real)sg;
+          w->atomic_add(G + (3 * i) * m + col, sgn * (nx * ax + ny * ay + nz * az));
+          w->atomic_add(G + (3 * i + 1) * m + col, sgn * (t1x * ax + t1y * ay + t1z * az));
+          w->atomic_add(G + (3 * i + 2) * m + col, sgn * (t2x * ax + t2y * ay + t2z * az));
+        }
+      };
+      w->sync();
+      int s0 = h.nn;
+      for (int L = h.nlev - 1; L >= 2; --L) {                 // ---- upward sweep: bias forces only
+        const int nk = (int)(((L < 16 ? nk0 : nk1) >> (4 * (L & 15))) & 15ull) + 1;
+        s0 -= nk;
+        real *cur = buf + (L & 1) * bstride;
+        const real *prev = buf + ((L + 1) & 1) * bstride;
+        for (int ps = 0; ps * 5 < nk; ps++) {
+          const int kk = ps * 5 + grp;
+          if (on && kk < nk) {
+            const int e = ti(h.o_lev, s0 + kk), n = e & 255, cfirst = (e >> 16) & 255, cc = (e >> 24) & 255;
+            real pa[6];
+            const real sg_ = n - 1 == cb2 ? real(-1) : (n - 1 == cb1 ? real(1) : real(0));
+#pragma unroll
+            for (int r_ = 0; r_ < 6; r_++) pa[r_] = sg_ * wrq[r_];
+            for (int j = 0; j < cc; j++) {
+              const real *src = prev + ((cfirst + j) * 12 + q_) * 6;
+#pragma unroll
+              for (int r_ = 0; r_ < 6; r_++) pa[r_] += src[r_];
+            }
+            const real *sn = S + 18 * n;
+            real u[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) { real a_ = 0; for (int r_ = 0; r_ < 6; r_++) a_ += sn[6 * j + r_] * pa[r_]; u[j] = -a_; }
+            real *dst = cur + (kk * 12 + q_) * 6;
+#pragma unroll
+            for (int r_ = 0; r_ < 6; r_++) { const float4_t wv = ld4(Wst + (n * 6 + r_) * 4); dst[r_] = pa[r_] + wv.x * u[0] + wv.y * u[1] + wv.z * u[2]; }
+            const float4_t d0 = ld4(this->Dinv + 8 * n), d1 = ld4(this->Dinv + 8 * n + 4);
+            real *yo = ys + (n * 12 + q_) * 3;
+            yo[0] = d0.x * u[0] + d0.y * u[1] + d0.z * u[2]; yo[1] = d0.y * u[0] + d0.w * u[1] + d1.x * u[2]; yo[2] = d0.z * u[0] + d1.x * u[1] + d1.y * u[2];
+          }
+        }
+        w->sync();
+      }
+      if (on && grp == 0) {                                   // ---- root (nodes 0 and 1 as one 6-dof joint), lane = right-hand side
+        const real *prev = buf;                              // level 2's rows
+        const int e = ti(h.o_lev, 1), cfirst = (e >> 16) & 255, cc = (e >> 24) & 255;
+        real f6[6];
+        const real sg_ = 0 == cb2 ? real(-1) : (0 == cb1 ? real(1) : real(0));
+#pragma unroll
+        for (int r_ = 0; r_ < 6; r_++) f6[r_] = -sg_ * wrq[r_];
+        for (int j = 0; j < cc; j++) {
+          const real *src = prev + ((cfirst + j) * 12 + q_) * 6;
+#pragma unroll
+          for (int r_ = 0; r_ < 6; r_++) f6[r_] -= src[r_];
+        }
+        const real *rf = this->rootf;
+        real ga[3], acc[6], gl[3];
+        for (int i = 0; i < 3; i++) ga[i] = f6[i] - (rf[12 + 3 * i] * f6[3] + rf[12 + 3 * i + 1] * f6[4] + rf[12 + 3 * i + 2] * f6[5]);
+        acc[0] = rf[6] * ga[0] + rf[7] * ga[1] + rf[8] * ga[2];
+        acc[1] = rf[7] * ga[0] + rf[9] * ga[1] + rf[10] * ga[2];
+        acc[2] = rf[8] * ga[0] + rf[10] * ga[1] + rf[11] * ga[2];
+        for (int j = 0; j < 3; j++) gl[j] = f6[3 + j] - (rf[21 + j] * acc[0] + rf[24 + j] * acc[1] + rf[27 + j] * acc[2]);
+        acc[3] = rf[0] * gl[0] + rf[1] * gl[1] + rf[2] * gl[2];
+        acc[4] = rf[1] * gl[0] + rf[3] * gl[1] + rf[4] * gl[2];
+        acc[5] = rf[2] * gl[0] + rf[4] * gl[1] + rf[5] * gl[2];
+        real *nxt = buf + bstride;                           // level 2's acceleration slots (the rows of level 3 that lived there are consumed)
+        for (int j = 0; j < cc; j++) {
+          real *o = nxt + ((cfirst + j) * 12 + q_) * 6;
+#pragma unroll
+          for (int r_ = 0; r_ < 6; r_++) o[r_] = acc[r_];
+        }
+        scatter(0, acc);
+      }
+      w->sync();
+      s0 = 2;
+      for (int L = 2; L < h.nlev; L++) {                      // ---- downward sweep: accelerations, pushed into the children's slots
+        const int nk = (int)(((L < 16 ? nk0 : nk1) >> (4 * (L & 15))) & 15ull) + 1;
+        const real *mine = buf + ((L + 1) & 1) * bstride;
+        real *nxt = buf + (L & 1) * bstride;
+        for (int ps = 0; ps * 5 < nk; ps++) {
+          const int kk = ps * 5 + grp;
+          if (on && kk < nk) {
+            const int e = ti(h.o_lev, s0 + kk), n = e & 255, cfirst = (e >> 16) & 255, cc = (e >> 24) & 255;
+            const real *apk = mine + (kk * 12 + q_) * 6;
+            real ap[6], acc[6];
+#pragma unroll
+            for (int r_ = 0; r_ < 6; r_++) ap[r_] = apk[r_];
+            const real *yo = ys + (n * 12 + q_) * 3;
+            real x0 = yo[0], x1 = yo[1], x2 = yo[2];
+#pragma unroll
+            for (int c = 0; c < 6; c++) { const float4_t wv = ld4(Wst + (n * 6 + c) * 4); x0 -= wv.x * ap[c]; x1 -= wv.y * ap[c]; x2 -= wv.z * ap[c]; }
+            const real *sn = S + 18 * n;
+#pragma unroll
+            for (int r_ = 0; r_ < 6; r_++) acc[r_] = ap[r_] + sn[r_] * x0 + sn[6 + r_] * x1 + sn[12 + r_] * x2;
+            if (L + 1 < h.nlev)
+              for (int j = 0; j < cc; j++) {
+                real *o = nxt + ((cfirst + j) * 12 + q_) * 6;
+#pragma unroll
+                for (int r_ = 0; r_ < 6; r_++) o[r_] = acc[r_];
+              }
+            scatter(n - 1, acc);
           }
         }
         s0 += nk;

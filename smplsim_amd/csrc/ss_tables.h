@@ -295,7 +295,9 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
     for (int k = 0; k < 9; k++) c[6 + k] = (real)G[k];
     c[15] = (real)d.geom_type[b];
   }
-  out.sc = make_layout_sc(nb, h.env_floats);
+  out.sc = make_layout_sc(nb, h.env_floats, h.l_Aown);
+  // up to Wst (kept for the re-solves) everything behind Aown is solver scratch
+  if (24 * (nb + 1) > h.l_Wst - h.l_Aown || 2 * 72 * h.maxlev > h.l_Wst - h.l_Aown) { out.error = "no room for the re-solve buffers over Aown / IA"; return false; }
   out.sc.npair = (int)out.pairs.size();
 
   h.dt = (real)d.timestep; h.grav = (real)d.gravity; h.margin = (real)d.margin; h.mu = (real)d.friction;

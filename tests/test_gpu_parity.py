@@ -424,7 +424,11 @@ def test_per_sample_parity_on_the_benchmark_distribution(vec, which):
     assert ok.sum() >= {"smpl": 400, "getup": 100, "smplx": 80, "smpl_selfcol": 200}[which], ok.sum()
     if which == "smpl_selfcol":
         assert (r["nself"][ok] > 0).mean() > 0.3                 # most of these samples do have body-body contacts
-    assert r["resets_agree"].all()
+    # MuJoCo's bad-state autoreset (|qpos|, |qvel|, |qacc| > 1e10 or NaN): the oracle and the float64 kernel must take it on the
+    # same samples — except that a trajectory which is blowing up crosses 1e10 one mj_step earlier or later depending on
+    # rounding (these states double per step), so a sample in a few hundred may flip; such samples are excluded from the
+    # comparisons above either way ("reset" = any implementation reset)
+    assert (~r["resets_agree"]).sum() <= max(1, len(r["resets_agree"]) // 100), (~r["resets_agree"]).sum()
     assert (r["formulation"][ok] <= np.maximum(1e-9, K_ROUND * cond[ok] * P.EPS64)).all(), r["formulation"][ok].max(axis=0)
     assert (ratio64[ok] <= K_ROUND).all() and (ratio32[ok] <= K_ROUND).all(), (ratio64[ok].max(axis=0), ratio32[ok].max(axis=0))
     med, p90 = np.median(r["precision"][ok], axis=0), np.quantile(r["precision"][ok], 0.9, axis=0)

@@ -34,7 +34,11 @@ def _check(r, label, min_samples):
         lines.append(f"obs (f32 vs f64 kernel) max {r['obs'][ok].max():.3e}  reward max {r['reward'][ok].max():.3e}")
     print("\n".join(lines))
     assert ok.sum() >= min_samples, ok.sum()
-    assert r["resets_agree"].all()
+    # MuJoCo's bad-state autoreset (|qpos|, |qvel|, |qacc| > 1e10 or NaN): the oracle and the float64 kernel must take it on the
+    # same samples — except that a trajectory which is blowing up crosses 1e10 one mj_step earlier or later depending on
+    # rounding (these states double per step), so a sample in a few hundred may flip; such samples are excluded from the
+    # comparisons above either way ("reset" = any implementation reset)
+    assert (~r["resets_agree"]).sum() <= max(1, len(r["resets_agree"]) // 100), (~r["resets_agree"]).sum()
     assert (r["formulation"][ok] <= np.maximum(1e-9, K_ROUND * cond[ok] * P.EPS64)).all(), r["formulation"][ok].max(axis=0)
     med, p90 = np.median(r["precision"][ok], axis=0), np.quantile(r["precision"][ok], 0.9, axis=0)
     assert med[0] < 5e-7 and med[1] < 5e-5 and p90[0] < 5e-6 and p90[1] < 5e-4, (med, p90)
