@@ -960,9 +960,11 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
           }
           arow[j] = v_;
         }
+        // inactive rows are identity rows with zero columns: their pivot steps would be no-ops, so only the active ones run
+        const unsigned long long rowmask = w->ballot(act_i);
 #pragma unroll
         for (int p_ = 0; p_ < 4 * kMaxSelf; p_++) {           // forward elimination
-          if (p_ < n4) {
+          if (p_ < n4 && ((rowmask >> p_) & 1ull)) {
             if (lane < n4) { cbuf[lane] = arow[p_]; rbuf[lane] = rhs; }
             w->sync();
             if (lane < n4 && lane > p_) {
@@ -974,9 +976,11 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
             w->sync();
           }
         }
+        if (lane < n4) cbuf[lane] = 0;                        // nu of the inactive rows
+        w->sync();
 #pragma unroll
         for (int p_ = 4 * kMaxSelf - 1; p_ >= 0; p_--) {      // back substitution
-          if (p_ < n4) {
+          if (p_ < n4 && ((rowmask >> p_) & 1ull)) {
             if (lane == p_) cbuf[p_] = rhs / arow[p_];
             w->sync();
             if (lane < p_) rhs -= arow[p_] * cbuf[p_];
@@ -1219,10 +1223,12 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       f6[4] = Ti[1] * gl0 + Ti[3] * gl1 + Ti[4] * gl2;
       f6[5] = Ti[2] * gl0 + Ti[4] * gl1 + Ti[5] * gl2;
       if constexpr (SELFCOL)
-        if (lane == 0) {                                       // the root's block inverses, for aba_resolve
+        if (lane == 0) {                                       // the root's block inverses, for aba_resolve: Ti | Si | Q T^-1 | Q  (8 x 16 bytes)
           real *rf = this->rootf;
-          for (int i = 0; i < 6; i++) { rf[i] = Ti[i]; rf[6 + i] = Si[i]; }
-          for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { rf[12 + 3 * i + j] = QT[i][j]; rf[21 + 3 * i + j] = A6[i][3 + j]; }
+          st4w(rf, Ti[0], Ti[1], Ti[2], Ti[3]); st4w(rf + 4, Ti[4], Ti[5], Si[0], Si[1]); st4w(rf + 8, Si[2], Si[3], Si[4], Si[5]);
+          st4w(rf + 12, QT[0][0], QT[0][1], QT[0][2], QT[1][0]); st4w(rf + 16, QT[1][1], QT[1][2], QT[2][0], QT[2][1]);
+          st4w(rf + 20, QT[2][2], A6[0][3], A6[0][4], A6[0][5]); st4w(rf + 24, A6[1][3], A6[1][4], A6[1][5], A6[2][3]);
+          st4w(rf + 28, A6[2][4], A6[2][5], 0.f, 0.f);
         }
       // f6 = spatial acceleration of body 0; joint solution: x_trans = a_lin, x_rot = R^T a_ang
       if (lane < 6) An[8 + lane] = lane == 0 ? f6[0] : lane == 1 ? f6[1] : lane == 2 ? f6[2] : lane == 3 ? f6[3] : lane == 4 ? f6[4] : f6[5];
