@@ -133,6 +133,11 @@ kern_t pick_kernel(int variant, int flavour, const ss::Hdr &h) {
     if (variant == 1) return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, true, false, ss::HdrRuntime, true>;
     return nullptr;
   }
+  if (flavour == 5) {                                        // body-body contacts + per-env body shapes
+    if (variant == 0) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS_SC, true, true, ss::HdrRuntime, true>;
+    if (variant == 1) return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, true, true, ss::HdrRuntime, true>;
+    return nullptr;
+  }
   if (variant == 0) {                                        // SMPL layout (24 bodies)
     if (flavour == 1) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, false>;
     return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, true>;
@@ -170,7 +175,7 @@ struct HipBackend {
   static int kernel_regs() { return regs_ref(); }
   static const char *launch(const ss::KArgs &k, int nenv, int envs_per_wg, size_t lds_bytes, void *stream, int fixed_epw, int max_wgs) {
     const bool bodyout = k.out0 && (k.mode == ss::MODE_STEP || k.mode == ss::MODE_RESET);
-    const int flavour = k.im ? 4 : (k.cfg.self_collision ? 3 : (k.st.shape_id ? 2 : (bodyout ? 1 : 0)));
+    const int flavour = k.im ? 4 : (k.cfg.self_collision ? (k.st.shape_id ? 5 : 3) : (k.st.shape_id ? 2 : (bodyout ? 1 : 0)));
     kern_t kern = pick_kernel(ss::kernel_variant(k.h), flavour, k.h);
     if (!kern) return "no kernel variant for this model size";
     static thread_local kern_t configured[16] = {};

@@ -91,7 +91,7 @@ struct ss_api {
     if (num_shapes == 1) return model_create(d, device, out);
     ss_model *m = new (std::nothrow) ss_model();
     if (!m) return fail(SS_ERR_NOMEM, "out of host memory");
-    std::vector<ss::real> bodyc, candc;
+    std::vector<ss::real> bodyc, candc, geomc;
     for (int s = 0; s < num_shapes; s++) {
       ss::HostModel hm;
       if (!ss::build_host_model(d[s], hm)) { std::string e = "shape " + std::to_string(s) + ": " + hm.error; delete m; return fail(SS_ERR_INVALID, e); }
@@ -106,7 +106,7 @@ struct ss_api {
         // everything but the geometry must agree: tree, joints, limits, gains, actuators, geom types, contact set, options
         const bool same = h.nb == g.nb && h.nv == g.nv && h.nu == g.nu && h.ncand == g.ncand && h.nbox == g.nbox && h.nslot == g.nslot &&
                           h.shared_words == g.shared_words && h.env_floats == g.env_floats && hm.shared == m->hm.shared &&
-                          hm.candb == m->hm.candb && hm.illegal_mask == m->hm.illegal_mask && h.dt == g.dt && h.grav == g.grav &&
+                          hm.candb == m->hm.candb && hm.pairs == m->hm.pairs && hm.illegal_mask == m->hm.illegal_mask && h.dt == g.dt && h.grav == g.grav &&
                           h.margin == g.margin && h.mu == g.mu && h.K == g.K && h.B == g.B;
         if (!same) { delete m; return fail(SS_ERR_INVALID, "shape " + std::to_string(s) + " differs from shape 0 in more than its geometry"); }
       }
@@ -114,6 +114,7 @@ struct ss_api {
       iw.resize((h.nv + 3) & ~3, ss::real(0));
       bodyc.insert(bodyc.end(), iw.begin(), iw.end());        // block = body constants, then the dof inverse weights
       candc.insert(candc.end(), hm.candc.begin(), hm.candc.end());
+      geomc.insert(geomc.end(), hm.geomc.begin(), hm.geomc.end());   // pair functions (self_collision batches): geoms of this shape
     }
     if (12 * m->hm.h.nb > m->hm.h.l_Wst - m->hm.h.l_IA) { delete m; return fail(SS_ERR_LDS, "no room for the per-env body offsets"); }
     m->device = device; m->num_shapes = num_shapes;
@@ -127,7 +128,9 @@ struct ss_api {
     m->d_bodyc = (ss::real *)up(bodyc.data(), bodyc.size() * sizeof(ss::real));
     m->d_candc = (ss::real *)up(candc.data(), candc.size() * sizeof(ss::real));
     m->d_candb = (int32_t *)up(m->hm.candb.data(), m->hm.candb.size() * 4);
-    if (!m->d_shared || !m->d_bodyc || !m->d_candc || !m->d_candb) { model_destroy(m); return fail(SS_ERR_HIP, "device table upload failed"); }
+    m->d_pairs = (int32_t *)up(m->hm.pairs.data(), m->hm.pairs.size() * 4);
+    m->d_geomc = (ss::real *)up(geomc.data(), geomc.size() * sizeof(ss::real));
+    if (!m->d_shared || !m->d_bodyc || !m->d_candc || !m->d_candb || !m->d_pairs || !m->d_geomc) { model_destroy(m); return fail(SS_ERR_HIP, "device table upload failed"); }
     *out = m;
     return SS_OK;
   }
@@ -149,7 +152,6 @@ struct ss_api {
     if (cfg->control_freq_inv < 1) return fail(SS_ERR_INVALID, "control_freq_inv must be >= 1");
     if (m->num_shapes > 1 && !st->shape_id) return fail(SS_ERR_INVALID, "a model with several shapes needs ss_state.shape_id");
     if (m->num_shapes == 1 && st->shape_id) return fail(SS_ERR_INVALID, "ss_state.shape_id given for a single-shape model");
-    if (cfg->self_collision && m->num_shapes > 1) return fail(SS_ERR_INVALID, "self_collision with per-env body shapes is not supported yet");
     if (cfg->self_collision && !m->d_pairs) return fail(SS_ERR_INVALID, "model has no pair table");
     if (cfg->task == SS_TASK_REACH && (cfg->reach_body < 0 || cfg->reach_body >= m->hm.h.nb)) return fail(SS_ERR_INVALID, "reach_body out of range");
     const ss::Hdr &h = m->hm.h;

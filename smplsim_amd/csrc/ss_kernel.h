@@ -104,7 +104,7 @@ SS_DEV bool is_bad(real x) { return !(x <= real(1e10) && x >= -real(1e10)); }
 // through the env's LDS slice) instead of the workgroup's shared table.  A separate instantiation: the single-shape code
 // is textually what it was.
 template <bool SHAPED> struct ShapeTables {};
-template <> struct ShapeTables<true> { const real *bodyc_s, *candc_s, *dinvw_s; };   // this env's tables
+template <> struct ShapeTables<true> { const real *bodyc_s, *candc_s, *dinvw_s, *geomc_s; };   // this env's tables
 
 // SELFCOL: contacts between the humanoid's own bodies (ss_env_cfg.self_collision).  Their rows couple two bodies, which the
 // per-body generalized inertias of the articulated-body solve cannot express; the Newton system H = H_tree + E^T W E (E: relative
@@ -157,6 +157,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
   SS_DEV const real *bodyc() const { if constexpr (SHAPED) return this->bodyc_s; else return k->bodyc; }
   SS_DEV const real *candc() const { if constexpr (SHAPED) return this->candc_s; else return k->candc; }
   SS_DEV real dof_invweight(int dof) const { if constexpr (SHAPED) return this->dinvw_s[dof]; else return dc(dof, 4); }
+  SS_DEV const real *geomc() const { if constexpr (SHAPED) return this->geomc_s; else return k->geomc; }   // geoms in their body frames (pair functions)
   // body of a contact slot: box b owns slots 4b'..4b'+3 (b' = box order), capsule ends follow
   SS_DEV int h_box_body(int sl) const { return k->candb[8 * (sl >> 2)] & 255; }
   SS_DEV int h_caps_body(int sl) const { int e = sl - 4 * k->h.nbox; int ci = 8 * k->h.nbox + e; return ci < k->h.ncand ? (k->candb[ci] & 255) : 0; }
@@ -168,6 +169,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       const size_t sid = (size_t)k->st.shape_id[env];
       this->bodyc_s = k->bodyc + sid * shape_stride(h); this->candc_s = k->candc + sid * h.ncand * kCandC;
       this->dinvw_s = this->bodyc_s + h.nb * kBodyC;
+      this->geomc_s = k->geomc ? k->geomc + sid * h.nb * kGeomC : nullptr;
     }
     S = L + h.l_S; R = L + h.l_R; r = L + h.l_r; V = L + h.l_V; Ab = L + h.l_Ab; An = L + h.l_An; Ad = An;
     Gb = L + h.l_Gb; tmpb = L + h.l_tmp; Aown = L + h.l_Aown; IA = L + h.l_IA; Ubuf = L + h.l_Ubuf; Wst = L + h.l_Wst;
@@ -694,7 +696,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       real *cand = this->G;                                  // candidates [kSelfCand][10]: pos3 n3 dist id b1 b2 (the Delassus block is not live yet)
       real *plist = this->Pb2;                               // pairs that passed the bounding-sphere test (<= 64 per round)
       if (lane < h.nb) {
-        const real *gcst = k->geomc + lane * kGeomC;
+        const real *gcst = geomc() + lane * kGeomC;
         const real *Rb = R + 9 * lane, *rb = r + 3 * lane;
         for (int i = 0; i < 3; i++) this->gc[3 * lane + i] = rb[i] + Rb[3 * i] * gcst[0] + Rb[3 * i + 1] * gcst[1] + Rb[3 * i + 2] * gcst[2];
       }
@@ -706,7 +708,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
         int pass_ = 0, q = p * 64 + lane;
         if (p < npass && q < npair) {
           const int pr = k->pairs[q], b1 = pr & 255, b2 = pr >> 8;
-          const real *g1 = k->geomc + b1 * kGeomC, *g2 = k->geomc + b2 * kGeomC;
+          const real *g1 = geomc() + b1 * kGeomC, *g2 = geomc() + b2 * kGeomC;
           const real r1 = g1[15] == real(SS_GEOM_BOX) ? SS_M(sqrt)(g1[3] * g1[3] + g1[4] * g1[4] + g1[5] * g1[5]) : g1[3] + g1[4];
           const real r2 = g2[15] == real(SS_GEOM_BOX) ? SS_M(sqrt)(g2[3] * g2[3] + g2[4] * g2[4] + g2[5] * g2[5]) : g2[3] + g2[4];
           const real dx = this->gc[3 * b2] - this->gc[3 * b1], dy = this->gc[3 * b2 + 1] - this->gc[3 * b1 + 1], dz = this->gc[3 * b2 + 2] - this->gc[3 * b1 + 2];
@@ -725,7 +727,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
             pid = (int)plist[lane];
             const int pr = k->pairs[pid];
             b1 = pr & 255; b2 = pr >> 8;
-            const real *g1 = k->geomc + b1 * kGeomC, *g2 = k->geomc + b2 * kGeomC;
+            const real *g1 = geomc() + b1 * kGeomC, *g2 = geomc() + b2 * kGeomC;
             real p1[3], m1[9], p2[3], m2[9];
             geom_frame(b1, g1, p1, m1); geom_frame(b2, g2, p2, m2);
             const real a1[3] = {m1[2], m1[5], m1[8]}, a2[3] = {m2[2], m2[5], m2[8]};

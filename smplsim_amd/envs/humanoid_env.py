@@ -105,10 +105,6 @@ class HumanoidEnv:
                                  pdp_scale=e.pdp_scale, pdd_scale=e.pdd_scale, sim_timestep_inv=self.sim_timestep_inv)
         if shape_mcs is not None and len(shape_mcs) > 1:
             kw["shape_id"] = list(range(num_envs))
-            if self.self_collision:                          # the pair functions read one geom table per model so far
-                import warnings
-                warnings.warn("per-env body shapes run with floor contacts only (self_collision is not combined with shape tables yet)")
-                self.self_collision = False
         self._vec = SMPLSimVecEnv(num_envs, model=self._model, task=self._TASK, state_init=e.state_init,
                                   self_obs_v=self.self_obs_v, control_mode=self.control_mode,
                                   episode_length=self.max_episode_length, control_freq_inv=self.control_freq_inv,

@@ -781,6 +781,34 @@ def test_smplx_imitation_env_on_gpu():
         assert np.abs(_np(obs)[:, env.base.obs_size:] - want_obs).max() < 1e-3 and np.abs(_np(rew) - want_rew).max() < 1e-4
 
 
+def test_self_collision_with_per_env_shapes_on_gpu(vec):
+    """Body-body contacts with one geom table per body shape (SHAPED + SELFCOL instantiation): every env of the mixed batch
+    against the same env in a single-shape self-collision batch (another instantiation of the same kernel source: round-off)."""
+    from smplsim_amd.batch import ShardModel
+    from smplsim_amd.mjcf_writer import scaled_xml_str
+    xmls = [scaled_xml_str("smpl_humanoid", 1.0), scaled_xml_str("smpl_humanoid", 0.9, {"L_Knee": 1.1, "R_Knee": 1.1}),
+            scaled_xml_str("smpl_humanoid", 1.1, {"Chest": 0.9, "L_Elbow": 1.2})]
+    sid = torch.tensor([0, 1, 2, 2, 1, 0, 0, 1, 2])
+    mixed = vec(9, model=ShardModel(xmls=xmls), shape_id=sid, autoreset=False, self_collision=True)
+    solos = [(torch.nonzero(sid == s)[:, 0].to(mixed.device), vec(3, model=ShardModel(xml=xmls[s]), autoreset=False, self_collision=True)) for s in range(3)]
+    obs0 = mixed.reset()[0]
+    for idx, so in solos:
+        assert (so.reset()[0] - obs0[idx]).abs().max() < 1e-6
+    g = torch.Generator().manual_seed(3)
+    seen = 0
+    for k in range(6):
+        act = (torch.rand(1, 69, generator=g) * 2 - 1).repeat(9, 1).to(mixed.device)
+        obs = mixed.step(act)[0]
+        for idx, so in solos:
+            o2 = so.step(act[idx])[0]
+            assert torch.equal(so.self_contacts, mixed.self_contacts[idx]), k
+            assert (so.qpos - mixed.qpos[idx]).abs().max() < TOL_QPOS_FREE and (o2 - obs[idx]).abs().max() < 2 * TOL_OBS, k
+            so.qpos.copy_(mixed.qpos[idx]); so.qvel.copy_(mixed.qvel[idx]); so.qacc_warm.copy_(mixed.qacc_warm[idx])
+            so.qpos_prev.copy_(mixed.qpos_prev[idx]); so.qvel_prev.copy_(mixed.qvel_prev[idx])
+        seen += int(mixed.self_contacts.sum())
+    assert seen > 0
+
+
 def test_shape_varied_env_groups_match_their_oracles_and_standalone_envs(vec):
     """Two body shapes in one shard: every group against the oracle built from ITS MJCF, and bit-identical
     to the same group stepped as a standalone env (the grouping / streams change nothing)."""

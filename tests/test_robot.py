@@ -135,9 +135,9 @@ def test_gym_env_with_shape_variation(emu_backend):
         HumanoidEnv(cfg)
     names, parents, V, J, W = _synthetic_meshes(_table("smpl_humanoid"), 3, 5)
     bodies = dict(verts=V, joints=J, skin_weights=W, joint_names=names, parents=parents)
-    with pytest.warns(UserWarning):
-        env = SMPLSimGymVecEnv(cfg, 3, bodies=bodies)
+    env = SMPLSimGymVecEnv(cfg, 3, bodies=bodies)
     assert env._single._model.num_shapes == 3 and env.single_observation_space.shape == (289,)
+    assert env._single.self_collision                            # the reference's contact set, with one geom table per body shape
     obs, _ = env.reset(seed=1)
     o2 = env.step(np.zeros((3, 69), np.float32))[0]
     assert o2.shape == (3, 289) and np.isfinite(o2).all() and np.abs(o2[0] - o2[1]).max() > 1e-4     # different bodies move differently

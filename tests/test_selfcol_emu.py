@@ -121,3 +121,42 @@ def test_smplx_with_self_collision():
         d.qpos = Q[i]; d.qvel = V[i]; d.ctrl = T[i]; d.warm = np.zeros(mc.nv); d.forward()
         assert eb.self_contacts[i] == d.nself
         assert np.abs(qacc[i] - d.qacc).max() < 1e-9 * np.abs(d.qacc).max()
+
+
+def test_self_collision_with_per_env_body_shapes():
+    """Body-body contacts + ss_model_create_shapes (the reference's has_shape_variation humanoids collide with themselves too): the
+    pair functions read the geom table of the env's own shape.  Every env of the mixed batch equals the same env in a single-shape
+    self-collision batch of its shape, bit for bit, and the thick-limbed shape collides where the thin one does not."""
+    from smplsim_amd.mjcf import compile_mjcf
+    from smplsim_amd.mjcf_writer import scaled_xml_str
+    xmls = [scaled_xml_str("smpl_humanoid", 1.0), scaled_xml_str("smpl_humanoid", 0.9, {"L_Knee": 1.1, "R_Knee": 1.1}),
+            scaled_xml_str("smpl_humanoid", 1.1, {"Chest": 0.9, "L_Elbow": 1.2})]
+    mcs = [compile_mjcf(x) for x in xmls]
+    tabs = pd_tables(mcs[0])
+    sid = np.array([0, 1, 2, 2, 1, 0], np.int32)
+    n = len(sid)
+    eb = emu.EmuBatch(mcs[0], tabs, n, legal_bodies=FEET, shape_mcs=mcs, shape_id=sid, self_collision=True)
+    solos = [(np.nonzero(sid == s)[0], emu.EmuBatch(mcs[s], tabs, int((sid == s).sum()), legal_bodies=FEET, self_collision=True)) for s in range(3)]
+    obs0 = eb.reset()
+    for idx, so in solos:
+        assert np.array_equal(so.reset(), obs0[idx])
+    rs = np.random.default_rng(4)
+    seen = 0
+    for k in range(6):
+        act = np.repeat(rs.uniform(-1, 1, (1, 69)), n, axis=0)               # the same violent action for every shape
+        obs, rew, term, trunc = eb.step(act)
+        for idx, so in solos:
+            o2, r2, t2, u2 = so.step(act[idx])
+            assert np.array_equal(o2, obs[idx]) and np.array_equal(so.qpos, eb.qpos[idx]) and np.array_equal(so.self_contacts, eb.self_contacts[idx]), k
+        seen += int(eb.self_contacts.sum())
+    assert seen > 0
+    om = oracle_model(self_collision=True, max_self_contacts=8)            # shape 0 is the packaged fixture: its oracle applies
+    oenv = O.OracleEnv(om)
+    oenv.reset()
+    e0 = emu.EmuBatch(mcs[0], tabs, 2, legal_bodies=FEET, shape_mcs=mcs, shape_id=np.array([0, 2], np.int32), self_collision=True)
+    e0.reset()
+    for k in range(4):
+        a = rs.uniform(-1, 1, 69)
+        e0.set_state(np.stack([oenv.data.qpos, e0.qpos[1]]), np.stack([oenv.data.qvel, e0.qvel[1]]), e0.qpos_prev, e0.qvel_prev)
+        oenv.step(a); e0.step(np.stack([a, a]))
+        assert e0.self_contacts[0] == oenv.data.nself and np.abs(e0.qpos[0] - oenv.data.qpos).max() < 2e-5 * max(1.0, np.abs(oenv.data.qvel).max())

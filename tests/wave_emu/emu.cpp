@@ -309,8 +309,8 @@ struct EmuBackend {
       void (*entry)(int, void *) = nullptr;
       const int variant = ss::kernel_variant(k.h);
       if (k.cfg.self_collision) {
-        if (variant == 0) entry = lane_entry<2, 2, 1, 1, false, ss::HdrRuntime, true>;
-        else if (variant == 1) entry = lane_entry<3, 3, 2, 2, false, ss::HdrRuntime, true>;
+        if (variant == 0) entry = k.st.shape_id ? lane_entry<2, 2, 1, 1, true, ss::HdrRuntime, true> : lane_entry<2, 2, 1, 1, false, ss::HdrRuntime, true>;
+        else if (variant == 1) entry = k.st.shape_id ? lane_entry<3, 3, 2, 2, true, ss::HdrRuntime, true> : lane_entry<3, 3, 2, 2, false, ss::HdrRuntime, true>;
         else return "no kernel variant for this model size";
         run_wave(m, entry, &c);
         continue;
