@@ -55,6 +55,12 @@ struct ss_batch {
   ss_imitation_io im_io{};
 };
 
+inline bool same_pair_ids(const std::vector<int32_t> &a, const std::vector<int32_t> &b) {
+  if (a.size() != b.size()) return false;
+  for (size_t i = 0; i < a.size(); i += 2) if (a[i] != b[i]) return false;
+  return true;
+}
+
 template <class BE>
 struct ss_api {
   static int fail(int code, const std::string &msg) {
@@ -92,6 +98,7 @@ struct ss_api {
     ss_model *m = new (std::nothrow) ss_model();
     if (!m) return fail(SS_ERR_NOMEM, "out of host memory");
     std::vector<ss::real> bodyc, candc, geomc;
+    std::vector<int32_t> pairs;                              // per shape: the ids are the same, the bounding-sphere reaches are not
     for (int s = 0; s < num_shapes; s++) {
       ss::HostModel hm;
       if (!ss::build_host_model(d[s], hm)) { std::string e = "shape " + std::to_string(s) + ": " + hm.error; delete m; return fail(SS_ERR_INVALID, e); }
@@ -106,7 +113,7 @@ struct ss_api {
         // everything but the geometry must agree: tree, joints, limits, gains, actuators, geom types, contact set, options
         const bool same = h.nb == g.nb && h.nv == g.nv && h.nu == g.nu && h.ncand == g.ncand && h.nbox == g.nbox && h.nslot == g.nslot &&
                           h.shared_words == g.shared_words && h.env_floats == g.env_floats && hm.shared == m->hm.shared &&
-                          hm.candb == m->hm.candb && hm.pairs == m->hm.pairs && hm.illegal_mask == m->hm.illegal_mask && h.dt == g.dt && h.grav == g.grav &&
+                          hm.candb == m->hm.candb && same_pair_ids(hm.pairs, m->hm.pairs) && hm.illegal_mask == m->hm.illegal_mask && h.dt == g.dt && h.grav == g.grav &&
                           h.margin == g.margin && h.mu == g.mu && h.K == g.K && h.B == g.B;
         if (!same) { delete m; return fail(SS_ERR_INVALID, "shape " + std::to_string(s) + " differs from shape 0 in more than its geometry"); }
       }
@@ -115,6 +122,7 @@ struct ss_api {
       bodyc.insert(bodyc.end(), iw.begin(), iw.end());        // block = body constants, then the dof inverse weights
       candc.insert(candc.end(), hm.candc.begin(), hm.candc.end());
       geomc.insert(geomc.end(), hm.geomc.begin(), hm.geomc.end());   // pair functions (self_collision batches): geoms of this shape
+      pairs.insert(pairs.end(), hm.pairs.begin(), hm.pairs.end());
     }
     if (12 * m->hm.h.nb > m->hm.h.l_Wst - m->hm.h.l_IA) { delete m; return fail(SS_ERR_LDS, "no room for the per-env body offsets"); }
     m->device = device; m->num_shapes = num_shapes;
@@ -128,7 +136,7 @@ struct ss_api {
     m->d_bodyc = (ss::real *)up(bodyc.data(), bodyc.size() * sizeof(ss::real));
     m->d_candc = (ss::real *)up(candc.data(), candc.size() * sizeof(ss::real));
     m->d_candb = (int32_t *)up(m->hm.candb.data(), m->hm.candb.size() * 4);
-    m->d_pairs = (int32_t *)up(m->hm.pairs.data(), m->hm.pairs.size() * 4);
+    m->d_pairs = (int32_t *)up(pairs.data(), pairs.size() * 4);
     m->d_geomc = (ss::real *)up(geomc.data(), geomc.size() * sizeof(ss::real));
     if (!m->d_shared || !m->d_bodyc || !m->d_candc || !m->d_candb || !m->d_pairs || !m->d_geomc) { model_destroy(m); return fail(SS_ERR_HIP, "device table upload failed"); }
     *out = m;

@@ -202,7 +202,7 @@ struct KArgs {
   real *out0, *out1, *out2;  // kinematics: xpos, xmat ; debug forward: M [N,nv,nv], bias [N,nv], qacc [N,nv]
   // body-body contacts (SELFCOL instantiations only; appended so that the plain kernels' argument layout is what it was)
   HdrSC sc;
-  const int32_t *pairs;       // [sc.npair] b1 | b2 << 8
+  const int32_t *pairs;       // [sc.npair][2] b1 | b2 << 8, float bits of the pair's bounding-sphere reach (per shape like geomc)
   const real *geomc;          // [nb][kGeomC]
   real *dbg_self;             // optional [N][kMaxSelf][kSelfRec]: the contact records of the last forward (ss_debug_self_contacts)
   // per-env body shapes (ss_model_create_shapes): bodyc holds num_shapes consecutive blocks of [nb][kBodyC] body constants

@@ -104,7 +104,7 @@ SS_DEV bool is_bad(real x) { return !(x <= real(1e10) && x >= -real(1e10)); }
 // through the env's LDS slice) instead of the workgroup's shared table.  A separate instantiation: the single-shape code
 // is textually what it was.
 template <bool SHAPED> struct ShapeTables {};
-template <> struct ShapeTables<true> { const real *bodyc_s, *candc_s, *dinvw_s, *geomc_s; };   // this env's tables
+template <> struct ShapeTables<true> { const real *bodyc_s, *candc_s, *dinvw_s, *geomc_s; const int32_t *pairs_s; };   // this env's tables
 
 // SELFCOL: contacts between the humanoid's own bodies (ss_env_cfg.self_collision).  Their rows couple two bodies, which the
 // per-body generalized inertias of the articulated-body solve cannot express; the Newton system H = H_tree + E^T W E (E: relative
@@ -158,6 +158,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
   SS_DEV const real *candc() const { if constexpr (SHAPED) return this->candc_s; else return k->candc; }
   SS_DEV real dof_invweight(int dof) const { if constexpr (SHAPED) return this->dinvw_s[dof]; else return dc(dof, 4); }
   SS_DEV const real *geomc() const { if constexpr (SHAPED) return this->geomc_s; else return k->geomc; }   // geoms in their body frames (pair functions)
+  SS_DEV const int32_t *pairs() const { if constexpr (SHAPED) return this->pairs_s; else return k->pairs; }
   // body of a contact slot: box b owns slots 4b'..4b'+3 (b' = box order), capsule ends follow
   SS_DEV int h_box_body(int sl) const { return k->candb[8 * (sl >> 2)] & 255; }
   SS_DEV int h_caps_body(int sl) const { int e = sl - 4 * k->h.nbox; int ci = 8 * k->h.nbox + e; return ci < k->h.ncand ? (k->candb[ci] & 255) : 0; }
@@ -170,6 +171,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       this->bodyc_s = k->bodyc + sid * shape_stride(h); this->candc_s = k->candc + sid * h.ncand * kCandC;
       this->dinvw_s = this->bodyc_s + h.nb * kBodyC;
       this->geomc_s = k->geomc ? k->geomc + sid * h.nb * kGeomC : nullptr;
+      this->pairs_s = k->pairs ? k->pairs + sid * 2 * k->sc.npair : nullptr;
     }
     S = L + h.l_S; R = L + h.l_R; r = L + h.l_r; V = L + h.l_V; Ab = L + h.l_Ab; An = L + h.l_An; Ad = An;
     Gb = L + h.l_Gb; tmpb = L + h.l_tmp; Aown = L + h.l_Aown; IA = L + h.l_IA; Ubuf = L + h.l_Ubuf; Wst = L + h.l_Wst;
@@ -703,18 +705,24 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       w->sync();
       int ncand = 0, nlist = 0;
       const int npass = (npair + 63) >> 6;
+      // the pair table entry of the NEXT round is requested before this round's test: one global round trip per round would
+      // otherwise sit in front of every ballot (the bodies' reaches are folded into the table: no second, dependent load)
+      const int32_t *ptab = pairs();
+      int pr_n = 0, rs_n = 0;
+      if (lane < npair) { pr_n = ptab[2 * lane]; rs_n = ptab[2 * lane + 1]; }
       for (int p = 0; p <= npass; p++) {
         // ---- broad phase of 64 pairs: bounding spheres about the geom centres
         int pass_ = 0, q = p * 64 + lane;
+        const int pr = pr_n, rs_bits = rs_n;
+        if (p + 1 < npass && q + 64 < npair) { pr_n = ptab[2 * (q + 64)]; rs_n = ptab[2 * (q + 64) + 1]; }
         if (p < npass && q < npair) {
-          const int pr = k->pairs[q], b1 = pr & 255, b2 = pr >> 8;
-          const real *g1 = geomc() + b1 * kGeomC, *g2 = geomc() + b2 * kGeomC;
-          const real r1 = g1[15] == real(SS_GEOM_BOX) ? SS_M(sqrt)(g1[3] * g1[3] + g1[4] * g1[4] + g1[5] * g1[5]) : g1[3] + g1[4];
-          const real r2 = g2[15] == real(SS_GEOM_BOX) ? SS_M(sqrt)(g2[3] * g2[3] + g2[4] * g2[4] + g2[5] * g2[5]) : g2[3] + g2[4];
+          const int b1 = pr & 255, b2 = pr >> 8;
+          float rs; __builtin_memcpy(&rs, &rs_bits, 4);
           const real dx = this->gc[3 * b2] - this->gc[3 * b1], dy = this->gc[3 * b2 + 1] - this->gc[3 * b1 + 1], dz = this->gc[3 * b2 + 2] - this->gc[3 * b1 + 2];
-          pass_ = !(SS_M(sqrt)(dx * dx + dy * dy + dz * dz) > r1 + r2 + h.margin);
+          pass_ = !(dx * dx + dy * dy + dz * dz > (real)rs * (real)rs);
         }
         const unsigned long long bal = w->ballot(pass_);
+        SS_FTICK(PF_ASM);
         int cnt = 0;
         for (unsigned long long t_ = bal; t_; t_ &= t_ - 1) cnt++;
         const bool flush = p == npass || nlist + cnt > 64;
@@ -725,7 +733,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
           int n = 0, pid = 0, b1 = 0, b2 = 0;
           if (lane < nlist) {
             pid = (int)plist[lane];
-            const int pr = k->pairs[pid];
+            const int pr = ptab[2 * pid];
             b1 = pr & 255; b2 = pr >> 8;
             const real *g1 = geomc() + b1 * kGeomC, *g2 = geomc() + b2 * kGeomC;
             real p1[3], m1[9], p2[3], m2[9];
@@ -736,6 +744,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
             else if (c1) n = sc::capsule_box(p1, a1, g1[3], g1[4], p2, m2, g2 + 3, h.margin, out);
             else n = sc::box_box(p1, m1, g1 + 3, p2, m2, g2 + 3, h.margin, out);
           }
+          SS_FTICK(PF_SOLVE);
           for (int kq = 0; kq < 8; kq++) {
             const int has = n > kq;
             const unsigned long long m_ = w->ballot(has);

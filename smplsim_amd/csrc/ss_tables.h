@@ -30,7 +30,8 @@ struct HostModel {
   std::vector<uint8_t> legal;     // [nb]
   uint64_t illegal_mask = 0;      // bodies whose floor contact terminates the episode
   int o_real = 0;                 // word offset of the real-valued part of `shared`
-  std::vector<int32_t> pairs;     // body-body candidate pairs after MuJoCo's static filters: b1 | b2 << 8 (normal points b1 -> b2)
+  std::vector<int32_t> pairs;     // body-body candidate pairs after MuJoCo's static filters, 2 words each: b1 | b2 << 8 (normal points
+                                  // b1 -> b2), and the float bits of the pair's bounding-sphere reach r1 + r2 + margin (broad phase)
   std::vector<real> geomc;        // [nb][kGeomC] geoms in their body frames (pair functions of the SELFCOL kernels)
   HdrSC sc{};
   std::string error;
@@ -286,6 +287,15 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
     if (ex) continue;
     const int first = (d.geom_type[i] == SS_GEOM_BOX && d.geom_type[j] == SS_GEOM_CAPSULE) ? j : i;
     out.pairs.push_back(first | ((first == i ? j : i) << 8));
+    // bounding spheres about the geom centres: half diagonal of a box, radius + half length of a capsule; a hair of slack so that
+    // the float rounding of the sum can never prune a pair the pair function would report (those are strictly inside)
+    auto reach = [&](int b) {
+      const double *z = d.geom_size + 3 * b;
+      return d.geom_type[b] == SS_GEOM_BOX ? std::sqrt(z[0] * z[0] + z[1] * z[1] + z[2] * z[2]) : z[0] + z[1];
+    };
+    const float rs = (float)((reach(i) + reach(j) + d.margin) * (1.0 + 1e-5));
+    int32_t bits; std::memcpy(&bits, &rs, 4);
+    out.pairs.push_back(bits);
   }
   out.geomc.assign((size_t)nb * kGeomC, real(0));
   for (int b = 0; b < nb; b++) {
@@ -298,7 +308,7 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   out.sc = make_layout_sc(nb, h.env_floats, h.l_Aown);
   // up to Wst (kept for the re-solves) everything behind Aown is solver scratch
   if (24 * (nb + 1) > h.l_Wst - h.l_Aown || 2 * 72 * h.maxlev > h.l_Wst - h.l_Aown) { out.error = "no room for the re-solve buffers over Aown / IA"; return false; }
-  out.sc.npair = (int)out.pairs.size();
+  out.sc.npair = (int)out.pairs.size() / 2;
 
   h.dt = (real)d.timestep; h.grav = (real)d.gravity; h.margin = (real)d.margin; h.mu = (real)d.friction;
   for (int k = 0; k < 5; k++) h.solimp[k] = (real)d.solimp[k];

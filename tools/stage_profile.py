@@ -31,7 +31,7 @@ for _ in range(steps):
 torch.cuda.synchronize()
 out = (C.c_ulonglong * 64)()
 rc = _lib.lib().ss_debug_prof(env.handle, out, 40)
-names = ["fwd_kin", "constraints", "newton_begin", "newton_prepare", "(unused)", "aba_solve", "(unused)", "newton_finish",
+names = ["fwd_kin", "constraints", "newton_begin", "newton_prepare", "sc:broad phase", "aba_solve", "sc:pair function calls", "newton_finish",
          "spd_prepare", "spd_finish", "integrate", "misc", "aba:up_phase1", "aba:up_last_sync", "aba:up_phase2", "aba:down", "(unused)",
          "fk:prologue", "fk:level_sweep", "fk:inertia_bias", "fk:subtree_C", "prep:base", "prep:contactK", "prep:subtree", "prep:grad",
          "selfcol:pair functions", "selfcol:factor+base solve", "selfcol:Delassus columns", "selfcol:dense solve", "selfcol:final re-solve"]
