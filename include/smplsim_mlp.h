@@ -1,0 +1,38 @@
+/* smplsim_mlp.h — C ABI of the policy-inference kernels of libsmplsim_hip.so (the sampler's caller side).
+ *
+ * The reference's sampler evaluates its Gaussian policy once per env step on the CPU worker that owns the env
+ * (PolicyGaussian.select_action -> MLP.forward, smpl_sim/learning/policy_gaussian.py:14-41, mlp.py:36-60, with the
+ * observation normalised by RunningNorm, running_norm.py:5-42).  With thousands of envs per GPU that forward pass is
+ * GEMM-shaped (4096 x 289 -> 2048 -> 1536 -> 1024 -> 1024 -> 512 -> 512 -> 69: 59 GFLOP per env step) and sits in the
+ * sampling loop next to ss_step, so it runs on the matrix cores: bf16 operands, fp32 accumulation
+ * (v_mfma_f32_32x32x16_bf16), bias + activation fused into the GEMM's epilogue, activations kept in bf16 between layers.
+ * The PPO update (backward pass) stays with the caller's autograd framework.
+ *
+ * Conventions as in smplsim_hip.h: device pointers, int status + ss_last_error(), work enqueued on the caller's stream.
+ */
+#ifndef SMPLSIM_MLP_H
+#define SMPLSIM_MLP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { SS_ACT_NONE = 0, SS_ACT_SILU = 1, SS_ACT_TANH = 2, SS_ACT_RELU = 3 };   /* mlp.py:13-21 (the ones the reference's cfgs use) */
+
+/* y = act(x W^T + b): x [M, K] bf16 row-major (K a multiple of 32, zero padded), W [N, K] bf16 row-major (torch.nn.Linear's
+ * layout), b [N] f32 or NULL, y [M, ldy] bf16 (y_is_f32 = 0) or f32; columns >= N of y are not written. */
+int ss_linear_bf16(const void *x, const void *w, const float *bias, void *y, int32_t M, int32_t N, int32_t K, int32_t ldy,
+                   int32_t activation, int32_t y_is_f32, void *stream);
+
+/* Observation -> first layer input: y = clamp(obs, clip_lo, clip_hi) (AgentPPO's clip_obs), then, when *norm_n > 0,
+ * clamp((y - mean) / (std + 1e-8), -norm_clip, norm_clip) (RunningNorm.forward in eval mode), rounded to bf16 into
+ * out [M, kpad] with the columns >= dim zeroed.  norm_* may be NULL (no normalisation). */
+int ss_obs_to_bf16(const float *obs, int32_t M, int32_t dim, int32_t obs_stride, const float *norm_mean, const float *norm_std,
+                   const int64_t *norm_n, float clip_lo, float clip_hi, float norm_clip, void *out, int32_t kpad, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

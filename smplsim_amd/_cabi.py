@@ -131,6 +131,17 @@ def bind(lib):
     return lib
 
 
+ACTIVATIONS = {"none": 0, "silu": 1, "tanh": 2, "relu": 3}
+MLP_EXPORTS = ["ss_linear_bf16", "ss_obs_to_bf16"]            # include/smplsim_mlp.h (product library only: the matrix-core kernels)
+
+
+def bind_mlp(lib):
+    vp = C.c_void_p
+    lib.ss_linear_bf16.argtypes = [vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]
+    lib.ss_obs_to_bf16.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, C.c_float, C.c_float, C.c_float, vp, C.c_int32, vp]
+    return lib
+
+
 EXPORTS = ["ss_model_create", "ss_model_create_shapes", "ss_model_destroy", "ss_model_dims", "ss_obs_size", "ss_batch_create",
            "ss_batch_destroy", "ss_reset", "ss_step", "ss_step_autoreset", "ss_substep", "ss_kinematics", "ss_debug_forward", "ss_debug_self_contacts",
            "ss_gae", "ss_debug_prof", "ss_set_order", "ss_set_body_outputs", "ss_set_launch_geometry", "ss_schedule_longest_first", "ss_launch_info", "ss_last_error",

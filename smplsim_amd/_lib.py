@@ -33,9 +33,9 @@ class ExtensionMissing(RuntimeError):
 
 def build(verbose=False, force=False):
     """hipcc --offload-arch=gfx950 build of the kernels + C ABI (cross-compiles without a GPU)."""
-    srcs = [os.path.join(SRC_DIR, f) for f in ("smplsim_hip.hip", "smplsim_motion.hip", "ss_kernel.h", "ss_selfcol.h", "ss_api.h", "ss_tables.h", "ss_hdr.h",
+    srcs = [os.path.join(SRC_DIR, f) for f in ("smplsim_hip.hip", "smplsim_motion.hip", "smplsim_mlp.hip", "ss_kernel.h", "ss_selfcol.h", "ss_api.h", "ss_tables.h", "ss_hdr.h",
                                                   "ss_motion.h", "ss_motion_api.h", "ss_wave_gpu.h", "ss_imfused.h", "ss_mjcf.h")]
-    srcs += [os.path.join(os.path.dirname(_PKG), "include", h) for h in ("smplsim_hip.h", "smplsim_motion.h")]
+    srcs += [os.path.join(os.path.dirname(_PKG), "include", h) for h in ("smplsim_hip.h", "smplsim_motion.h", "smplsim_mlp.h")]
     opt = os.environ.get("SS_HIPCC_OPT", DEFAULT_OPT).split()
     mopt = os.environ.get("SS_HIPCC_MOTION_OPT", MOTION_OPT).split()
     stamp = LIB_PATH + ".flags"                              # rebuild when the flags change, not only the sources
@@ -44,7 +44,7 @@ def build(verbose=False, force=False):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
-    for src, flags in ((srcs[0], opt), (srcs[1], mopt)):      # stepper and motion library: one object each, their own flags
+    for src, flags in ((srcs[0], opt), (srcs[1], mopt), (srcs[2], mopt)):   # stepper, motion library, policy MLP: one object each, their own flags
         obj = os.path.join(_PKG, os.path.basename(src).replace(".hip", ".o"))
         cmd = [hipcc, "--offload-arch=gfx950", *flags, "-std=c++17", "-fPIC", "-c", src, "-o", obj]
         if verbose:
@@ -72,5 +72,5 @@ def lib():
         # torch first: it brings its own libamdhip64; loaded after ours (which links /opt/rocm's) the process would hold two HIP
         # runtimes and the first hipSetDevice fails ("cannot select device")
         import torch  # noqa: F401
-        _LIB = _cabi.bind(ctypes.CDLL(LIB_PATH))
+        _LIB = _cabi.bind_mlp(_cabi.bind(ctypes.CDLL(LIB_PATH)))
     return _LIB

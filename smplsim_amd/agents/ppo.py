@@ -43,6 +43,7 @@ class PPOConfig:
     min_batch_size: int = 51200
     bootstrap: bool = True
     amp_bf16: bool = False      # run the update's network passes under bf16 autocast (MFMA rate); off = the reference's fp32
+    mfma_inference: bool = False   # sampler: policy forward by the library's fused bf16 MFMA kernels (learning/fast_policy.py)
     extra: dict = field(default_factory=dict)
 
 
@@ -62,6 +63,10 @@ class AgentPPO:
         self.epoch, self.num_steps = 0, 0
         self.horizon = max(1, -(-c.min_batch_size // env.num_envs))
         self._obs = None
+        self.fast_policy = None
+        if c.mfma_inference:
+            from ..learning.fast_policy import FusedPolicyInference
+            self.fast_policy = FusedPolicyInference(self.policy_net, c.clip_obs_range if c.clip_obs else None)
 
     # ------------------------------------------------------------------ sampling
     def _prep_obs(self, obs):
@@ -86,8 +91,11 @@ class AgentPPO:
         state = self._prep_obs(self._obs)
         for t in range(T):
             states[t] = state
-            with self._autocast():
-                a = self._f32(self.policy_net.select_action(state, mean_action, generator=self.gen))
+            if self.fast_policy is not None:
+                a = self.fast_policy.select_action(state, mean_action, generator=self.gen)
+            else:
+                with self._autocast():
+                    a = self._f32(self.policy_net.select_action(state, mean_action, generator=self.gen))
             actions[t] = a
             obs, rew, died, timed_out, _ = env.step(self._prep_actions(a))
             rewards[t] = rew
@@ -152,6 +160,8 @@ class AgentPPO:
                 torch.nn.utils.clip_grad_norm_(self.policy_net.parameters(), c.policy_grad_clip)
             self.optimizer_policy.step()
             info["surr_loss"] = loss.detach()
+        if self.fast_policy is not None:
+            self.fast_policy.refresh()                          # bf16 snapshots of the updated weights for the sampler
         self.epoch += 1
         info["mean_reward"] = batch["rewards"].mean()
         info["episodes_ended"] = (1.0 - batch["not_done"]).sum()
@@ -171,6 +181,8 @@ class AgentPPO:
 
     def set_full_state_weights(self, state):
         self.policy_net.load_state_dict(state["policy"]); self.value_net.load_state_dict(state["value"])
+        if self.fast_policy is not None:
+            self.fast_policy.refresh()
         self.epoch = state["epoch"]
         self.optimizer_value.load_state_dict(state["optimizer_value"])
         self.optimizer_policy.load_state_dict(state["optimizer_policy"])

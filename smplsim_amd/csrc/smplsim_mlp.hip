@@ -1,0 +1,189 @@
+// smplsim_mlp.hip — gfx950 policy-inference kernels + their C ABI (include/smplsim_mlp.h): y = act(x W^T + b) on the matrix
+// cores (v_mfma_f32_32x32x16_bf16: bf16 operands, fp32 accumulation), bias and activation fused into the epilogue.
+//
+// Tiling for 64-wide wavefronts: a workgroup of 4 waves owns a 128 x BN output tile (BN = 128, or 64 for the narrow layers so that
+// they still cover the chip), each wave a 64 x BN/2 quadrant = 2 x BN/64 MFMA tiles of 32 x 32 held in 32 / 64 accumulator
+// registers.  Both operands are K-contiguous (activations row-major, weights in torch.nn.Linear's [out, in] layout), so a lane's
+// MFMA fragment — 8 consecutive k of one row — is one 16-byte LDS read; K advances 64 per LDS tile (four MFMA K-steps), the next
+// tile's global loads are in flight while the current one is multiplied (register double buffer, two LDS buffers, one barrier per
+// tile).  LDS rows are padded by 8 bf16 (16 B) so that the 32 rows a fragment read touches spread over the banks.
+// The A and B fragments use the same lane -> k assignment (k = k16 + 8 * (lane / 32) + j), which is all the instruction needs for
+// the products to pair up; the C layout is col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <string>
+
+#include "../../include/smplsim_hip.h"
+#include "../../include/smplsim_mlp.h"
+#include "ss_api.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // 16-byte staging register (a native vector: HIP's uint4 class kept loop-carried stages in scratch)
+
+constexpr int BM = 128;
+
+__device__ __forceinline__ float activate(float v, int act) {
+  if (act == SS_ACT_SILU) return v / (1.f + __expf(-v));
+  if (act == SS_ACT_TANH) { const float e = __expf(-2.f * fabsf(v)); const float t = (1.f - e) / (1.f + e); return v < 0.f ? -t : t; }
+  if (act == SS_ACT_RELU) return v > 0.f ? v : 0.f;
+  return v;
+}
+
+template <int BN, int BK, bool F32OUT>
+__global__ void __launch_bounds__(256) ss_linear_kernel(const __bf16 *__restrict__ X, const __bf16 *__restrict__ W, const float *__restrict__ bias,
+                                                        void *__restrict__ Y, int M, int N, int K, int ldy, int act) {
+  constexpr int TN = BN / 64;                                // MFMA tiles per wave along N (the wave's quadrant is 64 x BN/2)
+  constexpr int LDS_STRIDE = BK + 8;                         // K per LDS tile (64, or 32 when K is an odd multiple of 32); rows padded by 16 bytes
+  constexpr int CPR = BK / 8;                                // 16-byte chunks per tile row
+  constexpr int ACH = BM * CPR / 256, BCH = BN * CPR / 256;  // chunks per thread
+  __shared__ __attribute__((aligned(16))) __bf16 As[2][BM * LDS_STRIDE];
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[2][BN * LDS_STRIDE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  f32x16 acc[2][TN];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  // global -> registers -> LDS: 16-byte chunk c of a tile = row c / CPR, k offset (c % CPR) * 8; rows beyond the matrix re-read its
+  // last row.  The row of chunk tid + 256 i is the row of chunk tid plus 256 i / CPR, the k offset is the same.
+  const int crow = tid / CPR, ckc = (tid % CPR) * 8, soff0 = crow * LDS_STRIDE + ckc;
+  constexpr int RSTEP = 256 / CPR;                           // rows between a thread's consecutive chunks
+  // Two register stages: the loads of tile t + 2 are issued while tile t is multiplied and are written to LDS one step later, so a
+  // load has two steps to land (one step — ~16 MFMAs per wave — is shorter than the memory latency; with a single stage every
+  // step waited for its own load: 1.6 us per step).  The K loop is unrolled by two so that the stages are fixed registers.
+  // (the stages are structs of named registers: arrays indexed by unrolled loops were left in scratch by the compiler here)
+  struct Stage { u32x4 a0, a1, a2, a3, b0, b1, b2, b3; };
+  Stage s0, s1;
+  const int nkt = K / BK;
+  const __bf16 *xrow[4], *wrow[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int ra = m0 + crow + RSTEP * (i < ACH ? i : 0), rb = n0 + crow + RSTEP * (i < BCH ? i : 0);
+    xrow[i] = X + (size_t)(ra < M ? ra : M - 1) * K + ckc;
+    wrow[i] = W + (size_t)(rb < N ? rb : N - 1) * K + ckc;
+  }
+#define SS_LD(p) (*reinterpret_cast<const u32x4 *>(p))
+#define SS_LOAD(S, T)                                                                                                          \
+  {                                                                                                                            \
+    const int ko_ = ((T) < nkt ? (T) : nkt - 1) * BK;                                                                          \
+    S.a0 = SS_LD(xrow[0] + ko_); if (ACH > 1) S.a1 = SS_LD(xrow[1] + ko_); if (ACH > 2) { S.a2 = SS_LD(xrow[2] + ko_); S.a3 = SS_LD(xrow[3] + ko_); } \
+    S.b0 = SS_LD(wrow[0] + ko_); if (BCH > 1) S.b1 = SS_LD(wrow[1] + ko_); if (BCH > 2) { S.b2 = SS_LD(wrow[2] + ko_); S.b3 = SS_LD(wrow[3] + ko_); } \
+  }
+#define SS_ST(base, i, v) (*reinterpret_cast<u32x4 *>(&base[soff0 + RSTEP * (i) * LDS_STRIDE]) = (v))
+#define SS_STORE(S, BUF)                                                                                                       \
+  {                                                                                                                            \
+    SS_ST(As[BUF], 0, S.a0); if (ACH > 1) SS_ST(As[BUF], 1, S.a1); if (ACH > 2) { SS_ST(As[BUF], 2, S.a2); SS_ST(As[BUF], 3, S.a3); } \
+    SS_ST(Bs[BUF], 0, S.b0); if (BCH > 1) SS_ST(Bs[BUF], 1, S.b1); if (BCH > 2) { SS_ST(Bs[BUF], 2, S.b2); SS_ST(Bs[BUF], 3, S.b3); } \
+  }
+#define SS_COMPUTE(BUF)                                                                                                        \
+  _Pragma("unroll") for (int k16 = 0; k16 < BK; k16 += 16) {                                                                   \
+    const int ko_ = k16 + 8 * (lane >> 5);                                                                                     \
+    bf16x8 a[2], b[TN];                                                                                                        \
+    _Pragma("unroll") for (int tm = 0; tm < 2; tm++) a[tm] = *reinterpret_cast<const bf16x8 *>(&As[BUF][(wm * 64 + tm * 32 + (lane & 31)) * LDS_STRIDE + ko_]); \
+    _Pragma("unroll") for (int tn = 0; tn < TN; tn++) b[tn] = *reinterpret_cast<const bf16x8 *>(&Bs[BUF][(wn * (BN / 2) + tn * 32 + (lane & 31)) * LDS_STRIDE + ko_]); \
+    _Pragma("unroll") for (int tm = 0; tm < 2; tm++)                                                                           \
+      _Pragma("unroll") for (int tn = 0; tn < TN; tn++) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0); \
+  }
+  SS_LOAD(s0, 0)
+  SS_STORE(s0, 0)
+  SS_LOAD(s1, 1)
+  __syncthreads();
+  for (int kt = 0; kt < nkt; kt += 2) {
+    SS_LOAD(s0, kt + 2)                                       // tile kt + 2 -> stage 0 (in flight for two steps)
+    SS_COMPUTE(0)                                            // tile kt
+    SS_STORE(s1, 1)                                           // tile kt + 1 (requested a step ago) -> the other LDS buffer
+    __syncthreads();
+    SS_LOAD(s1, kt + 3)                                       // (past the end the loads re-read the last tile: unconditional)
+    if (kt + 1 < nkt) { SS_COMPUTE(1) }
+    SS_STORE(s0, 0)
+    __syncthreads();
+  }
+#undef SS_LD
+#undef SS_ST
+#undef SS_LOAD
+#undef SS_STORE
+#undef SS_COMPUTE
+  // epilogue: bias + activation, bf16 (the next layer's operand) or f32 (the head)
+#pragma unroll
+  for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+    for (int tn = 0; tn < TN; tn++) {
+      const int col = n0 + wn * (BN / 2) + tn * 32 + (lane & 31);
+      const float bv = (bias && col < N) ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < M && col < N) {
+          const float v = activate(acc[tm][tn][r] + bv, act);
+          if (F32OUT) reinterpret_cast<float *>(Y)[(size_t)row * ldy + col] = v;
+          else reinterpret_cast<__bf16 *>(Y)[(size_t)row * ldy + col] = (__bf16)v;
+        }
+      }
+    }
+}
+
+__global__ void __launch_bounds__(256) ss_obs_to_bf16_kernel(const float *obs, int M, int dim, int stride, const float *mean, const float *sd,
+                                                             const long long *n, float lo, float hi, float clip, __bf16 *out, int kpad) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)M * kpad) return;
+  const int row = (int)(idx / kpad), c = (int)(idx % kpad);
+  float v = 0.f;
+  if (c < dim) {
+    v = fminf(fmaxf(obs[(size_t)row * stride + c], lo), hi);
+    if (mean && sd && n && *n > 0) v = fminf(fmaxf((v - mean[c]) / (sd[c] + 1e-8f), -clip), clip);
+  }
+  out[idx] = (__bf16)v;
+}
+
+int fail(int code, const char *msg) { ss::last_error() = msg; return code; }
+
+}  // namespace
+
+extern "C" {
+
+int ss_linear_bf16(const void *x, const void *w, const float *bias, void *y, int32_t M, int32_t N, int32_t K, int32_t ldy, int32_t act,
+                   int32_t y_is_f32, void *stream) {
+  if (!x || !w || !y) return fail(SS_ERR_INVALID, "null argument");
+  if (M < 1 || N < 1 || K < 32 || K % 32 || ldy < N) return fail(SS_ERR_INVALID, "ss_linear_bf16: K must be a positive multiple of 32, ldy >= N");
+  if (act < SS_ACT_NONE || act > SS_ACT_RELU) return fail(SS_ERR_INVALID, "unknown activation");
+  const __bf16 *X = static_cast<const __bf16 *>(x), *Wt = static_cast<const __bf16 *>(w);
+  hipStream_t st = (hipStream_t)stream;
+  const int gm = (M + BM - 1) / BM;
+  // wide tiles when they still give every CU a workgroup, narrow ones otherwise
+  const bool wide = (long long)((N + 127) / 128) * gm >= 256 && N >= 128;
+  static const bool force32 = getenv("SS_MLP_BK32") != nullptr;   // A/B switch (tools/gpu_mlp.py)
+  const bool k64 = K % 64 == 0 && !force32;
+#define SS_LAUNCH(BN_, BK_, F32_) hipLaunchKernelGGL((ss_linear_kernel<BN_, BK_, F32_>), grid, dim3(256), 0, st, X, Wt, bias, y, M, N, K, ldy, act)
+  if (wide) {
+    dim3 grid((N + 127) / 128, gm);
+    if (k64) { if (y_is_f32) SS_LAUNCH(128, 64, true); else SS_LAUNCH(128, 64, false); }
+    else { if (y_is_f32) SS_LAUNCH(128, 32, true); else SS_LAUNCH(128, 32, false); }
+  } else {
+    dim3 grid((N + 63) / 64, gm);
+    if (k64) { if (y_is_f32) SS_LAUNCH(64, 64, true); else SS_LAUNCH(64, 64, false); }
+    else { if (y_is_f32) SS_LAUNCH(64, 32, true); else SS_LAUNCH(64, 32, false); }
+  }
+#undef SS_LAUNCH
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SS_OK : fail(SS_ERR_HIP, hipGetErrorString(e));
+}
+
+int ss_obs_to_bf16(const float *obs, int32_t M, int32_t dim, int32_t obs_stride, const float *mean, const float *sd, const int64_t *n,
+                   float lo, float hi, float clip, void *out, int32_t kpad, void *stream) {
+  if (!obs || !out) return fail(SS_ERR_INVALID, "null argument");
+  if (M < 1 || dim < 1 || kpad < dim || kpad % 32 || obs_stride < dim) return fail(SS_ERR_INVALID, "ss_obs_to_bf16: kpad must be a multiple of 32 and >= dim");
+  const long long total = (long long)M * kpad;
+  hipLaunchKernelGGL(ss_obs_to_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, obs, M, dim, obs_stride, mean, sd,
+                     reinterpret_cast<const long long *>(n), lo, hi, clip, static_cast<__bf16 *>(out), kpad);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SS_OK : fail(SS_ERR_HIP, hipGetErrorString(e));
+}
+
+}

@@ -24,6 +24,7 @@ class MLP(nn.Module):
         if activation not in _ACTIVATIONS:
             raise ValueError(f"unknown activation {activation!r}")
         self._act = _ACTIVATIONS[activation]
+        self.activation_name = activation
         dims = [int(input_dim), *[int(h) for h in hidden_dims]]
         self.out_dim = dims[-1]
         self.affine_layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))

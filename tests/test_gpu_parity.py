@@ -895,3 +895,61 @@ def test_external_init_refuses_autoreset(vec):
     obs, _ = env.reset()
     ref = vec(4, autoreset=False)
     assert torch.equal(ref.reset()[0], obs)              # the Default pose written by hand == StateInit Default
+
+
+# ---------------------------------------------------------------------------------------------- policy inference on the matrix cores
+@pytest.mark.parametrize("M,N,K,act", [(4096, 2048, 320, "silu"), (1000, 512, 1024, "tanh"), (37, 69, 512, "none"), (256, 1536, 2048, "relu")])
+def test_linear_bf16_mfma_kernel(M, N, K, act):
+    """ss_linear_bf16 against torch on the same bf16-rounded operands with fp32 accumulation: asymmetric operands (a row / column
+    swap or a wrong fragment layout cannot pass), ragged M and N, both tile widths, every epilogue."""
+    import ctypes as C
+    from smplsim_amd import _cabi
+    from smplsim_amd._lib import lib
+    g = torch.Generator().manual_seed(M + N)
+    x = (torch.randn(M, K, generator=g) * 0.5 + torch.linspace(-1, 1, K)[None, :] * 0.3).to(torch.bfloat16).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5 + torch.linspace(-1, 1, N)[:, None] * 0.02).to(torch.bfloat16).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    ref = x.float() @ w.float().T + b
+    ref = {"silu": torch.nn.functional.silu, "tanh": torch.tanh, "relu": torch.relu, "none": lambda t: t}[act](ref)
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    y32 = torch.full((M, N + 3), 7.0, device="cuda")
+    assert lib().ss_linear_bf16(ptr(x), ptr(w), ptr(b), ptr(y32), M, N, K, N + 3, _cabi.ACTIVATIONS[act], 1, st) == 0
+    torch.cuda.synchronize()
+    assert (y32[:, N:] == 7.0).all()                                 # nothing written beyond column N
+    err = (y32[:, :N] - ref).abs().max().item()
+    assert err < 2e-3 * max(1.0, ref.abs().max().item()), err        # fp32 accumulation in another order
+    y16 = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    assert lib().ss_linear_bf16(ptr(x), ptr(w), ptr(b), ptr(y16), M, N, K, N, _cabi.ACTIVATIONS[act], 0, st) == 0
+    torch.cuda.synchronize()
+    assert (y16.float() - ref).abs().max().item() < 1e-2 * max(1.0, ref.abs().max().item())
+    assert lib().ss_linear_bf16(ptr(x), ptr(w), ptr(b), ptr(y16), M, N, K - 1, N, 0, 0, st) == -1     # K must be a multiple of 32
+
+
+def test_fused_policy_inference_matches_the_torch_policy():
+    """FusedPolicyInference (obs clamp + RunningNorm + 7 fused bf16 layers) against PolicyGaussian in fp32: the action means agree
+    to bf16 round-off through the 7 layers, with the normalisation on (n > 0) and off (n = 0), on a strided observation tensor."""
+    from smplsim_amd.learning.fast_policy import FusedPolicyInference
+    from smplsim_amd.learning.networks import PolicyGaussian
+    torch.manual_seed(0)
+    pol = PolicyGaussian(289, 69).cuda().eval()
+    big = torch.randn(1500, 300, device="cuda") * 3.0
+    obs = big[:, 5:294]                                              # row stride 300
+    fast = FusedPolicyInference(pol, (-5.0, 5.0))
+    for trained in (False, True):
+        if trained:
+            pol.train(); pol.norm(obs.clamp(-5, 5)); pol.eval()     # running statistics from one batch
+            with torch.no_grad():
+                for l in pol.net.affine_layers:
+                    l.weight.mul_(1.5)
+            fast.refresh()
+        with torch.no_grad():
+            want = pol.select_action(obs.clamp(-5, 5), mean_action=True)
+        got = fast.select_action(obs, mean_action=True)
+        torch.cuda.synchronize()
+        scale = want.abs().max().item()
+        assert (got - want).abs().max().item() < 0.03 * scale + 1e-3, ((got - want).abs().max().item(), scale)
+    g1 = torch.Generator(device="cuda").manual_seed(5); g2 = torch.Generator(device="cuda").manual_seed(5)
+    a = fast.select_action(obs, generator=g1)
+    n = torch.randn(a.shape, device="cuda", generator=g2)
+    assert torch.allclose(a, fast.mean(obs) + pol.action_log_std.exp() * n, atol=1e-6)

@@ -19,9 +19,9 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     lib = ctypes.CDLL(path)
     header = "".join(open(os.path.join(ROOT, "include", h)).read() for h in sorted(os.listdir(os.path.join(ROOT, "include"))))
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)        # prose in comments mentions reference functions
-    declared = set(re.findall(r"\b(ss_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(ss_[a-z0-9_]+)\s*\(", header))
     declared -= {"ss_status"}
-    assert declared == set(_cabi.EXPORTS), declared ^ set(_cabi.EXPORTS)
+    assert declared == set(_cabi.EXPORTS) | set(_cabi.MLP_EXPORTS), declared ^ (set(_cabi.EXPORTS) | set(_cabi.MLP_EXPORTS))
     for name in declared:
         assert getattr(lib, name) is not None
     lib.ss_last_error.restype = ctypes.c_char_p
