@@ -221,6 +221,23 @@ int ss_launch_info(const ss_batch *b, int32_t *envs_per_wg, int32_t *lds_bytes, 
  * persistent workgroups of a launch (0 = one per CU), so that K concurrent batches can each own 1/K of the CUs. */
 int ss_set_launch_geometry(ss_batch *b, int32_t envs_per_wg, int32_t max_workgroups);
 
+/* State access by field for hosts that do not keep the ss_state pointers around (teacher forcing, checkpoints; what callers of
+ * the reference read from / write to mjData: data.qpos, data.qvel, data.xpos, data.xmat, the velocity sensors, the floor
+ * contacts).  Device-to-device copies on `stream` between the batch's bound buffers and `buf` (a device pointer, float32 unless
+ * noted); XPOS / XMAT run mj_kinematics on the current qpos (ss_kinematics) into the batch's own scratch first.
+ * ss_set_state accepts QPOS, QVEL, QACC_WARM and CUR_T; QPOS / QVEL also overwrite the "previous" copies the Stable-PD controller
+ * takes its stale M, C from (i.e. the state counts as having been forwarded, like after mj_forward). */
+enum { SS_FIELD_QPOS = 0,      /* [N,nq] */
+       SS_FIELD_QVEL = 1,      /* [N,nv] */
+       SS_FIELD_XPOS = 2,      /* [N,nbody,3] */
+       SS_FIELD_XMAT = 3,      /* [N,nbody,9] */
+       SS_FIELD_BODY_VEL = 4,  /* [N,nbody,6] framelinvel ; frameangvel of the last forward */
+       SS_FIELD_TOUCH = 5,     /* [N,2] int32: bit b = body b touches the floor */
+       SS_FIELD_QACC_WARM = 6, /* [N,nv] */
+       SS_FIELD_CUR_T = 7 };   /* [N] int32 */
+int ss_get_state(ss_batch *b, int32_t field, void *buf, void *stream);
+int ss_set_state(ss_batch *b, int32_t field, const void *buf, void *stream);
+
 /* Message of the calling thread's last failed call; and of the last failed call that took this handle (valid until the next
  * failing call on the handle or its destruction) — for hosts that call from pooled threads and cannot rely on thread identity. */
 const char *ss_last_error(void);

@@ -97,6 +97,8 @@ class MjcfOptions(C.Structure):
 def bind(lib):
     vp = C.c_void_p
     lib.ss_model_create_from_mjcf.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(MjcfOptions), C.c_int, C.POINTER(vp)]
+    lib.ss_get_state.argtypes = [vp, C.c_int32, vp, vp]
+    lib.ss_set_state.argtypes = [vp, C.c_int32, vp, vp]
     lib.ss_imitation_bind.argtypes = [vp, C.POINTER(ImitationIO)]
     lib.ss_imitation_step_fused.argtypes = [vp, vp, vp, vp]
     lib.ss_model_last_error.argtypes = [vp]; lib.ss_model_last_error.restype = C.c_char_p
@@ -131,6 +133,7 @@ def bind(lib):
     return lib
 
 
+FIELDS = {"qpos": 0, "qvel": 1, "xpos": 2, "xmat": 3, "body_vel": 4, "touch": 5, "qacc_warm": 6, "cur_t": 7}   # SS_FIELD_*
 ACTIVATIONS = {"none": 0, "silu": 1, "tanh": 2, "relu": 3}
 MLP_EXPORTS = ["ss_linear_bf16", "ss_obs_to_bf16"]            # include/smplsim_mlp.h (product library only: the matrix-core kernels)
 
@@ -145,7 +148,7 @@ def bind_mlp(lib):
 EXPORTS = ["ss_model_create", "ss_model_create_shapes", "ss_model_destroy", "ss_model_dims", "ss_obs_size", "ss_batch_create",
            "ss_batch_destroy", "ss_reset", "ss_step", "ss_step_autoreset", "ss_substep", "ss_kinematics", "ss_debug_forward", "ss_debug_self_contacts",
            "ss_gae", "ss_debug_prof", "ss_set_order", "ss_set_body_outputs", "ss_set_launch_geometry", "ss_schedule_longest_first", "ss_launch_info", "ss_last_error",
-           "ss_model_create_from_mjcf", "ss_model_last_error", "ss_batch_last_error", "ss_imitation_bind", "ss_imitation_step_fused",
+           "ss_model_create_from_mjcf", "ss_model_last_error", "ss_batch_last_error", "ss_imitation_bind", "ss_imitation_step_fused", "ss_get_state", "ss_set_state",
            "ss_motion_cook", "ss_motion_state_at", "ss_motion_resample", "ss_imitation_step"]
 
 

@@ -157,6 +157,7 @@ struct HipBackend {
   static bool upload(void *dst, const void *src, size_t n) { return hipMemcpy(dst, src, n, hipMemcpyHostToDevice) == hipSuccess; }
   static bool set_device(int d) { return hipSetDevice(d) == hipSuccess; }
   static bool download(void *dst, const void *src, size_t n) { return hipMemcpy(dst, src, n, hipMemcpyDeviceToHost) == hipSuccess; }
+  static bool copy_d2d(void *dst, const void *src, size_t n, void *stream) { return hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess; }
   static int lds_capacity() { return 160 * 1024; }
   static int num_cus() { int d = 0, n = 256; if (hipGetDevice(&d) == hipSuccess) { hipDeviceProp_t p; if (hipGetDeviceProperties(&p, d) == hipSuccess) n = p.multiProcessorCount; } return n; }
   static int max_waves(int variant, int selfcol) { return (variant == 0 ? (selfcol ? SS_MAX_THREADS_SC : SS_MAX_THREADS) : SS_MAX_THREADS_X) / 64; }

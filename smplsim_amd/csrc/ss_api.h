@@ -51,6 +51,7 @@ struct ss_batch {
   int fixed_envs_per_wg = 0, max_wgs = 0; // ss_set_launch_geometry: 0 = automatic (small batches are spread over all CUs)
   mutable std::string err;                // message of the last failed call that took this handle
   mutable int parity = 0;                 // which of the two work counters the next launch uses (it clears the other one)
+  float *d_kin = nullptr;                 // [N, nb, 12] scratch of ss_get_state(XPOS / XMAT)
   void *d_im = nullptr;                   // ss::mo::ImFused on the device (ss_imitation_bind)
   ss_imitation_io im_io{};
 };
@@ -275,6 +276,41 @@ struct ss_api {
     k.im = b->d_im; k.im_rand = rand;                        // reward / flags come from the imitation part
     return run(b, k, stream);
   }
+  // ---- state by field (device-to-device copies between the bound buffers and the caller's)
+  static int state_field(ss_batch *b, int field, void *buf, bool set, void *stream) {
+    if (!b || !buf) return fail(SS_ERR_INVALID, "null argument");
+    if (sizeof(ss::real) != sizeof(float)) return fail(SS_ERR_INVALID, "not available in the float64 build");
+    const ss::Hdr &h = b->m->hm.h;
+    const size_t N = (size_t)b->st.num_envs;
+    if (!BE::set_device(b->m->device)) return fail(SS_ERR_HIP, "cannot select device");
+    auto copy = [&](void *mine, size_t bytes) { return (set ? BE::copy_d2d(mine, buf, bytes, stream) : BE::copy_d2d(buf, mine, bytes, stream)) ? SS_OK : fail(SS_ERR_HIP, "device copy failed"); };
+    switch (field) {
+      case SS_FIELD_QPOS: {
+        if (int rc = copy(b->st.qpos, N * h.nq * 4)) return rc;
+        return set ? (BE::copy_d2d(b->st.qpos_prev, buf, N * h.nq * 4, stream) ? SS_OK : fail(SS_ERR_HIP, "device copy failed")) : SS_OK;
+      }
+      case SS_FIELD_QVEL: {
+        if (int rc = copy(b->st.qvel, N * h.nv * 4)) return rc;
+        return set ? (BE::copy_d2d(b->st.qvel_prev, buf, N * h.nv * 4, stream) ? SS_OK : fail(SS_ERR_HIP, "device copy failed")) : SS_OK;
+      }
+      case SS_FIELD_QACC_WARM: return copy(b->st.qacc_warm, N * h.nv * 4);
+      case SS_FIELD_CUR_T: return copy(b->st.cur_t, N * 4);
+      default: break;
+    }
+    if (set) return fail(SS_ERR_INVALID, "ss_set_state: field is read-only (QPOS, QVEL, QACC_WARM, CUR_T can be set)");
+    switch (field) {
+      case SS_FIELD_BODY_VEL: return copy(b->st.body_vel, N * h.nb * 6 * 4);
+      case SS_FIELD_TOUCH: return copy(b->st.touch, N * 2 * 4);
+      case SS_FIELD_XPOS: case SS_FIELD_XMAT: {
+        if (!b->d_kin) b->d_kin = (float *)BE::alloc(N * h.nb * 12 * 4);
+        if (!b->d_kin) return fail(SS_ERR_NOMEM, "device allocation failed");
+        float *xp = b->d_kin, *xm = b->d_kin + N * h.nb * 3;
+        if (int rc = kinematics(b, xp, xm, stream)) return rc;
+        return field == SS_FIELD_XPOS ? copy(xp, N * h.nb * 3 * 4) : copy(xm, N * h.nb * 9 * 4);
+      }
+      default: return fail(SS_ERR_INVALID, "unknown state field");
+    }
+  }
   static int substep(ss_batch *b, const float *actions, int n, void *stream) {
     if (!b || !actions || n < 1) return fail(SS_ERR_INVALID, "bad argument");
     ss::KArgs k = base_args(b, ss::MODE_SUBSTEP);
@@ -312,7 +348,7 @@ struct ss_api {
   }                                                                                                                  \
   int ss_obs_size(const ss_model *m, const ss_env_cfg *c) { return (m && c) ? ss::obs_size(m->hm.h, *c) : SS_ERR_INVALID; } \
   int ss_batch_create(const ss_model *m, const ss_env_cfg *c, const ss_state *s, ss_batch **o) { ss::HandleScope hs_(m ? &m->err : nullptr); return ss_api<BE>::batch_create(m, c, s, o); } \
-  void ss_batch_destroy(ss_batch *b) { if (b) { BE::free_(b->d_im); BE::free_(b->d_counter); BE::free_(b->d_prof); BE::free_(b->d_sched); delete b; } }          \
+  void ss_batch_destroy(ss_batch *b) { if (b) { BE::free_(b->d_kin); BE::free_(b->d_im); BE::free_(b->d_counter); BE::free_(b->d_prof); BE::free_(b->d_sched); delete b; } }          \
   int ss_set_order(ss_batch *b, const int32_t *order) { ss::HandleScope hs_(b ? &b->err : nullptr);                                                              \
     if (!b) return ss_api<BE>::fail(SS_ERR_INVALID, "null batch");                                                  \
     b->order = order; return SS_OK;                                                                                  \
@@ -354,6 +390,8 @@ struct ss_api {
   int ss_step(ss_batch *b, const float *a, const float *tr, float *obs, float *rew, uint8_t *te, uint8_t *tu, void *st) { ss::HandleScope hs_(b ? &b->err : nullptr); return ss_api<BE>::step(b, a, tr, obs, rew, te, tu, st); } \
   int ss_step_autoreset(ss_batch *b, const float *a, const float *tr, const float *tr2, float *obs, float *obs_next, float *rew, \
                         uint8_t *te, uint8_t *tu, void *st) { ss::HandleScope hs_(b ? &b->err : nullptr); return ss_api<BE>::step_autoreset(b, a, tr, tr2, obs, obs_next, rew, te, tu, st); } \
+  int ss_get_state(ss_batch *b, int32_t field, void *buf, void *st) { ss::HandleScope hs_(b ? &b->err : nullptr); return ss_api<BE>::state_field(b, field, buf, false, st); } \
+  int ss_set_state(ss_batch *b, int32_t field, const void *buf, void *st) { ss::HandleScope hs_(b ? &b->err : nullptr); return ss_api<BE>::state_field(b, field, const_cast<void *>(buf), true, st); } \
   int ss_imitation_bind(ss_batch *b, const ss_imitation_io *io) { ss::HandleScope hs_(b ? &b->err : nullptr); return ss_api<BE>::imitation_bind(b, io); } \
   int ss_imitation_step_fused(ss_batch *b, const float *a, const float *rand, void *st) { ss::HandleScope hs_(b ? &b->err : nullptr); return ss_api<BE>::imitation_step_fused(b, a, rand, st); } \
   int ss_substep(ss_batch *b, const float *a, int n, void *st) { ss::HandleScope hs_(b ? &b->err : nullptr); return ss_api<BE>::substep(b, a, n, st); }          \

@@ -87,3 +87,38 @@ def test_per_handle_error_strings():
     out = C.c_void_p()
     assert L.ss_batch_create(a.model, C.byref(cfg), C.byref(st), C.byref(out)) == -1
     assert L.ss_model_last_error(a.model) != b"" and L.ss_model_last_error(b.model) == b""
+
+
+def test_state_access_by_field():
+    """ss_get_state / ss_set_state: the bound buffers through the C entry (a host that does not keep the ss_state pointers)."""
+    xml = default_xml_str("smpl_humanoid")
+    mc = compile_mjcf(xml)
+    a = EmuBatch(mc, _tables(mc), 3, legal_bodies=FEET)
+    L = a.L
+    a.reset()
+    rs = np.random.default_rng(0)
+    a.step(rs.uniform(-0.3, 0.3, (3, 69)))
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    q = np.zeros((3, mc.nq), np.float32); v = np.zeros((3, mc.nv), np.float32); t = np.zeros(3, np.int32)
+    assert L.ss_get_state(a.batch, _cabi.FIELDS["qpos"], p(q), None) == 0 and np.array_equal(q, a.qpos)
+    assert L.ss_get_state(a.batch, _cabi.FIELDS["qvel"], p(v), None) == 0 and np.array_equal(v, a.qvel)
+    assert L.ss_get_state(a.batch, _cabi.FIELDS["cur_t"], p(t), None) == 0 and t.tolist() == [1, 1, 1]
+    xp = np.zeros((3, mc.nbody, 3), np.float32); xm = np.zeros((3, mc.nbody, 9), np.float32)
+    assert L.ss_get_state(a.batch, _cabi.FIELDS["xpos"], p(xp), None) == 0 and L.ss_get_state(a.batch, _cabi.FIELDS["xmat"], p(xm), None) == 0
+    kx, km = a.kinematics()
+    assert np.array_equal(xp, kx) and np.array_equal(xm, km)
+    bv = np.zeros((3, mc.nbody, 6), np.float32)
+    assert L.ss_get_state(a.batch, _cabi.FIELDS["body_vel"], p(bv), None) == 0 and np.array_equal(bv, a.body_vel)
+    # set: another batch restored from these fields continues identically
+    b = EmuBatch(mc, _tables(mc), 3, legal_bodies=FEET)
+    b.reset()
+    w = np.zeros((3, mc.nv), np.float32)
+    assert L.ss_get_state(a.batch, _cabi.FIELDS["qacc_warm"], p(w), None) == 0
+    a.qpos_prev[:] = a.qpos; a.qvel_prev[:] = a.qvel                  # what a restore does: the state counts as forwarded
+    for f, arr in (("qpos", q), ("qvel", v), ("qacc_warm", w), ("cur_t", t)):
+        assert L.ss_set_state(b.batch, _cabi.FIELDS[f], p(arr), None) == 0
+    act = rs.uniform(-0.3, 0.3, (3, 69))
+    oa, ob = a.step(act)[0], b.step(act)[0]
+    assert np.array_equal(oa, ob) and np.array_equal(a.qpos, b.qpos)
+    assert L.ss_set_state(b.batch, _cabi.FIELDS["xpos"], p(xp), None) == -1 and b"read-only" in L.ss_batch_last_error(b.batch)
+    assert L.ss_get_state(b.batch, 99, p(xp), None) == -1

@@ -226,6 +226,7 @@ struct EmuBackend {
   static bool upload(void *dst, const void *src, size_t n) { memcpy(dst, src, n); return true; }
   static bool set_device(int) { return true; }
   static bool download(void *dst, const void *src, size_t n) { memcpy(dst, src, n); return true; }
+  static bool copy_d2d(void *dst, const void *src, size_t n, void *) { memmove(dst, src, n); return true; }
   static int lds_capacity() { return 160 * 1024; }
   static int kernel_regs() { return 0; }
   static int max_waves(int, int) { return 16; }
