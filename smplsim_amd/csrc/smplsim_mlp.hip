@@ -35,7 +35,7 @@ __device__ __forceinline__ float activate(float v, int act) {
 
 template <int BN, int BK, bool F32OUT>
 __global__ void __launch_bounds__(256) ss_linear_kernel(const __bf16 *__restrict__ X, const __bf16 *__restrict__ W, const float *__restrict__ bias,
-                                                        void *__restrict__ Y, int M, int N, int K, int ldy, int act) {
+                                                        void *__restrict__ Y, int M, int N, int K, int ldy, int act, int xcd_remap) {
   constexpr int TN = BN / 64;                                // MFMA tiles per wave along N (the wave's quadrant is 64 x BN/2)
   constexpr int LDS_STRIDE = BK + 8;                         // K per LDS tile (64, or 32 when K is an odd multiple of 32); rows padded by 16 bytes
   constexpr int CPR = BK / 8;                                // 16-byte chunks per tile row
@@ -43,7 +43,20 @@ __global__ void __launch_bounds__(256) ss_linear_kernel(const __bf16 *__restrict
   __shared__ __attribute__((aligned(16))) __bf16 As[2][BM * LDS_STRIDE];
   __shared__ __attribute__((aligned(16))) __bf16 Bs[2][BN * LDS_STRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (id % 8), each with its own 4 MB L2.  Give XCD x the
+  // row-blocks [x gy/8, (x+1) gy/8) and walk them column-block-major inside the XCD: its activations (gy/8 x 128 rows) stay in
+  // its L2 across all column-blocks and the weights stream through once per XCD — instead of every XCD touching every row-block
+  // (the kernel is bound by L2 / fabric traffic: 64 FLOP per byte at 128 x 128 tiles).
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int gx = gridDim.x, gy = gridDim.y;
+    if (xcd_remap && gy % 8 == 0) {
+      const int id = by * gx + bx, xcd = id & 7, idx = id >> 3, rows_per = gy >> 3;
+      by = xcd * rows_per + idx % rows_per;
+      bx = idx / rows_per;
+    }
+  }
+  const int m0 = by * BM, n0 = bx * BN;
   f32x16 acc[2][TN];
 #pragma unroll
   for (int i = 0; i < 2; i++)
@@ -158,9 +171,10 @@ int ss_linear_bf16(const void *x, const void *w, const float *bias, void *y, int
   const int gm = (M + BM - 1) / BM;
   // wide tiles when they still give every CU a workgroup, narrow ones otherwise
   const bool wide = (long long)((N + 127) / 128) * gm >= 256 && N >= 128;
-  static const bool force32 = getenv("SS_MLP_BK32") != nullptr;   // A/B switch (tools/gpu_mlp.py)
+  static const bool force32 = getenv("SS_MLP_BK32") != nullptr;   // A/B switches (tools/gpu_mlp.py)
+  static const int remap = getenv("SS_MLP_NOREMAP") ? 0 : 1;
   const bool k64 = K % 64 == 0 && !force32;
-#define SS_LAUNCH(BN_, BK_, F32_) hipLaunchKernelGGL((ss_linear_kernel<BN_, BK_, F32_>), grid, dim3(256), 0, st, X, Wt, bias, y, M, N, K, ldy, act)
+#define SS_LAUNCH(BN_, BK_, F32_) hipLaunchKernelGGL((ss_linear_kernel<BN_, BK_, F32_>), grid, dim3(256), 0, st, X, Wt, bias, y, M, N, K, ldy, act, remap)
   if (wide) {
     dim3 grid((N + 127) / 128, gm);
     if (k64) { if (y_is_f32) SS_LAUNCH(128, 64, true); else SS_LAUNCH(128, 64, false); }
