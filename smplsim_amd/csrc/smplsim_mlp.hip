@@ -1,9 +1,10 @@
 // smplsim_mlp.hip — gfx950 policy-inference kernels + their C ABI (include/smplsim_mlp.h): y = act(x W^T + b) on the matrix
 // cores (v_mfma_f32_32x32x16_bf16: bf16 operands, fp32 accumulation), bias and activation fused into the epilogue.
 //
-// Tiling for 64-wide wavefronts: a workgroup of 4 waves owns a 128 x BN output tile (BN = 128, or 64 for the narrow layers so that
-// they still cover the chip), each wave a 64 x BN/2 quadrant = 2 x BN/64 MFMA tiles of 32 x 32 held in 32 / 64 accumulator
-// registers.  Both operands are K-contiguous (activations row-major, weights in torch.nn.Linear's [out, in] layout), so a lane's
+// Tiling for 64-wide wavefronts: a workgroup of 8 waves (4 x 2) owns a 128 x BN output tile (BN = 128, or 64 for the narrow layers
+// so that they still cover the chip), each wave 32 x BN/2 of it = 1 x BN/64 MFMA tiles of 32 x 32 in 16 / 32 accumulator
+// registers (8 waves instead of 4 with twice the tile each: -16 % on the whole MLP — at 4096 rows there are only ~1.5 workgroups
+// per CU, and the K loop's barrier and load latency need waves to hide behind; a 16-wave split measured the same as 8).  Both operands are K-contiguous (activations row-major, weights in torch.nn.Linear's [out, in] layout), so a lane's
 // MFMA fragment — 8 consecutive k of one row — is one 16-byte LDS read; K advances 64 per LDS tile (four MFMA K-steps), the next
 // tile's global loads are in flight while the current one is multiplied (register double buffer, two LDS buffers, one barrier per
 // tile).  LDS rows are padded by 8 bf16 (16 B) so that the 32 rows a fragment read touches spread over the banks.
@@ -33,16 +34,19 @@ __device__ __forceinline__ float activate(float v, int act) {
   return v;
 }
 
-template <int BN, int BK, bool F32OUT>
-__global__ void __launch_bounds__(256) ss_linear_kernel(const __bf16 *__restrict__ X, const __bf16 *__restrict__ W, const float *__restrict__ bias,
+template <int BN, int BK, bool F32OUT, int WM, int WN = 2>
+__global__ void __launch_bounds__(64 * WM * WN) ss_linear_kernel(const __bf16 *__restrict__ X, const __bf16 *__restrict__ W, const float *__restrict__ bias,
                                                         void *__restrict__ Y, int M, int N, int K, int ldy, int act, int xcd_remap) {
-  constexpr int TN = BN / 64;                                // MFMA tiles per wave along N (the wave's quadrant is 64 x BN/2)
+  constexpr int TN = BN / (32 * WN);                         // MFMA tiles per wave along N (WM x WN waves, each (128 / WM) x (BN / WN))
   constexpr int LDS_STRIDE = BK + 8;                         // K per LDS tile (64, or 32 when K is an odd multiple of 32); rows padded by 16 bytes
+  constexpr int NT = 64 * WM * WN;
+  constexpr int TM = BM / (32 * WM);                         // MFMA tiles per wave along M (2 for 4 waves, 1 for 8)
   constexpr int CPR = BK / 8;                                // 16-byte chunks per tile row
-  constexpr int ACH = BM * CPR / 256, BCH = BN * CPR / 256;  // chunks per thread
+  constexpr int ACH = BM * CPR / NT, BCH = BN * CPR / NT;    // chunks per thread
+
   __shared__ __attribute__((aligned(16))) __bf16 As[2][BM * LDS_STRIDE];
   __shared__ __attribute__((aligned(16))) __bf16 Bs[2][BN * LDS_STRIDE];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / WN, wn = wave % WN;
   // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (id % 8), each with its own 4 MB L2.  Give XCD x the
   // row-blocks [x gy/8, (x+1) gy/8) and walk them column-block-major inside the XCD: its activations (gy/8 x 128 rows) stay in
   // its L2 across all column-blocks and the weights stream through once per XCD — instead of every XCD touching every row-block
@@ -57,9 +61,9 @@ __global__ void __launch_bounds__(256) ss_linear_kernel(const __bf16 *__restrict
     }
   }
   const int m0 = by * BM, n0 = bx * BN;
-  f32x16 acc[2][TN];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < TM; i++)
 #pragma unroll
     for (int j = 0; j < TN; j++)
 #pragma unroll
@@ -67,7 +71,7 @@ __global__ void __launch_bounds__(256) ss_linear_kernel(const __bf16 *__restrict
   // global -> registers -> LDS: 16-byte chunk c of a tile = row c / CPR, k offset (c % CPR) * 8; rows beyond the matrix re-read its
   // last row.  The row of chunk tid + 256 i is the row of chunk tid plus 256 i / CPR, the k offset is the same.
   const int crow = tid / CPR, ckc = (tid % CPR) * 8, soff0 = crow * LDS_STRIDE + ckc;
-  constexpr int RSTEP = 256 / CPR;                           // rows between a thread's consecutive chunks
+  constexpr int RSTEP = NT / CPR;                           // rows between a thread's consecutive chunks
   // Two register stages: the loads of tile t + 2 are issued while tile t is multiplied and are written to LDS one step later, so a
   // load has two steps to land (one step — ~16 MFMAs per wave — is shorter than the memory latency; with a single stage every
   // step waited for its own load: 1.6 us per step).  The K loop is unrolled by two so that the stages are fixed registers.
@@ -98,10 +102,10 @@ __global__ void __launch_bounds__(256) ss_linear_kernel(const __bf16 *__restrict
 #define SS_COMPUTE(BUF)                                                                                                        \
   _Pragma("unroll") for (int k16 = 0; k16 < BK; k16 += 16) {                                                                   \
     const int ko_ = k16 + 8 * (lane >> 5);                                                                                     \
-    bf16x8 a[2], b[TN];                                                                                                        \
-    _Pragma("unroll") for (int tm = 0; tm < 2; tm++) a[tm] = *reinterpret_cast<const bf16x8 *>(&As[BUF][(wm * 64 + tm * 32 + (lane & 31)) * LDS_STRIDE + ko_]); \
-    _Pragma("unroll") for (int tn = 0; tn < TN; tn++) b[tn] = *reinterpret_cast<const bf16x8 *>(&Bs[BUF][(wn * (BN / 2) + tn * 32 + (lane & 31)) * LDS_STRIDE + ko_]); \
-    _Pragma("unroll") for (int tm = 0; tm < 2; tm++)                                                                           \
+    bf16x8 a[TM], b[TN];                                                                                                       \
+    _Pragma("unroll") for (int tm = 0; tm < TM; tm++) a[tm] = *reinterpret_cast<const bf16x8 *>(&As[BUF][(wm * (32 * TM) + tm * 32 + (lane & 31)) * LDS_STRIDE + ko_]); \
+    _Pragma("unroll") for (int tn = 0; tn < TN; tn++) b[tn] = *reinterpret_cast<const bf16x8 *>(&Bs[BUF][(wn * (BN / WN) + tn * 32 + (lane & 31)) * LDS_STRIDE + ko_]); \
+    _Pragma("unroll") for (int tm = 0; tm < TM; tm++)                                                                          \
       _Pragma("unroll") for (int tn = 0; tn < TN; tn++) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], b[tn], acc[tm][tn], 0, 0, 0); \
   }
   SS_LOAD(s0, 0)
@@ -125,14 +129,14 @@ __global__ void __launch_bounds__(256) ss_linear_kernel(const __bf16 *__restrict
 #undef SS_COMPUTE
   // epilogue: bias + activation, bf16 (the next layer's operand) or f32 (the head)
 #pragma unroll
-  for (int tm = 0; tm < 2; tm++)
+  for (int tm = 0; tm < TM; tm++)
 #pragma unroll
     for (int tn = 0; tn < TN; tn++) {
-      const int col = n0 + wn * (BN / 2) + tn * 32 + (lane & 31);
+      const int col = n0 + wn * (BN / WN) + tn * 32 + (lane & 31);
       const float bv = (bias && col < N) ? bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        const int row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int row = m0 + wm * (32 * TM) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row < M && col < N) {
           const float v = activate(acc[tm][tn][r] + bv, act);
           if (F32OUT) reinterpret_cast<float *>(Y)[(size_t)row * ldy + col] = v;
@@ -173,8 +177,13 @@ int ss_linear_bf16(const void *x, const void *w, const float *bias, void *y, int
   const bool wide = (long long)((N + 127) / 128) * gm >= 256 && N >= 128;
   static const bool force32 = getenv("SS_MLP_BK32") != nullptr;   // A/B switches (tools/gpu_mlp.py)
   static const int remap = getenv("SS_MLP_NOREMAP") ? 0 : 1;
+  static const bool waves8 = getenv("SS_MLP_WAVES4") == nullptr;   // 8 waves per workgroup (32 x BN/2 each): twice the waves per SIMD
   const bool k64 = K % 64 == 0 && !force32;
-#define SS_LAUNCH(BN_, BK_, F32_) hipLaunchKernelGGL((ss_linear_kernel<BN_, BK_, F32_>), grid, dim3(256), 0, st, X, Wt, bias, y, M, N, K, ldy, act, remap)
+#define SS_LAUNCH(BN_, BK_, F32_)                                                                                              \
+  do {                                                                                                                         \
+    if (waves8 && BK_ == 64) hipLaunchKernelGGL((ss_linear_kernel<BN_, BK_, F32_, 4>), grid, dim3(512), 0, st, X, Wt, bias, y, M, N, K, ldy, act, remap); \
+    else hipLaunchKernelGGL((ss_linear_kernel<BN_, BK_, F32_, 2>), grid, dim3(256), 0, st, X, Wt, bias, y, M, N, K, ldy, act, remap);    \
+  } while (0)
   if (wide) {
     dim3 grid((N + 127) / 128, gm);
     if (k64) { if (y_is_f32) SS_LAUNCH(128, 64, true); else SS_LAUNCH(128, 64, false); }
