@@ -896,9 +896,6 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
         same = !w->any(sig != this->sig_prev);
         this->sig_prev = sig;
         if (!same) this->gvalid = 0u;
-#ifdef SS_COUNT_SAME
-        if (lane == 0) { extern long ss_cnt_same, ss_cnt_all; ss_cnt_all++; ss_cnt_same += same; }
-#endif
       }
       int act = 0;
       if (lane < ns) { const real *rc = this->rec + kSelfRec * lane; act = rc[RC_JAR] < 0 || rc[RC_JAR + 1] < 0 || rc[RC_JAR + 2] < 0 || rc[RC_JAR + 3] < 0; }
