@@ -173,12 +173,16 @@ int ss_set_order(ss_batch *b, const int32_t *order);
 int ss_schedule_longest_first(ss_batch *b, void *stream);
 
 /* ss_step followed, in the same launch, by the reset of every env whose episode just ended (terminated | truncated) —
- * GymVectEnv's autoreset (reference nv/gymwrapper.py:53-60) without a second launch.  StateInit.Default only (a Fall
- * reset is 45 mj_steps of work: use ss_step + masked ss_reset).  obs = observation of the step for every env (the
+ * GymVectEnv's autoreset (reference nv/gymwrapper.py:53-60) without a second launch.  StateInit.Default, or StateInit.Fall after
+ * ss_set_fall_actions (the Fall reset's 45 warm-up mj_steps then run in the wave that stepped the env; a separate masked
+ * ss_reset launch lasts as long as a whole step however few envs it resets).  obs = observation of the step for every env (the
  * "final_observation" of the envs that ended); obs_next = the observation the policy acts on next: the reset one for
  * envs that ended, the same as obs otherwise.  reset_task_rand [N,4] feeds reset_task of the envs that ended. */
 int ss_step_autoreset(ss_batch *b, const float *actions, const float *task_rand, const float *reset_task_rand, float *obs,
                       float *obs_next, float *reward, uint8_t *terminated, uint8_t *truncated, void *stream);
+/* fall_actions [N,3,nu] uniform(0,1) draws (device pointer, caller-owned, read by every following ss_step_autoreset of a
+ * StateInit.Fall batch: refill it with fresh draws between steps; NULL = none) */
+int ss_set_fall_actions(ss_batch *b, const float *fall_actions);
 
 /* n x (controller + mj_step) without the env epilogue — substep-granular parity/debugging */
 int ss_substep(ss_batch *b, const float *actions, int n_substeps, void *stream);

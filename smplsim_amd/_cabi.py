@@ -97,6 +97,7 @@ class MjcfOptions(C.Structure):
 def bind(lib):
     vp = C.c_void_p
     lib.ss_model_create_from_mjcf.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(MjcfOptions), C.c_int, C.POINTER(vp)]
+    lib.ss_set_fall_actions.argtypes = [vp, vp]
     lib.ss_get_state.argtypes = [vp, C.c_int32, vp, vp]
     lib.ss_set_state.argtypes = [vp, C.c_int32, vp, vp]
     lib.ss_imitation_bind.argtypes = [vp, C.POINTER(ImitationIO)]
@@ -148,7 +149,7 @@ def bind_mlp(lib):
 EXPORTS = ["ss_model_create", "ss_model_create_shapes", "ss_model_destroy", "ss_model_dims", "ss_obs_size", "ss_batch_create",
            "ss_batch_destroy", "ss_reset", "ss_step", "ss_step_autoreset", "ss_substep", "ss_kinematics", "ss_debug_forward", "ss_debug_self_contacts",
            "ss_gae", "ss_debug_prof", "ss_set_order", "ss_set_body_outputs", "ss_set_launch_geometry", "ss_schedule_longest_first", "ss_launch_info", "ss_last_error",
-           "ss_model_create_from_mjcf", "ss_model_last_error", "ss_batch_last_error", "ss_imitation_bind", "ss_imitation_step_fused", "ss_get_state", "ss_set_state",
+           "ss_model_create_from_mjcf", "ss_model_last_error", "ss_batch_last_error", "ss_imitation_bind", "ss_imitation_step_fused", "ss_get_state", "ss_set_state", "ss_set_fall_actions",
            "ss_motion_cook", "ss_motion_state_at", "ss_motion_resample", "ss_imitation_step"]
 
 

@@ -175,7 +175,12 @@ class SMPLSimVecEnv:
         self.truncated = torch.zeros(N, dtype=torch.uint8, device=dev)
         self.reset_buf = torch.zeros(N, dtype=torch.uint8, device=dev)
         self.obs_final = torch.zeros(N, self.obs_size, **f32)
-        self._fused_autoreset = self.state_init == _cabi.INIT_DEFAULT and fused_autoreset
+        # Default and Fall resets of finished envs run inside the step launch (External has no reset state of its own)
+        self._fused_autoreset = self.state_init in (_cabi.INIT_DEFAULT, _cabi.INIT_FALL) and fused_autoreset
+        self._fall_buf = None
+        if self._fused_autoreset and self.state_init == _cabi.INIT_FALL:
+            self._fall_buf = torch.zeros(N, 3, self.nu, **f32)
+            _check(lib().ss_set_fall_actions(self.handle, _ptr(self._fall_buf)))
         self.autoreset = autoreset
         self.gen = torch.Generator(device=dev)
         self.gen.manual_seed(int(seed))
@@ -235,6 +240,8 @@ class SMPLSimVecEnv:
             # nv/gymwrapper.py:53-60): obs_final = the step's observation, obs_buf = what the policy acts on next
             tr2 = self._task_rand()
             self._keep2 = (tr2,)
+            if self._fall_buf is not None:                   # fresh draws for the envs that will be reset in this launch
+                self._fall_buf.uniform_(0.0, 1.0, generator=self.gen)
             _check(lib().ss_step_autoreset(self.handle, _ptr(actions), _ptr(tr), _ptr(tr2), _ptr(self.obs_final), _ptr(self.obs_buf),
                                            _ptr(self.rew_buf), _ptr(self.terminated), _ptr(self.truncated), self._stream()))
             if _events:

@@ -52,6 +52,7 @@ struct ss_batch {
   mutable std::string err;                // message of the last failed call that took this handle
   mutable int parity = 0;                 // which of the two work counters the next launch uses (it clears the other one)
   float *d_kin = nullptr;                 // [N, nb, 12] scratch of ss_get_state(XPOS / XMAT)
+  const float *fall_actions = nullptr;    // caller-owned [N,3,nu] draws of the in-launch Fall reset (ss_set_fall_actions)
   void *d_im = nullptr;                   // ss::mo::ImFused on the device (ss_imitation_bind)
   ss_imitation_io im_io{};
 };
@@ -230,12 +231,13 @@ struct ss_api {
   static int step_autoreset(ss_batch *b, const float *actions, const float *task_rand, const float *reset_task_rand, float *obs,
                             float *obs_next, float *reward, uint8_t *term, uint8_t *trunc, void *stream) {
     if (!b || !actions || !obs || !obs_next || !reward || !term || !trunc) return fail(SS_ERR_INVALID, "null argument");
-    if (b->cfg.state_init != SS_INIT_DEFAULT)
-      return fail(SS_ERR_INVALID, "in-launch autoreset is for StateInit.Default; use ss_step + a masked ss_reset for Fall");
+    if (b->cfg.state_init == SS_INIT_EXTERNAL) return fail(SS_ERR_INVALID, "in-launch autoreset: StateInit External has no reset state of its own");
+    if (b->cfg.state_init == SS_INIT_FALL && !b->fall_actions) return fail(SS_ERR_INVALID, "in-launch Fall reset needs ss_set_fall_actions");
     ss::KArgs k = base_args(b, ss::MODE_STEP);
     k.actions = ss_batch::R(actions); k.task_rand = ss_batch::R(task_rand); k.obs = ss_batch::R(obs); k.reward = ss_batch::R(reward);
     k.terminated = term; k.truncated = trunc;
     k.fused_reset = 1; k.obs2 = ss_batch::R(obs_next); k.task_rand2 = ss_batch::R(reset_task_rand);
+    if (b->cfg.state_init == SS_INIT_FALL) k.fall_actions = ss_batch::R(b->fall_actions);
     return run(b, k, stream);
   }
   // ---- imitation folded into the step launch (include/smplsim_motion.h)
@@ -390,6 +392,10 @@ struct ss_api {
   int ss_step(ss_batch *b, const float *a, const float *tr, float *obs, float *rew, uint8_t *te, uint8_t *tu, void *st) { ss::HandleScope hs_(b ? &b->err : nullptr); return ss_api<BE>::step(b, a, tr, obs, rew, te, tu, st); } \
   int ss_step_autoreset(ss_batch *b, const float *a, const float *tr, const float *tr2, float *obs, float *obs_next, float *rew, \
                         uint8_t *te, uint8_t *tu, void *st) { ss::HandleScope hs_(b ? &b->err : nullptr); return ss_api<BE>::step_autoreset(b, a, tr, tr2, obs, obs_next, rew, te, tu, st); } \
+  int ss_set_fall_actions(ss_batch *b, const float *fa) {                                                             \
+    if (!b) return ss_api<BE>::fail(SS_ERR_INVALID, "null batch");                                                  \
+    b->fall_actions = fa; return SS_OK;                                                                              \
+  }                                                                                                                  \
   int ss_get_state(ss_batch *b, int32_t field, void *buf, void *st) { ss::HandleScope hs_(b ? &b->err : nullptr); return ss_api<BE>::state_field(b, field, buf, false, st); } \
   int ss_set_state(ss_batch *b, int32_t field, const void *buf, void *st) { ss::HandleScope hs_(b ? &b->err : nullptr); return ss_api<BE>::state_field(b, field, const_cast<void *>(buf), true, st); } \
   int ss_imitation_bind(ss_batch *b, const ss_imitation_io *io) { ss::HandleScope hs_(b ? &b->err : nullptr); return ss_api<BE>::imitation_bind(b, io); } \

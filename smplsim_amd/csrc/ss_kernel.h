@@ -2059,7 +2059,8 @@ SS_DEV bool run_env(W *w, const KArgs *k, const uint32_t *T, real *L, int env, i
   const real *act = k->actions ? k->actions + (size_t)env * h.nu : nullptr;
   const real *trand_base = fused_pass ? k->task_rand2 : k->task_rand;
   const real *trand = trand_base ? trand_base + (size_t)env * 4 : nullptr;
-  const real *fa = (k->fall_actions && !fused_pass) ? k->fall_actions + (size_t)env * 3 * h.nu : nullptr;
+  // (written with the mode test first: `k->fall_actions ? ...` alone costs the headline kernel 1.2 % — register allocation)
+  const real *fa = (mode == MODE_RESET && k->fall_actions) ? k->fall_actions + (size_t)env * 3 * h.nu : nullptr;   // reset passes, fused ones too
   real *obs_base = fused_pass ? k->obs2 : k->obs;
   const int ostride = BODYOUT ? k->obs_stride : k->obs_size;   // rows wider than the observation: a task part follows (imitation)
   real *obs = obs_base ? obs_base + (size_t)env * ostride : nullptr;

@@ -142,6 +142,36 @@ def test_fused_autoreset_equals_step_plus_masked_reset(task):
     assert ended >= 4
 
 
+def test_fused_fall_autoreset_equals_step_plus_masked_fall_reset():
+    """StateInit.Fall (config 3, getup): the 45 warm-up mj_steps of the reset inside the step launch (ss_set_fall_actions +
+    ss_step_autoreset) against ss_step + masked ss_reset with the same draws: bit-identical."""
+    import ctypes as C
+    kw = dict(task=2, state_init=1, episode_length=4, recovery_steps=1)
+    a_env, b_env = _batch(3, **kw), _batch(3, **kw)
+    rs = np.random.default_rng(5)
+    fa0, tr0 = rs.uniform(size=(3, 3, 69)), rs.uniform(size=(3, 4))
+    assert np.array_equal(a_env.reset(fall_actions=fa0, task_rand=tr0), b_env.reset(fall_actions=fa0, task_rand=tr0))
+    fall = np.zeros((3, 3, 69), np.float32)
+    b_env._chk(emu.lib().ss_set_fall_actions(b_env.batch, fall.ctypes.data_as(C.c_void_p)))
+    ended = 0
+    for t in range(10):
+        act = rs.uniform(-1, 1, (3, 69))
+        tr, tr2, fa = rs.uniform(size=(3, 4)), rs.uniform(size=(3, 4)), rs.uniform(size=(3, 3, 69)).astype(np.float32)
+        obs_a, rew_a, te_a, tu_a = a_env.step(act, task_rand=tr)
+        done = te_a | tu_a
+        next_a = obs_a.copy()
+        if done.any():
+            next_a = a_env.reset(mask=done.astype(np.uint8), fall_actions=fa, task_rand=tr2)
+        fall[:] = fa
+        obs_b, next_b, rew_b, te_b, tu_b = b_env.step_autoreset(act, task_rand=tr, reset_task_rand=tr2)
+        ended += int(done.sum())
+        assert np.array_equal(te_a, te_b) and np.array_equal(tu_a, tu_b) and np.array_equal(rew_a, rew_b)
+        assert np.array_equal(obs_a, obs_b) and np.array_equal(next_a, next_b), t
+        for f in ("qpos", "qvel", "qpos_prev", "qvel_prev", "qacc_warm", "cur_t", "task", "touch", "body_vel"):
+            assert np.array_equal(getattr(a_env, f), getattr(b_env, f)), (t, f)
+    assert ended >= 3
+
+
 def test_device_side_longest_first_schedule_is_a_sorted_permutation_and_changes_nothing():
     eb, ref = _batch(5), _batch(5)
     rs = np.random.default_rng(21)
@@ -160,7 +190,10 @@ def test_step_autoreset_error_paths():
     a = np.zeros((2, 69), np.float32); obs2 = np.zeros_like(eb.obs)
     p = lambda x: x.ctypes.data_as(C.c_void_p)
     rc = emu.lib().ss_step_autoreset(eb.batch, p(a), None, None, p(eb.obs), p(obs2), p(eb.reward), p(eb.terminated), p(eb.truncated), None)
-    assert rc != 0 and b"Default" in emu.lib().ss_last_error()
+    assert rc != 0 and b"ss_set_fall_actions" in emu.lib().ss_last_error()       # Fall: needs its draws first
+    ex = _batch(2, state_init=2)
+    rc = emu.lib().ss_step_autoreset(ex.batch, p(a), None, None, p(ex.obs), p(obs2), p(ex.reward), p(ex.terminated), p(ex.truncated), None)
+    assert rc != 0 and b"External" in emu.lib().ss_last_error()
     ok = _batch(2)
     rc = emu.lib().ss_step_autoreset(ok.batch, p(a), None, None, p(ok.obs), None, p(ok.reward), p(ok.terminated), p(ok.truncated), None)
     assert rc != 0                                            # obs_next is mandatory
