@@ -27,7 +27,7 @@ WORKLOADS = {
             "actions per control step, 15 mj_steps @450 Hz per step, obs v1 (289 f32) + reward + reset flags fused, "
             "device-side autoreset",
     "getup": "BASELINE config 3 shard: {N} SMPL humanoids, env=getup (obs 290, height reward, contact termination, 60-step "
-             "recovery), StateInit.Fall (45 warm-up mj_steps per reset), uniform(-1,1) actions (ms_per_step includes the masked Fall-reset launch, kernel_ms is the step launch)",
+             "recovery), StateInit.Fall (45 warm-up mj_steps per reset), uniform(-1,1) actions; the Fall reset of finished envs runs inside the step launch (ss_set_fall_actions + ss_step_autoreset)",
     "imitation": "BASELINE config 5 shard: {N} SMPL humanoids tracking motion clips (synthetic smooth clips in the AMASS pickle "
                  "format; no dataset in the image), reference-state init, PD replay of the clip as the policy, per step ONE launch "
                  "(ss_imitation_step_fused): ss_step (obs v2, body frames) + clip lookup at t and t+dt, 576-float task obs, PHC tracking "
