@@ -7,6 +7,7 @@ wxyz / qpos / qvel packing.  PyTorch is only the owner of device
 streams here; all arithmetic happens in libsmplsim_hip.so.
 """
 import ctypes as C
+import os
 import warnings
 
 import numpy as np
@@ -59,7 +60,7 @@ class ShardModel:
     """Compiled model + device tables (ss_model) for one device."""
 
     def __init__(self, xml=None, humanoid="smpl_humanoid", device=0, contact_bodies=DEFAULT_CONTACT_BODIES,
-                 control_mode="uhc_pd", clip_actions=True, pdp_scale=1.0, pdd_scale=1.0, sim_timestep_inv=450, tables=None, xmls=None, mcs=None, compiler="python"):
+                 control_mode="uhc_pd", clip_actions=True, pdp_scale=1.0, pdd_scale=1.0, sim_timestep_inv=450, tables=None, xmls=None, mcs=None, compiler="python", lazy=False):
         """compiler: "python" = smplsim_amd.mjcf + gains build the ss_model_desc; "native" = the library compiles the MJCF text and
         the gain tables itself (ss_model_create_from_mjcf — the entry a non-Python host uses; single shape, reference gain table).
         tables: optional (kp, kd, torque_lim, act_scale, act_offset) per actuator for models whose bodies are not in
@@ -81,27 +82,42 @@ class ShardModel:
             self.mc.actuator_names, lambda n: rng[n], clip_actions=clip_actions, control_mode=control_mode,
             pdp_scale=pdp_scale, pdd_scale=pdd_scale)
         self.device = int(device)
-        self.handle = C.c_void_p()
         if compiler == "native":
             if self.num_shapes != 1 or self.xml is None or tables is not None:
                 raise ValueError("compiler='native' takes one MJCF text and the reference's gain table")
-            names = (C.c_char_p * len(contact_bodies))(*[n.encode() for n in contact_bodies])
-            opt = _cabi.MjcfOptions(_cabi.CONTROL_MODES[control_mode], int(bool(clip_actions)), pdp_scale, pdd_scale, 1.0 / sim_timestep_inv,
-                                    len(contact_bodies), names)
-            txt = self.xml.encode()
-            _check(lib().ss_model_create_from_mjcf(txt, len(txt), C.byref(opt), self.device, C.byref(self.handle)))
-            return
         elif compiler != "python":
             raise ValueError(f"unknown compiler {compiler!r}")
-        descs, self._keep = (_cabi.ModelDesc * self.num_shapes)(), []
-        for i, mc in enumerate(self.mcs):
-            descs[i], keep = _cabi.make_model_desc(mc, *self.tables, legal_bodies=tuple(contact_bodies), timestep=1.0 / sim_timestep_inv)
-            self._keep.append(keep)
-        _check(lib().ss_model_create_shapes(descs, self.num_shapes, self.device, C.byref(self.handle)))
+        self._args = dict(compiler=compiler, contact_bodies=tuple(contact_bodies), control_mode=control_mode, clip_actions=clip_actions,
+                          pdp_scale=pdp_scale, pdd_scale=pdd_scale, sim_timestep_inv=sim_timestep_inv)
+        self._handle, self._pid = None, None
+        if not lazy:
+            self.handle
+
+    @property
+    def handle(self):
+        """The ss_model handle, created on first use IN THE PROCESS THAT USES IT (lazy=True: a model built before a fork — the
+        reference's sampler workers, agents/agent.py:121-145 — gets its device tables in every worker's own HIP context)."""
+        if self._handle is None or self._pid != os.getpid():
+            a = self._args
+            h = C.c_void_p()
+            if a["compiler"] == "native":
+                names = (C.c_char_p * len(a["contact_bodies"]))(*[n.encode() for n in a["contact_bodies"]])
+                opt = _cabi.MjcfOptions(_cabi.CONTROL_MODES[a["control_mode"]], int(bool(a["clip_actions"])), a["pdp_scale"], a["pdd_scale"],
+                                        1.0 / a["sim_timestep_inv"], len(a["contact_bodies"]), names)
+                txt = self.xml.encode()
+                _check(lib().ss_model_create_from_mjcf(txt, len(txt), C.byref(opt), self.device, C.byref(h)))
+            else:
+                descs, self._keep = (_cabi.ModelDesc * self.num_shapes)(), []
+                for i, mc in enumerate(self.mcs):
+                    descs[i], keep = _cabi.make_model_desc(mc, *self.tables, legal_bodies=a["contact_bodies"], timestep=1.0 / a["sim_timestep_inv"])
+                    self._keep.append(keep)
+                _check(lib().ss_model_create_shapes(descs, self.num_shapes, self.device, C.byref(h)))
+            self._handle, self._pid = h, os.getpid()
+        return self._handle
 
     def __del__(self):
-        h = getattr(self, "handle", None)
-        if h:
+        h = getattr(self, "_handle", None)
+        if h and getattr(self, "_pid", None) == os.getpid():
             try:
                 lib().ss_model_destroy(h)
             except Exception:

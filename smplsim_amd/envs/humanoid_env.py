@@ -100,16 +100,21 @@ class HumanoidEnv:
         # (`env.self_collision: False` = floor contacts and joint limits only, the faster path; not a key of the reference's yaml)
         self.self_collision = bool(e.get("self_collision", True) if hasattr(e, "get") else getattr(e, "self_collision", True))
         kw = self._task_kwargs(e)
+        # Nothing touches the GPU here: the model's device tables and the batch are created on first use, in the process that uses
+        # them — the reference's sampler builds the env once and forks its worker processes (agents/agent.py:121-145), and a forked
+        # child cannot use its parent's HIP context.  (No GPU at that point = RuntimeError there: there is no CPU path.)
         self._model = ShardModel(xml=self.default_xml_str, mcs=shape_mcs, device=device, contact_bodies=self.contact_bodies,
                                  control_mode=self.control_mode, clip_actions=self.clip_actions,
-                                 pdp_scale=e.pdp_scale, pdd_scale=e.pdd_scale, sim_timestep_inv=self.sim_timestep_inv)
+                                 pdp_scale=e.pdp_scale, pdd_scale=e.pdd_scale, sim_timestep_inv=self.sim_timestep_inv, lazy=True)
         if shape_mcs is not None and len(shape_mcs) > 1:
             kw["shape_id"] = list(range(num_envs))
-        self._vec = SMPLSimVecEnv(num_envs, model=self._model, task=self._TASK, state_init=e.state_init,
-                                  self_obs_v=self.self_obs_v, control_mode=self.control_mode,
-                                  episode_length=self.max_episode_length, control_freq_inv=self.control_freq_inv,
-                                  root_height_obs=self._root_height_obs, power_scale=float(self.power_scale),
-                                  autoreset=False, self_collision=self.self_collision, **kw)
+        self._num_envs = num_envs
+        self._vec_kw = dict(model=self._model, task=self._TASK, state_init=e.state_init,
+                            self_obs_v=self.self_obs_v, control_mode=self.control_mode,
+                            episode_length=self.max_episode_length, control_freq_inv=self.control_freq_inv,
+                            root_height_obs=self._root_height_obs, power_scale=float(self.power_scale),
+                            autoreset=False, self_collision=self.self_collision, **kw)
+        self._vec_obj, self._vec_pid = None, None
         mc = self._model.mc
         self.mj_body_names = ["world"] + list(mc.body_names)
         self.body_names_orig = list(mc.body_names)
@@ -131,6 +136,13 @@ class HumanoidEnv:
         self.reward_info = {}
         self.viewer = self.renderer = None
 
+    @property
+    def _vec(self):
+        """The GPU batch of this env object, created on first use in the calling process (see __init__)."""
+        if self._vec_obj is None or self._vec_pid != os.getpid():
+            self._vec_obj, self._vec_pid = SMPLSimVecEnv(self._num_envs, **self._vec_kw), os.getpid()
+        return self._vec_obj
+
     # ---- sizes
     def _task_kwargs(self, e):
         return {}
@@ -139,10 +151,13 @@ class HumanoidEnv:
         return self.dof_size
 
     def get_obs_size(self):
-        return self._vec.obs_size
+        return self.get_self_obs_size() + self.get_task_obs_size()
 
     def get_self_obs_size(self):
-        return self._vec.obs_size - self.get_task_obs_size()
+        # reference humanoid_env.py:293-299 (= ss_obs_size of the library, without needing the device)
+        nb = self._model.mc.nbody
+        nd = 3 * (nb - 1)
+        return (1 if self._root_height_obs else 0) + nd + (6 * nb + 6 + nd if self.self_obs_v == 1 else 12 * nb)
 
     def get_task_obs_size(self):
         return 0
@@ -191,7 +206,8 @@ class HumanoidEnv:
         return None
 
     def close(self):
-        self._vec.close()
+        if self._vec_obj is not None and self._vec_pid == os.getpid():
+            self._vec_obj.close()
 
     # ---- state accessors used by callers of the reference env
     def get_qpos(self):

@@ -1,5 +1,7 @@
 """GPU parity tests proper (-m gpu): the HIP path, through the product API and the C ABI, against the
 float64 CPU oracle on the same seeded inputs, plus size-independent properties at the benchmark size."""
+import os
+
 import numpy as np
 import pytest
 
@@ -953,3 +955,14 @@ def test_fused_policy_inference_matches_the_torch_policy():
     a = fast.select_action(obs, generator=g1)
     n = torch.randn(a.shape, device="cuda", generator=g2)
     assert torch.allclose(a, fast.mean(obs) + pol.action_log_std.exp() * n, atol=1e-6)
+
+
+def test_env_built_before_fork_runs_in_worker_processes():
+    """The reference's sampler builds the env once and forks its workers (agents/agent.py:121-145, num_threads > 1).  HumanoidEnv
+    creates its device state lazily in the process that uses it: two forked workers and then the parent step the same env object,
+    each in its own HIP context, and get the same trajectory (run in a fresh interpreter: this one has a HIP context already)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fork_workers_check.py")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "fork workers ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
