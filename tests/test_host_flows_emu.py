@@ -104,6 +104,28 @@ def test_fused_imitation_step_equals_the_launch_sequence_it_replaces(emu_backend
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(envs[0].base.cur_t, envs[1].base.cur_t)
 
 
+def test_imitation_bind_error_paths(emu_backend):
+    import ctypes as C
+    import test_motion_lib as T
+    from smplsim_amd import _cabi
+    from smplsim_amd.batch import SMPLSimVecEnv
+    from smplsim_amd.imitation import SMPLSimImitationVecEnv
+    lib = T.make_lib(emu_backend)
+    L = emu_backend
+    env = SMPLSimImitationVecEnv(2, lib, seed=0)                  # bound (fused)
+    io = env_io = _cabi.ImitationIO()
+    plain = SMPLSimVecEnv(2, autoreset=False)                      # task base but StateInit Default, no body outputs
+    assert L.ss_imitation_bind(plain.handle, C.byref(io)) == -1
+    assert L.ss_imitation_step_fused(plain.handle, C.c_void_p(plain.qpos.data_ptr()), None, None) == -1 and b"bind" in L.ss_batch_last_error(plain.handle)
+    assert L.ss_imitation_bind(env.base.handle, None) == -1
+    assert L.ss_imitation_bind(env.base.handle, C.byref(env_io)) == -1            # null motion data
+    # a too small row stride is refused
+    from smplsim_amd.batch import _ptr
+    bad = _cabi.ImitationIO(C.pointer(lib.data), env.cfg, *[_ptr(t) for t in (env.motion_ids, env.start_times, env.offset, lib.sampling_cdf)],
+                            env.dt, 1, _ptr(env.obs_final), _ptr(env.obs_buf), 10, _ptr(env.rew_buf), _ptr(env.reward_parts), _ptr(env.terminated), _ptr(env.truncated))
+    assert L.ss_imitation_bind(env.base.handle, C.byref(bad)) == -1 and b"obs_stride" in L.ss_batch_last_error(env.base.handle)
+
+
 def test_per_env_shapes_through_the_python_api_on_the_emulator(emu_backend):
     from smplsim_amd.batch import ShardModel, SMPLSimVecEnv
     from smplsim_amd.mjcf_writer import scaled_xml_str

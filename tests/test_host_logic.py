@@ -103,3 +103,19 @@ def test_import_shim_lets_the_rest_of_the_reference_resolve_behind_it():
     assert out.returncode == 0, out.stderr[-2000:]
     mod, mlp_file, ml_mod = out.stdout.split()
     assert mod.startswith("smplsim_amd.") and mlp_file.startswith(ref) and ml_mod == "smplsim_amd.motion_lib"
+
+
+def test_mlp_entry_points_validate_their_arguments():
+    """include/smplsim_mlp.h: the argument checks run before any launch, so they can be exercised without a GPU."""
+    import torch  # noqa: F401
+    from smplsim_amd import _cabi, _lib
+    _lib.build()
+    lib = _cabi.bind_mlp(ctypes.CDLL(_lib.LIB_PATH))
+    lib.ss_last_error.restype = ctypes.c_char_p
+    one = ctypes.c_void_p(16)                                       # never dereferenced: every call below fails its checks first
+    assert lib.ss_linear_bf16(None, one, None, one, 4, 4, 32, 4, 0, 0, None) == -1 and b"null" in lib.ss_last_error()
+    assert lib.ss_linear_bf16(one, one, None, one, 4, 4, 33, 4, 0, 0, None) == -1 and b"multiple of 32" in lib.ss_last_error()
+    assert lib.ss_linear_bf16(one, one, None, one, 4, 8, 32, 4, 0, 0, None) == -1                 # ldy < N
+    assert lib.ss_linear_bf16(one, one, None, one, 4, 4, 32, 4, 9, 0, None) == -1 and b"activation" in lib.ss_last_error()
+    assert lib.ss_obs_to_bf16(one, 4, 289, 289, None, None, None, -5.0, 5.0, 5.0, one, 300, None) == -1      # kpad not a multiple of 32
+    assert lib.ss_obs_to_bf16(one, 4, 289, 100, None, None, None, -5.0, 5.0, 5.0, one, 320, None) == -1      # row stride < dim
