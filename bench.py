@@ -287,6 +287,7 @@ def main(argv=None):
     ap.add_argument("--self-collision", action="store_true",
                     help="contacts between the humanoid's own bodies like mj_step on the reference MJCF (SURVEY 8f-4); default: floor "
                          "contacts and joint limits only")
+    ap.add_argument("--newton-iters", type=int, default=8, help="Newton iteration cap per mj_step (default 8; MuJoCo's own default is 100)")
     ap.add_argument("--unfused", action="store_true", help="imitation: the separate launches instead of ss_imitation_step_fused")
     ap.add_argument("--clips", type=int, default=256, help="imitation: synthetic clips per shard")
     ap.add_argument("--clip-frames", type=int, default=300, help="imitation: frames per synthetic clip (30 fps)")
@@ -309,15 +310,15 @@ def main(argv=None):
         return run_imitation(args, rank, local_rank, world, dist, dev)
     if args.workload == "smpl":
         env = SMPLSimVecEnv(N, device=local_rank, task="HumanoidEnv", state_init="Default", self_obs_v=1,
-                            autoreset=True, seed=shard.shard_seed(1234, rank), self_collision=args.self_collision)
+                            autoreset=True, seed=shard.shard_seed(1234, rank), self_collision=args.self_collision, newton_iters=args.newton_iters)
     elif args.workload == "getup":
         env = SMPLSimVecEnv(N, device=local_rank, task="HumanoidGetup", state_init="Fall", self_obs_v=1,
-                            autoreset=True, seed=shard.shard_seed(1234, rank), self_collision=args.self_collision)
+                            autoreset=True, seed=shard.shard_seed(1234, rank), self_collision=args.self_collision, newton_iters=args.newton_iters)
     else:
         from smplsim_amd.batch import ShardModel
         env = SMPLSimVecEnv(N, model=ShardModel(humanoid="smplx_humanoid", device=local_rank), task="HumanoidEnv",
                             state_init="Default", self_obs_v=1, autoreset=True, seed=shard.shard_seed(1234, rank),
-                            self_collision=args.self_collision)
+                            self_collision=args.self_collision, newton_iters=args.newton_iters)
     g = torch.Generator(device=dev)
     g.manual_seed(shard.shard_seed(1234, rank))
     env.reset()
@@ -374,7 +375,7 @@ def main(argv=None):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload].format(N=N),
                        "envs_per_gpu": N, "parallelism": f"independent shards x{world} (no collective)",
-                       "launch": launch, "mean_newton_iters_per_step": iters, "newton_iters_p50_p99_max": [it_p50, it_p99, it_max],
+                       "launch": launch, "newton_iters_cap": args.newton_iters, "mean_newton_iters_per_step": iters, "newton_iters_p50_p99_max": [it_p50, it_p99, it_max],
                        "bad_state_resets_total": nwarn, "self_collision": bool(getattr(env, "self_collision", False)),
                        "envs_with_body_body_contact_frac": float((env.self_contacts > 0).float().mean().item()),
                        "mean_body_body_contacts": float(env.self_contacts.float().mean().item()),
