@@ -120,6 +120,11 @@ kern_t pick_kernel(int variant, int flavour, const ss::Hdr &h) {
 #endif
   if (variant == 0 && flavour == 0) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, false, false>;
 #ifndef SS_ONLY_HEADLINE                                     // (experiment builds, tools/build_variant.sh, keep the headline kernel alone)
+  if (flavour == 6) {                                        // the same with per-env body shapes (PHC-style: every env tracks clips with its own body)
+    if (variant == 0) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, true, ss::HdrRuntime, false, true>;
+    if (variant == 1) return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, true, true, ss::HdrRuntime, false, true>;
+    return nullptr;
+  }
   if (flavour == 4) {                                        // imitation task folded into the step launch (ss_imitation_step_fused)
 #ifndef SS_NO_FIXED_LAYOUT
     if (variant == 0 && HdrSmpl::matches(h)) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, false, HdrSmpl, false, true>;
@@ -176,7 +181,7 @@ struct HipBackend {
   static int kernel_regs() { return regs_ref(); }
   static const char *launch(const ss::KArgs &k, int nenv, int envs_per_wg, size_t lds_bytes, void *stream, int fixed_epw, int max_wgs) {
     const bool bodyout = k.out0 && (k.mode == ss::MODE_STEP || k.mode == ss::MODE_RESET);
-    const int flavour = k.im ? 4 : (k.cfg.self_collision ? (k.st.shape_id ? 5 : 3) : (k.st.shape_id ? 2 : (bodyout ? 1 : 0)));
+    const int flavour = k.im ? (k.st.shape_id ? 6 : 4) : (k.cfg.self_collision ? (k.st.shape_id ? 5 : 3) : (k.st.shape_id ? 2 : (bodyout ? 1 : 0)));
     kern_t kern = pick_kernel(ss::kernel_variant(k.h), flavour, k.h);
     if (!kern) return "no kernel variant for this model size";
     static thread_local kern_t configured[16] = {};

@@ -162,3 +162,38 @@ def test_package_has_no_backend_switch():
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             batch._shard_device(0)
+
+
+def test_fused_imitation_step_with_per_env_shapes(emu_backend):
+    """PHC-style setup (every env its own body shape, clips cooked with that shape's offsets): the one-launch imitation step on the
+    SHAPED instantiation against the launch sequence, bit for bit, through re-initialisations."""
+    import test_motion_lib as T
+    from smplsim_amd.batch import ShardModel
+    from smplsim_amd.imitation import SMPLSimImitationVecEnv
+    from smplsim_amd.mjcf_writer import scaled_xml_str
+    from smplsim_amd.motion_lib import MotionLibSMPL, Skeleton
+    xmls = [scaled_xml_str("smpl_humanoid", 1.0), scaled_xml_str("smpl_humanoid", 0.9, {"L_Knee": 1.1, "R_Knee": 1.1}),
+            scaled_xml_str("smpl_humanoid", 1.1, {"Chest": 0.9})]
+    model = ShardModel(xmls=xmls, device=0)
+    sks = [Skeleton.from_model_const(mc) for mc in model.mcs]
+    lib = MotionLibSMPL(T.clip_dict(), sks[0], device=0)
+    lib.load_motions(random_sample=False, offsets=np.stack([sk.offsets for sk in sks]))
+    n = 6
+    sid = np.arange(n, dtype=np.int32) % 3
+    envs = [SMPLSimImitationVecEnv(n, lib, model=model, shape_id=sid, seed=4, fused=f, termination_distance=0.15) for f in (True, False)]
+    assert envs[0].fused and not envs[1].fused
+    for e in envs:
+        e.offset[:, 2] = 0.3
+    t0 = np.array([0.1, 0.2, 0.3, 1.2, 0.0, 0.5], np.float32)
+    o = [e.reset(motion_ids=sid, start_times=t0)[0].clone() for e in envs]
+    assert torch.equal(*o)
+    g = torch.Generator().manual_seed(2)
+    resets = 0
+    for k in range(5):
+        act = envs[0].reference_actions() if k % 2 == 0 else (torch.rand(n, 69, generator=g) - 0.5) * 2.0
+        (o1, r1, te1, tr1, i1), (o2, r2, te2, tr2, i2) = [e.step(act.clone()) for e in envs]
+        assert torch.equal(te1, te2) and torch.equal(tr1, tr2) and torch.equal(r1, r2) and torch.equal(o1, o2), k
+        assert torch.equal(i1["final_observation"], i2["final_observation"]) and torch.equal(envs[0].base.qpos, envs[1].base.qpos)
+        assert torch.equal(envs[0].motion_ids, envs[1].motion_ids)
+        resets += int((te1 | tr1).sum())
+    assert resets >= 2
