@@ -33,7 +33,7 @@ class ExtensionMissing(RuntimeError):
 
 def build(verbose=False, force=False):
     """hipcc --offload-arch=gfx950 build of the kernels + C ABI (cross-compiles without a GPU)."""
-    srcs = [os.path.join(SRC_DIR, f) for f in ("smplsim_hip.hip", "smplsim_motion.hip", "smplsim_mlp.hip", "ss_kernel.h", "ss_selfcol.h", "ss_api.h", "ss_tables.h", "ss_hdr.h",
+    srcs = [os.path.join(SRC_DIR, f) for f in ("smplsim_hip.hip", "smplsim_hip_sc.hip", "smplsim_hip_im.hip", "smplsim_motion.hip", "smplsim_mlp.hip", "ss_env_kernel.h", "ss_kernel.h", "ss_selfcol.h", "ss_api.h", "ss_tables.h", "ss_hdr.h",
                                                   "ss_motion.h", "ss_motion_api.h", "ss_wave_gpu.h", "ss_imfused.h", "ss_mjcf.h")]
     srcs += [os.path.join(os.path.dirname(_PKG), "include", h) for h in ("smplsim_hip.h", "smplsim_motion.h", "smplsim_mlp.h")]
     opt = os.environ.get("SS_HIPCC_OPT", DEFAULT_OPT).split()
@@ -43,14 +43,17 @@ def build(verbose=False, force=False):
     if not force and same_flags and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
-    for src, flags in ((srcs[0], opt), (srcs[1], mopt), (srcs[2], mopt)):   # stepper, motion library, policy MLP: one object each, their own flags
-        obj = os.path.join(_PKG, os.path.basename(src).replace(".hip", ".o"))
+    objs, procs = [], []
+    for src, flags in ((srcs[0], opt), (srcs[1], opt), (srcs[2], opt), (srcs[3], mopt), (srcs[4], mopt)):   # stepper (3 units), motion library, policy MLP: their own
+        obj = os.path.join(_PKG, os.path.basename(src).replace(".hip", ".o"))   # flags, compiled side by side
         cmd = [hipcc, "--offload-arch=gfx950", *flags, "-std=c++17", "-fPIC", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        procs.append((cmd, subprocess.Popen(cmd)))
         objs.append(obj)
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))

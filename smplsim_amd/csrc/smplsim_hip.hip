@@ -6,73 +6,10 @@
 // 3072 resident wave slots: the first env of a wave is static, the rest come from a device counter.
 #include <hip/hip_runtime.h>
 
-#include "ss_api.h"
-#include "ss_kernel.h"
-#include "ss_wave_gpu.h"
-
-// launch bounds per kernel variant = the number of envs whose LDS slices fit one CU, rounded up to whole waves per
-// SIMD.  SMPL: 12 envs -> 3 waves/SIMD -> 168-VGPR cap (16 spilled dwords at -O3, 47 at the shipped -Os, which is faster all the same).  SMPL-X: 5 envs -> 2 waves/SIMD, 256 VGPRs,
-// no spills.  (History of the trade-off: profiles/r01i_ab_launch_bounds.txt.)
-#ifndef SS_MAX_THREADS
-#define SS_MAX_THREADS 768
-#endif
-#ifndef SS_MAX_THREADS_X
-#define SS_MAX_THREADS_X 384
-#endif
-// self-collision instantiation of the SMPL size: its LDS slice (18.2 KB) lets 8 envs share a CU -> 2 waves/SIMD, 256 VGPRs
-#ifndef SS_MAX_THREADS_SC
-#define SS_MAX_THREADS_SC 512
-#endif
+#include "ss_env_kernel.h"
 
 namespace {
 
-
-// IMIT: the instantiation of ss_imitation_step_fused — after the step pass the wave runs the imitation task of its env and, if the
-// env finished, the reference-state re-initialisation (ss_imfused.h) around the stepper's own reset pass.
-template <int DOFP, int CANDP, int SLOTP, int NPASS, int MAXT, bool BODYOUT, bool SHAPED, class HT = ss::HdrRuntime, bool SELFCOL = false, bool IMIT = false>
-__global__ void __launch_bounds__(MAXT) ss_env_kernel(const ss::KArgs k) {
-  extern __shared__ __align__(16) uint32_t lds[];
-  if (blockIdx.x == 0 && threadIdx.x == 0) *k.work_counter_next = 0;   // the next launch's counter (this launch uses the other one)
-  for (int i = threadIdx.x; i < k.h.shared_words; i += blockDim.x) lds[i] = k.shared_g[i];
-  __syncthreads();
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> LDS bases stay in SGPRs
-  const int slice = SELFCOL ? k.sc.env_floats : HT::view(k.h).env_floats;
-  float *L = reinterpret_cast<float *>(lds + ((k.h.shared_words + 3) & ~3)) + (size_t)wave * slice;
-  WaveGpu w{(int)(threadIdx.x & 63)};
-  // persistent wavefronts: env-steps have heavy-tailed cost (Newton iterations), so every wave pulls the
-  // next env id from a device counter instead of owning a fixed slice of the batch.  The first env of every wave is
-  // its own global wave index (no atomic: thousands of waves hitting one counter at launch serialise in L2).
-  const int total_waves = (int)(gridDim.x * (blockDim.x >> 6));
-  bool first = true;
-  for (;;) {
-    int env = wave * (int)gridDim.x + (int)blockIdx.x;       // consecutive (= similarly heavy) envs go to different CUs
-    if (!first) {
-      if (w.ln == 0) env = atomicAdd(k.work_counter, 1) + total_waves;
-      env = __builtin_amdgcn_readfirstlane(env);
-    }
-    first = false;
-    if (env >= k.st.num_envs) break;
-    if (k.order) env = __builtin_amdgcn_readfirstlane(k.order[env]);   // longest-processing-time-first hand-out
-    int mode = k.mode;
-    if constexpr (IMIT) {
-      const ss::mo::ImFused *f = static_cast<const ss::mo::ImFused *>(k.im);
-      ss::run_env<WaveGpu, DOFP, CANDP, SLOTP, NPASS, BODYOUT, SHAPED, HT, SELFCOL>(&w, &k, lds, L, env, mode);
-      w.sync();
-      if (ss::mo::fused_after_step(&w, f, k.im_rand, env)) {
-        ss::run_env<WaveGpu, DOFP, CANDP, SLOTP, NPASS, BODYOUT, SHAPED, HT, SELFCOL>(&w, &k, lds, L, env, ss::MODE_RESET);
-        w.sync();
-        ss::mo::fused_after_reset(&w, f, env);
-      }
-      continue;
-    }
-    for (int rep = 0; rep < 2; rep++) {                       // second trip = fused Default reset of an env whose episode ended
-      const bool again = ss::run_env<WaveGpu, DOFP, CANDP, SLOTP, NPASS, BODYOUT, SHAPED, HT, SELFCOL>(&w, &k, lds, L, env, mode);
-      w.sync();
-      if (!again) break;
-      mode = ss::MODE_RESET;
-    }
-  }
-}
 
 // GAE: one lane per env column, time loop backwards; every [t, :] row access is coalesced across the wave.  HBM bound
 // and tiny (5 arrays of T*N floats), it only exists so that the rollout never leaves the device.
@@ -104,12 +41,10 @@ __global__ void __launch_bounds__(1024) ss_order_kernel(const int32_t *iters, in
 }
 
 
-typedef void (*kern_t)(const ss::KArgs);
+typedef ss::kern_t kern_t;
 // instantiations per model size: plain (the headline), +body-frame outputs, +per-env body shapes (which includes the outputs)
 // The two fixtures' sizes get instantiations with compile-time dimensions and LDS layout (HdrFixedT, ss_hdr.h): -2.4% per step
 // launch on the SMPL headline (profiles/r02b_variants.txt); any other model of a variant's size class runs the generic one.
-typedef ss::HdrFixedT<24, 5> HdrSmpl;                        // SMPL: 24 bodies, at most 5 nodes in a tree level
-typedef ss::HdrFixedT<52, 10> HdrSmplx;                      // SMPL-X/H: 52 bodies, 10 finger nodes per level
 kern_t pick_kernel(int variant, int flavour, const ss::Hdr &h) {
 #ifndef SS_NO_FIXED_LAYOUT
   if (variant == 0 && flavour == 0 && HdrSmpl::matches(h)) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, false, false, HdrSmpl>;
@@ -120,29 +55,8 @@ kern_t pick_kernel(int variant, int flavour, const ss::Hdr &h) {
 #endif
   if (variant == 0 && flavour == 0) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, false, false>;
 #ifndef SS_ONLY_HEADLINE                                     // (experiment builds, tools/build_variant.sh, keep the headline kernel alone)
-  if (flavour == 6) {                                        // the same with per-env body shapes (PHC-style: every env tracks clips with its own body)
-    if (variant == 0) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, true, ss::HdrRuntime, false, true>;
-    if (variant == 1) return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, true, true, ss::HdrRuntime, false, true>;
-    return nullptr;
-  }
-  if (flavour == 4) {                                        // imitation task folded into the step launch (ss_imitation_step_fused)
-#ifndef SS_NO_FIXED_LAYOUT
-    if (variant == 0 && HdrSmpl::matches(h)) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, false, HdrSmpl, false, true>;
-#endif
-    if (variant == 0) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, false, ss::HdrRuntime, false, true>;
-    if (variant == 1) return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, true, false, ss::HdrRuntime, false, true>;
-    return nullptr;
-  }
-  if (flavour == 3) {                                        // body-body contacts (ss_env_cfg.self_collision); also writes the body frames
-    if (variant == 0) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS_SC, true, false, ss::HdrRuntime, true>;
-    if (variant == 1) return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, true, false, ss::HdrRuntime, true>;
-    return nullptr;
-  }
-  if (flavour == 5) {                                        // body-body contacts + per-env body shapes
-    if (variant == 0) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS_SC, true, true, ss::HdrRuntime, true>;
-    if (variant == 1) return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, true, true, ss::HdrRuntime, true>;
-    return nullptr;
-  }
+  if (flavour == 3 || flavour == 5 || flavour == 7) return ss::pick_kernel_selfcol(variant, flavour == 5, flavour == 7);   // smplsim_hip_sc.hip
+  if (flavour == 4 || flavour == 6) return ss::pick_kernel_imitation(variant, flavour == 6, h);                          // smplsim_hip_im.hip
   if (variant == 0) {                                        // SMPL layout (24 bodies)
     if (flavour == 1) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, false>;
     return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, true>;
@@ -181,12 +95,12 @@ struct HipBackend {
   static int kernel_regs() { return regs_ref(); }
   static const char *launch(const ss::KArgs &k, int nenv, int envs_per_wg, size_t lds_bytes, void *stream, int fixed_epw, int max_wgs) {
     const bool bodyout = k.out0 && (k.mode == ss::MODE_STEP || k.mode == ss::MODE_RESET);
-    const int flavour = k.im ? (k.st.shape_id ? 6 : 4) : (k.cfg.self_collision ? (k.st.shape_id ? 5 : 3) : (k.st.shape_id ? 2 : (bodyout ? 1 : 0)));
+    const int flavour = k.im ? (k.cfg.self_collision ? 7 : (k.st.shape_id ? 6 : 4)) : (k.cfg.self_collision ? (k.st.shape_id ? 5 : 3) : (k.st.shape_id ? 2 : (bodyout ? 1 : 0)));
     kern_t kern = pick_kernel(ss::kernel_variant(k.h), flavour, k.h);
     if (!kern) return "no kernel variant for this model size";
-    static thread_local kern_t configured[16] = {};
-    static thread_local size_t configured_lds[16] = {};
-    const int slot = 8 * ss::kernel_variant(k.h) + flavour;
+    static thread_local kern_t configured[32] = {};
+    static thread_local size_t configured_lds[32] = {};
+    const int slot = 16 * ss::kernel_variant(k.h) + flavour;
     if (configured[slot] != kern || configured_lds[slot] < lds_bytes) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
       if (e != hipSuccess) return hipGetErrorString(e);

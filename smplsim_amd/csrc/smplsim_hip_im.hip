@@ -1,0 +1,22 @@
+// smplsim_hip_im.hip — the step kernel's instantiations of ss_imitation_step_fused (IMIT = true: imitation task and reference-state
+// re-initialisation inside the step launch, ss_imfused.h): a translation unit of its own, compiled next to smplsim_hip.hip
+// (ss_env_kernel.h).
+#include "ss_env_kernel.h"
+
+namespace ss {
+
+kern_t pick_kernel_imitation(int variant, bool shaped, const Hdr &h) {
+  if (shaped) {                                              // per-env body shapes (PHC-style: every env tracks clips with its own body)
+    if (variant == 0) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, true, HdrRuntime, false, true>;
+    if (variant == 1) return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, true, true, HdrRuntime, false, true>;
+    return nullptr;
+  }
+#ifndef SS_NO_FIXED_LAYOUT
+  if (variant == 0 && HdrSmpl::matches(h)) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, false, HdrSmpl, false, true>;
+#endif
+  if (variant == 0) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, false, HdrRuntime, false, true>;
+  if (variant == 1) return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, true, false, HdrRuntime, false, true>;
+  return nullptr;
+}
+
+}  // namespace ss

@@ -1,0 +1,22 @@
+// smplsim_hip_sc.hip — the step kernel's instantiations with body-body contacts (ss_env_cfg.self_collision; SELFCOL = true): a
+// translation unit of its own so that it compiles next to smplsim_hip.hip instead of after it (ss_env_kernel.h).
+#include "ss_env_kernel.h"
+
+namespace ss {
+
+kern_t pick_kernel_selfcol(int variant, bool shaped, bool imit) {
+  if (imit) {                                                // imitation step with body-body contacts: SMPL size class, one shape
+    if (variant == 0 && !shaped) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS_SC, true, false, HdrRuntime, true, true>;
+    return nullptr;
+  }
+  if (shaped) {                                              // one geom table per body shape
+    if (variant == 0) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS_SC, true, true, HdrRuntime, true>;
+    if (variant == 1) return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, true, true, HdrRuntime, true>;
+    return nullptr;
+  }
+  if (variant == 0) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS_SC, true, false, HdrRuntime, true>;   // (also writes the body frames)
+  if (variant == 1) return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, true, false, HdrRuntime, true>;
+  return nullptr;
+}
+
+}  // namespace ss

@@ -249,7 +249,8 @@ struct ss_api {
     if (io->data->nbody != h.nb) return fail(SS_ERR_INVALID, "motion data and model disagree on nbody");
     if (b->cfg.state_init != SS_INIT_EXTERNAL || b->cfg.task != SS_TASK_BASE)
       return fail(SS_ERR_INVALID, "the fused imitation step needs a batch with task base and StateInit External");
-    if (b->cfg.self_collision) return fail(SS_ERR_INVALID, "fused imitation step: self_collision batches use the separate launches");
+    if (b->cfg.self_collision && (b->st.shape_id || ss::kernel_variant(h) != 0))
+      return fail(SS_ERR_INVALID, "fused imitation step with self_collision: SMPL-sized single-shape models only (use the separate launches)");
     if (!b->body_xpos || !b->body_xmat) return fail(SS_ERR_INVALID, "call ss_set_body_outputs first");
     if (!io->motion_ids || !io->start_times || !io->obs_final || !io->obs_next || !io->reward || !io->terminated || !io->truncated)
       return fail(SS_ERR_INVALID, "null buffer in ss_imitation_io");

@@ -63,7 +63,8 @@ class SMPLSimImitationVecEnv:
         _check(lib().ss_set_body_outputs(b.handle, _ptr(self.xpos), _ptr(self.xmat)))
         # resampling draws of the re-initialisations: a block of RAND_BLOCK steps per torch.rand launch
         self._rand_block, self._rand_i = None, self.RAND_BLOCK
-        self.fused = bool(fused) and not b.self_collision
+        # (with body-body contacts the one-launch step is compiled for SMPL-sized single-shape models only)
+        self.fused = bool(fused) and not (b.self_collision and (b.shape_id is not None or b.nv > 128))
         self.obs_final = torch.zeros(N, self.obs_size, **f32)
         self._bound = None
         self._bind()

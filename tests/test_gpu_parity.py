@@ -721,6 +721,33 @@ def test_fused_imitation_step_on_gpu_equals_the_launch_sequence(humanoid):
     assert resets >= 20
 
 
+def test_fused_imitation_step_with_body_body_contacts_on_gpu():
+    """SELFCOL + IMIT instantiation: the one-launch imitation step with body-body contacts against the launch sequence."""
+    import test_motion_lib as T
+    from smplsim_amd.imitation import SMPLSimImitationVecEnv
+    lib = T.make_lib(None, device=0)
+    n = 64
+    envs = [SMPLSimImitationVecEnv(n, lib, seed=9, fused=f, termination_distance=0.2, self_collision=True) for f in (True, False)]
+    assert envs[0].fused and not envs[1].fused
+    for e in envs:
+        e.offset[:, 2] = 0.05
+    o = [e.reset()[0].clone() for e in envs]
+    assert (o[0] - o[1]).abs().max() < 1e-5
+    g = torch.Generator().manual_seed(4)
+    contacts = resets = 0
+    for k in range(6):
+        act = ((torch.rand(n, 69, generator=g) - 0.5) * 2.0).to(envs[0].device)
+        (o1, r1, te1, tr1, i1), (o2, r2, te2, tr2, i2) = [e.step(act.clone()) for e in envs]
+        torch.cuda.synchronize()
+        assert torch.equal(te1, te2) and torch.equal(tr1, tr2) and torch.equal(envs[0].motion_ids, envs[1].motion_ids), k
+        assert torch.equal(envs[0].base.self_contacts, envs[1].base.self_contacts)
+        assert (r1 - r2).abs().max() < 1e-5 and (o1 - o2).abs().max() < 2 * TOL_OBS and (envs[0].base.qpos - envs[1].base.qpos).abs().max() < TOL_QPOS_FREE, k
+        for f in ("qpos", "qvel", "qpos_prev", "qvel_prev", "qacc_warm"):
+            getattr(envs[1].base, f).copy_(getattr(envs[0].base, f))
+        contacts += int(envs[0].base.self_contacts.sum()); resets += int((te1 | tr1).sum())
+    assert contacts > 0 and resets > 0
+
+
 def test_motion_lib_52_body_skeleton_on_gpu():
     import test_motion_lib as T
     from smplsim_amd import _lib

@@ -197,3 +197,27 @@ def test_fused_imitation_step_with_per_env_shapes(emu_backend):
         assert torch.equal(envs[0].motion_ids, envs[1].motion_ids)
         resets += int((te1 | tr1).sum())
     assert resets >= 2
+
+
+def test_fused_imitation_step_with_body_body_contacts(emu_backend):
+    """The one-launch imitation step on the self-collision instantiation against the launch sequence (wild actions fold the arms
+    through the torso: body-body contacts and early terminations), bit for bit."""
+    import test_motion_lib as T
+    from smplsim_amd.imitation import SMPLSimImitationVecEnv
+    lib = T.make_lib(emu_backend)
+    n = 4
+    envs = [SMPLSimImitationVecEnv(n, lib, seed=9, fused=f, termination_distance=0.2, self_collision=True) for f in (True, False)]
+    assert envs[0].fused and envs[0].base.self_collision
+    for e in envs:
+        e.offset[:, 2] = 0.05
+    ids, t0 = np.array([0, 1, 2, 0], np.int32), np.array([0.1, 0.2, 0.3, 1.2], np.float32)
+    assert torch.equal(*[e.reset(motion_ids=ids, start_times=t0)[0].clone() for e in envs])
+    g = torch.Generator().manual_seed(4)
+    contacts = 0
+    for k in range(5):
+        act = (torch.rand(n, 69, generator=g) - 0.5) * 2.0
+        (o1, r1, te1, tr1, i1), (o2, r2, te2, tr2, i2) = [e.step(act.clone()) for e in envs]
+        assert torch.equal(te1, te2) and torch.equal(tr1, tr2) and torch.equal(r1, r2) and torch.equal(o1, o2), k
+        assert torch.equal(envs[0].base.qpos, envs[1].base.qpos) and torch.equal(envs[0].base.self_contacts, envs[1].base.self_contacts)
+        contacts += int(envs[0].base.self_contacts.sum())
+    assert contacts > 0

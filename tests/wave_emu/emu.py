@@ -7,6 +7,7 @@ the same C ABI as the product library, with host (numpy) buffers instead of devi
 import ctypes as C
 import os
 import subprocess
+import threading
 
 import numpy as np
 
@@ -14,15 +15,17 @@ from smplsim_amd import _cabi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBS = {}
+_LOCK = threading.Lock()              # parity_tools steps batches from a thread pool: one `make`, one load
 
 
 def lib(f64=False):
     """f64=True: the float64 instantiation of the same kernel source (-DSS_F64, Newton run to convergence): every array of
     the C ABI declared float* is then a float64 array."""
     name = "libss_emu64.so" if f64 else "libss_emu.so"
-    if name not in _LIBS:
-        subprocess.check_call(["make", "-s", "-C", _HERE, name])
-        _LIBS[name] = _cabi.bind(C.CDLL(os.path.join(_HERE, name)))
+    with _LOCK:
+        if name not in _LIBS:
+            subprocess.check_call(["make", "-s", "-C", _HERE, name])
+            _LIBS[name] = _cabi.bind(C.CDLL(os.path.join(_HERE, name)))
     return _LIBS[name]
 
 

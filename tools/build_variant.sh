@@ -6,9 +6,12 @@ cd "$(dirname "$0")/.."
 NAME=$1; shift
 OPT=${SS_HIPCC_OPT:--Os -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-ilp}
 mkdir -p build/variants
-/opt/rocm/bin/hipcc --offload-arch=gfx950 $OPT "$@" -std=c++17 -fPIC -c smplsim_amd/csrc/smplsim_hip.hip -o build/variants/hip_$NAME.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 $OPT "$@" -std=c++17 -fPIC -c smplsim_amd/csrc/smplsim_hip.hip -o build/variants/hip_$NAME.o &
+/opt/rocm/bin/hipcc --offload-arch=gfx950 $OPT "$@" -std=c++17 -fPIC -c smplsim_amd/csrc/smplsim_hip_sc.hip -o build/variants/hip_sc_$NAME.o &
+/opt/rocm/bin/hipcc --offload-arch=gfx950 $OPT "$@" -std=c++17 -fPIC -c smplsim_amd/csrc/smplsim_hip_im.hip -o build/variants/hip_im_$NAME.o &
+wait
 [ -f build/variants/motion.o ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c smplsim_amd/csrc/smplsim_motion.hip -o build/variants/motion.o
 [ -f build/variants/mlp.o ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c smplsim_amd/csrc/smplsim_mlp.hip -o build/variants/mlp.o
 mkdir -p smplsim_amd/variants
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/variants/hip_$NAME.o build/variants/motion.o build/variants/mlp.o -o smplsim_amd/variants/libsmplsim_hip_$NAME.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/variants/hip_$NAME.o build/variants/hip_sc_$NAME.o build/variants/hip_im_$NAME.o build/variants/motion.o build/variants/mlp.o -o smplsim_amd/variants/libsmplsim_hip_$NAME.so
 echo built smplsim_amd/variants/libsmplsim_hip_$NAME.so

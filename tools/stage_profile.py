@@ -17,7 +17,8 @@ prof_so = os.environ.get("SS_PROF_LIB") or os.path.join(ROOT, "gpurun_out", "lib
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 if not os.environ.get("SS_PROF_LIB"):                        # or a prebuilt -DSS_PROFILE variant (tools/build_variant.sh prof -DSS_PROFILE)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", *_lib.DEFAULT_OPT.split(), "-std=c++17", "-shared", "-fPIC", "-DSS_PROFILE", *os.environ.get("SS_EXTRA", "").split(),
-                       os.path.join(_lib.SRC_DIR, "smplsim_hip.hip"), "-o", prof_so])
+                       *[os.path.join(_lib.SRC_DIR, f) for f in ("smplsim_hip.hip", "smplsim_hip_sc.hip", "smplsim_hip_im.hip", "smplsim_motion.hip", "smplsim_mlp.hip")],
+                       "-o", prof_so])
 _lib._LIB = _cabi.bind(C.CDLL(prof_so))
 from smplsim_amd.batch import SMPLSimVecEnv
 
