@@ -368,7 +368,7 @@ def main(argv=None):
                 "fp32_useful_frac": N * flops / (kern_ms * 1e-3) / FP32_VECTOR_PEAK, "flops_per_env_step_model": flops,
                 "waves_per_cu": launch["envs_per_workgroup"],
                 "note": "path is LDS-latency/VALU bound, not HBM bound (DESIGN.md §roofline)"}
-        roof.update(pmc_summary(args.workload, N))
+        roof.update(pmc_summary(args.workload + ("_selfcollision" if args.self_collision else ""), N))
         out = {
             "metric": "env-steps/sec (whole node), 4096-env SMPL rollout at 1/2/4/8 MI355X", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
