@@ -122,7 +122,8 @@ int ss_imitation_step(const ss_motion_data *data, const ss_imitation_cfg *cfg, c
  * and the task observation of the new state.  Same element functions, same results as that sequence of six launches.
  *
  * ss_imitation_bind stores the buffers (device pointers the caller keeps alive and in place) with the batch; the batch must
- * have task base, StateInit External and ss_set_body_outputs buffers.  Rows of obs_final / obs_next are
+ * have task base, StateInit External and ss_set_body_outputs buffers (per-env body shapes are fine; with self_collision the
+ * one-launch step exists for SMPL-sized single-shape models — otherwise SS_ERR_INVALID, use the separate launches).  Rows of obs_final / obs_next are
  * [self observation | task observation (24 J)] at a row stride of obs_stride floats: obs_final = after the step (what the
  * learner stores), obs_next = what the policy acts on next (= obs_final for envs that go on). */
 struct ss_batch;
