@@ -287,7 +287,7 @@ def main(argv=None):
     ap.add_argument("--self-collision", action="store_true",
                     help="contacts between the humanoid's own bodies like mj_step on the reference MJCF (SURVEY 8f-4); default: floor "
                          "contacts and joint limits only")
-    ap.add_argument("--newton-iters", type=int, default=8, help="Newton iteration cap per mj_step (default 8; MuJoCo's own default is 100)")
+    ap.add_argument("--newton-iters", type=int, default=0, help="mjOption.iterations: Newton iteration cap per mj_step (0 = MuJoCo's default, 100)")
     ap.add_argument("--unfused", action="store_true", help="imitation: the separate launches instead of ss_imitation_step_fused")
     ap.add_argument("--clips", type=int, default=256, help="imitation: synthetic clips per shard")
     ap.add_argument("--clip-frames", type=int, default=300, help="imitation: frames per synthetic clip (30 fps)")

@@ -70,6 +70,9 @@ typedef struct {
   const int32_t *geom_conaffinity; /* [nbody] */
   int32_t nexclude;
   const int32_t *exclude;        /* [nexclude,2] body indices */
+  /* mjModel.stat.meaninertia: mean diagonal of the joint-space inertia matrix (armature included) at qpos0.  It scales the
+   * solver's termination test like in mj_step (below: ss_env_cfg.solver_tolerance).  <= 0 is rejected. */
+  double meaninertia;
 } ss_model_desc;
 
 /* Environment configuration (the keys of the reference's smpl_sim/data/cfg/env yaml files). */
@@ -79,13 +82,20 @@ typedef struct {
   float power_scale;
   float tar_speed_min, tar_speed_max; int32_t speed_change_min, speed_change_max;
   float tar_height_min, tar_height_max; int32_t height_change_min, height_change_max, recovery_steps;
-  int32_t newton_iters;          /* max Newton iterations of the constraint solve per substep (default 8) */
+  int32_t newton_iters;          /* mjOption.iterations: max Newton iterations of the constraint solve per mj_step; 0 = MuJoCo's
+                                    default, 100 (the reference MJCF does not override it) */
   /* reach task (tasks/humanoid_reach.py): target x,y in +-tar_dist_max, z in [tar_height_min, tar_height_max], resampled
    * every [height_change_min, height_change_max) steps; reward on the world position of body `reach_body` */
   float tar_dist_max; int32_t reach_body;
   /* 1: contacts between the humanoid's own bodies (capsule-capsule, capsule-box, box-box) as mj_step makes
    * them for the reference MJCF; 0: floor contacts and joint limits only.  At most SS_MAX_SELF_CONTACTS (the deepest) per env */
   int32_t self_collision;
+  /* mjOption.tolerance: the Newton iteration of an mj_step ends like MuJoCo's (engine_solver.c, mj_solPrimal) when
+   *   improvement * scale < tolerance   or   gradient * scale < tolerance,   scale = 1 / (meaninertia * max(1, nv)),
+   * improvement = the cost decrease of the iteration, gradient = the norm of the cost gradient after it — or, float32 only, when
+   * the Newton decrement is below the rounding error of its own evaluation (DESIGN.md "solver termination").  0 = MuJoCo's default
+   * 1e-8 (the reference MJCF does not override it). */
+  float solver_tolerance;
 } ss_env_cfg;
 enum { SS_MAX_SELF_CONTACTS = 8 };
 

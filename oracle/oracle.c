@@ -138,6 +138,9 @@ struct om_model {
   int self_collision, npair, max_self;
   int pair_b1[MAXPAIR], pair_b2[MAXPAIR];
   double brad[OM_MAXB];                       /* bounding-sphere radius of the body's geom about its centre */
+  /* constraint solver settings (om_model_set_solver): mjModel.stat.meaninertia, mjOption.tolerance / iterations */
+  double meaninertia, tolerance;
+  int solver_mode, iterations;
 };
 
 struct om_data {
@@ -300,6 +303,11 @@ om_model *om_model_create(const om_desc *ds) {
     m->body_invw[b][0] = tr / 3; m->body_invw[b][1] = rot / 3;
   }
   for (int i = 0; i < nv; i++) m->dof_invw[i] = Minv[i * nv + i];
+  /* mj_setConst: stat.meaninertia = mean diagonal of qM at qpos0; MuJoCo's solver defaults (the reference MJCF sets neither) */
+  m->meaninertia = 0;
+  for (int i = 0; i < nv; i++) m->meaninertia += d->M[i * nv + i];
+  m->meaninertia /= nv > 1 ? nv : 1;
+  m->solver_mode = OM_SOLVER_MUJOCO; m->tolerance = 1e-8; m->iterations = 100;
   for (int g = 0; g < 2; g++) {
     double a = (m->dof_invw[3 * g] + m->dof_invw[3 * g + 1] + m->dof_invw[3 * g + 2]) / 3;
     m->dof_invw[3 * g] = m->dof_invw[3 * g + 1] = m->dof_invw[3 * g + 2] = a;
@@ -308,6 +316,11 @@ om_model *om_model_create(const om_desc *ds) {
   return m;
 }
 void om_model_destroy(om_model *m) { free(m); }
+void om_model_set_solver(om_model *m, int mode, double tolerance, int iterations) {
+  m->solver_mode = mode;
+  if (tolerance > 0) m->tolerance = tolerance;
+  if (iterations > 0) m->iterations = iterations;
+}
 
 int om_model_get(const om_model *m, int field, double *out) {
   int nb = m->nbody;
@@ -322,6 +335,7 @@ int om_model_get(const om_model *m, int field, double *out) {
     case OM_M_BODY_INVW: for (int b = 0; b < nb; b++) { out[2 * b] = m->body_invw[b][0]; out[2 * b + 1] = m->body_invw[b][1]; } return 2 * nb;
     case OM_M_DOF_INVW: memcpy(out, m->dof_invw, m->nv * sizeof(double)); return m->nv;
     case OM_M_RANGE: for (int i = 0; i < m->nv; i++) { out[2 * i] = m->range[i][0]; out[2 * i + 1] = m->range[i][1]; } return 2 * m->nv;
+    case OM_M_MEANINERTIA: out[0] = m->meaninertia; return 1;
   }
   return -1;
 }
@@ -647,15 +661,6 @@ static int capsule_box(const double *cp, const double *ca, double r, double h, c
   return n;
 }
 
-/* signed distance of point x (world) to the box and the outward direction of the nearest surface point (world) */
-static double point_box_sdf(const double *x, const double *bp, const double *bm, const double *bs, double *cl_w, double *n_w) {
-  ncon t;
-  /* a zero-radius sphere; a point farther than any margin still needs its distance, so the margin is infinite here */
-  sphere_box(x, 0.0, bp, bm, bs, 1e300, NULL, &t);
-  for (int i = 0; i < 3; i++) { n_w[i] = -t.normal[i]; cl_w[i] = t.pos[i] - n_w[i] * 0.5 * t.dist; }
-  return t.dist;
-}
-
 static int box_box(const double *pa, const double *ma, const double *sa, const double *pb, const double *mb, const double *sb,
                    double margin, ncon *o) {
   double A[3][3], B[3][3], t[3], R[3][3], AR[3][3];
@@ -709,27 +714,64 @@ static int box_box(const double *pa, const double *ma, const double *sa, const d
     o[0].dist = ebest;
     return 1;
   }
-  /* face contact: vertices of either box within the margin of the other box's surface whose nearest surface point lies on
-   * the face the separating axis selects (normal within 45 degrees of the axis) */
-  for (int which = 0; which < 2 && n < 8; which++) {
-    const double *pv = which ? pa : pb, *sv = which ? sa : sb;         /* box providing the vertices */
-    const double (*V)[3] = which ? A : B;
-    const double *po = which ? pb : pa, *mo = which ? mb : ma, *so = which ? sb : sa;   /* box providing the surface */
-    for (int c = 0; c < 8 && n < 8; c++) {
-      double x[3]; v3cpy(x, pv);
-      for (int k = 0; k < 3; k++) v3addscl(x, V[k], ((c >> k) & 1 ? 1.0 : -1.0) * sv[k]);
-      double cl[3], nw[3];
-      double dist = point_box_sdf(x, po, mo, so, cl, nw);
+  /* face contact (the manifold of ODE's dBoxBox, from which mjc_BoxBox descends): reference face = the face of the box owning
+   * the best axis that looks at the other box; incident face = the other box's face most anti-parallel to it; the incident
+   * rectangle is clipped (Sutherland-Hodgman) against the reference face's four side planes; the clipped polygon's vertices
+   * within the margin of the reference plane are the contacts — half way between vertex and plane, normal = the axis */
+  {
+    const int ref_a = bcode < 3, ir = ref_a ? bcode : bcode - 3, i1 = (ir + 1) % 3, i2 = (ir + 2) % 3;
+    const double (*Rf)[3] = ref_a ? A : B;
+    const double (*Xi)[3] = ref_a ? B : A;
+    const double *pr = ref_a ? pa : pb, *sr = ref_a ? sa : sb, *pi = ref_a ? pb : pa, *si = ref_a ? sb : sa;
+    double nout[3]; for (int k = 0; k < 3; k++) nout[k] = ref_a ? bn[k] : -bn[k];
+    int j = 0; double bd = -1;
+    for (int k = 0; k < 3; k++) { double dk = fabs(v3dot(nout, Xi[k])); if (dk > bd) { bd = dk; j = k; } }
+    const double sgn = v3dot(nout, Xi[j]) > 0 ? -1.0 : 1.0;
+    const int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    double poly[8][3], tmp[8][3];
+    int np = 4;
+    for (int v = 0; v < 4; v++) {
+      const double su = (v == 0 || v == 3) ? si[j1] : -si[j1], sv = v < 2 ? si[j2] : -si[j2];
+      for (int k = 0; k < 3; k++) poly[v][k] = pi[k] + sgn * si[j] * Xi[j][k] + su * Xi[j1][k] + sv * Xi[j2][k];
+    }
+    const double clip_tol = 1e-5 * (sr[i1] + sr[i2]);
+    for (int e = 0; e < 4 && np > 0; e++) {
+      const int tt = e < 2 ? i1 : i2;
+      const double sg = (e & 1) ? -1.0 : 1.0;
+      double rel[3]; v3sub(rel, poly[np - 1], pr);
+      double fprev = sg * v3dot(rel, Rf[tt]) - sr[tt];
+      int nq = 0;
+      for (int v = 0; v < np; v++) {
+        const double *x = poly[v], *xp = poly[v == 0 ? np - 1 : v - 1];
+        v3sub(rel, x, pr);
+        const double f = sg * v3dot(rel, Rf[tt]) - sr[tt];
+        const int in = f <= clip_tol, inp = fprev <= clip_tol;
+        if (in != inp && nq < 8) { const double u = fprev / (fprev - f); for (int k = 0; k < 3; k++) tmp[nq][k] = xp[k] + u * (x[k] - xp[k]); nq++; }
+        if (in && nq < 8) { v3cpy(tmp[nq], x); nq++; }
+        fprev = f;
+      }
+      np = nq;
+      memcpy(poly, tmp, sizeof poly);
+    }
+    double kept[8][3];
+    for (int v = 0; v < np && n < 8; v++) {
+      double rel[3]; v3sub(rel, poly[v], pr);
+      const double dist = v3dot(rel, nout) - sr[ir];
       if (dist > margin) continue;
-      /* nw: outward normal of the surface box at the nearest point; towards the vertex box it is +bn (surface = A) or -bn */
-      double al = v3dot(nw, bn) * (which ? -1.0 : 1.0);
-      if (al < 0.70710678) continue;
-      for (int k = 0; k < 3; k++) { o[n].pos[k] = 0.5 * (x[k] + cl[k]); o[n].normal[k] = bn[k]; }
+      int dup = 0;
+      for (int q = 0; q < n; q++) {
+        double e[3]; v3sub(e, kept[q], poly[v]);
+        const double en_ = v3dot(e, nout);
+        v3addscl(e, nout, -en_);
+        if (v3dot(e, e) <= clip_tol * clip_tol) dup = 1;
+      }
+      if (dup) continue;
+      v3cpy(kept[n], poly[v]);
+      for (int k = 0; k < 3; k++) { o[n].pos[k] = poly[v][k] - 0.5 * dist * nout[k]; o[n].normal[k] = bn[k]; }
       o[n].dist = dist;
       n++;
     }
   }
-  (void)bcode;
   return n;
 }
 
@@ -905,26 +947,31 @@ static void solve_constraints(const om_model *m, om_data *d) {
   /* warm start: the better of qacc_warmstart and qacc_smooth */
   double cw = eval_cost(m, d, d->warm, d->ejar), cs = eval_cost(m, d, d->qacc_smooth, d->ejar);
   memcpy(a, cw < cs ? d->warm : d->qacc_smooth, sizeof(double) * nv);
-  for (int it = 0; it < 100; it++) {
+  /* Newton with exact line search.  Two termination rules (om_model_set_solver):
+   *   OM_SOLVER_MUJOCO     mj_solPrimal's (MuJoCo engine_solver.c; reached from the reference through mujoco.mj_step,
+   *                        humanoid_env.py:450): after every iteration
+   *                          improvement = scale (cost_before - cost_after), gradient = scale |grad(a_after)|,
+   *                          scale = 1 / (meaninertia max(1, nv));  stop when either is < opt.tolerance (1e-8), or after
+   *                          opt.iterations (100) iterations, or when the line search finds no step (alpha = 0)
+   *   OM_SOLVER_CONVERGED  to the rounding level of the forces (the triage reference: what any faithful solver converges to) */
+  const int mj = m->solver_mode == OM_SOLVER_MUJOCO;
+  const double scale = 1.0 / (m->meaninertia * (nv > 1 ? nv : 1));
+  const int maxit = mj ? m->iterations : 100;
+  double cost = cw < cs ? cw : cs, improvement = 0;
+  for (int it = 0; it < maxit; it++) {
     eval_cost(m, d, a, d->ejar);
-    /* gradient = M (a - as) + J^T (D jar)_-   and Hessian = M + J^T D_active J */
+    /* gradient = M (a - as) + J^T (D jar)_- */
     for (int i = 0; i < nv; i++) {
       double s = 0;
       for (int k = 0; k < nv; k++) s += d->M[i * nv + k] * (a[k] - d->qacc_smooth[k]);
       grad[i] = s;
     }
-    memcpy(d->H, d->M, sizeof(double) * nv * nv);
     for (int r = 0; r < ne; r++) {
       if (d->ejar[r] >= 0) { d->eforce[r] = 0; continue; }
       const double *row = d->J + (size_t)r * nv;
       double Dj = d->eD[r] * d->ejar[r];
       d->eforce[r] = -Dj;
-      for (int i = 0; i < nv; i++) {
-        if (row[i] == 0) continue;
-        grad[i] += row[i] * Dj;
-        double ri = d->eD[r] * row[i];
-        for (int k = 0; k <= i; k++) d->H[i * nv + k] += ri * row[k];
-      }
+      for (int i = 0; i < nv; i++) grad[i] += row[i] * Dj;
     }
     double gn = 0, fn = 0;
     for (int i = 0; i < nv; i++) {
@@ -932,8 +979,19 @@ static void solve_constraints(const om_model *m, om_data *d) {
       gn += grad[i] * grad[i]; fn += fs * fs;
     }
     for (int r = 0; r < ne; r++) fn += d->eforce[r] * d->eforce[r];
-    if (sqrt(gn) <= 1e-13 * (1.0 + sqrt(fn))) break;      /* gradient at rounding level of the forces */
-    d->solver_iter = it + 1;
+    if (mj) { if (it > 0 && (improvement < m->tolerance || scale * sqrt(gn) < m->tolerance)) break; }
+    else if (sqrt(gn) <= 1e-13 * (1.0 + sqrt(fn))) break;   /* gradient at rounding level of the forces */
+    /* Hessian = M + J^T D_active J */
+    memcpy(d->H, d->M, sizeof(double) * nv * nv);
+    for (int r = 0; r < ne; r++) {
+      if (d->ejar[r] >= 0) continue;
+      const double *row = d->J + (size_t)r * nv;
+      for (int i = 0; i < nv; i++) {
+        if (row[i] == 0) continue;
+        double ri = d->eD[r] * row[i];
+        for (int k = 0; k <= i; k++) d->H[i * nv + k] += ri * row[k];
+      }
+    }
     for (int i = 0; i < nv; i++) for (int k = i + 1; k < nv; k++) d->H[i * nv + k] = d->H[k * nv + i];
     if (chol_factor(d->H, nv)) break;
     for (int i = 0; i < nv; i++) dir[i] = -grad[i];
@@ -961,7 +1019,8 @@ static void solve_constraints(const om_model *m, om_data *d) {
         if (x_ < 0) { d1 += d->eD[r_] * x_ * d->ejd[r_]; d2 += d->eD[r_] * d->ejd[r_] * d->ejd[r_]; } } } while (0)
     double lo = 0, hi = 1, d1, d2, dlo;
     DPHI(0.0, dlo, d2);
-    if (dlo >= 0) break;                                    /* not a descent direction: converged */
+    if (dlo >= 0) break;                                    /* not a descent direction: converged (MuJoCo: alpha = 0) */
+    d->solver_iter = it + 1;
     DPHI(hi, d1, d2);
     int guard = 0;
     while (d1 < 0 && guard++ < 60) { lo = hi; hi *= 2; DPHI(hi, d1, d2); }
@@ -980,7 +1039,11 @@ static void solve_constraints(const om_model *m, om_data *d) {
     }
     double step = 0;
     for (int i = 0; i < nv; i++) { a[i] += al * dir[i]; step += al * dir[i] * al * dir[i]; }
-    if (sqrt(step) < 1e-15) break;
+    if (mj) {
+      const double newcost = eval_cost(m, d, a, d->ejar);
+      improvement = scale * (cost - newcost);
+      cost = newcost;
+    } else if (sqrt(step) < 1e-15) break;
   }
   eval_cost(m, d, a, d->ejar);
   memcpy(d->qacc, a, sizeof(double) * nv);

@@ -56,8 +56,14 @@ om_model *om_model_create(const om_desc *d);
 void om_model_destroy(om_model *m);
 /* compiled constants, for checking the product's compiler: field ids below */
 enum { OM_M_MASS = 0, OM_M_IPOS, OM_M_IQUAT, OM_M_INERTIA, OM_M_GPOS, OM_M_GQUAT, OM_M_GSIZE,
-       OM_M_BODY_INVW, OM_M_DOF_INVW, OM_M_RANGE };
+       OM_M_BODY_INVW, OM_M_DOF_INVW, OM_M_RANGE, OM_M_MEANINERTIA };
 int om_model_get(const om_model *m, int field, double *out);
+/* Termination of the constraint solver's Newton iteration.  OM_SOLVER_MUJOCO (the default: what mj_step does, MuJoCo
+ * engine_solver.c mj_solPrimal): improvement * scale < tolerance || gradient * scale < tolerance, scale = 1 / (meaninertia *
+ * max(1, nv)), at most `iterations` iterations (MuJoCo's defaults 1e-8 / 100; arguments <= 0 keep the current values).
+ * OM_SOLVER_CONVERGED: iterate until the gradient is at the rounding level of the forces (the parity triage's reference). */
+enum { OM_SOLVER_CONVERGED = 0, OM_SOLVER_MUJOCO = 1 };
+void om_model_set_solver(om_model *m, int mode, double tolerance, int iterations);
 
 om_data *om_data_create(const om_model *m);
 void om_data_destroy(om_data *d);

@@ -19,7 +19,8 @@ TASK_BASE, TASK_SPEED, TASK_GETUP, TASK_REACH = 0, 1, 2, 3
 INIT_DEFAULT, INIT_FALL, INIT_EXTERNAL = 0, 1, 2
 
 # field ids (oracle.h)
-M_MASS, M_IPOS, M_IQUAT, M_INERTIA, M_GPOS, M_GQUAT, M_GSIZE, M_BODY_INVW, M_DOF_INVW, M_RANGE = range(10)
+M_MASS, M_IPOS, M_IQUAT, M_INERTIA, M_GPOS, M_GQUAT, M_GSIZE, M_BODY_INVW, M_DOF_INVW, M_RANGE, M_MEANINERTIA = range(11)
+SOLVER_CONVERGED, SOLVER_MUJOCO = 0, 1
 (D_QPOS, D_QVEL, D_QACC, D_WARM, D_CTRL, D_M, D_BIAS, D_XPOS, D_XQUAT, D_LINVEL, D_ANGVEL, D_TOUCH, D_NCON,
  D_CON_POS, D_CON_DIST, D_CON_BODY, D_QACC_SMOOTH, D_NEFC, D_EFC_FORCE, D_SOLVER_ITER, D_ENERGY, D_XIPOS,
  D_QFRC_CONSTRAINT, D_CON_FRAME, D_CON_BODY1, D_NSELF) = range(26)
@@ -93,6 +94,8 @@ def lib():
         for f in ("om_kinematics", "om_forward", "om_step"):
             getattr(L, f).argtypes = [C.c_void_p, C.c_void_p]
         L.om_model_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.om_model_set_solver.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int]
+        L.om_model_set_solver.restype = None
         L.om_get.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.om_set.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.om_spd_torque.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -167,9 +170,11 @@ def read_mjcf_primitives(xml):
 
 class OracleModel:
     def __init__(self, xml, kp, kd, torque_lim, act_scale, act_offset, legal_bodies=(), timestep=1.0 / 450, self_collision=False,
-                 max_self_contacts=0):
+                 max_self_contacts=0, solver="mujoco", tolerance=0.0, iterations=0):
         """self_collision: body-body contacts per the MJCF's contype / conaffinity / excludes (False = floor only);
-        max_self_contacts: keep only the deepest N of them (0 = all)."""
+        max_self_contacts: keep only the deepest N of them (0 = all);
+        solver: "mujoco" = mj_step's own termination of the Newton iteration (opt.tolerance 1e-8 scaled by meaninertia * nv,
+        opt.iterations 100; `tolerance` / `iterations` override), "converged" = to the rounding level (parity triage)."""
         P = read_mjcf_primitives(xml)
         self.prim = P
         self.nbody = len(P["names"])
@@ -203,6 +208,7 @@ class OracleModel:
         self.h = lib().om_model_create(C.byref(d))
         if not self.h:
             raise RuntimeError("om_model_create failed")
+        lib().om_model_set_solver(self.h, {"mujoco": SOLVER_MUJOCO, "converged": SOLVER_CONVERGED}[solver], float(tolerance), int(iterations))
 
     def get(self, field):
         out = np.zeros(16 * 64 + 8 * 200, dtype=np.float64)

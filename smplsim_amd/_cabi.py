@@ -30,6 +30,7 @@ class ModelDesc(C.Structure):
         ("timestep", C.c_double), ("gravity", C.c_double), ("solref", C.c_double * 2), ("solimp", C.c_double * 5),
         ("margin", C.c_double), ("friction", C.c_double), ("impratio", C.c_double),
         ("geom_contype", C.c_void_p), ("geom_conaffinity", C.c_void_p), ("nexclude", C.c_int32), ("exclude", C.c_void_p),
+        ("meaninertia", C.c_double),
     ]
 
 
@@ -43,6 +44,7 @@ class EnvCfg(C.Structure):
         ("tar_height_min", C.c_float), ("tar_height_max", C.c_float), ("height_change_min", C.c_int32),
         ("height_change_max", C.c_int32), ("recovery_steps", C.c_int32), ("newton_iters", C.c_int32),
         ("tar_dist_max", C.c_float), ("reach_body", C.c_int32), ("self_collision", C.c_int32),
+        ("solver_tolerance", C.c_float),
     ]
 
 
@@ -184,14 +186,16 @@ def make_model_desc(mc, kp, kd, torque_lim, act_scale, act_offset, legal_bodies=
     ex = [(mc.body_names.index(a), mc.body_names.index(b)) for a, b in mc.excludes]
     d.nexclude = len(ex)
     d.exclude = arr(np.array(ex, dtype=np.int32).reshape(-1, 2), np.int32) if ex else None
+    d.meaninertia = mc.meaninertia
     return d, keep
 
 
 def make_env_cfg(task=TASK_BASE, state_init=INIT_DEFAULT, self_obs_v=1, control_mode=CTRL_UHC_PD,
                  episode_length=300, control_freq_inv=15, root_height_obs=True, power_scale=1.0,
                  tar_speed=(0.0, 5.0), speed_change=(100, 200), tar_height=(0.5, 1.2), height_change=(100, 200),
-                 recovery_steps=60, newton_iters=8, tar_dist_max=1.0, reach_body=0, self_collision=False):
+                 recovery_steps=60, newton_iters=0, tar_dist_max=1.0, reach_body=0, self_collision=False, solver_tolerance=0.0):
+    """newton_iters / solver_tolerance: mjOption.iterations / tolerance; 0 = MuJoCo's defaults (100, 1e-8)."""
     return EnvCfg(task, state_init, self_obs_v, control_mode, episode_length, control_freq_inv, int(root_height_obs),
                   power_scale, tar_speed[0], tar_speed[1], speed_change[0], speed_change[1], tar_height[0],
                   tar_height[1], height_change[0], height_change[1], recovery_steps, newton_iters, tar_dist_max, reach_body,
-                  int(bool(self_collision)))
+                  int(bool(self_collision)), solver_tolerance)

@@ -130,8 +130,8 @@ class SMPLSimVecEnv:
     def __init__(self, num_envs, model=None, device=0, task="HumanoidEnv", state_init="Default", self_obs_v=1,
                  control_mode="uhc_pd", episode_length=300, control_freq_inv=15, root_height_obs=True,
                  power_scale=1.0, tar_speed=(0.0, 5.0), speed_change=(100, 200), tar_height=(0.5, 1.2),
-                 height_change=(100, 200), recovery_steps=60, tar_dist_max=1.0, reach_body="R_Hand", newton_iters=8, fused_autoreset=True,
-                 autoreset=True, seed=0, lpt_order=True, shape_id=None, self_collision=False,
+                 height_change=(100, 200), recovery_steps=60, tar_dist_max=1.0, reach_body="R_Hand", newton_iters=0, fused_autoreset=True,
+                 autoreset=True, seed=0, lpt_order=True, shape_id=None, self_collision=False, solver_tolerance=0.0,
                  **model_kw):
         self.device = _shard_device(device if model is None else model.device)   # raises before any table is built without a GPU
         self.model = model if model is not None else ShardModel(device=device, control_mode=control_mode, **model_kw)
@@ -151,7 +151,7 @@ class SMPLSimVecEnv:
             control_freq_inv=control_freq_inv, root_height_obs=root_height_obs, power_scale=power_scale,
             tar_speed=tar_speed, speed_change=speed_change, tar_height=tar_height, height_change=height_change,
             recovery_steps=recovery_steps, newton_iters=newton_iters, tar_dist_max=tar_dist_max,
-            reach_body=self._body_index(mc, reach_body), self_collision=self_collision)
+            reach_body=self._body_index(mc, reach_body), self_collision=self_collision, solver_tolerance=solver_tolerance)
         self.self_collision = bool(self_collision)
         if not self.self_collision:
             _warn_floor_only()

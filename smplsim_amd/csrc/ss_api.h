@@ -169,7 +169,11 @@ struct ss_api {
     ss_batch *b = new (std::nothrow) ss_batch();
     if (!b) return fail(SS_ERR_NOMEM, "out of host memory");
     b->m = m; b->cfg = *cfg; b->st = *st;
-    if (b->cfg.newton_iters <= 0) b->cfg.newton_iters = 8;
+    // mjOption.iterations / tolerance (MuJoCo's defaults: the reference MJCF sets neither).  The kernel gets the tolerance in
+    // cost units: tolerance / scale, scale = 1 / (meaninertia * max(1, nv)) as in mj_solPrimal (shape 0's meaninertia for
+    // a model with several body shapes)
+    if (b->cfg.newton_iters <= 0) b->cfg.newton_iters = 100;
+    b->cfg.solver_tolerance = (float)((cfg->solver_tolerance > 0.f ? (double)cfg->solver_tolerance : 1e-8) * m->hm.meaninertia * (h.nv > 1 ? h.nv : 1));
     b->obs_size = ss::obs_size(h, *cfg);
     size_t shared_b = (size_t)((h.shared_words + 3) & ~3) * 4;
     const size_t env_b = (size_t)(cfg->self_collision ? m->hm.sc.env_floats : h.env_floats) * sizeof(ss::real);
@@ -199,8 +203,7 @@ struct ss_api {
     k.illegal_mask = m->hm.illegal_mask;
     k.sc = m->hm.sc; k.pairs = m->d_pairs; k.geomc = m->d_geomc; k.dbg_self = ss_batch::R(b->dbg_self);
     k.mode = mode; k.nsub = b->cfg.control_freq_inv; k.obs_size = b->obs_size;
-    k.work_counter = b->d_counter + b->parity; k.work_counter_next = b->d_counter + (b->parity ^ 1);
-    b->parity ^= 1;
+    k.work_counter = b->d_counter + b->parity; k.work_counter_next = b->d_counter + (b->parity ^ 1);   // run() flips the parity
     k.obs_stride = b->obs_size;
     k.prof = b->d_prof;
     k.order = b->order;
@@ -211,6 +214,9 @@ struct ss_api {
     if (!BE::set_device(b->m->device)) return fail(SS_ERR_HIP, "cannot select device");
     const char *err = BE::launch(k, b->st.num_envs, b->envs_per_wg, b->lds_bytes, stream, b->fixed_envs_per_wg, b->max_wgs);
     if (err) return fail(SS_ERR_HIP, err);
+    // only a launch that ran has zeroed the other work counter: a failed one leaves the pair as it was (the counter it would
+    // have used is still zero), so the next launch starts from a clean counter either way
+    b->parity ^= 1;
     return SS_OK;
   }
   static int reset(ss_batch *b, const uint8_t *mask, const float *fall_actions, const float *task_rand, float *obs, void *stream) {

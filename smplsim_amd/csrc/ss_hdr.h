@@ -12,16 +12,14 @@ namespace ss { typedef double real; }
 #define SS_M(fn) fn
 #define SS_LS_TOL_EFF 1e-13                  /* "exact" line search */
 #define SS_ROUND_REL 2.2e-15                 /* rounding level of the line-search terms (10 eps) */
-#define SS_MOVE_REL 4e-16
-#define SS_MOVE_ABS 1e-24
+#define SS_DG_NOISE 1.8e-15                  /* Newton decrement vs the sum of |its terms|: 16 rounding units */
 #define SS_LS_MAXIT 60
 #else
 namespace ss { typedef float real; }
 #define SS_M(fn) fn##f
 #define SS_LS_TOL_EFF SS_LS_TOL
 #define SS_ROUND_REL 2e-6f
-#define SS_MOVE_REL 4e-7f
-#define SS_MOVE_ABS 1e-12f
+#define SS_DG_NOISE 1e-6f
 #define SS_LS_MAXIT 16
 #endif
 

@@ -1728,12 +1728,25 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
     SS_FTICK(PF_P_GRAD);
   }
 
-  // exact line search along delta, step, active-set change detection; returns true when converged
+  // exact line search along delta, step, termination test; returns true when the Newton iteration of this mj_step ends.
+  // Termination follows mj_solPrimal (MuJoCo engine_solver.c; call site: reference humanoid_env.py:450):
+  //     improvement * scale < tolerance  ||  gradient * scale < tolerance ,   scale = 1 / (meaninertia * max(1, nv))
+  // with tol = tolerance / scale handed over in cfg.solver_tolerance (ss_api.h):
+  //   improvement   the cost decrease of this iteration, evaluated along the search line from the same per-row terms as the
+  //                 line search (cost(0) - cost(al) = -(c1 al + c2 al^2 / 2 + sum_rows D/2 [(x1)_-^2 - (x0)_-^2]), differences of
+  //                 squares factored): relative accuracy of the rounding unit, where the difference of two evaluated costs
+  //                 (what MuJoCo forms in float64) would be all rounding error in float32;
+  //   gradient      never formed in joint space here (the body part of the gradient enters the sweeps as bias forces).  The
+  //                 test is replaced by its two observable consequences: a full Newton step inside one quadratic piece of the
+  //                 cost (al = 1 accepted, active set unchanged) lands on that piece's minimiser, gradient = 0 up to rounding;
+  //                 and a Newton decrement -delta.grad below the rounding error of its own evaluation (SS_DG_NOISE times the
+  //                 sum of the absolute values of its terms) means the gradient is below the rounding error of the forces it is
+  //                 the sum of — the iterate is then left as it is (the direction is rounding noise).
   SS_DEV bool newton_finish() {
     fresh();
     typename HT::type h = HT::view(k->h);
     eval_rows(An + 8, 8, delta, true);                       // aba_solve left the body accelerations of delta in An
-    real dg_ = 0.f, s_a = 0.f, s_b = 0.f;
+    real dg_ = 0.f, dgabs = 0.f, s_a = 0.f, s_b = 0.f;
 #pragma unroll
     for (int p = 0; p < DOFP; p++) {                          // delta . gradient, joint-space part (same terms as newton_prepare)
       int i = p * 64 + lane;
@@ -1741,13 +1754,14 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
         real s_ = C[i] + dc(i, 0) * a[i] - tau[i];
         const Limit &l = lim[p];
         if (l.sign != 0.f && l.jar < 0.f) s_ += l.sign * l.D * l.jar;
-        dg_ += delta[i] * s_;
+        const real t_ = delta[i] * s_;
+        dg_ += t_; dgabs += SS_M(fabs)(t_);
       }
     }
     if (lane < h.nb) {                                        // body part: (J_b delta) . Pb_b
       const real *ab_ = An + 8 * (lane + 1), *pb_ = Pb + 6 * lane;
 #pragma unroll
-      for (int c = 0; c < 6; c++) dg_ += ab_[c] * pb_[c];
+      for (int c = 0; c < 6; c++) { const real t_ = ab_[c] * pb_[c]; dg_ += t_; dgabs += SS_M(fabs)(t_); }
     }
 #pragma unroll
     for (int p = 0; p < SLOTP; p++) {
@@ -1769,10 +1783,18 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
         const real *rc = this->rec + kSelfRec * lane;
         for (int i = 0; i < 4; i++) if (rc[RC_JAR + i] < 0) { ss_a += rc[RC_D] * rc[RC_JAR + i] * rc[RC_JD + i]; ss_b += rc[RC_D] * rc[RC_JD + i] * rc[RC_JD + i]; }
       }
-      if (this->nself > 0) { ss_a = w->sum(ss_a); ss_b = w->sum(ss_b); }
+      if (this->nself > 0) { dgabs += SS_M(fabs)(ss_a); ss_a = w->sum(ss_a); ss_b = w->sum(ss_b); }
     }
-    dg_ = w->sum(dg_); s_a = w->sum(s_a); s_b = w->sum(s_b);
+    dg_ = w->sum(dg_); dgabs = w->sum(dgabs); s_a = w->sum(s_a); s_b = w->sum(s_b);
     dg_ += ss_a; s_a += ss_a; s_b += ss_b;
+    // the Newton decrement is rounding noise of its own terms (or the direction is not a descent direction, or NaN): done,
+    // the iterate stays
+    if (!(-dg_ > SS_DG_NOISE * dgabs)) {
+#if defined(SS_TRACE_NEWTON) && !defined(__HIPCC__)
+      if (lane == 0) fprintf(stderr, "NT env %d it %d dg %.4e dgabs %.4e : decrement at rounding level\n", env, iters, (double)dg_, (double)dgabs);
+#endif
+      return true;
+    }
     const real c1 = dg_ - s_a, c2 = -dg_ - s_b;            // phi'(al) = c1 + al c2 + sum_active(al) D (jar + al jd) jd
     real al = 1.f, d1, d2;
     ls_eval(1.f, c1, c2, d1, d2);
@@ -1795,16 +1817,12 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
         ls_eval(al, c1, c2, d1, d2);
       }
     }
-    int changed = 0, moving = 0;
+    int changed = 0;
+    real dcost = 0.f;                                        // sum over this lane's rows of D [(x1)_-^2 - (x0)_-^2], x1 = x0 + al jd
 #pragma unroll
     for (int p = 0; p < DOFP; p++) {
       int i = p * 64 + lane;
-      if (i < h.nv) {
-        const real st_ = al * delta[i], an = a[i] + st_;
-        a[i] = an;
-        // still moving: the step is above float32 resolution of the iterate (false for NaN/inf too)
-        moving |= SS_M(fabs)(st_) > SS_MOVE_REL * SS_M(fabs)(an) + SS_MOVE_ABS && SS_M(fabs)(an) <= real(1e10);
-      }
+      if (i < h.nv) a[i] += al * delta[i];
     }
     for (int idx = lane; idx < 6 * h.nb; idx += 64) { const int b = idx / 6; Ab[idx] += al * An[8 + 2 * b + idx]; }
 #pragma unroll
@@ -1813,8 +1831,9 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       if (!c.active) continue;
 #pragma unroll
       for (int r_ = 0; r_ < 4; r_++) {
-        real nj = c.jar[r_] + al * c.jd[r_];
-        changed |= (nj < 0.f) != (c.jar[r_] < 0.f);
+        const real x0 = c.jar[r_], st_ = al * c.jd[r_], nj = x0 + st_;
+        changed |= (nj < 0.f) != (x0 < 0.f);
+        dcost += c.D * row_dcost(x0, st_, nj);
         c.jar[r_] = nj;
       }
     }
@@ -1822,28 +1841,35 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
     for (int p = 0; p < DOFP; p++) {
       Limit &l = lim[p];
       if (l.sign == 0.f) continue;
-      real nj = l.jar + al * l.jd;
-      changed |= (nj < 0.f) != (l.jar < 0.f);
+      const real x0 = l.jar, st_ = al * l.jd, nj = x0 + st_;
+      changed |= (nj < 0.f) != (x0 < 0.f);
+      dcost += l.D * row_dcost(x0, st_, nj);
       l.jar = nj;
     }
     if constexpr (SELFCOL) {
       if (lane < this->nself) {
         real *rc = this->rec + kSelfRec * lane;
         for (int i = 0; i < 4; i++) {
-          const real nj = rc[RC_JAR + i] + al * rc[RC_JD + i];
-          changed |= (nj < 0) != (rc[RC_JAR + i] < 0);
+          const real x0 = rc[RC_JAR + i], st_ = al * rc[RC_JD + i], nj = x0 + st_;
+          changed |= (nj < 0) != (x0 < 0);
+          dcost += rc[RC_D] * row_dcost(x0, st_, nj);
           rc[RC_JAR + i] = nj;
         }
       }
     }
+    dcost = w->sum(dcost);
+    const real improvement = -(al * (c1 + 0.5f * c2 * al) + 0.5f * dcost);
     w->sync();
-    // converged: full Newton step with an unchanged active set, or no representable progress any more
+    const bool piece_min = !w->any(changed) && exact;        // full Newton step within one quadratic piece: its minimiser
 #if defined(SS_TRACE_NEWTON) && !defined(__HIPCC__)
-    { const bool ch = w->any(changed), mv = w->any(moving);
-      if (lane == 0) fprintf(stderr, "NT env %d it %d dg %.4e sa %.4e sb %.4e al %.4f exact %d changed %d moving %d\n", env, iters, dg_, s_a, s_b, al, (int)exact, (int)ch, (int)mv);
-      return (!ch && exact) || !mv; }
+    if (lane == 0) fprintf(stderr, "NT env %d it %d dg %.4e dgabs %.4e sa %.4e sb %.4e al %.6f exact %d piece_min %d improvement %.4e tol %.3e\n", env, iters, (double)dg_, (double)dgabs, (double)s_a, (double)s_b, (double)al, (int)exact, (int)piece_min, (double)improvement, (double)k->cfg.solver_tolerance);
 #endif
-    return (!w->any(changed) && exact) || !w->any(moving);
+    return piece_min || !(improvement >= (real)k->cfg.solver_tolerance);
+  }
+  // one row's term of the cost change along the line, times 2 / D:  (x1)_-^2 - (x0)_-^2  with x1 = x0 + st
+  SS_DEV static real row_dcost(real x0, real st, real x1) {
+    const bool a0 = x0 < 0.f, a1 = x1 < 0.f;
+    return a0 ? (a1 ? st * (x0 + x1) : -x0 * x0) : (a1 ? x1 * x1 : real(0));
   }
 
   // ------------------------------------------------------------------ controllers (torque for the NEXT mj_step)
@@ -2066,7 +2092,7 @@ SS_DEV bool run_env(W *w, const KArgs *k, const uint32_t *T, real *L, int env, i
   real *obs = obs_base ? obs_base + (size_t)env * ostride : nullptr;
   // step pass of a fused launch: the post-step observation also goes to obs2 (envs that do not reset keep it)
   real *obs_also = (!fused_pass && k->fused_reset && k->obs2) ? k->obs2 + (size_t)env * ostride : nullptr;
-  const int maxit = cf.newton_iters > 0 ? cf.newton_iters : 8;
+  const int maxit = cf.newton_iters > 0 ? cf.newton_iters : 100;   // mjOption.iterations
 
   int cur_t = st.cur_t[env];
   // task scalars: speed/getup [target, change_steps, recovery, -] ; reach [tx, ty, tz, change_steps]

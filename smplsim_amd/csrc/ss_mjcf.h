@@ -320,6 +320,8 @@ inline bool compile(const char *xml, size_t len, const ss_mjcf_options *opt, Com
     }
   }
   for (int i = 0; i < nv; i++) { M[(size_t)i * nv + i] += c.arm[i]; for (int j = i + 1; j < nv; j++) M[(size_t)i * nv + j] = M[(size_t)j * nv + i]; }
+  double trace_M = 0;                                          // mjModel.stat.meaninertia
+  for (int i = 0; i < nv; i++) trace_M += M[(size_t)i * nv + i];
   std::vector<double> L = M, Minv((size_t)nv * nv, 0.0);       // Cholesky, then the inverse column by column
   for (int j = 0; j < nv; j++) {
     double s = L[(size_t)j * nv + j];
@@ -385,6 +387,7 @@ inline bool compile(const char *xml, size_t len, const ss_mjcf_options *opt, Com
   for (int k = 0; k < 5; k++) d.solimp[k] = si[k];
   d.margin = c.margin; d.friction = c.friction; d.impratio = 1.0;
   d.geom_contype = c.contype.data(); d.geom_conaffinity = c.conaff.data(); d.nexclude = (int)c.excl.size() / 2; d.exclude = c.excl.empty() ? nullptr : c.excl.data();
+  d.meaninertia = trace_M / (nv > 1 ? nv : 1);
   return true;
 }
 

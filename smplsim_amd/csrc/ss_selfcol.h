@@ -8,9 +8,11 @@
 //   capsule-box      the segment point closest to the box — exact minimiser of the convex piecewise-quadratic squared
 //                    distance, found from the zero of its piecewise-linear slope — a sphere-box test there and one at the
 //                    far end of the segment (at most 2 contacts)
-//   box-box          separating-axis test over the 15 axes; face axis: the vertices of either box within the margin of the
-//                    other's surface whose nearest surface point is on the selected face (at most 8); edge-edge axis: one
-//                    contact at the closest points of the supporting edges
+//   box-box          separating-axis test over the 15 axes; face axis: the face of the other box that faces the selected
+//                    (reference) face is clipped against the reference face's side planes (Sutherland-Hodgman, the face
+//                    manifold of ODE's dBoxBox that mjc_BoxBox descends from) and the clipped polygon's vertices within the
+//                    margin of the reference face are the contacts (at most 8); edge-edge axis: one contact at the closest
+//                    points of the supporting edges
 // One lane runs one pair; plain scalar code in the kernel's scalar type.  Normals point from the pair's first geom to its second.
 #pragma once
 #include "ss_hdr.h"
@@ -168,15 +170,16 @@ SS_DEV int box_box(const real *pa, const real *ma, const real *sa, const real *p
   const real t[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
   for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { R[i][j] = dot3(A[i], B[j]); AR[i][j] = SS_M(fabs)(R[i][j]); }
   real best = real(-1e30), bn[3] = {0, 0, 0};
+  int bcode = 0;                                             // reference face: axis i of A (0..2) or axis j of B (3..5)
   for (int i = 0; i < 3; i++) {
     const real tl = dot3(t, A[i]);
     const real sep = SS_M(fabs)(tl) - (sa[i] + sb[0] * AR[i][0] + sb[1] * AR[i][1] + sb[2] * AR[i][2]);
-    if (sep > best) { best = sep; const real sg = tl >= 0 ? real(1) : real(-1); for (int k = 0; k < 3; k++) bn[k] = sg * A[i][k]; }
+    if (sep > best) { best = sep; bcode = i; const real sg = tl >= 0 ? real(1) : real(-1); for (int k = 0; k < 3; k++) bn[k] = sg * A[i][k]; }
   }
   for (int j = 0; j < 3; j++) {
     const real tl = dot3(t, B[j]);
     const real sep = SS_M(fabs)(tl) - (sa[0] * AR[0][j] + sa[1] * AR[1][j] + sa[2] * AR[2][j] + sb[j]);
-    if (sep > best) { best = sep; const real sg = tl >= 0 ? real(1) : real(-1); for (int k = 0; k < 3; k++) bn[k] = sg * B[j][k]; }
+    if (sep > best) { best = sep; bcode = 3 + j; const real sg = tl >= 0 ? real(1) : real(-1); for (int k = 0; k < 3; k++) bn[k] = sg * B[j][k]; }
   }
   real ebest = real(-1e30), en[3] = {0, 0, 0}; int ecode = -1;
   for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
@@ -207,28 +210,66 @@ SS_DEV int box_box(const real *pa, const real *ma, const real *sa, const real *p
     o[0].dist = ebest;
     return 1;
   }
-  int n = 0;
-  for (int which = 0; which < 2 && n < 8; which++) {
-    const real *pv = which ? pa : pb, *sv = which ? sa : sb;
-    const real *po = which ? pb : pa, *mo = which ? mb : ma, *so = which ? sb : sa;
-    for (int c = 0; c < 8 && n < 8; c++) {
-      real x[3] = {pv[0], pv[1], pv[2]};
-      for (int k = 0; k < 3; k++) {
-        const real s_ = ((c >> k) & 1 ? real(1) : real(-1)) * sv[k];
-        const real *ax = which ? A[k] : B[k];
-        x[0] += ax[0] * s_; x[1] += ax[1] * s_; x[2] += ax[2] * s_;
+  // ---- face contact.  Reference face = the face of the box that owns the best axis, on the side of the other box; incident
+  // face = the face of the other box most anti-parallel to it.  The incident rectangle is clipped against the four side planes of
+  // the reference face; every vertex of the clipped polygon within the margin of the reference plane is a contact, placed half
+  // way between the vertex and the plane, normal = the axis (first geom -> second geom).  A vertex within clip_tol of a side plane
+  // counts as inside (clip_tol far above float32 rounding: the float64 twin classifies alike), coincident output points are merged.
+  const bool refA = bcode < 3;
+  const int ir = refA ? bcode : bcode - 3, i1 = (ir + 1) % 3, i2 = (ir + 2) % 3;
+  const real(*Rf)[3] = refA ? A : B;
+  const real(*Xi)[3] = refA ? B : A;
+  const real *pr = refA ? pa : pb, *sr = refA ? sa : sb, *pi_ = refA ? pb : pa, *si = refA ? sb : sa;
+  const real nout[3] = {refA ? bn[0] : -bn[0], refA ? bn[1] : -bn[1], refA ? bn[2] : -bn[2]};   // outward normal of the reference face
+  int j = 0; real bd = real(-1);
+  for (int k = 0; k < 3; k++) { const real d_ = SS_M(fabs)(dot3(nout, Xi[k])); if (d_ > bd) { bd = d_; j = k; } }
+  const real sgn = dot3(nout, Xi[j]) > 0 ? real(-1) : real(1);
+  const int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+  real poly[8][3], tmp[8][3];
+  int np = 4;
+  for (int v = 0; v < 4; v++) {
+    const real su = (v == 0 || v == 3) ? si[j1] : -si[j1], sv = v < 2 ? si[j2] : -si[j2];
+    for (int k = 0; k < 3; k++) poly[v][k] = pi_[k] + sgn * si[j] * Xi[j][k] + su * Xi[j1][k] + sv * Xi[j2][k];
+  }
+  const real clip_tol = real(1e-5) * (sr[i1] + sr[i2]);
+  for (int e = 0; e < 4 && np > 0; e++) {
+    const int tt = e < 2 ? i1 : i2;
+    const real sg = (e & 1) ? real(-1) : real(1);
+    real fprev;
+    { const real *x = poly[np - 1]; fprev = sg * ((x[0] - pr[0]) * Rf[tt][0] + (x[1] - pr[1]) * Rf[tt][1] + (x[2] - pr[2]) * Rf[tt][2]) - sr[tt]; }
+    int nq = 0;
+    for (int v = 0; v < np; v++) {
+      const real *x = poly[v], *xp = poly[v == 0 ? np - 1 : v - 1];
+      const real f = sg * ((x[0] - pr[0]) * Rf[tt][0] + (x[1] - pr[1]) * Rf[tt][1] + (x[2] - pr[2]) * Rf[tt][2]) - sr[tt];
+      const bool in = f <= clip_tol, inp = fprev <= clip_tol;
+      if (in != inp && nq < 8) {                              // the edge crosses the plane
+        const real u = fprev / (fprev - f);
+        for (int k = 0; k < 3; k++) tmp[nq][k] = xp[k] + u * (x[k] - xp[k]);
+        nq++;
       }
-      NCon tcon;
-      sphere_box(x, real(0), po, mo, so, real(1e30), nullptr, &tcon);  // zero-radius sphere: signed distance and nearest surface point
-      if (tcon.dist > margin) continue;
-      // -tcon.n: outward normal of the surface box at the nearest point; towards the vertex box it is +bn (surface = A) or -bn
-      const real al = -(tcon.n[0] * bn[0] + tcon.n[1] * bn[1] + tcon.n[2] * bn[2]) * (which ? real(-1) : real(1));
-      if (al < real(0.70710678)) continue;
-      // nearest surface point = tcon.pos + tcon.n * dist / 2 ; contact at the middle between it and the vertex
-      for (int k = 0; k < 3; k++) { o[n].pos[k] = real(0.5) * (x[k] + (tcon.pos[k] + tcon.n[k] * real(0.5) * tcon.dist)); o[n].n[k] = bn[k]; }
-      o[n].dist = tcon.dist;
-      n++;
+      if (in && nq < 8) { for (int k = 0; k < 3; k++) tmp[nq][k] = x[k]; nq++; }
+      fprev = f;
     }
+    np = nq;
+    for (int v = 0; v < np; v++) for (int k = 0; k < 3; k++) poly[v][k] = tmp[v][k];
+  }
+  int n = 0;
+  const real merge2 = clip_tol * clip_tol;
+  for (int v = 0; v < np && n < 8; v++) {
+    const real *x = poly[v];
+    const real dist = (x[0] - pr[0]) * nout[0] + (x[1] - pr[1]) * nout[1] + (x[2] - pr[2]) * nout[2] - sr[ir];
+    if (dist > margin) continue;
+    bool dup = false;
+    for (int q_ = 0; q_ < n; q_++) {                          // tmp is free again: it keeps the vertices already emitted
+      const real ex = tmp[q_][0] - x[0], ey = tmp[q_][1] - x[1], ez = tmp[q_][2] - x[2];
+      const real en_ = ex * nout[0] + ey * nout[1] + ez * nout[2];
+      const real tx = ex - en_ * nout[0], ty = ey - en_ * nout[1], tz = ez - en_ * nout[2];
+      dup |= tx * tx + ty * ty + tz * tz <= merge2;
+    }
+    if (dup) continue;
+    for (int k = 0; k < 3; k++) { tmp[n][k] = x[k]; o[n].pos[k] = x[k] - real(0.5) * dist * nout[k]; o[n].n[k] = bn[k]; }
+    o[n].dist = dist;
+    n++;
   }
   return n;
 }

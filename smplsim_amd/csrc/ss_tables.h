@@ -34,6 +34,7 @@ struct HostModel {
                                   // b1 -> b2), and the float bits of the pair's bounding-sphere reach r1 + r2 + margin (broad phase)
   std::vector<real> geomc;        // [nb][kGeomC] geoms in their body frames (pair functions of the SELFCOL kernels)
   HdrSC sc{};
+  double meaninertia = 0;         // mjModel.stat.meaninertia (scale of the solver's termination test)
   std::string error;
 };
 
@@ -57,6 +58,8 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   for (int b = 1; b < nb; b++)
     if (d.body_parent[b] < 0 || d.body_parent[b] >= b) { out.error = "parents must precede children"; return false; }
   h.nb = nb; h.nn = nb + 1; h.nv = 6 + 3 * (nb - 1); h.nq = h.nv + 1; h.nu = d.nu;
+  if (!(d.meaninertia > 0.0)) { out.error = "meaninertia must be positive (mean diagonal of the inertia matrix at qpos0)"; return false; }
+  out.meaninertia = d.meaninertia;
   const int nn = h.nn, nv = h.nv;
 
   // ---- node tree

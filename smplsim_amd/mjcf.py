@@ -86,6 +86,7 @@ class ModelConst:
     geom_margin: float = 0.001
     friction: float = 1.0
     impratio: float = 1.0
+    meaninertia: float = 0.0       # mjModel.stat.meaninertia: mean diagonal of qM at qpos0 (scales the solver tolerance)
 
     @property
     def total_mass(self) -> float:
@@ -351,3 +352,4 @@ def _set_invweight0(mc: ModelConst):
     d[0:3] = d[0:3].mean()
     d[3:6] = d[3:6].mean()
     mc.dof_invweight0[:] = d
+    mc.meaninertia = float(np.trace(M) / max(1, mc.nv))

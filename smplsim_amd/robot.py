@@ -281,6 +281,7 @@ def compile_tables(tables):
         d = np.diag(Minv[s]).copy()
         d[0:3] = d[0:3].mean(); d[3:6] = d[3:6].mean()
         mc.dof_invweight0[:] = d
+        mc.meaninertia = float(np.trace(M[s]) / max(1, nv))
     return mcs
 
 

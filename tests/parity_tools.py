@@ -5,16 +5,20 @@ One *sample* = one control step (15 mj_steps) of one env: the pre-step state the
 the action, and the float32 post-step state some implementation of the kernel produced (the GPU, or the wavefront
 emulator).  Every sample is replayed from exactly that pre-step state by
 
-  oracle        oracle/oracle.c, float64, different formulation, Newton run to its own tolerance
-  f64           the kernel source instantiated in float64 on the emulator (tests/wave_emu, -DSS_F64), Newton to convergence
-  f64 cap       the same with the product's Newton cap (8 iterations per mj_step)
-  f64 perturbed f64 again from inputs perturbed by half a float32 ulp (relative 2^-24, random signs): the response of the
+  oracle        oracle/oracle.c, float64, different formulation, at MuJoCo's solver settings (mj_solPrimal's termination:
+                tolerance 1e-8 scaled by meaninertia * nv, 100 iterations) = what mj_step computes
+  oracle conv   the same with the Newton iteration run to the rounding level
+  f64           the kernel source instantiated in float64 on the emulator (tests/wave_emu, -DSS_F64) at the SHIPPED solver
+                settings (ss_env_cfg defaults: MuJoCo's tolerance and iteration count, the kernel's own form of the test)
+  f64 conv      the same with the tolerance test off (1e-30): Newton to convergence
+  f64 perturbed f64 conv from inputs perturbed by half a float32 ulp (relative 2^-24, random signs): the response of the
                 one-control-step map to float32-sized input noise = the sample's conditioning
 
 which separates the three things a float32-vs-oracle difference can be made of:
-  formulation   f64 vs oracle        (must be at the float64 rounding level times the conditioning)
-  precision     float32 vs f64 cap   (must be at the float32 rounding level times the conditioning)
-  Newton cap    f64 cap vs f64       (reported; a property of the product's iteration cap, not of the arithmetic)
+  formulation   f64 conv vs oracle conv   (must be at the float64 rounding level times the conditioning)
+  solver rule   f64 vs oracle             (the kernel's termination test against MuJoCo's, same arithmetic: must be within the
+                                           stated per-step tolerance)
+  precision     float32 vs f64            (must be at the float32 rounding level times the conditioning)
 Errors are relative to the sample's velocity scale max(1, |qvel|_max) like in test_gpu_parity.py.
 """
 import concurrent.futures as cf
@@ -27,6 +31,7 @@ from oracle import oracle as O
 from wave_emu import emu
 
 EPS32, EPS64 = 2.0 ** -24, 2.0 ** -53
+MAX_SELF = 8                              # SS_MAX_SELF_CONTACTS: the oracle keeps the same number of body-body contacts
 FIELDS = ("qpos", "qvel", "qpos_prev", "qvel_prev", "qacc_warm")
 
 
@@ -40,7 +45,10 @@ def _chunks(n, k):
     return [(b[i], b[i + 1]) for i in range(k) if b[i + 1] > b[i]]
 
 
-def emu_step(pre, actions, f64, newton_iters, humanoid="smpl_humanoid", task="HumanoidEnv", task_state=None, cur_t=None,
+TOL_STEP = np.array([1e-5, 2e-3])        # stated per-control-step tolerance (qpos, qvel relative to the velocity scale)
+
+
+def emu_step(pre, actions, f64, newton_iters=0, humanoid="smpl_humanoid", task="HumanoidEnv", task_state=None, cur_t=None,
              task_rand=None, **cfg):
     """One control step of len(actions) independent envs on the emulator from the given pre-step arrays (threaded).
     Returns dict(qpos, qvel, obs, reward, terminated, truncated, nwarn, iters)."""
@@ -70,9 +78,9 @@ def emu_step(pre, actions, f64, newton_iters, humanoid="smpl_humanoid", task="Hu
     return out
 
 
-def oracle_step(pre, actions, humanoid="smpl_humanoid", self_collision=False):
+def oracle_step(pre, actions, humanoid="smpl_humanoid", self_collision=False, solver="mujoco"):
     """The same control step by the float64 oracle (base task: state only), threaded."""
-    om = oracle_model(humanoid, self_collision=bool(self_collision), max_self_contacts=8 if self_collision else 0)
+    om = oracle_model(humanoid, self_collision=bool(self_collision), max_self_contacts=MAX_SELF if self_collision else 0, solver=solver)
     n = len(actions)
     q, v, nw = np.zeros((n, om.nq)), np.zeros((n, om.nv)), np.zeros(n, np.int32)
 
@@ -150,26 +158,32 @@ def rel_err(a, b):
     return np.stack([np.abs(a["qpos"] - b["qpos"]).max(axis=1) / scale, np.abs(a["qvel"] - b["qvel"]).max(axis=1) / scale], 1)
 
 
-def triage(pre, actions, post32, humanoid="smpl_humanoid", cap=8, n_perturb=8, task="HumanoidEnv", **cfg):
+def triage(pre, actions, post32, humanoid="smpl_humanoid", n_perturb=8, task="HumanoidEnv", **cfg):
     """Replays of every sample (module docstring).  Returns a dict of [S, 2] relative error arrays + bookkeeping."""
     kw = dict(humanoid=humanoid, task=task, task_state=pre.get("task"), cur_t=pre.get("cur_t"), task_rand=pre.get("task_rand"), **cfg)
-    orc = oracle_step(pre, actions, humanoid, self_collision=cfg.get("self_collision", False))
-    f64 = emu_step(pre, actions, True, 100, **kw)
-    f64cap = emu_step(pre, actions, True, cap, **kw)
+    sc = cfg.get("self_collision", False)
+    orc = oracle_step(pre, actions, humanoid, self_collision=sc)
+    orc_conv = oracle_step(pre, actions, humanoid, self_collision=sc, solver="converged")
+    f64 = emu_step(pre, actions, True, **kw)
+    f64conv = emu_step(pre, actions, True, solver_tolerance=1e-30, **kw)
     cond = np.zeros((len(actions), 2))
     for s in range(n_perturb):
-        p = emu_step(perturb(pre, 100 + s), actions, True, 100, **kw)
-        cond = np.maximum(cond, rel_err(p, f64) / EPS32)        # output error per unit of relative input error
+        p = emu_step(perturb(pre, 100 + s), actions, True, solver_tolerance=1e-30, **kw)
+        cond = np.maximum(cond, rel_err(p, f64conv) / EPS32)        # output error per unit of relative input error
     # a sample is "reset" when any implementation hit MuJoCo's bad-state autoreset inside the step (|x| > 1e10): the state
     # was replaced by qpos0 then, which is a discontinuity of the map — compared only through the reset flags
-    reset = (orc["nwarn"] > 0) | (f64["nwarn"] > 0) | (f64cap["nwarn"] > 0) | (post32["nwarn"] > 0)
+    reset = (orc["nwarn"] > 0) | (orc_conv["nwarn"] > 0) | (f64["nwarn"] > 0) | (f64conv["nwarn"] > 0) | (post32["nwarn"] > 0)
     extra = {}
     if "obs" in post32:                                          # observation / reward of the float32 kernel vs its float64 twin
-        vs = np.maximum(1.0, np.abs(f64cap["qvel"]).max(axis=1))
-        extra = dict(obs=np.abs(post32["obs"] - f64cap["obs"]).max(axis=1) / vs, reward=np.abs(post32["reward"] - f64cap["reward"]), vscale=vs)
-    return dict(**extra, formulation=rel_err(f64, orc), precision=rel_err(post32, f64cap), cap_gap=rel_err(f64cap, f64),
-                f32_vs_oracle=rel_err(post32, orc), cond=cond, reset=reset,
-                resets_agree=(orc["nwarn"] > 0) == (f64["nwarn"] > 0), iters=f64["iters"], iters_cap=f64cap["iters"], nself=f64["nself"])
+        vs = np.maximum(1.0, np.abs(f64["qvel"]).max(axis=1))
+        extra = dict(obs=np.abs(post32["obs"] - f64["obs"]).max(axis=1) / vs, reward=np.abs(post32["reward"] - f64["reward"]), vscale=vs)
+    return dict(**extra, formulation=rel_err(f64conv, orc_conv), precision=rel_err(post32, f64), solver_rule=rel_err(f64, orc),
+                oracle_rule=rel_err(orc, orc_conv), f32_vs_oracle=rel_err(post32, orc), cond=cond, reset=reset,
+                resets_agree=(orc["nwarn"] > 0) == (f64["nwarn"] > 0), iters=f64["iters"], iters32=post32.get("iters"), nself=f64["nself"])
+
+
+def within_tol(e, tol=TOL_STEP):
+    return (e <= tol).all(axis=1)
 
 
 def summarize(name, e, mask):

@@ -41,7 +41,11 @@ def _record(name, **vals):
         os.makedirs(out, exist_ok=True)
         path = os.path.join(out, "parity_measured.json")
         cur = json.load(open(path)) if os.path.exists(path) else {}
-        cur[name] = {k: (float(v) if np.ndim(v) == 0 else [float(x) for x in np.ravel(v)]) for k, v in vals.items()}
+        def conv(v):
+            if isinstance(v, (list, tuple)) and any(isinstance(x, (list, tuple)) for x in v):
+                return [conv(x) for x in v]                      # nested records (e.g. the listed outliers)
+            return float(v) if np.ndim(v) == 0 else [float(x) for x in np.ravel(v)]
+        cur[name] = {k: conv(v) for k, v in vals.items()}
         json.dump(cur, open(path, "w"), indent=1)
     except OSError:
         pass
@@ -363,23 +367,31 @@ def test_fused_autoreset_equals_two_launch_path(vec):
     assert ended > 64
 
 
-@pytest.mark.parametrize("which", ["smpl", "getup", "smplx", "smpl_selfcol"])
+@pytest.mark.parametrize("which", ["smpl", "getup", "smplx", "smpl_selfcol", "getup_selfcol", "smplx_selfcol"])
 def test_per_sample_parity_on_the_benchmark_distribution(vec, which):
     """The benchmark's own states, per sample (GPU twin of test_parity_f64.py): envs driven by full-range uniform(-1,1)
-    actions (thrown around, lying on the floor with ~10 bodies in contact, some diverging).  At several control steps the
-    envs with the most Newton iterations (the stragglers of the launch) plus a random sample are replayed from the GPU's own
-    pre-step state by the float64 oracle, the float64 instantiation of the kernel (converged / product cap) and its
-    input-perturbed twins; asserted per sample: formulation (f64 kernel vs oracle) <= 1e-9, identical bad-state resets,
-    precision (GPU float32 vs f64 kernel at the same cap) <= K * cond * 2^-24, and observation / reward / flags of the GPU
-    against the f64 kernel.  BASELINE configs 2 (smpl), 3 (getup, StateInit.Fall) and 4 (smplx)."""
+    actions (thrown around, lying on the floor with ~10 bodies in contact, some diverging), the GPU at its SHIPPED solver
+    settings.  At several control steps the envs with the most Newton iterations (the stragglers of the launch) plus a random
+    sample are replayed from the GPU's own pre-step state by the float64 oracle at MuJoCo's solver settings (and converged), the
+    float64 instantiation of the kernel (shipped settings / converged) and its input-perturbed twins; asserted per sample:
+    formulation (f64 kernel vs oracle, both converged) <= 1e-9, identical bad-state resets, solver rule (f64 kernel at the shipped
+    settings vs the oracle at MuJoCo's) within the stated per-step tolerance on >= 99.5% of the samples (the rest listed),
+    precision (GPU float32 vs f64 kernel) <= TOL_STEP * max(1, cond / COND_REF), the fraction of samples on which the GPU is within
+    TOL_STEP of the oracle at MuJoCo's settings, and observation / reward of the GPU against the f64 kernel.
+    BASELINE configs 2 (smpl), 3 (getup, StateInit.Fall) and 4 (smplx), each also with the reference MJCF's body-body contacts."""
     import parity_tools as P
-    from test_parity_f64 import COND_FLOOR, K_ROUND
+    from test_parity_f64 import COND_FLOOR, K_ROUND, f32_bound
     from smplsim_amd.batch import ShardModel
+    base = which.replace("_selfcol", "")
+    selfcol = which.endswith("_selfcol")
     N, steps, every, per_step = {"smpl": (4096, 36, 5, (24, 60)), "getup": (1024, 12, 4, (12, 40)), "smplx": (1024, 24, 6, (8, 20)),
-                                 "smpl_selfcol": (2048, 24, 4, (16, 40))}[which]
-    humanoid = "smplx_humanoid" if which == "smplx" else "smpl_humanoid"
-    kw = dict(task="HumanoidGetup", state_init="Fall") if which == "getup" else (dict(self_collision=True) if which == "smpl_selfcol" else {})
-    tkw = {"task": "HumanoidGetup", "state_init": 1} if which == "getup" else ({"self_collision": True} if which == "smpl_selfcol" else {})
+                                 "smpl_selfcol": (2048, 24, 4, (16, 40)), "getup_selfcol": (1024, 12, 4, (8, 24)),
+                                 "smplx_selfcol": (512, 18, 6, (4, 10))}[which]
+    humanoid = "smplx_humanoid" if base == "smplx" else "smpl_humanoid"
+    kw = dict(task="HumanoidGetup", state_init="Fall") if base == "getup" else {}
+    tkw = {"task": "HumanoidGetup", "state_init": 1} if base == "getup" else {}
+    if selfcol:
+        kw["self_collision"] = True; tkw["self_collision"] = True
     env = vec(N, model=ShardModel(humanoid=humanoid), autoreset=True, seed=11, **kw)
     g = torch.Generator(device=env.device); g.manual_seed(11)
     env.reset()
@@ -411,20 +423,28 @@ def test_per_sample_parity_on_the_benchmark_distribution(vec, which):
     pre = {k: np.concatenate([p[k] for p in pres]) for k in pres[0]}
     post = {k: np.concatenate([p[k] for p in posts]) for k in posts[0]}
     A = np.concatenate(acts)
-    r = P.triage(pre, A, post, humanoid=humanoid, **tkw)
+    r = P.triage(pre, A, post, humanoid=humanoid, n_perturb=4 if base == "smplx" and selfcol else 8, **tkw)
     ok = ~r["reset"]
     cond = np.maximum(r["cond"], COND_FLOOR)
-    ratio32, ratio64 = r["precision"] / (cond * P.EPS32), r["formulation"] / (cond * P.EPS64)
-    for k in ("formulation", "precision", "cap_gap", "f32_vs_oracle", "cond"):
+    ratio64 = r["formulation"] / (cond * P.EPS64)
+    bound32 = f32_bound(r["cond"])
+    rule_ok, f32_ok = P.within_tol(r["solver_rule"]), P.within_tol(r["f32_vs_oracle"])
+    for k in ("formulation", "solver_rule", "oracle_rule", "precision", "f32_vs_oracle", "cond"):
         print(P.summarize(k, r[k], ok))
+    outside = [(int(i), r["f32_vs_oracle"][i].tolist(), r["cond"][i].tolist()) for i in np.flatnonzero(ok & ~f32_ok)]
+    print(f"solver rule within {P.TOL_STEP}: {rule_ok[ok].mean():.4f}; outside {r['solver_rule'][ok & ~rule_ok].tolist()}")
+    print(f"GPU float32 vs oracle at MuJoCo's settings within {P.TOL_STEP}: {f32_ok[ok].mean():.4f}; outside (sample, error, cond): {outside}")
     _record("benchmark_distribution_" + which, samples=len(ok), resets=int((~ok).sum()), max_newton_iters=int(post["iters"].max()),
-            formulation_max=r["formulation"][ok].max(axis=0), precision_median=np.median(r["precision"][ok], axis=0),
+            mean_newton_iters=float(post["iters"].mean()), mean_newton_iters_f64_kernel=float(r["iters"].mean()),
+            formulation_max=r["formulation"][ok].max(axis=0), solver_rule_max=r["solver_rule"][ok].max(axis=0),
+            solver_rule_within_tol_frac=float(rule_ok[ok].mean()), oracle_mujoco_vs_converged_max=r["oracle_rule"][ok].max(axis=0),
+            precision_median=np.median(r["precision"][ok], axis=0),
             precision_p99=np.quantile(r["precision"][ok], 0.99, axis=0), precision_max=r["precision"][ok].max(axis=0),
-            precision_over_cond_eps_max=ratio32[ok].max(axis=0), cap_gap_nonzero_frac=float((r["cap_gap"][ok].max(axis=1) > 0).mean()),
-            cap_gap_max=r["cap_gap"][ok].max(axis=0), f32_vs_oracle_max=r["f32_vs_oracle"][ok].max(axis=0), obs_max=r["obs"][ok].max(),
-            reward_max=r["reward"][ok].max())
-    assert ok.sum() >= {"smpl": 400, "getup": 100, "smplx": 80, "smpl_selfcol": 200}[which], ok.sum()
-    if which == "smpl_selfcol":
+            precision_over_bound_max=(r["precision"][ok] / bound32[ok]).max(axis=0),
+            f32_vs_oracle_within_tol_frac=float(f32_ok[ok].mean()), f32_vs_oracle_outside=outside,
+            f32_vs_oracle_max=r["f32_vs_oracle"][ok].max(axis=0), obs_max=r["obs"][ok].max(), reward_max=r["reward"][ok].max())
+    assert ok.sum() >= {"smpl": 400, "getup": 100, "smplx": 80, "smpl_selfcol": 200, "getup_selfcol": 60, "smplx_selfcol": 30}[which], ok.sum()
+    if selfcol:
         assert (r["nself"][ok] > 0).mean() > 0.3                 # most of these samples do have body-body contacts
     # MuJoCo's bad-state autoreset (|qpos|, |qvel|, |qacc| > 1e10 or NaN): the oracle and the float64 kernel must take it on the
     # same samples — except that a trajectory which is blowing up crosses 1e10 one mj_step earlier or later depending on
@@ -432,13 +452,15 @@ def test_per_sample_parity_on_the_benchmark_distribution(vec, which):
     # comparisons above either way ("reset" = any implementation reset)
     assert (~r["resets_agree"]).sum() <= max(1, len(r["resets_agree"]) // 100), (~r["resets_agree"]).sum()
     assert (r["formulation"][ok] <= np.maximum(1e-9, K_ROUND * cond[ok] * P.EPS64)).all(), r["formulation"][ok].max(axis=0)
-    assert (ratio64[ok] <= K_ROUND).all() and (ratio32[ok] <= K_ROUND).all(), (ratio64[ok].max(axis=0), ratio32[ok].max(axis=0))
+    assert (ratio64[ok] <= K_ROUND).all(), ratio64[ok].max(axis=0)
+    assert rule_ok[ok].mean() >= 0.995, (rule_ok[ok].mean(), r["solver_rule"][ok & ~rule_ok])
+    assert (r["precision"][ok] <= bound32[ok]).all(), (r["precision"][ok] / bound32[ok]).max(axis=0)
     med, p90 = np.median(r["precision"][ok], axis=0), np.quantile(r["precision"][ok], 0.9, axis=0)
     assert med[0] < 5e-7 and med[1] < 5e-5 and p90[0] < 5e-6 and p90[1] < 5e-4, (med, p90)
+    assert f32_ok[ok].mean() >= 0.9, f32_ok[ok].mean()           # (the stragglers are over-represented in these samples)
     worst = r["precision"].max(axis=1)
     assert (r["obs"][ok] <= 4 * worst[ok] + 1e-5).all()
     assert (r["reward"][ok] <= 2 * r["precision"][ok, 0] * r["vscale"][ok] + 1e-6).all()
-    assert (r["cap_gap"][ok].max(axis=1) == 0).mean() >= 0.85
 
 
 def test_self_collision_on_gpu(vec):

@@ -86,6 +86,32 @@ def test_box_box_known_answers():
     assert O.narrow_phase("bb", a, ([0.3, 0, 0], I3, [0.1, 0.1, 0.05])) == []
 
 
+def test_box_box_face_manifold_of_crossed_boxes():
+    """Two bars crossed in a '+', the upper one 1 cm into the lower one: no vertex of either box is inside the other, the
+    contact manifold is the overlap rectangle of the two faces (mjc_BoxBox / ODE clip the incident face against the reference
+    face's side planes and return its 4 corners).  Also yawed, where the clipped polygon's corners are edge-edge crossings."""
+    lower = ([0, 0, 0], I3, [0.3, 0.05, 0.05])
+    for yaw in (0.0, 0.3, -1.1):
+        Rz = _rot([0, 0, 1], yaw)
+        upper = ([0, 0, 0.1 - 0.01], Rz, [0.05, 0.3, 0.05])
+        c = O.narrow_phase("bb", lower, upper)
+        assert len(c) == 4, (yaw, c)
+        assert all(abs(x[2] + 0.01) < 1e-12 and np.allclose(x[1], [0, 0, 1]) and abs(x[0][2] - 0.045) < 1e-12 for x in c)
+        # the corners are the crossings of the lower bar's long edges (y = +-0.05) with the upper bar's (its local x = +-0.05)
+        P2 = np.array([x[0][:2] for x in c])
+        assert np.allclose(np.abs(P2[:, 1]), 0.05, atol=1e-12)
+        loc = P2 @ Rz[:2, :2]                                    # in the upper bar's frame
+        assert np.allclose(np.abs(loc[:, 0]), 0.05, atol=1e-12)
+        assert abs(P2.mean(axis=0)).max() < 1e-12
+        # roles swapped: same points, opposite normal
+        c2 = O.narrow_phase("bb", upper, lower)
+        assert len(c2) == 4 and all(np.allclose(x[1], [0, 0, -1]) for x in c2)
+        assert np.allclose(sorted(map(tuple, np.round(P2, 9))), sorted(tuple(np.round(x[0][:2], 9)) for x in c2))
+    # a box tilted onto a face: only the corner region below the margin survives the depth test
+    c = O.narrow_phase("bb", ([0, 0, 0], I3, [0.2, 0.2, 0.05]), ([0, 0, 0.05 + 0.0705], _rot([1, 1, 0], 0.6), [0.05, 0.05, 0.05]))
+    assert 1 <= len(c) <= 2 and all(x[2] < 0.001 for x in c)
+
+
 def _self_contact_state(rs, om):
     """Arms folded into the torso / legs crossed: random large joint angles until the model reports body-body contacts."""
     d = O.OracleData(om)

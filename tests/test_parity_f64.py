@@ -2,29 +2,47 @@
 (CPU: both kernel builds run on the wavefront emulator; the GPU twin is test_gpu_parity.py::test_per_sample_parity_*).
 
 What is asserted PER SAMPLE (tests/parity_tools.py explains the replays), errors relative to max(1, |qvel|_max):
-  formulation  float64 kernel vs oracle       <= max(1e-9, K cond 2^-53)   (the two formulations solve the same problem:
-               measured max 1e-12 on the emulator's samples, 7e-10 on the GPU's stragglers)
+  formulation  float64 kernel vs oracle, both converged   <= max(1e-9, K cond 2^-53)   (the two formulations solve the same
+               problem: measured max 1e-12 on the emulator's samples, 7e-10 on the GPU's stragglers)
   resets       MuJoCo bad-state autoresets (|x| > 1e10) happen in the same samples in oracle and float64 kernel
-  precision    float32 kernel vs float64 kernel at the same Newton cap   <= K * cond * 2^-24 with K = 8192, where cond is the
-               sample's measured response to float32-sized input noise (floored at COND_FLOOR): the float32 error is a bounded
-               multiple of rounding unit x conditioning; the float64 kernel's distance to the oracle obeys the same K with 2^-53
-  cap gap      float64 kernel with the product's cap (8 Newton iterations per mj_step) vs converged: reported, and zero for at
-               least 85% of the samples
+  solver rule  float64 kernel at the SHIPPED solver settings vs the oracle at MuJoCo's (mj_solPrimal's termination test,
+               tolerance 1e-8, 100 iterations): within the stated per-step tolerance P.TOL_STEP on >= 99.5% of the samples, the
+               others listed (the kernel's form of the test — DESIGN.md "solver termination" — against MuJoCo's own)
+  precision    float32 kernel vs float64 kernel, both at the shipped settings   <= K * cond * 2^-24 with K = 8192, where cond is
+               the sample's measured response to float32-sized input noise (floored at COND_FLOOR): the float32 error is a
+               bounded multiple of rounding unit x conditioning; the float64 kernel's distance to the oracle obeys the same K with
+               2^-53.  The fraction of samples whose float32 result is within P.TOL_STEP of the oracle at MuJoCo's settings is
+               reported and bounded below
 """
 import numpy as np
 import pytest
 
 import parity_tools as P
 
-K_ROUND = 8192.0
+K_ROUND = 8192.0                          # float64 kernel vs oracle: error <= K cond 2^-53 (two formulations, float64 rounding)
 COND_FLOOR = np.array([1.0, 50.0])       # qpos, qvel: the conditioning of a quiet sample (measured medians 0.7 / 60)
+# float32 kernel vs float64 kernel, per sample: the stated per-step tolerance P.TOL_STEP holds for every sample whose measured
+# conditioning is at most COND_REF (about the median of the benchmark's states) and grows in proportion to the conditioning
+# beyond it:  error <= TOL_STEP * max(1, cond / COND_REF)  (= 168 / 419 rounding units x conditioning; measured maxima 74 / 103
+# on the emulator's samples)
+COND_REF = np.array([1.0, 80.0])
 
 
-def _check(r, label, min_samples):
+def f32_bound(cond):
+    return P.TOL_STEP * np.maximum(1.0, cond / COND_REF)
+
+
+def _check(r, label, min_samples, min_f32_ok=0.95):
     ok = ~r["reset"]
     lines = [f"[{label}] samples {len(ok)}, with a bad-state autoreset inside the step {int((~ok).sum())}"]
-    for k in ("formulation", "precision", "cap_gap", "f32_vs_oracle", "cond"):
+    for k in ("formulation", "solver_rule", "oracle_rule", "precision", "f32_vs_oracle", "cond"):
         lines.append(P.summarize(k, r[k], ok))
+    rule_ok, f32_ok = P.within_tol(r["solver_rule"]), P.within_tol(r["f32_vs_oracle"])
+    lines.append(f"solver rule within {P.TOL_STEP}: {rule_ok[ok].mean():.4f} of the samples; outside: {np.flatnonzero(ok & ~rule_ok).tolist()} {r['solver_rule'][ok & ~rule_ok].tolist()}")
+    lines.append(f"float32 vs oracle (MuJoCo settings) within {P.TOL_STEP}: {f32_ok[ok].mean():.4f} of the samples; outside (sample, error, cond): "
+                 f"{[(int(i), r['f32_vs_oracle'][i].tolist(), r['cond'][i].tolist()) for i in np.flatnonzero(ok & ~f32_ok)]}")
+    if r.get("iters32") is not None:
+        lines.append(f"Newton iterations per control step: float32 mean {r['iters32'].mean():.2f} max {r['iters32'].max()}, float64 kernel mean {r['iters'].mean():.2f} max {r['iters'].max()}")
     cond = np.maximum(r["cond"], COND_FLOOR)
     ratio32 = r["precision"] / (cond * P.EPS32)
     ratio64 = r["formulation"] / (cond * P.EPS64)
@@ -43,8 +61,12 @@ def _check(r, label, min_samples):
     med, p90 = np.median(r["precision"][ok], axis=0), np.quantile(r["precision"][ok], 0.9, axis=0)
     assert med[0] < 5e-7 and med[1] < 5e-5 and p90[0] < 5e-6 and p90[1] < 5e-4, (med, p90)
     assert (ratio64[ok] <= K_ROUND).all(), ratio64[ok].max(axis=0)
-    assert (ratio32[ok] <= K_ROUND).all(), ratio32[ok].max(axis=0)
-    assert (r["cap_gap"][ok].max(axis=1) == 0).mean() >= 0.85
+    bound32 = f32_bound(r["cond"])
+    lines_ = f"precision / f32_bound(cond): max {(r['precision'][ok] / bound32[ok]).max(axis=0)}"
+    print(lines_)
+    assert (r["precision"][ok] <= bound32[ok]).all(), (r["precision"][ok] / bound32[ok]).max(axis=0)
+    assert rule_ok[ok].mean() >= 0.995, (rule_ok[ok].mean(), r["solver_rule"][ok & ~rule_ok])
+    assert f32_ok[ok].mean() >= min_f32_ok, f32_ok[ok].mean()
     return lines
 
 

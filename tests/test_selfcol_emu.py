@@ -32,7 +32,7 @@ def _states(n, seed, min_self=1, humanoid="smpl_humanoid"):
 def test_constrained_acceleration_with_body_body_contacts(f64, tol):
     mc = model_const()
     om, Q, V, T = _states(10, 2)
-    eb = emu.EmuBatch(mc, pd_tables(mc), len(Q), legal_bodies=FEET, f64=f64, newton_iters=100 if f64 else 8, self_collision=True)
+    eb = emu.EmuBatch(mc, pd_tables(mc), len(Q), legal_bodies=FEET, f64=f64, self_collision=True)
     eb.set_state(Q, V)
     M, bias, qacc = eb.debug_forward(T)
     d = O.OracleData(om)
@@ -44,9 +44,55 @@ def test_constrained_acceleration_with_body_body_contacts(f64, tol):
         seen.add((d.nself > 0, d.ncon > d.nself))
     assert (True, True) in seen and (True, False) in seen      # with and without simultaneous floor contacts
     # without the flag the same states take the floor-only path: the acceleration differs
-    eb0 = emu.EmuBatch(mc, pd_tables(mc), len(Q), legal_bodies=FEET, f64=f64, newton_iters=100 if f64 else 8)
+    eb0 = emu.EmuBatch(mc, pd_tables(mc), len(Q), legal_bodies=FEET, f64=f64)
     eb0.set_state(Q, V)
     assert np.abs(eb0.debug_forward(T)[2] - qacc).max() > 1e-2 and (eb0.self_contacts == 0).all()
+
+
+def _kernel_narrow_phase(kind, g1, g2, margin, f64):
+    """The kernel's pair functions (ss_selfcol.h) on raw geometry through the emulator's test hook."""
+    import ctypes as C
+    L = emu.lib(f64)
+    flat = lambda g: np.concatenate([np.ravel(np.asarray(x, dtype=np.float64)) for x in g])
+    inp = np.ascontiguousarray(np.concatenate([flat(g1), flat(g2), [margin], np.zeros(4)]))
+    out = np.zeros(1 + 7 * 8)
+    n = L.ss_emu_narrow_phase({"cc": 0, "cb": 1, "bb": 2}[kind], inp.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    return [(out[1 + 7 * i:4 + 7 * i].copy(), out[4 + 7 * i:7 + 7 * i].copy(), float(out[7 + 7 * i])) for i in range(n)]
+
+
+@pytest.mark.parametrize("f64,tol", [(True, 1e-10), (False, 3e-5)])
+def test_pair_functions_of_the_kernel_match_the_oracle(f64, tol):
+    """capsule-capsule / capsule-box / box-box of ss_selfcol.h against the oracle's twins on random touching geometry, plus the
+    crossed-boxes known answer (face manifold = the overlap rectangle, no vertex of either box inside the other)."""
+    from scipy.spatial.transform import Rotation as sRot
+    rs = np.random.default_rng(4)
+    seen = {"cc": 0, "cb": 0, "bb": 0}
+    multi = 0
+    for trial in range(600):
+        kind = ("cc", "cb", "bb")[trial % 3]
+        def geom(box, centre):
+            Rm = sRot.random(random_state=rs.integers(1 << 30)).as_matrix()
+            if box:
+                return (centre, Rm, rs.uniform(0.03, 0.15, 3))
+            return (centre, Rm[:, 2], rs.uniform(0.03, 0.08), rs.uniform(0.05, 0.2))
+        g1 = geom(kind == "bb", np.zeros(3))
+        g2 = geom(kind != "cc", rs.normal(size=3) * 0.12)
+        margin = 0.001
+        ref = O.narrow_phase(kind, g1, g2, margin)
+        if not ref or min(abs(c[2] - margin) for c in ref) < 1e-4:     # borderline at the margin: float32 may decide otherwise
+            continue
+        got = _kernel_narrow_phase(kind, g1, g2, margin, f64)
+        assert len(got) == len(ref), (kind, trial, len(got), len(ref))
+        for (p, n, d), (p2, n2, d2) in zip(sorted(ref, key=lambda c: tuple(np.round(c[0], 4))), sorted(got, key=lambda c: tuple(np.round(c[0], 4)))):
+            assert np.abs(p - p2).max() < tol and np.abs(n - n2).max() < tol and abs(d - d2) < tol, (kind, trial)
+        seen[kind] += 1
+        multi += len(ref) > 1
+    assert min(seen.values()) >= 15 and multi >= 10, (seen, multi)
+    lower, I3 = ([0, 0, 0], np.eye(3), [0.3, 0.05, 0.05]), np.eye(3)
+    for yaw in (0.0, 0.3):
+        Rz = sRot.from_euler("z", yaw).as_matrix()
+        got = _kernel_narrow_phase("bb", lower, ([0, 0, 0.09], Rz, [0.05, 0.3, 0.05]), 0.001, f64)
+        assert len(got) == 4 and all(abs(c[2] + 0.01) < tol and np.abs(c[1] - [0, 0, 1]).max() < tol for c in got)
 
 
 def test_capacity_rule_keeps_the_deepest_eight():
@@ -67,7 +113,7 @@ def test_capacity_rule_keeps_the_deepest_eight():
     assert found is not None
     d8.qpos = found; d8.qvel = np.zeros(75); d8.ctrl = np.zeros(69); d8.forward()
     assert d8.nself == 8 and int(d8.get(O.D_NSELF)[2]) == da.nself - 8
-    eb = emu.EmuBatch(mc, pd_tables(mc), 1, legal_bodies=FEET, f64=True, newton_iters=100, self_collision=True)
+    eb = emu.EmuBatch(mc, pd_tables(mc), 1, legal_bodies=FEET, f64=True, self_collision=True)
     eb.set_state(found[None], np.zeros((1, 75)))
     qacc = eb.debug_forward(np.zeros((1, 69)))[2][0]
     assert eb.self_contacts[0] == 8
@@ -113,7 +159,7 @@ def test_smplx_with_self_collision():
     """52 bodies, 1265 candidate pairs (20 broad-phase rounds of 64 lanes)."""
     mc = model_const("smplx_humanoid")
     om, Q, V, T = _states(3, 4, humanoid="smplx_humanoid")
-    eb = emu.EmuBatch(mc, pd_tables(mc), len(Q), legal_bodies=FEET, f64=True, newton_iters=100, self_collision=True)
+    eb = emu.EmuBatch(mc, pd_tables(mc), len(Q), legal_bodies=FEET, f64=True, self_collision=True)
     eb.set_state(Q, V)
     qacc = eb.debug_forward(T)[2]
     d = O.OracleData(om)
