@@ -92,7 +92,7 @@ def pmc_summary(workload, n_envs):
     if j.get("envs_per_gpu") != n_envs:
         return {}
     keys = ("traffic", "valu_issue_frac", "lds_wait_frac", "lds_bank_conflict_frac", "wave_active_frac", "scratch_bytes_per_lane",
-            "vgprs", "lds_bytes_per_workgroup", "waves_per_cu")
+            "vgprs", "waves_per_cu")
     out = {k: j[k] for k in keys if k in j}
     out["pmc_source"] = "profiles/" + os.path.basename(path) + " (" + j.get("profile", "?") + ")"
     return out
@@ -146,6 +146,71 @@ def cpu_baseline(seconds=12.0):
             "build": flags,
             "sample": f"{nenv} envs x {steps2} control steps, uniform(-1,1) actions, float64 C oracle "
                       f"(oracle/oracle.c; NOT MuJoCo; dense Cholesky per Newton iteration), {cores} threads (cgroup/affinity-usable cores), {dt:.1f}s"}
+
+
+def parity_probe(env, abuf, g, humanoid, n=64):
+    """Live check of the timed configuration against the CPU oracle at MuJoCo's solver settings (the oracle as checker, after
+    the timed region): one more control step of the batch; the envs with the most Newton iterations plus the first n / 2 envs
+    are replayed by oracle/oracle.c (float64, mj_solPrimal's termination: tolerance 1e-8, 100 iterations) from the GPU's own
+    pre-step state.  newton_cap_gap_frac = the fraction of the replayed samples (no episode end, no bad-state autoreset inside
+    the step) whose GPU result is outside the stated per-step tolerance of the oracle's (tests/parity_tools.TOL_STEP; errors
+    relative to max(1, |qvel|_max)) — float32 rounding on chaotic states included: tests/test_gpu_parity.py splits the causes."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import parity_tools as P
+    heavy = torch.argsort(env.solver_iters, descending=True)[:n // 2]
+    idx = torch.unique(torch.cat([heavy, torch.arange(n // 2, device=heavy.device)]))
+    pre = {k: getattr(env, k)[idx].double().cpu().numpy() for k in P.FIELDS}
+    nw0 = env.nwarn[idx].clone()
+    act = abuf.uniform_(-1.0, 1.0, generator=g)
+    _, _, term, trunc, _ = env.step(act)
+    Gpu.sync()
+    alive = ~(term.bool() | trunc.bool())[idx].cpu().numpy()
+    post = dict(qpos=env.qpos[idx].double().cpu().numpy(), qvel=env.qvel[idx].double().cpu().numpy())
+    nw = (env.nwarn[idx] - nw0).cpu().numpy()
+    orc = P.oracle_step(pre, act[idx].double().cpu().numpy(), humanoid, self_collision=bool(getattr(env, "self_collision", False)))
+    ok = alive & (nw == 0) & (orc["nwarn"] == 0)
+    e = P.rel_err(post, orc)
+    within = P.within_tol(e)
+    return {"samples": int(ok.sum()), "skipped_episode_end_or_bad_state_reset": int((~ok).sum()),
+            "newton_cap_gap_frac": float((~within[ok]).mean()) if ok.any() else None,
+            "max_rel_err_qpos_qvel": e[ok].max(axis=0).tolist() if ok.any() else None,
+            "median_rel_err_qpos_qvel": np.median(e[ok], axis=0).tolist() if ok.any() else None,
+            "stated_tolerance_qpos_qvel": P.TOL_STEP.tolist(),
+            "oracle": "oracle/oracle.c float64 at MuJoCo's solver settings (tolerance 1e-8 x meaninertia x nv, 100 iterations); NOT MuJoCo itself"}
+
+
+def reference_contact_set(args, rank, local_rank, dev, humanoid_model, workload_kw, steps=20, warmup=5):
+    """The same batch with the reference MJCF's full contact set (body-body contacts on, smpl_humanoid.xml:5,24,231-242): a short
+    run after the headline loop, so that the driver-run line carries the figure next to the floor-contact one."""
+    import torch
+    from smplsim_amd import shard
+    from smplsim_amd.batch import SMPLSimVecEnv
+    N = args.envs_per_gpu
+    env = SMPLSimVecEnv(N, model=humanoid_model, autoreset=True, seed=shard.shard_seed(1234, rank), self_collision=True,
+                        newton_iters=args.newton_iters, **workload_kw)
+    g = torch.Generator(device=dev); g.manual_seed(shard.shard_seed(4321, rank))
+    env.reset()
+    abuf = torch.empty(N, env.nu, device=dev)
+    for _ in range(warmup):
+        env.step(abuf.uniform_(-1.0, 1.0, generator=g))
+    ev0 = [Gpu.event() for _ in range(steps)]; ev1 = [Gpu.event() for _ in range(steps)]
+    Gpu.sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        env.step(abuf.uniform_(-1.0, 1.0, generator=g), _events=(ev0[i], ev1[i]))
+    Gpu.sync()
+    el = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    bstep = algorithmic_bytes(env.nq, env.nv, env.nu, env.obs_size)
+    return {"value": N * steps / el, "unit": "env-steps/s (this GPU)", "steps": steps, "ms_per_step": 1e3 * el / steps, "kernel_ms": kern_ms,
+            "frac": N * bstep / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "envs_per_cu": env.launch_info()["envs_per_workgroup"],
+            "mean_newton_iters_per_step": float(env.solver_iters.float().mean().item()),
+            "envs_with_body_body_contact_frac": float((env.self_contacts > 0).float().mean().item()),
+            "mean_body_body_contacts": float(env.self_contacts.float().mean().item()),
+            "max_body_body_contacts_kept": int(env.self_contacts.max().item()),
+            "note": "self_collision=True: capsule-capsule / capsule-box / box-box between all non-excluded, non-adjacent body pairs, "
+                    "as mj_step collides the reference MJCF"}
 
 
 def synthetic_clips(num, frames, seed):
@@ -288,6 +353,7 @@ def main(argv=None):
                     help="contacts between the humanoid's own bodies like mj_step on the reference MJCF (SURVEY 8f-4); default: floor "
                          "contacts and joint limits only")
     ap.add_argument("--newton-iters", type=int, default=0, help="mjOption.iterations: Newton iteration cap per mj_step (0 = MuJoCo's default, 100)")
+    ap.add_argument("--no-reference-contact-set", action="store_true", help="skip the short self_collision=True run after the timed loop")
     ap.add_argument("--unfused", action="store_true", help="imitation: the separate launches instead of ss_imitation_step_fused")
     ap.add_argument("--clips", type=int, default=256, help="imitation: synthetic clips per shard")
     ap.add_argument("--clip-frames", type=int, default=300, help="imitation: frames per synthetic clip (30 fps)")
@@ -308,17 +374,13 @@ def main(argv=None):
     N = args.envs_per_gpu
     if args.workload == "imitation":
         return run_imitation(args, rank, local_rank, world, dist, dev)
-    if args.workload == "smpl":
-        env = SMPLSimVecEnv(N, device=local_rank, task="HumanoidEnv", state_init="Default", self_obs_v=1,
-                            autoreset=True, seed=shard.shard_seed(1234, rank), self_collision=args.self_collision, newton_iters=args.newton_iters)
-    elif args.workload == "getup":
-        env = SMPLSimVecEnv(N, device=local_rank, task="HumanoidGetup", state_init="Fall", self_obs_v=1,
-                            autoreset=True, seed=shard.shard_seed(1234, rank), self_collision=args.self_collision, newton_iters=args.newton_iters)
-    else:
-        from smplsim_amd.batch import ShardModel
-        env = SMPLSimVecEnv(N, model=ShardModel(humanoid="smplx_humanoid", device=local_rank), task="HumanoidEnv",
-                            state_init="Default", self_obs_v=1, autoreset=True, seed=shard.shard_seed(1234, rank),
-                            self_collision=args.self_collision, newton_iters=args.newton_iters)
+    from smplsim_amd.batch import ShardModel
+    humanoid = "smplx_humanoid" if args.workload == "smplx" else "smpl_humanoid"
+    model = ShardModel(humanoid=humanoid, device=local_rank)
+    workload_kw = dict(task="HumanoidGetup", state_init="Fall", self_obs_v=1) if args.workload == "getup" else \
+        dict(task="HumanoidEnv", state_init="Default", self_obs_v=1)
+    env = SMPLSimVecEnv(N, model=model, autoreset=True, seed=shard.shard_seed(1234, rank), self_collision=args.self_collision,
+                        newton_iters=args.newton_iters, **workload_kw)
     g = torch.Generator(device=dev)
     g.manual_seed(shard.shard_seed(1234, rank))
     env.reset()
@@ -352,6 +414,11 @@ def main(argv=None):
     it_sorted = torch.sort(env.solver_iters.float()).values
     it_p50, it_p99, it_max = (float(it_sorted[int(q * (N - 1))].item()) for q in (0.5, 0.99, 1.0))
 
+    # every rank runs it (ranks stay in step); rank 0 reports its own GPU's figure
+    refset = None
+    if not args.self_collision and not args.no_reference_contact_set:
+        refset = reference_contact_set(args, rank, local_rank, dev, model, workload_kw)
+
     if rank == 0:
         total_envs = N * world
         value = shard.whole_job_throughput(total_envs * args.steps, elapsed)
@@ -375,15 +442,26 @@ def main(argv=None):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload].format(N=N),
                        "envs_per_gpu": N, "parallelism": f"independent shards x{world} (no collective)",
-                       "launch": launch, "newton_iters_cap": args.newton_iters, "mean_newton_iters_per_step": iters, "newton_iters_p50_p99_max": [it_p50, it_p99, it_max],
+                       "launch": launch,
+                       "solver": {"iterations": args.newton_iters if args.newton_iters > 0 else 100, "tolerance": 1e-8,
+                                  "rule": "mj_solPrimal's termination (improvement or gradient, scaled by 1 / (meaninertia nv), below the "
+                                          "tolerance), MuJoCo's defaults; tests/test_gpu_parity.py holds the kernel at these settings to the "
+                                          "oracle at the same"},
+                       "newton_iters_cap": args.newton_iters if args.newton_iters > 0 else 100,
+                       "mean_newton_iters_per_step": iters, "newton_iters_p50_p99_max": [it_p50, it_p99, it_max],
                        "bad_state_resets_total": nwarn, "self_collision": bool(getattr(env, "self_collision", False)),
                        "envs_with_body_body_contact_frac": float((env.self_contacts > 0).float().mean().item()),
                        "mean_body_body_contacts": float(env.self_contacts.float().mean().item()),
                        "obs_finite": finite, "parity_pin": PARITY_PIN},
             "roofline": roof,
         }
+        if refset is not None:
+            out["config"]["reference_contact_set"] = refset
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+            probe = parity_probe(env, abuf, g, humanoid)
+            out["config"]["parity_probe"] = probe
+            out["config"]["newton_cap_gap_frac"] = probe["newton_cap_gap_frac"]
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""Golden MJCFs of the body-shape rules, made by the REFERENCE's own `Skeleton` (smpl_sim/smpllib/skeleton_local.py:275-684:
+`load_from_offsets` + `construct_tree` / `write_xml_bodynode`) on synthetic bodies.
+
+Run in the build container only (needs /root/reference):
+    python tests/golden/make_golden_robot.py
+writes tests/golden/robot_vectors.json (committed): per case the inputs (joint offsets, parents, joint ranges, per-body vertex
+sets and hull volumes, flags) and the XML string the reference wrote.  tests/test_robot.py feeds the same inputs to
+smplsim_amd.robot.skeleton_table and compares every body, joint, geom, exclude and motor.
+
+The class needs lxml (absent here) for four calls only — XMLParser, parse, SubElement, tostring — which are mapped onto
+xml.etree.ElementTree below; `smpl_sim` is a shell package with a real ModuleSpec (its __init__ imports dead code), so that
+importlib.resources.files('smpl_sim') in the method defaults resolves to the reference's data directory; joblib / the SMPL
+parser are not touched by these methods.  Every line that computes a number is the reference's unmodified code.
+
+The SMPL parser (betas -> vertices) needs the licensed model files, so the bodies are synthetic: the packaged mean body's
+joint offsets, scaled and jittered, random vertex clouds around each bone as hull vertices, hull volume = their convex hull's.
+"""
+import importlib.util
+import json
+import os
+import sys
+import types
+import xml.etree.ElementTree as ET
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+
+
+def _install_shims():
+    sys.dont_write_bytecode = True
+    # lxml.etree -> xml.etree.ElementTree
+    lx = types.ModuleType("lxml")
+    et = types.ModuleType("lxml.etree")
+
+    class XMLParser:
+        def __init__(self, **kw):
+            pass
+
+    et.XMLParser = XMLParser
+    et.parse = lambda fname, parser=None: ET.parse(str(fname))
+    et.ElementTree, et.Element, et.SubElement = ET.ElementTree, ET.Element, ET.SubElement
+    et.tostring = lambda tree, pretty_print=False: ET.tostring(tree.getroot() if hasattr(tree, "getroot") else tree)
+    lx.etree = et
+    sys.modules["lxml"], sys.modules["lxml.etree"] = lx, et
+    sys.modules.setdefault("joblib", types.ModuleType("joblib"))
+    # smpl_sim as a shell package (no __init__ executed) with a real spec: files('smpl_sim') -> /root/reference/smpl_sim
+    for pkg in ("smpl_sim", "smpl_sim.utils", "smpl_sim.smpllib"):
+        d = os.path.join(REF, *pkg.split("."))
+        spec = importlib.util.spec_from_file_location(pkg, os.path.join(d, "__init__.py"), submodule_search_locations=[d])
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[pkg] = m
+    sys.path.insert(0, REF)
+
+
+def _bodies(name):
+    t = json.load(open(os.path.join(ROOT, "smplsim_amd", "data", name + ".json")))
+    names = [b["name"] for b in t["bodies"]]
+    parents = {b["name"]: b["parent"] for b in t["bodies"]}
+    offsets = {b["name"]: np.array(b["pos"], np.float64) for b in t["bodies"]}
+    return names, parents, offsets
+
+
+def make_case(rs, humanoid, smpl_model, flags, scale, jitter):
+    from scipy.spatial import ConvexHull
+    names, parents, base = _bodies(humanoid)
+    offsets = {n: np.round(base[n] * scale * (1 + jitter * rs.normal(size=3)), 6) for n in names}   # (rounded: smaller file)
+    children = {n: [c for c in names if parents[c] == n] for n in names}
+    jrange = {n: np.round(np.sort(rs.uniform(-np.pi, np.pi, (3, 2)), axis=1), 6) for n in names[1:]}
+    hulls = {}
+    for n in names:
+        end = np.mean([offsets[c] for c in children[n]], axis=0) if children[n] else offsets[n] + 0.002
+        L = max(np.linalg.norm(end), 0.03)
+        # a cloud around the segment joint -> bone end, thick enough to have volume
+        tpar = rs.uniform(-0.15, 1.1, (14, 1))
+        pts = np.round(tpar * end[None] + rs.normal(size=(14, 3)) * rs.uniform(0.15, 0.45) * L, 5)
+        hulls[n] = {"norm_verts": pts, "volume": float(ConvexHull(pts).volume)}
+    return dict(humanoid=humanoid, smpl_model=smpl_model, flags=flags, names=names, parents=parents,
+                offsets={n: offsets[n].tolist() for n in names}, jrange={n: jrange[n].tolist() for n in jrange},
+                hulls={n: {"norm_verts": hulls[n]["norm_verts"].tolist(), "volume": hulls[n]["volume"]} for n in names})
+
+
+EXCLUDES = [["Torso", "Chest"], ["Head", "Chest"], ["R_Knee", "R_Toe"], ["R_Knee", "L_Ankle"], ["R_Knee", "L_Toe"], ["L_Knee", "L_Toe"],
+            ["L_Knee", "R_Ankle"], ["L_Knee", "R_Toe"], ["L_Shoulder", "Chest"], ["R_Shoulder", "Chest"]]   # smpl_local_robot.py:1472-1483
+
+
+def run_reference(case):
+    import smpl_sim.smpllib.skeleton_local as sl
+    sk = sl.Skeleton(smpl_model=case["smpl_model"])
+    f = case["flags"]
+    offsets = {n: np.array(case["offsets"][n]) for n in case["names"]}               # dict order = joint order
+    jrange = {n: np.array(v) for n, v in case["jrange"].items()}
+    hull_dict = {n: {"norm_verts": torch.tensor(np.array(h["norm_verts"])), "volume": h["volume"]} for n, h in case["hulls"].items()}
+    sk.load_from_offsets(offsets, case["parents"], 1, jrange, hull_dict, {}, ["x", "y", "z"], {}, sim="mujoco",
+                         upright_start=f["upright_start"], remove_toe=False, freeze_hand=False, box_body=True, big_ankle=True,
+                         real_weight_porpotion_capsules=f["real_weight_porpotion_capsules"],
+                         real_weight_porpotion_boxes=f["real_weight_porpotion_boxes"], real_weight=f["real_weight"],
+                         ball_joints=False, create_vel_sensors=True, exclude_contacts=EXCLUDES)
+    xml = sk.write_str(bump_buffer=True)
+    return xml.decode() if isinstance(xml, bytes) else xml
+
+
+def main():
+    _install_shims()
+    rs = np.random.default_rng(20260926)
+    F = lambda **kw: {**dict(upright_start=False, real_weight=True, real_weight_porpotion_capsules=True, real_weight_porpotion_boxes=True), **kw}
+    plan = [("smpl_humanoid", "smpl", F(), 1.0, 0.0),                       # the mean body's joints, random hulls
+            ("smpl_humanoid", "smpl", F(), 1.15, 0.05),
+            ("smpl_humanoid", "smpl", F(), 0.85, 0.08),
+            ("smpl_humanoid", "smpl", F(real_weight=False), 1.05, 0.04),
+            ("smpl_humanoid", "smpl", F(real_weight_porpotion_capsules=False), 0.95, 0.04),
+            ("smpl_humanoid", "smpl", F(real_weight_porpotion_boxes=False), 1.1, 0.06),
+            ("smpl_humanoid", "smpl", F(upright_start=True), 1.0, 0.03),
+            ("smpl_humanoid", "smpl", F(real_weight=False, real_weight_porpotion_capsules=False, real_weight_porpotion_boxes=False), 0.9, 0.05),
+            # SMPL-X last: the reference's GEOM_TYPES dict is module state and the smplx flag turns the wrists into boxes for good
+            ("smplx_humanoid", "smplx", F(), 1.0, 0.0),
+            ("smplx_humanoid", "smplx", F(), 1.1, 0.05),
+            ("smplx_humanoid", "smplx", F(upright_start=True, real_weight_porpotion_boxes=False), 0.92, 0.04)]
+    cases = []
+    for humanoid, model, flags, scale, jitter in plan:
+        c = make_case(rs, humanoid, model, flags, scale, jitter)
+        c["xml"] = run_reference(c)
+        cases.append(c)
+        print(humanoid, flags, "xml bytes", len(c["xml"]))
+    out = os.path.join(HERE, "robot_vectors.json")
+    json.dump({"generator": "tests/golden/make_golden_robot.py", "reference": "smpl_sim/smpllib/skeleton_local.py Skeleton.load_from_offsets + write_str",
+               "cases": cases}, open(out, "w"))
+    print("wrote", out, os.path.getsize(out), "bytes")
+
+
+if __name__ == "__main__":
+    main()
