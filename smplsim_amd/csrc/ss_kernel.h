@@ -1246,29 +1246,61 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       s0 = 2;
     }
     SS_FTICK(PF_F_SYNC1);
-    for (int L = 2; L < h.nlev; L++) {                        // ---- downward sweep below the root
-      const int nk = (int)(((L < 16 ? nk0 : nk1) >> (4 * (L & 15))) & 15ull) + 1;
+    // ---- downward sweep below the root:  x_n = y_n - W_n^T a_parent,  a_n = a_parent + S_n x_n.  Lane r of the node's group holds
+    // row r: its own W row (one 16-byte read; y_j rides in row j's fourth slot) and component r of the parent's acceleration; the
+    // three sums over the rows are 8-lane DPP sums (idle lanes hold zeros) — 5 LDS reads per lane and level instead of 12, and the
+    // only read that waits for the previous level is the parent's component.
+#ifndef SS_DOWN_PREFETCH
+#define SS_DOWN_PREFETCH 0
+#endif
+    // SS_DOWN_PREFETCH (experiment, off): the node's static data (level record, W row, S row) does not depend on the sweep and can
+    // be requested one level ahead (1: the record only, 2: record two levels ahead + W and S rows one level ahead), so that per
+    // level only the read of the parent's component waits for the previous level's write.  Measured on the MI355X: -1 % and -2 %
+    // (profiles/r03_chain_candidates.md) — the extra live registers and moves cost more than the shorter chain brings.
+    auto NK = [&](int L) { return L < h.nlev ? (int)(((L < 16 ? nk0 : nk1) >> (4 * (L & 15))) & 15ull) + 1 : 0; };
+    int e1[NPASS], e2[NPASS];                                 // records of this level / the next one (-1: no node for this lane)
+    float4_t wr1[NPASS]; real sa1[NPASS], sb1[NPASS], sc1[NPASS];   // W row and S row of this level's node
+    auto rec = [&](int L, int start, int ps) { const int kk = ps * 8 + g; return (r_ < 6 && kk < NK(L)) ? ti(h.o_lev, start + kk) : -1; };
+    int st1 = 2, st2 = 2 + NK(2);
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ps++) {
+      e1[ps] = rec(2, st1, ps); e2[ps] = rec(3, st2, ps);
+      wr1[ps].x = wr1[ps].y = wr1[ps].z = wr1[ps].w = 0.f; sa1[ps] = sb1[ps] = sc1[ps] = 0.f;
+      if (SS_DOWN_PREFETCH >= 2 && e1[ps] >= 0) {
+        const int n = e1[ps] & 255; wr1[ps] = ld4(Wst + (n * 6 + r_) * 4);
+        const real *sn = S + 18 * n + r_; sa1[ps] = sn[0]; sb1[ps] = sn[6]; sc1[ps] = sn[12];
+      }
+    }
+    for (int L = 2; L < h.nlev; L++) {
+      const int st3 = st2 + NK(L + 1);
 #pragma unroll
       for (int ps = 0; ps < NPASS; ps++) {
-        const int kk = ps * 8 + g;
-        if (r_ < 6 && kk < nk) {
-          const int e = ti(h.o_lev, s0 + kk), n = e & 255, pn = (e >> 8) & 255;
-          float4_t p0, p1; p0.x = p0.y = p0.z = p0.w = 0.f; p1 = p0;
-          real apr = 0.f;
-          if (n > 0) { p0 = ld4(An + 8 * pn); p1 = ld4(An + 8 * pn + 4); apr = An[8 * pn + r_]; }
-          float4_t Wn[6];
-#pragma unroll
-          for (int c = 0; c < 6; c++) Wn[c] = ld4(Wst + (n * 6 + c) * 4);
-          const real ap[6] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y};
-          real x0 = Wn[0].w, x1 = Wn[1].w, x2 = Wn[2].w;
-#pragma unroll
-          for (int c = 0; c < 6; c++) { x0 -= Wn[c].x * ap[c]; x1 -= Wn[c].y * ap[c]; x2 -= Wn[c].z * ap[c]; }
-          const real *sn = S + 18 * n + r_;
-          An[8 * n + r_] = apr + sn[0] * x0 + sn[6] * x1 + sn[12] * x2;
-          if (r_ < 3) x[3 * n + r_] = r_ == 0 ? x0 : (r_ == 1 ? x1 : x2);
+        const int e = SS_DOWN_PREFETCH >= 1 ? e1[ps] : rec(L, st1, ps);
+        const int n = e >= 0 ? (e & 255) : -1;
+        real p0 = 0.f, p1 = 0.f, p2 = 0.f, apr = 0.f, s_0 = 0.f, s_1 = 0.f, s_2 = 0.f;
+        if (n >= 0) {
+          const int pn = (e >> 8) & 255;
+          apr = An[8 * pn + r_];
+          float4_t wr;
+          if (SS_DOWN_PREFETCH >= 2) { wr = wr1[ps]; s_0 = sa1[ps]; s_1 = sb1[ps]; s_2 = sc1[ps]; }
+          else { wr = ld4(Wst + (n * 6 + r_) * 4); const real *sn = S + 18 * n + r_; s_0 = sn[0]; s_1 = sn[6]; s_2 = sn[12]; }
+          p0 = wr.x * apr - (r_ == 0 ? wr.w : 0.f); p1 = wr.y * apr - (r_ == 1 ? wr.w : 0.f); p2 = wr.z * apr - (r_ == 2 ? wr.w : 0.f);
+        }
+        if (SS_DOWN_PREFETCH >= 1) {                          // next level's record is here by now; request its data and the record after it
+          e1[ps] = e2[ps];
+          if (SS_DOWN_PREFETCH >= 2 && e2[ps] >= 0) {
+            const int n2 = e2[ps] & 255; wr1[ps] = ld4(Wst + (n2 * 6 + r_) * 4);
+            const real *sn = S + 18 * n2 + r_; sa1[ps] = sn[0]; sb1[ps] = sn[6]; sc1[ps] = sn[12];
+          }
+          e2[ps] = rec(L + 2, st3, ps);
+        }
+        p0 = w->sum8(p0); p1 = w->sum8(p1); p2 = w->sum8(p2);   // = -x_n in every lane of the group
+        if (n >= 0) {
+          An[8 * n + r_] = apr - (s_0 * p0 + s_1 * p1 + s_2 * p2);
+          if (r_ < 3) x[3 * n + r_] = -(r_ == 0 ? p0 : (r_ == 1 ? p1 : p2));
         }
       }
-      s0 += nk;
+      st1 = st2; st2 = st3;
       w->sync();
     }
     SS_FTICK(PF_F_BSOL);
