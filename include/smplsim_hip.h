@@ -205,6 +205,12 @@ int ss_kinematics(ss_batch *b, float *xpos, float *xmat, void *stream);
  * off).  Saves the extra launch for callers that need world body poses every step (the imitation task, smplsim_motion.h). */
 int ss_set_body_outputs(ss_batch *b, float *xpos, float *xmat);
 
+/* Optional by-product of ss_step / ss_step_autoreset: HumanoidEnv.curr_power_usage (reference humanoid_env.py:443-451) — per
+ * mj_step of the control step, |qfrc_actuator * qvel| of every hinge dof with the torque applied in that mj_step and the velocity
+ * after it: power [N, control_freq_inv, nv - 6] (caller-owned; NULL = off, the default).  Like ss_set_body_outputs it selects the
+ * kernel instantiation with the optional outputs. */
+int ss_set_power_output(ss_batch *b, float *power);
+
 /* Diagnostics for parity triage: one mj_forward at (qpos, qvel) with raw joint torques [N,nu] (NULL = 0);
  * writes the dense joint-space mass matrix [N,nv,nv] (what mj_fullM returns; the stepping path itself never forms
  * it), qfrc_bias [N,nv] and the constrained qacc [N,nv]. */
@@ -251,6 +257,9 @@ enum { SS_FIELD_QPOS = 0,      /* [N,nq] */
        SS_FIELD_CUR_T = 7 };   /* [N] int32 */
 int ss_get_state(ss_batch *b, int32_t field, void *buf, void *stream);
 int ss_set_state(ss_batch *b, int32_t field, const void *buf, void *stream);
+
+/* Launches of one batch must be enqueued on ONE stream (or be ordered by the caller's events): a launch zeroes the work counter of
+ * the next one, so a launch on another stream must not start before the previous launch of the batch has finished. */
 
 /* Message of the calling thread's last failed call; and of the last failed call that took this handle (valid until the next
  * failing call on the handle or its destruction) — for hosts that call from pooled threads and cannot rely on thread identity. */

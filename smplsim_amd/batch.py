@@ -296,6 +296,15 @@ class SMPLSimVecEnv:
         _check(lib().ss_kinematics(self.handle, _ptr(xpos), _ptr(xmat), self._stream()))
         return xpos, xmat
 
+    def enable_power_usage(self):
+        """HumanoidEnv.curr_power_usage (reference humanoid_env.py:443-451) for the batch: after every step `self.power_usage`
+        [N, control_freq_inv, nv - 6] holds |qfrc_actuator * qvel| of every hinge dof per mj_step (ss_set_power_output; selects the
+        kernel instantiation with the optional outputs)."""
+        if getattr(self, "power_usage", None) is None:
+            self.power_usage = torch.zeros(self.num_envs, int(self.cfg.control_freq_inv), self.nv - 6, device=self.device)
+            _check(lib().ss_set_power_output(self.handle, _ptr(self.power_usage)))
+        return self.power_usage
+
     def debug_forward(self, torques=None):
         """(M [N,nv,nv], qfrc_bias, qacc) of one mj_forward at the current state (parity triage)."""
         M = torch.zeros(self.num_envs, self.nv, self.nv, device=self.device)

@@ -94,7 +94,7 @@ struct HipBackend {
   static int &regs_ref() { static int r = 0; return r; }
   static int kernel_regs() { return regs_ref(); }
   static const char *launch(const ss::KArgs &k, int nenv, int envs_per_wg, size_t lds_bytes, void *stream, int fixed_epw, int max_wgs) {
-    const bool bodyout = k.out0 && (k.mode == ss::MODE_STEP || k.mode == ss::MODE_RESET);
+    const bool bodyout = (k.out0 || k.power) && (k.mode == ss::MODE_STEP || k.mode == ss::MODE_RESET);
     const int flavour = k.im ? (k.cfg.self_collision ? 7 : (k.st.shape_id ? 6 : 4)) : (k.cfg.self_collision ? (k.st.shape_id ? 5 : 3) : (k.st.shape_id ? 2 : (bodyout ? 1 : 0)));
     kern_t kern = pick_kernel(ss::kernel_variant(k.h), flavour, k.h);
     if (!kern) return "no kernel variant for this model size";

@@ -210,6 +210,7 @@ struct KArgs {
   const void *im;             // ss::mo::ImFused on the device (ss_imitation_step_fused), or null
   const float *im_rand;       // [N,2] uniform draws for the re-initialisation of finished envs, or null = none
   int32_t *work_counter_next; // the counter of the NEXT launch on this batch: zeroed by this one (no memset between launches)
+  real *power;                // optional [N, nsub, nv - 6]: |torque * velocity| per mj_step (ss_set_power_output; body-output instantiations)
 };
 
 // floats of one env's LDS slice for this launch

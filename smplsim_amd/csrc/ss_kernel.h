@@ -2248,6 +2248,9 @@ SS_DEV bool run_env(W *w, const KArgs *k, const uint32_t *T, real *L, int env, i
       if (is_debug) break;
       if (sim.any_bad(sim.a, h.nv)) { sim.reset_data(); redo = true; break; }        // mj_checkAcc -> autoreset
       sim.integrate();
+      if constexpr (BODYOUT)                                 // HumanoidEnv.curr_power_usage: |qfrc_actuator * qvel| of this mj_step's torque and the new velocity
+        if (k->power && mode == MODE_STEP)
+          for (int i = 6 + lane; i < h.nv; i += 64) k->power[((size_t)env * nsub + s) * (h.nv - 6) + i - 6] = SS_M(fabs)(sim.tau[i] * sim.v[i]);
       SS_TICK(PF_INTEG);
       if (!next_action) break;
       solve = SOLVE_SPD;

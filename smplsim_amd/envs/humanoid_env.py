@@ -209,6 +209,18 @@ class HumanoidEnv:
         if self._vec_obj is not None and self._vec_pid == os.getpid():
             self._vec_obj.close()
 
+    @property
+    def curr_power_usage(self):
+        """reference humanoid_env.py:443-451: one array [nv - 6] per mj_step of the last control step, |qfrc_actuator * qvel| with the
+        torque applied in that mj_step and the velocity after it.  Recorded from the first access on (the step launch writes it as
+        an optional by-product): empty before the next step."""
+        v = self._vec
+        first = getattr(v, "power_usage", None) is None
+        p = v.enable_power_usage()
+        if first or self.cur_t == 0:
+            return []
+        return [row.astype(np.float64) for row in p[0].cpu().numpy()]
+
     # ---- state accessors used by callers of the reference env
     def get_qpos(self):
         return self.mj_data.qpos

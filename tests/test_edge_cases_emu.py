@@ -289,3 +289,35 @@ def test_fixed_layout_instantiation_is_bit_identical_to_the_generic_one(humanoid
     for x, y in zip(*outs):
         assert np.array_equal(x, y)
     assert outs[0][4].max() > 15                            # contacts were active (one Newton iteration per mj_step otherwise)
+
+
+@pytest.mark.parametrize("f64,tol", [(True, 1e-9), (False, 2e-4)])
+def test_power_usage_output_matches_the_reference_definition(f64, tol):
+    """HumanoidEnv.curr_power_usage (reference humanoid_env.py:443-451): per mj_step |qfrc_actuator[6:] * qvel[6:]| with the torque
+    of that mj_step and the velocity after it — the optional by-product of the step launch (ss_set_power_output) against the
+    oracle doing what the reference's loop does."""
+    from oracle import oracle as O
+    mc = model_const()
+    om = oracle_model()
+    rs = np.random.default_rng(12)
+    n = 3
+    eb = emu.EmuBatch(mc, pd_tables(mc), n, legal_bodies=FEET, f64=f64)
+    eb.reset()
+    P = eb.set_power_output()
+    acts = rs.uniform(-0.6, 0.6, (n, mc.nu))
+    pre_q, pre_v, pre_w = eb.qpos.astype(np.float64), eb.qvel.astype(np.float64), eb.qacc_warm.astype(np.float64)
+    pq, pv = eb.qpos_prev.astype(np.float64), eb.qvel_prev.astype(np.float64)
+    eb.step(acts)
+    assert P.shape == (n, 15, 69) and np.abs(P).max() > 1.0
+    for i in range(n):
+        d = O.OracleData(om)
+        d.qpos = pq[i]; d.qvel = pv[i]; d.forward()
+        d.qpos = pre_q[i]; d.qvel = pre_v[i]; d.warm = pre_w[i]
+        for s_ in range(15):
+            tau = d.spd_torque(acts[i]); d.ctrl = tau; d.step()
+            ref = np.abs(tau * d.qvel[6:])
+            assert np.abs(P[i, s_] - ref).max() < tol * max(1.0, np.abs(ref).max()), (i, s_)
+    # off again: the buffer keeps its contents
+    eb._chk(eb.L.ss_set_power_output(eb.batch, None))
+    keep = P.copy(); eb.step(acts)
+    assert np.array_equal(P, keep)

@@ -537,12 +537,15 @@ def test_gym_style_single_env_matches_oracle():
     assert np.abs(obs - oenv.reset()).max() < 1e-6
     env.action_space.seed(0)
     action = env.action_space.sample()                        # benchmark.py:100 reuses one action for all reps
+    assert env.curr_power_usage == []                          # recorded from the first access on (humanoid_env.py:443-451)
     for i in range(5):
         obs, rew, term, trunc, info = env.step(action=action)
         o_ref, r, te, tu = oenv.step(action.astype(np.float64))
         assert isinstance(rew, float) and isinstance(term, bool) and isinstance(trunc, bool)
         assert np.abs(obs - o_ref).max() < 5e-3 * max(1.0, np.abs(o_ref[220:]).max())
         assert (term, trunc) == (te, tu)
+        pw = env.curr_power_usage
+        assert len(pw) == 15 and pw[0].shape == (69,) and all((p >= 0).all() for p in pw) and max(p.max() for p in pw) > 0.1
     env.close()
 
 

@@ -129,6 +129,11 @@ class EmuBatch:
         self.xpos_out = np.zeros((self.N, self.mc.nbody, 3), self.ft); self.xmat_out = np.zeros((self.N, self.mc.nbody, 9), self.ft)
         self._chk(self.L.ss_set_body_outputs(self.batch, _p(self.xpos_out), _p(self.xmat_out)))
 
+    def set_power_output(self):
+        self.power = np.zeros((self.N, int(self.cfg.control_freq_inv), self.mc.nv - 6), self.ft)
+        self._chk(self.L.ss_set_power_output(self.batch, _p(self.power)))
+        return self.power
+
     def kinematics(self):
         xpos = np.zeros((self.N, self.mc.nbody, 3), self.ft); xmat = np.zeros((self.N, self.mc.nbody, 9), self.ft)
         self._chk(self.L.ss_kinematics(self.batch, _p(xpos), _p(xmat), None))
