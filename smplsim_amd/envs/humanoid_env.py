@@ -141,6 +141,8 @@ class HumanoidEnv:
         """The GPU batch of this env object, created on first use in the calling process (see __init__)."""
         if self._vec_obj is None or self._vec_pid != os.getpid():
             self._vec_obj, self._vec_pid = SMPLSimVecEnv(self._num_envs, **self._vec_kw), os.getpid()
+            # the host formulas of get_obs_size() (spaces are needed before any device exists) against the library's ss_obs_size
+            assert self._vec_obj.obs_size == self.get_obs_size(), (self._vec_obj.obs_size, self.get_obs_size())
         return self._vec_obj
 
     # ---- sizes
@@ -154,7 +156,10 @@ class HumanoidEnv:
         return self.get_self_obs_size() + self.get_task_obs_size()
 
     def get_self_obs_size(self):
-        # reference humanoid_env.py:293-299 (= ss_obs_size of the library, without needing the device)
+        # reference humanoid_env.py:293-299 (= ss_obs_size of the library, without needing the device; checked against it when the
+        # device batch is created).  With has_shape_variation the reference adds 10 to _num_self_obs (:304-305) although its
+        # compute_proprioception produces no shape entries — its declared space and its observation disagree; here the space has
+        # the observation's length (INTEGRATION.md "deviations")
         nb = self._model.mc.nbody
         nd = 3 * (nb - 1)
         return (1 if self._root_height_obs else 0) + nd + (6 * nb + 6 + nd if self.self_obs_v == 1 else 12 * nb)
