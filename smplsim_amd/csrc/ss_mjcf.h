@@ -45,7 +45,10 @@ struct Parser {
     }
   }
   static bool namech(char c) { return std::isalnum((unsigned char)c) || c == '_' || c == '-' || c == ':' || c == '.'; }
+  int depth = 0;                                             // nesting of the element being read (caller-supplied text: bounded recursion)
   std::unique_ptr<Node> element() {
+    struct Depth { int &d; explicit Depth(int &x) : d(x) { d++; } ~Depth() { d--; } } dg_(depth);
+    if (depth > 256) { err = "XML parse error: elements nested deeper than 256"; return nullptr; }
     skip();
     if (p >= end || *p != '<') { err = "XML parse error: expected '<'"; return nullptr; }
     p++;
@@ -223,7 +226,9 @@ inline bool compile(const char *xml, size_t len, const ss_mjcf_options *opt, Com
       t = SS_GEOM_BOX;
       if (!floats(mget(g, "size", ""), 3, size, err, "box size") || !floats(mget(g, "pos", "0 0 0"), 3, gp, err, "geom pos") ||
           !floats(mget(g, "quat", "1 0 0 0"), 4, gq, err, "geom quat")) { ok = false; return; }
+      if (!(size[0] > 0 && size[1] > 0 && size[2] > 0)) { err = "box sizes must be positive"; ok = false; return; }
       const double n = std::sqrt(gq[0] * gq[0] + gq[1] * gq[1] + gq[2] * gq[2] + gq[3] * gq[3]);
+      if (!(n > 0)) { err = "geom quat must not be zero"; ok = false; return; }
       for (int i = 0; i < 4; i++) gq[i] /= n;
     } else if (gt == "capsule") {
       t = SS_GEOM_CAPSULE;
@@ -233,6 +238,8 @@ inline bool compile(const char *xml, size_t len, const ss_mjcf_options *opt, Com
       if (!floats(g["fromto"], 6, ft, err, "fromto")) { ok = false; return; }
       const double vec[3] = {ft[3] - ft[0], ft[4] - ft[1], ft[5] - ft[2]};
       size[0] = r1[0]; size[1] = 0.5 * std::sqrt(vec[0] * vec[0] + vec[1] * vec[1] + vec[2] * vec[2]);
+      if (!(size[0] > 0)) { err = "capsule radius must be positive"; ok = false; return; }
+      if (!(size[1] > 1e-9)) { err = "capsule fromto has zero length"; ok = false; return; }
       for (int i = 0; i < 3; i++) gp[i] = 0.5 * (ft[i] + ft[3 + i]);
       z_to_quat(vec, gq);
     } else { err = "geom type '" + gt + "' is not supported"; ok = false; return; }

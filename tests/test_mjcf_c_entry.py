@@ -60,6 +60,8 @@ def test_c_compiler_options():
     (lambda s: s.replace("<mujoco", "<mujoc0", 1), "mujoco"),
     (lambda s: s[: len(s) // 2], "XML parse error"),
     (lambda s: s.replace('axis="0.0 1.0 0.0"', 'axis="0 0.7 0.7"', 1), "hinge axes"),
+    (lambda s: "<mujoco>" + "<a>" * 5000 + "</a>" * 5000 + "</mujoco>", "nested deeper"),        # bounded recursion, not a stack overflow
+    (lambda s: __import__("re").sub(r'fromto="[^"]*"', 'fromto="0.1 0.2 0.3 0.1 0.2 0.3"', s, count=1), "zero length"),
 ])
 def test_c_compiler_rejects_what_the_python_compiler_rejects(edit, msg):
     L = lib()
