@@ -88,11 +88,17 @@ class AgentPPO:
         states = torch.empty(T, N, self.state_dim, **f)
         actions = torch.empty(T, N, self.action_dim, **f)
         rewards, not_done, not_dead = (torch.empty(T, N, **f) for _ in range(3))
+        # bf16 sampler: the behaviour policy's own log-densities go into the batch (the update's fp32 network would give the PPO
+        # ratio a denominator from a slightly different policy: a mean error of 1e-2 at sigma 0.08 moves log-probs noticeably)
+        behaviour_logp = torch.empty(T, N, 1, **f) if (self.fast_policy is not None and not mean_action) else None
         state = self._prep_obs(self._obs)
         for t in range(T):
             states[t] = state
             if self.fast_policy is not None:
-                a = self.fast_policy.select_action(state, mean_action, generator=self.gen)
+                if behaviour_logp is not None:
+                    a, behaviour_logp[t] = self.fast_policy.select_action(state, mean_action, generator=self.gen, return_log_prob=True)
+                else:
+                    a = self.fast_policy.select_action(state, mean_action, generator=self.gen)
             else:
                 with self._autocast():
                     a = self._f32(self.policy_net.select_action(state, mean_action, generator=self.gen))
@@ -105,8 +111,11 @@ class AgentPPO:
         self._obs = obs
         self.num_steps += T * N
         exps = torch.full((T, N), 0.0 if mean_action else 1.0, **f)
-        return dict(states=states, actions=actions, rewards=rewards, not_done=not_done, not_dead=not_dead, exps=exps,
-                    last_state=state.clone())
+        out = dict(states=states, actions=actions, rewards=rewards, not_done=not_done, not_dead=not_dead, exps=exps,
+                   last_state=state.clone())
+        if behaviour_logp is not None:
+            out["log_probs"] = behaviour_logp
+        return out
 
     # ------------------------------------------------------------------ update
     def _autocast(self):
@@ -146,8 +155,11 @@ class AgentPPO:
         ret = ret.reshape(T * N, 1)
         actions = batch["actions"].reshape(T * N, -1)
         ind = batch["exps"].reshape(-1).nonzero(as_tuple=False).squeeze(1)
-        with torch.no_grad(), self._autocast():
-            fixed_log_probs = self._f32(self.policy_net.get_log_prob(states, actions))
+        if "log_probs" in batch:                               # sampled by the bf16 inference path: its own log-densities
+            fixed_log_probs = batch["log_probs"].reshape(T * N, 1)
+        else:
+            with torch.no_grad(), self._autocast():
+                fixed_log_probs = self._f32(self.policy_net.get_log_prob(states, actions))
         self.policy_net.train(); self.value_net.train()        # RunningNorm statistics follow the training passes
         s_i, a_i, adv_i, flp_i = states[ind], actions[ind], adv[ind], fixed_log_probs[ind]
         info = {}

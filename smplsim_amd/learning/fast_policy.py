@@ -9,6 +9,7 @@ MFMA rate.  The weights are snapshots (bf16 copies, padded to the kernels' tile 
 This is an inference path only — no autograd; the PPO update evaluates the fp32 networks as before.
 """
 import ctypes as C
+import math
 
 import torch
 
@@ -85,9 +86,17 @@ class FusedPolicyInference:
         return out
 
     @torch.no_grad()
-    def select_action(self, obs, mean_action=False, generator=None):
+    def select_action(self, obs, mean_action=False, generator=None, return_log_prob=False):
+        """return_log_prob: also the log-density of the drawn action under THIS (bf16) behaviour policy, [M, 1] — what the PPO ratio's
+        denominator must be when the sampler runs here while the update evaluates the fp32 network (normal_log_density of the
+        reference's PolicyGaussian.get_log_prob, learning_utils.py: sum over the action dimensions)."""
         mean = self.mean(obs)
         if mean_action:
-            return mean
+            return (mean, None) if return_log_prob else mean
         noise = torch.randn(mean.shape, device=mean.device, dtype=mean.dtype, generator=generator)
-        return torch.addcmul(mean, self.policy.action_log_std.exp(), noise)
+        log_std = self.policy.action_log_std
+        act = torch.addcmul(mean, log_std.exp(), noise)
+        if not return_log_prob:
+            return act
+        logp = (-0.5 * noise.pow(2) - 0.5 * math.log(2.0 * math.pi) - log_std).sum(1, keepdim=True)
+        return act, logp

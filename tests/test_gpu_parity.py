@@ -1007,6 +1007,12 @@ def test_fused_policy_inference_matches_the_torch_policy():
     a = fast.select_action(obs, generator=g1)
     n = torch.randn(a.shape, device="cuda", generator=g2)
     assert torch.allclose(a, fast.mean(obs) + pol.action_log_std.exp() * n, atol=1e-6)
+    # the behaviour policy's own log-density of the drawn action (what the PPO ratio divides by when the sampler runs here)
+    g3 = torch.Generator(device="cuda").manual_seed(5)
+    a2, logp = fast.select_action(obs, generator=g3, return_log_prob=True)
+    z = (a2 - fast.mean(obs)) * torch.exp(-pol.action_log_std)
+    want_lp = (-0.5 * z * z - pol.action_log_std - 0.5 * np.log(2 * np.pi)).sum(1, keepdim=True)
+    assert torch.equal(a2, a) and logp.shape == (1500, 1) and torch.allclose(logp, want_lp, atol=2e-3)
 
 
 def test_env_built_before_fork_runs_in_worker_processes():
