@@ -268,9 +268,12 @@ def run_imitation(args, rank, local_rank, world, dist, dev):
     rew_acc = torch.zeros(N, device=dev); end_acc = torch.zeros(N, dtype=torch.int32, device=dev)
     for i in range(args.steps):
         a = env.reference_actions()                              # the stand-in policy (one clip lookup launch + two elementwise ones)
-        ev0[i].record()
-        env.step(a)                                              # fused: schedule + the one step launch; --unfused: the whole sequence
-        ev1[i].record()
+        if env.fused:
+            env.step(a, _events=(ev0[i], ev1[i]))                # events around the ONE launch of the step (ss_imitation_step_fused)
+        else:
+            ev0[i].record()
+            env.step(a)                                          # --unfused: the whole launch sequence
+            ev1[i].record()
         rew_acc.add_(env.rew_buf); end_acc.add_(env.terminated); end_acc.add_(env.truncated)
     rew_sum, ended = rew_acc.mean(), end_acc.sum()
     shard.barrier(dist, world, dev)
@@ -293,13 +296,26 @@ def run_imitation(args, rank, local_rank, world, dist, dev):
     e1.record(); Gpu.sync()
     cook_ms = e0.elapsed_time(e1) / 20
     if rank == 0:
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic_imitation.json")
-        if os.path.exists(tpath) and N == 1024:
-            traffic, traffic_src = json.load(open(tpath))["bytes_per_step_launch"], "profiles/hbm_traffic_imitation.json"
-        im_bytes = 4 * (18 * J + 2 * 2 * 13 * J + 24 * J + 5) + 1          # sim state + 2 lookups x 2 frames + obs, reward, parts, flag
+        # dominant kernel = the step launch itself (the IMIT instantiation of ss_env_kernel: physics + imitation task + re-initialisation of
+        # finished envs).  Algorithmic bytes per env-step: the stepper's state in / out and the self observation (SURVEY 8d formula) plus the
+        # imitation part: two clip lookups (t: reward / termination, t + dt: task observation) of two frames x 13 J floats each, the task
+        # observation (24 J), reward + 4 parts + flag.  PMC figures from the committed passes of this command (tools/gpu_prof.sh).
+        step_bytes = algorithmic_bytes(env.base.nq, env.base.nv, env.base.nu, env.self_obs_size)
+        im_bytes = 4 * (2 * 2 * 13 * J + 24 * J + 5) + 1
         cook_bytes = 4 * (75 + 13 * J + 4 * J + 6 * J + 6 * (J - 1) + 76 + 75)  # raw clip in; gts,grs,lrs,gvs,gavs,dof_pos,dvs,qpos,qvel out
-        ach = N * im_bytes / (im_ms * 1e-3) / 1e9
+        bstep = step_bytes + im_bytes
+        ach = N * bstep / (kern_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "traffic_unit": "bytes per step launch",
+                "kernel": "ss_env_kernel<IMIT> via ss_imitation_step_fused" if env.fused else "launch sequence ss_step .. ss_imitation_step (--unfused)",
+                "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": bstep,
+                "algorithmic_bytes_split": {"stepper_state_and_self_obs": step_bytes, "clip_lookups_task_obs_reward": im_bytes},
+                "waves_per_cu": env.base.launch_info()["envs_per_workgroup"],
+                "imitation_task_alone": {"kernel": "ss_imitation_kernel<32> (the task part as its own launch, not part of the timed loop)",
+                                         "kernel_ms": im_ms, "GB/s": N * (im_bytes + 4 * 18 * J) / (im_ms * 1e-3) / 1e9},
+                "note": "the step launch is the physics of the env step (LDS-latency / VALU bound like the headline kernel, DESIGN.md); "
+                        f"{N} envs are launched as ceil(N / CUs) envs per workgroup over all CUs"}
+        roof.update(pmc_summary("imitation", N))
         out = {
             "metric": "env-steps/sec (whole node), motion-imitation rollout", "value": shard.whole_job_throughput(N * world * args.steps, elapsed),
             "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -308,13 +324,11 @@ def run_imitation(args, rank, local_rank, world, dist, dev):
                        "parallelism": f"independent shards x{world} (no collective)", "launch": env.base.launch_info(),
                        "mean_reward": float(rew_sum.item()) / args.steps, "episodes_ended": int(ended.item()),
                        "obs_finite": bool(torch.isfinite(env.obs_buf).all().item()), "parity_pin": PARITY_PIN,
-                       "env_step_ms (events around env.step)": kern_ms, "fused_step": bool(env.fused), "load_motions_s (upload + cook)": load_s,
+                       "fused_step": bool(env.fused), "load_motions_s (upload + cook)": load_s,
+                       "mean_newton_iters_per_step": float(env.base.solver_iters.float().mean().item()),
                        "cook": {"ms": cook_ms, "frames_per_s": F / (cook_ms * 1e-3), "GB/s": F * cook_bytes / (cook_ms * 1e-3) / 1e9,
                                 "algorithmic_bytes_per_frame": cook_bytes}},
-            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_unit": "bytes per launch", "traffic_source": traffic_src, "kernel": "ss_imitation_kernel<32>", "kernel_ms": im_ms, "algorithmic_bytes_per_env_step": im_bytes,
-                         "note": f"{N} envs x {im_bytes} B is far below what fills HBM for the ~us a launch lasts: launch-latency bound at this size; "
-                                 "the step's time is the physics part of the step launch (env_step_ms)"},
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_motion()

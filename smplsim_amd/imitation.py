@@ -129,7 +129,8 @@ class SMPLSimImitationVecEnv:
         self.obs_buf[:, :self.self_obs_size] = b.obs_buf
         return self.obs_buf, {"critic_state": self.obs_buf}
 
-    def step(self, actions):
+    def step(self, actions, _events=None):
+        """_events: (start, end) torch.cuda.Event pair recorded around the step launch itself (bench.py's kernel time; fused only)."""
         b = self.base
         if self.fused:
             actions = actions.to(torch.float32).contiguous()
@@ -139,7 +140,11 @@ class SMPLSimImitationVecEnv:
             self._bind()
             if b.lpt_order:
                 _check(lib().ss_schedule_longest_first(b.handle, b._stream()))
+            if _events:
+                _events[0].record()
             _check(lib().ss_imitation_step_fused(b.handle, _ptr(actions), _ptr(rand), b._stream()))
+            if _events:
+                _events[1].record()
             if b.lpt_order:
                 _check(lib().ss_set_order(b.handle, None))
             # the flag bytes are 0 / 1: viewed, not converted (no launch)
