@@ -194,6 +194,10 @@ def reference_contact_set(args, rank, local_rank, dev, humanoid_model, workload_
     abuf = torch.empty(N, env.nu, device=dev)
     for _ in range(warmup):
         env.step(abuf.uniform_(-1.0, 1.0, generator=g))
+    from smplsim_amd._lib import lib
+    from smplsim_amd.batch import _check, _ptr
+    trunc = torch.zeros(N, dtype=torch.int32, device=dev)       # mj_steps whose body-body contact list exceeded the kernel's capacity
+    _check(lib().ss_debug_self_truncation(env.handle, _ptr(trunc)))
     ev0 = [Gpu.event() for _ in range(steps)]; ev1 = [Gpu.event() for _ in range(steps)]
     Gpu.sync()
     t0 = time.perf_counter()
@@ -209,6 +213,9 @@ def reference_contact_set(args, rank, local_rank, dev, humanoid_model, workload_
             "envs_with_body_body_contact_frac": float((env.self_contacts > 0).float().mean().item()),
             "mean_body_body_contacts": float(env.self_contacts.float().mean().item()),
             "max_body_body_contacts_kept": int(env.self_contacts.max().item()),
+            "truncated_mj_step_frac": float(trunc.sum().item()) / (N * steps * 15),
+            "truncation": "SS_MAX_SELF_CONTACTS = 8 (the deepest are kept; MuJoCo keeps all): fraction of mj_steps of the timed steps whose "
+                          "list was cut; what it changes is measured in profiles/r03_selfcol_truncation.txt (oracle capped vs uncapped)",
             "note": "self_collision=True: capsule-capsule / capsule-box / box-box between all non-excluded, non-adjacent body pairs, "
                     "as mj_step collides the reference MJCF"}
 

@@ -219,6 +219,10 @@ int ss_debug_forward(ss_batch *b, const float *torques, float *M, float *bias, f
  * body-body contact records of each env's last forward pass (mjData.contact of the body pairs): body1 body2 | world position 3 |
  * normal body1->body2 3 | first tangent 3 | 1/R of the pyramid rows | aref 4 | jar 4 | jd 4 ; NULL turns it off. */
 int ss_debug_self_contacts(ss_batch *b, float *records);
+/* Diagnostics (self_collision batches): counts [N] (int32, caller-owned, NULL = off) — every mj_step of env n whose narrow phase
+ * found more than SS_MAX_SELF_CONTACTS body-body contacts (only the deepest are kept; MuJoCo keeps all: the reference MJCF asks for
+ * nconmax 700, smpl_humanoid.xml:293) adds 1 to counts[n].  bench.py reports the rate as reference_contact_set.truncated_mj_step_frac. */
+int ss_debug_self_truncation(ss_batch *b, int32_t *counts);
 /* ---- caller side of the path: device-side generalised advantage estimation for the PPO sampler that
  * feeds ss_step.  The rollout is stored time-major [T,N]; one recursion per env column, exactly the loop of the
  * reference's estimate_advantages (smpl_sim/learning/learning_utils.py:198-218):

@@ -48,6 +48,7 @@ struct ss_batch {
   static ss::real *R(float *p) { return reinterpret_cast<ss::real *>(p); }               // C-ABI arrays as the kernel's scalar type
   static const ss::real *R(const float *p) { return reinterpret_cast<const ss::real *>(p); }
   float *dbg_self = nullptr;              // caller-owned, optional (ss_debug_self_contacts)
+  int32_t *self_trunc = nullptr;          // caller-owned, optional [N] (ss_debug_self_truncation)
   float *power = nullptr;                 // caller-owned, optional [N, control_freq_inv, nv - 6] (ss_set_power_output)
   int fixed_envs_per_wg = 0, max_wgs = 0; // ss_set_launch_geometry: 0 = automatic (small batches are spread over all CUs)
   mutable std::string err;                // message of the last failed call that took this handle
@@ -209,7 +210,7 @@ struct ss_api {
     k.prof = b->d_prof;
     k.order = b->order;
     if (mode == ss::MODE_STEP || mode == ss::MODE_RESET) { k.out0 = ss_batch::R(b->body_xpos); k.out1 = ss_batch::R(b->body_xmat); }
-    if (mode == ss::MODE_STEP) k.power = ss_batch::R(b->power);
+    if (mode == ss::MODE_STEP) { k.power = ss_batch::R(b->power); k.self_trunc = b->self_trunc; }
     return k;
   }
   static int run(const ss_batch *b, const ss::KArgs &k, void *stream) {
@@ -376,6 +377,10 @@ struct ss_api {
   int ss_set_power_output(ss_batch *b, float *power) { ss::HandleScope hs_(b ? &b->err : nullptr);                                                               \
     if (!b) return ss_api<BE>::fail(SS_ERR_INVALID, "null batch");                                                  \
     b->power = power; return SS_OK;                                                                                  \
+  }                                                                                                                  \
+  int ss_debug_self_truncation(ss_batch *b, int32_t *counts) { ss::HandleScope hs_(b ? &b->err : nullptr);                                                       \
+    if (!b) return ss_api<BE>::fail(SS_ERR_INVALID, "null batch");                                                  \
+    b->self_trunc = counts; return SS_OK;                                                                            \
   }                                                                                                                  \
   int ss_debug_self_contacts(ss_batch *b, float *records) { ss::HandleScope hs_(b ? &b->err : nullptr);                                                           \
     if (!b) return ss_api<BE>::fail(SS_ERR_INVALID, "null batch");                                                  \

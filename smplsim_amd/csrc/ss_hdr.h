@@ -211,6 +211,7 @@ struct KArgs {
   const float *im_rand;       // [N,2] uniform draws for the re-initialisation of finished envs, or null = none
   int32_t *work_counter_next; // the counter of the NEXT launch on this batch: zeroed by this one (no memset between launches)
   real *power;                // optional [N, nsub, nv - 6]: |torque * velocity| per mj_step (ss_set_power_output; body-output instantiations)
+  int32_t *self_trunc;        // optional [N]: += 1 per mj_step whose body-body contact list was cut to kMaxSelf (ss_debug_self_truncation)
 };
 
 // floats of one env's LDS slice for this launch

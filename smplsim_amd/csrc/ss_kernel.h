@@ -703,7 +703,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
         for (int i = 0; i < 3; i++) this->gc[3 * lane + i] = rb[i] + Rb[3 * i] * gcst[0] + Rb[3 * i + 1] * gcst[1] + Rb[3 * i + 2] * gcst[2];
       }
       w->sync();
-      int ncand = 0, nlist = 0;
+      int ncand = 0, nlist = 0, over = 0;
       const int npass = (npair + 63) >> 6;
       // the pair table entry of the NEXT round is requested before this round's test: one global round trip per round would
       // otherwise sit in front of every ballot (the bodies' reaches are folded into the table: no second, dependent load)
@@ -761,7 +761,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
             }
             ncand += tot;
           }
-          if (ncand > kSelfCand) ncand = kSelfCand;
+          if (ncand > kSelfCand) { ncand = kSelfCand; over = 1; }
           nlist = 0;
           w->sync();
         }
@@ -823,6 +823,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       if (slot >= 0) for (int i = 0; i < kSelfRec; i++) this->rec[kSelfRec * slot + i] = rcd[i];
       SS_FTICK(PF_SC_NARROW);
       if (write_count && lane == 0 && k->st.self_contacts) k->st.self_contacts[env] = nk;
+      if (lane == 0 && k->self_trunc && (over || ncand > kMaxSelf)) k->self_trunc[env] += 1;   // this mj_step's list was cut
       if (write_count && k->dbg_self && slot >= 0)           // diagnostics: positions made absolute
         for (int i = 0; i < kSelfRec; i++) k->dbg_self[((size_t)env * kMaxSelf + slot) * kSelfRec + i] = rcd[i] + (i >= RC_POS && i < RC_POS + 3 ? q[i - RC_POS] : real(0));
       w->sync();

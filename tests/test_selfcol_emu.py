@@ -119,6 +119,17 @@ def test_capacity_rule_keeps_the_deepest_eight():
     assert eb.self_contacts[0] == 8
     assert np.abs(qacc - d8.qacc).max() < 1e-9 * np.abs(d8.qacc).max()
     assert np.abs(qacc - da.qacc).max() > 1e-6 * np.abs(da.qacc).max()
+    # the truncation counter (ss_debug_self_truncation): one count per mj_step whose list was cut, none for a sparse state
+    import ctypes as C
+    eb2 = emu.EmuBatch(mc, pd_tables(mc), 2, legal_bodies=FEET, f64=True, self_collision=True)
+    eb2.set_state(np.stack([found, default_qpos(76)]), np.zeros((2, 75)))
+    cnt = np.zeros(2, np.int32)
+    eb2._chk(eb2.L.ss_debug_self_truncation(eb2.batch, cnt.ctypes.data_as(C.c_void_p)))
+    eb2.substep(np.zeros((2, 69)), 1)
+    assert cnt[0] == 0 and cnt[1] == 0                        # substep launches are not counted (MODE_STEP only)
+    eb2.cur_t[:] = 0
+    eb2.step(np.zeros((2, 69)))
+    assert 1 <= cnt[0] <= 15 and cnt[1] == 0
 
 
 def test_teacher_forced_control_steps_with_self_collision():
