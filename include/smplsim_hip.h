@@ -178,8 +178,10 @@ int ss_step(ss_batch *b, const float *actions, const float *task_rand, float *ob
  * order).  The persistent wavefronts pull env ids in this order; passing the envs sorted by their previous step's
  * `solver_iters` (descending) starts the expensive ones first (longest-processing-time-first). */
 int ss_set_order(ss_batch *b, const int32_t *order);
-/* Same hint computed on the device: hand the envs out by decreasing ss_state.solver_iters of the last step (counting
- * sort in one small launch on `stream`, library-owned buffer); stays in force until ss_set_order(b, NULL/other). */
+/* Same hint computed on the device from what the previous step left in ss_state: the envs are handed out by decreasing
+ *   key = solver_iters + 6 (bodies touching the floor) + 8 ln(1 + max |qacc_warm|) + 8 ln(1 + max |qvel|),
+ * a predictor of the coming step's Newton-iteration count (profiles/r03_lpt_features.txt) — two small launches on `stream`
+ * (key per env, counting sort), library-owned buffers; stays in force until ss_set_order(b, NULL/other). */
 int ss_schedule_longest_first(ss_batch *b, void *stream);
 
 /* ss_step followed, in the same launch, by the reset of every env whose episode just ended (terminated | truncated) —

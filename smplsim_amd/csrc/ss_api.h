@@ -43,7 +43,7 @@ struct ss_batch {
   int32_t *d_counter = nullptr;
   unsigned long long *d_prof = nullptr;   // SS_PROFILE builds only
   const int32_t *order = nullptr;         // caller-owned device array or null
-  int32_t *d_sched = nullptr;             // library-owned [N] hand-out order written by ss_schedule_longest_first
+  int32_t *d_sched = nullptr;             // library-owned [2N]: hand-out order written by ss_schedule_longest_first, then its keys
   float *body_xpos = nullptr, *body_xmat = nullptr;   // caller-owned, optional: written by every step / reset (ss_set_body_outputs)
   static ss::real *R(float *p) { return reinterpret_cast<ss::real *>(p); }               // C-ABI arrays as the kernel's scalar type
   static const ss::real *R(const float *p) { return reinterpret_cast<const ss::real *>(p); }
@@ -389,9 +389,9 @@ struct ss_api {
   int ss_schedule_longest_first(ss_batch *b, void *stream) { ss::HandleScope hs_(b ? &b->err : nullptr);                                                        \
     if (!b) return ss_api<BE>::fail(SS_ERR_INVALID, "null batch");                                                  \
     if (!BE::set_device(b->m->device)) return ss_api<BE>::fail(SS_ERR_HIP, "cannot select device");                  \
-    if (!b->d_sched) b->d_sched = (int32_t *)BE::alloc(sizeof(int32_t) * (size_t)b->st.num_envs);                      \
+    if (!b->d_sched) b->d_sched = (int32_t *)BE::alloc(2 * sizeof(int32_t) * (size_t)b->st.num_envs);                  \
     if (!b->d_sched) return ss_api<BE>::fail(SS_ERR_NOMEM, "device allocation failed");                              \
-    const char *err = BE::order_by_iters(b->st.solver_iters, b->d_sched, b->st.num_envs, stream);                     \
+    const char *err = BE::order_by_key(b->st, b->m->hm.h.nv, b->d_sched + b->st.num_envs, b->d_sched, stream);         \
     if (err) return ss_api<BE>::fail(SS_ERR_HIP, err);                                                               \
     b->order = b->d_sched; return SS_OK;                                                                             \
   }                                                                                                                  \

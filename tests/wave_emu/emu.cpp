@@ -9,6 +9,7 @@
 // other's LDS writes across sync points — a stricter model than lock-step SIMT, which makes missing
 // syncs show up as wrong answers here.  Each collective carries a site id that is checked for
 // convergence (all lanes must arrive at the same site).
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -230,10 +231,22 @@ struct EmuBackend {
   static int lds_capacity() { return 160 * 1024; }
   static int kernel_regs() { return 0; }
   static int max_waves(int, int) { return 16; }
-  static const char *order_by_iters(const int32_t *iters, int32_t *order, int n, void *) {
+  static const char *order_by_key(const ss_state &st, int nv, int32_t *key, int32_t *order, void *) {   // same key as ss_key_kernel
+    const int n = st.num_envs;
+    const ss::real *qv = reinterpret_cast<const ss::real *>(st.qvel), *qa = reinterpret_cast<const ss::real *>(st.qacc_warm);
+    for (int e = 0; e < n; e++) {
+      float vm = 0.f, am = 0.f;
+      for (int i = 0; i < nv; i++) {
+        const float v = fabsf((float)qv[(size_t)e * nv + i]), a = fabsf((float)qa[(size_t)e * nv + i]);
+        vm = fmaxf(vm, v == v ? v : 1e6f); am = fmaxf(am, a == a ? a : 1e12f);
+      }
+      const int tc = __builtin_popcount((unsigned)st.touch[2 * e]) + __builtin_popcount((unsigned)st.touch[2 * e + 1]);
+      const float k = (float)st.solver_iters[e] + 6.f * (float)tc + 8.f * log1pf(fminf(am, 1e12f)) + 8.f * log1pf(fminf(vm, 1e6f));
+      key[e] = (int32_t)fminf(fmaxf(k, 0.f), 1023.f);
+    }
     std::vector<int> idx(n);
     for (int i = 0; i < n; i++) idx[i] = i;
-    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return iters[a] > iters[b]; });
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return key[a] > key[b]; });
     for (int i = 0; i < n; i++) order[i] = idx[i];
     return nullptr;
   }
