@@ -91,8 +91,8 @@ def pmc_summary(workload, n_envs):
     j = json.load(open(path))
     if j.get("envs_per_gpu") != n_envs:
         return {}
-    keys = ("traffic", "valu_issue_frac", "lds_wait_frac", "lds_bank_conflict_frac", "wave_active_frac", "scratch_bytes_per_lane",
-            "vgprs", "waves_per_cu")
+    keys = ("traffic", "valu_issue_frac", "lds_wait_frac", "lds_bank_conflict_frac", "wave_active_frac", "wave_slot_occupancy",
+            "scratch_bytes_per_lane", "vgprs", "waves_per_cu")
     out = {k: j[k] for k in keys if k in j}
     out["pmc_source"] = "profiles/" + os.path.basename(path) + " (" + j.get("profile", "?") + ")"
     return out

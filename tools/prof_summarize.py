@@ -96,12 +96,16 @@ for kname, cs in summary.get("pmc", {}).items():
     if "hbm_traffic" in summary:
         lim["traffic"] = summary["hbm_traffic"]["bytes_per_step_launch"]
         lim["traffic_method"] = summary["hbm_traffic"]["method"]
-    for k_src, k_dst in (("Scratch_Size", "scratch_bytes_per_lane"), ("VGPR_Count", "vgprs_trace_field"), ("LDS_Block_Size", "lds_bytes_per_workgroup"),
-                         ("Workgroup_Size", "workgroup_size")):
+    # (LDS_Block_Size is not reported: the kernel's LDS is dynamic and the trace field shows 0.  VGPR_Count: rocprofv3 decodes the
+    # kernel descriptor's granulated count with the pre-gfx90a granule of 4 — (20 + 1) x 4 = 84 for this kernel; on gfx950 the
+    # granule is 8: (20 + 1) x 8 = 168 = .amdhsa_next_free_vgpr = hipFuncGetAttributes().numRegs = ss_launch_info's value)
+    for k_src, k_dst in (("Scratch_Size", "scratch_bytes_per_lane"), ("VGPR_Count", "vgprs_trace_field_granule4"), ("Workgroup_Size", "workgroup_size")):
         try:
             lim[k_dst] = int(res.get(k_src))
         except (TypeError, ValueError):
             pass
+    if lim.get("vgprs_trace_field_granule4"):
+        lim["vgprs"] = 2 * lim["vgprs_trace_field_granule4"]
     if lim.get("workgroup_size"):
         lim["waves_per_cu"] = lim["workgroup_size"] // 64
     summary["limiters"] = lim
