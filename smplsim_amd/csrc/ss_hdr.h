@@ -87,7 +87,8 @@ constexpr Layout make_layout(int nb, int maxlev) {
 // static pair table.  Kept out of Hdr: Hdr's layout is part of the plain kernels' register allocation.
 constexpr int kMaxSelf = SS_MAX_SELF_CONTACTS;   // body-body contacts kept per env (the deepest)
 constexpr int kSelfRec = 24;                     // floats per contact record: b1 b2 | pos3 | n3 | t13 | D | aref4 | jar4 | jd4 | pad
-constexpr int kSelfCand = 32;                    // narrow-phase candidates before the deepest kMaxSelf are kept
+constexpr int kSelfCand = 56;                    // narrow-phase candidates before the deepest kMaxSelf are kept (10 floats each in the Delassus block's
+                                                 // storage, 9 kMaxSelf^2 = 576 floats; the selection step runs one lane per candidate)
 constexpr int kGeomC = 16;                       // floats per body in the geom table: gpos3 gsize3 gmat9 (row-major) type
 struct HdrSC {
   int npair;                                     // candidate body pairs of the model (b1 | b2 << 8 each)

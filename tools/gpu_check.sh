@@ -1,8 +1,10 @@
-set -x
-mkdir -p gpurun_out
-python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" 
-tail -8 gpurun_out/smoke.log
-timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"
-tail -15 gpurun_out/pytest_gpu.log
-timeout 600 python bench.py --steps 50 --warmup 5 > gpurun_out/bench1.json 2> gpurun_out/bench1.err; echo "bench rc=$?"
-cat gpurun_out/bench1.json; tail -3 gpurun_out/bench1.err
+# what a gpurun call executes to validate the tree: smoke, the GPU tests, the default bench line (as the driver runs it)
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5
+timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -15
+python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; python -c "
+import json
+d=json.load(open('gpurun_out/bench_default.json')); c=d['config']
+print('value', round(d['value']), 'ms/step', round(d['ms_per_step'],4), 'kernel_ms', round(d['roofline']['kernel_ms'],4), 'frac', d['roofline']['frac'], 'traffic', d['roofline'].get('traffic'), d['roofline'].get('pmc_source'))
+print('reference_contact_set', {k: c['reference_contact_set'][k] for k in ('value','ms_per_step','kernel_ms','frac','envs_per_cu','truncated_mj_step_frac')})
+print('parity_probe', c['parity_probe']); print('cpu_baseline', d['cpu_baseline']['value'], d['cpu_baseline']['cores'])"
