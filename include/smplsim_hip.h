@@ -97,7 +97,10 @@ typedef struct {
    * 1e-8 (the reference MJCF does not override it). */
   float solver_tolerance;
 } ss_env_cfg;
-enum { SS_MAX_SELF_CONTACTS = 8 };
+#ifndef SS_MAX_SELF_CONTACTS_N
+#define SS_MAX_SELF_CONTACTS_N 8          /* build-time capacity (experiment builds: -DSS_MAX_SELF_CONTACTS_N=12) */
+#endif
+enum { SS_MAX_SELF_CONTACTS = SS_MAX_SELF_CONTACTS_N };
 
 /* Device buffers of one shard of environments (all caller-owned, float32 unless noted). */
 typedef struct {
