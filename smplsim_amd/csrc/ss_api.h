@@ -203,6 +203,7 @@ struct ss_api {
     k.h = m->hm.h; k.cfg = b->cfg; k.st = b->st;
     k.shared_g = m->d_shared; k.bodyc = m->d_bodyc; k.candc = m->d_candc; k.candb = m->d_candb;
     k.illegal_mask = m->hm.illegal_mask;
+    k.hc = m->hm.hc;
     k.sc = m->hm.sc; k.pairs = m->d_pairs; k.geomc = m->d_geomc; k.dbg_self = ss_batch::R(b->dbg_self);
     k.mode = mode; k.nsub = b->cfg.control_freq_inv; k.obs_size = b->obs_size;
     k.work_counter = b->d_counter + b->parity; k.work_counter_next = b->d_counter + (b->parity ^ 1);   // run() flips the parity

@@ -80,6 +80,6 @@ __global__ void __launch_bounds__(MAXT) ss_env_kernel(const ss::KArgs k) {
 
 
 typedef ss::HdrFixedT<24, 5> HdrSmpl;                        // SMPL: 24 bodies, at most 5 nodes in a tree level
-typedef ss::HdrFixedT<52, 10> HdrSmplx;                      // SMPL-X/H: 52 bodies, 10 finger nodes per level
+typedef ss::HdrFixedT<52, 12> HdrSmplx;                      // SMPL-X/H: 52 bodies, 12 nodes in the widest level of the centred tree
 
 }  // namespace

@@ -159,6 +159,21 @@ struct HdrFixedT {
   static bool matches(const Hdr &h) { return h.nb == NB && h.maxlev == MAXLEV; }
 };
 
+// Elimination tree of the articulated-body solves of the plain (no body-body contact) instantiations: the body tree re-rooted at its
+// CENTRE.  H x = b is a free-floating tree's system, any body can carry the six free unknowns; eliminating towards the centre
+// instead of towards the pelvis makes the sweeps as deep as the tree's radius, not its height (SMPL: 6 levels instead of 8,
+// SMPL-X: 7 instead of 10).  An edge walked against the kinematic direction uses the same joint with S -> -S; the free joint
+// becomes a bias force on body 0.  Built by ss_tables.h; appended to KArgs (Hdr's layout is part of the kernels' register allocation).
+struct HdrC {
+  int nlev;                    // levels below the root (level 1 = the root's neighbours)
+  int o_lev;                   // word offset of the level records in the shared blob, 2 words per node, level 1 first:
+                               //   word 0: body | joint node << 8 | neighbour towards the root << 16 | (S negated) << 24 | (body 0) << 25
+                               //   word 1: first child's position in the next level | child count << 8
+  int root;                    // root body
+  int pel_level;               // level of body 0 (0 = it is the root)
+  unsigned long long nkpack[2];   // (nodes in level L) - 1, 4 bits per level, level L at bit 4 (L - 1)
+};
+
 // compiled kernel variants: 0 = SMPL-sized (<= 128 dofs / candidates, <= 64 contact slots, <= 8 nodes per tree level),
 // 1 = SMPL-X/H-sized (<= 192 dofs / candidates, <= 128 slots, <= 16 nodes per level); -1 = none fits
 inline int kernel_variant(const Hdr &h) {
@@ -213,6 +228,7 @@ struct KArgs {
   int32_t *work_counter_next; // the counter of the NEXT launch on this batch: zeroed by this one (no memset between launches)
   real *power;                // optional [N, nsub, nv - 6]: |torque * velocity| per mj_step (ss_set_power_output; body-output instantiations)
   int32_t *self_trunc;        // optional [N]: += 1 per mj_step whose body-body contact list was cut to kMaxSelf (ss_debug_self_truncation)
+  HdrC hc;                    // centred elimination tree (aba_solve of the plain instantiations)
 };
 
 // floats of one env's LDS slice for this launch

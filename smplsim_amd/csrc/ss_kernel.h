@@ -115,7 +115,7 @@ template <> struct ShapeTables<true> { const real *bodyc_s, *candc_s, *dinvw_s, 
 template <bool SELFCOL> struct SelfColState {};
 template <> struct SelfColState<true> {
   real *rec, *G, *uvec, *lam, *Pb2, *delta2, *gc;          // per-env LDS arrays (HdrSC)
-  real *Dinv, *rootf, *ysave, *An3;                        // D^-1 per node and the root's block inverses of the last aba_solve; re-solve buffers
+  real *Dinv, *rootf, *ysave, *An3;                        // D's factors (Ldl3) per node and the root's block inverses of the last aba_solve; re-solve buffers
   int nself;                                               // wave-uniform count of body-body contacts of this pass
   // the tree Hessian of consecutive Newton iterations of one mj_step differs only when a floor-contact / joint-limit row changes
   // side: while this lane's rows keep their state (sig) the factorization in LDS and the Delassus columns computed so far stay valid
@@ -293,6 +293,8 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       if (tmp2) A2[idx] = s2;
     }
   }
+
+  static constexpr bool kCentred = !SELFCOL;               // elimination tree of aba_solve (see there)
 
   // ------------------------------------------------------------------ kinematics + velocities + inertia + bias
   // with_dyn = false: positions/orientations only (observation FK)
@@ -1078,7 +1080,224 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
   }
 
   // pb: optional per-body bias force (6 per body): the system solved is  H x = b - sum_b J_b^T pb_b
+  // Plain instantiations eliminate towards the centre of the body tree (aba_solve_centre below); the body-body-contact
+  // instantiations keep the pelvis-rooted sweeps, whose factorization aba_resolve / aba_columns re-use.
   SS_DEV void aba_solve(real *x, const real *pb) {
+    if constexpr (kCentred) aba_solve_centre(x, pb); else aba_solve_pelvis(x, pb);
+  }
+
+  // ---- the same solve with the elimination tree rooted at the centre of the body tree (HdrC, ss_tables.h).
+  // H x = b is the system of a free-floating tree: the six free unknowns may sit on any body.  With the root at the tree's centre
+  // the sweeps are as deep as the tree's radius (SMPL: 6 levels instead of 8 below the pelvis; SMPL-X: 7 instead of 10).  For a node
+  // (body b, joint j, neighbour e towards the root):  a_b = a_e + S' q''_j  with S' = S_j when e is b's kinematic parent and -S_j when
+  // the edge is walked against the kinematic direction (e is b's kinematic child and j is e's joint); minimising the node's energy over
+  // q''_j gives exactly the recursion above with S':  U = IA S', D = S'^T U + diag, u = b_j - S'^T pA, W = U D^-1, y = D^-1 u,
+  // IA' = IA - W U^T, pA' = pA + U y  and  q''_j = y - W^T a_e,  a_b = a_e + S' q''_j  on the way down.  The free joint (identity
+  // motion subspace between the world and body 0) constrains nothing: its right-hand side is a bias force -S_fb b_fb on body 0, and
+  // its solution is read off body 0's acceleration.  The root has no joint: IA a = -pA, a 6x6 system as before.
+  // Storage: (W, y) per BODY in Wst, accelerations per body in An (slot b + 1, as the consumers expect), x per joint dof.
+  SS_DEV void aba_solve_centre(real *x, const real *pb) {
+    fresh();
+    typename HT::type h = HT::view(k->h);
+    const HdrC &hc = k->hc;
+    const int r_ = lane & 7, g = lane >> 3;
+    int off[6];                                              // packed-symmetric offsets of row r_
+#pragma unroll
+    for (int c = 0; c < 6; c++) { const int lo = r_ < c ? r_ : c, hi = r_ < c ? c : r_; off[c] = (lo * (11 - lo)) / 2 + hi; }
+    SS_FT0();
+    const unsigned long long nk0 = hc.nkpack[0], nk1 = hc.nkpack[1];
+    auto NKC = [&](int L) { return (int)((((L - 1) < 16 ? nk0 : nk1) >> (4 * ((L - 1) & 15))) & 15ull) + 1; };   // nodes of level L >= 1
+    // the free joint's right-hand side as a force on body 0 (row r_):  (S_fb b_fb)_r = R b_rot (angular rows; node 1's S holds the
+    // columns of R) ; b_trans (linear rows)
+    auto fb_force = [&]() { return r_ < 3 ? S[18 + r_] * x[3] + S[24 + r_] * x[4] + S[30 + r_] * x[5] : x[r_ - 3]; };
+    int s0 = h.nb - 1;                                        // records of level L start at s0(L) = (nodes of the levels before it)
+    for (int L = hc.nlev; L >= 1; --L) {
+      const int nk = NKC(L);
+      s0 -= nk;
+      real *cur = IA + (L & 1) * h.ia_stride;
+      const real *prev = IA + ((L + 1) & 1) * h.ia_stride;
+      real row[NPASS][6], pa[NPASS], Ur[NPASS][3], red[NPASS][9];
+      int nod[NPASS], jnt[NPASS];
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ps++) {                    // ---- part 1: articulated row, U_r = IA_r S', partial S'^T U
+        const int kk = ps * 8 + g;
+        nod[ps] = -1; jnt[ps] = 0;
+#pragma unroll
+        for (int t = 0; t < 9; t++) red[ps][t] = 0.f;
+        if (r_ < 6 && kk < nk) {
+          const int e0 = ti(hc.o_lev, 2 * (s0 + kk)), e1 = ti(hc.o_lev, 2 * (s0 + kk) + 1);
+          const int b = e0 & 255, jn = (e0 >> 8) & 255, cfirst = e1 & 255, cc = (e1 >> 8) & 255;
+          const real sgn = (e0 >> 24) & 1 ? real(-1) : real(1);
+          nod[ps] = b; jnt[ps] = jn;
+          real rw[6], pv = pb ? pb[6 * b + r_] : 0.f;
+          if ((e0 >> 25) & 1) pv -= fb_force();
+          const real *ao = Aown + 21 * b;
+#pragma unroll
+          for (int c = 0; c < 6; c++) rw[c] = ao[off[c]];
+          real sv[18];                                       // S_j: issued before the child loop, consumed after it
+          const real *sn = S + 18 * jn;
+#pragma unroll
+          for (int t = 0; t < 18; t++) sv[t] = sn[t];
+          const real sr0 = sgn * sn[r_], sr1 = sgn * sn[6 + r_], sr2 = sgn * sn[12 + r_];   // row r of S'
+          for (int j = 0; j < cc; j++) {
+            const real *src = prev + ((cfirst + j) * 6 + r_) * 8;
+            const float4_t v0 = ld4(src), v1 = ld4(src + 4);
+            rw[0] += v0.x; rw[1] += v0.y; rw[2] += v0.z; rw[3] += v0.w; rw[4] += v1.x; rw[5] += v1.y; pv += v1.z;
+          }
+#pragma unroll
+          for (int j = 0; j < 3; j++) {
+            real acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < 6; c++) acc += rw[c] * sv[6 * j + c];
+            Ur[ps][j] = sgn * acc;
+          }
+#pragma unroll
+          for (int c = 0; c < 6; c++) row[ps][c] = rw[c];
+          pa[ps] = pv;
+          st4w(Ubuf + (kk * 6 + r_) * 4, Ur[ps][0], Ur[ps][1], Ur[ps][2], pv);
+          red[ps][0] = sr0 * Ur[ps][0]; red[ps][1] = sr1 * Ur[ps][0]; red[ps][2] = sr1 * Ur[ps][1];
+          red[ps][3] = sr2 * Ur[ps][0]; red[ps][4] = sr2 * Ur[ps][1]; red[ps][5] = sr2 * Ur[ps][2];
+          red[ps][6] = sr0 * pv; red[ps][7] = sr1 * pv; red[ps][8] = sr2 * pv;
+        }
+      }
+      SS_FTICK(PF_F_P13);
+      w->sync();                                              // U rows visible to the node's other lanes
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ps++)
+#pragma unroll
+        for (int t = 0; t < 9; t++) red[ps][t] = w->sum8(red[ps][t]);
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ps++) {                    // ---- part 2: joint-space 3x3 algebra, rows handed towards the root
+        const int kk = ps * 8 + g, b = nod[ps], jn = jnt[ps];
+        if (b >= 0) {
+          float4_t U[6];
+#pragma unroll
+          for (int c = 0; c < 6; c++) U[c] = ld4(Ubuf + (kk * 6 + c) * 4);
+          const real u0 = x[3 * jn] - red[ps][6], u1 = x[3 * jn + 1] - red[ps][7], u2 = x[3 * jn + 2] - red[ps][8];
+          Ldl3 Dj;
+          Dj.factor(red[ps][0] + diag[3 * jn], red[ps][1], red[ps][2] + diag[3 * jn + 1], red[ps][3], red[ps][4], red[ps][5] + diag[3 * jn + 2]);
+          real y0, y1, y2, w0, w1, w2;
+          Dj.solve(u0, u1, u2, y0, y1, y2);
+          const real a0 = Ur[ps][0], a1 = Ur[ps][1], a2 = Ur[ps][2];
+          Dj.solve(a0, a1, a2, w0, w1, w2);
+          real rn[6];
+#pragma unroll
+          for (int c = 0; c < 6; c++) rn[c] = row[ps][c] - (w0 * U[c].x + w1 * U[c].y + w2 * U[c].z);
+          const real pn = pa[ps] + a0 * y0 + a1 * y1 + a2 * y2;
+          real *dst = cur + (kk * 6 + r_) * 8;
+          st4w(dst, rn[0], rn[1], rn[2], rn[3]); st4w(dst + 4, rn[4], rn[5], pn, 0.f);
+          st4w(Wst + (b * 6 + r_) * 4, w0, w1, w2, r_ == 0 ? y0 : (r_ == 1 ? y1 : y2));
+        }
+      }
+      SS_FTICK(PF_F_P2);
+      w->sync();
+    }
+    // ---- root body: no joint, IA a = -pA (the free joint's force too when the root is body 0)
+    {
+      real *rows = IA;                                        // level 1 wrote buffer 1; buffer 0 is free
+      const real *prev = IA + h.ia_stride;
+      const int c_ = hc.root, cc = hc.nlev >= 1 ? NKC(1) : 0;   // every node of level 1 is a child of the root
+      if (lane < 6) {
+        real rw[6], pv = pb ? pb[6 * c_ + lane] : 0.f;
+        if (c_ == 0) pv -= fb_force();
+        const real *ao = Aown + 21 * c_;
+#pragma unroll
+        for (int c = 0; c < 6; c++) rw[c] = ao[off[c]];
+        for (int j = 0; j < cc; j++) {
+          const real *src = prev + (j * 6 + lane) * 8;
+          const float4_t v0 = ld4(src), v1 = ld4(src + 4);
+          rw[0] += v0.x; rw[1] += v0.y; rw[2] += v0.z; rw[3] += v0.w; rw[4] += v1.x; rw[5] += v1.y; pv += v1.z;
+        }
+        st4w(rows + 8 * lane, rw[0], rw[1], rw[2], rw[3]); st4w(rows + 8 * lane + 4, rw[4], rw[5], -pv, 0.f);
+      }
+      w->sync();
+      real A6[6][6], f6[6];                                   // every lane solves the same 6x6 system
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        const float4_t v0 = ld4(rows + 8 * i), v1 = ld4(rows + 8 * i + 4);
+        A6[i][0] = v0.x; A6[i][1] = v0.y; A6[i][2] = v0.z; A6[i][3] = v0.w; A6[i][4] = v1.x; A6[i][5] = v1.y; f6[i] = v1.z;
+      }
+      // 2x2 block elimination with closed-form 3x3 inverses (as in aba_solve_pelvis)
+      real Ti[6], Si[6];
+      sym3_inverse(A6[3][3], A6[4][3], A6[4][4], A6[5][3], A6[5][4], A6[5][5], Ti);
+      real QT[3][3];
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const real q0 = A6[i][3], q1 = A6[i][4], q2 = A6[i][5];
+        QT[i][0] = q0 * Ti[0] + q1 * Ti[1] + q2 * Ti[2];
+        QT[i][1] = q0 * Ti[1] + q1 * Ti[3] + q2 * Ti[4];
+        QT[i][2] = q0 * Ti[2] + q1 * Ti[4] + q2 * Ti[5];
+      }
+      real Sc[3][3], ga[3];
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int j = 0; j <= i; j++) Sc[i][j] = A6[i][j] - (QT[i][0] * A6[j][3] + QT[i][1] * A6[j][4] + QT[i][2] * A6[j][5]);
+        ga[i] = f6[i] - (QT[i][0] * f6[3] + QT[i][1] * f6[4] + QT[i][2] * f6[5]);
+      }
+      sym3_inverse(Sc[0][0], Sc[1][0], Sc[1][1], Sc[2][0], Sc[2][1], Sc[2][2], Si);
+      const real aa0 = Si[0] * ga[0] + Si[1] * ga[1] + Si[2] * ga[2];
+      const real aa1 = Si[1] * ga[0] + Si[3] * ga[1] + Si[4] * ga[2];
+      const real aa2 = Si[2] * ga[0] + Si[4] * ga[1] + Si[5] * ga[2];
+      const real gl0 = f6[3] - (A6[0][3] * aa0 + A6[1][3] * aa1 + A6[2][3] * aa2);
+      const real gl1 = f6[4] - (A6[0][4] * aa0 + A6[1][4] * aa1 + A6[2][4] * aa2);
+      const real gl2 = f6[5] - (A6[0][5] * aa0 + A6[1][5] * aa1 + A6[2][5] * aa2);
+      f6[0] = aa0; f6[1] = aa1; f6[2] = aa2;
+      f6[3] = Ti[0] * gl0 + Ti[1] * gl1 + Ti[2] * gl2;
+      f6[4] = Ti[1] * gl0 + Ti[3] * gl1 + Ti[4] * gl2;
+      f6[5] = Ti[2] * gl0 + Ti[4] * gl1 + Ti[5] * gl2;
+      if (lane < 6) An[8 * (c_ + 1) + lane] = lane == 0 ? f6[0] : lane == 1 ? f6[1] : lane == 2 ? f6[2] : lane == 3 ? f6[3] : lane == 4 ? f6[4] : f6[5];
+      if (c_ == 0) {                                          // the free joint's solution: x_trans = a_lin, x_rot = R^T a_ang
+        if (lane < 3) x[lane] = lane == 0 ? f6[3] : (lane == 1 ? f6[4] : f6[5]);
+        else if (lane < 6) { const int j = lane - 3; x[lane] = S[18 + 6 * j] * f6[0] + S[18 + 6 * j + 1] * f6[1] + S[18 + 6 * j + 2] * f6[2]; }
+      }
+      w->sync();
+    }
+    SS_FTICK(PF_F_SYNC1);
+    // ---- sweep away from the root:  q''_j = y - W^T a_e,  a_b = a_e + S' q''_j  (row-distributed: one W row per lane, DPP sums)
+    s0 = 0;
+    for (int L = 1; L <= hc.nlev; L++) {
+      const int nk = NKC(L);
+      const bool pel_level = L == hc.pel_level;               // wave-uniform: this level holds body 0
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ps++) {
+        const int kk = ps * 8 + g;
+        int b = -1, jn = 0, pel = 0;
+        real p0 = 0.f, p1 = 0.f, p2 = 0.f, apr = 0.f, s_0 = 0.f, s_1 = 0.f, s_2 = 0.f;
+        if (r_ < 6 && kk < nk) {
+          const int e0 = ti(hc.o_lev, 2 * (s0 + kk)), en = (e0 >> 16) & 255;
+          b = e0 & 255; jn = (e0 >> 8) & 255; pel = (e0 >> 25) & 1;
+          const real sgn = (e0 >> 24) & 1 ? real(-1) : real(1);
+          const float4_t wr = ld4(Wst + (b * 6 + r_) * 4);
+          const real *sn = S + 18 * jn + r_;
+          s_0 = sgn * sn[0]; s_1 = sgn * sn[6]; s_2 = sgn * sn[12];
+          apr = An[8 * (en + 1) + r_];
+          p0 = wr.x * apr - (r_ == 0 ? wr.w : 0.f); p1 = wr.y * apr - (r_ == 1 ? wr.w : 0.f); p2 = wr.z * apr - (r_ == 2 ? wr.w : 0.f);
+        }
+        p0 = w->sum8(p0); p1 = w->sum8(p1); p2 = w->sum8(p2);   // = -q''_j in every lane of the group
+        real acc = 0.f;
+        if (b >= 0) {
+          acc = apr - (s_0 * p0 + s_1 * p1 + s_2 * p2);
+          An[8 * (b + 1) + r_] = acc;
+          if (r_ < 3) x[3 * jn + r_] = -(r_ == 0 ? p0 : (r_ == 1 ? p1 : p2));
+        }
+        if (pel_level) {                                       // body 0 reached: the free joint's solution from its acceleration
+          real t0 = 0.f, t1 = 0.f, t2 = 0.f;                  // R^T a_ang: lane r < 3 holds component r of a_ang
+          if (pel && r_ < 3) { t0 = S[18 + r_] * acc; t1 = S[24 + r_] * acc; t2 = S[30 + r_] * acc; }
+          t0 = w->sum8(t0); t1 = w->sum8(t1); t2 = w->sum8(t2);
+          if (pel) {
+            if (r_ >= 3 && r_ < 6) x[r_ - 3] = acc;             // x_trans = a_lin
+            else if (r_ < 3) x[3 + r_] = r_ == 0 ? t0 : (r_ == 1 ? t1 : t2);
+          }
+        }
+      }
+      s0 += nk;
+      w->sync();
+    }
+    SS_FTICK(PF_F_BSOL);
+  }
+
+  SS_DEV void aba_solve_pelvis(real *x, const real *pb) {
     fresh();
     typename HT::type h = HT::view(k->h);
     const int r_ = lane & 7, g = lane >> 3;
@@ -1150,16 +1369,13 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
           float4_t U[6];
 #pragma unroll
           for (int c = 0; c < 6; c++) U[c] = ld4(Ubuf + (kk * 6 + c) * 4);
-          const real d00 = red[ps][0] + diag[3 * n], d10 = red[ps][1], d11 = red[ps][2] + diag[3 * n + 1];
-          const real d20 = red[ps][3], d21 = red[ps][4], d22 = red[ps][5] + diag[3 * n + 2];
           const real u0 = x[3 * n] - red[ps][6], u1 = x[3 * n + 1] - red[ps][7], u2 = x[3 * n + 2] - red[ps][8];
-          const real c00 = d11 * d22 - d21 * d21, c01 = d21 * d20 - d10 * d22, c02 = d10 * d21 - d11 * d20;
-          const real id = rcp_nr(d00 * c00 + d10 * c01 + d20 * c02);
-          const real i00 = c00 * id, i01 = c01 * id, i02 = c02 * id;
-          const real i11 = (d00 * d22 - d20 * d20) * id, i12 = (d10 * d20 - d00 * d21) * id, i22 = (d00 * d11 - d10 * d10) * id;
-          const real y0 = i00 * u0 + i01 * u1 + i02 * u2, y1 = i01 * u0 + i11 * u1 + i12 * u2, y2 = i02 * u0 + i12 * u1 + i22 * u2;
+          Ldl3 Dj;
+          Dj.factor(red[ps][0] + diag[3 * n], red[ps][1], red[ps][2] + diag[3 * n + 1], red[ps][3], red[ps][4], red[ps][5] + diag[3 * n + 2]);
+          real y0, y1, y2, w0, w1, w2;
+          Dj.solve(u0, u1, u2, y0, y1, y2);
           const real a0 = Ur[ps][0], a1 = Ur[ps][1], a2 = Ur[ps][2];
-          const real w0 = a0 * i00 + a1 * i01 + a2 * i02, w1 = a0 * i01 + a1 * i11 + a2 * i12, w2 = a0 * i02 + a1 * i12 + a2 * i22;
+          Dj.solve(a0, a1, a2, w0, w1, w2);
           real rn[6];
 #pragma unroll
           for (int c = 0; c < 6; c++) rn[c] = row[ps][c] - (w0 * U[c].x + w1 * U[c].y + w2 * U[c].z);
@@ -1167,7 +1383,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
           real *dst = cur + (kk * 6 + r_) * 8;
           st4w(dst, rn[0], rn[1], rn[2], rn[3]); st4w(dst + 4, rn[4], rn[5], pn, 0.f);
           st4w(Wst + (n * 6 + r_) * 4, w0, w1, w2, r_ == 0 ? y0 : (r_ == 1 ? y1 : y2));
-          if constexpr (SELFCOL) if (r_ == 0) { st4w(this->Dinv + 8 * n, i00, i01, i02, i11); st4w(this->Dinv + 8 * n + 4, i12, i22, 0.f, 0.f); }
+          if constexpr (SELFCOL) if (r_ == 0) { st4w(this->Dinv + 8 * n, Dj.ie0, Dj.ie1, Dj.ie2, Dj.l10); st4w(this->Dinv + 8 * n + 4, Dj.l20, Dj.l21, 0.f, 0.f); }
         }
       }
       SS_FTICK(PF_F_P2);
@@ -1357,15 +1573,16 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
 #pragma unroll
             for (int j = 0; j < 3; j++) red[q_][j] = w->sum8(red[q_][j]);
           if (n >= 0) {
-            const float4_t d0 = ld4(this->Dinv + 8 * n), d1 = ld4(this->Dinv + 8 * n + 4);
+            const Ldl3 Dj = load_ldl(n);
             real *dst = cur + (kk * 6 + r_) * 8;
 #pragma unroll
             for (int q_ = 0; q_ < K; q_++) {
               const real u0 = bf(3 * n, q_) - red[q_][0], u1 = bf(3 * n + 1, q_) - red[q_][1], u2 = bf(3 * n + 2, q_) - red[q_][2];
               dst[q_] = pa[q_] + wr0 * u0 + wr1 * u1 + wr2 * u2;
               if (r_ < 3) {
-                const real yv = r_ == 0 ? d0.x * u0 + d0.y * u1 + d0.z * u2 : (r_ == 1 ? d0.y * u0 + d0.w * u1 + d1.x * u2 : d0.z * u0 + d1.x * u1 + d1.y * u2);
-                ysave[(n * K + q_) * 4 + r_] = yv;
+                real s0, s1, s2;
+                Dj.solve(u0, u1, u2, s0, s1, s2);
+                ysave[(n * K + q_) * 4 + r_] = r_ == 0 ? s0 : (r_ == 1 ? s1 : s2);
               }
             }
           }
@@ -1518,9 +1735,9 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
             real *dst = cur + (kk * 12 + q_) * 6;
 #pragma unroll
             for (int r_ = 0; r_ < 6; r_++) { const float4_t wv = ld4(Wst + (n * 6 + r_) * 4); dst[r_] = pa[r_] + wv.x * u[0] + wv.y * u[1] + wv.z * u[2]; }
-            const float4_t d0 = ld4(this->Dinv + 8 * n), d1 = ld4(this->Dinv + 8 * n + 4);
+            const Ldl3 Dj = load_ldl(n);
             real *yo = ys + (n * 12 + q_) * 3;
-            yo[0] = d0.x * u[0] + d0.y * u[1] + d0.z * u[2]; yo[1] = d0.y * u[0] + d0.w * u[1] + d1.x * u[2]; yo[2] = d0.z * u[0] + d1.x * u[1] + d1.y * u[2];
+            Dj.solve(u[0], u[1], u[2], yo[0], yo[1], yo[2]);
           }
         }
         w->sync();
@@ -1589,6 +1806,36 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
         w->sync();
       }
     }
+  }
+
+  // The joint-space 3x3 D = S^T IA S + diag of a node, factored D = L E L^T (L unit lower triangular, E diagonal) and applied by
+  // substitution.  The point is the residual, not the cost: W = U D^-1 has to satisfy W D = U to rounding for the downdate
+  // IA' = IA - W U^T to take the joint's freedom out of IA exactly (IA' S = U - W D = 0).  A substitution solve is backward
+  // stable whatever D's condition; an explicit cofactor inverse leaves W D - U ~ cond(D) x 6e-8, which acts as a spurious
+  // joint stiffness.  D of a trunk joint carries the legs on one side in the centred tree (twist axis vs bending axes: condition
+  // ~30): with the cofactor inverse its dofs were 4x less accurate than with this (profiles/r03_centred_elimination.md).
+  struct Ldl3 {
+    real ie0, ie1, ie2, l10, l20, l21;
+    SS_DEV void factor(real d00, real d10, real d11, real d20, real d21, real d22) {
+      ie0 = rcp_nr(d00); l10 = d10 * ie0; l20 = d20 * ie0;
+      const real t21 = d21 - l20 * d10;
+      ie1 = rcp_nr(d11 - l10 * d10); l21 = t21 * ie1;
+      ie2 = rcp_nr(d22 - l20 * d20 - l21 * t21);
+    }
+    SS_DEV void solve(real b0, real b1, real b2, real &s0, real &s1, real &s2) const {
+      const real z1 = b1 - l10 * b0, z2 = b2 - l20 * b0 - l21 * z1;
+      s2 = z2 * ie2; s1 = z1 * ie1 - l21 * s2; s0 = b0 * ie0 - l10 * s1 - l20 * s2;
+    }
+  };
+
+  // node n's factors as aba_solve_pelvis left them (body-body-contact instantiations: the re-solves apply D^-1 to new right-hand sides)
+  SS_DEV Ldl3 load_ldl(int n) const {
+    Ldl3 f;
+    if constexpr (SELFCOL) {
+      const float4_t d0 = ld4(this->Dinv + 8 * n), d1 = ld4(this->Dinv + 8 * n + 4);
+      f.ie0 = d0.x; f.ie1 = d0.y; f.ie2 = d0.z; f.l10 = d0.w; f.l20 = d1.x; f.l21 = d1.y;
+    }
+    return f;
   }
 
   // inverse of the symmetric 3x3 [d00 d10 d20; d10 d11 d21; d20 d21 d22] -> (i00 i01 i02 i11 i12 i22)

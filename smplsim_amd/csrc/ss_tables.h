@@ -34,6 +34,7 @@ struct HostModel {
                                   // b1 -> b2), and the float bits of the pair's bounding-sphere reach r1 + r2 + margin (broad phase)
   std::vector<real> geomc;        // [nb][kGeomC] geoms in their body frames (pair functions of the SELFCOL kernels)
   HdrSC sc{};
+  HdrC hc{};                      // centred elimination tree of the plain solves
   double meaninertia = 0;         // mjModel.stat.meaninertia (scale of the solver's termination test)
   std::string error;
 };
@@ -253,6 +254,57 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
     }
     h.n_sumsmall = (int)small_l.size(); h.n_sumbig = (int)big_l.size();
     h.o_sumsmall = push_i(small_l); h.o_sumbig = push_i(big_l); h.o_sumcover = push_i(cover);
+  }
+  {
+    // ---- centred elimination tree (HdrC): the root minimises the depth (ties: the narrower widest level, then the lower index);
+    // the widest level may not exceed 16 nodes (two passes of 8 lane groups)
+    std::vector<std::vector<int>> adj(nb);
+    for (int b = 1; b < nb; b++) { adj[b].push_back(d.body_parent[b]); adj[d.body_parent[b]].push_back(b); }
+    auto bfs = [&](int c, std::vector<int> &dep, std::vector<int> &towards) {
+      dep.assign(nb, -1); towards.assign(nb, -1);
+      std::vector<int> q{c}; dep[c] = 0;
+      for (size_t i = 0; i < q.size(); i++) for (int o : adj[q[i]]) if (dep[o] < 0) { dep[o] = dep[q[i]] + 1; towards[o] = q[i]; q.push_back(o); }
+    };
+    int best = 0, bestd = 1 << 30, bestw = 1 << 30;
+    std::vector<int> dep, tw;
+    for (int c = 0; c < nb; c++) {
+      bfs(c, dep, tw);
+      int dmax = 0; for (int b = 0; b < nb; b++) dmax = std::max(dmax, dep[b]);
+      std::vector<int> wd(dmax + 1, 0); for (int b = 0; b < nb; b++) wd[dep[b]]++;
+      int wmax = 0; for (int L = 1; L <= dmax; L++) wmax = std::max(wmax, wd[L]);
+      if (wmax > 16) continue;
+      if (dmax < bestd || (dmax == bestd && wmax < bestw)) { best = c; bestd = dmax; bestw = wmax; }
+    }
+    bfs(best, dep, tw);
+    bestd = 0; for (int b = 0; b < nb; b++) bestd = std::max(bestd, dep[b]);
+    HdrC &hc = out.hc;
+    hc.root = best; hc.nlev = bestd; hc.pel_level = dep[0]; hc.nkpack[0] = hc.nkpack[1] = 0ull;
+    if (bestd > 32) { out.error = "tree too deep"; return false; }
+    // level lists: children of one node contiguous, in the order of their parents' positions
+    std::vector<std::vector<int>> levb(bestd + 1);
+    levb[0].push_back(best);
+    for (int L = 1; L <= bestd; L++)
+      for (int pb_ : levb[L - 1]) for (int b = 0; b < nb; b++) if (dep[b] == L && tw[b] == pb_) levb[L].push_back(b);
+    std::vector<int> rec;
+    for (int L = 1; L <= bestd; L++) {
+      const int nk = (int)levb[L].size();
+      maxlev = std::max(maxlev, nk);
+      hc.nkpack[(L - 1) >> 4] |= (unsigned long long)(nk - 1) << (4 * ((L - 1) & 15));
+      for (int b : levb[L]) {
+        const int e = tw[b];                                    // neighbour towards the root
+        const bool kin = d.body_parent[b] == e;                 // walked along the kinematic direction: b's own joint
+        const int jn = (kin ? b : e) + 1;                       // node index of the joint on this edge (its dofs are 3 jn ..)
+        int cfirst = 0, cc = 0;
+        if (L < bestd)
+          for (int k2 = 0; k2 < (int)levb[L + 1].size(); k2++)
+            if (tw[levb[L + 1][k2]] == b) { if (cc == 0) cfirst = k2; cc++; }
+        rec.push_back(b | (jn << 8) | (e << 16) | ((kin ? 0 : 1) << 24) | ((b == 0 ? 1 : 0) << 25));
+        rec.push_back(cfirst | (cc << 8));
+      }
+    }
+    if (rec.empty()) { rec.push_back(0); rec.push_back(0); }
+    hc.o_lev = push_i(rec);
+    h.maxlev = maxlev;                                        // the level buffers are sized for the wider of the two trees
   }
   while (S.size() % 4) S.push_back(0u);                     // reals start 16-byte aligned
   out.o_real = (int)S.size();

@@ -179,3 +179,29 @@ def test_smplx_layout_runs_and_matches():
         o_emu, *_ = eb.step(a[None])
         assert np.abs(eb.qpos[0] - env.data.qpos).max() < 1e-4
         assert np.abs(o_ref - o_emu[0]).max() < 5e-3
+
+
+def test_tree_solve_keeps_float32_accuracy_at_the_trunk_joints():
+    """One articulated-body solve (airborne, torque-dominated: a single Newton iteration = H x = tau), float32 kernel against its
+    float64 instantiation, per dof group.  The elimination tree is rooted at the Spine: the Torso / Spine / Chest joints sit next to the
+    root with the legs on one side, their joint-space 3x3 D is poorly conditioned, and W = U D^-1 has to satisfy W D = U to rounding
+    (Ldl3 in ss_kernel.h).  With an explicit cofactor inverse these joints came out at 1.7e-6 / 4.2e-6 / 3.1e-6 on these states
+    (medians, relative to the largest acceleration of the sample) and the free joint at 5.1e-7; with the substitution solve
+    0.8e-6 / 2.3e-6 / 1.4e-6 and 2.4e-7 (profiles/r03_centred_elimination.md)."""
+    n = 24
+    Q, V = _states(n, 5)
+    Q[:, 2] += 5.0                                             # no floor contact
+    tq = np.random.default_rng(2).uniform(-1, 1, (n, 69)) * 20000
+    acc = {}
+    for f64 in (True, False):
+        eb = _batch(n, f64=f64)
+        eb.set_state(Q, 0 * V)
+        acc[f64] = eb.debug_forward(tq)[2].astype(np.float64)
+    scale = np.maximum(1.0, np.abs(acc[True]).max(1))
+    err = np.abs(acc[False] - acc[True]) / scale[:, None]
+    groups = {"root": slice(0, 6), "hips": np.r_[6:9, 18:21], "Torso": slice(30, 33), "Spine": slice(33, 36), "Chest": slice(36, 39),
+              "leaves": np.r_[9:18, 21:30, 48:60, 63:75]}
+    med = {k: float(np.median(err[:, s].max(1))) for k, s in groups.items()}
+    print(med)
+    assert med["Torso"] < 1.3e-6 and med["Spine"] < 3.2e-6 and med["Chest"] < 2.3e-6, med
+    assert med["root"] < 4e-7 and med["hips"] < 1.0e-6 and med["leaves"] < 5e-6, med

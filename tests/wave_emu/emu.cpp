@@ -332,7 +332,7 @@ struct EmuBackend {
       // like the GPU launcher: the SMPL-sized model without per-env shapes runs the compile-time-layout instantiation
       if (variant == 0 && !k.st.shape_id && ss::HdrFixedT<24, 5>::matches(k.h) && !getenv("SS_EMU_GENERIC")) entry = lane_entry<2, 2, 1, 1, false, ss::HdrFixedT<24, 5>>;
       else if (variant == 0) entry = k.st.shape_id ? lane_entry<2, 2, 1, 1, true> : lane_entry<2, 2, 1, 1, false>;
-      else if (variant == 1 && !k.st.shape_id && ss::HdrFixedT<52, 10>::matches(k.h) && !getenv("SS_EMU_GENERIC")) entry = lane_entry<3, 3, 2, 2, false, ss::HdrFixedT<52, 10>>;
+      else if (variant == 1 && !k.st.shape_id && ss::HdrFixedT<52, 12>::matches(k.h) && !getenv("SS_EMU_GENERIC")) entry = lane_entry<3, 3, 2, 2, false, ss::HdrFixedT<52, 12>>;
       else if (variant == 1) entry = k.st.shape_id ? lane_entry<3, 3, 2, 2, true> : lane_entry<3, 3, 2, 2, false>;
       else return "no kernel variant for this model size";
       run_wave(m, entry, &c);
