@@ -294,7 +294,6 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
     }
   }
 
-  static constexpr bool kCentred = !SELFCOL;               // elimination tree of aba_solve (see there)
 
   // ------------------------------------------------------------------ kinematics + velocities + inertia + bias
   // with_dyn = false: positions/orientations only (observation FK)
@@ -1080,23 +1079,19 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
   }
 
   // pb: optional per-body bias force (6 per body): the system solved is  H x = b - sum_b J_b^T pb_b
-  // Plain instantiations eliminate towards the centre of the body tree (aba_solve_centre below); the body-body-contact
-  // instantiations keep the pelvis-rooted sweeps, whose factorization aba_resolve / aba_columns re-use.
+  //
+  // The elimination tree is rooted at the CENTRE of the body tree (HdrC, ss_tables.h), not at the pelvis.  H x = b is the system of a
+  // free-floating tree: the six free unknowns may sit on any body.  With the root at the tree's centre the sweeps are as deep as the
+  // tree's radius (SMPL: 6 levels instead of 8 below the pelvis; SMPL-X: 7 instead of 10).  For a node (body b, joint j, neighbour e
+  // towards the root):  a_b = a_e + S' q''_j  with S' = S_j when e is b's kinematic parent and -S_j when the edge is walked against
+  // the kinematic direction (e is b's kinematic child and j is e's joint); minimising the node's energy over q''_j gives exactly the
+  // recursion above with S':  U = IA S', D = S'^T U + diag, u = b_j - S'^T pA, W = U D^-1, y = D^-1 u, IA' = IA - W U^T,
+  // pA' = pA + U y  and  q''_j = y - W^T a_e,  a_b = a_e + S' q''_j  on the way down.  The free joint (identity motion subspace
+  // between the world and body 0) constrains nothing: its right-hand side is a bias force -S_fb b_fb on body 0, and its solution is
+  // read off body 0's acceleration.  The root has no joint: IA a = -pA, a 6x6 system in world coordinates.
+  // Storage: (W, y) per BODY in Wst, accelerations per body in An (slot b + 1, as the consumers expect), x per joint dof; the
+  // body-body-contact instantiations keep D's factors per body and the root's block inverses for aba_resolve / aba_columns.
   SS_DEV void aba_solve(real *x, const real *pb) {
-    if constexpr (kCentred) aba_solve_centre(x, pb); else aba_solve_pelvis(x, pb);
-  }
-
-  // ---- the same solve with the elimination tree rooted at the centre of the body tree (HdrC, ss_tables.h).
-  // H x = b is the system of a free-floating tree: the six free unknowns may sit on any body.  With the root at the tree's centre
-  // the sweeps are as deep as the tree's radius (SMPL: 6 levels instead of 8 below the pelvis; SMPL-X: 7 instead of 10).  For a node
-  // (body b, joint j, neighbour e towards the root):  a_b = a_e + S' q''_j  with S' = S_j when e is b's kinematic parent and -S_j when
-  // the edge is walked against the kinematic direction (e is b's kinematic child and j is e's joint); minimising the node's energy over
-  // q''_j gives exactly the recursion above with S':  U = IA S', D = S'^T U + diag, u = b_j - S'^T pA, W = U D^-1, y = D^-1 u,
-  // IA' = IA - W U^T, pA' = pA + U y  and  q''_j = y - W^T a_e,  a_b = a_e + S' q''_j  on the way down.  The free joint (identity
-  // motion subspace between the world and body 0) constrains nothing: its right-hand side is a bias force -S_fb b_fb on body 0, and
-  // its solution is read off body 0's acceleration.  The root has no joint: IA a = -pA, a 6x6 system as before.
-  // Storage: (W, y) per BODY in Wst, accelerations per body in An (slot b + 1, as the consumers expect), x per joint dof.
-  SS_DEV void aba_solve_centre(real *x, const real *pb) {
     fresh();
     typename HT::type h = HT::view(k->h);
     const HdrC &hc = k->hc;
@@ -1187,6 +1182,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
           real *dst = cur + (kk * 6 + r_) * 8;
           st4w(dst, rn[0], rn[1], rn[2], rn[3]); st4w(dst + 4, rn[4], rn[5], pn, 0.f);
           st4w(Wst + (b * 6 + r_) * 4, w0, w1, w2, r_ == 0 ? y0 : (r_ == 1 ? y1 : y2));
+          if constexpr (SELFCOL) if (r_ == 0) { st4w(this->Dinv + 8 * b, Dj.ie0, Dj.ie1, Dj.ie2, Dj.l10); st4w(this->Dinv + 8 * b + 4, Dj.l20, Dj.l21, 0.f, 0.f); }
         }
       }
       SS_FTICK(PF_F_P2);
@@ -1217,7 +1213,9 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
         const float4_t v0 = ld4(rows + 8 * i), v1 = ld4(rows + 8 * i + 4);
         A6[i][0] = v0.x; A6[i][1] = v0.y; A6[i][2] = v0.z; A6[i][3] = v0.w; A6[i][4] = v1.x; A6[i][5] = v1.y; f6[i] = v1.z;
       }
-      // 2x2 block elimination with closed-form 3x3 inverses (as in aba_solve_pelvis)
+      // 2x2 block elimination with closed-form 3x3 inverses (shallow dependency chains; an L D L^T over 6 pivots is
+      // a 60-deep chain for a lone wave):  A = [P Q; Q^T T],  a_ang = (P - Q T^-1 Q^T)^-1 (f_a - Q T^-1 f_l),
+      // a_lin = T^-1 (f_l - Q^T a_ang)
       real Ti[6], Si[6];
       sym3_inverse(A6[3][3], A6[4][3], A6[4][4], A6[5][3], A6[5][4], A6[5][5], Ti);
       real QT[3][3];
@@ -1246,6 +1244,14 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       f6[3] = Ti[0] * gl0 + Ti[1] * gl1 + Ti[2] * gl2;
       f6[4] = Ti[1] * gl0 + Ti[3] * gl1 + Ti[4] * gl2;
       f6[5] = Ti[2] * gl0 + Ti[4] * gl1 + Ti[5] * gl2;
+      if constexpr (SELFCOL)
+        if (lane == 0) {                                       // the root's block inverses, for the re-solves: Ti | Si | Q T^-1 | Q  (8 x 16 bytes)
+          real *rf = this->rootf;
+          st4w(rf, Ti[0], Ti[1], Ti[2], Ti[3]); st4w(rf + 4, Ti[4], Ti[5], Si[0], Si[1]); st4w(rf + 8, Si[2], Si[3], Si[4], Si[5]);
+          st4w(rf + 12, QT[0][0], QT[0][1], QT[0][2], QT[1][0]); st4w(rf + 16, QT[1][1], QT[1][2], QT[2][0], QT[2][1]);
+          st4w(rf + 20, QT[2][2], A6[0][3], A6[0][4], A6[0][5]); st4w(rf + 24, A6[1][3], A6[1][4], A6[1][5], A6[2][3]);
+          st4w(rf + 28, A6[2][4], A6[2][5], 0.f, 0.f);
+        }
       if (lane < 6) An[8 * (c_ + 1) + lane] = lane == 0 ? f6[0] : lane == 1 ? f6[1] : lane == 2 ? f6[2] : lane == 3 ? f6[3] : lane == 4 ? f6[4] : f6[5];
       if (c_ == 0) {                                          // the free joint's solution: x_trans = a_lin, x_rot = R^T a_ang
         if (lane < 3) x[lane] = lane == 0 ? f6[3] : (lane == 1 ? f6[4] : f6[5]);
@@ -1297,309 +1303,93 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
     SS_FTICK(PF_F_BSOL);
   }
 
-  SS_DEV void aba_solve_pelvis(real *x, const real *pb) {
-    fresh();
-    typename HT::type h = HT::view(k->h);
-    const int r_ = lane & 7, g = lane >> 3;
-    int off[6];                                              // packed-symmetric offsets of row r_
-#pragma unroll
-    for (int c = 0; c < 6; c++) { const int lo = r_ < c ? r_ : c, hi = r_ < c ? c : r_; off[c] = (lo * (11 - lo)) / 2 + hi; }
-    SS_FT0();
-    const unsigned long long nk0 = h.nkpack[0], nk1 = h.nkpack[1];
-    int s0 = h.nn;
-    for (int L = h.nlev - 1; L >= 2; --L) {                    // the two root nodes are solved together below
-      const int nk = (int)(((L < 16 ? nk0 : nk1) >> (4 * (L & 15))) & 15ull) + 1;
-      s0 -= nk;
-      real *cur = IA + (L & 1) * h.ia_stride;
-      const real *prev = IA + ((L + 1) & 1) * h.ia_stride;
-      real row[NPASS][6], pa[NPASS], Ur[NPASS][3], red[NPASS][9];
-      int nod[NPASS];
-#pragma unroll
-      for (int ps = 0; ps < NPASS; ps++) {                    // ---- part 1: articulated row, U_r = IA_r S, partial S^T U
-        const int kk = ps * 8 + g;
-        nod[ps] = -1;
-#pragma unroll
-        for (int t = 0; t < 9; t++) red[ps][t] = 0.f;
-        if (r_ < 6 && kk < nk) {
-          const int e = ti(h.o_lev, s0 + kk), n = e & 255, cfirst = (e >> 16) & 255, cc = (e >> 24) & 255;
-          nod[ps] = n;
-          real rw[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, pv = (pb && n > 0) ? pb[6 * (n - 1) + r_] : 0.f;
-          if (n > 0) {
-            const real *ao = Aown + 21 * (n - 1);
-#pragma unroll
-            for (int c = 0; c < 6; c++) rw[c] = ao[off[c]];
-          }
-          real sv[18];                                       // S_n: issued before the child loop, consumed after it
-          const real *sn = S + 18 * n;
-#pragma unroll
-          for (int t = 0; t < 18; t++) sv[t] = sn[t];
-          const real sr0 = sn[r_], sr1 = sn[6 + r_], sr2 = sn[12 + r_];   // row r of S_n
-          for (int j = 0; j < cc; j++) {
-            const real *src = prev + ((cfirst + j) * 6 + r_) * 8;
-            const float4_t v0 = ld4(src), v1 = ld4(src + 4);
-            rw[0] += v0.x; rw[1] += v0.y; rw[2] += v0.z; rw[3] += v0.w; rw[4] += v1.x; rw[5] += v1.y; pv += v1.z;
-          }
-#pragma unroll
-          for (int j = 0; j < 3; j++) {
-            real acc = 0.f;
-#pragma unroll
-            for (int c = 0; c < 6; c++) acc += rw[c] * sv[6 * j + c];
-            Ur[ps][j] = acc;
-          }
-#pragma unroll
-          for (int c = 0; c < 6; c++) row[ps][c] = rw[c];
-          pa[ps] = pv;
-          st4w(Ubuf + (kk * 6 + r_) * 4, Ur[ps][0], Ur[ps][1], Ur[ps][2], pv);
-          // this row's terms of D = S^T U (lower triangle) and of S^T pA; the 8-lane sums below complete them
-          red[ps][0] = sr0 * Ur[ps][0]; red[ps][1] = sr1 * Ur[ps][0]; red[ps][2] = sr1 * Ur[ps][1];
-          red[ps][3] = sr2 * Ur[ps][0]; red[ps][4] = sr2 * Ur[ps][1]; red[ps][5] = sr2 * Ur[ps][2];
-          red[ps][6] = sr0 * pv; red[ps][7] = sr1 * pv; red[ps][8] = sr2 * pv;
-        }
-      }
-      SS_FTICK(PF_F_P13);
-      w->sync();                                              // U rows visible to the node's other lanes
-#pragma unroll
-      for (int ps = 0; ps < NPASS; ps++)                      // sums over the node's 8 lanes (idle lanes hold zeros): no LDS
-#pragma unroll
-        for (int t = 0; t < 9; t++) red[ps][t] = w->sum8(red[ps][t]);
-#pragma unroll
-      for (int ps = 0; ps < NPASS; ps++) {                    // ---- part 2: joint-space 3x3 algebra, rows handed up
-        const int kk = ps * 8 + g, n = nod[ps];
-        if (n >= 0) {
-          float4_t U[6];
-#pragma unroll
-          for (int c = 0; c < 6; c++) U[c] = ld4(Ubuf + (kk * 6 + c) * 4);
-          const real u0 = x[3 * n] - red[ps][6], u1 = x[3 * n + 1] - red[ps][7], u2 = x[3 * n + 2] - red[ps][8];
-          Ldl3 Dj;
-          Dj.factor(red[ps][0] + diag[3 * n], red[ps][1], red[ps][2] + diag[3 * n + 1], red[ps][3], red[ps][4], red[ps][5] + diag[3 * n + 2]);
-          real y0, y1, y2, w0, w1, w2;
-          Dj.solve(u0, u1, u2, y0, y1, y2);
-          const real a0 = Ur[ps][0], a1 = Ur[ps][1], a2 = Ur[ps][2];
-          Dj.solve(a0, a1, a2, w0, w1, w2);
-          real rn[6];
-#pragma unroll
-          for (int c = 0; c < 6; c++) rn[c] = row[ps][c] - (w0 * U[c].x + w1 * U[c].y + w2 * U[c].z);
-          const real pn = pa[ps] + a0 * y0 + a1 * y1 + a2 * y2;
-          real *dst = cur + (kk * 6 + r_) * 8;
-          st4w(dst, rn[0], rn[1], rn[2], rn[3]); st4w(dst + 4, rn[4], rn[5], pn, 0.f);
-          st4w(Wst + (n * 6 + r_) * 4, w0, w1, w2, r_ == 0 ? y0 : (r_ == 1 ? y1 : y2));
-          if constexpr (SELFCOL) if (r_ == 0) { st4w(this->Dinv + 8 * n, Dj.ie0, Dj.ie1, Dj.ie2, Dj.l10); st4w(this->Dinv + 8 * n + 4, Dj.l20, Dj.l21, 0.f, 0.f); }
-        }
-      }
-      SS_FTICK(PF_F_P2);
-      w->sync();
-    }
-    // ---- root: body 0 and its free joint (nodes 0 and 1) as ONE 6-dof joint.  S_root = blockdiag(R, 1) is orthogonal
-    // and the free joint has neither armature nor limits nor gains, so  S^T (IA a + pA) = b  is the 6x6 system
-    // IA a = S b - pA  in world coordinates: no transform of the matrix, no hand-up, two tree levels less per sweep.
-    {
-      real *rows = IA + h.ia_stride;                          // the level buffer that level 2 did not use
-      const real *prev = IA;                                  // rows handed up by level 2
-      if (lane < 6) {
-        const int e = ti(h.o_lev, 1), cfirst = (e >> 16) & 255, cc = (e >> 24) & 255;
-        real rw[6], pv = pb ? pb[lane] : 0.f;
-#pragma unroll
-        for (int c = 0; c < 6; c++) rw[c] = Aown[off[c]];
-        for (int j = 0; j < cc; j++) {
-          const real *src = prev + ((cfirst + j) * 6 + lane) * 8;
-          const float4_t v0 = ld4(src), v1 = ld4(src + 4);
-          rw[0] += v0.x; rw[1] += v0.y; rw[2] += v0.z; rw[3] += v0.w; rw[4] += v1.x; rw[5] += v1.y; pv += v1.z;
-        }
-        // (S b)_r: angular part R b_rot (S of node 1 holds the columns of R), linear part b_trans
-        const real sb = lane < 3 ? S[18 + lane] * x[3] + S[24 + lane] * x[4] + S[30 + lane] * x[5] : x[lane - 3];
-        st4w(rows + 8 * lane, rw[0], rw[1], rw[2], rw[3]); st4w(rows + 8 * lane + 4, rw[4], rw[5], sb - pv, 0.f);
-      }
-      w->sync();
-      real A6[6][6], f6[6];                                   // every lane solves the same 6x6 system (L D L^T)
-#pragma unroll
-      for (int i = 0; i < 6; i++) {
-        const float4_t v0 = ld4(rows + 8 * i), v1 = ld4(rows + 8 * i + 4);
-        A6[i][0] = v0.x; A6[i][1] = v0.y; A6[i][2] = v0.z; A6[i][3] = v0.w; A6[i][4] = v1.x; A6[i][5] = v1.y; f6[i] = v1.z;
-      }
-      // 2x2 block elimination with closed-form 3x3 inverses (shallow dependency chains; an L D L^T over 6 pivots is
-      // a 60-deep chain for a lone wave):  A = [P Q; Q^T T],  a_ang = (P - Q T^-1 Q^T)^-1 (f_a - Q T^-1 f_l),
-      // a_lin = T^-1 (f_l - Q^T a_ang)
-      real Ti[6], Si[6];                                      // symmetric inverses: 00 01 02 11 12 22
-      sym3_inverse(A6[3][3], A6[4][3], A6[4][4], A6[5][3], A6[5][4], A6[5][5], Ti);
-      real QT[3][3];                                          // Q T^-1
-#pragma unroll
-      for (int i = 0; i < 3; i++) {
-        const real q0 = A6[i][3], q1 = A6[i][4], q2 = A6[i][5];
-        QT[i][0] = q0 * Ti[0] + q1 * Ti[1] + q2 * Ti[2];
-        QT[i][1] = q0 * Ti[1] + q1 * Ti[3] + q2 * Ti[4];
-        QT[i][2] = q0 * Ti[2] + q1 * Ti[4] + q2 * Ti[5];
-      }
-      real Sc[3][3], ga[3];                                   // Schur complement P - Q T^-1 Q^T and its right-hand side
-#pragma unroll
-      for (int i = 0; i < 3; i++) {
-#pragma unroll
-        for (int j = 0; j <= i; j++) Sc[i][j] = A6[i][j] - (QT[i][0] * A6[j][3] + QT[i][1] * A6[j][4] + QT[i][2] * A6[j][5]);
-        ga[i] = f6[i] - (QT[i][0] * f6[3] + QT[i][1] * f6[4] + QT[i][2] * f6[5]);
-      }
-      sym3_inverse(Sc[0][0], Sc[1][0], Sc[1][1], Sc[2][0], Sc[2][1], Sc[2][2], Si);
-      const real aa0 = Si[0] * ga[0] + Si[1] * ga[1] + Si[2] * ga[2];
-      const real aa1 = Si[1] * ga[0] + Si[3] * ga[1] + Si[4] * ga[2];
-      const real aa2 = Si[2] * ga[0] + Si[4] * ga[1] + Si[5] * ga[2];
-      const real gl0 = f6[3] - (A6[0][3] * aa0 + A6[1][3] * aa1 + A6[2][3] * aa2);
-      const real gl1 = f6[4] - (A6[0][4] * aa0 + A6[1][4] * aa1 + A6[2][4] * aa2);
-      const real gl2 = f6[5] - (A6[0][5] * aa0 + A6[1][5] * aa1 + A6[2][5] * aa2);
-      f6[0] = aa0; f6[1] = aa1; f6[2] = aa2;
-      f6[3] = Ti[0] * gl0 + Ti[1] * gl1 + Ti[2] * gl2;
-      f6[4] = Ti[1] * gl0 + Ti[3] * gl1 + Ti[4] * gl2;
-      f6[5] = Ti[2] * gl0 + Ti[4] * gl1 + Ti[5] * gl2;
-      if constexpr (SELFCOL)
-        if (lane == 0) {                                       // the root's block inverses, for aba_resolve: Ti | Si | Q T^-1 | Q  (8 x 16 bytes)
-          real *rf = this->rootf;
-          st4w(rf, Ti[0], Ti[1], Ti[2], Ti[3]); st4w(rf + 4, Ti[4], Ti[5], Si[0], Si[1]); st4w(rf + 8, Si[2], Si[3], Si[4], Si[5]);
-          st4w(rf + 12, QT[0][0], QT[0][1], QT[0][2], QT[1][0]); st4w(rf + 16, QT[1][1], QT[1][2], QT[2][0], QT[2][1]);
-          st4w(rf + 20, QT[2][2], A6[0][3], A6[0][4], A6[0][5]); st4w(rf + 24, A6[1][3], A6[1][4], A6[1][5], A6[2][3]);
-          st4w(rf + 28, A6[2][4], A6[2][5], 0.f, 0.f);
-        }
-      // f6 = spatial acceleration of body 0; joint solution: x_trans = a_lin, x_rot = R^T a_ang
-      if (lane < 6) An[8 + lane] = lane == 0 ? f6[0] : lane == 1 ? f6[1] : lane == 2 ? f6[2] : lane == 3 ? f6[3] : lane == 4 ? f6[4] : f6[5];
-      if (lane < 3) x[lane] = lane == 0 ? f6[3] : (lane == 1 ? f6[4] : f6[5]);
-      else if (lane < 6) { const int j = lane - 3; x[lane] = S[18 + 6 * j] * f6[0] + S[18 + 6 * j + 1] * f6[1] + S[18 + 6 * j + 2] * f6[2]; }
-      w->sync();
-      s0 = 2;
-    }
-    SS_FTICK(PF_F_SYNC1);
-    // ---- downward sweep below the root:  x_n = y_n - W_n^T a_parent,  a_n = a_parent + S_n x_n.  Lane r of the node's group holds
-    // row r: its own W row (one 16-byte read; y_j rides in row j's fourth slot) and component r of the parent's acceleration; the
-    // three sums over the rows are 8-lane DPP sums (idle lanes hold zeros) — 5 LDS reads per lane and level instead of 12, and the
-    // only read that waits for the previous level is the parent's component.
-#ifndef SS_DOWN_PREFETCH
-#define SS_DOWN_PREFETCH 0
-#endif
-    // SS_DOWN_PREFETCH (experiment, off): the node's static data (level record, W row, S row) does not depend on the sweep and can
-    // be requested one level ahead (1: the record only, 2: record two levels ahead + W and S rows one level ahead), so that per
-    // level only the read of the parent's component waits for the previous level's write.  Measured on the MI355X: -1 % and -2 %
-    // (profiles/r03_chain_candidates.md) — the extra live registers and moves cost more than the shorter chain brings.
-    auto NK = [&](int L) { return L < h.nlev ? (int)(((L < 16 ? nk0 : nk1) >> (4 * (L & 15))) & 15ull) + 1 : 0; };
-    int e1[NPASS], e2[NPASS];                                 // records of this level / the next one (-1: no node for this lane)
-    float4_t wr1[NPASS]; real sa1[NPASS], sb1[NPASS], sc1[NPASS];   // W row and S row of this level's node
-    auto rec = [&](int L, int start, int ps) { const int kk = ps * 8 + g; return (r_ < 6 && kk < NK(L)) ? ti(h.o_lev, start + kk) : -1; };
-    int st1 = 2, st2 = 2 + NK(2);
-#pragma unroll
-    for (int ps = 0; ps < NPASS; ps++) {
-      e1[ps] = rec(2, st1, ps); e2[ps] = rec(3, st2, ps);
-      wr1[ps].x = wr1[ps].y = wr1[ps].z = wr1[ps].w = 0.f; sa1[ps] = sb1[ps] = sc1[ps] = 0.f;
-      if (SS_DOWN_PREFETCH >= 2 && e1[ps] >= 0) {
-        const int n = e1[ps] & 255; wr1[ps] = ld4(Wst + (n * 6 + r_) * 4);
-        const real *sn = S + 18 * n + r_; sa1[ps] = sn[0]; sb1[ps] = sn[6]; sc1[ps] = sn[12];
-      }
-    }
-    for (int L = 2; L < h.nlev; L++) {
-      const int st3 = st2 + NK(L + 1);
-#pragma unroll
-      for (int ps = 0; ps < NPASS; ps++) {
-        const int e = SS_DOWN_PREFETCH >= 1 ? e1[ps] : rec(L, st1, ps);
-        const int n = e >= 0 ? (e & 255) : -1;
-        real p0 = 0.f, p1 = 0.f, p2 = 0.f, apr = 0.f, s_0 = 0.f, s_1 = 0.f, s_2 = 0.f;
-        if (n >= 0) {
-          const int pn = (e >> 8) & 255;
-          apr = An[8 * pn + r_];
-          float4_t wr;
-          if (SS_DOWN_PREFETCH >= 2) { wr = wr1[ps]; s_0 = sa1[ps]; s_1 = sb1[ps]; s_2 = sc1[ps]; }
-          else { wr = ld4(Wst + (n * 6 + r_) * 4); const real *sn = S + 18 * n + r_; s_0 = sn[0]; s_1 = sn[6]; s_2 = sn[12]; }
-          p0 = wr.x * apr - (r_ == 0 ? wr.w : 0.f); p1 = wr.y * apr - (r_ == 1 ? wr.w : 0.f); p2 = wr.z * apr - (r_ == 2 ? wr.w : 0.f);
-        }
-        if (SS_DOWN_PREFETCH >= 1) {                          // next level's record is here by now; request its data and the record after it
-          e1[ps] = e2[ps];
-          if (SS_DOWN_PREFETCH >= 2 && e2[ps] >= 0) {
-            const int n2 = e2[ps] & 255; wr1[ps] = ld4(Wst + (n2 * 6 + r_) * 4);
-            const real *sn = S + 18 * n2 + r_; sa1[ps] = sn[0]; sb1[ps] = sn[6]; sc1[ps] = sn[12];
-          }
-          e2[ps] = rec(L + 2, st3, ps);
-        }
-        p0 = w->sum8(p0); p1 = w->sum8(p1); p2 = w->sum8(p2);   // = -x_n in every lane of the group
-        if (n >= 0) {
-          An[8 * n + r_] = apr - (s_0 * p0 + s_1 * p1 + s_2 * p2);
-          if (r_ < 3) x[3 * n + r_] = -(r_ == 0 ? p0 : (r_ == 1 ? p1 : p2));
-        }
-      }
-      st1 = st2; st2 = st3;
-      w->sync();
-    }
-    SS_FTICK(PF_F_BSOL);
-  }
-
-  // Re-solve with the factorization the last aba_solve left in LDS (W per node in Wst, D^-1 per node, the root's block inverses):
-  // H X = B - sum_b J_b^T PB_b for K right-hand sides in the same sweeps.  Only the bias quantities travel: one hand-off per level
-  // going up (no U rows), one going down — about a third of a full solve for K = 1, and K = 3 costs little more.
+  // Re-solve with the factorization the last aba_solve left in LDS (W per body in Wst, D's factors per body, the root's block inverses):
+  // H X = B - sum_b J_b^T PB_b for K right-hand sides in the same sweeps over the centred tree.  Only the bias quantities travel: one
+  // hand-off per level going up (no U rows), one going down — about a third of a full solve for K = 1, and K = 3 costs little more.
   //   bf(dof, k)        joint-space right-hand side of system k
   //   pf(body, row, k)  row of the per-body bias force of system k
-  //   Aout              body accelerations of the solutions, Aout[(node * K + k) * 8 + row]
+  //   Aout              body accelerations of the solutions, Aout[((body + 1) * K + k) * 8 + row]
   //   xout              (K = 1, or null) joint-space solution
   template <int K, class BF, class PF>
   SS_DEV void aba_resolve(BF bf, PF pf, real *Aout, real *xout) {
     if constexpr (SELFCOL) {
       fresh();
       typename HT::type h = HT::view(k->h);
+      const HdrC &hc = k->hc;
       const int r_ = lane & 7, g = lane >> 3;
-      const unsigned long long nk0 = h.nkpack[0], nk1 = h.nkpack[1];
+      const unsigned long long nk0 = hc.nkpack[0], nk1 = hc.nkpack[1];
+      auto NKC = [&](int L) { return (int)((((L - 1) < 16 ? nk0 : nk1) >> (4 * ((L - 1) & 15))) & 15ull) + 1; };
+      // row `row` of the free joint's right-hand side as a force on body 0 (see aba_solve)
+      auto fb_force = [&](int row, int q_) { return row < 3 ? S[18 + row] * bf(3, q_) + S[24 + row] * bf(4, q_) + S[30 + row] * bf(5, q_) : bf(row - 3, q_); };
       real *ysave = this->ysave;
-      int s0 = h.nn;
-      for (int L = h.nlev - 1; L >= 2; --L) {
-        const int nk = (int)(((L < 16 ? nk0 : nk1) >> (4 * (L & 15))) & 15ull) + 1;
+      int s0 = h.nb - 1;
+      for (int L = hc.nlev; L >= 1; --L) {
+        const int nk = NKC(L);
         s0 -= nk;
         real *cur = IA + (L & 1) * h.ia_stride;
         const real *prev = IA + ((L + 1) & 1) * h.ia_stride;
 #pragma unroll
         for (int ps = 0; ps < NPASS; ps++) {
           const int kk = ps * 8 + g;
-          int n = -1;
+          int b = -1, jn = 0;
           real pa[K], red[K][3], wr0 = 0, wr1 = 0, wr2 = 0;
 #pragma unroll
           for (int q_ = 0; q_ < K; q_++) { pa[q_] = 0; red[q_][0] = red[q_][1] = red[q_][2] = 0; }
           if (r_ < 6 && kk < nk) {
-            const int e = ti(h.o_lev, s0 + kk), cfirst = (e >> 16) & 255, cc = (e >> 24) & 255;
-            n = e & 255;
+            const int e0 = ti(hc.o_lev, 2 * (s0 + kk)), e1 = ti(hc.o_lev, 2 * (s0 + kk) + 1), cfirst = e1 & 255, cc = (e1 >> 8) & 255;
+            b = e0 & 255; jn = (e0 >> 8) & 255;
+            const real sgn = (e0 >> 24) & 1 ? real(-1) : real(1);
 #pragma unroll
-            for (int q_ = 0; q_ < K; q_++) pa[q_] = pf(n - 1, r_, q_);
+            for (int q_ = 0; q_ < K; q_++) pa[q_] = pf(b, r_, q_);
+            if ((e0 >> 25) & 1) {
+#pragma unroll
+              for (int q_ = 0; q_ < K; q_++) pa[q_] -= fb_force(r_, q_);
+            }
             for (int j = 0; j < cc; j++) {
               const real *src = prev + ((cfirst + j) * 6 + r_) * 8;
 #pragma unroll
               for (int q_ = 0; q_ < K; q_++) pa[q_] += src[q_];
             }
-            const real *sn = S + 18 * n;
-            const real sr0 = sn[r_], sr1 = sn[6 + r_], sr2 = sn[12 + r_];
+            const real *sn = S + 18 * jn;
+            const real sr0 = sgn * sn[r_], sr1 = sgn * sn[6 + r_], sr2 = sgn * sn[12 + r_];
 #pragma unroll
             for (int q_ = 0; q_ < K; q_++) { red[q_][0] = sr0 * pa[q_]; red[q_][1] = sr1 * pa[q_]; red[q_][2] = sr2 * pa[q_]; }
-            const float4_t wv = ld4(Wst + (n * 6 + r_) * 4);
+            const float4_t wv = ld4(Wst + (b * 6 + r_) * 4);
             wr0 = wv.x; wr1 = wv.y; wr2 = wv.z;
           }
 #pragma unroll
           for (int q_ = 0; q_ < K; q_++)
 #pragma unroll
             for (int j = 0; j < 3; j++) red[q_][j] = w->sum8(red[q_][j]);
-          if (n >= 0) {
-            const Ldl3 Dj = load_ldl(n);
+          if (b >= 0) {
+            const Ldl3 Dj = load_ldl(b);
             real *dst = cur + (kk * 6 + r_) * 8;
 #pragma unroll
             for (int q_ = 0; q_ < K; q_++) {
-              const real u0 = bf(3 * n, q_) - red[q_][0], u1 = bf(3 * n + 1, q_) - red[q_][1], u2 = bf(3 * n + 2, q_) - red[q_][2];
+              const real u0 = bf(3 * jn, q_) - red[q_][0], u1 = bf(3 * jn + 1, q_) - red[q_][1], u2 = bf(3 * jn + 2, q_) - red[q_][2];
               dst[q_] = pa[q_] + wr0 * u0 + wr1 * u1 + wr2 * u2;
               if (r_ < 3) {
-                real s0, s1, s2;
-                Dj.solve(u0, u1, u2, s0, s1, s2);
-                ysave[(n * K + q_) * 4 + r_] = r_ == 0 ? s0 : (r_ == 1 ? s1 : s2);
+                real t0, t1, t2;
+                Dj.solve(u0, u1, u2, t0, t1, t2);
+                ysave[(b * K + q_) * 4 + r_] = r_ == 0 ? t0 : (r_ == 1 ? t1 : t2);
               }
             }
           }
         }
         w->sync();
       }
-      {                                                      // ---- root (nodes 0 and 1 as one 6-dof joint)
-        real *rows = IA + h.ia_stride;
-        const real *prev = IA;
+      const int c_ = hc.root;
+      {                                                      // ---- root body: IA a = -pA with the stored block inverses
+        real *rows = IA;
+        const real *prev = IA + h.ia_stride;
+        const int cc = hc.nlev >= 1 ? NKC(1) : 0;
         if (lane < 6) {
-          const int e = ti(h.o_lev, 1), cfirst = (e >> 16) & 255, cc = (e >> 24) & 255;
 #pragma unroll
           for (int q_ = 0; q_ < K; q_++) {
-            real pv = pf(0, lane, q_);
-            for (int j = 0; j < cc; j++) pv += prev[((cfirst + j) * 6 + lane) * 8 + q_];
-            const real sb = lane < 3 ? S[18 + lane] * bf(3, q_) + S[24 + lane] * bf(4, q_) + S[30 + lane] * bf(5, q_) : bf(lane - 3, q_);
-            rows[8 * q_ + lane] = sb - pv;
+            real pv = pf(c_, lane, q_);
+            if (c_ == 0) pv -= fb_force(lane, q_);
+            for (int j = 0; j < cc; j++) pv += prev[(j * 6 + lane) * 8 + q_];
+            rows[8 * q_ + lane] = -pv;
           }
         }
         w->sync();
@@ -1617,39 +1407,55 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
           al_[0] = rf[0] * gl[0] + rf[1] * gl[1] + rf[2] * gl[2];
           al_[1] = rf[1] * gl[0] + rf[3] * gl[1] + rf[4] * gl[2];
           al_[2] = rf[2] * gl[0] + rf[4] * gl[1] + rf[5] * gl[2];
-          if (lane < 6) Aout[(1 * K + q_) * 8 + lane] = lane < 3 ? (lane == 0 ? aa[0] : lane == 1 ? aa[1] : aa[2]) : (lane == 3 ? al_[0] : lane == 4 ? al_[1] : al_[2]);
-          if (xout && q_ == 0) {
+          if (lane < 6) Aout[((c_ + 1) * K + q_) * 8 + lane] = lane < 3 ? (lane == 0 ? aa[0] : lane == 1 ? aa[1] : aa[2]) : (lane == 3 ? al_[0] : lane == 4 ? al_[1] : al_[2]);
+          if (xout && q_ == 0 && c_ == 0) {
             if (lane < 3) xout[lane] = lane == 0 ? al_[0] : (lane == 1 ? al_[1] : al_[2]);
             else if (lane < 6) { const int j = lane - 3; xout[lane] = S[18 + 6 * j] * aa[0] + S[18 + 6 * j + 1] * aa[1] + S[18 + 6 * j + 2] * aa[2]; }
           }
         }
         w->sync();
-        s0 = 2;
       }
-      for (int L = 2; L < h.nlev; L++) {                      // ---- downward sweep
-        const int nk = (int)(((L < 16 ? nk0 : nk1) >> (4 * (L & 15))) & 15ull) + 1;
+      s0 = 0;
+      for (int L = 1; L <= hc.nlev; L++) {                    // ---- sweep away from the root (row-distributed, as in aba_solve)
+        const int nk = NKC(L);
+        const bool pel_level = xout && L == hc.pel_level;
 #pragma unroll
         for (int ps = 0; ps < NPASS; ps++) {
           const int kk = ps * 8 + g;
+          int b = -1, jn = 0, en = 0, pel = 0;
+          real s_0 = 0.f, s_1 = 0.f, s_2 = 0.f;
+          float4_t wr; wr.x = wr.y = wr.z = wr.w = 0.f;
           if (r_ < 6 && kk < nk) {
-            const int e = ti(h.o_lev, s0 + kk), n = e & 255, pn = (e >> 8) & 255;
-            float4_t Wn[6];
+            const int e0 = ti(hc.o_lev, 2 * (s0 + kk));
+            b = e0 & 255; jn = (e0 >> 8) & 255; en = (e0 >> 16) & 255; pel = (e0 >> 25) & 1;
+            const real sgn = (e0 >> 24) & 1 ? real(-1) : real(1);
+            wr = ld4(Wst + (b * 6 + r_) * 4);
+            const real *sn = S + 18 * jn + r_;
+            s_0 = sgn * sn[0]; s_1 = sgn * sn[6]; s_2 = sgn * sn[12];
+          }
 #pragma unroll
-            for (int c = 0; c < 6; c++) Wn[c] = ld4(Wst + (n * 6 + c) * 4);
-            const real *sn = S + 18 * n + r_;
-            const real s_0 = sn[0], s_1 = sn[6], s_2 = sn[12];
-#pragma unroll
-            for (int q_ = 0; q_ < K; q_++) {
-              const real *apk = Aout + (pn * K + q_) * 8;
-              const float4_t p0 = ld4(apk), p1 = ld4(apk + 4);
-              const real ap[6] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y};
-              const real apr = apk[r_];
-              const real *ys = ysave + (n * K + q_) * 4;
-              real x0 = ys[0], x1 = ys[1], x2 = ys[2];
-#pragma unroll
-              for (int c = 0; c < 6; c++) { x0 -= Wn[c].x * ap[c]; x1 -= Wn[c].y * ap[c]; x2 -= Wn[c].z * ap[c]; }
-              Aout[(n * K + q_) * 8 + r_] = apr + s_0 * x0 + s_1 * x1 + s_2 * x2;
-              if (xout && q_ == 0 && r_ < 3) xout[3 * n + r_] = r_ == 0 ? x0 : (r_ == 1 ? x1 : x2);
+          for (int q_ = 0; q_ < K; q_++) {
+            real apr = 0.f, p0 = 0.f, p1 = 0.f, p2 = 0.f;
+            if (b >= 0) {
+              apr = Aout[((en + 1) * K + q_) * 8 + r_];
+              const real yv = r_ < 3 ? ysave[(b * K + q_) * 4 + r_] : 0.f;
+              p0 = wr.x * apr - (r_ == 0 ? yv : 0.f); p1 = wr.y * apr - (r_ == 1 ? yv : 0.f); p2 = wr.z * apr - (r_ == 2 ? yv : 0.f);
+            }
+            p0 = w->sum8(p0); p1 = w->sum8(p1); p2 = w->sum8(p2);   // = -x_j in every lane of the group
+            real acc = 0.f;
+            if (b >= 0) {
+              acc = apr - (s_0 * p0 + s_1 * p1 + s_2 * p2);
+              Aout[((b + 1) * K + q_) * 8 + r_] = acc;
+              if (xout && q_ == 0 && r_ < 3) xout[3 * jn + r_] = -(r_ == 0 ? p0 : (r_ == 1 ? p1 : p2));
+            }
+            if (pel_level && q_ == 0) {                        // body 0 reached: the free joint's solution from its acceleration
+              real t0 = 0.f, t1 = 0.f, t2 = 0.f;
+              if (pel && r_ < 3) { t0 = S[18 + r_] * acc; t1 = S[24 + r_] * acc; t2 = S[30 + r_] * acc; }
+              t0 = w->sum8(t0); t1 = w->sum8(t1); t2 = w->sum8(t2);
+              if (pel) {
+                if (r_ >= 3 && r_ < 6) xout[r_ - 3] = acc;
+                else if (r_ < 3) xout[3 + r_] = r_ == 0 ? t0 : (r_ == 1 ? t1 : t2);
+              }
             }
           }
         }
@@ -1663,15 +1469,16 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
   // factorization in LDS: the 12 right-hand sides (unit relative force along the normal and the two tangents of each contact)
   // are spread over the lanes — lane = (node of the tree level, right-hand side), 5 nodes x 12 per pass, the lane carries all six
   // rows of its node, so there is no cross-lane reduction — instead of one re-solve sweep per contact.  Hand-off rows travel through
-  // two level buffers in the Aown / IA region (dead here), indexed by the node's position in its level, so that a parent finds
-  // its children's rows going up and pushes its acceleration into its children's slots going down.  The accelerations are not
-  // kept: every (body, right-hand side) lane adds its body's share of the relative acceleration of every contact the body is
-  // part of straight into G (two commutative additions per entry at most: one per body of the contact).
+  // two level buffers in the Aown / IA region (dead here), indexed by the node's position in its level, so that a node finds
+  // its children's rows going towards the root and pushes its acceleration into its children's slots going away from it.  The
+  // accelerations are not kept: every (body, right-hand side) lane adds its body's share of the relative acceleration of every
+  // contact the body is part of straight into G (two commutative additions per entry at most: one per body of the contact).
   //     G[(3 i + k) m + 3 c + d] = frame_i[k] . (acceleration of contact i's point, body 2 minus body 1, for unit force d of contact c)
   SS_DEV void aba_columns(unsigned cm, real *G, int m) {
     if constexpr (SELFCOL) {
       fresh();
       typename HT::type h = HT::view(k->h);
+      const HdrC &hc = k->hc;
       const int ns = this->nself;
       const int q_ = lane % 12, grp = lane / 12;
       int nsel = 0;
@@ -1691,7 +1498,8 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       real *buf = Aown;
       real *ys = this->ysave;
       const int bstride = 72 * h.maxlev;
-      const unsigned long long nk0 = h.nkpack[0], nk1 = h.nkpack[1];
+      const unsigned long long nk0 = hc.nkpack[0], nk1 = hc.nkpack[1];
+      auto NKC = [&](int L) { return (int)((((L - 1) < 16 ? nk0 : nk1) >> (4 * ((L - 1) & 15))) & 15ull) + 1; };
       // share of body b (acceleration acc: angular ; linear at the root origin) in the rows of every contact it belongs to
       auto scatter = [&](int b, const real *acc) {
         for (int i = 0; i < ns; i++) {
@@ -1709,18 +1517,20 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
         }
       };
       w->sync();
-      int s0 = h.nn;
-      for (int L = h.nlev - 1; L >= 2; --L) {                 // ---- upward sweep: bias forces only
-        const int nk = (int)(((L < 16 ? nk0 : nk1) >> (4 * (L & 15))) & 15ull) + 1;
+      int s0 = h.nb - 1;
+      for (int L = hc.nlev; L >= 1; --L) {                    // ---- sweep towards the root: bias forces only
+        const int nk = NKC(L);
         s0 -= nk;
         real *cur = buf + (L & 1) * bstride;
         const real *prev = buf + ((L + 1) & 1) * bstride;
         for (int ps = 0; ps * 5 < nk; ps++) {
           const int kk = ps * 5 + grp;
           if (on && kk < nk) {
-            const int e = ti(h.o_lev, s0 + kk), n = e & 255, cfirst = (e >> 16) & 255, cc = (e >> 24) & 255;
+            const int e0 = ti(hc.o_lev, 2 * (s0 + kk)), e1 = ti(hc.o_lev, 2 * (s0 + kk) + 1);
+            const int b = e0 & 255, jn = (e0 >> 8) & 255, cfirst = e1 & 255, cc = (e1 >> 8) & 255;
+            const real sgn = (e0 >> 24) & 1 ? real(-1) : real(1);
             real pa[6];
-            const real sg_ = n - 1 == cb2 ? real(-1) : (n - 1 == cb1 ? real(1) : real(0));
+            const real sg_ = b == cb2 ? real(-1) : (b == cb1 ? real(1) : real(0));
 #pragma unroll
             for (int r_ = 0; r_ < 6; r_++) pa[r_] = sg_ * wrq[r_];
             for (int j = 0; j < cc; j++) {
@@ -1728,29 +1538,30 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
 #pragma unroll
               for (int r_ = 0; r_ < 6; r_++) pa[r_] += src[r_];
             }
-            const real *sn = S + 18 * n;
+            const real *sn = S + 18 * jn;
             real u[3];
 #pragma unroll
-            for (int j = 0; j < 3; j++) { real a_ = 0; for (int r_ = 0; r_ < 6; r_++) a_ += sn[6 * j + r_] * pa[r_]; u[j] = -a_; }
+            for (int j = 0; j < 3; j++) { real a_ = 0; for (int r_ = 0; r_ < 6; r_++) a_ += sn[6 * j + r_] * pa[r_]; u[j] = -sgn * a_; }
             real *dst = cur + (kk * 12 + q_) * 6;
 #pragma unroll
-            for (int r_ = 0; r_ < 6; r_++) { const float4_t wv = ld4(Wst + (n * 6 + r_) * 4); dst[r_] = pa[r_] + wv.x * u[0] + wv.y * u[1] + wv.z * u[2]; }
-            const Ldl3 Dj = load_ldl(n);
-            real *yo = ys + (n * 12 + q_) * 3;
+            for (int r_ = 0; r_ < 6; r_++) { const float4_t wv = ld4(Wst + (b * 6 + r_) * 4); dst[r_] = pa[r_] + wv.x * u[0] + wv.y * u[1] + wv.z * u[2]; }
+            const Ldl3 Dj = load_ldl(b);
+            real *yo = ys + (b * 12 + q_) * 3;
             Dj.solve(u[0], u[1], u[2], yo[0], yo[1], yo[2]);
           }
         }
         w->sync();
       }
-      if (on && grp == 0) {                                   // ---- root (nodes 0 and 1 as one 6-dof joint), lane = right-hand side
-        const real *prev = buf;                              // level 2's rows
-        const int e = ti(h.o_lev, 1), cfirst = (e >> 16) & 255, cc = (e >> 24) & 255;
+      const int c_ = hc.root;
+      if (on && grp == 0) {                                   // ---- root body, lane = right-hand side
+        const real *prev = buf + bstride;                    // level 1's rows
+        const int cc = hc.nlev >= 1 ? NKC(1) : 0;
         real f6[6];
-        const real sg_ = 0 == cb2 ? real(-1) : (0 == cb1 ? real(1) : real(0));
+        const real sg_ = c_ == cb2 ? real(-1) : (c_ == cb1 ? real(1) : real(0));
 #pragma unroll
         for (int r_ = 0; r_ < 6; r_++) f6[r_] = -sg_ * wrq[r_];
         for (int j = 0; j < cc; j++) {
-          const real *src = prev + ((cfirst + j) * 12 + q_) * 6;
+          const real *src = prev + (j * 12 + q_) * 6;
 #pragma unroll
           for (int r_ = 0; r_ < 6; r_++) f6[r_] -= src[r_];
         }
@@ -1764,42 +1575,45 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
         acc[3] = rf[0] * gl[0] + rf[1] * gl[1] + rf[2] * gl[2];
         acc[4] = rf[1] * gl[0] + rf[3] * gl[1] + rf[4] * gl[2];
         acc[5] = rf[2] * gl[0] + rf[4] * gl[1] + rf[5] * gl[2];
-        real *nxt = buf + bstride;                           // level 2's acceleration slots (the rows of level 3 that lived there are consumed)
+        real *nxt = buf;                                     // level 1's acceleration slots (the rows of level 2 that lived there are consumed)
         for (int j = 0; j < cc; j++) {
-          real *o = nxt + ((cfirst + j) * 12 + q_) * 6;
+          real *o = nxt + (j * 12 + q_) * 6;
 #pragma unroll
           for (int r_ = 0; r_ < 6; r_++) o[r_] = acc[r_];
         }
-        scatter(0, acc);
+        scatter(c_, acc);
       }
       w->sync();
-      s0 = 2;
-      for (int L = 2; L < h.nlev; L++) {                      // ---- downward sweep: accelerations, pushed into the children's slots
-        const int nk = (int)(((L < 16 ? nk0 : nk1) >> (4 * (L & 15))) & 15ull) + 1;
+      s0 = 0;
+      for (int L = 1; L <= hc.nlev; L++) {                    // ---- sweep away from the root: accelerations, pushed into the children's slots
+        const int nk = NKC(L);
         const real *mine = buf + ((L + 1) & 1) * bstride;
         real *nxt = buf + (L & 1) * bstride;
         for (int ps = 0; ps * 5 < nk; ps++) {
           const int kk = ps * 5 + grp;
           if (on && kk < nk) {
-            const int e = ti(h.o_lev, s0 + kk), n = e & 255, cfirst = (e >> 16) & 255, cc = (e >> 24) & 255;
+            const int e0 = ti(hc.o_lev, 2 * (s0 + kk)), e1 = ti(hc.o_lev, 2 * (s0 + kk) + 1);
+            const int b = e0 & 255, jn = (e0 >> 8) & 255, cfirst = e1 & 255, cc = (e1 >> 8) & 255;
+            const real sgn = (e0 >> 24) & 1 ? real(-1) : real(1);
             const real *apk = mine + (kk * 12 + q_) * 6;
             real ap[6], acc[6];
 #pragma unroll
             for (int r_ = 0; r_ < 6; r_++) ap[r_] = apk[r_];
-            const real *yo = ys + (n * 12 + q_) * 3;
+            const real *yo = ys + (b * 12 + q_) * 3;
             real x0 = yo[0], x1 = yo[1], x2 = yo[2];
 #pragma unroll
-            for (int c = 0; c < 6; c++) { const float4_t wv = ld4(Wst + (n * 6 + c) * 4); x0 -= wv.x * ap[c]; x1 -= wv.y * ap[c]; x2 -= wv.z * ap[c]; }
-            const real *sn = S + 18 * n;
+            for (int c = 0; c < 6; c++) { const float4_t wv = ld4(Wst + (b * 6 + c) * 4); x0 -= wv.x * ap[c]; x1 -= wv.y * ap[c]; x2 -= wv.z * ap[c]; }
+            const real *sn = S + 18 * jn;
+            x0 *= sgn; x1 *= sgn; x2 *= sgn;
 #pragma unroll
             for (int r_ = 0; r_ < 6; r_++) acc[r_] = ap[r_] + sn[r_] * x0 + sn[6 + r_] * x1 + sn[12 + r_] * x2;
-            if (L + 1 < h.nlev)
+            if (L < hc.nlev)
               for (int j = 0; j < cc; j++) {
                 real *o = nxt + ((cfirst + j) * 12 + q_) * 6;
 #pragma unroll
                 for (int r_ = 0; r_ < 6; r_++) o[r_] = acc[r_];
               }
-            scatter(n - 1, acc);
+            scatter(b, acc);
           }
         }
         s0 += nk;
@@ -1828,7 +1642,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
     }
   };
 
-  // node n's factors as aba_solve_pelvis left them (body-body-contact instantiations: the re-solves apply D^-1 to new right-hand sides)
+  // body b's factors as aba_solve left them (body-body-contact instantiations: the re-solves apply D^-1 to new right-hand sides)
   SS_DEV Ldl3 load_ldl(int n) const {
     Ldl3 f;
     if constexpr (SELFCOL) {
