@@ -33,12 +33,14 @@ constexpr int kCandC = 8;    // floats per contact candidate
 // Header passed to the kernels by value: dims, table offsets (32-bit words into the shared blob),
 // per-env LDS layout (float offsets) and physics scalars.
 struct Hdr {
-  int nb, nn, nv, nq, nu, ncand, nlev, nblev, nbox, nslot, maxlev;
-  unsigned long long nkpack[2];      // (nodes in level L) - 1, 4 bits per level: level bounds by SALU shifts, no table/kernarg loads
+  int nb, nn, nv, nq, nu, ncand, nlev, reserved0, nbox, nslot, maxlev;
+  unsigned long long reserved1[2];   // reserved0..2: slots of the pelvis-rooted level tables (rounds 1-2).  Kept as padding: the offsets
+                                     // of the fields behind them are part of the kernels' register allocation, and closing the gaps
+                                     // cost 0.7 % on the headline (same-box A/B, profiles/r03_centred_elimination.md)
   // shared-blob word offsets
   // (o_dofc, o_boff: real-valued tables, offsets in reals from the start of the blob; the layout of this struct is part of
   // the kernel's register allocation — one more field here cost 850 SGPR reloads in the step kernel)
-  int o_dofc, o_boff, o_chainnode, o_ndepth, o_lev, o_bparent, o_sumsmall, o_sumbig, o_sumcover, n_sumsmall, n_sumbig, shared_words;
+  int o_dofc, o_boff, o_chainnode, o_ndepth, reserved2, o_bparent, o_sumsmall, o_sumbig, o_sumcover, n_sumsmall, n_sumbig, shared_words;
   // per-env LDS float offsets.  Z = solver region: Aown | IA (2 level buffers) | Ubuf | Wst ; aliases: contact records
   // at Z, R/r inside Wst, Gb and the body_accel scratch inside IA, Ad = Ubuf = An, V = Pb
   int l_q, l_v, l_a, l_tau, l_C, l_Pb, l_delta, l_diag, l_S, l_Ab, l_An, l_Aown, l_IA, l_Ubuf, l_Wst,
@@ -136,17 +138,16 @@ struct HdrFixed {
                        l_diag = LY.l_diag, l_S = LY.l_S, l_Ab = LY.l_Ab, l_An = LY.l_An, l_Aown = LY.l_Aown, l_IA = LY.l_IA,
                        l_Ubuf = LY.l_Ubuf, l_Wst = LY.l_Wst, l_R = LY.l_R, l_r = LY.l_r, l_Gb = LY.l_Gb, l_tmp = LY.l_tmp, l_V = LY.l_V,
                        l_Iown = LY.l_Iown, ia_stride = LY.ia_stride, env_floats = LY.env_floats;
-  const int &nu, &ncand, &nlev, &nblev, &nbox, &nslot;
-  const unsigned long long (&nkpack)[2];
-  const int &o_dofc, &o_boff, &o_chainnode, &o_ndepth, &o_lev, &o_bparent, &o_sumsmall, &o_sumbig, &o_sumcover, &n_sumsmall, &n_sumbig,
+  const int &nu, &ncand, &nlev, &nbox, &nslot;
+  const int &o_dofc, &o_boff, &o_chainnode, &o_ndepth, &o_bparent, &o_sumsmall, &o_sumbig, &o_sumcover, &n_sumsmall, &n_sumbig,
       &shared_words;
   const real &dt, &grav, &margin, &mu;
   const real (&solimp)[5];
   const real &K, &B;
   const real (&qpos0_root)[3];
   SS_HD explicit HdrFixed(const Hdr &h)
-      : nu(h.nu), ncand(h.ncand), nlev(h.nlev), nblev(h.nblev), nbox(h.nbox), nslot(h.nslot), nkpack(h.nkpack), o_dofc(h.o_dofc),
-        o_boff(h.o_boff), o_chainnode(h.o_chainnode), o_ndepth(h.o_ndepth), o_lev(h.o_lev), o_bparent(h.o_bparent),
+      : nu(h.nu), ncand(h.ncand), nlev(h.nlev), nbox(h.nbox), nslot(h.nslot), o_dofc(h.o_dofc),
+        o_boff(h.o_boff), o_chainnode(h.o_chainnode), o_ndepth(h.o_ndepth), o_bparent(h.o_bparent),
         o_sumsmall(h.o_sumsmall), o_sumbig(h.o_sumbig), o_sumcover(h.o_sumcover), n_sumsmall(h.n_sumsmall), n_sumbig(h.n_sumbig),
         shared_words(h.shared_words), dt(h.dt), grav(h.grav), margin(h.margin), mu(h.mu), solimp(h.solimp), K(h.K), B(h.B),
         qpos0_root(h.qpos0_root) {}
@@ -159,11 +160,11 @@ struct HdrFixedT {
   static bool matches(const Hdr &h) { return h.nb == NB && h.maxlev == MAXLEV; }
 };
 
-// Elimination tree of the articulated-body solves of the plain (no body-body contact) instantiations: the body tree re-rooted at its
-// CENTRE.  H x = b is a free-floating tree's system, any body can carry the six free unknowns; eliminating towards the centre
-// instead of towards the pelvis makes the sweeps as deep as the tree's radius, not its height (SMPL: 6 levels instead of 8,
-// SMPL-X: 7 instead of 10).  An edge walked against the kinematic direction uses the same joint with S -> -S; the free joint
-// becomes a bias force on body 0.  Built by ss_tables.h; appended to KArgs (Hdr's layout is part of the kernels' register allocation).
+// Elimination tree of the articulated-body solves: the body tree re-rooted at its CENTRE.  H x = b is a free-floating tree's system,
+// any body can carry the six free unknowns; eliminating towards the centre instead of towards the pelvis makes the sweeps as deep as
+// the tree's radius, not its height (SMPL: 6 levels instead of 8, SMPL-X: 7 instead of 10).  An edge walked against the kinematic
+// direction uses the same joint with S -> -S; the free joint becomes a bias force on body 0.  Built by ss_tables.h; a member of KArgs
+// rather than of Hdr (Hdr's layout is part of the kernels' register allocation).
 struct HdrC {
   int nlev;                    // levels below the root (level 1 = the root's neighbours)
   int o_lev;                   // word offset of the level records in the shared blob, 2 words per node, level 1 first:
@@ -228,7 +229,7 @@ struct KArgs {
   int32_t *work_counter_next; // the counter of the NEXT launch on this batch: zeroed by this one (no memset between launches)
   real *power;                // optional [N, nsub, nv - 6]: |torque * velocity| per mj_step (ss_set_power_output; body-output instantiations)
   int32_t *self_trunc;        // optional [N]: += 1 per mj_step whose body-body contact list was cut to kMaxSelf (ss_debug_self_truncation)
-  HdrC hc;                    // centred elimination tree (aba_solve of the plain instantiations)
+  HdrC hc;                    // elimination tree of aba_solve / aba_resolve / aba_columns
 };
 
 // floats of one env's LDS slice for this launch

@@ -64,16 +64,15 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   const int nn = h.nn, nv = h.nv;
 
   // ---- node tree
-  std::vector<int> nparent(nn), ndepth(nn), bdepth(nb);
-  nparent[0] = -1; ndepth[0] = 0; nparent[1] = 0; ndepth[1] = 1; bdepth[0] = 0;
+  std::vector<int> nparent(nn), ndepth(nn);
+  nparent[0] = -1; ndepth[0] = 0; nparent[1] = 0; ndepth[1] = 1;
   for (int b = 1; b < nb; b++) {
     int p = d.body_parent[b];
-    nparent[b + 1] = p + 1; ndepth[b + 1] = ndepth[p + 1] + 1; bdepth[b] = bdepth[p] + 1;
+    nparent[b + 1] = p + 1; ndepth[b + 1] = ndepth[p + 1] + 1;
   }
-  int nlev = 0, nblev = 0;
+  int nlev = 0;
   for (int n = 0; n < nn; n++) nlev = std::max(nlev, ndepth[n] + 1);
-  for (int b = 0; b < nb; b++) nblev = std::max(nblev, bdepth[b] + 1);
-  h.nlev = nlev; h.nblev = nblev;
+  h.nlev = nlev;
   const int CN = nlev;                                     // chain node table row width
   std::vector<int> chainnode(nn * CN, 0);
   for (int n = 0; n < nn; n++) {
@@ -82,17 +81,13 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
     for (size_t k = 0; k < anc.size(); k++) chainnode[n * CN + k] = anc[k];
     chainnode[n * CN + anc.size()] = n;                    // convenient: chain includes self at its depth
   }
-  std::vector<int> levstart(nlev + 1, 0), levnodes, blevstart(nblev + 1, 0), blevbodies;
-  for (int L = 0; L < nlev; L++) {
-    levstart[L] = (int)levnodes.size();
-    for (int n = 0; n < nn; n++) if (ndepth[n] == L) levnodes.push_back(n);
+  // bodies must come in depth-first order (the subtree of b is the index range [b, b + size): subtree_sum): b's parent is
+  // b - 1 or one of its ancestors
+  for (int b = 2; b < nb; b++) {
+    int a = b - 1;
+    while (a > 0 && a != d.body_parent[b]) a = d.body_parent[a];
+    if (a != d.body_parent[b]) { out.error = "bodies must be in depth-first order"; return false; }
   }
-  levstart[nlev] = (int)levnodes.size();
-  for (int L = 0; L < nblev; L++) {
-    blevstart[L] = (int)blevbodies.size();
-    for (int b = 0; b < nb; b++) if (bdepth[b] == L) blevbodies.push_back(b);
-  }
-  blevstart[nblev] = (int)blevbodies.size();
 
   for (int i = 0; i < 6; i++)                              // the root solve treats the free joint as a plain 6x6 system
     if (d.dof_armature[i] != 0.0) { out.error = "armature on the free joint is not supported"; return false; }
@@ -179,32 +174,8 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   }
 
   // ---- shared blob (copied into LDS once per workgroup)
-  if (nlev > 32 || nblev > 32) { out.error = "tree too deep"; return false; }
-  // level records of the articulated-body sweeps, one word per node in level order:
-  //   n | parent_node<<8 | first_child_slot<<16 | child_count<<24
-  // (bodies are in depth-first order, so the children of a node are contiguous in the next level's list)
-  std::vector<int> lev(nn, 0);
-  int maxlev = 0;
-  for (int L = 0; L < nlev; L++) {
-    const int nk = levstart[L + 1] - levstart[L];
-    maxlev = std::max(maxlev, nk);
-    for (int kk = 0; kk < nk; kk++) {
-      const int n = levnodes[levstart[L] + kk];
-      int cfirst = 0, cc = 0;
-      if (L + 1 < nlev)
-        for (int k2 = 0; k2 < levstart[L + 2] - levstart[L + 1]; k2++)
-          if (nparent[levnodes[levstart[L + 1] + k2]] == n) {
-            if (cc == 0) cfirst = k2;
-            else if (k2 != cfirst + cc) { out.error = "bodies must be in depth-first order"; return false; }
-            cc++;
-          }
-      lev[levstart[L] + kk] = n | ((n > 0 ? nparent[n] : 0) << 8) | (cfirst << 16) | (cc << 24);
-    }
-  }
-  if (maxlev > 16) { out.error = "more than 16 nodes in one tree level"; return false; }
-  h.maxlev = maxlev;
-  h.nkpack[0] = h.nkpack[1] = 0ull;
-  for (int L = 0; L < nlev; L++) h.nkpack[L >> 4] |= (unsigned long long)(levstart[L + 1] - levstart[L] - 1) << (4 * (L & 15));
+  if (nlev > 32) { out.error = "tree too deep"; return false; }
+  int maxlev = 0;                                           // widest level of the elimination tree (below)
   auto &S = out.shared; S.clear();
   auto push_i = [&](const std::vector<int> &v) { int o = (int)S.size(); for (int x : v) S.push_back((uint32_t)x); return o; };
   std::vector<real> Sf;                                    // real-valued tables, appended behind the integer ones below
@@ -213,7 +184,6 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   for (int b = 0; b < nb; b++) for (int k = 0; k < 3; k++) Sf.push_back(b == 0 ? real(0) : (real)d.body_pos[3 * b + k]);
   h.o_chainnode = push_i(chainnode);
   h.o_ndepth = push_i(ndepth);
-  h.o_lev = push_i(lev);
   std::vector<int> bpar(d.body_parent, d.body_parent + nb);
   h.o_bparent = push_i(bpar);
   {
@@ -256,8 +226,9 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
     h.o_sumsmall = push_i(small_l); h.o_sumbig = push_i(big_l); h.o_sumcover = push_i(cover);
   }
   {
-    // ---- centred elimination tree (HdrC): the root minimises the depth (ties: the narrower widest level, then the lower index);
-    // the widest level may not exceed 16 nodes (two passes of 8 lane groups)
+    // ---- elimination tree of the articulated-body sweeps (HdrC): the body tree re-rooted at its centre.  The root minimises the
+    // depth (ties: the narrower widest level, then the lower index); the widest level may not exceed 16 nodes (two passes of 8
+    // lane groups)
     std::vector<std::vector<int>> adj(nb);
     for (int b = 1; b < nb; b++) { adj[b].push_back(d.body_parent[b]); adj[d.body_parent[b]].push_back(b); }
     auto bfs = [&](int c, std::vector<int> &dep, std::vector<int> &towards) {
@@ -304,7 +275,9 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
     }
     if (rec.empty()) { rec.push_back(0); rec.push_back(0); }
     hc.o_lev = push_i(rec);
-    h.maxlev = maxlev;                                        // the level buffers are sized for the wider of the two trees
+    if (maxlev > 16) { out.error = "more than 16 nodes in one tree level"; return false; }
+    if (maxlev < 1) maxlev = 1;
+    h.maxlev = maxlev;                                        // sizes the level buffers of the LDS layout
   }
   while (S.size() % 4) S.push_back(0u);                     // reals start 16-byte aligned
   out.o_real = (int)S.size();
@@ -313,7 +286,6 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   h.shared_words = (int)S.size();
   const int real0 = out.o_real / (int)(sizeof(real) / 4);   // kernel-side offsets count reals from the start of the blob
   h.o_dofc += real0; h.o_boff += real0;
-  (void)blevstart; (void)blevbodies;
 
   // ---- per-env LDS layout (floats); arrays with disjoint lifetimes share storage (LDS capacity sets the number
   // of resident envs per CU)

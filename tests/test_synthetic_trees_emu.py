@@ -46,7 +46,7 @@ def _comb(branches):
     return _table(bodies)
 
 
-@pytest.mark.parametrize("name,table,root_z", [("chain15", _chain(14), 2.8), ("comb9", _comb(9), 0.40)])
+@pytest.mark.parametrize("name,table,root_z", [("chain15", _chain(14), 2.8), ("comb9", _comb(9), 0.40), ("comb17", _comb(17), 0.40)])
 def test_synthetic_tree_matches_oracle(name, table, root_z):
     xml = table_to_mjcf(table)
     mc = compile_mjcf(xml)
@@ -83,7 +83,9 @@ def test_synthetic_tree_matches_oracle(name, table, root_z):
 
 
 def test_too_many_nodes_in_one_level_is_rejected():
-    xml = table_to_mjcf(_comb(17))                              # 17 nodes in one tree level > the 16 the kernels handle
+    # 18 branches: whichever body the elimination tree is rooted at, one level holds >= 17 nodes > the 16 the kernels handle
+    # (17 branches fit: rooted at a branch, the root body and the other 16 branches are on different levels)
+    xml = table_to_mjcf(_comb(18))
     mc = compile_mjcf(xml)
     nu = mc.nu
     tables = (np.full(nu, 60.0), np.full(nu, 6.0), np.full(nu, 40.0), np.full(nu, 2.0), np.zeros(nu))
