@@ -6,6 +6,12 @@ for w in getup smplx imitation; do
   timeout 600 python bench.py --workload $w --steps 300 --warmup 20 --no-cpu-baseline > gpurun_out/r03_bench_${w}.json 2>> gpurun_out/bench.err; echo "bench $w rc=$?"
 done
 timeout 600 python bench.py --steps 100 --warmup 20 --no-cpu-baseline --self-collision > gpurun_out/r03_bench_smpl4096_selfcollision.json 2>> gpurun_out/bench.err; echo "bench selfcol rc=$?"
+if [ -n "$BENCH_ONLY" ]; then   # only the bench lines (they cite profiles/pmc_summary_*.json as committed)
+  for f in gpurun_out/r03_bench_*.json; do python -c "
+import json,sys
+d=json.load(open('$f')); print('$f', round(d['value']), round(d['ms_per_step'],3), d['roofline'].get('kernel_ms'), d['roofline'].get('frac'))"; done
+  exit 0
+fi
 TAG=r03_smpl WORKLOAD=smpl ENVS_PER_GPU=4096 BENCH_ARGS="--no-reference-contact-set" bash tools/gpu_prof.sh > gpurun_out/prof_smpl.log 2>&1; echo "prof smpl rc=$?"
 TAG=r03_getup WORKLOAD=getup ENVS_PER_GPU=4096 BENCH_ARGS="--workload getup --no-reference-contact-set" bash tools/gpu_prof.sh > gpurun_out/prof_getup.log 2>&1; echo "prof getup rc=$?"
 TAG=r03_smplx WORKLOAD=smplx ENVS_PER_GPU=4096 BENCH_ARGS="--workload smplx --no-reference-contact-set" bash tools/gpu_prof.sh > gpurun_out/prof_smplx.log 2>&1; echo "prof smplx rc=$?"
