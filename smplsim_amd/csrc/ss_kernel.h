@@ -1117,6 +1117,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       for (int ps = 0; ps < NPASS; ps++) {                    // ---- part 1: articulated row, U_r = IA_r S', partial S'^T U
         const int kk = ps * 8 + g;
         nod[ps] = -1; jnt[ps] = 0;
+        if (ps > 0 && ps * 8 >= nk) continue;                 // wave-uniform: a level of <= 8 nodes runs one pass (SMPL-X: 4 of 7 levels)
 #pragma unroll
         for (int t = 0; t < 9; t++) red[ps][t] = 0.f;
         if (r_ < 6 && kk < nk) {
@@ -1158,11 +1159,14 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       SS_FTICK(PF_F_P13);
       w->sync();                                              // U rows visible to the node's other lanes
 #pragma unroll
-      for (int ps = 0; ps < NPASS; ps++)
+      for (int ps = 0; ps < NPASS; ps++) {
+        if (ps > 0 && ps * 8 >= nk) continue;
 #pragma unroll
         for (int t = 0; t < 9; t++) red[ps][t] = w->sum8(red[ps][t]);
+      }
 #pragma unroll
       for (int ps = 0; ps < NPASS; ps++) {                    // ---- part 2: joint-space 3x3 algebra, rows handed towards the root
+        if (ps > 0 && ps * 8 >= nk) continue;
         const int kk = ps * 8 + g, b = nod[ps], jn = jnt[ps];
         if (b >= 0) {
           float4_t U[6];
@@ -1267,6 +1271,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       const bool pel_level = L == hc.pel_level;               // wave-uniform: this level holds body 0
 #pragma unroll
       for (int ps = 0; ps < NPASS; ps++) {
+        if (ps > 0 && ps * 8 >= nk) continue;
         const int kk = ps * 8 + g;
         int b = -1, jn = 0, pel = 0;
         real p0 = 0.f, p1 = 0.f, p2 = 0.f, apr = 0.f, s_0 = 0.f, s_1 = 0.f, s_2 = 0.f;
@@ -1330,6 +1335,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
         const real *prev = IA + ((L + 1) & 1) * h.ia_stride;
 #pragma unroll
         for (int ps = 0; ps < NPASS; ps++) {
+          if (ps > 0 && ps * 8 >= nk) continue;
           const int kk = ps * 8 + g;
           int b = -1, jn = 0;
           real pa[K], red[K][3], wr0 = 0, wr1 = 0, wr2 = 0;
@@ -1421,6 +1427,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
         const bool pel_level = xout && L == hc.pel_level;
 #pragma unroll
         for (int ps = 0; ps < NPASS; ps++) {
+          if (ps > 0 && ps * 8 >= nk) continue;
           const int kk = ps * 8 + g;
           int b = -1, jn = 0, en = 0, pel = 0;
           real s_0 = 0.f, s_1 = 0.f, s_2 = 0.f;
