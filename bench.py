@@ -180,7 +180,7 @@ def parity_probe(env, abuf, g, humanoid, n=64):
             "oracle": "oracle/oracle.c float64 at MuJoCo's solver settings (tolerance 1e-8 x meaninertia x nv, 100 iterations); NOT MuJoCo itself"}
 
 
-def reference_contact_set(args, rank, local_rank, dev, humanoid_model, workload_kw, steps=20, warmup=5):
+def reference_contact_set(args, rank, local_rank, dev, humanoid_model, workload_kw, steps=30, warmup=20):
     """The same batch with the reference MJCF's full contact set (body-body contacts on, smpl_humanoid.xml:5,24,231-242): a short
     run after the headline loop, so that the driver-run line carries the figure next to the floor-contact one."""
     import torch

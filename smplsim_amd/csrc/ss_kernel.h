@@ -115,7 +115,7 @@ template <> struct ShapeTables<true> { const real *bodyc_s, *candc_s, *dinvw_s, 
 template <bool SELFCOL> struct SelfColState {};
 template <> struct SelfColState<true> {
   real *rec, *G, *uvec, *lam, *Pb2, *delta2, *gc;          // per-env LDS arrays (HdrSC)
-  real *Dinv, *rootf, *ysave, *An3;                        // D's factors (Ldl3) per node and the root's block inverses of the last aba_solve; re-solve buffers
+  real *Dinv, *rootf, *ysave, *An3;                        // D's factors (Ldl3) per body and the root's block inverses of the last aba_solve; re-solve buffers
   int nself;                                               // wave-uniform count of body-body contacts of this pass
   // the tree Hessian of consecutive Newton iterations of one mj_step differs only when a floor-contact / joint-limit row changes
   // side: while this lane's rows keep their state (sig) the factorization in LDS and the Delassus columns computed so far stay valid
@@ -1054,16 +1054,16 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
   // H = sum_b J_b^T A_b J_b + diag  (J_b = body Jacobian, A_b = 6x6 generalized inertia of body b: its spatial
   // inertia, plus the contact matrix K_b in the Newton system; diag = armature (+ limit rows / Kd dt)).  That is a
   // mass matrix with generalized body inertias, so the system is solved like forward dynamics, by Featherstone's
-  // articulated-body recursion over the node tree — H is never formed or factored.  All spatial quantities live
-  // in one world-aligned frame, so parent accumulation is a plain add.
-  //   up   (leaves -> root), node n:  IA = A_n + sum_children IA'_c,  pA = sum_children pA'_c
-  //        U = IA S_n, D = S_n^T U + diag_n, u = b_n - S_n^T pA, W = U D^-1, y = D^-1 u
-  //        IA' = IA - W U^T,  pA' = pA + U y            (handed to the parent)
-  //   down (root -> leaves):          x_n = y - W^T a_parent,  a_n = a_parent + S_n x_n
+  // articulated-body recursion over the ELIMINATION TREE (the body tree re-rooted at its centre, see aba_solve) — H is never
+  // formed or factored.  All spatial quantities live in one world-aligned frame, so accumulation towards the root is a plain add.
+  //   towards the root, node (body b, joint j):  IA = A_b + sum_children IA'_c,  pA = pb_b + sum_children pA'_c
+  //        U = IA S'_j, D = S'_j^T U + diag_j, u = b_j - S'_j^T pA, W = U D^-1, y = D^-1 u     (D^-1 by substitution: Ldl3)
+  //        IA' = IA - W U^T,  pA' = pA + U y            (handed to the neighbour towards the root)
+  //   away from the root:                         x_j = y - W^T a_e,  a_b = a_e + S'_j x_j
   // Lane roles: 8 lanes per node of the level (lane = 8 * slot + r), lane r < 6 owns row r of the node's 6x6 / 6x3
-  // quantities; the 3x3 joint-space algebra is redundant per lane.  Two wave syncs per level going up, one going
-  // down.  Rows of the level's IA', pA' go through a two-level LDS buffer; (W_r, y_r) are kept per node.
-  // On return x holds the solution and An[8 n ..] the node accelerations a_n (= the body accelerations J_b x).
+  // quantities; the 3x3 joint-space algebra is redundant per lane.  Two wave syncs per level going towards the root, one going
+  // away.  Rows of the level's IA', pA' go through a two-level LDS buffer; (W_r, y_r) are kept per body.
+  // On return x holds the solution and An[8 (b + 1) ..] the body accelerations a_b = J_b x.
   SS_DEV static void st4w(real *p, real a, real b, real c, real d) { float4_t v; v.x = a; v.y = b; v.z = c; v.w = d; *reinterpret_cast<float4_t *>(p) = v; }
 
   SS_DEV void write_own_inertia() {                          // Aown[b] = expand(Ib), packed upper triangle (ang;lin)
