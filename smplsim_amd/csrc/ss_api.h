@@ -165,6 +165,7 @@ struct ss_api {
     if (m->num_shapes > 1 && !st->shape_id) return fail(SS_ERR_INVALID, "a model with several shapes needs ss_state.shape_id");
     if (m->num_shapes == 1 && st->shape_id) return fail(SS_ERR_INVALID, "ss_state.shape_id given for a single-shape model");
     if (cfg->self_collision && !m->d_pairs) return fail(SS_ERR_INVALID, "model has no pair table");
+    if (cfg->self_collision && !m->hm.self_collision_unavailable.empty()) return fail(SS_ERR_INVALID, m->hm.self_collision_unavailable.c_str());
     if (cfg->task == SS_TASK_REACH && (cfg->reach_body < 0 || cfg->reach_body >= m->hm.h.nb)) return fail(SS_ERR_INVALID, "reach_body out of range");
     const ss::Hdr &h = m->hm.h;
     if (ss::kernel_variant(h) < 0) return fail(SS_ERR_INVALID, "model too large for the compiled kernel variants");

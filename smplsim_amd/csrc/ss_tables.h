@@ -37,6 +37,7 @@ struct HostModel {
   HdrC hc{};                      // centred elimination tree of the plain solves
   double meaninertia = 0;         // mjModel.stat.meaninertia (scale of the solver's termination test)
   std::string error;
+  std::string self_collision_unavailable;   // non-empty: the model cannot run with ss_env_cfg.self_collision (reason)
 };
 
 // real-valued part of the shared blob (HostModel::shared from word h.o_real on)
@@ -334,7 +335,8 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   }
   out.sc = make_layout_sc(nb, h.env_floats, h.l_Aown);
   // up to Wst (kept for the re-solves) everything behind Aown is solver scratch
-  if (24 * (nb + 1) > h.l_Wst - h.l_Aown || 2 * 72 * h.maxlev > h.l_Wst - h.l_Aown) { out.error = "no room for the re-solve buffers over Aown / IA"; return false; }
+  // (a tree of two bodies is too small for that; such a model still steps without body-body contacts — it has no candidate pair anyway)
+  if (24 * (nb + 1) > h.l_Wst - h.l_Aown || 2 * 72 * h.maxlev > h.l_Wst - h.l_Aown) out.self_collision_unavailable = "no room for the re-solve buffers over Aown / IA";
   out.sc.npair = (int)out.pairs.size() / 2;
 
   h.dt = (real)d.timestep; h.grav = (real)d.gravity; h.margin = (real)d.margin; h.mu = (real)d.friction;
