@@ -157,6 +157,10 @@ int ss_model_create_from_mjcf(const char *xml, size_t len, const ss_mjcf_options
 void ss_model_destroy(ss_model *m);
 /* nq, nv, nu, nbody, obs size for (self_obs_v, task, root_height_obs) — humanoid_env.py:293-299 */
 int ss_model_dims(const ss_model *m, int32_t *nq, int32_t *nv, int32_t *nu, int32_t *nbody);
+/* Diagnostics: the elimination tree of the articulated-body solves ("the elimination tree is rooted at the centre of the
+ * body tree"): root = the body the sweeps run towards (SMPL: 10, Spine; SMPL-X: Chest), levels = tree levels below it (6 / 7; rooted
+ * at the pelvis the trees are 8 / 10 deep), widest = nodes in its widest level (<= 16).  Any pointer may be NULL. */
+int ss_model_elimination_tree(const ss_model *m, int32_t *root, int32_t *levels, int32_t *widest);
 int ss_obs_size(const ss_model *m, const ss_env_cfg *cfg);
 
 /* mujoco.MjData(model) for N envs: binds caller-owned state buffers */

@@ -120,6 +120,7 @@ def bind(lib):
     lib.ss_debug_forward.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.ss_debug_self_contacts.argtypes = [vp, vp]
     lib.ss_debug_self_truncation.argtypes = [vp, vp]
+    lib.ss_model_elimination_tree.argtypes = [vp, vp, vp, vp]
     lib.ss_step_autoreset.argtypes = [vp] * 10
     lib.ss_schedule_longest_first.argtypes = [vp, vp]
     lib.ss_gae.argtypes = [vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_float, C.c_float, vp, vp, vp]
@@ -150,7 +151,7 @@ def bind_mlp(lib):
     return lib
 
 
-EXPORTS = ["ss_model_create", "ss_model_create_shapes", "ss_model_destroy", "ss_model_dims", "ss_obs_size", "ss_batch_create",
+EXPORTS = ["ss_model_create", "ss_model_create_shapes", "ss_model_destroy", "ss_model_dims", "ss_model_elimination_tree", "ss_obs_size", "ss_batch_create",
            "ss_batch_destroy", "ss_reset", "ss_step", "ss_step_autoreset", "ss_substep", "ss_kinematics", "ss_debug_forward", "ss_debug_self_contacts", "ss_debug_self_truncation",
            "ss_gae", "ss_debug_prof", "ss_set_order", "ss_set_body_outputs", "ss_set_power_output", "ss_set_launch_geometry", "ss_schedule_longest_first", "ss_launch_info", "ss_last_error",
            "ss_model_create_from_mjcf", "ss_model_last_error", "ss_batch_last_error", "ss_imitation_bind", "ss_imitation_step_fused", "ss_get_state", "ss_set_state", "ss_set_fall_actions",

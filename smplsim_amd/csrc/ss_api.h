@@ -360,6 +360,14 @@ struct ss_api {
     if (nb) *nb = m->hm.h.nb;                                                                                        \
     return SS_OK;                                                                                                    \
   }                                                                                                                  \
+  int ss_model_elimination_tree(const ss_model *m, int32_t *root, int32_t *levels, int32_t *widest) {                 \
+    ss::HandleScope hs_(m ? &m->err : nullptr);                                                                      \
+    if (!m) return ss_api<BE>::fail(SS_ERR_INVALID, "null model");                                                   \
+    if (root) *root = m->hm.hc.root;                                                                                 \
+    if (levels) *levels = m->hm.hc.nlev;                                                                             \
+    if (widest) *widest = m->hm.h.maxlev;                                                                            \
+    return SS_OK;                                                                                                    \
+  }                                                                                                                  \
   int ss_obs_size(const ss_model *m, const ss_env_cfg *c) { return (m && c) ? ss::obs_size(m->hm.h, *c) : SS_ERR_INVALID; } \
   int ss_batch_create(const ss_model *m, const ss_env_cfg *c, const ss_state *s, ss_batch **o) { ss::HandleScope hs_(m ? &m->err : nullptr); return ss_api<BE>::batch_create(m, c, s, o); } \
   void ss_batch_destroy(ss_batch *b) { if (b) { BE::free_(b->d_kin); BE::free_(b->d_im); BE::free_(b->d_counter); BE::free_(b->d_prof); BE::free_(b->d_sched); delete b; } }          \

@@ -115,3 +115,19 @@ def test_smallest_trees_step_like_the_oracle(n):
     eb.substep(a[None], 30)
     assert np.abs(eb.qpos[0] - oenv.data.qpos).max() < 2e-6
     assert np.abs(eb.qvel[0] - oenv.data.qvel).max() < 2e-5
+
+
+def _tree(name):
+    import ctypes as C
+    from helpers import FEET, model_const, pd_tables
+    mc = model_const(name)
+    eb = emu.EmuBatch(mc, pd_tables(mc), 1, legal_bodies=FEET)
+    root, lev, wid = C.c_int32(), C.c_int32(), C.c_int32()
+    assert eb.L.ss_model_elimination_tree(eb.model, C.byref(root), C.byref(lev), C.byref(wid)) == 0
+    return mc.body_names[root.value], lev.value, wid.value
+
+
+def test_elimination_tree_of_the_shipped_humanoids_is_rooted_at_the_centre():
+    """SMPL: rooted at the Spine the sweeps are 6 levels deep (8 below the pelvis: the arm chain); SMPL-X: Chest, 7 levels (10)."""
+    assert _tree("smpl_humanoid") == ("Spine", 6, 5)
+    assert _tree("smplx_humanoid") == ("Chest", 7, 12)
