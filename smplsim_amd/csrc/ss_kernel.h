@@ -51,8 +51,8 @@
 namespace ss {
 
 enum { PF_FWD = 0, PF_CONS, PF_NBEGIN, PF_NPREP, PF_ASM, PF_FACTOR, PF_SOLVE, PF_NFIN, PF_SPDPREP, PF_SPDFIN, PF_INTEG, PF_MISC,
-       PF_F_P13, PF_F_SYNC1, PF_F_P2, PF_F_BSOL, PF_F_SYNC2,
-       PF_K_PRO, PF_K_LEV, PF_K_INERTIA, PF_K_SUMS, PF_P_BASE, PF_P_CONTACT, PF_P_SUMS, PF_P_GRAD,
+       PF_F_P13, PF_F_SYNC1, PF_F_P2, PF_F_BSOL, PF_K_CHAIN,
+       PF_K_PRO, PF_K_LEV, PF_K_INERTIA, PF_K_SUMS, PF_K_VPROD, PF_P_CONTACT, PF_P_SUMS, PF_P_GRAD,
        PF_SC_NARROW, PF_SC_BASE, PF_SC_COLS, PF_SC_DENSE, PF_SC_FINAL, PF_COUNT };
 #ifdef SS_PROFILE
 #define SS_FT0() unsigned long long ft__ = w->clock()
@@ -429,6 +429,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
     // node terms + chain sums again
     chain_sum(Ad, V, Wst + 12 * h.nb, Ab);                   // Ab: body accelerations of the iterate newton_begin starts from
     w->sync();
+    SS_FTICK(PF_K_CHAIN);
     if (lane < h.nn) {
       const int n = lane;
       real d[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -462,6 +463,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
     w->sync();
     chain_sum(tmpb, Ad);
     w->sync();
+    SS_FTICK(PF_K_VPROD);
     if (lane < h.nb) {
 #pragma unroll
       for (int c = 0; c < 6; c++) { vb[c] = V[6 * lane + c]; ab[c] = Ad[6 * lane + c]; }

@@ -33,8 +33,8 @@ torch.cuda.synchronize()
 out = (C.c_ulonglong * 64)()
 rc = _lib.lib().ss_debug_prof(env.handle, out, 40)
 names = ["fwd_kin", "constraints", "newton_begin", "newton_prepare", "sc:broad phase", "aba_solve", "sc:pair function calls", "newton_finish",
-         "spd_prepare", "spd_finish", "integrate", "misc", "aba:up_phase1", "aba:up_last_sync", "aba:up_phase2", "aba:down", "(unused)",
-         "fk:prologue", "fk:level_sweep", "fk:inertia_bias", "fk:subtree_C", "prep:base", "prep:contactK", "prep:subtree", "prep:grad",
+         "spd_prepare", "spd_finish", "integrate", "misc", "aba:up_phase1", "aba:up_last_sync", "aba:up_phase2", "aba:down", "fk:chain sums (V, Ab)",
+         "fk:prologue", "fk:level_sweep", "fk:body inertia + bias force", "fk:subtree_C", "fk:velocity products + chain sum", "prep:contactK", "prep:subtree", "prep:grad",
          "selfcol:pair functions", "selfcol:factor+base solve", "selfcol:Delassus columns", "selfcol:dense solve", "selfcol:final re-solve"]
 tot = sum(out[i] for i in range(12))
 iters = float(env.solver_iters.float().mean().item())
