@@ -95,13 +95,13 @@ constexpr int kGeomC = 16;                       // floats per body in the geom 
 struct HdrSC {
   int npair;                                     // candidate body pairs of the model (b1 | b2 << 8 each)
   int l_rec, l_G, l_u, l_lam, l_Pb2, l_delta2, l_gc;   // float offsets in the env slice
-  int l_Dinv, l_rootf, l_ysave, l_An3;                 // factor pieces kept for re-solves, and the 3-right-hand-side sweep's buffers
+  int l_Dinv, l_rootf, l_ysave, l_An3;                 // factor pieces kept for the re-solves (l_An3: unused since the Delassus columns are
+                                                       // aba_columns' — the slot stays, HdrSC's offsets are part of the register allocation like Hdr's)
   int env_floats;                                // slice size of a SELFCOL env
 };
-// l_Aown: the base layout's Aown offset.  The 3-right-hand-side sweep's acceleration buffer An3 (24 floats per node) lies over Aown
+// l_Aown: the base layout's Aown offset.  aba_columns' two level buffers (72 floats per node of the widest level each) lie over Aown
 // and the head of IA behind it: Aown is dead once the tree Hessian is factorized (every consumer rewrites it first) and the re-solves
-// use IA only in their upward sweep, An3 only from the root on, and An3 is read out before the next sweep starts.  (Without this
-// the SMPL slice was 21.7 KB = 7 envs per CU; with it 19.3 KB = 8.)
+// use IA only in their sweep towards the root.  (Without this the SMPL slice was 21.7 KB = 7 envs per CU; with it 19.3 KB = 8.)
 constexpr HdrSC make_layout_sc(int nb, int base_floats, int l_Aown) {
   const int nv = 6 + 3 * (nb - 1);
   HdrSC y{};

@@ -115,7 +115,7 @@ template <> struct ShapeTables<true> { const real *bodyc_s, *candc_s, *dinvw_s, 
 template <bool SELFCOL> struct SelfColState {};
 template <> struct SelfColState<true> {
   real *rec, *G, *uvec, *lam, *Pb2, *delta2, *gc;          // per-env LDS arrays (HdrSC)
-  real *Dinv, *rootf, *ysave, *An3;                        // D's factors (Ldl3) per body and the root's block inverses of the last aba_solve; re-solve buffers
+  real *Dinv, *rootf, *ysave;                              // D's factors (Ldl3) per body and the root's block inverses of the last aba_solve; re-solve buffers
   int nself;                                               // wave-uniform count of body-body contacts of this pass
   // the tree Hessian of consecutive Newton iterations of one mj_step differs only when a floor-contact / joint-limit row changes
   // side: while this lane's rows keep their state (sig) the factorization in LDS and the Delassus columns computed so far stay valid
@@ -183,7 +183,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       const HdrSC &y = k->sc;
       this->rec = L + y.l_rec; this->G = L + y.l_G; this->uvec = L + y.l_u; this->lam = L + y.l_lam; this->Pb2 = L + y.l_Pb2;
       this->delta2 = L + y.l_delta2; this->gc = L + y.l_gc; this->nself = 0;
-      this->Dinv = L + y.l_Dinv; this->rootf = L + y.l_rootf; this->ysave = L + y.l_ysave; this->An3 = L + y.l_An3;
+      this->Dinv = L + y.l_Dinv; this->rootf = L + y.l_rootf; this->ysave = L + y.l_ysave;
     }
 #pragma unroll
     for (int p = 0; p < SLOTP; p++) con[p].active = 0;
