@@ -1115,8 +1115,9 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       const real *prev = IA + ((L + 1) & 1) * h.ia_stride;
       real row[NPASS][6], pa[NPASS], Ur[NPASS][3], red[NPASS][9];
       int nod[NPASS], jnt[NPASS];
+      real sg[NPASS];
 #pragma unroll
-      for (int ps = 0; ps < NPASS; ps++) {                    // ---- part 1: articulated row, U_r = IA_r S', partial S'^T U
+      for (int ps = 0; ps < NPASS; ps++) {                    // ---- part 1: articulated row, U_r = IA_r S_j, partial S_j^T U
         const int kk = ps * 8 + g;
         nod[ps] = -1; jnt[ps] = 0;
         if (ps > 0 && ps * 8 >= nk) continue;                 // wave-uniform: a level of <= 8 nodes runs one pass (SMPL-X: 4 of 7 levels)
@@ -1126,7 +1127,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
           const int e0 = ti(hc.o_lev, 2 * (s0 + kk)), e1 = ti(hc.o_lev, 2 * (s0 + kk) + 1);
           const int b = e0 & 255, jn = (e0 >> 8) & 255, cfirst = e1 & 255, cc = (e1 >> 8) & 255;
           const real sgn = (e0 >> 24) & 1 ? real(-1) : real(1);
-          nod[ps] = b; jnt[ps] = jn;
+          nod[ps] = b; jnt[ps] = jn; sg[ps] = sgn;
           real rw[6], pv = pb ? pb[6 * b + r_] : 0.f;
           if ((e0 >> 25) & 1) pv -= fb_force();
           const real *ao = Aown + 21 * b;
@@ -1136,7 +1137,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
           const real *sn = S + 18 * jn;
 #pragma unroll
           for (int t = 0; t < 18; t++) sv[t] = sn[t];
-          const real sr0 = sgn * sn[r_], sr1 = sgn * sn[6 + r_], sr2 = sgn * sn[12 + r_];   // row r of S'
+          const real sr0 = sn[r_], sr1 = sn[6 + r_], sr2 = sn[12 + r_];   // row r of S_j (the sign of S' cancels in U D^-1 U^T and in D)
           for (int j = 0; j < cc; j++) {
             const real *src = prev + ((cfirst + j) * 6 + r_) * 8;
             const float4_t v0 = ld4(src), v1 = ld4(src + 4);
@@ -1147,7 +1148,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
             real acc = 0.f;
 #pragma unroll
             for (int c = 0; c < 6; c++) acc += rw[c] * sv[6 * j + c];
-            Ur[ps][j] = sgn * acc;
+            Ur[ps][j] = acc;
           }
 #pragma unroll
           for (int c = 0; c < 6; c++) row[ps][c] = rw[c];
@@ -1174,7 +1175,10 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
           float4_t U[6];
 #pragma unroll
           for (int c = 0; c < 6; c++) U[c] = ld4(Ubuf + (kk * 6 + c) * 4);
-          const real u0 = x[3 * jn] - red[ps][6], u1 = x[3 * jn + 1] - red[ps][7], u2 = x[3 * jn + 2] - red[ps][8];
+          // with S' = sgn S_j:  D, IA' = IA - W U^T and W U^T do not see the sign; u' = sgn u = sgn b_j - S_j^T pA gives y' = sgn y,
+          // pA' = pA + U y' and, on the way back, z = sgn q''_j = y' - W^T a_e, a_b = a_e + S_j z: W and y' are stored for the unsigned S_j
+          const real sgn = sg[ps];
+          const real u0 = sgn * x[3 * jn] - red[ps][6], u1 = sgn * x[3 * jn + 1] - red[ps][7], u2 = sgn * x[3 * jn + 2] - red[ps][8];
           Ldl3 Dj;
           Dj.factor(red[ps][0] + diag[3 * jn], red[ps][1], red[ps][2] + diag[3 * jn + 1], red[ps][3], red[ps][4], red[ps][5] + diag[3 * jn + 2]);
           real y0, y1, y2, w0, w1, w2;
@@ -1276,23 +1280,23 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
         if (ps > 0 && ps * 8 >= nk) continue;
         const int kk = ps * 8 + g;
         int b = -1, jn = 0, pel = 0;
-        real p0 = 0.f, p1 = 0.f, p2 = 0.f, apr = 0.f, s_0 = 0.f, s_1 = 0.f, s_2 = 0.f;
+        real p0 = 0.f, p1 = 0.f, p2 = 0.f, apr = 0.f, s_0 = 0.f, s_1 = 0.f, s_2 = 0.f, nsg = 0.f;
         if (r_ < 6 && kk < nk) {
           const int e0 = ti(hc.o_lev, 2 * (s0 + kk)), en = (e0 >> 16) & 255;
           b = e0 & 255; jn = (e0 >> 8) & 255; pel = (e0 >> 25) & 1;
           const real sgn = (e0 >> 24) & 1 ? real(-1) : real(1);
           const float4_t wr = ld4(Wst + (b * 6 + r_) * 4);
           const real *sn = S + 18 * jn + r_;
-          s_0 = sgn * sn[0]; s_1 = sgn * sn[6]; s_2 = sgn * sn[12];
+          s_0 = sn[0]; s_1 = sn[6]; s_2 = sn[12]; nsg = -sgn;
           apr = An[8 * (en + 1) + r_];
           p0 = wr.x * apr - (r_ == 0 ? wr.w : 0.f); p1 = wr.y * apr - (r_ == 1 ? wr.w : 0.f); p2 = wr.z * apr - (r_ == 2 ? wr.w : 0.f);
         }
-        p0 = w->sum8(p0); p1 = w->sum8(p1); p2 = w->sum8(p2);   // = -q''_j in every lane of the group
+        p0 = w->sum8(p0); p1 = w->sum8(p1); p2 = w->sum8(p2);   // = -z = -sgn q''_j in every lane of the group
         real acc = 0.f;
         if (b >= 0) {
           acc = apr - (s_0 * p0 + s_1 * p1 + s_2 * p2);
           An[8 * (b + 1) + r_] = acc;
-          if (r_ < 3) x[3 * jn + r_] = -(r_ == 0 ? p0 : (r_ == 1 ? p1 : p2));
+          if (r_ < 3) x[3 * jn + r_] = nsg * (r_ == 0 ? p0 : (r_ == 1 ? p1 : p2));
         }
         if (pel_level) {                                       // body 0 reached: the free joint's solution from its acceleration
           real t0 = 0.f, t1 = 0.f, t2 = 0.f;                  // R^T a_ang: lane r < 3 holds component r of a_ang
@@ -1340,7 +1344,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
           if (ps > 0 && ps * 8 >= nk) continue;
           const int kk = ps * 8 + g;
           int b = -1, jn = 0;
-          real pa[K], red[K][3], wr0 = 0, wr1 = 0, wr2 = 0;
+          real pa[K], red[K][3], wr0 = 0, wr1 = 0, wr2 = 0, sg = 1;
 #pragma unroll
           for (int q_ = 0; q_ < K; q_++) { pa[q_] = 0; red[q_][0] = red[q_][1] = red[q_][2] = 0; }
           if (r_ < 6 && kk < nk) {
@@ -1359,7 +1363,8 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
               for (int q_ = 0; q_ < K; q_++) pa[q_] += src[q_];
             }
             const real *sn = S + 18 * jn;
-            const real sr0 = sgn * sn[r_], sr1 = sgn * sn[6 + r_], sr2 = sgn * sn[12 + r_];
+            const real sr0 = sn[r_], sr1 = sn[6 + r_], sr2 = sn[12 + r_];
+            sg = sgn;
 #pragma unroll
             for (int q_ = 0; q_ < K; q_++) { red[q_][0] = sr0 * pa[q_]; red[q_][1] = sr1 * pa[q_]; red[q_][2] = sr2 * pa[q_]; }
             const float4_t wv = ld4(Wst + (b * 6 + r_) * 4);
@@ -1374,7 +1379,8 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
             real *dst = cur + (kk * 6 + r_) * 8;
 #pragma unroll
             for (int q_ = 0; q_ < K; q_++) {
-              const real u0 = bf(3 * jn, q_) - red[q_][0], u1 = bf(3 * jn + 1, q_) - red[q_][1], u2 = bf(3 * jn + 2, q_) - red[q_][2];
+              // u' = sgn u (see aba_solve: W and the saved y' belong to the unsigned S_j)
+              const real u0 = sg * bf(3 * jn, q_) - red[q_][0], u1 = sg * bf(3 * jn + 1, q_) - red[q_][1], u2 = sg * bf(3 * jn + 2, q_) - red[q_][2];
               dst[q_] = pa[q_] + wr0 * u0 + wr1 * u1 + wr2 * u2;
               if (r_ < 3) {
                 real t0, t1, t2;
@@ -1432,7 +1438,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
           if (ps > 0 && ps * 8 >= nk) continue;
           const int kk = ps * 8 + g;
           int b = -1, jn = 0, en = 0, pel = 0;
-          real s_0 = 0.f, s_1 = 0.f, s_2 = 0.f;
+          real s_0 = 0.f, s_1 = 0.f, s_2 = 0.f, nsg = 0.f;
           float4_t wr; wr.x = wr.y = wr.z = wr.w = 0.f;
           if (r_ < 6 && kk < nk) {
             const int e0 = ti(hc.o_lev, 2 * (s0 + kk));
@@ -1440,7 +1446,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
             const real sgn = (e0 >> 24) & 1 ? real(-1) : real(1);
             wr = ld4(Wst + (b * 6 + r_) * 4);
             const real *sn = S + 18 * jn + r_;
-            s_0 = sgn * sn[0]; s_1 = sgn * sn[6]; s_2 = sgn * sn[12];
+            s_0 = sn[0]; s_1 = sn[6]; s_2 = sn[12]; nsg = -sgn;
           }
 #pragma unroll
           for (int q_ = 0; q_ < K; q_++) {
@@ -1455,7 +1461,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
             if (b >= 0) {
               acc = apr - (s_0 * p0 + s_1 * p1 + s_2 * p2);
               Aout[((b + 1) * K + q_) * 8 + r_] = acc;
-              if (xout && q_ == 0 && r_ < 3) xout[3 * jn + r_] = -(r_ == 0 ? p0 : (r_ == 1 ? p1 : p2));
+              if (xout && q_ == 0 && r_ < 3) xout[3 * jn + r_] = nsg * (r_ == 0 ? p0 : (r_ == 1 ? p1 : p2));
             }
             if (pel_level && q_ == 0) {                        // body 0 reached: the free joint's solution from its acceleration
               real t0 = 0.f, t1 = 0.f, t2 = 0.f;
@@ -1537,7 +1543,6 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
           if (on && kk < nk) {
             const int e0 = ti(hc.o_lev, 2 * (s0 + kk)), e1 = ti(hc.o_lev, 2 * (s0 + kk) + 1);
             const int b = e0 & 255, jn = (e0 >> 8) & 255, cfirst = e1 & 255, cc = (e1 >> 8) & 255;
-            const real sgn = (e0 >> 24) & 1 ? real(-1) : real(1);
             real pa[6];
             const real sg_ = b == cb2 ? real(-1) : (b == cb1 ? real(1) : real(0));
 #pragma unroll
@@ -1550,7 +1555,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
             const real *sn = S + 18 * jn;
             real u[3];
 #pragma unroll
-            for (int j = 0; j < 3; j++) { real a_ = 0; for (int r_ = 0; r_ < 6; r_++) a_ += sn[6 * j + r_] * pa[r_]; u[j] = -sgn * a_; }
+            for (int j = 0; j < 3; j++) { real a_ = 0; for (int r_ = 0; r_ < 6; r_++) a_ += sn[6 * j + r_] * pa[r_]; u[j] = -a_; }   // u' = sgn u: no sign left
             real *dst = cur + (kk * 12 + q_) * 6;
 #pragma unroll
             for (int r_ = 0; r_ < 6; r_++) { const float4_t wv = ld4(Wst + (b * 6 + r_) * 4); dst[r_] = pa[r_] + wv.x * u[0] + wv.y * u[1] + wv.z * u[2]; }
@@ -1603,7 +1608,6 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
           if (on && kk < nk) {
             const int e0 = ti(hc.o_lev, 2 * (s0 + kk)), e1 = ti(hc.o_lev, 2 * (s0 + kk) + 1);
             const int b = e0 & 255, jn = (e0 >> 8) & 255, cfirst = e1 & 255, cc = (e1 >> 8) & 255;
-            const real sgn = (e0 >> 24) & 1 ? real(-1) : real(1);
             const real *apk = mine + (kk * 12 + q_) * 6;
             real ap[6], acc[6];
 #pragma unroll
@@ -1613,7 +1617,6 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
 #pragma unroll
             for (int c = 0; c < 6; c++) { const float4_t wv = ld4(Wst + (b * 6 + c) * 4); x0 -= wv.x * ap[c]; x1 -= wv.y * ap[c]; x2 -= wv.z * ap[c]; }
             const real *sn = S + 18 * jn;
-            x0 *= sgn; x1 *= sgn; x2 *= sgn;
 #pragma unroll
             for (int r_ = 0; r_ < 6; r_++) acc[r_] = ap[r_] + sn[r_] * x0 + sn[6 + r_] * x1 + sn[12 + r_] * x2;
             if (L < hc.nlev)
