@@ -24,18 +24,16 @@ struct WaveGpu {
   template <int CTRL> static __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
   template <int CTRL> static __device__ __forceinline__ float dpp_f(float v) { return __builtin_bit_cast(float, dpp_i<CTRL>(__builtin_bit_cast(int, v))); }
   static __device__ __forceinline__ float rl(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
-  // wave-wide sum, result in every lane: 4 DPP steps give every 16-lane row its sum r0..r3, row_bcast:15 adds lane 15 of rows 0 / 2
-  // into rows 1 / 3, row_bcast:31 adds lane 31 into row 3, lane 63 holds (r0 + r1) + (r2 + r3): one readlane (7 instructions; four
-  // readlanes and three adds were 12: +0.65 % on the headline, same bits — profiles/r03_centred_elimination.md 11)
-  template <int CTRL, int ROWMASK> static __device__ __forceinline__ float dpp_rows_f(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xF, false));
-  }
+  // wave-wide sum, result in every lane: 4 DPP steps give every 16-lane row its sum r0..r3, row_bcast:15 adds lane 15 of every row
+  // into the next one (row 3 = r3 + r2, row 1 = r1 + r0; rows 0 and 2 are not used again), row_bcast:31 adds lane 31 into rows 2
+  // and 3: lane 63 holds (r3 + r2) + (r1 + r0), one readlane (6 fused DPP adds + 1 readlane; four readlanes and three adds were 12
+  // instructions: profiles/r03_centred_elimination.md 11)
   __device__ __forceinline__ float sum(float v) const {
     v += dpp_f<0xB1>(v); v += dpp_f<0x4E>(v); v += dpp_f<0x141>(v); v += dpp_f<0x140>(v);
-    v += dpp_rows_f<0x142, 0xA>(v); v += dpp_rows_f<0x143, 0xC>(v);
+    v += dpp_f<0x142>(v); v += dpp_f<0x143>(v);
+    asm volatile("" : "+v"(v));
     return rl(v, 63);
   }
-  // sum over the lane's aligned group of 8 lanes: xor 1, xor 2, then the mirrored half row
   // (the empty asm pins the last add next to its DPP move: the optimizer otherwise sinks the add into the conditional block that
   // consumes the sum, where it can no longer be fused into one v_add_f32_dpp — 9 extra instructions per tree level)
   __device__ __forceinline__ float sum8(float v) const { v += dpp_f<0xB1>(v); v += dpp_f<0x4E>(v); v += dpp_f<0x141>(v); asm volatile("" : "+v"(v)); return v; }
