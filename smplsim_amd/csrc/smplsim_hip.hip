@@ -84,7 +84,7 @@ kern_t pick_kernel(int variant, int flavour, const ss::Hdr &h) {
 #endif
   if (variant == 0 && flavour == 0) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, false, false>;
 #ifndef SS_ONLY_HEADLINE                                     // (experiment builds, tools/build_variant.sh, keep the headline kernel alone)
-  if (flavour == 3 || flavour == 5 || flavour == 7) return ss::pick_kernel_selfcol(variant, flavour == 5, flavour == 7);   // smplsim_hip_sc.hip
+  if (flavour == 3 || flavour == 5 || flavour == 7) return ss::pick_kernel_selfcol(variant, flavour == 5, flavour == 7, h);   // smplsim_hip_sc.hip
   if (flavour == 4 || flavour == 6) return ss::pick_kernel_imitation(variant, flavour == 6, h);                          // smplsim_hip_im.hip
   if (variant == 0) {                                        // SMPL layout (24 bodies)
     if (flavour == 1) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, false>;

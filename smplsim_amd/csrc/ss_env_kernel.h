@@ -25,7 +25,7 @@
 namespace ss {
 typedef void (*kern_t)(const KArgs);
 // instantiations that live in the other translation units (nullptr = not compiled for this size class)
-kern_t pick_kernel_selfcol(int variant, bool shaped, bool imit);
+kern_t pick_kernel_selfcol(int variant, bool shaped, bool imit, const Hdr &h);
 kern_t pick_kernel_imitation(int variant, bool shaped, const Hdr &h);
 }  // namespace ss
 
