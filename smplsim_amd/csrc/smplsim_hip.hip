@@ -79,6 +79,7 @@ kern_t pick_kernel(int variant, int flavour, const ss::Hdr &h) {
   if (variant == 0 && flavour == 0 && HdrSmpl::matches(h)) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, false, false, HdrSmpl>;
 #ifndef SS_ONLY_HEADLINE
   if (variant == 0 && flavour == 1 && HdrSmpl::matches(h)) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, false, HdrSmpl>;
+  if (variant == 0 && flavour == 2 && HdrSmpl::matches(h)) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, true, HdrSmpl>;   // per-env body shapes
   if (variant == 1 && flavour == 0 && HdrSmplx::matches(h)) return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, false, false, HdrSmplx>;
 #endif
 #endif
