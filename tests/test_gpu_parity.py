@@ -247,13 +247,14 @@ def test_pd_and_torque_controllers_on_gpu(vec, mode):
     assert np.abs(_np(env.qpos)[0] - d.qpos).max() < 1e-5 * vmax
 
 
-@pytest.mark.parametrize("shape", ["chain15", "comb9"])
+@pytest.mark.parametrize("shape", ["chain15", "comb9", "comb17"])
 def test_synthetic_trees_on_gpu(vec, shape):
-    """Deep chain (15 tree levels) and wide comb (9 nodes in one level: two 8-node passes, the large kernel variant)."""
+    """Deep chain (15 bodies: the elimination tree is rooted at its middle, 7 levels), wide comb (9 nodes in one level: two 8-node
+    passes, the large kernel variant) and a comb of 17 branches (rooted at a branch: 16 nodes in the widest level)."""
     from smplsim_amd.batch import ShardModel
     from smplsim_amd.mjcf_writer import table_to_mjcf
     from test_synthetic_trees_emu import _chain, _comb
-    xml = table_to_mjcf(_chain(14) if shape == "chain15" else _comb(9))
+    xml = table_to_mjcf(_chain(14) if shape == "chain15" else _comb(9 if shape == "comb9" else 17))
     root_z = 2.8 if shape == "chain15" else 0.40
     from smplsim_amd.mjcf import compile_mjcf
     mc = compile_mjcf(xml)
