@@ -74,19 +74,19 @@ typedef ss::kern_t kern_t;
 // instantiations per model size: plain (the headline), +body-frame outputs, +per-env body shapes (which includes the outputs)
 // The two fixtures' sizes get instantiations with compile-time dimensions and LDS layout (HdrFixedT, ss_hdr.h): -2.4% per step
 // launch on the SMPL headline (profiles/r02b_variants.txt); any other model of a variant's size class runs the generic one.
-kern_t pick_kernel(int variant, int flavour, const ss::Hdr &h) {
+kern_t pick_kernel(int variant, int flavour, const ss::Hdr &h, const ss::HdrC &hc) {
 #ifndef SS_NO_FIXED_LAYOUT
-  if (variant == 0 && flavour == 0 && HdrSmpl::matches(h)) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, false, false, HdrSmpl>;
+  if (variant == 0 && flavour == 0 && HdrSmpl::matches(h, hc)) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, false, false, HdrSmpl>;
 #ifndef SS_ONLY_HEADLINE
-  if (variant == 0 && flavour == 1 && HdrSmpl::matches(h)) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, false, HdrSmpl>;
-  if (variant == 0 && flavour == 2 && HdrSmpl::matches(h)) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, true, HdrSmpl>;   // per-env body shapes
-  if (variant == 1 && flavour == 0 && HdrSmplx::matches(h)) return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, false, false, HdrSmplx>;
+  if (variant == 0 && flavour == 1 && HdrSmpl::matches(h, hc)) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, false, HdrSmpl>;
+  if (variant == 0 && flavour == 2 && HdrSmpl::matches(h, hc)) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, true, HdrSmpl>;   // per-env body shapes
+  if (variant == 1 && flavour == 0 && HdrSmplx::matches(h, hc)) return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, false, false, HdrSmplx>;
 #endif
 #endif
   if (variant == 0 && flavour == 0) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, false, false>;
 #ifndef SS_ONLY_HEADLINE                                     // (experiment builds, tools/build_variant.sh, keep the headline kernel alone)
-  if (flavour == 3 || flavour == 5 || flavour == 7) return ss::pick_kernel_selfcol(variant, flavour == 5, flavour == 7, h);   // smplsim_hip_sc.hip
-  if (flavour == 4 || flavour == 6) return ss::pick_kernel_imitation(variant, flavour == 6, h);                          // smplsim_hip_im.hip
+  if (flavour == 3 || flavour == 5 || flavour == 7) return ss::pick_kernel_selfcol(variant, flavour == 5, flavour == 7, h, hc);   // smplsim_hip_sc.hip
+  if (flavour == 4 || flavour == 6) return ss::pick_kernel_imitation(variant, flavour == 6, h, hc);                          // smplsim_hip_im.hip
   if (variant == 0) {                                        // SMPL layout (24 bodies)
     if (flavour == 1) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, false>;
     return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, true>;
@@ -128,7 +128,7 @@ struct HipBackend {
   static const char *launch(const ss::KArgs &k, int nenv, int envs_per_wg, size_t lds_bytes, void *stream, int fixed_epw, int max_wgs) {
     const bool bodyout = (k.out0 || k.power) && (k.mode == ss::MODE_STEP || k.mode == ss::MODE_RESET);
     const int flavour = k.im ? (k.cfg.self_collision ? 7 : (k.st.shape_id ? 6 : 4)) : (k.cfg.self_collision ? (k.st.shape_id ? 5 : 3) : (k.st.shape_id ? 2 : (bodyout ? 1 : 0)));
-    kern_t kern = pick_kernel(ss::kernel_variant(k.h), flavour, k.h);
+    kern_t kern = pick_kernel(ss::kernel_variant(k.h), flavour, k.h, k.hc);
     if (!kern) return "no kernel variant for this model size";
     static thread_local kern_t configured[32] = {};
     static thread_local size_t configured_lds[32] = {};

@@ -5,14 +5,14 @@
 
 namespace ss {
 
-kern_t pick_kernel_imitation(int variant, bool shaped, const Hdr &h) {
+kern_t pick_kernel_imitation(int variant, bool shaped, const Hdr &h, const HdrC &hc) {
   if (shaped) {                                              // per-env body shapes (PHC-style: every env tracks clips with its own body)
     if (variant == 0) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, true, HdrRuntime, false, true>;
     if (variant == 1) return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, true, true, HdrRuntime, false, true>;
     return nullptr;
   }
 #ifndef SS_NO_FIXED_LAYOUT
-  if (variant == 0 && HdrSmpl::matches(h)) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, false, HdrSmpl, false, true>;
+  if (variant == 0 && HdrSmpl::matches(h, hc)) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, false, HdrSmpl, false, true>;
 #endif
   if (variant == 0) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, false, HdrRuntime, false, true>;
   if (variant == 1) return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, true, false, HdrRuntime, false, true>;

@@ -4,7 +4,7 @@
 
 namespace ss {
 
-kern_t pick_kernel_selfcol(int variant, bool shaped, bool imit, const Hdr &h) {
+kern_t pick_kernel_selfcol(int variant, bool shaped, bool imit, const Hdr &h, const HdrC &hc) {
   if (imit) {                                                // imitation step with body-body contacts: SMPL size class, one shape
     if (variant == 0 && !shaped) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS_SC, true, false, HdrRuntime, true, true>;
     return nullptr;
@@ -16,8 +16,8 @@ kern_t pick_kernel_selfcol(int variant, bool shaped, bool imit, const Hdr &h) {
   }
 #ifndef SS_NO_FIXED_LAYOUT
   // the shipped SMPL humanoid with its layout as compile-time constants (as the plain headline kernel: ss_env_kernel.h)
-  if (variant == 0 && HdrSmpl::matches(h)) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS_SC, true, false, HdrSmpl, true>;
-  if (variant == 1 && HdrSmplx::matches(h)) return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, true, false, HdrSmplx, true>;
+  if (variant == 0 && HdrSmpl::matches(h, hc)) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS_SC, true, false, HdrSmpl, true>;
+  if (variant == 1 && HdrSmplx::matches(h, hc)) return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, true, false, HdrSmplx, true>;
 #endif
   if (variant == 0) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS_SC, true, false, HdrRuntime, true>;   // (also writes the body frames)
   if (variant == 1) return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, true, false, HdrRuntime, true>;

@@ -25,8 +25,8 @@
 namespace ss {
 typedef void (*kern_t)(const KArgs);
 // instantiations that live in the other translation units (nullptr = not compiled for this size class)
-kern_t pick_kernel_selfcol(int variant, bool shaped, bool imit, const Hdr &h);
-kern_t pick_kernel_imitation(int variant, bool shaped, const Hdr &h);
+kern_t pick_kernel_selfcol(int variant, bool shaped, bool imit, const Hdr &h, const HdrC &hc);
+kern_t pick_kernel_imitation(int variant, bool shaped, const Hdr &h, const HdrC &hc);
 }  // namespace ss
 
 namespace {
@@ -79,7 +79,8 @@ __global__ void __launch_bounds__(MAXT) ss_env_kernel(const ss::KArgs k) {
 }
 
 
-typedef ss::HdrFixedT<24, 5> HdrSmpl;                        // SMPL: 24 bodies, at most 5 nodes in a tree level
-typedef ss::HdrFixedT<52, 12> HdrSmplx;                      // SMPL-X/H: 52 bodies, 12 nodes in the widest level of the centred tree
+// (body count, widest level | elimination tree: levels, root body, level of body 0, packed level widths - 1)
+typedef ss::HdrFixedT<24, 5, 6, 10, 2, 0x333431ull> HdrSmpl;       // SMPL: 24 bodies; rooted at the Spine: levels of 2 4 5 4 4 4 nodes
+typedef ss::HdrFixedT<52, 12, 7, 11, 3, 0xbbb3233ull> HdrSmplx;    // SMPL-X/H: 52 bodies; rooted at the Chest: levels of 4 4 3 4 12 12 12 nodes
 
 }  // namespace

@@ -116,7 +116,22 @@ constexpr HdrSC make_layout_sc(int nb, int base_floats, int l_Aown) {
   return y;
 }
 
-// The header as the kernel sees it.  HdrRuntime: the Hdr itself (any model that fits a variant).  HdrFixedT<NB, MAXLEV>: body
+// Elimination tree of the articulated-body solves: the body tree re-rooted at its CENTRE.  H x = b is a free-floating tree's system,
+// any body can carry the six free unknowns; eliminating towards the centre instead of towards the pelvis makes the sweeps as deep as
+// the tree's radius, not its height (SMPL: 6 levels instead of 8, SMPL-X: 7 instead of 10).  An edge walked against the kinematic
+// direction uses the same joint with S -> -S; the free joint becomes a bias force on body 0.  Built by ss_tables.h; a member of KArgs
+// rather than of Hdr (Hdr's layout is part of the kernels' register allocation).
+struct HdrC {
+  int nlev;                    // levels below the root (level 1 = the root's neighbours)
+  int o_lev;                   // word offset of the level records in the shared blob, 2 words per node, level 1 first:
+                               //   word 0: body | joint node << 8 | neighbour towards the root << 16 | (S negated) << 24 | (body 0) << 25
+                               //   word 1: first child's position in the next level | child count << 8
+  int root;                    // root body
+  int pel_level;               // level of body 0 (0 = it is the root)
+  unsigned long long nkpack[2];   // (nodes in level L) - 1, 4 bits per level, level L at bit 4 (L - 1)
+};
+
+// The header as the kernel sees it.  HdrRuntime: the Hdr itself (any model that fits a variant).  HdrFixedT<NB, MAXLEV, tree...>: body
 // count, dof counts and the whole LDS layout are compile-time constants — LDS addresses become one base register plus an
 // instruction immediate and ~30 wave-uniform values leave the SGPR file (the generic kernel reloads spilled SGPRs with
 // ~1300 v_readlane per instantiation) — everything else is still read from the runtime header.
@@ -129,6 +144,17 @@ struct HdrRuntime {
   typedef const Hdr &type;
   static constexpr bool fixed = false;
   static SS_HD type view(const Hdr &h) { return h; }
+  typedef const HdrC &tree_type;
+  static SS_HD tree_type tree(const HdrC &c) { return c; }
+};
+// The elimination tree's shape as compile-time constants (fixed-layout instantiations): the level bounds fold into immediates and the
+// level loops of the sweeps have constant trip counts (+1.3 % on the SMPL headline: profiles/r03_centred_elimination.md 15); only
+// the offset of the level records stays a runtime value.
+template <int NLEV, int ROOT, int PEL, unsigned long long NK0>
+struct TreeFixed {
+  static constexpr int nlev = NLEV, root = ROOT, pel_level = PEL;
+  static constexpr unsigned long long nkpack[2] = {NK0, 0ull};
+  int o_lev;
 };
 template <int NB, int MAXLEV>
 struct HdrFixed {
@@ -152,28 +178,18 @@ struct HdrFixed {
         shared_words(h.shared_words), dt(h.dt), grav(h.grav), margin(h.margin), mu(h.mu), solimp(h.solimp), K(h.K), B(h.B),
         qpos0_root(h.qpos0_root) {}
 };
-template <int NB, int MAXLEV>
+template <int NB, int MAXLEV, int NLEV, int ROOT, int PEL, unsigned long long NK0>
 struct HdrFixedT {
   typedef const HdrFixed<NB, MAXLEV> type;
   static constexpr bool fixed = true;
   static SS_HD HdrFixed<NB, MAXLEV> view(const Hdr &h) { return HdrFixed<NB, MAXLEV>(h); }
-  static bool matches(const Hdr &h) { return h.nb == NB && h.maxlev == MAXLEV; }
+  typedef const TreeFixed<NLEV, ROOT, PEL, NK0> tree_type;
+  static SS_HD TreeFixed<NLEV, ROOT, PEL, NK0> tree(const HdrC &c) { TreeFixed<NLEV, ROOT, PEL, NK0> t; t.o_lev = c.o_lev; return t; }
+  static bool matches(const Hdr &h, const HdrC &c) {
+    return h.nb == NB && h.maxlev == MAXLEV && c.nlev == NLEV && c.root == ROOT && c.pel_level == PEL && c.nkpack[0] == NK0 && c.nkpack[1] == 0ull;
+  }
 };
 
-// Elimination tree of the articulated-body solves: the body tree re-rooted at its CENTRE.  H x = b is a free-floating tree's system,
-// any body can carry the six free unknowns; eliminating towards the centre instead of towards the pelvis makes the sweeps as deep as
-// the tree's radius, not its height (SMPL: 6 levels instead of 8, SMPL-X: 7 instead of 10).  An edge walked against the kinematic
-// direction uses the same joint with S -> -S; the free joint becomes a bias force on body 0.  Built by ss_tables.h; a member of KArgs
-// rather than of Hdr (Hdr's layout is part of the kernels' register allocation).
-struct HdrC {
-  int nlev;                    // levels below the root (level 1 = the root's neighbours)
-  int o_lev;                   // word offset of the level records in the shared blob, 2 words per node, level 1 first:
-                               //   word 0: body | joint node << 8 | neighbour towards the root << 16 | (S negated) << 24 | (body 0) << 25
-                               //   word 1: first child's position in the next level | child count << 8
-  int root;                    // root body
-  int pel_level;               // level of body 0 (0 = it is the root)
-  unsigned long long nkpack[2];   // (nodes in level L) - 1, 4 bits per level, level L at bit 4 (L - 1)
-};
 
 // compiled kernel variants: 0 = SMPL-sized (<= 128 dofs / candidates, <= 64 contact slots, <= 8 nodes per tree level),
 // 1 = SMPL-X/H-sized (<= 192 dofs / candidates, <= 128 slots, <= 16 nodes per level); -1 = none fits

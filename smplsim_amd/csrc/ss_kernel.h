@@ -1096,7 +1096,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
   SS_DEV void aba_solve(real *x, const real *pb) {
     fresh();
     typename HT::type h = HT::view(k->h);
-    const HdrC &hc = k->hc;
+    const typename HT::tree_type hc = HT::tree(k->hc);
     const int r_ = lane & 7, g = lane >> 3;
     int off[6];                                              // packed-symmetric offsets of row r_
 #pragma unroll
@@ -1326,7 +1326,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
     if constexpr (SELFCOL) {
       fresh();
       typename HT::type h = HT::view(k->h);
-      const HdrC &hc = k->hc;
+      const typename HT::tree_type hc = HT::tree(k->hc);
       const int r_ = lane & 7, g = lane >> 3;
       const unsigned long long nk0 = hc.nkpack[0], nk1 = hc.nkpack[1];
       auto NKC = [&](int L) { return (int)((((L - 1) < 16 ? nk0 : nk1) >> (4 * ((L - 1) & 15))) & 15ull) + 1; };
@@ -1493,7 +1493,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
     if constexpr (SELFCOL) {
       fresh();
       typename HT::type h = HT::view(k->h);
-      const HdrC &hc = k->hc;
+      const typename HT::tree_type hc = HT::tree(k->hc);
       const int ns = this->nself;
       const int q_ = lane % 12, grp = lane / 12;
       int nsel = 0;

@@ -851,13 +851,21 @@ def test_self_collision_with_per_env_shapes_on_gpu(vec):
         assert (so.reset()[0] - obs0[idx]).abs().max() < 1e-6
     g = torch.Generator().manual_seed(3)
     seen = 0
+    nwarn_seen = mixed.nwarn.clone()
     for k in range(6):
         act = (torch.rand(1, 69, generator=g) * 2 - 1).repeat(9, 1).to(mixed.device)
         obs = mixed.step(act)[0]
         for idx, so in solos:
             o2 = so.step(act[idx])[0]
-            assert torch.equal(so.self_contacts, mixed.self_contacts[idx]), k
-            assert (so.qpos - mixed.qpos[idx]).abs().max() < TOL_QPOS_FREE and (o2 - obs[idx]).abs().max() < 2 * TOL_OBS, k
+            assert torch.equal(so.self_contacts, mixed.self_contacts[idx]) or bool((mixed.nwarn[idx] != nwarn_seen[idx]).any()), k
+            # two instantiations (fixed / runtime layout): round-off, relative to the velocity scale; an env whose state blew up inside
+            # the step (MuJoCo's bad-state reset, counted in nwarn) crosses the 1e10 threshold one mj_step earlier or later depending on
+            # rounding and is not compared (as in the per-sample tests)
+            calm = (mixed.nwarn[idx] == nwarn_seen[idx]) & (so.nwarn == nwarn_seen[idx])
+            nwarn_seen[idx] = mixed.nwarn[idx]; so.nwarn.copy_(mixed.nwarn[idx])
+            if bool(calm.any()):
+                vmax = max(1.0, float(mixed.qvel[idx][calm].abs().max()))
+                assert (so.qpos - mixed.qpos[idx])[calm].abs().max() < TOL_QPOS_FREE and (o2 - obs[idx])[calm].abs().max() < 2 * TOL_OBS * vmax, (k, vmax)
             so.qpos.copy_(mixed.qpos[idx]); so.qvel.copy_(mixed.qvel[idx]); so.qacc_warm.copy_(mixed.qacc_warm[idx])
             so.qpos_prev.copy_(mixed.qpos_prev[idx]); so.qvel_prev.copy_(mixed.qvel_prev[idx])
         seen += int(mixed.self_contacts.sum())
