@@ -1066,6 +1066,10 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
   // quantities; the 3x3 joint-space algebra is redundant per lane.  Two wave syncs per level going towards the root, one going
   // away.  Rows of the level's IA', pA' go through a two-level LDS buffer; (W_r, y_r) are kept per body.
   // On return x holds the solution and An[8 (b + 1) ..] the body accelerations a_b = J_b x.
+  // The level loops of the sweeps are fully unrolled where the tree's shape is a compile-time constant (fixed-layout instantiations:
+  // 6 / 7 levels): level bounds, buffer parities and record offsets become immediates (+3 % on the SMPL headline, same bits —
+  // profiles/r03_centred_elimination.md 16); with a runtime tree they stay loops.
+  static constexpr int kUnrollLevels = HT::fixed ? 16 : 1;
   SS_DEV static void st4w(real *p, real a, real b, real c, real d) { float4_t v; v.x = a; v.y = b; v.z = c; v.w = d; *reinterpret_cast<float4_t *>(p) = v; }
 
   SS_DEV void write_own_inertia() {                          // Aown[b] = expand(Ib), packed upper triangle (ang;lin)
@@ -1108,6 +1112,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
     // columns of R) ; b_trans (linear rows)
     auto fb_force = [&]() { return r_ < 3 ? S[18 + r_] * x[3] + S[24 + r_] * x[4] + S[30 + r_] * x[5] : x[r_ - 3]; };
     int s0 = h.nb - 1;                                        // records of level L start at s0(L) = (nodes of the levels before it)
+#pragma unroll kUnrollLevels
     for (int L = hc.nlev; L >= 1; --L) {
       const int nk = NKC(L);
       s0 -= nk;
@@ -1272,6 +1277,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
     SS_FTICK(PF_F_SYNC1);
     // ---- sweep away from the root:  q''_j = y - W^T a_e,  a_b = a_e + S' q''_j  (row-distributed: one W row per lane, DPP sums)
     s0 = 0;
+#pragma unroll kUnrollLevels
     for (int L = 1; L <= hc.nlev; L++) {
       const int nk = NKC(L);
       const bool pel_level = L == hc.pel_level;               // wave-uniform: this level holds body 0
@@ -1334,6 +1340,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       auto fb_force = [&](int row, int q_) { return row < 3 ? S[18 + row] * bf(3, q_) + S[24 + row] * bf(4, q_) + S[30 + row] * bf(5, q_) : bf(row - 3, q_); };
       real *ysave = this->ysave;
       int s0 = h.nb - 1;
+#pragma unroll kUnrollLevels
       for (int L = hc.nlev; L >= 1; --L) {
         const int nk = NKC(L);
         s0 -= nk;
@@ -1430,6 +1437,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
         w->sync();
       }
       s0 = 0;
+#pragma unroll kUnrollLevels
       for (int L = 1; L <= hc.nlev; L++) {                    // ---- sweep away from the root (row-distributed, as in aba_solve)
         const int nk = NKC(L);
         const bool pel_level = xout && L == hc.pel_level;
@@ -1533,6 +1541,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       };
       w->sync();
       int s0 = h.nb - 1;
+#pragma unroll kUnrollLevels
       for (int L = hc.nlev; L >= 1; --L) {                    // ---- sweep towards the root: bias forces only
         const int nk = NKC(L);
         s0 -= nk;
@@ -1599,6 +1608,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       }
       w->sync();
       s0 = 0;
+#pragma unroll kUnrollLevels
       for (int L = 1; L <= hc.nlev; L++) {                    // ---- sweep away from the root: accelerations, pushed into the children's slots
         const int nk = NKC(L);
         const real *mine = buf + ((L + 1) & 1) * bstride;
