@@ -360,12 +360,17 @@ struct ss_api {
     if (nb) *nb = m->hm.h.nb;                                                                                        \
     return SS_OK;                                                                                                    \
   }                                                                                                                  \
-  int ss_model_elimination_tree(const ss_model *m, int32_t *root, int32_t *levels, int32_t *widest) {                 \
+  int ss_model_elimination_tree(const ss_model *m, int32_t *root, int32_t *levels, int32_t *widest, int32_t *widths) { \
     ss::HandleScope hs_(m ? &m->err : nullptr);                                                                      \
     if (!m) return ss_api<BE>::fail(SS_ERR_INVALID, "null model");                                                   \
-    if (root) *root = m->hm.hc.root;                                                                                 \
-    if (levels) *levels = m->hm.hc.nlev;                                                                             \
+    const ss::HdrC &c = m->hm.hc;                                                                                    \
+    if (root) *root = c.root;                                                                                        \
+    if (levels) *levels = c.nlev;                                                                                    \
     if (widest) *widest = m->hm.h.maxlev;                                                                            \
+    if (widths) {                                                                                                    \
+      widths[0] = c.pel_level;                                                                                       \
+      for (int L = 1; L <= c.nlev && L <= 32; L++) widths[L] = (int)((c.nkpack[(L - 1) >> 4] >> (4 * ((L - 1) & 15))) & 15ull) + 1; \
+    }                                                                                                                \
     return SS_OK;                                                                                                    \
   }                                                                                                                  \
   int ss_obs_size(const ss_model *m, const ss_env_cfg *c) { return (m && c) ? ss::obs_size(m->hm.h, *c) : SS_ERR_INVALID; } \
