@@ -129,6 +129,7 @@ struct HdrC {
   int root;                    // root body
   int pel_level;               // level of body 0 (0 = it is the root)
   unsigned long long nkpack[2];   // (nodes in level L) - 1, 4 bits per level, level L at bit 4 (L - 1)
+  unsigned long long cpack;       // most children of a node of level L (clamped to 7), 3 bits per level, level L at bit 3 (L - 1)
 };
 
 // The header as the kernel sees it.  HdrRuntime: the Hdr itself (any model that fits a variant).  HdrFixedT<NB, MAXLEV, tree...>: body
@@ -150,10 +151,11 @@ struct HdrRuntime {
 // The elimination tree's shape as compile-time constants (fixed-layout instantiations): the level bounds fold into immediates and the
 // level loops of the sweeps have constant trip counts (+1.3 % on the SMPL headline: profiles/r03_centred_elimination.md 15); only
 // the offset of the level records stays a runtime value.
-template <int NLEV, int ROOT, int PEL, unsigned long long NK0>
+template <int NLEV, int ROOT, int PEL, unsigned long long NK0, unsigned long long CP>
 struct TreeFixed {
   static constexpr int nlev = NLEV, root = ROOT, pel_level = PEL;
   static constexpr unsigned long long nkpack[2] = {NK0, 0ull};
+  static constexpr unsigned long long cpack = CP;
   int o_lev;
 };
 template <int NB, int MAXLEV>
@@ -178,15 +180,15 @@ struct HdrFixed {
         shared_words(h.shared_words), dt(h.dt), grav(h.grav), margin(h.margin), mu(h.mu), solimp(h.solimp), K(h.K), B(h.B),
         qpos0_root(h.qpos0_root) {}
 };
-template <int NB, int MAXLEV, int NLEV, int ROOT, int PEL, unsigned long long NK0>
+template <int NB, int MAXLEV, int NLEV, int ROOT, int PEL, unsigned long long NK0, unsigned long long CP>
 struct HdrFixedT {
   typedef const HdrFixed<NB, MAXLEV> type;
   static constexpr bool fixed = true;
   static SS_HD HdrFixed<NB, MAXLEV> view(const Hdr &h) { return HdrFixed<NB, MAXLEV>(h); }
-  typedef const TreeFixed<NLEV, ROOT, PEL, NK0> tree_type;
-  static SS_HD TreeFixed<NLEV, ROOT, PEL, NK0> tree(const HdrC &c) { TreeFixed<NLEV, ROOT, PEL, NK0> t; t.o_lev = c.o_lev; return t; }
+  typedef const TreeFixed<NLEV, ROOT, PEL, NK0, CP> tree_type;
+  static SS_HD TreeFixed<NLEV, ROOT, PEL, NK0, CP> tree(const HdrC &c) { TreeFixed<NLEV, ROOT, PEL, NK0, CP> t; t.o_lev = c.o_lev; return t; }
   static bool matches(const Hdr &h, const HdrC &c) {
-    return h.nb == NB && h.maxlev == MAXLEV && c.nlev == NLEV && c.root == ROOT && c.pel_level == PEL && c.nkpack[0] == NK0 && c.nkpack[1] == 0ull;
+    return h.nb == NB && h.maxlev == MAXLEV && c.nlev == NLEV && c.root == ROOT && c.pel_level == PEL && c.nkpack[0] == NK0 && c.nkpack[1] == 0ull && c.cpack == CP;
   }
 };
 

@@ -1143,10 +1143,17 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
 #pragma unroll
           for (int t = 0; t < 18; t++) sv[t] = sn[t];
           const real sr0 = sn[r_], sr1 = sn[6 + r_], sr2 = sn[12 + r_];   // row r of S_j (the sign of S' cancels in U D^-1 U^T and in D)
-          for (int j = 0; j < cc; j++) {
+          auto add_child = [&](int j) {
             const real *src = prev + ((cfirst + j) * 6 + r_) * 8;
             const float4_t v0 = ld4(src), v1 = ld4(src + 4);
             rw[0] += v0.x; rw[1] += v0.y; rw[2] += v0.z; rw[3] += v0.w; rw[4] += v1.x; rw[5] += v1.y; pv += v1.z;
+          };
+          if constexpr (HT::fixed) {                         // the most children of a node of this level is a constant of the unrolled level:
+            const int cm = (int)((hc.cpack >> (3 * (L - 1))) & 7ull);   // predicated adds instead of a lane-varying loop (none on the leaf level)
+#pragma unroll
+            for (int j = 0; j < 7; j++) if (j < cm && j < cc) add_child(j);
+          } else {
+            for (int j = 0; j < cc; j++) add_child(j);
           }
 #pragma unroll
           for (int j = 0; j < 3; j++) {

@@ -250,7 +250,7 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
     bfs(best, dep, tw);
     bestd = 0; for (int b = 0; b < nb; b++) bestd = std::max(bestd, dep[b]);
     HdrC &hc = out.hc;
-    hc.root = best; hc.nlev = bestd; hc.pel_level = dep[0]; hc.nkpack[0] = hc.nkpack[1] = 0ull;
+    hc.root = best; hc.nlev = bestd; hc.pel_level = dep[0]; hc.nkpack[0] = hc.nkpack[1] = 0ull; hc.cpack = 0ull;
     if (bestd > 32) { out.error = "tree too deep"; return false; }
     // level lists: children of one node contiguous, in the order of their parents' positions
     std::vector<std::vector<int>> levb(bestd + 1);
@@ -262,6 +262,7 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
       const int nk = (int)levb[L].size();
       maxlev = std::max(maxlev, nk);
       hc.nkpack[(L - 1) >> 4] |= (unsigned long long)(nk - 1) << (4 * ((L - 1) & 15));
+      int cmaxL = 0;
       for (int b : levb[L]) {
         const int e = tw[b];                                    // neighbour towards the root
         const bool kin = d.body_parent[b] == e;                 // walked along the kinematic direction: b's own joint
@@ -272,7 +273,10 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
             if (tw[levb[L + 1][k2]] == b) { if (cc == 0) cfirst = k2; cc++; }
         rec.push_back(b | (jn << 8) | (e << 16) | ((kin ? 0 : 1) << 24) | ((b == 0 ? 1 : 0) << 25));
         rec.push_back(cfirst | (cc << 8));
+        cmaxL = std::max(cmaxL, cc);
       }
+      if (L <= 21) hc.cpack |= (unsigned long long)std::min(cmaxL, 7) << (3 * (L - 1));
+      else hc.cpack |= 0ull;
     }
     if (rec.empty()) { rec.push_back(0); rec.push_back(0); }
     hc.o_lev = push_i(rec);
