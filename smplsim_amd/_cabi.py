@@ -120,7 +120,7 @@ def bind(lib):
     lib.ss_debug_forward.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.ss_debug_self_contacts.argtypes = [vp, vp]
     lib.ss_debug_self_truncation.argtypes = [vp, vp]
-    lib.ss_model_elimination_tree.argtypes = [vp, vp, vp, vp, vp]
+    lib.ss_model_elimination_tree.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.ss_step_autoreset.argtypes = [vp] * 10
     lib.ss_schedule_longest_first.argtypes = [vp, vp]
     lib.ss_gae.argtypes = [vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_float, C.c_float, vp, vp, vp]

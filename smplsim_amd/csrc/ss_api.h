@@ -360,7 +360,7 @@ struct ss_api {
     if (nb) *nb = m->hm.h.nb;                                                                                        \
     return SS_OK;                                                                                                    \
   }                                                                                                                  \
-  int ss_model_elimination_tree(const ss_model *m, int32_t *root, int32_t *levels, int32_t *widest, int32_t *widths) { \
+  int ss_model_elimination_tree(const ss_model *m, int32_t *root, int32_t *levels, int32_t *widest, int32_t *widths, int32_t *most_children) { \
     ss::HandleScope hs_(m ? &m->err : nullptr);                                                                      \
     if (!m) return ss_api<BE>::fail(SS_ERR_INVALID, "null model");                                                   \
     const ss::HdrC &c = m->hm.hc;                                                                                    \
@@ -371,6 +371,7 @@ struct ss_api {
       widths[0] = c.pel_level;                                                                                       \
       for (int L = 1; L <= c.nlev && L <= 32; L++) widths[L] = (int)((c.nkpack[(L - 1) >> 4] >> (4 * ((L - 1) & 15))) & 15ull) + 1; \
     }                                                                                                                \
+    if (most_children) for (int L = 1; L <= c.nlev && L <= 21; L++) most_children[L] = (int)((c.cpack >> (3 * (L - 1))) & 7ull); \
     return SS_OK;                                                                                                    \
   }                                                                                                                  \
   int ss_obs_size(const ss_model *m, const ss_env_cfg *c) { return (m && c) ? ss::obs_size(m->hm.h, *c) : SS_ERR_INVALID; } \
