@@ -158,6 +158,7 @@ struct om_data {
   double *J, *epos, *emargin, *ediag, *eD, *eR, *earef, *eforce, *ejar, *ejd;
   double *H, *work, *work2;                    /* nv x nv each */
   int solver_iter, nwarn;
+  double qpos_fwd[OM_MAXV + 1], qvel_fwd[OM_MAXV];   /* the state of the last om_forward: what the (stale) M and bias belong to */
   /* SimplePID state (reference controllers.py:193-262): per actuator integral and last error; pid_dt = the dt the env
    * hands the controller (timestep * control_freq_inv, humanoid_env.py:319) */
   double pid_i[OM_MAXV], pid_e[OM_MAXV], pid_dt;
@@ -1069,6 +1070,7 @@ static void solve_constraints(const om_model *m, om_data *d) {
 
 void om_forward(const om_model *m, om_data *d) {
   int nv = m->nv;
+  memcpy(d->qpos_fwd, d->qpos, sizeof d->qpos_fwd); memcpy(d->qvel_fwd, d->qvel, sizeof d->qvel_fwd);
   om_kinematics(m, d);
   compute_M(m, d);
   collide(m, d);
@@ -1419,6 +1421,8 @@ int om_get(const om_model *m, const om_data *d, int f, double *out) {
     case OM_D_NEFC: out[0] = d->nefc; return 1;
     case OM_D_EFC_FORCE: memcpy(out, d->eforce, sizeof(double) * d->nefc); return d->nefc;
     case OM_D_SOLVER_ITER: out[0] = d->solver_iter; out[1] = d->nwarn; return 2;
+    case OM_D_QPOS_FWD: memcpy(out, d->qpos_fwd, sizeof(double) * m->nq); return m->nq;
+    case OM_D_QVEL_FWD: memcpy(out, d->qvel_fwd, sizeof(double) * nv); return nv;
     case OM_D_ENERGY: {
       double ke = 0, pe = 0;
       for (int i = 0; i < nv; i++) { double s = 0; for (int k = 0; k < nv; k++) s += d->M[i * nv + k] * d->qvel[k]; ke += 0.5 * d->qvel[i] * s; }

@@ -91,7 +91,8 @@ enum { OM_D_QPOS = 0, OM_D_QVEL, OM_D_QACC, OM_D_WARM, OM_D_CTRL, OM_D_M, OM_D_B
        OM_D_LINVEL, OM_D_ANGVEL, OM_D_TOUCH, OM_D_NCON, OM_D_CON_POS, OM_D_CON_DIST, OM_D_CON_BODY,
        OM_D_QACC_SMOOTH, OM_D_NEFC, OM_D_EFC_FORCE, OM_D_SOLVER_ITER, OM_D_ENERGY, OM_D_XIPOS,
        OM_D_QFRC_CONSTRAINT, OM_D_CON_FRAME, OM_D_CON_BODY1 /* first body of every contact, -1 = floor */,
-       OM_D_NSELF /* [contacts between two bodies, candidate pairs of the model, contacts dropped by max_self_contacts] */ };
+       OM_D_NSELF /* [contacts between two bodies, candidate pairs of the model, contacts dropped by max_self_contacts] */,
+       OM_D_QPOS_FWD, OM_D_QVEL_FWD /* the state of the last om_forward: the M and bias the Stable-PD controller reads belong to it */ };
 int om_get(const om_model *m, const om_data *d, int field, double *out);
 int om_set(const om_model *m, om_data *d, int field, const double *in);
 

@@ -23,7 +23,7 @@ M_MASS, M_IPOS, M_IQUAT, M_INERTIA, M_GPOS, M_GQUAT, M_GSIZE, M_BODY_INVW, M_DOF
 SOLVER_CONVERGED, SOLVER_MUJOCO = 0, 1
 (D_QPOS, D_QVEL, D_QACC, D_WARM, D_CTRL, D_M, D_BIAS, D_XPOS, D_XQUAT, D_LINVEL, D_ANGVEL, D_TOUCH, D_NCON,
  D_CON_POS, D_CON_DIST, D_CON_BODY, D_QACC_SMOOTH, D_NEFC, D_EFC_FORCE, D_SOLVER_ITER, D_ENERGY, D_XIPOS,
- D_QFRC_CONSTRAINT, D_CON_FRAME, D_CON_BODY1, D_NSELF) = range(26)
+ D_QFRC_CONSTRAINT, D_CON_FRAME, D_CON_BODY1, D_NSELF, D_QPOS_FWD, D_QVEL_FWD) = range(28)
 
 
 class _Desc(C.Structure):
@@ -251,6 +251,8 @@ class OracleData:
     qvel = property(lambda s: s.get(D_QVEL), lambda s, v: s.set(D_QVEL, v))
     ctrl = property(lambda s: s.get(D_CTRL), lambda s, v: s.set(D_CTRL, v))
     warm = property(lambda s: s.get(D_WARM), lambda s, v: s.set(D_WARM, v))
+    qpos_fwd = property(lambda s: s.get(D_QPOS_FWD))      # the state of the last forward pass: the stale M / bias the
+    qvel_fwd = property(lambda s: s.get(D_QVEL_FWD))      # Stable-PD controller reads belong to it
     qacc = property(lambda s: s.get(D_QACC))
     bias = property(lambda s: s.get(D_BIAS), lambda s, v: s.set(D_BIAS, v))
     M = property(lambda s: s.get(D_M).reshape(s.m.nv, s.m.nv), lambda s, v: s.set(D_M, v))

@@ -15,6 +15,7 @@ TASKS = {"HumanoidEnv": TASK_BASE, "HumanoidSpeed": TASK_SPEED, "HumanoidGetup":
 CONTROL_MODES = {"uhc_pd": CTRL_UHC_PD, "pd": CTRL_PD, "torque": CTRL_TORQUE, "simple_pid": CTRL_SIMPLE_PID,
                  "default": CTRL_DEFAULT}
 STATE_INITS = {"Default": INIT_DEFAULT, "Fall": INIT_FALL, "External": INIT_EXTERNAL}
+SS_MAX_SELF_CONTACTS = 64        # include/smplsim_hip.h: one body-body contact per lane of the env's wavefront
 
 
 class ModelDesc(C.Structure):

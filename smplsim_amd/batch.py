@@ -314,6 +314,15 @@ class SMPLSimVecEnv:
         _check(lib().ss_debug_forward(self.handle, _ptr(tq), _ptr(M), _ptr(bias), _ptr(qacc), self._stream()))
         return M, bias, qacc
 
+    def debug_self_contacts(self):
+        """Body-body contact records of every env's last forward pass (mjData.contact of the body pairs; parity triage):
+        after every launch `self.self_records` [N, SS_MAX_SELF_CONTACTS, 24] holds body1 body2 | position 3 | normal 3 | first
+        tangent 3 | 1/R | aref 4 | ... of the first `self.self_contacts[n]` contacts (ss_debug_self_contacts)."""
+        if getattr(self, "self_records", None) is None:
+            self.self_records = torch.zeros(self.num_envs, _cabi.SS_MAX_SELF_CONTACTS, 24, device=self.device)
+            _check(lib().ss_debug_self_contacts(self.handle, _ptr(self.self_records)))
+        return self.self_records
+
     def set_state(self, qpos, qvel, qpos_prev=None, qvel_prev=None, warm=None):
         """Teacher forcing / checkpoint restore.  *_prev default to the state itself (== after mj_forward)."""
         def as_t(x):

@@ -140,8 +140,10 @@ class EmuBatch:
         return xpos, xmat
 
     def debug_self_contacts(self):
-        """Turn on the record dump of the body-body contacts: self.self_records [N, 8, 24] after every launch."""
-        self.self_records = np.zeros((self.N, 8, 24), self.ft)
+        """Turn on the record dump of the body-body contacts: self.self_records [N, SS_MAX_SELF_CONTACTS = 64, 24] after every
+        launch (one record per lane of the env's wavefront; the first self.self_contacts[n] are valid)."""
+        from smplsim_amd import _cabi
+        self.self_records = np.zeros((self.N, _cabi.SS_MAX_SELF_CONTACTS, 24), self.ft)
         self._chk(self.L.ss_debug_self_contacts(self.batch, _p(self.self_records)))
         return self.self_records
 
