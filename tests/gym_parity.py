@@ -80,6 +80,8 @@ def run(env, mode, steps=120, to_np=lambda t: np.asarray(t)):
         within = bool((t["precision"][0] <= bound).all())
         rec["cause"] = ("conditioning: the one-step map amplifies a float32 rounding of the input %.1e / %.1e times (qpos / qvel)" % tuple(t["cond"][0])
                         if green64 and within else "UNEXPLAINED")
+        if not rec["contact_sets_equal"]:
+            rec["cause"] += "; the body-body contact lists of the step's last forward pass differ (kernel %d, oracle %d: a pair within float32 rounding of the margin)" % (len(mine), len(theirs))
         if t["reset"][0]:
             rec["cause"] = "a float64 replay takes MuJoCo's bad-state reset inside the step (state blowing up)"
         outside.append(rec)
