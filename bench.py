@@ -38,6 +38,13 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 HBM_MEASURED_GBS = 6290.0       # the copy bandwidth measured on this part (same guide); roofline.frac_measured_peak
 FP32_VECTOR_PEAK = 157.3e12     # MI355X_MICROARCH.md: FP32 vector peak (256 CUs x 4 SIMD-32 x 2 flop x 2.4 GHz, packed)
+SCALING_NOTE = ("default = WEAK scaling: 4096 envs on every GPU, independent shards, value = sum over the ranks.  Read as STRONG scaling "
+                "(--envs-total 4096: the same 4096 envs split over the ranks, 512 per GPU = 2 per CU at 8 GPUs) the metric is bounded by the "
+                "step time of ONE env: a launch ends when its heaviest env ends, one env alone on a CU needs 1.19-1.24 ms for the ~100 Newton "
+                "iterations of the heaviest env of a step (profiles/r04_lone_wave.txt) against 1.47 ms for the whole 4096-env launch on one "
+                "GPU, so 8 GPUs can step the SAME 4096 envs at most ~1.25x faster than one (<= ~3.4 M env-steps/s), whereas the weak-scaling "
+                "figure grows with the GPU count (no collective, no shared resource but the host).  Neither curve has been measured on hardware "
+                "by the builder (one-GPU boxes only); the driver's --gpus N runs are weak scaling unless it passes --envs-total")
 PARITY_PIN = ("none (mujoco absent): the oracle's mj_step restates MuJoCo's documented pipeline and is pinned to nothing; "
               "controllers / observations / rewards / gains are pinned to the reference's own code (tests/golden)")
 
@@ -92,10 +99,15 @@ def pmc_summary(workload, n_envs):
     j = json.load(open(path))
     if j.get("envs_per_gpu") != n_envs:
         return {}
+    from smplsim_amd._lib import source_hash
+    src = "profiles/" + os.path.basename(path) + " (" + j.get("profile", "?") + ")"
+    if j.get("src_hash") != source_hash():
+        # counters of another tree (kernel sources / headers / compiler flags changed since the passes were taken): not merged
+        return {"pmc_stale": True, "pmc_source": src, "pmc_src_hash": j.get("src_hash"), "src_hash": source_hash()}
     keys = ("traffic", "valu_issue_frac", "lds_wait_frac", "lds_bank_conflict_frac", "wave_active_frac", "wave_slot_occupancy",
             "scratch_bytes_per_lane", "vgprs", "waves_per_cu")
     out = {k: j[k] for k in keys if k in j}
-    out["pmc_source"] = "profiles/" + os.path.basename(path) + " (" + j.get("profile", "?") + ")"
+    out.update(pmc_stale=False, pmc_source=src, src_hash=j["src_hash"])
     return out
 
 
@@ -333,8 +345,8 @@ def run_imitation(args, rank, local_rank, world, dist, dev):
         out = {
             "metric": "env-steps/sec (whole node), motion-imitation rollout", "value": shard.whole_job_throughput(N * world * args.steps, elapsed),
             "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": WORKLOADS["imitation"].format(N=N), "envs_per_gpu": N, "clips": ml.num_current_motions(), "frames": F,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": WORKLOADS["imitation"].format(N=N), "envs_per_gpu": N, "envs_total": N * world, "clips": ml.num_current_motions(), "frames": F,
                        "parallelism": f"independent shards x{world} (no collective)", "launch": env.base.launch_info(),
                        "mean_reward": float(rew_sum.item()) / args.steps, "episodes_ended": int(ended.item()),
                        "obs_finite": bool(torch.isfinite(env.obs_buf).all().item()), "parity_pin": PARITY_PIN,
@@ -376,6 +388,9 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs-per-gpu", type=int, default=None, help="default 4096 (imitation: 1024 = 8192 envs on 8 GPUs)")
+    ap.add_argument("--envs-total", type=int, default=None,
+                    help="STRONG scaling: this many envs in total, split evenly over the ranks (the metric's '4096-env rollout at 1/2/4/8 MI355X' "
+                         "read literally: --envs-total 4096); default = weak scaling with --envs-per-gpu envs on every rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1234, help="seed of the envs and of the action stream (A/B studies: the launch follows its heaviest env, "
                     "so two kernels with different rounding are only comparable over several trajectories)")
@@ -400,6 +415,11 @@ def main(argv=None):
     dev = Gpu.device(local_rank)
 
     from smplsim_amd.batch import SMPLSimVecEnv
+    args.scaling = "weak"
+    if args.envs_total is not None:
+        if args.envs_total % world:
+            raise SystemExit(f"--envs-total {args.envs_total} is not a multiple of the {world} ranks")
+        args.envs_per_gpu, args.scaling = args.envs_total // world, "strong"
     if args.envs_per_gpu is None:
         args.envs_per_gpu = 1024 if args.workload == "imitation" else ENVS_PER_GPU
     N = args.envs_per_gpu
@@ -473,9 +493,10 @@ def main(argv=None):
         out = {
             "metric": "env-steps/sec (whole node), 4096-env SMPL rollout at 1/2/4/8 MI355X", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload].format(N=N),
-                       "envs_per_gpu": N, "parallelism": f"independent shards x{world} (no collective)",
+                       "envs_per_gpu": N, "envs_total": N * world, "parallelism": f"independent shards x{world} (no collective)",
+                       "scaling_note": SCALING_NOTE,
                        "host_cores_pinned_per_rank": (len(host_cores) if host_cores else None),
                        "launch": launch,
                        "solver": {"iterations": args.newton_iters if args.newton_iters > 0 else 100, "tolerance": 1e-8,

@@ -73,7 +73,8 @@ typedef struct {
   const int32_t *exclude;        /* [nexclude,2] body indices */
   /* mjModel.stat.meaninertia: mean diagonal of the joint-space inertia matrix (armature included) at qpos0.  It scales the
    * solver's termination test like in mj_step (below: ss_env_cfg.solver_tolerance).  <= 0: the library computes it from this
-   * description (a caller that zero-initialises the struct of ABI 2, which ended before this field, keeps working). */
+   * description.  (Only callers compiled against THIS header may leave it at 0: a caller built against the shorter ABI-2 struct
+   * hands over an object that ends before this field, and reading it is undefined behaviour, not zero — INTEGRATION.md "ABI history".) */
   double meaninertia;
 } ss_model_desc;
 
@@ -254,7 +255,8 @@ int ss_gae(const float *rewards, const float *not_done, const float *not_dead, c
 int ss_debug_prof(ss_batch *b, unsigned long long *out, int n);
 
 /* launch geometry: resident envs per workgroup = per CU (LDS-capacity bound) and the LDS bytes of such a workgroup; batches
- * smaller than (CUs x envs_per_wg) are launched with ceil(N / CUs) envs per workgroup so that they cover every CU */
+ * smaller than (CUs x envs_per_wg) are launched with ceil(N / CUs) envs per workgroup so that they cover every CU;
+ * kernel_regs = VGPRs of the kernel instantiation THIS batch launched last (0 before its first launch) */
 int ss_launch_info(const ss_batch *b, int32_t *envs_per_wg, int32_t *lds_bytes, int32_t *kernel_regs);
 
 /* Launch-geometry override for callers that step several batches concurrently on different streams (body-shape groups):

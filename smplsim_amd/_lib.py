@@ -70,6 +70,22 @@ def build(verbose=False, force=False):
     return LIB_PATH
 
 
+def source_hash():
+    """What a profile / counter summary was taken on: sha256 (16 hex digits) over every file under smplsim_amd/csrc and include/
+    plus the compiler flags of the three groups of translation units.  tools/prof_summarize.py stores it in profiles/pmc_summary_*.json,
+    bench.py recomputes it and refuses counter blocks of another tree (roofline.pmc_stale)."""
+    import hashlib
+    h = hashlib.sha256()
+    inc = os.path.join(os.path.dirname(_PKG), "include")
+    for d in (SRC_DIR, inc):
+        for f in sorted(os.listdir(d)):
+            if f.endswith((".h", ".hip")):
+                h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    h.update(" ".join([os.environ.get("SS_HIPCC_OPT", DEFAULT_OPT), "|", os.environ.get("SS_HIPCC_SC_OPT", SC_OPT), "|",
+                       os.environ.get("SS_HIPCC_MOTION_OPT", MOTION_OPT)]).encode())
+    return h.hexdigest()[:16]
+
+
 def lib():
     global _LIB
     if _LIB is None:

@@ -123,7 +123,7 @@ struct HipBackend {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? nullptr : hipGetErrorString(e);
   }
-  static int &regs_ref() { static int r = 0; return r; }
+  static int &regs_ref() { static thread_local int r = 0; return r; }
   static int kernel_regs() { return regs_ref(); }
   static const char *launch(const ss::KArgs &k, int nenv, int envs_per_wg, size_t lds_bytes, void *stream, int fixed_epw, int max_wgs) {
     const bool bodyout = (k.out0 || k.power) && (k.mode == ss::MODE_STEP || k.mode == ss::MODE_RESET);
@@ -132,14 +132,16 @@ struct HipBackend {
     if (!kern) return "no kernel variant for this model size";
     static thread_local kern_t configured[32] = {};
     static thread_local size_t configured_lds[32] = {};
+    static thread_local int regs_by_slot[32] = {};            // VGPRs per instantiation: launch_info reports the LAUNCHED kernel's
     const int slot = 16 * ss::kernel_variant(k.h) + flavour;
     if (configured[slot] != kern || configured_lds[slot] < lds_bytes) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
       if (e != hipSuccess) return hipGetErrorString(e);
       hipFuncAttributes fa;
-      if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern)) == hipSuccess) regs_ref() = fa.numRegs;
+      if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern)) == hipSuccess) regs_by_slot[slot] = fa.numRegs;
       configured[slot] = kern; configured_lds[slot] = lds_bytes;
     }
+    regs_ref() = regs_by_slot[slot];                          // of this launch (ss_api::run copies it into the batch)
     static thread_local int cus = num_cus();
     // small batches: spread the envs over all CUs instead of filling a third of them with full workgroups — a wave that
     // shares its CU with 3 others runs ~13% faster than one of 12 (1024 envs: 1.27 -> 1.13 ms per step launch)

@@ -208,11 +208,15 @@ int ss_linear_bf16(const void *x, const void *w, const float *bias, void *y, int
     const size_t lds_ = (size_t)2 * (BM + BN_) * (BK_ + 8) * sizeof(__bf16);                                                   \
     if (waves8 && BK_ == 64) {                                                                                          \
       auto kern_ = ss_linear_kernel<BN_, BK_, F32_, 4>;                                                                        \
-      static bool cfg_ = false;                                                                                                \
-      if (!cfg_) { if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_) != hipSuccess) return fail(SS_ERR_HIP, "cannot size the GEMM's LDS"); cfg_ = true; } \
+      /* per launch: the attribute belongs to the (kernel, device) pair and the call is a table write (a process-wide flag left */ \
+      /* the wide tiles of a second GPU at the 64 KB default: ADVICE r4) */                                                     \
+      if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_) != hipSuccess) return fail(SS_ERR_HIP, "cannot size the GEMM's LDS"); \
       hipLaunchKernelGGL(kern_, grid, dim3(512), lds_, st, X, Wt, bias, y, M, N, K, ldy, act, remap);                           \
     } else {                                                                                                                   \
       auto kern_ = ss_linear_kernel<(BN_ > 128 ? 128 : BN_), BK_, F32_, 2>;                                                     \
+      if ((size_t)2 * (BM + (BN_ > 128 ? 128 : BN_)) * (BK_ + 8) * sizeof(__bf16) > 64 * 1024 &&                                  \
+          hipFuncSetAttribute(reinterpret_cast<const void *>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize,                \
+                              (int)((size_t)2 * (BM + (BN_ > 128 ? 128 : BN_)) * (BK_ + 8) * sizeof(__bf16))) != hipSuccess) return fail(SS_ERR_HIP, "cannot size the GEMM's LDS"); \
       hipLaunchKernelGGL(kern_, dim3((N + (BN_ > 128 ? 128 : BN_) - 1) / (BN_ > 128 ? 128 : BN_), gm), dim3(256),              \
                          (size_t)2 * (BM + (BN_ > 128 ? 128 : BN_)) * (BK_ + 8) * sizeof(__bf16), st, X, Wt, bias, y, M, N, K, ldy, act, remap); \
     }                                                                                                                          \

@@ -52,6 +52,7 @@ struct ss_batch {
   float *power = nullptr;                 // caller-owned, optional [N, control_freq_inv, nv - 6] (ss_set_power_output)
   int fixed_envs_per_wg = 0, max_wgs = 0; // ss_set_launch_geometry: 0 = automatic (small batches are spread over all CUs)
   mutable std::string err;                // message of the last failed call that took this handle
+  mutable int kernel_regs = 0;            // VGPRs of the kernel instantiation this batch launched last (ss_launch_info)
   mutable int parity = 0;                 // which of the two work counters the next launch uses (it clears the other one)
   float *d_kin = nullptr;                 // [N, nb, 12] scratch of ss_get_state(XPOS / XMAT)
   const float *fall_actions = nullptr;    // caller-owned [N,3,nu] draws of the in-launch Fall reset (ss_set_fall_actions)
@@ -227,6 +228,7 @@ struct ss_api {
     if (!BE::set_device(b->m->device)) return fail(SS_ERR_HIP, "cannot select device");
     const char *err = BE::launch(k, b->st.num_envs, b->envs_per_wg, b->lds_bytes, stream, b->fixed_envs_per_wg, b->max_wgs);
     if (err) return fail(SS_ERR_HIP, err);
+    b->kernel_regs = BE::kernel_regs();
     // only a launch that ran has zeroed the other work counter: a failed one leaves the pair as it was (the counter it would
     // have used is still zero), so the next launch starts from a clean counter either way
     b->parity ^= 1;
@@ -450,7 +452,7 @@ struct ss_api {
     if (!b) return ss_api<BE>::fail(SS_ERR_INVALID, "null batch");                                                   \
     if (epw) *epw = b->envs_per_wg;                                                                                  \
     if (lds) *lds = (int32_t)b->lds_bytes;                                                                           \
-    if (regs) *regs = BE::kernel_regs();                                                                             \
+    if (regs) *regs = b->kernel_regs;                                                                                \
     return SS_OK;                                                                                                    \
   }                                                                                                                  \
   const char *ss_last_error(void) { return ss::last_error().c_str(); }                                               \

@@ -630,7 +630,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
           real axx = Rb[0] * cv[3] + Rb[1] * cv[4] + Rb[2] * cv[5];
           real axy = Rb[3] * cv[3] + Rb[4] * cv[4] + Rb[5] * cv[5];
           real nn = SS_M(sqrt)(axx * axx + axy * axy);
-          if (nn < real(1e-15)) { t1x = 1.f; t1y = 0.f; } else { t1x = axx / nn; t1y = axy / nn; }
+          if (nn < real(1e-15)) { t1x = 0.f; t1y = 1.f; } else { t1x = axx / nn; t1y = axy / nn; }   // no hint (sphere, upright capsule): mju_makeFrame's default e_y, like the oracle
         }
       }
       unsigned long long bal = w->ballot(qual && !caps);

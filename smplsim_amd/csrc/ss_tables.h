@@ -57,6 +57,9 @@ inline void quat2mat(const double *q, double *m) {
 // these humanoids is aligned with the world (hinges at zero, root orientation identity), so dof (body j, axis a) sees
 //     M_ii = sum over the bodies b of j's subtree of  a^T I_b a + m_b |a x (c_b - p_j)|^2   (+ armature),
 // and the free joint the total mass (3 x) and the same sum about the root's position (3 x).
+// (ss_model_desc has neither body quaternions nor joint axes: every model it can describe has world-aligned body frames at
+// the zero pose and three hinges x, y, z per body, which is what the sums below use; the root orientation in qpos0 does not enter —
+// the diagonal of M is invariant under a rigid rotation of the whole tree, the root's angular dofs being body-frame ones.)
 inline double meaninertia_at_qpos0(const ss_model_desc &d) {
   const int nb = d.nbody, nv = 6 + 3 * (nb - 1);
   std::vector<double> p(3 * nb), c(3 * nb), I(9 * nb);

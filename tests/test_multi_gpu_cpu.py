@@ -112,6 +112,15 @@ def test_bench_main_under_world_size_2(tmp_path, workload, extra):
     assert res["roofline"]["bound"] == "hbm" and res["roofline"]["achieved"] > 0
 
 
+def test_bench_main_strong_scaling_switch(tmp_path):
+    """--envs-total: the metric's "4096-env rollout at 1/2/4/8 MI355X" read literally — the same envs split over the ranks
+    ("scaling": "strong"); the line carries the bound of that reading (config.scaling_note)."""
+    res = _run_world(tmp_path, _BENCH, ["--gpus", "2", "--envs-total", "6", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    assert res["scaling"] == "strong" and res["config"]["envs_per_gpu"] == 3 and res["config"]["envs_total"] == 6
+    assert abs(res["value"] - 6 * 2 / (res["ms_per_step"] * 1e-3 * 2)) < 1e-6 * res["value"]
+    assert "1.25x" in res["config"]["scaling_note"] and "--envs-total" in res["config"]["scaling_note"]
+
+
 def test_ranks_pin_disjoint_slices_of_the_host_cores():
     """shard.pin_host_threads: every rank of a node keeps its own slice of the cores the process may run on (bench.py calls it before the
     process group starts); a single rank, or fewer cores than ranks, leaves the affinity alone."""

@@ -10,6 +10,9 @@ from collections import defaultdict
 
 prof, out = sys.argv[1], sys.argv[2]
 summary = {}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from smplsim_amd._lib import source_hash   # noqa: E402  (the tree the counters were taken on: bench.py refuses a summary of another tree)
+SRC_HASH = source_hash()
 # kernel trace: per-kernel count / avg / total duration
 for f in glob.glob(os.path.join(prof, "trace", "**", "*kernel_trace.csv"), recursive=True):
     agg = defaultdict(lambda: [0, 0.0])
@@ -76,7 +79,7 @@ for kname, cs in summary.get("pmc", {}).items():
         continue
     g = lambda c: cs[c]["mean_per_dispatch"] if c in cs else None
     res = summary.get("step_kernel_resources", {})
-    lim = {"workload": os.environ.get("WORKLOAD", "smpl"), "envs_per_gpu": int(os.environ.get("ENVS_PER_GPU", "4096")),
+    lim = {"workload": os.environ.get("WORKLOAD", "smpl"), "envs_per_gpu": int(os.environ.get("ENVS_PER_GPU", "4096")), "src_hash": SRC_HASH,
            "profile": os.environ.get("TAG", "prof"), "step_launch_avg_us": summary.get("step_launches", {}).get("avg_us")}
     cyc = g("GRBM_GUI_ACTIVE") / 8.0 if g("GRBM_GUI_ACTIVE") else None
     n_simd = 1024
