@@ -12,9 +12,12 @@ whole episodes, so a rollout column can end mid-episode; its last step bootstrap
 (`bootstrap=False` reproduces the reference's zero).  Everything — observations, actions, rewards, flags, advantages —
 stays in HBM; the only host synchronisation per epoch is the logging read-back.
 """
+import math
 from dataclasses import dataclass, field
 
 import torch
+
+_LOG_2PI = math.log(2.0 * math.pi)
 
 from ..learning.gae import estimate_advantages_columns, normalize_advantages
 from ..learning.networks import MLP, PolicyGaussian, Value
@@ -113,6 +116,75 @@ class AgentPPO:
         exps = torch.full((T, N), 0.0 if mean_action else 1.0, **f)
         out = dict(states=states, actions=actions, rewards=rewards, not_done=not_done, not_dead=not_dead, exps=exps,
                    last_state=state.clone())
+        if behaviour_logp is not None:
+            out["log_probs"] = behaviour_logp
+        return out
+
+    @torch.no_grad()
+    def sample_pipelined(self, pipe, horizon=None, mean_action=False):
+        """sample() over a pipeline.PipelinedVecEnv of the same job: per control step, sub-batch g's policy forward, action sampling and
+        step launch are issued on stream g, so the GEMM tiles of one sub-batch run on the CUs that the tail of another sub-batch's step
+        launch has already left.  Same draws as sample(): the Gaussian noise of a step is drawn for all N envs
+        from self.gen and sliced, the env's inputs come from the pipeline's master generator — every env gets what it gets in the
+        single batch, the returned tensors are bit-identical to sample()'s (GPU test; the bf16 policy's row results do not depend
+        on the number of rows: the K order of the MFMA kernels is the same for every tile width)."""
+        T, N, G = horizon or self.horizon, pipe.num_envs, pipe.sub_batches
+        assert N == self.env.num_envs or self.env is pipe
+        self.policy_net.eval()
+        if getattr(self, "_pipe_obs", None) is None:
+            self._pipe_obs = pipe.reset()
+        f = dict(device=self.device, dtype=torch.float32)
+        states = torch.empty(T, N, self.state_dim, **f)
+        actions = torch.empty(T, N, self.action_dim, **f)
+        rewards, not_done, not_dead = (torch.empty(T, N, **f) for _ in range(3))
+        behaviour_logp = torch.empty(T, N, 1, **f) if (self.fast_policy is not None and not mean_action) else None
+        last_state = torch.empty(N, self.state_dim, **f)
+        from ..pipeline import _record_event
+        start = _record_event(self.device)                       # the buffers above exist before any sub-stream touches them
+        cuda = self.device.type == "cuda"
+        obs = list(self._pipe_obs)
+        for t in range(T):
+            noise = None if mean_action else torch.randn(N, self.action_dim, generator=self.gen, **f)
+            pipe.draw_step_inputs()
+            ev = _record_event(self.device)
+            for g in range(G):
+                r, s = pipe.rows(g), pipe.streams[g]
+                with pipe.stream(g):
+                    s.wait_event(ev)
+                    if t == 0:
+                        s.wait_event(start)
+                    if noise is not None and cuda:
+                        noise.record_stream(s)
+                    state = self._prep_obs(obs[g])
+                    states[t, r] = state
+                    if self.fast_policy is not None:
+                        mean = self.fast_policy.mean(state, slot=g)
+                    else:
+                        with self._autocast():
+                            mean = self._f32(self.policy_net.select_action(state, True))
+                    if mean_action:
+                        a = mean
+                    else:
+                        log_std = self.policy_net.action_log_std
+                        a = torch.addcmul(mean, log_std.exp(), noise[r]) if self.fast_policy is not None else mean + log_std.exp() * noise[r]
+                        if behaviour_logp is not None:
+                            behaviour_logp[t, r] = (-0.5 * noise[r].pow(2) - 0.5 * _LOG_2PI - log_std).sum(1, keepdim=True)
+                    actions[t, r] = a
+                    o, rew, died, timed_out, _ = pipe.step_async(g, self._prep_actions(a))
+                    rewards[t, r] = rew
+                    not_dead[t, r] = (~died).to(torch.float32)
+                    not_done[t, r] = (~(died | timed_out)).to(torch.float32)
+                    obs[g] = o
+                    if t == T - 1:
+                        last_state[r] = self._prep_obs(o)
+        if cuda:
+            cur = torch.cuda.current_stream(self.device)
+            for s in pipe.streams:                                # the caller's stream continues after every sub-batch's last step
+                cur.wait_stream(s)
+        self._pipe_obs = obs
+        self.num_steps += T * N
+        exps = torch.full((T, N), 0.0 if mean_action else 1.0, **f)
+        out = dict(states=states, actions=actions, rewards=rewards, not_done=not_done, not_dead=not_dead, exps=exps, last_state=last_state)
         if behaviour_logp is not None:
             out["log_probs"] = behaviour_logp
         return out

@@ -239,9 +239,11 @@ class SMPLSimVecEnv:
         _check(lib().ss_reset(self.handle, _ptr(m), _ptr(fa), _ptr(tr), _ptr(self.obs_buf), self._stream()))
         return self.obs_buf, {"critic_state": self.obs_buf}
 
-    def step(self, actions, task_rand=None, _events=None):
+    def step(self, actions, task_rand=None, _events=None, task_rand2=None, _fall_drawn=False):
         """One control step of every env (+ masked autoreset).  `_events` = (start, end) torch.cuda.Event pair recorded
-        around the step launch only (bench.py's per-launch kernel timing)."""
+        around the step launch only (bench.py's per-launch kernel timing).  task_rand / task_rand2 (the step's and the in-launch
+        reset's task draws) and _fall_drawn (self._fall_buf already holds this step's Fall draws) let a caller that splits one job
+        into sub-batches hand every env the draws it would get in the unsplit batch (pipeline.PipelinedVecEnv)."""
         actions = actions.to(torch.float32).contiguous()
         assert actions.shape == (self.num_envs, self.nu) and actions.device == self.device
         tr = task_rand if task_rand is not None else self._task_rand()
@@ -254,9 +256,9 @@ class SMPLSimVecEnv:
         if self.autoreset and self._fused_autoreset:
             # one launch: step + Default reset of the envs whose episode ended (GymVectEnv semantics, reference
             # nv/gymwrapper.py:53-60): obs_final = the step's observation, obs_buf = what the policy acts on next
-            tr2 = self._task_rand()
+            tr2 = task_rand2 if task_rand2 is not None else self._task_rand()
             self._keep2 = (tr2,)
-            if self._fall_buf is not None:                   # fresh draws for the envs that will be reset in this launch
+            if self._fall_buf is not None and not _fall_drawn:   # fresh draws for the envs that will be reset in this launch
                 self._fall_buf.uniform_(0.0, 1.0, generator=self.gen)
             _check(lib().ss_step_autoreset(self.handle, _ptr(actions), _ptr(tr), _ptr(tr2), _ptr(self.obs_final), _ptr(self.obs_buf),
                                            _ptr(self.rew_buf), _ptr(self.terminated), _ptr(self.truncated), self._stream()))

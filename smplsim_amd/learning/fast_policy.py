@@ -40,7 +40,7 @@ class FusedPolicyInference:
         self.action_dim = self.layers[-1].out_features
         self.kpad = [_pad_to(l.in_features, 32) for l in self.layers]
         self.w, self.b = [], []
-        self._bufs, self._M = None, 0
+        self._bufs = {}
         self.refresh()
 
     @torch.no_grad()
@@ -53,21 +53,21 @@ class FusedPolicyInference:
             self.w.append(w.contiguous())
             self.b.append(l.bias.detach().to(torch.float32).contiguous())
 
-    def _buffers(self, M):
-        if self._bufs is None or self._M != M:
+    def _buffers(self, M, slot=0):
+        """Scratch of one forward pass in flight; `slot` = which of several concurrent passes (sub-batches on their own streams)."""
+        if slot not in self._bufs or self._bufs[slot][0] != M:
             width = max(max(l.out_features for l in self.layers[:-1]), self.kpad[0])
             bf = dict(dtype=torch.bfloat16, device=self.device)
             # flat ping-pong buffers: a layer's output [M, N] is the next layer's operand [M, K = N], row stride = its own width
-            self._bufs = (torch.zeros(M * width, **bf), torch.zeros(M * width, **bf), torch.zeros(M, self.action_dim, dtype=torch.float32, device=self.device))
-            self._M = M
-        return self._bufs
+            self._bufs[slot] = (M, torch.zeros(M * width, **bf), torch.zeros(M * width, **bf), torch.zeros(M, self.action_dim, dtype=torch.float32, device=self.device))
+        return self._bufs[slot][1:]
 
     @torch.no_grad()
-    def mean(self, obs):
+    def mean(self, obs, slot=0):
         """Action means [M, action_dim] (fp32) of a batch of raw observations [M, state_dim] (fp32, any row stride)."""
         assert obs.dtype == torch.float32 and obs.dim() == 2 and obs.shape[1] == self.state_dim and obs.stride(1) == 1
         M = obs.shape[0]
-        a, b, out = self._buffers(M)
+        a, b, out = self._buffers(M, slot)
         L, st = lib(), _launch_stream(self.device)
         nm = self.policy.norm
         _check(L.ss_obs_to_bf16(_ptr(obs), M, self.state_dim, obs.stride(0), _ptr(nm.mean), _ptr(nm.std), _ptr(nm.n), self.clip[0], self.clip[1],

@@ -505,26 +505,53 @@ def test_self_collision_on_gpu(vec):
     assert with_self >= 5 and w2[0] < 2e-5 and w2[1] < 2e-3 and w2[2] < 2e-3, w2
 
 
-def test_pipelined_sub_batches_equal_their_standalone_envs(vec):
-    """PipelinedVecEnv: G sub-batches on G streams, stepped round-robin, give exactly what the same shards give alone."""
+def test_pipelined_sub_batches_are_the_single_batch_bit_for_bit(vec):
+    """PipelinedVecEnv(N, G, seed): G sub-batches on G streams, stepped round-robin, ARE the job SMPLSimVecEnv(N, seed) — the master
+    generator hands every env the draws it gets in the single batch — bit for bit through autoresets (GPU twin of the emulator test)."""
     from smplsim_amd.pipeline import PipelinedVecEnv
-    pipe = PipelinedVecEnv(256, sub_batches=4, seed=3, task="HumanoidSpeed")
-    solo = [vec(64, seed=3 + 1000 * g, task="HumanoidSpeed") for g in range(4)]
-    pipe.reset()
-    for e in solo:
-        e.reset()
-    gens = [torch.Generator(device=pipe.device) for _ in range(4)]
-    for t in range(6):
-        outs = []
-        for g in range(4):
-            gens[g].manual_seed(100 * t + g)
-            with pipe.stream(g):
-                a = torch.rand(64, 69, generator=gens[g], device=pipe.device) * 2 - 1
-            outs.append((a, pipe.step_async(g, a)))
-        pipe.synchronize()
-        for g, (a, (obs, rew, term, trunc, _)) in enumerate(outs):
-            o2, r2, te2, tu2, _ = solo[g].step(a)
-            assert torch.equal(obs, o2) and torch.equal(rew, r2) and torch.equal(term, te2) and torch.equal(trunc, tu2)
+    kw = dict(seed=3, task="HumanoidSpeed", episode_length=6)
+    pipe, one = PipelinedVecEnv(256, sub_batches=4, **kw), vec(256, **kw)
+    pipe.reset(); one.reset()
+    pipe.synchronize()
+    assert torch.equal(one.obs_buf, torch.cat([e.obs_buf for e in pipe.envs]))
+    gen = torch.Generator(device=pipe.device); gen.manual_seed(7)
+    for t in range(10):
+        a = torch.rand(256, 69, generator=gen, device=pipe.device) * 2 - 1
+        torch.cuda.synchronize()
+        outs = [pipe.step_async(g, a[pipe.rows(g)]) for g in range(4)]
+        o1, r1, te1, tu1, i1 = one.step(a)
+        pipe.synchronize(); torch.cuda.synchronize()
+        assert torch.equal(o1, torch.cat([o[0] for o in outs])) and torch.equal(r1, torch.cat([o[1] for o in outs]))
+        assert torch.equal(te1, torch.cat([o[2] for o in outs])) and torch.equal(tu1, torch.cat([o[3] for o in outs]))
+        assert torch.equal(i1["final_observation"], torch.cat([o[4]["final_observation"] for o in outs]))
+        assert torch.equal(one.qpos, torch.cat([e.qpos for e in pipe.envs])) and torch.equal(one.qvel, torch.cat([e.qvel for e in pipe.envs]))
+    assert int(one.cur_t.max()) <= 7                            # the short episodes were truncated and reset inside the step launches
+    pipe.close(); one.close()
+
+
+def test_pipelined_sampler_equals_the_serial_sampler_on_gpu(vec):
+    """AgentPPO.sample_pipelined (sub-batches on their own streams: one sub-batch's bf16 MFMA policy forward fills the tail of another's
+    step launch) returns the rollout of AgentPPO.sample bit for bit: the MFMA kernels' row results do not depend on the row count."""
+    from smplsim_amd.agents.ppo import AgentPPO, PPOConfig
+    from smplsim_amd.pipeline import PipelinedVecEnv
+    N, G, T = 512, 4, 6
+    kw = dict(task="HumanoidSpeed", episode_length=4, seed=9)
+    for mfma in (True, False):
+        cfg = PPOConfig(hidden=(256, 128), min_batch_size=N * T, mfma_inference=mfma)
+        a1 = AgentPPO(vec(N, **kw), cfg, seed=4)
+        pipe = PipelinedVecEnv(N, sub_batches=G, **kw)
+        a2 = AgentPPO(pipe, cfg, seed=4)
+        for _ in range(2):
+            b1, b2 = a1.sample(), a2.sample_pipelined(pipe)
+            torch.cuda.synchronize()
+            assert set(b1) == set(b2)
+            for k in b1:
+                if mfma or k not in ("states", "actions", "last_state"):
+                    assert torch.equal(b1[k], b2[k]), (mfma, k, (b1[k] - b2[k]).abs().max())
+                else:                                            # torch / hipBLASLt picks its kernel by the row count
+                    assert torch.allclose(b1[k], b2[k], rtol=0, atol=1e-5), (k, (b1[k] - b2[k]).abs().max())
+        assert (1.0 - b1["not_done"]).sum() >= N
+        a1.env.close(); pipe.close()
 
 
 @pytest.mark.parametrize("mode", ["one_action", "fresh_actions"])

@@ -221,3 +221,70 @@ def test_fused_imitation_step_with_body_body_contacts(emu_backend):
         assert torch.equal(envs[0].base.qpos, envs[1].base.qpos) and torch.equal(envs[0].base.self_contacts, envs[1].base.self_contacts)
         contacts += int(envs[0].base.self_contacts.sum())
     assert contacts > 0
+
+
+class _HostStream:
+    """Stand-in for a HIP stream on the emulator: everything is synchronous there."""
+    def wait_event(self, ev): pass
+    def synchronize(self): pass
+
+
+@pytest.fixture()
+def host_streams(monkeypatch):
+    import contextlib
+    from smplsim_amd import pipeline
+    monkeypatch.setattr(pipeline, "_make_stream", lambda device: _HostStream())
+    monkeypatch.setattr(pipeline, "_stream_ctx", lambda stream: contextlib.nullcontext())
+    monkeypatch.setattr(pipeline, "_record_event", lambda device: None)
+
+
+@pytest.mark.parametrize("task,init", [("HumanoidSpeed", "Default"), ("HumanoidGetup", "Fall")])
+def test_pipelined_sub_batches_are_the_single_batch_bit_for_bit(emu_backend, host_streams, task, init):
+    """pipeline.PipelinedVecEnv(N, G, seed) is the SAME job as SMPLSimVecEnv(N, seed): the master generator draws every step's task
+    targets / Fall-reset actions for all N envs in the single batch's order and hands the sub-batches row slices, so state,
+    observations, rewards and flags agree bit for bit through autoresets (short episodes force them)."""
+    from smplsim_amd.batch import SMPLSimVecEnv
+    from smplsim_amd.pipeline import PipelinedVecEnv
+    N, G = 6, 3
+    kw = dict(task=task, state_init=init, episode_length=4, seed=5, recovery_steps=2)    # (getup: no reset during the recovery grace)
+    one, pipe = SMPLSimVecEnv(N, **kw), PipelinedVecEnv(N, sub_batches=G, **kw)
+    o1, _ = one.reset()
+    op = pipe.reset()
+    assert torch.equal(o1, torch.cat(op))
+    g = torch.Generator(); g.manual_seed(1)
+    ended = 0
+    for t in range(10):
+        a = torch.rand(N, one.nu, generator=g) * 2 - 1
+        o1, r1, te1, tu1, i1 = one.step(a)
+        outs = [pipe.step_async(k, a[pipe.rows(k)].contiguous()) for k in range(G)]
+        assert torch.equal(o1, torch.cat([o[0] for o in outs])) and torch.equal(r1, torch.cat([o[1] for o in outs]))
+        assert torch.equal(te1, torch.cat([o[2] for o in outs])) and torch.equal(tu1, torch.cat([o[3] for o in outs]))
+        assert torch.equal(i1["final_observation"], torch.cat([o[4]["final_observation"] for o in outs]))
+        assert torch.equal(one.qpos, torch.cat([e.qpos for e in pipe.envs])) and torch.equal(one.task_state, torch.cat([e.task_state for e in pipe.envs]))
+        ended += int((te1 | tu1).sum())
+    assert ended >= N, ended                                     # every env went through at least one in-launch reset
+    one.close(); pipe.close()
+
+
+def test_pipelined_sampler_equals_the_serial_sampler(emu_backend, host_streams):
+    """AgentPPO.sample_pipelined over G sub-batches returns the rollout of AgentPPO.sample over the single batch: same policy draws
+    (the step's noise is drawn for all N envs and sliced), same env inputs (master generator), same tensors."""
+    from smplsim_amd.agents.ppo import AgentPPO, PPOConfig
+    from smplsim_amd.batch import SMPLSimVecEnv
+    from smplsim_amd.pipeline import PipelinedVecEnv
+    N, G, T = 8, 2, 5
+    kw = dict(task="HumanoidSpeed", episode_length=3, seed=9)
+    cfg = PPOConfig(hidden=(32, 32), min_batch_size=N * T)
+    a1 = AgentPPO(SMPLSimVecEnv(N, **kw), cfg, seed=4)
+    pipe = PipelinedVecEnv(N, sub_batches=G, **kw)
+    a2 = AgentPPO(pipe, cfg, seed=4)
+    for round_ in range(2):                                      # the second call continues from the kept observations
+        b1, b2 = a1.sample(), a2.sample_pipelined(pipe)
+        assert set(b1) == set(b2)
+        for k in b1:
+            if k in ("states", "actions", "last_state"):         # through the torch policy on the host: row results of a matmul may depend
+                assert torch.allclose(b1[k], b2[k], rtol=0, atol=1e-6), k   # on the row count by a rounding (the MFMA kernels' do not: GPU test)
+            else:
+                assert torch.equal(b1[k], b2[k]), k
+    assert (1.0 - b1["not_done"]).sum() >= N
+    a1.env.close(); pipe.close()
