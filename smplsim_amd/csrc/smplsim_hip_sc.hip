@@ -14,7 +14,7 @@ kern_t pick_kernel_selfcol(int variant, bool shaped, bool imit, const Hdr &h, co
 #ifndef SS_NO_FIXED_LAYOUT
   // the shipped SMPL humanoid with its layout as compile-time constants (as the plain headline kernel: ss_env_kernel.h)
   if (variant == 0 && HdrSmpl::matches(h, hc)) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS_SC, true, false, HdrSmpl, true>;
-  if (variant == 1 && HdrSmplx::matches(h, hc)) return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, true, false, HdrSmplx, true>;
+  if (variant == 1 && ss::HdrSmplxFixedSC::matches(h, hc)) return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, true, false, ss::HdrSmplxFixedSC, true>;   // (the plain, non-aliased layout: ss_hdr.h)
 #endif
   if (variant == 0) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS_SC, true, false, HdrRuntime, true>;   // (also writes the body frames)
   if (variant == 1) return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, true, false, HdrRuntime, true>;

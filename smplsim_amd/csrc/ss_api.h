@@ -134,7 +134,7 @@ struct ss_api {
       geomc.insert(geomc.end(), hm.geomc.begin(), hm.geomc.end());   // pair functions (self_collision batches): geoms of this shape
       pairs.insert(pairs.end(), hm.pairs.begin(), hm.pairs.end());
     }
-    if (12 * m->hm.h.nb > m->hm.h.l_Wst - m->hm.h.l_IA) { delete m; return fail(SS_ERR_LDS, "no room for the per-env body offsets"); }
+    if (12 * m->hm.h_sc.nb > m->hm.h_sc.l_Wst - m->hm.h_sc.l_IA) { delete m; return fail(SS_ERR_LDS, "no room for the per-env body offsets"); }   // (the aliased layout has the 12 nb by construction)
     m->device = device; m->num_shapes = num_shapes;
     if (!BE::set_device(device)) { delete m; return fail(SS_ERR_HIP, "cannot select device"); }
     auto up = [&](const void *src, size_t bytes) -> void * {
@@ -210,7 +210,7 @@ struct ss_api {
   static ss::KArgs base_args(const ss_batch *b, int mode) {
     ss::KArgs k{};
     const ss_model *m = b->m;
-    k.h = m->hm.h; k.cfg = b->cfg; k.st = b->st;
+    k.h = b->cfg.self_collision ? m->hm.h_sc : m->hm.h; k.cfg = b->cfg; k.st = b->st;   // (body-body-contact batches: the plain LDS layout, ss_tables.h)
     k.shared_g = m->d_shared; k.bodyc = m->d_bodyc; k.candc = m->d_candc; k.candb = m->d_candb;
     k.illegal_mask = m->hm.illegal_mask;
     k.hc = m->hm.hc;

@@ -33,10 +33,11 @@ constexpr int kCandC = 8;    // floats per contact candidate
 // Header passed to the kernels by value: dims, table offsets (32-bit words into the shared blob),
 // per-env LDS layout (float offsets) and physics scalars.
 struct Hdr {
-  int nb, nn, nv, nq, nu, ncand, nlev, reserved0, nbox, nslot, maxlev;
-  unsigned long long reserved1[2];   // reserved0..2: slots of the pelvis-rooted level tables (rounds 1-2).  Kept as padding: the offsets
-                                     // of the fields behind them are part of the kernels' register allocation, and closing the gaps
-                                     // cost 0.7 % on the headline (same-box A/B, profiles/r03_centred_elimination.md)
+  int nb, nn, nv, nq, nu, ncand, nlev, a_stride, nbox, nslot, maxlev;
+  int l_Rloc, l_w2;                  // a_stride, l_Rloc, l_w2 (round 5: the aliased layout below) sit in the slots of the pelvis-rooted level
+  unsigned long long reserved1;      // tables of rounds 1-2, which had been kept as padding: the offsets of the fields behind them are part of
+                                     // the kernels' register allocation, and closing the gaps cost 0.7 % on the headline (same-box A/B,
+                                     // profiles/r03_centred_elimination.md)
   // shared-blob word offsets
   // (o_dofc, o_boff: real-valued tables, offsets in reals from the start of the blob; the layout of this struct is part of
   // the kernel's register allocation — one more field here cost 850 SGPR reloads in the step kernel)
@@ -55,9 +56,17 @@ struct Hdr {
 // immediates.  Arrays with disjoint lifetimes share storage (LDS capacity sets the number of resident envs per CU).
 struct Layout {
   int l_q, l_v, l_a, l_tau, l_Fb, l_Pb, l_delta, l_diag, l_S, l_Ab, l_An, l_Aown, l_IA, l_Ubuf, l_Wst, l_R, l_r, l_Gb, l_tmp, l_V, l_Iown,
-      ia_stride, l_act, env_floats;
+      ia_stride, l_act, env_floats, a_stride, l_Rloc, l_w2;
 };
-constexpr Layout make_layout(int nb, int maxlev) {
+// alias_w (round 5; the SMPL-X size class, where LDS and not the register file caps the resident envs: 5 -> 6 per CU): the (W, y) rows of
+// a body take the place of its generalized inertia.  A body's Aown row is read in part 1 of ITS level of the sweep towards the root and
+// never again in that solve (the next solve rebuilds it from Iown), its (W, y) is written in part 2 of the same level and read on the way
+// back — one slot of 24 reals per body serves both (a_stride 24 instead of the packed 21), and the 24 nn reals of the separate (W, y)
+// region go away.  What else lived in that region moves into the stretch An | Aown | IA, which is idle outside the solves:
+//   forward pass      An: node terms (Ad) | Aown: local rotations (+ per-env body offsets) 12 nb, w2 6 nn (tmp later over the rotations) | ... | R, r
+//   constraints       An .. : the contact records (13 per slot, checked against l_R by ss_tables.h) | ... | R, r (the last 12 nb of the stretch)
+//   solves            An: accelerations / U rows | Aown = (W, y), 24 per body | IA: the level buffer (48 per node of the widest level)
+constexpr Layout make_layout(int nb, int maxlev, bool alias_w = false) {
   const int nn = nb + 1, nv = 6 + 3 * (nb - 1);
   Layout y{};
   int o = 0;
@@ -74,6 +83,24 @@ constexpr Layout make_layout(int nb, int maxlev) {
   y.l_Iown = take(10 * nb);                                // own spatial inertia of every body (10 parameters)
   y.l_An = take(8 * nn);                                   // node accelerations of the last solve; Ad (6 nb) aliases it
   // solver region Z
+  if (alias_w) {
+    y.a_stride = 24;
+    y.l_Aown = take(24 * nb);                              // I_b + K_b packed symmetric (21) in a slot of 24: the body's (W, y) rows overwrite it
+    y.ia_stride = 0;
+    const int gb = (6 * nb + 3) & ~3, t6 = (6 * nn + 3) & ~3;
+    y.l_IA = take(48 * maxlev);
+    y.l_Gb = y.l_IA;                                       // (subtree sums: diagnostics only — ss_debug_forward — never while the level buffer is live)
+    y.l_Rloc = y.l_Aown; y.l_tmp = y.l_Aown;               // local rotations (9 nb) + per-env body offsets (3 nb); tmp over them (a sync apart)
+    y.l_w2 = y.l_Aown + 12 * nb;
+    y.l_Ubuf = 24 * maxlev <= 8 * nn ? y.l_An : take(24 * maxlev);
+    y.l_Wst = y.l_Aown;
+    y.l_R = o - 12 * nb; y.l_r = y.l_R + 9 * nb;           // the end of the stretch: behind the contact records, over the level buffer
+    // (12 nb + 6 nn <= 24 nb and gb <= 48 maxlev hold for every tree ss_tables.h asks this layout for; it checks them)
+    (void)gb; (void)t6;
+    y.env_floats = o;
+    return y;
+  }
+  y.a_stride = 21;
   y.l_Aown = take(21 * nb);                                // per-body generalized inertia I_b + K_b, packed symmetric
   // ONE level buffer: a level's part 1 has consumed its children's rows before its part 2 writes the level's own (one wavefront per
   // env: its LDS operations retire in program order), so the rows handed towards the root overwrite the ones they were built from
@@ -86,8 +113,15 @@ constexpr Layout make_layout(int nb, int maxlev) {
   y.l_Ubuf = 24 * maxlev <= 8 * nn ? y.l_An : take(24 * maxlev);
   y.l_Wst = take(24 * nn);                                 // (W_r, y_r) per node row, kept for the downward sweep
   y.l_R = y.l_Wst; y.l_r = y.l_Wst + 9 * nb;               // R, r: forward kinematics .. constraints / observations
+  y.l_Rloc = y.l_IA; y.l_w2 = y.l_Wst + 12 * nb;           // local rotations of the kinematics in the level buffer; w2: the free part of (W, y) behind R, r
   y.env_floats = o;
   return y;
+}
+// can a tree use the aliased layout?  (the forward pass's scratch must fit the Aown region, the contact records must end before R)
+constexpr bool alias_layout_fits(int nb, int maxlev, int nslot) {
+  const int nn = nb + 1;
+  const Layout y = make_layout(nb, maxlev, true);
+  return ((6 * nb + 3) & ~3) <= 48 * maxlev && y.l_w2 + ((6 * nn + 3) & ~3) <= y.l_R && 13 * nslot <= y.l_R - y.l_An;
 }
 
 // Body-body contacts (SELFCOL instantiations, ss_env_cfg.self_collision): extra per-env LDS arrays behind the base layout and the
@@ -185,14 +219,15 @@ struct TreeFixed {
   static constexpr unsigned long long cpack = CP, chain = CH, neg = NG;
   int o_lev;
 };
-template <int NB, int MAXLEV>
+template <int NB, int MAXLEV, bool ALIAS = false>
 struct HdrFixed {
-  static constexpr Layout LY = make_layout(NB, MAXLEV);
+  static constexpr Layout LY = make_layout(NB, MAXLEV, ALIAS);
   static constexpr int nb = NB, nn = NB + 1, nv = 6 + 3 * (NB - 1), nq = 7 + 3 * (NB - 1), maxlev = MAXLEV;
   static constexpr int l_q = LY.l_q, l_v = LY.l_v, l_a = LY.l_a, l_tau = LY.l_tau, l_Fb = LY.l_Fb, l_Pb = LY.l_Pb, l_delta = LY.l_delta,
                        l_diag = LY.l_diag, l_S = LY.l_S, l_Ab = LY.l_Ab, l_An = LY.l_An, l_Aown = LY.l_Aown, l_IA = LY.l_IA,
                        l_Ubuf = LY.l_Ubuf, l_Wst = LY.l_Wst, l_R = LY.l_R, l_r = LY.l_r, l_Gb = LY.l_Gb, l_tmp = LY.l_tmp, l_V = LY.l_V,
-                       l_Iown = LY.l_Iown, ia_stride = LY.ia_stride, l_act = LY.l_act, env_floats = LY.env_floats;
+                       l_Iown = LY.l_Iown, ia_stride = LY.ia_stride, l_act = LY.l_act, env_floats = LY.env_floats,
+                       a_stride = LY.a_stride, l_Rloc = LY.l_Rloc, l_w2 = LY.l_w2;
   const int &nu, &ncand, &nlev, &nbox, &nslot;
   const int &o_dofc, &o_boff, &o_chainnode, &o_ndepth, &o_bparent, &o_sumsmall, &o_sumbig, &o_sumcover, &n_sumsmall, &n_sumbig,
       &shared_words;
@@ -207,15 +242,15 @@ struct HdrFixed {
         shared_words(h.shared_words), dt(h.dt), grav(h.grav), margin(h.margin), mu(h.mu), solimp(h.solimp), K(h.K), B(h.B),
         qpos0_root(h.qpos0_root) {}
 };
-template <int NB, int MAXLEV, int NLEV, int ROOT, int PEL, unsigned long long NK0, unsigned long long CP, unsigned long long CH, unsigned long long NG>
+template <int NB, int MAXLEV, int NLEV, int ROOT, int PEL, unsigned long long NK0, unsigned long long CP, unsigned long long CH, unsigned long long NG, bool ALIAS = false>
 struct HdrFixedT {
-  typedef const HdrFixed<NB, MAXLEV> type;
+  typedef const HdrFixed<NB, MAXLEV, ALIAS> type;
   static constexpr bool fixed = true;
-  static SS_HD HdrFixed<NB, MAXLEV> view(const Hdr &h) { return HdrFixed<NB, MAXLEV>(h); }
+  static SS_HD HdrFixed<NB, MAXLEV, ALIAS> view(const Hdr &h) { return HdrFixed<NB, MAXLEV, ALIAS>(h); }
   typedef const TreeFixed<NLEV, ROOT, PEL, NK0, CP, CH, NG> tree_type;
   static SS_HD TreeFixed<NLEV, ROOT, PEL, NK0, CP, CH, NG> tree(const HdrC &c) { TreeFixed<NLEV, ROOT, PEL, NK0, CP, CH, NG> t; t.o_lev = c.o_lev; return t; }
   static bool matches(const Hdr &h, const HdrC &c) {
-    return h.nb == NB && h.maxlev == MAXLEV && c.nlev == NLEV && c.root == ROOT && c.pel_level == PEL && c.nkpack[0] == NK0 && c.nkpack[1] == 0ull && c.cpack == CP && c.chain == CH && c.neg == NG;
+    return h.nb == NB && h.maxlev == MAXLEV && h.a_stride == (ALIAS ? 24 : 21) && h.env_floats == HdrFixed<NB, MAXLEV, ALIAS>::env_floats && c.nlev == NLEV && c.root == ROOT && c.pel_level == PEL && c.nkpack[0] == NK0 && c.nkpack[1] == 0ull && c.cpack == CP && c.chain == CH && c.neg == NG;
   }
 };
 
@@ -224,7 +259,8 @@ struct HdrFixedT {
 // (body count, widest level | elimination tree: levels, root body, level of body 0, packed level widths - 1, packed most-children per level,
 //  mask of the 1:1 levels, mask of the levels with a negated motion subspace)
 typedef HdrFixedT<24, 5, 6, 10, 2, 0x333431ull, 0x1253ull, 0x1cull, 0x3ull> HdrSmplFixed;       // SMPL: 24 bodies; rooted at the Spine: levels of 2 4 5 4 4 4 nodes
-typedef HdrFixedT<52, 12, 7, 11, 3, 0xbbb3233ull, 0x9a89ull, 0x33ull, 0x7ull> HdrSmplxFixed;    // SMPL-X/H: 52 bodies; rooted at the Chest: levels of 4 4 3 4 12 12 12 nodes
+typedef HdrFixedT<52, 12, 7, 11, 3, 0xbbb3233ull, 0x9a89ull, 0x33ull, 0x7ull, true> HdrSmplxFixed;    // SMPL-X/H: 52 bodies; rooted at the Chest: levels of 4 4 3 4 12 12 12 nodes; aliased (W, y)
+typedef HdrFixedT<52, 12, 7, 11, 3, 0xbbb3233ull, 0x9a89ull, 0x33ull, 0x7ull, false> HdrSmplxFixedSC;  // the same tree on the plain layout: body-body-contact batches (their dense system lives in Aown .. (W, y))
 
 // compiled kernel variants: 0 = SMPL-sized (<= 128 dofs / candidates, <= 64 contact slots, <= 8 nodes per tree level),
 // 1 = SMPL-X/H-sized (<= 192 dofs / candidates, <= 128 slots, <= 16 nodes per level); -1 = none fits

@@ -141,7 +141,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
   const uint32_t *T;      // shared tables in LDS (integer tables, then the real-valued ones)
   int lane, env;
   // per-env LDS arrays
-  real *S, *R, *r, *V, *Ab, *An, *Ad, *Gb, *tmpb, *Aown, *IA, *Ubuf, *Wst, *q, *v, *a, *tau, *Pb, *delta, *Fb, *actl, *diag, *Iown;
+  real *S, *R, *r, *V, *Ab, *An, *Ad, *Gb, *tmpb, *Aown, *IA, *Ubuf, *Wst, *Rlocp, *w2p, *q, *v, *a, *tau, *Pb, *delta, *Fb, *actl, *diag, *Iown;
   // per-lane constants
   int bpar, bdep;
   // per-lane state
@@ -187,6 +187,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
     }
     S = L + h.l_S; R = L + h.l_R; r = L + h.l_r; V = L + h.l_V; Ab = L + h.l_Ab; An = L + h.l_An; Ad = An;
     Gb = L + h.l_Gb; tmpb = L + h.l_tmp; Aown = L + h.l_Aown; IA = L + h.l_IA; Ubuf = L + h.l_Ubuf; Wst = L + h.l_Wst;
+    Rlocp = L + h.l_Rloc; w2p = L + h.l_w2;
     q = L + h.l_q; v = L + h.l_v; a = L + h.l_a; tau = L + h.l_tau; Pb = L + h.l_Pb;
     delta = L + h.l_delta; Fb = L + h.l_Fb; actl = L + h.l_act; diag = L + h.l_diag; Iown = L + h.l_Iown;
     bpar = -1; bdep = -1;
@@ -362,7 +363,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
     // The local rotations go through LDS (level-buffer region, free here) and every body walks its own chain of
     // ancestors from the root: redundant arithmetic across lanes is free, a level-by-level sweep costs one LDS
     // hand-off per tree level on every pass.
-    real *Rloc = IA;
+    real *Rloc = Rlocp;                                      // (the level buffer; the aliased layout: the head of the idle Aown region)
     if (lane >= 1 && lane < h.nb) {
 #pragma unroll
       for (int i = 0; i < 9; i++) Rloc[9 * lane + i] = Rl[i];
@@ -421,7 +422,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       if (with_dyn) {                                          // this node's terms of the body velocities S_n qd_n and of the
         const real q0 = v[3 * n], q1 = v[3 * n + 1], q2 = v[3 * n + 2];      // body accelerations of the warm start S_n a_n
         const real g0 = a[3 * n], g1 = a[3 * n + 1], g2 = a[3 * n + 2];
-        real *w2 = Wst + 12 * h.nb;                           // free part of the (W, y) region behind R, r
+        real *w2 = w2p;                                       // free part of the (W, y) region behind R, r (aliased layout: behind the local rotations)
 #pragma unroll
         for (int c = 0; c < 6; c++) {
           Ad[6 * n + c] = sd[0][c] * q0 + sd[1][c] * q1 + sd[2][c] * q2;
@@ -435,7 +436,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       Ad[7] = Rb[3] * wl0 + Rb[4] * wl1 + Rb[5] * wl2;
       Ad[8] = Rb[6] * wl0 + Rb[7] * wl1 + Rb[8] * wl2;
       Ad[9] = Ad[10] = Ad[11] = 0.f;
-      real *w2 = Wst + 12 * h.nb;
+      real *w2 = w2p;
       const real g0 = a[3], g1 = a[4], g2 = a[5];
       w2[0] = w2[1] = w2[2] = 0.f; w2[3] = a[0]; w2[4] = a[1]; w2[5] = a[2];
       w2[6] = Rb[0] * g0 + Rb[1] * g1 + Rb[2] * g2;
@@ -448,7 +449,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
     if (!with_dyn) return;
     // ---- body velocities V_b = chain sums of the node terms written above, then the velocity-product accelerations:
     // node terms + chain sums again
-    chain_sum(Ad, V, Wst + 12 * h.nb, Ab);                   // Ab: body accelerations of the iterate newton_begin starts from
+    chain_sum(Ad, V, w2p, Ab);                   // Ab: body accelerations of the iterate newton_begin starts from
     w->sync();
     SS_FTICK(PF_K_CHAIN);
     if (lane < h.nn) {
@@ -980,7 +981,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
 
   SS_DEV void write_own_inertia() {                          // Aown[b] = expand(Ib), packed upper triangle (ang;lin)
     if (lane < hdr().nb) {
-      real *o = Aown + 21 * lane;
+      real *o = Aown + hdr().a_stride * lane;
       const real *Ib = Iown + 10 * lane;
       const real m = Ib[0], cx = Ib[1], cy = Ib[2], cz = Ib[3];
       o[0] = Ib[4]; o[1] = Ib[5]; o[2] = Ib[6]; o[3] = 0.f; o[4] = -cz; o[5] = cy;
@@ -1058,7 +1059,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
           real rw[6], pv = pb[6 * b + r_];
           if (!HT::fixed || L == hc.pel_level)               // (a constant of the unrolled level: the test is compiled into body 0's level only)
             if ((e0 >> 25) & 1) pv -= fb_force();
-          const real *ao = Aown + 21 * b;
+          const real *ao = Aown + h.a_stride * b;
 #pragma unroll
           for (int c = 0; c < 6; c++) rw[c] = ao[off[c]];
           real sv[18];                                       // S_j: issued before the child loop, consumed after it
@@ -1170,7 +1171,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       if (lane < 6) {
         pv = pb[6 * c_ + lane];
         if (c_ == 0) pv -= fb_force();
-        const real *ao = Aown + 21 * c_;
+        const real *ao = Aown + h.a_stride * c_;
 #pragma unroll
         for (int c = 0; c < 6; c++) rw[c] = ao[off[c]];
         for (int j = 0; j < cc; j++) {
@@ -1755,7 +1756,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
         const real *I = Iown + 10 * b;
         real Ia[6];
         imul(I, Ab + 6 * b, Ia);
-        real *g = Pb + 6 * b, *o = Aown + 21 * b;
+        real *g = Pb + 6 * b, *o = Aown + h.a_stride * b;
 #pragma unroll
         for (int t = 0; t < 6; t++) g[t] = Ia[t] + vals[t] + Fb[6 * b + t];
         const real m = I[0], cx = I[1], cy = I[2], cz = I[3];

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -21,6 +22,7 @@ namespace ss {
 
 struct HostModel {
   Hdr h{};
+  Hdr h_sc{};                     // the same header on the plain (non-aliased) LDS layout: what body-body-contact batches run on (= h when h is not aliased)
   std::vector<uint32_t> shared;   // tables copied into LDS once per workgroup: integer tables, then the real-valued ones
   std::vector<real> bodyc;        // [nb][kBodyC]: off3 ipos3 mass Ibody6 invw_tr  (loaded into registers)
   std::vector<real> candc;        // [ncand][kCandC]
@@ -356,13 +358,22 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   // ---- per-env LDS layout (floats); arrays with disjoint lifetimes share storage (LDS capacity sets the number
   // of resident envs per CU)
   if (nn > 64) { out.error = "too many nodes"; return false; }
+  // The SMPL-X size class (more than 32 bodies: LDS, not the register file, caps its resident envs) gets the aliased layout when its
+  // records fit (ss_hdr.h make_layout); body-body-contact batches of such a model run on the plain one (h_sc), whose Aown .. (W, y)
+  // stretch holds their dense system.
+  auto fill = [&](Hdr &g, const Layout &y) {
+    g.l_q = y.l_q; g.l_v = y.l_v; g.l_a = y.l_a; g.l_tau = y.l_tau; g.l_Fb = y.l_Fb; g.l_act = y.l_act; g.l_delta = y.l_delta; g.l_Pb = y.l_Pb; g.l_V = y.l_V;
+    g.l_diag = y.l_diag; g.l_S = y.l_S; g.l_Ab = y.l_Ab; g.l_Iown = y.l_Iown; g.l_An = y.l_An; g.l_Aown = y.l_Aown; g.ia_stride = y.ia_stride;
+    g.l_IA = y.l_IA; g.l_Gb = y.l_Gb; g.l_tmp = y.l_tmp; g.l_Ubuf = y.l_Ubuf; g.l_Wst = y.l_Wst; g.l_R = y.l_R; g.l_r = y.l_r;
+    g.a_stride = y.a_stride; g.l_Rloc = y.l_Rloc; g.l_w2 = y.l_w2; g.reserved1 = 0ull;
+    g.env_floats = y.env_floats;
+  };
+  const bool alias = nb > 32 && alias_layout_fits(nb, maxlev, h.nslot) && !std::getenv("SS_NO_ALIAS_LAYOUT");
   {
-    const Layout y = make_layout(nb, maxlev);
-    h.l_q = y.l_q; h.l_v = y.l_v; h.l_a = y.l_a; h.l_tau = y.l_tau; h.l_Fb = y.l_Fb; h.l_act = y.l_act; h.l_delta = y.l_delta; h.l_Pb = y.l_Pb; h.l_V = y.l_V;
-    h.l_diag = y.l_diag; h.l_S = y.l_S; h.l_Ab = y.l_Ab; h.l_Iown = y.l_Iown; h.l_An = y.l_An; h.l_Aown = y.l_Aown; h.ia_stride = y.ia_stride;
-    h.l_IA = y.l_IA; h.l_Gb = y.l_Gb; h.l_tmp = y.l_tmp; h.l_Ubuf = y.l_Ubuf; h.l_Wst = y.l_Wst; h.l_R = y.l_R; h.l_r = y.l_r;
-    h.env_floats = y.env_floats;
+    const Layout y = make_layout(nb, maxlev, false);
+    fill(h, y);
     if (13 * h.nslot > h.l_Wst - h.l_An) { out.error = "contact record buffer does not fit"; return false; }
+    if (alias) fill(h, make_layout(nb, maxlev, true));
   }
 
   // ---- body-body collision: candidate pairs (mj_collision's static filters: contype / conaffinity masks, parent-child
@@ -401,7 +412,10 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
     for (int k = 0; k < 9; k++) c[6 + k] = (real)G[k];
     c[15] = (real)d.geom_type[b];
   }
-  out.sc = make_layout_sc(nb, h.env_floats, h.l_Aown);
+  {
+    const Layout yp = make_layout(nb, maxlev, false);
+    out.sc = make_layout_sc(nb, yp.env_floats, yp.l_Aown);
+  }
   out.sc.npair = (int)out.pairs.size() / 2;
   // per body of the elimination tree (SELFCOL kernels copy this into the env's LDS slice): neighbour towards the root (255: it is the
   // root) | joint node << 8 | (S negated) << 16, and the mask of the bodies on its way to the root (itself included, the root not)
@@ -434,6 +448,8 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   h.B = (real)(2.0 / (dmax * tc));
   for (int k = 0; k < 3; k++) h.qpos0_root[k] = (real)d.qpos0[k];
   if (d.impratio != 1.0) { out.error = "impratio != 1 is not supported"; return false; }
+  out.h_sc = h;
+  fill(out.h_sc, make_layout(nb, maxlev, false));
   return true;
 }
 

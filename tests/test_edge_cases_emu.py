@@ -291,6 +291,42 @@ def test_fixed_layout_instantiation_is_bit_identical_to_the_generic_one(humanoid
     assert outs[0][4].max() > 15                            # contacts were active (one Newton iteration per mj_step otherwise)
 
 
+@pytest.mark.parametrize("generic", [False, True])
+def test_aliased_lds_layout_is_bit_identical_to_the_plain_one(generic, monkeypatch):
+    """Round 5: the SMPL-X size class keeps a body's (W, y) rows in the slot of its generalized inertia and moves the forward pass's
+    scratch, the contact records and R, r into the idle An | Aown | IA stretch (ss_hdr.h make_layout(alias_w): 6 resident envs per CU
+    instead of 5).  Same arithmetic, other addresses: the results must be the plain layout's (SS_NO_ALIAS_LAYOUT, read when the model is
+    built) bit for bit — fixed-layout and generic instantiation, through contact-rich steps, a reset and the velocity sensors (obs v2)."""
+    import ctypes as C
+    from helpers import FEET, model_const, pd_tables
+    mc = model_const("smplx_humanoid")
+    rs = np.random.default_rng(11)
+    acts = rs.uniform(-1, 1, (4, 3, mc.nu))
+    if generic:
+        monkeypatch.setenv("SS_EMU_GENERIC", "1")
+    outs, per_wg = [], []
+    for plain in (False, True):
+        if plain:
+            monkeypatch.setenv("SS_NO_ALIAS_LAYOUT", "1")
+        eb = emu.EmuBatch(mc, pd_tables(mc), 3, legal_bodies=FEET, task=1, self_obs_v=2)
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        eb.L.ss_launch_info(eb.batch, C.byref(a), C.byref(b), C.byref(c)); per_wg.append(a.value)
+        eb.reset(task_rand=np.full((3, 4), 0.5))
+        q = eb.qpos.copy(); q[:, 2] = 0.45                    # dropped onto the floor: contacts, limits, many Newton iterations
+        eb.set_state(q, eb.qvel.copy())
+        rec = []
+        for t, act in enumerate(acts):
+            obs, rew, term, trunc = eb.step(act, np.full((3, 4), 0.25))
+            rec += [eb.qpos.copy(), eb.qvel.copy(), obs.copy(), rew.copy(), eb.solver_iters.copy(), eb.body_vel.copy()]
+            if t == 1:
+                rec.append(eb.reset(mask=np.array([1, 0, 0], np.uint8), task_rand=np.full((3, 4), 0.3)))
+        outs.append(rec)
+    assert per_wg == [6, 5]                                   # what the layout is for
+    for x, y in zip(*outs):
+        assert np.array_equal(x, y)
+    assert max(r.max() for r in outs[0][4::6] if r.dtype == np.int32) > 15
+
+
 @pytest.mark.parametrize("f64,tol", [(True, 1e-9), (False, 2e-4)])
 def test_power_usage_output_matches_the_reference_definition(f64, tol):
     """HumanoidEnv.curr_power_usage (reference humanoid_env.py:443-451): per mj_step |qfrc_actuator[6:] * qvel[6:]| with the torque

@@ -29,7 +29,7 @@ a1 = AgentPPO(SMPLSimVecEnv(N, **kw), cfg, seed=0)
 (r, b1) = run(a1, a1.sample)
 res["serial"] = {"env_steps_per_s": round(r[0]), "host_issue_ms_per_step": round(r[1], 3), "ms_per_step": round(r[2], 3)}
 a1.env.close()
-for G in [int(x) for x in os.environ.get("GS", "2,4,8").split(",")]:
+for G in [int(x) for x in os.environ.get("GS", "2,4,8").split(",") if int(x) > 1]:
     pipe = PipelinedVecEnv(N, sub_batches=G, **kw)
     a2 = AgentPPO(pipe, cfg, seed=0)
     (r, b2) = run(a2, lambda: a2.sample_pipelined(pipe))
