@@ -141,6 +141,8 @@ struct om_model {
   /* constraint solver settings (om_model_set_solver): mjModel.stat.meaninertia, mjOption.tolerance / iterations */
   double meaninertia, tolerance;
   int solver_mode, iterations;
+  int ls_mode, ls_iterations;                  /* om_model_set_linesearch: OM_LS_EXACT | OM_LS_MUJOCO (mjOption.ls_tolerance / ls_iterations) */
+  double ls_tolerance;
 };
 
 struct om_data {
@@ -158,6 +160,7 @@ struct om_data {
   double *J, *epos, *emargin, *ediag, *eD, *eR, *earef, *eforce, *ejar, *ejd;
   double *H, *work, *work2;                    /* nv x nv each */
   int solver_iter, nwarn;
+  long ls_evals, ls_calls, ls_exhausted;         /* line-search statistics since creation (OM_D_LS_STATS) */
   double qpos_fwd[OM_MAXV + 1], qvel_fwd[OM_MAXV];   /* the state of the last om_forward: what the (stale) M and bias belong to */
   /* SimplePID state (reference controllers.py:193-262): per actuator integral and last error; pid_dt = the dt the env
    * hands the controller (timestep * control_freq_inv, humanoid_env.py:319) */
@@ -314,6 +317,7 @@ om_model *om_model_create(const om_desc *ds) {
   for (int i = 0; i < nv; i++) m->meaninertia += d->M[i * nv + i];
   m->meaninertia /= nv > 1 ? nv : 1;
   m->solver_mode = OM_SOLVER_MUJOCO; m->tolerance = 1e-8; m->iterations = 100;
+  m->ls_mode = OM_LS_EXACT; m->ls_tolerance = 0.01; m->ls_iterations = 50;
   for (int g = 0; g < 2; g++) {
     double a = (m->dof_invw[3 * g] + m->dof_invw[3 * g + 1] + m->dof_invw[3 * g + 2]) / 3;
     m->dof_invw[3 * g] = m->dof_invw[3 * g + 1] = m->dof_invw[3 * g + 2] = a;
@@ -322,6 +326,11 @@ om_model *om_model_create(const om_desc *ds) {
   return m;
 }
 void om_model_destroy(om_model *m) { free(m); }
+void om_model_set_linesearch(om_model *m, int mode, double ls_tolerance, int ls_iterations) {
+  m->ls_mode = mode;
+  if (ls_tolerance > 0) m->ls_tolerance = ls_tolerance;
+  if (ls_iterations > 0) m->ls_iterations = ls_iterations;
+}
 void om_model_set_solver(om_model *m, int mode, double tolerance, int iterations) {
   m->solver_mode = mode;
   if (tolerance > 0) m->tolerance = tolerance;
@@ -947,6 +956,73 @@ static double eval_cost(const om_model *m, om_data *d, const double *a, double *
   return cost;
 }
 
+/* ---- MuJoCo's line search (OM_LS_MUJOCO): a restatement of PrimalSearch of MuJoCo's engine_solver.c (the Newton / CG solvers' 1-D
+ * search; reached from the reference through mujoco.mj_step, humanoid_env.py:450; MuJoCo 3.x; "parity unpinned" like the rest of
+ * mj_step: MJ-(V9b) of oracle.h).  phi(alpha) = cost(a + alpha dir) is convex and piecewise quadratic; a point carries alpha, cost and
+ * the first two derivatives.
+ *   gtol = tolerance * ls_tolerance * |dir| / scale           (scale = 1 / (meaninertia max(1, nv)): the solver's own scaling)
+ *   p0 = phi at 0;  p1 = phi at the Newton point of p0;  p1 = p0 if that raised the cost;  done if |p1'| < gtol
+ *   phase 1 (one-sided): while the slope keeps its sign (p1' dir <= -gtol): p2 = p1, p1 = Newton point of p1; done if |p1'| < gtol
+ *   phase 2 (bracket p1 | p2, slopes of opposite sign): candidates = the Newton points of both ends and the midpoint; any candidate with
+ *            |slope| < gtol ends the search; otherwise each end moves to the candidate with the slope of its own sign that is closest
+ *            to zero; no end moved -> the midpoint is returned
+ *   every evaluation counts against ls_iterations (50); when they run out: the lower end of the bracket if it improves on p0, else 0.
+ * alpha = 0 ends the solver's iteration ("no improvement").  An inexact search: the Newton iterates differ from the exact search's by
+ * up to gtol in the slope — 1e-10 |dir| meaninertia nv — which is why the two searches give the same solver output to ~1e-9
+ * (DESIGN.md 4d has the measured table). */
+typedef struct { double alpha, cost, d1, d2; } ls_pnt;
+typedef struct { const om_data *d; int ne; double q1, q2; int evals; } ls_ctx;
+static void ls_point(ls_ctx *c, double al, ls_pnt *p) {
+  const om_data *d = c->d;
+  double cost = al * c->q1 + 0.5 * al * al * c->q2, d1 = c->q1 + al * c->q2, d2 = c->q2;
+  for (int r = 0; r < c->ne; r++) {
+    const double x = d->ejar[r] + al * d->ejd[r];
+    if (x < 0) { cost += 0.5 * d->eD[r] * x * x; d1 += d->eD[r] * x * d->ejd[r]; d2 += d->eD[r] * d->ejd[r] * d->ejd[r]; }
+  }
+  p->alpha = al; p->cost = cost; p->d1 = d1; p->d2 = d2; c->evals++;
+}
+static int ls_update_bracket(ls_ctx *c, ls_pnt *p, const ls_pnt cand[3], ls_pnt *pnext) {
+  int flag = 0;
+  for (int i = 0; i < 3; i++) {
+    if (p->d1 < 0 && cand[i].d1 < 0 && p->d1 < cand[i].d1) { *p = cand[i]; flag = 1; }
+    else if (p->d1 > 0 && cand[i].d1 > 0 && p->d1 > cand[i].d1) { *p = cand[i]; flag = 2; }
+  }
+  if (flag) ls_point(c, p->alpha - p->d1 / p->d2, pnext);
+  return flag;
+}
+static double mujoco_linesearch(ls_ctx *c, double snorm, double gtol, int ls_iterations, int *exhausted) {
+  ls_pnt p0, p1, p2, pmid, p1next, p2next;
+  *exhausted = 0;
+  if (snorm < 1e-15) return 0;                               /* mjMINVAL: search vector too small */
+  ls_point(c, 0, &p0);
+  ls_point(c, p0.alpha - p0.d1 / p0.d2, &p1);
+  if (p0.cost < p1.cost) p1 = p0;
+  if (fabs(p1.d1) < gtol) return p1.alpha;
+  const int dir = p1.d1 < 0 ? 1 : -1;
+  int p2update = 0;
+  p2 = p1;
+  while (p1.d1 * dir <= -gtol && c->evals < ls_iterations) {
+    p2 = p1; p2update = 1;
+    ls_point(c, p1.alpha - p1.d1 / p1.d2, &p1);
+    if (fabs(p1.d1) < gtol) return p1.alpha;
+  }
+  if (c->evals >= ls_iterations) { *exhausted = 1; return p1.alpha; }
+  if (!p2update) return p1.alpha;
+  p2next = p1;
+  ls_point(c, p1.alpha - p1.d1 / p1.d2, &p1next);
+  while (c->evals < ls_iterations) {
+    ls_point(c, 0.5 * (p1.alpha + p2.alpha), &pmid);
+    const ls_pnt cand[3] = {p1next, p2next, pmid};
+    for (int i = 0; i < 3; i++) if (fabs(cand[i].d1) < gtol) return cand[i].alpha;
+    const int b1 = ls_update_bracket(c, &p1, cand, &p1next), b2 = ls_update_bracket(c, &p2, cand, &p2next);
+    if (!b1 && !b2) return pmid.alpha;
+  }
+  *exhausted = 1;
+  if (p1.cost <= p2.cost && p1.cost < p0.cost) return p1.alpha;
+  if (p2.cost <= p1.cost && p2.cost < p0.cost) return p2.alpha;
+  return 0;
+}
+
 static void solve_constraints(const om_model *m, om_data *d) {
   int nv = m->nv, ne = d->nefc;
   double a[OM_MAXV], grad[OM_MAXV], dir[OM_MAXV], Ma[OM_MAXV];
@@ -1033,6 +1109,20 @@ static void solve_constraints(const om_model *m, om_data *d) {
     DPHI(0.0, dlo, d2);
     if (dlo >= 0) break;                                    /* not a descent direction: converged (MuJoCo: alpha = 0) */
     d->solver_iter = it + 1;
+    if (m->ls_mode == OM_LS_MUJOCO) {
+      ls_ctx lc = {d, ne, q1, q2, 0};
+      double sn = 0;
+      for (int i = 0; i < nv; i++) sn += dir[i] * dir[i];
+      int exhausted = 0;
+      const double al_mj = mujoco_linesearch(&lc, sqrt(sn), m->tolerance * m->ls_tolerance * sqrt(sn) / scale, m->ls_iterations, &exhausted);
+      d->ls_evals += lc.evals; d->ls_calls++; d->ls_exhausted += exhausted;
+      if (al_mj == 0) { d->solver_iter = it; break; }       /* "no improvement": mj_solPrimal leaves its loop */
+      for (int i = 0; i < nv; i++) a[i] += al_mj * dir[i];
+      const double newcost = eval_cost(m, d, a, d->ejar);
+      improvement = scale * (cost - newcost);
+      cost = newcost;
+      continue;
+    }
     DPHI(hi, d1, d2);
     int guard = 0;
     while (d1 < 0 && guard++ < 60) { lo = hi; hi *= 2; DPHI(hi, d1, d2); }
@@ -1421,6 +1511,7 @@ int om_get(const om_model *m, const om_data *d, int f, double *out) {
     case OM_D_NEFC: out[0] = d->nefc; return 1;
     case OM_D_EFC_FORCE: memcpy(out, d->eforce, sizeof(double) * d->nefc); return d->nefc;
     case OM_D_SOLVER_ITER: out[0] = d->solver_iter; out[1] = d->nwarn; return 2;
+    case OM_D_LS_STATS: out[0] = (double)d->ls_evals; out[1] = (double)d->ls_calls; out[2] = (double)d->ls_exhausted; return 3;
     case OM_D_QPOS_FWD: memcpy(out, d->qpos_fwd, sizeof(double) * m->nq); return m->nq;
     case OM_D_QVEL_FWD: memcpy(out, d->qvel_fwd, sizeof(double) * nv); return nv;
     case OM_D_ENERGY: {

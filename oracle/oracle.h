@@ -25,6 +25,9 @@
  *         functions"): this is the item most likely to need a change                              test_pair_functions_against_mujoco
  *   (V8)  constraint rows: impedance, aref, R = diagApprox (1 + mu^2), Rpy = 2 mu^2 R, limit rows test_stage_constraint_rows
  *   (V9)  the solve: qacc, efc_force, qfrc_constraint (Newton, mj_solPrimal's termination)        test_stage_solve
+ *   (V9b) the solve's line search: solver_niter of the V9 states and of the benchmark rollout with OM_LS_MUJOCO
+ *         (PrimalSearch restated: bracketing + 1-D Newton, ls_tolerance 0.01, ls_iterations 50) against the
+ *         exact search the kernel and the default oracle use                                      test_stage_solve_iterations
  *   (V10) one mj_step; one control step of the reference loop (15 x Stable PD + mj_step)          test_stage_step_and_control_step
  *   (V11) the benchmark workload's statistics: bad-state autoreset rate, Newton iterations per
  *         control step (does MuJoCo diverge as often as the oracle and the kernel do?)            test_rollout_statistics_of_the_benchmark_workload
@@ -84,6 +87,13 @@ int om_model_get(const om_model *m, int field, double *out);
  * OM_SOLVER_CONVERGED: iterate until the gradient is at the rounding level of the forces (the parity triage's reference). */
 enum { OM_SOLVER_CONVERGED = 0, OM_SOLVER_MUJOCO = 1 };
 void om_model_set_solver(om_model *m, int mode, double tolerance, int iterations);
+/* The Newton iteration's 1-D search.  OM_LS_EXACT (the default, and what the HIP kernel does): the minimiser of the convex piecewise-
+ * quadratic cost along the Newton direction, to rounding.  OM_LS_MUJOCO: mj_solPrimal's PrimalSearch — bracketing + 1-D Newton steps,
+ * stopped at |slope| < tolerance * ls_tolerance * |direction| / scale or after ls_iterations evaluations (MuJoCo's defaults 0.01 / 50;
+ * arguments <= 0 keep the current values).  The converged solution is the same; iterates, iteration counts and the point at which
+ * `improvement < tolerance` fires can differ: MJ-(V9b). */
+enum { OM_LS_EXACT = 0, OM_LS_MUJOCO = 1 };
+void om_model_set_linesearch(om_model *m, int mode, double ls_tolerance, int ls_iterations);
 
 om_data *om_data_create(const om_model *m);
 void om_data_destroy(om_data *d);
@@ -92,7 +102,8 @@ enum { OM_D_QPOS = 0, OM_D_QVEL, OM_D_QACC, OM_D_WARM, OM_D_CTRL, OM_D_M, OM_D_B
        OM_D_QACC_SMOOTH, OM_D_NEFC, OM_D_EFC_FORCE, OM_D_SOLVER_ITER, OM_D_ENERGY, OM_D_XIPOS,
        OM_D_QFRC_CONSTRAINT, OM_D_CON_FRAME, OM_D_CON_BODY1 /* first body of every contact, -1 = floor */,
        OM_D_NSELF /* [contacts between two bodies, candidate pairs of the model, contacts dropped by max_self_contacts] */,
-       OM_D_QPOS_FWD, OM_D_QVEL_FWD /* the state of the last om_forward: the M and bias the Stable-PD controller reads belong to it */ };
+       OM_D_QPOS_FWD, OM_D_QVEL_FWD /* the state of the last om_forward: the M and bias the Stable-PD controller reads belong to it */,
+       OM_D_LS_STATS /* [line-search evaluations, line searches, searches that ran out of ls_iterations] since creation (OM_LS_MUJOCO) */ };
 int om_get(const om_model *m, const om_data *d, int field, double *out);
 int om_set(const om_model *m, om_data *d, int field, const double *in);
 

@@ -23,7 +23,7 @@ M_MASS, M_IPOS, M_IQUAT, M_INERTIA, M_GPOS, M_GQUAT, M_GSIZE, M_BODY_INVW, M_DOF
 SOLVER_CONVERGED, SOLVER_MUJOCO = 0, 1
 (D_QPOS, D_QVEL, D_QACC, D_WARM, D_CTRL, D_M, D_BIAS, D_XPOS, D_XQUAT, D_LINVEL, D_ANGVEL, D_TOUCH, D_NCON,
  D_CON_POS, D_CON_DIST, D_CON_BODY, D_QACC_SMOOTH, D_NEFC, D_EFC_FORCE, D_SOLVER_ITER, D_ENERGY, D_XIPOS,
- D_QFRC_CONSTRAINT, D_CON_FRAME, D_CON_BODY1, D_NSELF, D_QPOS_FWD, D_QVEL_FWD) = range(28)
+ D_QFRC_CONSTRAINT, D_CON_FRAME, D_CON_BODY1, D_NSELF, D_QPOS_FWD, D_QVEL_FWD, D_LS_STATS) = range(29)
 
 
 class _Desc(C.Structure):
@@ -96,6 +96,8 @@ def lib():
         L.om_model_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.om_model_set_solver.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int]
         L.om_model_set_solver.restype = None
+        L.om_model_set_linesearch.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int]
+        L.om_model_set_linesearch.restype = None
         L.om_get.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.om_set.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.om_spd_torque.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -173,11 +175,13 @@ def read_mjcf_primitives(xml):
 
 class OracleModel:
     def __init__(self, xml, kp, kd, torque_lim, act_scale, act_offset, legal_bodies=(), timestep=1.0 / 450, self_collision=False,
-                 max_self_contacts=0, solver="mujoco", tolerance=0.0, iterations=0):
+                 max_self_contacts=0, solver="mujoco", tolerance=0.0, iterations=0, linesearch="exact", ls_tolerance=0.0, ls_iterations=0):
         """self_collision: body-body contacts per the MJCF's contype / conaffinity / excludes (False = floor only);
         max_self_contacts: keep only the deepest N of them (0 = all);
         solver: "mujoco" = mj_step's own termination of the Newton iteration (opt.tolerance 1e-8 scaled by meaninertia * nv,
-        opt.iterations 100; `tolerance` / `iterations` override), "converged" = to the rounding level (parity triage)."""
+        opt.iterations 100; `tolerance` / `iterations` override), "converged" = to the rounding level (parity triage);
+        linesearch: "exact" (the kernel's, the default) or "mujoco" = mj_solPrimal's PrimalSearch restated (bracketing + 1-D Newton,
+        opt.ls_tolerance 0.01, opt.ls_iterations 50; oracle.h MJ-(V9b))."""
         P = read_mjcf_primitives(xml)
         self.prim = P
         self.nbody = len(P["names"])
@@ -212,6 +216,7 @@ class OracleModel:
         if not self.h:
             raise RuntimeError("om_model_create failed")
         lib().om_model_set_solver(self.h, {"mujoco": SOLVER_MUJOCO, "converged": SOLVER_CONVERGED}[solver], float(tolerance), int(iterations))
+        lib().om_model_set_linesearch(self.h, {"exact": 0, "mujoco": 1}[linesearch], float(ls_tolerance), int(ls_iterations))
 
     def get(self, field):
         out = np.zeros(16 * 64 + 8 * 200, dtype=np.float64)
@@ -270,7 +275,9 @@ class OracleData:
     con_frame = property(lambda s: s.get(D_CON_FRAME).reshape(-1, 3, 3))
     nself = property(lambda s: int(s.get(D_NSELF)[0]))                      # contacts between two bodies
     solver_iter = property(lambda s: int(s.get(D_SOLVER_ITER)[0]))
-    nwarn = property(lambda s: int(s.get(D_SOLVER_ITER)[1]))     # mj_checkPos/Vel/Acc autoresets so far
+    nwarn = property(lambda s: int(s.get(D_SOLVER_ITER)[1]))
+    ls_stats = property(lambda s: s.get(D_LS_STATS).astype(np.int64))   # [evaluations, searches, searches out of ls_iterations] (linesearch='mujoco')
+     # mj_checkPos/Vel/Acc autoresets so far
 
     def kinematics(self):
         lib().om_kinematics(self.m.h, self.h)

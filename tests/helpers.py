@@ -25,13 +25,13 @@ def pd_tables(mc, **kw):
 
 @functools.lru_cache(maxsize=None)
 def oracle_model(name="smpl_humanoid", timestep=1.0 / 450, control_mode="uhc_pd", self_collision=False, max_self_contacts=0,
-                 solver="mujoco"):
+                 solver="mujoco", linesearch="exact"):
     """solver: "mujoco" = mj_step's termination of the Newton iteration (tolerance 1e-8, 100 iterations: what the product is
     compared with), "converged" = to rounding level (the formulation leg of the parity triage)."""
     mc = model_const(name)
     kp, kd, tl, sc, of = pd_tables(mc, control_mode=control_mode)
     return O.OracleModel(default_xml_str(name), kp, kd, tl, sc, of, legal_bodies=FEET, timestep=timestep,
-                         self_collision=self_collision, max_self_contacts=max_self_contacts, solver=solver)
+                         self_collision=self_collision, max_self_contacts=max_self_contacts, solver=solver, linesearch=linesearch)
 
 
 def golden():

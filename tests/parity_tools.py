@@ -78,11 +78,14 @@ def emu_step(pre, actions, f64, newton_iters=0, humanoid="smpl_humanoid", task="
     return out
 
 
-def oracle_step(pre, actions, humanoid="smpl_humanoid", self_collision=False, solver="mujoco"):
-    """The same control step by the float64 oracle (base task: state only), threaded."""
-    om = oracle_model(humanoid, self_collision=bool(self_collision), max_self_contacts=MAX_SELF if self_collision else 0, solver=solver)
+def oracle_step(pre, actions, humanoid="smpl_humanoid", self_collision=False, solver="mujoco", linesearch="exact"):
+    """The same control step by the float64 oracle (base task: state only), threaded.  Also returns the Newton iterations of the
+    control step (sum over its 15 mj_steps) and, with linesearch="mujoco", the line search's statistics per sample."""
+    om = oracle_model(humanoid, self_collision=bool(self_collision), max_self_contacts=MAX_SELF if self_collision else 0, solver=solver,
+                      linesearch=linesearch)
     n = len(actions)
     q, v, nw = np.zeros((n, om.nq)), np.zeros((n, om.nv)), np.zeros(n, np.int32)
+    its, lss = np.zeros(n, np.int64), np.zeros((n, 3), np.int64)
 
     def run(lo_hi):
         for i in range(*lo_hi):
@@ -90,12 +93,12 @@ def oracle_step(pre, actions, humanoid="smpl_humanoid", self_collision=False, so
             d.qpos = pre["qpos_prev"][i]; d.qvel = pre["qvel_prev"][i]; d.forward()      # stale M, C of the last mj_forward
             d.qpos = pre["qpos"][i]; d.qvel = pre["qvel"][i]; d.warm = pre["qacc_warm"][i]
             for _ in range(15):
-                d.ctrl = d.spd_torque(actions[i]); d.step()
-            q[i], v[i], nw[i] = d.qpos, d.qvel, d.nwarn
+                d.ctrl = d.spd_torque(actions[i]); d.step(); its[i] += d.solver_iter
+            q[i], v[i], nw[i], lss[i] = d.qpos, d.qvel, d.nwarn, d.ls_stats
 
     with cf.ThreadPoolExecutor(n_threads()) as ex:
         list(ex.map(run, _chunks(n, n_threads())))
-    return dict(qpos=q, qvel=v, nwarn=nw)
+    return dict(qpos=q, qvel=v, nwarn=nw, iters=its, ls_stats=lss)
 
 
 def rollout_samples_emu(n_envs, n_steps, seed, skip=8, humanoid="smpl_humanoid", amp=1.0, task="HumanoidEnv", state_init="Default",

@@ -100,6 +100,28 @@ def test_stage_solve(G, h, c):
 
 
 @pytest.mark.parametrize("h,c", [(h, "floor") for h in ("smpl_humanoid", "smplx_humanoid")])
+def test_stage_solve_iterations(G, h, c):
+    """MJ-(V9b): mj_solPrimal's iteration count (mjData.solver_niter) of the cold-started solve on the V9 states against the oracle's
+    with MuJoCo's line search restated (OM_LS_MUJOCO: bracketing + 1-D Newton, ls_tolerance 0.01, ls_iterations 50) and with the exact
+    search the kernel uses.  On the oracle's own states the two searches give the same counts and the same qacc to 1e-9
+    (tests/test_oracle_linesearch.py); what MuJoCo's count says about either is what this test is for."""
+    pre = f"{h}_{c}_"
+    counts = {}
+    for ls in ("mujoco", "exact"):
+        om = oracle_model(h, linesearch=ls)
+        d = O.OracleData(om)
+        its = []
+        for i in range(len(G[pre + "qpos"])):
+            d.qpos = G[pre + "qpos"][i]; d.qvel = G[pre + "qvel"][i]; d.ctrl = G[pre + "ctrl"][i]; d.warm = np.zeros(om.nv)
+            d.forward()
+            its.append(d.solver_iter)
+        counts[ls] = np.asarray(its)
+    mj = np.asarray(G[pre + "solver_niter"]).astype(int)
+    print(f"[{h}] solver_niter MuJoCo {mj.tolist()}  oracle with MuJoCo's search {counts['mujoco'].tolist()}  exact search {counts['exact'].tolist()}")
+    assert (np.abs(counts["mujoco"] - mj) <= 1).mean() >= 0.9 and np.abs(counts["mujoco"] - mj).max() <= 3
+
+
+@pytest.mark.parametrize("h,c", [(h, "floor") for h in ("smpl_humanoid", "smplx_humanoid")])
 def test_stage_step_and_control_step(G, h, c):
     pre = f"{h}_{c}_"
     om = oracle_model(h)

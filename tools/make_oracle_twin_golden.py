@@ -24,7 +24,7 @@ def main(out, n_cases=4, rollout=(8, 150)):
             pre = f"{h}_{c}_"
             rs = np.random.default_rng(20240925)
             keys = ("qpos qvel ctrl xpos xquat xipos qM qfrc_bias ncon con_geom1 con_geom2 con_pos con_dist nefc qacc_smooth qacc efc_force "
-                    "qfrc_constraint step_qpos step_qvel roll_action roll_qpos roll_qvel").split()
+                    "qfrc_constraint solver_niter step_qpos step_qvel roll_action roll_qpos roll_qvel").split()
             acc = {k: [] for k in keys}
             d = O.OracleData(om)
             for case in range(n_cases):
@@ -38,7 +38,7 @@ def main(out, n_cases=4, rollout=(8, 150)):
                 vals = dict(qpos=q, qvel=v, ctrl=u, xpos=d.xpos, xquat=d.xquat, xipos=d.xipos, qM=d.M, qfrc_bias=d.bias, ncon=nc,
                             con_geom1=padc(d.con_body1 + 1), con_geom2=padc(d.con_body + 1), con_pos=padc(d.con_pos), con_dist=padc(d.con_dist),
                             nefc=ne, qacc_smooth=d.get(O.D_QACC_SMOOTH), qacc=d.qacc, efc_force=np.pad(d.get(O.D_EFC_FORCE), (0, 1000 - ne)),
-                            qfrc_constraint=d.get(O.D_QFRC_CONSTRAINT))
+                            qfrc_constraint=d.get(O.D_QFRC_CONSTRAINT), solver_niter=d.solver_iter)
                 d.ctrl = np.zeros(nu); d.step()
                 vals.update(step_qpos=d.qpos, step_qvel=d.qvel)
                 d.qpos = q; d.qvel = v * 0.2; d.warm = np.zeros(nv); d.ctrl = np.zeros(nu); d.forward()
