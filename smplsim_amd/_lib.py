@@ -28,6 +28,8 @@ DEFAULT_OPT = "-Os -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-il
 # -O3 / -O2 5.90 ms per 4096-env step, -Os 6.39 ms (same-box A/B, profiles/r04_selfcol_ab.txt); scratch 912 vs 1104 bytes per lane
 SC_OPT = "-O3 -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-ilp"
 MOTION_OPT = "-O3"
+# the SMPL-X/H size class (smplsim_hip_x.hip, round 5; 256 VGPRs, 6 envs per CU): -O2 2.93 ms per 4096-env step, -O3 2.95, -Os 2.97
+X_OPT = "-O2 -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-ilp"
 
 
 class ExtensionMissing(RuntimeError):
@@ -36,20 +38,21 @@ class ExtensionMissing(RuntimeError):
 
 def build(verbose=False, force=False):
     """hipcc --offload-arch=gfx950 build of the kernels + C ABI (cross-compiles without a GPU)."""
-    srcs = [os.path.join(SRC_DIR, f) for f in ("smplsim_hip.hip", "smplsim_hip_sc.hip", "smplsim_hip_im.hip", "smplsim_motion.hip", "smplsim_mlp.hip", "ss_env_kernel.h", "ss_kernel.h", "ss_selfcol.h", "ss_api.h", "ss_tables.h", "ss_hdr.h",
+    srcs = [os.path.join(SRC_DIR, f) for f in ("smplsim_hip.hip", "smplsim_hip_sc.hip", "smplsim_hip_im.hip", "smplsim_motion.hip", "smplsim_mlp.hip", "smplsim_hip_x.hip", "ss_env_kernel.h", "ss_kernel.h", "ss_selfcol.h", "ss_api.h", "ss_tables.h", "ss_hdr.h",
                                                   "ss_motion.h", "ss_motion_api.h", "ss_wave_gpu.h", "ss_imfused.h", "ss_mjcf.h")]
     srcs += [os.path.join(os.path.dirname(_PKG), "include", h) for h in ("smplsim_hip.h", "smplsim_motion.h", "smplsim_mlp.h")]
     opt = os.environ.get("SS_HIPCC_OPT", DEFAULT_OPT).split()
     scopt = os.environ.get("SS_HIPCC_SC_OPT", SC_OPT).split()
     mopt = os.environ.get("SS_HIPCC_MOTION_OPT", MOTION_OPT).split()
+    xopt = os.environ.get("SS_HIPCC_X_OPT", X_OPT).split()
     stamp = LIB_PATH + ".flags"                              # rebuild when the flags change, not only the sources
-    flag_str = " ".join(opt + ["|"] + scopt + ["|"] + mopt)
+    flag_str = " ".join(opt + ["|"] + scopt + ["|"] + mopt + ["|"] + xopt)
     same_flags = os.path.exists(stamp) and open(stamp).read() == flag_str
     if not force and same_flags and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs, procs = [], []
-    for src, flags in ((srcs[0], opt), (srcs[1], scopt), (srcs[2], opt), (srcs[3], mopt), (srcs[4], mopt)):   # stepper (3 units), motion library, policy MLP: their own
+    for src, flags in ((srcs[0], opt), (srcs[1], scopt), (srcs[2], opt), (srcs[3], mopt), (srcs[4], mopt), (srcs[5], xopt)):   # stepper (4 units), motion library, policy MLP: their own
         obj = os.path.join(_PKG, os.path.basename(src).replace(".hip", ".o"))   # flags, compiled side by side
         cmd = [hipcc, "--offload-arch=gfx950", *flags, "-std=c++17", "-fPIC", "-c", src, "-o", obj]
         if verbose:
@@ -82,7 +85,7 @@ def source_hash():
             if f.endswith((".h", ".hip")):
                 h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
     h.update(" ".join([os.environ.get("SS_HIPCC_OPT", DEFAULT_OPT), "|", os.environ.get("SS_HIPCC_SC_OPT", SC_OPT), "|",
-                       os.environ.get("SS_HIPCC_MOTION_OPT", MOTION_OPT)]).encode())
+                       os.environ.get("SS_HIPCC_MOTION_OPT", MOTION_OPT), "|", os.environ.get("SS_HIPCC_X_OPT", X_OPT)]).encode())
     return h.hexdigest()[:16]
 
 

@@ -80,7 +80,6 @@ kern_t pick_kernel(int variant, int flavour, const ss::Hdr &h, const ss::HdrC &h
 #ifndef SS_ONLY_HEADLINE
   if (variant == 0 && flavour == 1 && HdrSmpl::matches(h, hc)) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, false, HdrSmpl>;
   if (variant == 0 && flavour == 2 && HdrSmpl::matches(h, hc)) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, true, HdrSmpl>;   // per-env body shapes
-  if (variant == 1 && flavour == 0 && HdrSmplx::matches(h, hc)) return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, false, false, HdrSmplx>;
 #endif
 #endif
   if (variant == 0 && flavour == 0) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, false, false>;
@@ -91,11 +90,7 @@ kern_t pick_kernel(int variant, int flavour, const ss::Hdr &h, const ss::HdrC &h
     if (flavour == 1) return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, false>;
     return ss_env_kernel<2, 2, 1, 1, SS_MAX_THREADS, true, true>;
   }
-  if (variant == 1) {                                        // SMPL-X/H layout (52 bodies)
-    if (flavour == 0) return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, false, false>;
-    if (flavour == 1) return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, true, false>;
-    return ss_env_kernel<3, 3, 2, 2, SS_MAX_THREADS_X, true, true>;
-  }
+  if (variant == 1) return ss::pick_kernel_x(flavour, h, hc);   // SMPL-X/H layout (52 bodies): smplsim_hip_x.hip
 #endif
   return nullptr;
 }

@@ -28,6 +28,7 @@ typedef void (*kern_t)(const KArgs);
 kern_t pick_kernel_selfcol(int variant, bool shaped, bool imit, const Hdr &h, const HdrC &hc);
 kern_t pick_kernel_imitation(int variant, bool shaped, const Hdr &h, const HdrC &hc);
 kern_t pick_kernel_imitation_selfcol(int variant, bool shaped, const Hdr &h, const HdrC &hc);
+kern_t pick_kernel_x(int flavour, const Hdr &h, const HdrC &hc);                      // smplsim_hip_x.hip: the SMPL-X/H size class
 }  // namespace ss
 
 namespace {
