@@ -32,6 +32,15 @@ int ss_linear_bf16(const void *x, const void *w, const float *bias, void *y, int
 int ss_obs_to_bf16(const float *obs, int32_t M, int32_t dim, int32_t obs_stride, const float *norm_mean, const float *norm_std,
                    const int64_t *norm_n, float clip_lo, float clip_hi, float norm_clip, void *out, int32_t kpad, void *stream);
 
+/* The Gaussian head of the sampler in one launch (PolicyGaussian.select_action, policy_gaussian.py:25-41 -> DiagGaussian.sample;
+ * Agent.preprocess_actions with clip_actions, agents/agent.py:153-161; normal_log_density of get_log_prob): per row
+ *   action = mean + exp(log_std) * noise          [M, dim], row stride lda (the rollout's action row: the UNCLIPPED draw is what is stored)
+ *   action_env = clamp(action, clip_lo, clip_hi)  [M, dim], row stride lde, or NULL (what the env is stepped with)
+ *   logp = sum_j -noise^2 / 2 - log sqrt(2 pi) - log_std_j   [M] or NULL (the behaviour policy's log-density of the draw)
+ * mean, noise [M, dim] dense f32; log_std [dim].  The caller draws the noise (its generator, its stream order). */
+int ss_gaussian_sample(const float *mean, const float *noise, const float *log_std, int32_t M, int32_t dim, float *action, int32_t lda,
+                       float *action_env, int32_t lde, float clip_lo, float clip_hi, float *logp, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,6 +80,61 @@ class AgentPPO:
         # rescale_actions(low, high, clip(a, low, high)) with the env's action space [-1, 1] is the clip itself
         return actions.clamp(-1.0, 1.0) if self.cfg.clip_actions else actions
 
+    # One control step of the sampler for a set of env rows (all of them, or one sub-batch of a pipeline): observation -> action ->
+    # env step -> rollout rows.  Per step: one clamp (straight into the rollout's state row), the policy forward, ONE launch for the
+    # Gaussian head on the bf16 path (ss_gaussian_sample: draw, clipped copy, log-density), the env's launches, three row stores; the
+    # episode flags stay uint8 until the rollout is complete (round 5: ~12 launches per step instead of ~25 next to the policy's nine).
+    def _sample_step(self, t, r, obs, noise, buf, mean_action, slot, step_fn):
+        c = self.cfg
+        state = buf["states"][t, r]
+        if c.clip_obs:
+            torch.clamp(obs, c.clip_obs_range[0], c.clip_obs_range[1], out=state)
+        else:
+            state.copy_(obs)
+        act_row = buf["actions"][t, r]
+        lo, hi = (-1.0, 1.0) if c.clip_actions else (-3.0e38, 3.0e38)
+        if self.fast_policy is not None:
+            mean = self.fast_policy.mean(state, slot=slot)
+            if mean_action:
+                act_row.copy_(mean)
+                a_env = self._prep_actions(mean)
+            else:
+                a_env = buf["a_env"][r]
+                self.fast_policy.sample_into(mean, noise, act_row, a_env, (lo, hi), buf["logp"][t, r] if buf["logp"] is not None else None)
+        else:
+            with self._autocast():
+                mean = self._f32(self.policy_net.select_action(state, True))
+            a = mean if mean_action else mean + self.policy_net.action_log_std.exp() * noise
+            act_row.copy_(a)
+            a_env = self._prep_actions(a)
+        obs, rew, died, timed_out, _ = step_fn(a_env)
+        buf["rewards"][t, r] = rew
+        buf["dead"][t, r] = died                               # (bool -> uint8 row: one launch each; turned into the float masks once)
+        torch.logical_or(died, timed_out, out=buf["done"][t, r])
+        return obs
+
+    def _rollout_buffers(self, T, N, mean_action):
+        f = dict(device=self.device, dtype=torch.float32)
+        # bf16 sampler: the behaviour policy's own log-densities go into the batch (the update's fp32 network would give the PPO
+        # ratio a denominator from a slightly different policy: a mean error of 1e-2 at sigma 0.08 moves log-probs noticeably)
+        return dict(states=torch.empty(T, N, self.state_dim, **f), actions=torch.empty(T, N, self.action_dim, **f),
+                    rewards=torch.empty(T, N, **f), dead=torch.empty(T, N, dtype=torch.bool, device=self.device),
+                    done=torch.empty(T, N, dtype=torch.bool, device=self.device), a_env=torch.empty(N, self.action_dim, **f),
+                    logp=torch.empty(T, N, 1, **f) if (self.fast_policy is not None and not mean_action) else None)
+
+    def _rollout_out(self, buf, last_obs_rows, mean_action):
+        T, N = buf["rewards"].shape
+        f = dict(device=self.device, dtype=torch.float32)
+        last = torch.empty(N, self.state_dim, **f)
+        for r, o in last_obs_rows:
+            last[r] = self._prep_obs(o)                          # post-autoreset observation = first state of the next episode
+        self.num_steps += T * N
+        out = dict(states=buf["states"], actions=buf["actions"], rewards=buf["rewards"], not_done=(~buf["done"]).to(torch.float32),
+                   not_dead=(~buf["dead"]).to(torch.float32), exps=torch.full((T, N), 0.0 if mean_action else 1.0, **f), last_state=last)
+        if buf["logp"] is not None:
+            out["log_probs"] = buf["logp"]
+        return out
+
     @torch.no_grad()
     def sample(self, horizon=None, mean_action=False):
         """Roll all envs `horizon` control steps forward.  Returns time-major tensors on the env's device."""
@@ -87,38 +142,13 @@ class AgentPPO:
         self.policy_net.eval()
         if self._obs is None:
             self._obs, _ = env.reset()
-        f = dict(device=self.device, dtype=torch.float32)
-        states = torch.empty(T, N, self.state_dim, **f)
-        actions = torch.empty(T, N, self.action_dim, **f)
-        rewards, not_done, not_dead = (torch.empty(T, N, **f) for _ in range(3))
-        # bf16 sampler: the behaviour policy's own log-densities go into the batch (the update's fp32 network would give the PPO
-        # ratio a denominator from a slightly different policy: a mean error of 1e-2 at sigma 0.08 moves log-probs noticeably)
-        behaviour_logp = torch.empty(T, N, 1, **f) if (self.fast_policy is not None and not mean_action) else None
-        state = self._prep_obs(self._obs)
+        buf = self._rollout_buffers(T, N, mean_action)
+        obs, rows = self._obs, slice(0, N)
         for t in range(T):
-            states[t] = state
-            if self.fast_policy is not None:
-                if behaviour_logp is not None:
-                    a, behaviour_logp[t] = self.fast_policy.select_action(state, mean_action, generator=self.gen, return_log_prob=True)
-                else:
-                    a = self.fast_policy.select_action(state, mean_action, generator=self.gen)
-            else:
-                with self._autocast():
-                    a = self._f32(self.policy_net.select_action(state, mean_action, generator=self.gen))
-            actions[t] = a
-            obs, rew, died, timed_out, _ = env.step(self._prep_actions(a))
-            rewards[t] = rew
-            not_dead[t] = (~died).to(torch.float32)
-            not_done[t] = (~(died | timed_out)).to(torch.float32)
-            state = self._prep_obs(obs)                        # post-autoreset observation = first state of the next episode
+            noise = None if mean_action else torch.randn(N, self.action_dim, generator=self.gen, device=self.device, dtype=torch.float32)
+            obs = self._sample_step(t, rows, obs, noise, buf, mean_action, 0, env.step)
         self._obs = obs
-        self.num_steps += T * N
-        exps = torch.full((T, N), 0.0 if mean_action else 1.0, **f)
-        out = dict(states=states, actions=actions, rewards=rewards, not_done=not_done, not_dead=not_dead, exps=exps,
-                   last_state=state.clone())
-        if behaviour_logp is not None:
-            out["log_probs"] = behaviour_logp
-        return out
+        return self._rollout_out(buf, [(rows, obs)], mean_action)
 
     @torch.no_grad()
     def sample_pipelined(self, pipe, horizon=None, mean_action=False):
@@ -127,67 +157,35 @@ class AgentPPO:
         launch has already left.  Same draws as sample(): the Gaussian noise of a step is drawn for all N envs
         from self.gen and sliced, the env's inputs come from the pipeline's master generator — every env gets what it gets in the
         single batch, the returned tensors are bit-identical to sample()'s (GPU test; the bf16 policy's row results do not depend
-        on the number of rows: the K order of the MFMA kernels is the same for every tile width)."""
+        on the number of rows: the K order of the MFMA kernels is the same for every tile width).  Measured (profiles/r05_sampler.txt):
+        no gain over the serial order at G = 2 and a loss at G >= 4 — a sub-batch's launch is as long as its heaviest env's chain
+        whatever its size, two step kernels cannot share a CU's LDS, and the host issues G times the launches."""
         T, N, G = horizon or self.horizon, pipe.num_envs, pipe.sub_batches
-        assert N == self.env.num_envs or self.env is pipe
         self.policy_net.eval()
         if getattr(self, "_pipe_obs", None) is None:
             self._pipe_obs = pipe.reset()
-        f = dict(device=self.device, dtype=torch.float32)
-        states = torch.empty(T, N, self.state_dim, **f)
-        actions = torch.empty(T, N, self.action_dim, **f)
-        rewards, not_done, not_dead = (torch.empty(T, N, **f) for _ in range(3))
-        behaviour_logp = torch.empty(T, N, 1, **f) if (self.fast_policy is not None and not mean_action) else None
-        last_state = torch.empty(N, self.state_dim, **f)
+        buf = self._rollout_buffers(T, N, mean_action)
         from ..pipeline import _record_event
-        start = _record_event(self.device)                       # the buffers above exist before any sub-stream touches them
         cuda = self.device.type == "cuda"
         obs = list(self._pipe_obs)
         for t in range(T):
-            noise = None if mean_action else torch.randn(N, self.action_dim, generator=self.gen, **f)
+            noise = None if mean_action else torch.randn(N, self.action_dim, generator=self.gen, device=self.device, dtype=torch.float32)
             pipe.draw_step_inputs()
-            ev = _record_event(self.device)
+            ev = _record_event(self.device)                      # (after the buffers' allocation, this step's noise and the env draws)
             for g in range(G):
                 r, s = pipe.rows(g), pipe.streams[g]
                 with pipe.stream(g):
                     s.wait_event(ev)
-                    if t == 0:
-                        s.wait_event(start)
                     if noise is not None and cuda:
                         noise.record_stream(s)
-                    state = self._prep_obs(obs[g])
-                    states[t, r] = state
-                    if self.fast_policy is not None:
-                        mean = self.fast_policy.mean(state, slot=g)
-                    else:
-                        with self._autocast():
-                            mean = self._f32(self.policy_net.select_action(state, True))
-                    if mean_action:
-                        a = mean
-                    else:
-                        log_std = self.policy_net.action_log_std
-                        a = torch.addcmul(mean, log_std.exp(), noise[r]) if self.fast_policy is not None else mean + log_std.exp() * noise[r]
-                        if behaviour_logp is not None:
-                            behaviour_logp[t, r] = (-0.5 * noise[r].pow(2) - 0.5 * _LOG_2PI - log_std).sum(1, keepdim=True)
-                    actions[t, r] = a
-                    o, rew, died, timed_out, _ = pipe.step_async(g, self._prep_actions(a))
-                    rewards[t, r] = rew
-                    not_dead[t, r] = (~died).to(torch.float32)
-                    not_done[t, r] = (~(died | timed_out)).to(torch.float32)
-                    obs[g] = o
-                    if t == T - 1:
-                        last_state[r] = self._prep_obs(o)
+                    obs[g] = self._sample_step(t, r, obs[g], None if noise is None else noise[r], buf, mean_action, g,
+                                               lambda a, g=g: pipe.step_async(g, a))
         if cuda:
             cur = torch.cuda.current_stream(self.device)
             for s in pipe.streams:                                # the caller's stream continues after every sub-batch's last step
                 cur.wait_stream(s)
         self._pipe_obs = obs
-        self.num_steps += T * N
-        exps = torch.full((T, N), 0.0 if mean_action else 1.0, **f)
-        out = dict(states=states, actions=actions, rewards=rewards, not_done=not_done, not_dead=not_dead, exps=exps, last_state=last_state)
-        if behaviour_logp is not None:
-            out["log_probs"] = behaviour_logp
-        return out
+        return self._rollout_out(buf, [(pipe.rows(g), obs[g]) for g in range(G)], mean_action)
 
     # ------------------------------------------------------------------ update
     def _autocast(self):

@@ -166,6 +166,26 @@ __global__ void __launch_bounds__(256) ss_obs_to_bf16_kernel(const float *obs, i
   out[idx] = (__bf16)v;
 }
 
+// Gaussian policy head of the sampler, one wavefront per env row: a = mean + exp(log_std) * noise (the product and the sum rounded
+// separately, like the torch expression it replaces), its clipped copy for the env, and the log-density of the draw.
+__global__ void __launch_bounds__(256) ss_gaussian_sample_kernel(const float *mean, const float *noise, const float *log_std, int M, int dim,
+                                                                 float *action, int lda, float *action_env, int lde, float lo, float hi, float *logp) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  float acc = 0.f;
+  for (int j = lane; j < dim; j += 64) {
+    const float ls = log_std[j], z = noise[(size_t)row * dim + j];
+    const float a = __fadd_rn(mean[(size_t)row * dim + j], __fmul_rn(__expf(ls), z));
+    action[(size_t)row * lda + j] = a;
+    if (action_env) action_env[(size_t)row * lde + j] = fminf(fmaxf(a, lo), hi);
+    acc += -0.5f * z * z - 0.91893853320467274f - ls;          // - log sqrt(2 pi)
+  }
+  if (logp) {
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    if (lane == 0) logp[row] = acc;
+  }
+}
+
 int fail(int code, const char *msg) { ss::last_error() = msg; return code; }
 
 }  // namespace
@@ -232,6 +252,16 @@ int ss_linear_bf16(const void *x, const void *w, const float *bias, void *y, int
   else SS_PICK(64);
 #undef SS_PICK
 #undef SS_LAUNCH
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SS_OK : fail(SS_ERR_HIP, hipGetErrorString(e));
+}
+
+int ss_gaussian_sample(const float *mean, const float *noise, const float *log_std, int32_t M, int32_t dim, float *action, int32_t lda,
+                       float *action_env, int32_t lde, float clip_lo, float clip_hi, float *logp, void *stream) {
+  if (!mean || !noise || !log_std || !action) return fail(SS_ERR_INVALID, "null argument");
+  if (M < 1 || dim < 1 || lda < dim || (action_env && lde < dim)) return fail(SS_ERR_INVALID, "ss_gaussian_sample: row strides must be >= dim");
+  hipLaunchKernelGGL(ss_gaussian_sample_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, mean, noise, log_std, M, dim, action, lda,
+                     action_env, lde, clip_lo, clip_hi, logp);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SS_OK : fail(SS_ERR_HIP, hipGetErrorString(e));
 }

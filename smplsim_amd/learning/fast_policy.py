@@ -86,6 +86,18 @@ class FusedPolicyInference:
         return out
 
     @torch.no_grad()
+    def sample_into(self, mean, noise, action_out, action_env, clip, logp_out=None):
+        """One launch for the Gaussian head (ss_gaussian_sample): action_out [M, nu] = mean + exp(log_std) * noise (a row slice of the
+        rollout's action tensor), action_env [M, nu] = its copy clipped to `clip` = (lo, hi) (what the env is stepped with), logp_out
+        [M, 1] = the draw's log-density under this behaviour policy.  Replaces eight elementwise torch launches per control step."""
+        M = mean.shape[0]
+        assert mean.is_contiguous() and noise.is_contiguous() and action_out.stride(1) == 1 and action_env.stride(1) == 1
+        assert logp_out is None or logp_out.is_contiguous()
+        _check(lib().ss_gaussian_sample(_ptr(mean), _ptr(noise), _ptr(self.policy.action_log_std), M, self.action_dim, _ptr(action_out),
+                                        action_out.stride(0), _ptr(action_env), action_env.stride(0), float(clip[0]), float(clip[1]),
+                                        _ptr(logp_out), _launch_stream(self.device)))
+
+    @torch.no_grad()
     def select_action(self, obs, mean_action=False, generator=None, return_log_prob=False):
         """return_log_prob: also the log-density of the drawn action under THIS (bf16) behaviour policy, [M, 1] — what the PPO ratio's
         denominator must be when the sampler runs here while the update evaluates the fp32 network (normal_log_density of the
