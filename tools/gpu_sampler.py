@@ -31,9 +31,14 @@ res["serial"] = {"env_steps_per_s": round(r[0]), "host_issue_ms_per_step": round
 a1.env.close()
 for G in [int(x) for x in os.environ.get("GS", "2,4,8").split(",") if int(x) > 1]:
     pipe = PipelinedVecEnv(N, sub_batches=G, **kw)
+    if os.environ.get("PIPE_EPW"):                                 # envs per workgroup of every sub-batch: small enough for two workgroups
+        from smplsim_amd._lib import lib                           # (of different sub-batches) to share a CU's LDS
+        from smplsim_amd.batch import _check
+        for e in pipe.envs:
+            _check(lib().ss_set_launch_geometry(e.handle, int(os.environ["PIPE_EPW"]), 0))
     a2 = AgentPPO(pipe, cfg, seed=0)
     (r, b2) = run(a2, lambda: a2.sample_pipelined(pipe))
-    res[f"pipelined_G{G}"] = {"env_steps_per_s": round(r[0]), "host_issue_ms_per_step": round(r[1], 3), "ms_per_step": round(r[2], 3),
+    res[f"pipelined_G{G}" + ("_epw" + os.environ["PIPE_EPW"] if os.environ.get("PIPE_EPW") else "")] = {"env_steps_per_s": round(r[0]), "host_issue_ms_per_step": round(r[1], 3), "ms_per_step": round(r[2], 3),
                               "rollout_equals_serial": bool(all(torch.equal(b1[k], b2[k]) for k in b1))}
     pipe.close()
 print(json.dumps(res))
