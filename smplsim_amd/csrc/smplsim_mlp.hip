@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 #include <string>
 
 #include "../../include/smplsim_hip.h"
@@ -37,6 +38,17 @@ __device__ __forceinline__ float activate(float v, int act) {
   if (act == SS_ACT_TANH) { const float e = __expf(-2.f * fabsf(v)); const float t = (1.f - e) / (1.f + e); return v < 0.f ? -t : t; }
   if (act == SS_ACT_RELU) return v > 0.f ? v : 0.f;
   return v;
+}
+
+// Epilogue arithmetic with the activation chosen ONCE (round 5: the per-element `switch` with an IEEE division behind it was ~75
+// instructions per output element, 3600 per wave for a 32 x 96 wave tile — a quarter of the kernel's time on the wide layers);
+// reciprocal by v_rcp_f32 (1 ulp: invisible behind the bf16 rounding of the result).
+struct ActNone { __device__ __forceinline__ float operator()(float v) const { return v; } };
+struct ActSilu { __device__ __forceinline__ float operator()(float v) const { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); } };
+struct ActTanh { __device__ __forceinline__ float operator()(float v) const { const float e = __expf(-2.f * fabsf(v)); const float t = (1.f - e) * __builtin_amdgcn_rcpf(1.f + e); return v < 0.f ? -t : t; } };
+struct ActRelu { __device__ __forceinline__ float operator()(float v) const { return v > 0.f ? v : 0.f; } };
+template <class F> __device__ __forceinline__ void with_activation(int act, F &&f) {
+  if (act == SS_ACT_SILU) f(ActSilu{}); else if (act == SS_ACT_TANH) f(ActTanh{}); else if (act == SS_ACT_RELU) f(ActRelu{}); else f(ActNone{});
 }
 
 template <int BN, int BK, bool F32OUT, int WM, int WN = 2>
@@ -134,23 +146,211 @@ __global__ void __launch_bounds__(64 * WM * WN) ss_linear_kernel(const __bf16 *_
 #undef SS_LOAD
 #undef SS_STORE
 #undef SS_COMPUTE
-  // epilogue: bias + activation, bf16 (the next layer's operand) or f32 (the head)
+  // epilogue: bias + activation (chosen once), bf16 (the next layer's operand; staged through LDS so that a lane stores 16 contiguous
+  // bytes of a row) or f32 (the head: a few columns, stored directly)
+  float bv[TN];
 #pragma unroll
-  for (int tm = 0; tm < TM; tm++)
+  for (int tn = 0; tn < TN; tn++) {
+    const int col = n0 + wn * (BN / WN) + tn * 32 + (lane & 31);
+    bv[tn] = (bias && col < N) ? bias[col] : 0.f;
+  }
+  if constexpr (F32OUT) {
+    with_activation(act, [&](auto fn) {
 #pragma unroll
-    for (int tn = 0; tn < TN; tn++) {
-      const int col = n0 + wn * (BN / WN) + tn * 32 + (lane & 31);
-      const float bv = (bias && col < N) ? bias[col] : 0.f;
+      for (int tm = 0; tm < TM; tm++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int row = m0 + wm * (32 * TM) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < M && col < N) {
-          const float v = activate(acc[tm][tn][r] + bv, act);
-          if (F32OUT) reinterpret_cast<float *>(Y)[(size_t)row * ldy + col] = v;
-          else reinterpret_cast<__bf16 *>(Y)[(size_t)row * ldy + col] = (__bf16)v;
+        for (int tn = 0; tn < TN; tn++) {
+          const int col = n0 + wn * (BN / WN) + tn * 32 + (lane & 31);
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int row = m0 + wm * (32 * TM) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row < M && col < N) reinterpret_cast<float *>(Y)[(size_t)row * ldy + col] = fn(acc[tm][tn][r] + bv[tn]);
+          }
         }
+    });
+  } else {
+    constexpr int CS = BN + 8;
+    __bf16 *Cs = lds_ab;                                       // (the K loop ended with a barrier: its buffers are free)
+    with_activation(act, [&](auto fn) {
+#pragma unroll
+      for (int tm = 0; tm < TM; tm++)
+#pragma unroll
+        for (int tn = 0; tn < TN; tn++) {
+          const int cl = wn * (BN / WN) + tn * 32 + (lane & 31);
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int rl = wm * (32 * TM) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            Cs[rl * CS + cl] = (__bf16)fn(acc[tm][tn][r] + bv[tn]);
+          }
+        }
+    });
+    __syncthreads();
+    __bf16 *Yb = reinterpret_cast<__bf16 *>(Y);
+    const bool vec_ok = (ldy & 7) == 0 && (reinterpret_cast<size_t>(Yb) & 15) == 0;
+    constexpr int OCPR = BN / 8;                              // 16-byte chunks per output tile row
+#pragma unroll
+    for (int i = 0; i < BM * OCPR / NT; i++) {
+      const int id = tid + NT * i, rl = id / OCPR, cc = (id % OCPR) * 8, row = m0 + rl, col = n0 + cc;
+      if (row >= M || col >= N) continue;
+      const u32x4 v = *reinterpret_cast<const u32x4 *>(Cs + rl * CS + cc);
+      if (vec_ok && col + 8 <= N) *reinterpret_cast<u32x4 *>(Yb + (size_t)row * ldy + col) = v;
+      else {
+        const __bf16 *e = reinterpret_cast<const __bf16 *>(&v);
+        for (int j = 0; j < 8 && col + j < N; j++) Yb[(size_t)row * ldy + col + j] = e[j];
       }
     }
+  }
+}
+
+// ---- round 5: the same GEMM with asynchronous global -> LDS copies (global_load_lds_dwordx4) and three K tiles in flight.
+// What round 4 measured (profiles/r04_mlp_gemm.txt): the register-staged K loop above is a chain global load -> LDS store -> barrier ->
+// fragment read that one workgroup per CU cannot hide.  Here a tile goes from global memory straight into LDS (no staging registers,
+// no ds_write pass), is requested two K steps before it is multiplied, and one barrier per K step remains:
+//     wait until tile t has landed (s_waitcnt vmcnt(loads of tile t + 1)) -> barrier -> request tile t + 2 -> multiply tile t
+// (the barrier proves that every wave has finished multiplying tile t - 1, whose LDS stage tile t + 2 overwrites).
+// LDS layout: a tile row is 64 bf16 = eight 16-byte chunks, rows dense (the copy writes wave-base + lane * 16: 8 rows of 8 chunks per
+// wave instruction, no padding possible); chunk c of row r sits at position c ^ ((r >> 1) & 7) — two rows fill the 64 banks, so the 16
+// rows a quarter of a fragment read touches need 8 distinct positions per row parity — the XOR is applied to the per-lane SOURCE
+// address of the copy (within the row's one 128-byte line) and to the fragment reads' addresses, so that the 32 rows a fragment
+// read touches spread over all banks (a ds_read_b128 of 64 lanes takes its four cycles, no more).
+typedef __attribute__((address_space(1))) const void ss_gvoid;
+typedef __attribute__((address_space(3))) void ss_lvoid;
+
+template <int BN, bool F32OUT>
+__global__ void __launch_bounds__(512) ss_linear_glds_kernel(const __bf16 *__restrict__ X, const __bf16 *__restrict__ W, const float *__restrict__ bias,
+                                                             void *__restrict__ Y, int M, int N, int K, int ldy, int act, int xcd_remap) {
+  constexpr int BK = 64, WM = 4, WN = 2, NST = 3;
+  constexpr int TN = BN / (32 * WN);                         // MFMA tiles per wave along N (a wave owns 32 x BN/2 of the 128 x BN tile)
+  constexpr int STAGE = (BM + BN) * BK;                      // bf16 elements of one stage: A rows, then B rows
+  constexpr int NI = (BM + BN) / 64;                         // copy instructions per wave and tile (8 rows each, 8 waves)
+  extern __shared__ __attribute__((aligned(16))) __bf16 lds_g[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave / WN, wn = wave % WN;
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int gx = gridDim.x, gy = gridDim.y;
+    if (xcd_remap && gy % 8 == 0) {                          // XCD-aware tile order (see ss_linear_kernel)
+      const int id = by * gx + bx, xcd = id & 7, idx = id >> 3, rows_per = gy >> 3;
+      by = xcd * rows_per + idx % rows_per;
+      bx = idx / rows_per;
+    }
+  }
+  const int m0 = by * BM, n0 = bx * BN;
+  f32x16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; j++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+  // this wave's copy instructions: instruction i covers tile rows 8 (wave + 8 i) .. + 8 of the stacked (A | B) tile; lane -> row
+  // lane / 8, chunk position lane % 8, source chunk (lane % 8) ^ (lane / 8)
+  const __bf16 *src[NI];
+  int dst[NI];
+#pragma unroll
+  for (int i = 0; i < NI; i++) {
+    const int blk = wave + 8 * i, row = 8 * blk + (lane >> 3), chunk = (lane & 7) ^ ((row >> 1) & 7);
+    if (row < BM) { const int g = m0 + row; src[i] = X + (size_t)(g < M ? g : M - 1) * K + chunk * 8; }
+    else { const int g = n0 + row - BM; src[i] = W + (size_t)(g < N ? g : N - 1) * K + chunk * 8; }
+    dst[i] = 8 * blk * BK;                                   // wave-uniform; the lane's 16 bytes follow at lane * 16
+  }
+  const int nkt = K / BK;
+  auto request = [&](int t) {
+    __bf16 *stage = lds_g + (t % NST) * STAGE;
+#pragma unroll
+    for (int i = 0; i < NI; i++) __builtin_amdgcn_global_load_lds((ss_gvoid *)(src[i] + (size_t)t * BK), (ss_lvoid *)(stage + dst[i]), 16, 0, 0);
+  };
+  request(0);
+  if (nkt > 1) request(1);
+  const int arow = wm * 32 + (lane & 31), ax = (arow >> 1) & 7, half = lane >> 5;
+  for (int kt = 0; kt < nkt; kt++) {
+    if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");   // tile kt landed (tile kt + 1 may still be on its way)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                             // ... for every wave's share of it, and tile kt - 1 is multiplied everywhere
+#ifndef SS_GX_NOLOAD
+    if (kt + 2 < nkt) request(kt + 2);
+#endif
+    const __bf16 *As = lds_g + (kt % NST) * STAGE, *Bs = As + BM * BK;
+    // fragments of k16 step ks + 1 are requested before step ks is multiplied (two register sets): the LDS latency of a step hides
+    // behind the previous step's MFMAs instead of in front of its own
+    bf16x8 fa[2], fb[2][TN];
+    auto frags = [&](int ks, int set) {
+      const int c = 2 * ks + half;                           // this lane's chunk of the k16 step: k = 16 ks + 8 (lane / 32) ..
+      fa[set] = *reinterpret_cast<const bf16x8 *>(As + arow * BK + ((c ^ ax) << 3));
+#pragma unroll
+      for (int tn = 0; tn < TN; tn++) {
+        const int brow = wn * (BN / WN) + tn * 32 + (lane & 31);
+        fb[set][tn] = *reinterpret_cast<const bf16x8 *>(Bs + brow * BK + ((c ^ ((brow >> 1) & 7)) << 3));
+      }
+    };
+    frags(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      if (ks < 3) frags(ks + 1, (ks + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);                      // (the scheduler would sink the reads back in front of their own MFMAs)
+#ifdef SS_GX_NOMFMA
+#pragma unroll
+      for (int tn = 0; tn < TN; tn++) acc[tn][0] += (float)fa[ks & 1][0] * (float)fb[ks & 1][tn][0];
+#else
+#pragma unroll
+      for (int tn = 0; tn < TN; tn++) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1], fb[ks & 1][tn], acc[tn], 0, 0, 0);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // (Round 5 also built the deeper pipeline — a whole tile's fragments of tile t + 1 read during tile t's MFMAs, three tiles in flight,
+  // the copy instructions spread behind the MFMAs: correct, and not faster (35.1-35.5 us against 34.6 on the 2048 -> 1536 layer).  With
+  // the K loop's copies removed the same loop runs 28.3 us: what is left is the L2 -> LDS traffic itself, 335 MB per GEMM at 128 x 192
+  // tiles = ~12 TB/s over the eight L2s; fewer bytes per flop need 256-wide tiles, of which this layer has 96-128 for 256 CUs.
+  // profiles/r05_mlp_gemm.txt)
+  // ---- epilogue: bias + activation, then the tile goes through LDS (the stages are free) so that every lane stores 16 contiguous
+  // bytes of an output row (the MFMA's C layout puts one column per lane: 2-byte stores, 48 store instructions per wave before)
+  float bv[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; tn++) {
+    const int col = n0 + wn * (BN / WN) + tn * 32 + (lane & 31);
+    bv[tn] = (bias && col < N) ? bias[col] : 0.f;
+  }
+  if constexpr (F32OUT) {
+    with_activation(act, [&](auto fn) {
+#pragma unroll
+      for (int tn = 0; tn < TN; tn++) {
+        const int col = n0 + wn * (BN / WN) + tn * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (row < M && col < N) reinterpret_cast<float *>(Y)[(size_t)row * ldy + col] = fn(acc[tn][r] + bv[tn]);
+        }
+      }
+    });
+  } else {
+    constexpr int CS = BN + 8;                               // row stride of the staged tile (16 bytes of padding: the column-per-lane writes spread over the banks)
+    __bf16 *Cs = lds_g;
+    __builtin_amdgcn_s_barrier();                             // every wave has multiplied the last tile: the stages may be overwritten
+    with_activation(act, [&](auto fn) {
+#pragma unroll
+      for (int tn = 0; tn < TN; tn++) {
+        const int cl = wn * (BN / WN) + tn * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int rl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          Cs[rl * CS + cl] = (__bf16)fn(acc[tn][r] + bv[tn]);
+        }
+      }
+    });
+    __syncthreads();
+    __bf16 *Yb = reinterpret_cast<__bf16 *>(Y);
+    const bool vec_ok = (ldy & 7) == 0 && (reinterpret_cast<size_t>(Yb) & 15) == 0;
+    constexpr int CPR = BN / 8;                               // 16-byte chunks per tile row
+#pragma unroll
+    for (int i = 0; i < BM * CPR / 512; i++) {
+      const int id = tid + 512 * i, rl = id / CPR, cc = (id % CPR) * 8, row = m0 + rl, col = n0 + cc;
+      if (row >= M || col >= N) continue;
+      const u32x4 v = *reinterpret_cast<const u32x4 *>(Cs + rl * CS + cc);
+      if (vec_ok && col + 8 <= N) *reinterpret_cast<u32x4 *>(Yb + (size_t)row * ldy + col) = v;
+      else {
+        const __bf16 *e = reinterpret_cast<const __bf16 *>(&v);
+        for (int j = 0; j < 8 && col + j < N; j++) Yb[(size_t)row * ldy + col + j] = e[j];
+      }
+    }
+  }
 }
 
 __global__ void __launch_bounds__(256) ss_obs_to_bf16_kernel(const float *obs, int M, int dim, int stride, const float *mean, const float *sd,
@@ -222,11 +422,18 @@ int ss_linear_bf16(const void *x, const void *w, const float *bias, void *y, int
     }
     if (force_bn && atoi(force_bn) > 0) bn = atoi(force_bn);
   }
+  static const bool glds = getenv("SS_MLP_NOGLDS") == nullptr;   // round 5: asynchronous global -> LDS copies, three K tiles in flight
 #define SS_LAUNCH(BN_, BK_, F32_)                                                                                              \
   do {                                                                                                                         \
     dim3 grid((N + BN_ - 1) / BN_, gm);                                                                                        \
-    const size_t lds_ = (size_t)2 * (BM + BN_) * (BK_ + 8) * sizeof(__bf16);                                                   \
-    if (waves8 && BK_ == 64) {                                                                                          \
+    const size_t loop_ = (size_t)2 * (BM + BN_) * (BK_ + 8) * sizeof(__bf16), tile_ = (size_t)BM * (BN_ + 8) * sizeof(__bf16);   \
+    const size_t lds_ = loop_ > tile_ ? loop_ : tile_;   /* K loop's two stages; the epilogue stages the output tile in the same memory */ \
+    if (waves8 && BK_ == 64 && glds && K >= 512) {   /* (a shallow K keeps the two-stage kernel: two workgroups per CU hide its short loop better) */                                                                                         \
+      auto kern_ = ss_linear_glds_kernel<BN_, F32_>;                                                                           \
+      const size_t l3_ = (size_t)3 * (BM + BN_) * 64 * sizeof(__bf16);                                                         \
+      if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3_) != hipSuccess) return fail(SS_ERR_HIP, "cannot size the GEMM's LDS"); \
+      hipLaunchKernelGGL(kern_, grid, dim3(512), l3_, st, X, Wt, bias, y, M, N, K, ldy, act, remap);                            \
+    } else if (waves8 && BK_ == 64) {                                                                                          \
       auto kern_ = ss_linear_kernel<BN_, BK_, F32_, 4>;                                                                        \
       /* per launch: the attribute belongs to the (kernel, device) pair and the call is a table write (a process-wide flag left */ \
       /* the wide tiles of a second GPU at the 64 KB default: ADVICE r4) */                                                     \
@@ -237,8 +444,9 @@ int ss_linear_bf16(const void *x, const void *w, const float *bias, void *y, int
       if ((size_t)2 * (BM + (BN_ > 128 ? 128 : BN_)) * (BK_ + 8) * sizeof(__bf16) > 64 * 1024 &&                                  \
           hipFuncSetAttribute(reinterpret_cast<const void *>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize,                \
                               (int)((size_t)2 * (BM + (BN_ > 128 ? 128 : BN_)) * (BK_ + 8) * sizeof(__bf16))) != hipSuccess) return fail(SS_ERR_HIP, "cannot size the GEMM's LDS"); \
+      const size_t l4a_ = (size_t)2 * (BM + (BN_ > 128 ? 128 : BN_)) * (BK_ + 8) * sizeof(__bf16), l4b_ = (size_t)BM * ((BN_ > 128 ? 128 : BN_) + 8) * sizeof(__bf16); \
       hipLaunchKernelGGL(kern_, dim3((N + (BN_ > 128 ? 128 : BN_) - 1) / (BN_ > 128 ? 128 : BN_), gm), dim3(256),              \
-                         (size_t)2 * (BM + (BN_ > 128 ? 128 : BN_)) * (BK_ + 8) * sizeof(__bf16), st, X, Wt, bias, y, M, N, K, ldy, act, remap); \
+                         l4a_ > l4b_ ? l4a_ : l4b_, st, X, Wt, bias, y, M, N, K, ldy, act, remap);                              \
     }                                                                                                                          \
   } while (0)
 #define SS_PICK(BN_)                                                                                                           \
