@@ -83,7 +83,7 @@ class AgentPPO:
     # One control step of the sampler for a set of env rows (all of them, or one sub-batch of a pipeline): observation -> action ->
     # env step -> rollout rows.  Per step: one clamp (straight into the rollout's state row), the policy forward, ONE launch for the
     # Gaussian head on the bf16 path (ss_gaussian_sample: draw, clipped copy, log-density), the env's launches, three row stores; the
-    # episode flags stay uint8 until the rollout is complete (round 5: ~12 launches per step instead of ~25 next to the policy's nine).
+    # episode flags stay boolean rows until the rollout is complete (round 5: ~12 launches per step instead of ~25 next to the policy's nine).
     def _sample_step(self, t, r, obs, noise, buf, mean_action, slot, step_fn):
         c = self.cfg
         state = buf["states"][t, r]
@@ -109,7 +109,7 @@ class AgentPPO:
             a_env = self._prep_actions(a)
         obs, rew, died, timed_out, _ = step_fn(a_env)
         buf["rewards"][t, r] = rew
-        buf["dead"][t, r] = died                               # (bool -> uint8 row: one launch each; turned into the float masks once)
+        buf["dead"][t, r] = died                               # (boolean rows: one launch each; turned into the float masks once, in _rollout_out)
         torch.logical_or(died, timed_out, out=buf["done"][t, r])
         return obs
 
