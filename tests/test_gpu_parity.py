@@ -1075,6 +1075,32 @@ def test_fused_policy_inference_matches_the_torch_policy():
     assert torch.equal(a2, a) and logp.shape == (1500, 1) and torch.allclose(logp, want_lp, atol=2e-3)
 
 
+def test_gaussian_sample_kernel_matches_the_torch_expressions():
+    """ss_gaussian_sample (the sampler's Gaussian head in one launch) against what it replaces: PolicyGaussian.select_action's draw
+    (reference policy_gaussian.py:25-41 -> DiagGaussian.sample), Agent.preprocess_actions' clip (agents/agent.py:153-161) and
+    normal_log_density of the draw — on a strided destination (a row block of a rollout tensor), M not a multiple of 4."""
+    import math
+    from smplsim_amd.learning.fast_policy import FusedPolicyInference
+    from smplsim_amd.learning.networks import PolicyGaussian
+    torch.manual_seed(3)
+    pol = PolicyGaussian(289, 69, (64, 32)).cuda().eval()
+    with torch.no_grad():
+        pol.action_log_std.copy_(torch.linspace(-3.0, -0.5, 69, device="cuda")[None])
+    fast = FusedPolicyInference(pol)
+    M = 1001
+    mean, noise = torch.randn(M, 69, device="cuda"), torch.randn(M, 69, device="cuda")
+    rollout = torch.zeros(3, 2 * M, 69, device="cuda")
+    a_env, logp = torch.zeros(M, 69, device="cuda"), torch.zeros(M, 1, device="cuda")
+    fast.sample_into(mean, noise, rollout[1, M:], a_env, (-1.0, 1.0), logp)
+    torch.cuda.synchronize()
+    ls = pol.action_log_std.detach()
+    ref = mean + ls.exp() * noise
+    assert torch.allclose(rollout[1, M:], ref, rtol=0, atol=2e-6) and float(rollout[0].abs().max()) == 0 and float(rollout[1, :M].abs().max()) == 0
+    assert torch.equal(a_env, rollout[1, M:].clamp(-1.0, 1.0))
+    ref_lp = (-0.5 * noise.pow(2) - 0.5 * math.log(2.0 * math.pi) - ls).sum(1, keepdim=True)
+    assert torch.allclose(logp, ref_lp, rtol=1e-5, atol=1e-4)
+
+
 def test_env_built_before_fork_runs_in_worker_processes():
     """The reference's sampler builds the env once and forks its workers (agents/agent.py:121-145, num_threads > 1).  HumanoidEnv
     creates its device state lazily in the process that uses it: two forked workers and then the parent step the same env object,
