@@ -1,7 +1,7 @@
 // smplsim_hip.hip — gfx950 (MI355X) build of the wavefront env stepper + the C ABI (include/smplsim_hip.h).
 //
 // Launch geometry: one workgroup per CU = E persistent wavefronts, each stepping one environment at a time (E chosen
-// so that the shared index tables + E per-env LDS slices fit the CU's 160 KiB LDS: 12 for SMPL, 6 for SMPL-X); no
+// so that the shared index tables + E per-env LDS slices fit the CU's 160 KiB LDS: 12 for SMPL, 7 for SMPL-X); no
 // workgroup barrier after the table copy — the wavefronts of a workgroup never talk to each other.  4096 envs =
 // 3072 resident wave slots: the first env of a wave is static, the rest come from a device counter.
 #include <hip/hip_runtime.h>

@@ -9,13 +9,13 @@
 #include "ss_wave_gpu.h"
 
 // launch bounds per kernel variant = the number of envs whose LDS slices fit one CU, rounded up to whole waves per
-// SIMD.  SMPL: 12 envs -> 3 waves/SIMD -> 168-VGPR cap (16 spilled dwords at -O3, 47 at the shipped -Os, which is faster all the same).  SMPL-X: 6 envs (aliased LDS layout, round 5; 5 on the plain one) -> 2 waves/SIMD, 256 VGPRs,
+// SIMD.  SMPL: 12 envs -> 3 waves/SIMD -> 168-VGPR cap (16 spilled dwords at -O3, 47 at the shipped -Os, which is faster all the same).  SMPL-X: 7 envs (aliased LDS layout + lean tables, round 5; 5 on the plain one) -> 2 waves/SIMD, 256 VGPRs,
 // no spills.  (History of the trade-off: profiles/r01i_ab_launch_bounds.txt.)
 #ifndef SS_MAX_THREADS
 #define SS_MAX_THREADS 768
 #endif
 #ifndef SS_MAX_THREADS_X
-#define SS_MAX_THREADS_X 384
+#define SS_MAX_THREADS_X 448
 #endif
 // self-collision instantiation of the SMPL size: 8 envs at most share a CU -> 2 waves/SIMD, 256 VGPRs
 #ifndef SS_MAX_THREADS_SC

@@ -34,8 +34,9 @@ constexpr int kCandC = 8;    // floats per contact candidate
 // per-env LDS layout (float offsets) and physics scalars.
 struct Hdr {
   int nb, nn, nv, nq, nu, ncand, nlev, a_stride, nbox, nslot, maxlev;
-  int l_Rloc, l_w2;                  // a_stride, l_Rloc, l_w2 (round 5: the aliased layout below) sit in the slots of the pelvis-rooted level
-  unsigned long long reserved1;      // tables of rounds 1-2, which had been kept as padding: the offsets of the fields behind them are part of
+  int l_Rloc, l_w2;                  // a_stride, l_Rloc, l_w2, o_arm, lean (round 5: the aliased layout below and the lean tables of
+  int o_arm, lean;                   // ss_tables.h) sit in the slots of the pelvis-rooted level tables of rounds 1-2, which had been
+                                     // kept as padding: the offsets of the fields behind them are part of
                                      // the kernels' register allocation, and closing the gaps cost 0.7 % on the headline (same-box A/B,
                                      // profiles/r03_centred_elimination.md)
   // shared-blob word offsets
@@ -73,7 +74,7 @@ constexpr Layout make_layout(int nb, int maxlev, bool alias_w = false) {
   auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
   y.l_q = take(nv + 1); y.l_v = take(nv); y.l_a = take(nv); y.l_tau = take(nv);
   y.l_Fb = take(6 * nb);                                   // per-body bias force of the forward pass (gravity, velocity products): qfrc_bias = sum_b J_b^T Fb_b
-  y.l_act = take(nv - 6);                                  // the action the controller is tracking (one HBM read per control step, not per mj_step)
+  y.l_act = alias_w ? o : take(nv - 6);                    // the action the controller is tracking (one HBM read per control step, not per mj_step; the lean layout reads it from global memory)
   y.l_delta = take(nv);
   y.l_Pb = take(6 * nb);                                   // per-body force I a - f of the Newton iterate (bias of the sweeps)
   y.l_V = y.l_Pb;                                          // V (body velocities): dead after make_constraints
@@ -205,6 +206,7 @@ struct HdrC {
 struct HdrRuntime {
   typedef const Hdr &type;
   static constexpr bool fixed = false;
+  static SS_HD bool lean(const Hdr &h) { return h.lean != 0; }
   static SS_HD type view(const Hdr &h) { return h; }
   typedef const HdrC &tree_type;
   static SS_HD tree_type tree(const HdrC &c) { return c; }
@@ -230,7 +232,7 @@ struct HdrFixed {
                        a_stride = LY.a_stride, l_Rloc = LY.l_Rloc, l_w2 = LY.l_w2;
   const int &nu, &ncand, &nlev, &nbox, &nslot;
   const int &o_dofc, &o_boff, &o_chainnode, &o_ndepth, &o_bparent, &o_sumsmall, &o_sumbig, &o_sumcover, &n_sumsmall, &n_sumbig,
-      &shared_words;
+      &shared_words, &o_arm;
   const real &dt, &grav, &margin, &mu;
   const real (&solimp)[5];
   const real &K, &B;
@@ -239,18 +241,19 @@ struct HdrFixed {
       : nu(h.nu), ncand(h.ncand), nlev(h.nlev), nbox(h.nbox), nslot(h.nslot), o_dofc(h.o_dofc),
         o_boff(h.o_boff), o_chainnode(h.o_chainnode), o_ndepth(h.o_ndepth), o_bparent(h.o_bparent),
         o_sumsmall(h.o_sumsmall), o_sumbig(h.o_sumbig), o_sumcover(h.o_sumcover), n_sumsmall(h.n_sumsmall), n_sumbig(h.n_sumbig),
-        shared_words(h.shared_words), dt(h.dt), grav(h.grav), margin(h.margin), mu(h.mu), solimp(h.solimp), K(h.K), B(h.B),
+        shared_words(h.shared_words), o_arm(h.o_arm), dt(h.dt), grav(h.grav), margin(h.margin), mu(h.mu), solimp(h.solimp), K(h.K), B(h.B),
         qpos0_root(h.qpos0_root) {}
 };
-template <int NB, int MAXLEV, int NLEV, int ROOT, int PEL, unsigned long long NK0, unsigned long long CP, unsigned long long CH, unsigned long long NG, bool ALIAS = false>
+template <int NB, int MAXLEV, int NLEV, int ROOT, int PEL, unsigned long long NK0, unsigned long long CP, unsigned long long CH, unsigned long long NG, bool ALIAS = false, bool LEAN = ALIAS>
 struct HdrFixedT {
   typedef const HdrFixed<NB, MAXLEV, ALIAS> type;
   static constexpr bool fixed = true;
+  static SS_HD constexpr bool lean(const Hdr &) { return LEAN; }    // (lean tables belong to the model, the aliased layout to its plain batches: ss_tables.h)
   static SS_HD HdrFixed<NB, MAXLEV, ALIAS> view(const Hdr &h) { return HdrFixed<NB, MAXLEV, ALIAS>(h); }
   typedef const TreeFixed<NLEV, ROOT, PEL, NK0, CP, CH, NG> tree_type;
   static SS_HD TreeFixed<NLEV, ROOT, PEL, NK0, CP, CH, NG> tree(const HdrC &c) { TreeFixed<NLEV, ROOT, PEL, NK0, CP, CH, NG> t; t.o_lev = c.o_lev; return t; }
   static bool matches(const Hdr &h, const HdrC &c) {
-    return h.nb == NB && h.maxlev == MAXLEV && h.a_stride == (ALIAS ? 24 : 21) && h.env_floats == HdrFixed<NB, MAXLEV, ALIAS>::env_floats && c.nlev == NLEV && c.root == ROOT && c.pel_level == PEL && c.nkpack[0] == NK0 && c.nkpack[1] == 0ull && c.cpack == CP && c.chain == CH && c.neg == NG;
+    return h.nb == NB && h.maxlev == MAXLEV && h.a_stride == (ALIAS ? 24 : 21) && (h.lean != 0) == LEAN && h.env_floats == HdrFixed<NB, MAXLEV, ALIAS>::env_floats && c.nlev == NLEV && c.root == ROOT && c.pel_level == PEL && c.nkpack[0] == NK0 && c.nkpack[1] == 0ull && c.cpack == CP && c.chain == CH && c.neg == NG;
   }
 };
 
@@ -260,7 +263,7 @@ struct HdrFixedT {
 //  mask of the 1:1 levels, mask of the levels with a negated motion subspace)
 typedef HdrFixedT<24, 5, 6, 10, 2, 0x333431ull, 0x1253ull, 0x1cull, 0x3ull> HdrSmplFixed;       // SMPL: 24 bodies; rooted at the Spine: levels of 2 4 5 4 4 4 nodes
 typedef HdrFixedT<52, 12, 7, 11, 3, 0xbbb3233ull, 0x9a89ull, 0x33ull, 0x7ull, true> HdrSmplxFixed;    // SMPL-X/H: 52 bodies; rooted at the Chest: levels of 4 4 3 4 12 12 12 nodes; aliased (W, y)
-typedef HdrFixedT<52, 12, 7, 11, 3, 0xbbb3233ull, 0x9a89ull, 0x33ull, 0x7ull, false> HdrSmplxFixedSC;  // the same tree on the plain layout: body-body-contact batches (their dense system lives in Aown .. (W, y))
+typedef HdrFixedT<52, 12, 7, 11, 3, 0xbbb3233ull, 0x9a89ull, 0x33ull, 0x7ull, false, true> HdrSmplxFixedSC;  // the same tree on the plain layout: body-body-contact batches (their dense system lives in Aown .. (W, y))
 
 // compiled kernel variants: 0 = SMPL-sized (<= 128 dofs / candidates, <= 64 contact slots, <= 8 nodes per tree level),
 // 1 = SMPL-X/H-sized (<= 192 dofs / candidates, <= 128 slots, <= 16 nodes per level); -1 = none fits

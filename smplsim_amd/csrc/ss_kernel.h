@@ -140,6 +140,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
   const KArgs *k;
   const uint32_t *T;      // shared tables in LDS (integer tables, then the real-valued ones)
   int lane, env;
+  const real *act_g;      // lean models: the action the controller is tracking, in global memory
   // per-env LDS arrays
   real *S, *R, *r, *V, *Ab, *An, *Ad, *Gb, *tmpb, *Aown, *IA, *Ubuf, *Wst, *Rlocp, *w2p, *q, *v, *a, *tau, *Pb, *delta, *Fb, *actl, *diag, *Iown;
   // per-lane constants
@@ -164,7 +165,14 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
 #else
   SS_DEV real tf(int off, int i) const { union { uint32_t u; float f; } c; c.u = T[off + i]; return c.f; }
 #endif
-  SS_DEV real dc(int dof, int f) const { return tf(k->h.o_dofc, dof * kDofC + f); }
+  // dof constants: in the workgroup's LDS tables, or — lean models (ss_tables.h: the SMPL-X size class) — in the global copy of the
+  // blob (L1-resident: read once or twice per mj_step and lane), with the armature, which the Newton iteration reads, in an LDS
+  // column of its own
+  SS_DEV real tfg(int off, int i) const { return reinterpret_cast<const real *>(k->shared_g)[off + i]; }
+  SS_DEV real dc(int dof, int f) const { return HT::lean(k->h) ? tfg(k->h.o_dofc, dof * kDofC + f) : tf(k->h.o_dofc, dof * kDofC + f); }
+  SS_DEV float4_t dcq(int dof, int qd) const { return ld4(reinterpret_cast<const real *>(k->shared_g) + k->h.o_dofc + dof * kDofC + 4 * qd); }   // lean: columns 4 qd .. 4 qd + 3 of a dof's row
+  SS_DEV real armature(int dof) const { return HT::lean(k->h) ? tf(k->h.o_arm, dof) : tf(k->h.o_dofc, dof * kDofC); }
+  SS_DEV real action_at(int ai) const { return HT::lean(k->h) ? act_g[ai] : actl[ai]; }   // the tracked action: LDS copy, or (lean) global
   SS_DEV typename HT::type hdr() const { return HT::view(k->h); }
   SS_DEV const real *bodyc() const { if constexpr (SHAPED) return this->bodyc_s; else return k->bodyc; }
   SS_DEV const real *candc() const { if constexpr (SHAPED) return this->candc_s; else return k->candc; }
@@ -176,7 +184,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
   SS_DEV int h_caps_body(int sl) const { int e = sl - 4 * k->h.nbox; int ci = 8 * k->h.nbox + e; return ci < k->h.ncand ? (k->candb[ci] & 255) : 0; }
 
   SS_DEV void init(W *w_, const KArgs *k_, const uint32_t *T_, real *L, int env_, real *pool_ = nullptr) {
-    w = w_; k = k_; T = T_; lane = w->lane(); env = env_;
+    w = w_; k = k_; T = T_; lane = w->lane(); env = env_; act_g = nullptr;
     typename HT::type h = HT::view(k->h);
     if constexpr (SHAPED) {
       const size_t sid = (size_t)k->st.shape_id[env];
@@ -684,8 +692,12 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       int i = p * 64 + lane;
       Limit &l = lim[p];
       l.sign = 0.f; l.D = 0.f; l.aref = 0.f; l.jar = 0.f; l.jd = 0.f;
-      if (i >= 6 && i < h.nv && dc(i, 3) != 0.f) {
-        real qi = q[i + 1], lo = dc(i, 1), hi = dc(i, 2), pos = 0.f;
+      // (lean models: the dof's constants come from global memory — one 16-byte read of (armature, lo, hi, limited) per dof, all of a
+      // lane's dofs requested before the first is used, instead of dependent scalar reads)
+      float4_t c0 = {};
+      if (HT::lean(k->h)) { if (i >= 6 && i < h.nv) c0 = dcq(i, 0); }
+      if (i >= 6 && i < h.nv && (HT::lean(k->h) ? c0.w : dc(i, 3)) != 0.f) {
+        real qi = q[i + 1], lo = HT::lean(k->h) ? c0.y : dc(i, 1), hi = HT::lean(k->h) ? c0.z : dc(i, 2), pos = 0.f;
         if (qi - lo < 0.f) { l.sign = 1.f; pos = qi - lo; }
         else if (hi - qi < 0.f) { l.sign = -1.f; pos = hi - qi; }
         if (l.sign != 0.f) {
@@ -1651,7 +1663,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
       w->sync();
       for (int i = lane; i < h.nv; i += 64) {
         const int n = i / 3, b = n > 0 ? n - 1 : 0;
-        real s_ = i == j ? dc(i, 0) : 0.f;
+        real s_ = i == j ? armature(i) : 0.f;
 #pragma unroll
         for (int c = 0; c < 6; c++) s_ += S[6 * i + c] * Gb[6 * b + c];
         out[(size_t)j * h.nv + i] = s_;
@@ -1773,8 +1785,8 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
     for (int p = 0; p < DOFP; p++) {
       int i = p * 64 + lane;
       if (i < h.nv) {
-        real s_ = dc(i, 0) * a[i] - tau[i];                  // (the bias force is part of Pb)
-        real dg = dc(i, 0);
+        real s_ = armature(i) * a[i] - tau[i];               // (the bias force is part of Pb)
+        real dg = armature(i);
         const Limit &l = lim[p];
         if (l.sign != 0.f && l.jar < 0.f) { s_ += l.sign * l.D * l.jar; dg += l.D; }
         diag[i] = dg; delta[i] = -s_;
@@ -1839,7 +1851,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
     for (int p = 0; p < DOFP; p++) {                          // delta . gradient, joint-space part (same terms as newton_prepare)
       int i = p * 64 + lane;
       if (i < h.nv) {
-        real s_ = dc(i, 0) * a[i] - tau[i];
+        real s_ = armature(i) * a[i] - tau[i];
         const Limit &l = lim[p];
         if (l.sign != 0.f && l.jar < 0.f) s_ += l.sign * l.D * l.jar;
         const real t_ = delta[i] * s_;
@@ -1975,7 +1987,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
         real t = 0.f;
         if (dc(i, 10) != 0.f) {
           const int ai = (int)dc(i, 11);
-          real act = actl[ai] + abias, lim_ = dc(i, 7);
+          real act = action_at(ai) + abias, lim_ = dc(i, 7);
           if (mode == SS_CTRL_DEFAULT) t = act;                // ctrl = action, unscaled and unclipped (humanoid_env.py:409-410)
           else {
             if (mode == SS_CTRL_PD) t = -dc(i, 5) * (q[i + 1] - (act * dc(i, 8) + dc(i, 9))) - dc(i, 6) * v[i];
@@ -2004,14 +2016,38 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
     fresh();
     typename HT::type h = HT::view(k->h);
     write_own_inertia();
+    if (HT::lean(k->h)) {
+      // lean models: a dof's constants are two 16-byte global reads — (invweight, kp, kd, torque limit), (scale, offset, actuated,
+      // actuator) — requested for all of the lane's dofs at once, then the tracked action (one dependent read each), then the arithmetic
+      // of the loop below, term for term
+      float4_t c1[DOFP], c2[DOFP];
+      real av[DOFP];
+#pragma unroll
+      for (int p = 0; p < DOFP; p++) { const int i = p * 64 + lane; c1[p] = float4_t{}; c2[p] = float4_t{}; if (i < h.nv) { c1[p] = dcq(i, 1); c2[p] = dcq(i, 2); } }
+#pragma unroll
+      for (int p = 0; p < DOFP; p++) av[p] = c2[p].z != 0.f ? act_g[(int)c2[p].w] : real(0);
+#pragma unroll
+      for (int p = 0; p < DOFP; p++) {
+        const int i = p * 64 + lane;
+        perr[p] = 0.f;
+        if (i < h.nv) {
+          const real kp = c1[p].y, kd = c1[p].z;
+          if (c2[p].z != 0.f) perr[p] = q[i + 1] + v[i] * h.dt - ((av[p] + abias) * c2[p].x + c2[p].y);
+          diag[i] = armature(i) + kd * h.dt;
+          delta[i] = -kp * perr[p] - kd * v[i];
+        }
+      }
+      w->sync();
+      return;
+    }
 #pragma unroll
     for (int p = 0; p < DOFP; p++) {
       int i = p * 64 + lane;
       perr[p] = 0.f;
       if (i < h.nv) {
         real kp = dc(i, 5), kd = dc(i, 6);
-        if (dc(i, 10) != 0.f) perr[p] = q[i + 1] + v[i] * h.dt - ((actl[(int)dc(i, 11)] + abias) * dc(i, 8) + dc(i, 9));
-        diag[i] = dc(i, 0) + kd * h.dt;
+        if (dc(i, 10) != 0.f) perr[p] = q[i + 1] + v[i] * h.dt - ((action_at((int)dc(i, 11)) + abias) * dc(i, 8) + dc(i, 9));
+        diag[i] = armature(i) + kd * h.dt;
         delta[i] = -kp * perr[p] - kd * v[i];                // (-C: the solve takes Fb as its per-body bias)
       }
     }
@@ -2020,6 +2056,26 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
   SS_DEV void spd_finish() {
     fresh();
     typename HT::type h = HT::view(k->h);
+    if (HT::lean(k->h)) {                                    // (as in spd_prepare: the rows first, then the loop below term for term)
+      float4_t c1[DOFP], c2[DOFP];
+#pragma unroll
+      for (int p = 0; p < DOFP; p++) { const int i = p * 64 + lane; c1[p] = float4_t{}; c2[p] = float4_t{}; if (i < h.nv) { c1[p] = dcq(i, 1); c2[p] = dcq(i, 2); } }
+#pragma unroll
+      for (int p = 0; p < DOFP; p++) {
+        const int i = p * 64 + lane;
+        if (i < h.nv) {
+          real t = 0.f;
+          if (c2[p].z != 0.f) {
+            const real lim_ = c1[p].w;
+            t = -c1[p].y * perr[p] - c1[p].z * (v[i] + delta[i] * h.dt);
+            t = SS_M(fmin)(SS_M(fmax)(t, -lim_), lim_);
+          }
+          tau[i] = t;
+        }
+      }
+      w->sync();
+      return;
+    }
 #pragma unroll
     for (int p = 0; p < DOFP; p++) {
       int i = p * 64 + lane;
@@ -2292,7 +2348,9 @@ SS_DEV bool run_env(W *w, const KArgs *k, const uint32_t *T, real *L, int env, i
       if (solve == SOLVE_NEWTON) { sim.newton_prepare(); SS_TICK(PF_NPREP); }
       else if (solve == SOLVE_SPD) {
         if (next_action != cached_action) {                  // the action in LDS: one HBM read per control step (per Fall-reset segment)
-          sim.load(sim.actl, next_action, h.nu); cached_action = next_action; w->sync();
+          if (HT::lean(k->h)) sim.act_g = next_action;        // (lean models read the action where it is)
+          else { sim.load(sim.actl, next_action, h.nu); w->sync(); }
+          cached_action = next_action;
         }
         if (cf.control_mode != SS_CTRL_UHC_PD) { sim.simple_controller(abias); break; }
         sim.spd_prepare(abias);

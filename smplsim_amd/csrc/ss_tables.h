@@ -223,10 +223,9 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   int maxlev = 0;                                           // widest level of the elimination tree (below)
   auto &S = out.shared; S.clear();
   auto push_i = [&](const std::vector<int> &v) { int o = (int)S.size(); for (int x : v) S.push_back((uint32_t)x); return o; };
-  std::vector<real> Sf;                                    // real-valued tables, appended behind the integer ones below
-  h.o_dofc = (int)Sf.size(); Sf.insert(Sf.end(), dofc.begin(), dofc.end());
-  h.o_boff = (int)Sf.size();                               // body frame offsets in the parent frame (chain walk of forward_kin)
-  for (int b = 0; b < nb; b++) for (int k = 0; k < 3; k++) Sf.push_back(b == 0 ? real(0) : (real)d.body_pos[3 * b + k]);
+  std::vector<real> Sf;                                    // real-valued tables, appended behind the integer ones below (assembled there)
+  std::vector<real> boffv;                                 // body frame offsets in the parent frame (chain walk of forward_kin)
+  for (int b = 0; b < nb; b++) for (int k = 0; k < 3; k++) boffv.push_back(b == 0 ? real(0) : (real)d.body_pos[3 * b + k]);
   h.o_chainnode = push_i(chainnode);
   h.o_ndepth = push_i(ndepth);
   std::vector<int> bpar(d.body_parent, d.body_parent + nb);
@@ -347,13 +346,34 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
     if (maxlev < 1) maxlev = 1;
     h.maxlev = maxlev;                                        // sizes the level buffer of the LDS layout
   }
+  // The SMPL-X size class (more than 32 bodies: LDS, not the register file, caps its resident envs; round 5) runs LEAN: the aliased
+  // env-slice layout (ss_hdr.h make_layout) and the dof-constant table left in global memory — 12 reals per dof = 7.6 KB of the
+  // workgroup's LDS for 52 bodies, read once or twice per mj_step per lane (limits, Stable PD: L1-resident), except the armature, which
+  // the Newton iteration reads and which keeps a column of its own in LDS.  Together with the action read from global memory instead
+  // of an LDS copy that is a seventh resident env per CU.  The LDS copy of the blob is its prefix of h.shared_words words; the dof
+  // table lies behind it.
+  const bool alias = nb > 32 && alias_layout_fits(nb, maxlev, h.nslot) && !std::getenv("SS_NO_ALIAS_LAYOUT");
+  h.lean = alias ? 1 : 0;
+  int lds_reals;
+  if (alias) {
+    h.o_boff = (int)Sf.size(); Sf.insert(Sf.end(), boffv.begin(), boffv.end());
+    h.o_arm = (int)Sf.size(); for (int i = 0; i < nv; i++) Sf.push_back(dofc[i * kDofC]);
+    while (Sf.size() % 4) Sf.push_back(real(0));
+    lds_reals = (int)Sf.size();
+    h.o_dofc = (int)Sf.size(); Sf.insert(Sf.end(), dofc.begin(), dofc.end());
+  } else {
+    h.o_dofc = (int)Sf.size(); Sf.insert(Sf.end(), dofc.begin(), dofc.end());
+    h.o_boff = (int)Sf.size(); Sf.insert(Sf.end(), boffv.begin(), boffv.end());
+    h.o_arm = 0;
+    lds_reals = (int)Sf.size();
+  }
   while (S.size() % 4) S.push_back(0u);                     // reals start 16-byte aligned
   out.o_real = (int)S.size();
   S.resize(S.size() + Sf.size() * (sizeof(real) / 4));
   std::memcpy(S.data() + out.o_real, Sf.data(), Sf.size() * sizeof(real));
-  h.shared_words = (int)S.size();
+  h.shared_words = out.o_real + lds_reals * (int)(sizeof(real) / 4);   // what a workgroup copies into LDS (the whole blob unless lean)
   const int real0 = out.o_real / (int)(sizeof(real) / 4);   // kernel-side offsets count reals from the start of the blob
-  h.o_dofc += real0; h.o_boff += real0;
+  h.o_dofc += real0; h.o_boff += real0; h.o_arm += real0;
 
   // ---- per-env LDS layout (floats); arrays with disjoint lifetimes share storage (LDS capacity sets the number
   // of resident envs per CU)
@@ -365,10 +385,9 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
     g.l_q = y.l_q; g.l_v = y.l_v; g.l_a = y.l_a; g.l_tau = y.l_tau; g.l_Fb = y.l_Fb; g.l_act = y.l_act; g.l_delta = y.l_delta; g.l_Pb = y.l_Pb; g.l_V = y.l_V;
     g.l_diag = y.l_diag; g.l_S = y.l_S; g.l_Ab = y.l_Ab; g.l_Iown = y.l_Iown; g.l_An = y.l_An; g.l_Aown = y.l_Aown; g.ia_stride = y.ia_stride;
     g.l_IA = y.l_IA; g.l_Gb = y.l_Gb; g.l_tmp = y.l_tmp; g.l_Ubuf = y.l_Ubuf; g.l_Wst = y.l_Wst; g.l_R = y.l_R; g.l_r = y.l_r;
-    g.a_stride = y.a_stride; g.l_Rloc = y.l_Rloc; g.l_w2 = y.l_w2; g.reserved1 = 0ull;
+    g.a_stride = y.a_stride; g.l_Rloc = y.l_Rloc; g.l_w2 = y.l_w2;
     g.env_floats = y.env_floats;
   };
-  const bool alias = nb > 32 && alias_layout_fits(nb, maxlev, h.nslot) && !std::getenv("SS_NO_ALIAS_LAYOUT");
   {
     const Layout y = make_layout(nb, maxlev, false);
     fill(h, y);

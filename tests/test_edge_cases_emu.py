@@ -321,7 +321,7 @@ def test_aliased_lds_layout_is_bit_identical_to_the_plain_one(generic, monkeypat
             if t == 1:
                 rec.append(eb.reset(mask=np.array([1, 0, 0], np.uint8), task_rand=np.full((3, 4), 0.3)))
         outs.append(rec)
-    assert per_wg == [6, 5]                                   # what the layout is for
+    assert per_wg == [7, 5]                                   # what the layout (and the lean tables) are for
     for x, y in zip(*outs):
         assert np.array_equal(x, y)
     assert max(r.max() for r in outs[0][4::6] if r.dtype == np.int32) > 15
