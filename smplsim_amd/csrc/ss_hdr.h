@@ -34,9 +34,11 @@ constexpr int kCandC = 8;    // floats per contact candidate
 // per-env LDS layout (float offsets) and physics scalars.
 struct Hdr {
   int nb, nn, nv, nq, nu, ncand, nlev, a_stride, nbox, nslot, maxlev;
-  int l_Rloc, l_w2;                  // a_stride, l_Rloc, l_w2, o_arm, lean (round 5: the aliased layout below and the lean tables of
-  int o_arm, lean;                   // ss_tables.h) sit in the slots of the pelvis-rooted level tables of rounds 1-2, which had been
-                                     // kept as padding: the offsets of the fields behind them are part of
+  int l_Rloc, l_w2;                  // a_stride, l_Rloc, l_w2 and arm_lean (round 5: the aliased layout below and the lean tables of
+  unsigned long long arm_lean;       // ss_tables.h; low word = o_arm, high word = lean: ONE 64-bit member — two ints in its place lower the
+                                     // struct's alignment to 4, which moves the kernel arguments behind it and cost the SMPL headline kernel
+                                     // 950 more v_readlane reloads, -1.6 %) sit in the slots of the pelvis-rooted level tables of rounds 1-2,
+                                     // which had been kept as padding: the offsets of the fields behind them are part of
                                      // the kernels' register allocation, and closing the gaps cost 0.7 % on the headline (same-box A/B,
                                      // profiles/r03_centred_elimination.md)
   // shared-blob word offsets
@@ -203,10 +205,13 @@ struct HdrC {
 #else
 #define SS_HD inline __attribute__((always_inline))
 #endif
+SS_HD int hdr_o_arm(const Hdr &h) { return (int)(h.arm_lean & 0xffffffffull); }
+SS_HD bool hdr_lean(const Hdr &h) { return (h.arm_lean >> 32) != 0ull; }
 struct HdrRuntime {
   typedef const Hdr &type;
   static constexpr bool fixed = false;
-  static SS_HD bool lean(const Hdr &h) { return h.lean != 0; }
+  static SS_HD bool lean(const Hdr &h) { return hdr_lean(h); }
+  static constexpr bool maybe_lean = true;
   static SS_HD type view(const Hdr &h) { return h; }
   typedef const HdrC &tree_type;
   static SS_HD tree_type tree(const HdrC &c) { return c; }
@@ -232,7 +237,7 @@ struct HdrFixed {
                        a_stride = LY.a_stride, l_Rloc = LY.l_Rloc, l_w2 = LY.l_w2;
   const int &nu, &ncand, &nlev, &nbox, &nslot;
   const int &o_dofc, &o_boff, &o_chainnode, &o_ndepth, &o_bparent, &o_sumsmall, &o_sumbig, &o_sumcover, &n_sumsmall, &n_sumbig,
-      &shared_words, &o_arm;
+      &shared_words;
   const real &dt, &grav, &margin, &mu;
   const real (&solimp)[5];
   const real &K, &B;
@@ -241,7 +246,7 @@ struct HdrFixed {
       : nu(h.nu), ncand(h.ncand), nlev(h.nlev), nbox(h.nbox), nslot(h.nslot), o_dofc(h.o_dofc),
         o_boff(h.o_boff), o_chainnode(h.o_chainnode), o_ndepth(h.o_ndepth), o_bparent(h.o_bparent),
         o_sumsmall(h.o_sumsmall), o_sumbig(h.o_sumbig), o_sumcover(h.o_sumcover), n_sumsmall(h.n_sumsmall), n_sumbig(h.n_sumbig),
-        shared_words(h.shared_words), o_arm(h.o_arm), dt(h.dt), grav(h.grav), margin(h.margin), mu(h.mu), solimp(h.solimp), K(h.K), B(h.B),
+        shared_words(h.shared_words), dt(h.dt), grav(h.grav), margin(h.margin), mu(h.mu), solimp(h.solimp), K(h.K), B(h.B),
         qpos0_root(h.qpos0_root) {}
 };
 template <int NB, int MAXLEV, int NLEV, int ROOT, int PEL, unsigned long long NK0, unsigned long long CP, unsigned long long CH, unsigned long long NG, bool ALIAS = false, bool LEAN = ALIAS>
@@ -249,11 +254,12 @@ struct HdrFixedT {
   typedef const HdrFixed<NB, MAXLEV, ALIAS> type;
   static constexpr bool fixed = true;
   static SS_HD constexpr bool lean(const Hdr &) { return LEAN; }    // (lean tables belong to the model, the aliased layout to its plain batches: ss_tables.h)
+  static constexpr bool maybe_lean = LEAN;
   static SS_HD HdrFixed<NB, MAXLEV, ALIAS> view(const Hdr &h) { return HdrFixed<NB, MAXLEV, ALIAS>(h); }
   typedef const TreeFixed<NLEV, ROOT, PEL, NK0, CP, CH, NG> tree_type;
   static SS_HD TreeFixed<NLEV, ROOT, PEL, NK0, CP, CH, NG> tree(const HdrC &c) { TreeFixed<NLEV, ROOT, PEL, NK0, CP, CH, NG> t; t.o_lev = c.o_lev; return t; }
   static bool matches(const Hdr &h, const HdrC &c) {
-    return h.nb == NB && h.maxlev == MAXLEV && h.a_stride == (ALIAS ? 24 : 21) && (h.lean != 0) == LEAN && h.env_floats == HdrFixed<NB, MAXLEV, ALIAS>::env_floats && c.nlev == NLEV && c.root == ROOT && c.pel_level == PEL && c.nkpack[0] == NK0 && c.nkpack[1] == 0ull && c.cpack == CP && c.chain == CH && c.neg == NG;
+    return h.nb == NB && h.maxlev == MAXLEV && h.a_stride == (ALIAS ? 24 : 21) && hdr_lean(h) == LEAN && h.env_floats == HdrFixed<NB, MAXLEV, ALIAS>::env_floats && c.nlev == NLEV && c.root == ROOT && c.pel_level == PEL && c.nkpack[0] == NK0 && c.nkpack[1] == 0ull && c.cpack == CP && c.chain == CH && c.neg == NG;
   }
 };
 

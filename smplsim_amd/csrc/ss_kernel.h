@@ -134,13 +134,17 @@ template <> struct SelfColState<true> {
   unsigned long long amask;                                // contacts with an active pyramid row at the current Newton iterate (newton_prepare)
 };
 
+// lean models (ss_tables.h) read the tracked action where it lies in global memory: the pointer exists only in the instantiations that
+// can run such a model (a member the SMPL headline kernel does not have: its register allocation is sensitive to every live value)
+template <bool MAYBE_LEAN> struct LeanState { const real *act_g = nullptr; SS_DEV const real *action_ptr() const { return act_g; } SS_DEV void set_action_ptr(const real *p) { act_g = p; } };
+template <> struct LeanState<false> { SS_DEV const real *action_ptr() const { return nullptr; } SS_DEV void set_action_ptr(const real *) {} };
+
 template <class W, int DOFP, int CANDP, int SLOTP, int NPASS, bool SHAPED = false, class HT = HdrRuntime, bool SELFCOL = false>
-struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
+struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL>, LeanState<HT::maybe_lean> {
   W *w;
   const KArgs *k;
   const uint32_t *T;      // shared tables in LDS (integer tables, then the real-valued ones)
   int lane, env;
-  const real *act_g;      // lean models: the action the controller is tracking, in global memory
   // per-env LDS arrays
   real *S, *R, *r, *V, *Ab, *An, *Ad, *Gb, *tmpb, *Aown, *IA, *Ubuf, *Wst, *Rlocp, *w2p, *q, *v, *a, *tau, *Pb, *delta, *Fb, *actl, *diag, *Iown;
   // per-lane constants
@@ -171,8 +175,8 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
   SS_DEV real tfg(int off, int i) const { return reinterpret_cast<const real *>(k->shared_g)[off + i]; }
   SS_DEV real dc(int dof, int f) const { return HT::lean(k->h) ? tfg(k->h.o_dofc, dof * kDofC + f) : tf(k->h.o_dofc, dof * kDofC + f); }
   SS_DEV float4_t dcq(int dof, int qd) const { return ld4(reinterpret_cast<const real *>(k->shared_g) + k->h.o_dofc + dof * kDofC + 4 * qd); }   // lean: columns 4 qd .. 4 qd + 3 of a dof's row
-  SS_DEV real armature(int dof) const { return HT::lean(k->h) ? tf(k->h.o_arm, dof) : tf(k->h.o_dofc, dof * kDofC); }
-  SS_DEV real action_at(int ai) const { return HT::lean(k->h) ? act_g[ai] : actl[ai]; }   // the tracked action: LDS copy, or (lean) global
+  SS_DEV real armature(int dof) const { return HT::lean(k->h) ? tf(hdr_o_arm(k->h), dof) : tf(k->h.o_dofc, dof * kDofC); }
+  SS_DEV real action_at(int ai) const { return HT::lean(k->h) ? this->action_ptr()[ai] : actl[ai]; }   // the tracked action: LDS copy, or (lean) global
   SS_DEV typename HT::type hdr() const { return HT::view(k->h); }
   SS_DEV const real *bodyc() const { if constexpr (SHAPED) return this->bodyc_s; else return k->bodyc; }
   SS_DEV const real *candc() const { if constexpr (SHAPED) return this->candc_s; else return k->candc; }
@@ -184,7 +188,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
   SS_DEV int h_caps_body(int sl) const { int e = sl - 4 * k->h.nbox; int ci = 8 * k->h.nbox + e; return ci < k->h.ncand ? (k->candb[ci] & 255) : 0; }
 
   SS_DEV void init(W *w_, const KArgs *k_, const uint32_t *T_, real *L, int env_, real *pool_ = nullptr) {
-    w = w_; k = k_; T = T_; lane = w->lane(); env = env_; act_g = nullptr;
+    w = w_; k = k_; T = T_; lane = w->lane(); env = env_;
     typename HT::type h = HT::view(k->h);
     if constexpr (SHAPED) {
       const size_t sid = (size_t)k->st.shape_id[env];
@@ -2025,7 +2029,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL> {
 #pragma unroll
       for (int p = 0; p < DOFP; p++) { const int i = p * 64 + lane; c1[p] = float4_t{}; c2[p] = float4_t{}; if (i < h.nv) { c1[p] = dcq(i, 1); c2[p] = dcq(i, 2); } }
 #pragma unroll
-      for (int p = 0; p < DOFP; p++) av[p] = c2[p].z != 0.f ? act_g[(int)c2[p].w] : real(0);
+      for (int p = 0; p < DOFP; p++) av[p] = c2[p].z != 0.f ? this->action_ptr()[(int)c2[p].w] : real(0);
 #pragma unroll
       for (int p = 0; p < DOFP; p++) {
         const int i = p * 64 + lane;
@@ -2348,9 +2352,8 @@ SS_DEV bool run_env(W *w, const KArgs *k, const uint32_t *T, real *L, int env, i
       if (solve == SOLVE_NEWTON) { sim.newton_prepare(); SS_TICK(PF_NPREP); }
       else if (solve == SOLVE_SPD) {
         if (next_action != cached_action) {                  // the action in LDS: one HBM read per control step (per Fall-reset segment)
-          if (HT::lean(k->h)) sim.act_g = next_action;        // (lean models read the action where it is)
-          else { sim.load(sim.actl, next_action, h.nu); w->sync(); }
-          cached_action = next_action;
+          if (HT::lean(k->h)) { sim.set_action_ptr(next_action); cached_action = next_action; }   // (lean models read the action where it is)
+          else { sim.load(sim.actl, next_action, h.nu); cached_action = next_action; w->sync(); }
         }
         if (cf.control_mode != SS_CTRL_UHC_PD) { sim.simple_controller(abias); break; }
         sim.spd_prepare(abias);

@@ -353,18 +353,16 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   // of an LDS copy that is a seventh resident env per CU.  The LDS copy of the blob is its prefix of h.shared_words words; the dof
   // table lies behind it.
   const bool alias = nb > 32 && alias_layout_fits(nb, maxlev, h.nslot) && !std::getenv("SS_NO_ALIAS_LAYOUT");
-  h.lean = alias ? 1 : 0;
-  int lds_reals;
+  int lds_reals, o_arm = 0;
   if (alias) {
     h.o_boff = (int)Sf.size(); Sf.insert(Sf.end(), boffv.begin(), boffv.end());
-    h.o_arm = (int)Sf.size(); for (int i = 0; i < nv; i++) Sf.push_back(dofc[i * kDofC]);
+    o_arm = (int)Sf.size(); for (int i = 0; i < nv; i++) Sf.push_back(dofc[i * kDofC]);
     while (Sf.size() % 4) Sf.push_back(real(0));
     lds_reals = (int)Sf.size();
     h.o_dofc = (int)Sf.size(); Sf.insert(Sf.end(), dofc.begin(), dofc.end());
   } else {
     h.o_dofc = (int)Sf.size(); Sf.insert(Sf.end(), dofc.begin(), dofc.end());
     h.o_boff = (int)Sf.size(); Sf.insert(Sf.end(), boffv.begin(), boffv.end());
-    h.o_arm = 0;
     lds_reals = (int)Sf.size();
   }
   while (S.size() % 4) S.push_back(0u);                     // reals start 16-byte aligned
@@ -373,7 +371,8 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   std::memcpy(S.data() + out.o_real, Sf.data(), Sf.size() * sizeof(real));
   h.shared_words = out.o_real + lds_reals * (int)(sizeof(real) / 4);   // what a workgroup copies into LDS (the whole blob unless lean)
   const int real0 = out.o_real / (int)(sizeof(real) / 4);   // kernel-side offsets count reals from the start of the blob
-  h.o_dofc += real0; h.o_boff += real0; h.o_arm += real0;
+  h.o_dofc += real0; h.o_boff += real0;
+  h.arm_lean = (unsigned long long)(uint32_t)(alias ? o_arm + real0 : 0) | ((unsigned long long)(alias ? 1 : 0) << 32);
 
   // ---- per-env LDS layout (floats); arrays with disjoint lifetimes share storage (LDS capacity sets the number
   // of resident envs per CU)
