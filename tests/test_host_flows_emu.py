@@ -143,6 +143,32 @@ def test_per_env_shapes_through_the_python_api_on_the_emulator(emu_backend):
         SMPLSimVecEnv(2, model=ShardModel(xmls=xmls), shape_id=[0, 5])
 
 
+def test_per_env_shapes_on_the_52_body_layout(emu_backend):
+    """The SMPL-X size class with per-env body shapes: the SHAPED generic kernel on the aliased LDS layout with lean tables (round 5: dof
+    constants in global memory, per-shape inverse weights and body offsets from the shape tables) — every env equals the single-shape env
+    of its own MJCF bit for bit, through floor contacts."""
+    from smplsim_amd.batch import ShardModel, SMPLSimVecEnv
+    from smplsim_amd.mjcf_writer import scaled_xml_str
+    from smplsim_amd.shapes import ShapeVariedVecEnv
+    xmls = [scaled_xml_str("smplx_humanoid", 1.0), scaled_xml_str("smplx_humanoid", 0.92, {"L_Knee": 1.08})]
+    env = ShapeVariedVecEnv(xmls, [1, 2], autoreset=False, seed=0)
+    assert env.num_envs == 3 and env.shape_id.tolist() == [0, 1, 1]
+    solos = [SMPLSimVecEnv(1, model=ShardModel(xml=x), autoreset=False) for x in xmls]
+    obs, _ = env.reset()
+    so = [e.reset()[0][0].clone() for e in solos]
+    assert torch.equal(obs[0], so[0]) and torch.equal(obs[1], so[1]) and torch.equal(obs[2], so[1]) and not torch.equal(obs[0], obs[1])
+    for e in [env.single] + solos:                                # dropped onto the floor: contacts, limits, Newton iterations
+        q = e.qpos.clone(); q[:, 2] = 0.4
+        e.set_state(q, e.qvel.clone())
+    g = torch.Generator(); g.manual_seed(2)
+    for _ in range(2):
+        a = torch.rand(3, env.nu, generator=g) * 1.2 - 0.6
+        o = env.step(a)[0]
+        o0, o1 = solos[0].step(a[:1])[0][0], solos[1].step(a[1:2])[0][0]
+        assert torch.equal(o[0], o0) and torch.equal(o[1], o1)
+    assert int(env.single.solver_iters.max()) > 15
+
+
 def test_native_mjcf_compiler_through_the_python_api_on_the_emulator(emu_backend):
     """ShardModel(compiler="native") = ss_model_create_from_mjcf: the same env, bit for bit, as the Python compiler's model."""
     from smplsim_amd.batch import ShardModel, SMPLSimVecEnv
