@@ -28,6 +28,10 @@ and, since round 4:
                       bad-state autoresets (mjWARN_BADQPOS / BADQVEL / BADQACC), the histogram of Newton iterations per mj_step
                       and of simultaneous contacts: what bench.py reports as bad_state_resets_total / newton_iters_p50_p99_max
                       for the kernel (3.9 % of the envs per control step reset; stragglers at 105-125 iterations)
+and, since round 5 (oracle.h MJ-(V9b)):
+    solve iterations  the `solver_niter` of the cold-started solve recorded above is compared with the oracle's count under MuJoCo's
+                      line search restated (OM_LS_MUJOCO: bracketing + 1-D Newton, ls_tolerance 0.01, ls_iterations 50) and under the
+                      exact search the HIP kernel uses: tests/test_oracle_vs_mujoco.py::test_stage_solve_iterations
 """
 import sys
 
