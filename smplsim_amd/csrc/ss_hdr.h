@@ -61,7 +61,8 @@ struct Layout {
   int l_q, l_v, l_a, l_tau, l_Fb, l_Pb, l_delta, l_diag, l_S, l_Ab, l_An, l_Aown, l_IA, l_Ubuf, l_Wst, l_R, l_r, l_Gb, l_tmp, l_V, l_Iown,
       ia_stride, l_act, env_floats, a_stride, l_Rloc, l_w2;
 };
-// alias_w (round 5; the SMPL-X size class, where LDS and not the register file caps the resident envs: 5 -> 6 per CU): the (W, y) rows of
+// alias_w (round 5; the SMPL-X size class, where LDS and not the register file caps the resident envs: 5 -> 6 per CU, 7 together with the
+// lean tables of ss_tables.h, which models on this layout also get): the (W, y) rows of
 // a body take the place of its generalized inertia.  A body's Aown row is read in part 1 of ITS level of the sweep towards the root and
 // never again in that solve (the next solve rebuilds it from Iown), its (W, y) is written in part 2 of the same level and read on the way
 // back — one slot of 24 reals per body serves both (a_stride 24 instead of the packed 21), and the 24 nn reals of the separate (W, y)
