@@ -7,8 +7,9 @@ launch, device-side autoreset.  One "step" = one control step of every env on ev
 (15 mj_steps each).  Weak scaling: independent shards, no collective in the data path.
 
     python bench.py --gpus 1 --steps 1000 --warmup 20
+    python bench.py --gpus 8                       # starts its own 8 ranks (one per GPU), like the reference's one-call fan-out
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W     # the same job when the caller brings the ranks
 """
 import argparse
 import json
@@ -59,6 +60,11 @@ class Gpu:
         import torch
         torch.cuda.set_device(index)
         return torch.device("cuda", index)
+
+    @staticmethod
+    def device_count():
+        import torch
+        return torch.cuda.device_count()
 
     @staticmethod
     def sync():
@@ -382,6 +388,28 @@ def cpu_baseline_motion():
                       "compare with config.cook.frames_per_s"}
 
 
+def spawn_ranks(n, argv):
+    """`bench.py --gpus N` called plainly (no RANK / WORLD_SIZE in the environment): start N ranks of THIS script, one per GPU, under
+    torch.distributed.run on the loopback address and hand its exit status back — the one-call fan-out of the reference's
+    examples/benchmark.py:78-81 (gym.vector.AsyncVectorEnv over worker processes).  The launcher sets RANK / LOCAL_RANK / WORLD_SIZE /
+    LOCAL_WORLD_SIZE / MASTER_*; the ranks take the branch below this call."""
+    import socket
+    import subprocess
+    have = Gpu.device_count()
+    if have < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {have} device(s) visible; refusing to run {n} ranks on fewer GPUs")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = os.path.abspath(sys.argv[0])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script, *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -409,7 +437,14 @@ def main(argv=None):
 
     import torch
     from smplsim_amd import shard
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus, list(sys.argv[1:] if argv is None else argv)))
     rank, local_rank, world = shard.rank_info()
+    if world != args.gpus:
+        # never print a line whose n_gpus is not what was asked for
+        raise SystemExit(f"bench.py --gpus {args.gpus} inside a launcher with WORLD_SIZE={world}: start as many ranks as GPUs requested")
     host_cores = shard.pin_host_threads(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))   # one slice of the host cores per rank
     dist = shard.init_process_group(Gpu.backend, local_rank) if world > 1 else None
     dev = Gpu.device(local_rank)

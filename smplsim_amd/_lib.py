@@ -28,7 +28,7 @@ DEFAULT_OPT = "-Os -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-il
 # -O3 / -O2 5.90 ms per 4096-env step, -Os 6.39 ms (same-box A/B, profiles/r04_selfcol_ab.txt); scratch 912 vs 1104 bytes per lane
 SC_OPT = "-O3 -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-ilp"
 MOTION_OPT = "-O3"
-# the SMPL-X/H size class (smplsim_hip_x.hip, round 5; 256 VGPRs, 6 envs per CU): -O2 2.93 ms per 4096-env step, -O3 2.95, -Os 2.97
+# the SMPL-X/H size class (smplsim_hip_x.hip, round 5; 256 VGPRs; A/B taken at 6 envs per CU, 7 since the lean tables): -O2 2.93 ms per 4096-env step, -O3 2.95, -Os 2.97
 X_OPT = "-O2 -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-ilp"
 
 

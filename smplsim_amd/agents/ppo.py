@@ -17,7 +17,6 @@ from dataclasses import dataclass, field
 
 import torch
 
-_LOG_2PI = math.log(2.0 * math.pi)
 
 from ..learning.gae import estimate_advantages_columns, normalize_advantages
 from ..learning.networks import MLP, PolicyGaussian, Value

@@ -353,6 +353,9 @@ __global__ void __launch_bounds__(512) ss_linear_glds_kernel(const __bf16 *__res
   }
 }
 
+// torch.clamp semantics: a NaN stays a NaN (fminf / fmaxf would return the bound and hide a diverged policy or observation from the env)
+__device__ __forceinline__ float clamp_keep_nan(float v, float lo, float hi) { return v != v ? v : fminf(fmaxf(v, lo), hi); }
+
 __global__ void __launch_bounds__(256) ss_obs_to_bf16_kernel(const float *obs, int M, int dim, int stride, const float *mean, const float *sd,
                                                              const long long *n, float lo, float hi, float clip, __bf16 *out, int kpad) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -360,8 +363,8 @@ __global__ void __launch_bounds__(256) ss_obs_to_bf16_kernel(const float *obs, i
   const int row = (int)(idx / kpad), c = (int)(idx % kpad);
   float v = 0.f;
   if (c < dim) {
-    v = fminf(fmaxf(obs[(size_t)row * stride + c], lo), hi);
-    if (mean && sd && n && *n > 0) v = fminf(fmaxf((v - mean[c]) / (sd[c] + 1e-8f), -clip), clip);
+    v = clamp_keep_nan(obs[(size_t)row * stride + c], lo, hi);
+    if (mean && sd && n && *n > 0) v = clamp_keep_nan((v - mean[c]) / (sd[c] + 1e-8f), -clip, clip);
   }
   out[idx] = (__bf16)v;
 }
@@ -377,7 +380,7 @@ __global__ void __launch_bounds__(256) ss_gaussian_sample_kernel(const float *me
     const float ls = log_std[j], z = noise[(size_t)row * dim + j];
     const float a = __fadd_rn(mean[(size_t)row * dim + j], __fmul_rn(__expf(ls), z));
     action[(size_t)row * lda + j] = a;
-    if (action_env) action_env[(size_t)row * lde + j] = fminf(fmaxf(a, lo), hi);
+    if (action_env) action_env[(size_t)row * lde + j] = clamp_keep_nan(a, lo, hi);
     acc += -0.5f * z * z - 0.91893853320467274f - ls;          // - log sqrt(2 pi)
   }
   if (logp) {

@@ -35,13 +35,26 @@ def _record_event(device):
 
 
 class PipelinedVecEnv:
-    def __init__(self, num_envs, sub_batches=4, device=0, seed=0, model=None, **env_kw):
+    def __init__(self, num_envs, sub_batches=4, device=0, seed=0, model=None, shape_id=None, **env_kw):
         assert num_envs % sub_batches == 0
         self.num_envs, self.sub_batches = num_envs, sub_batches
         n = self.n = num_envs // sub_batches
-        first = SMPLSimVecEnv(n, device=device, seed=seed, model=model, **env_kw)
+        # body shapes belong to the JOB's env ids: env i has shape i % num_shapes by default (SMPLSimVecEnv's rule on N envs), so
+        # sub-batch g gets rows g n .. (g + 1) n of the job's table, not a table that restarts at 0 with every sub-batch
+        num_shapes = model.num_shapes if model is not None else 1
+        if shape_id is None and num_shapes > 1:
+            shape_id = torch.arange(num_envs) % num_shapes
+        if shape_id is not None:
+            shape_id = torch.as_tensor(shape_id)
+            if shape_id.shape != (num_envs,):
+                raise ValueError("shape_id must hold one shape index per env of the whole job")
+
+        def sid(g):
+            return None if shape_id is None else shape_id[g * n:(g + 1) * n]
+
+        first = SMPLSimVecEnv(n, device=device, seed=seed, model=model, shape_id=sid(0), **env_kw)
         # one model (one set of device tables) for all sub-batches
-        self.envs = [first] + [SMPLSimVecEnv(n, device=device, seed=seed, model=first.model, **env_kw) for _ in range(1, sub_batches)]
+        self.envs = [first] + [SMPLSimVecEnv(n, device=device, seed=seed, model=first.model, shape_id=sid(g), **env_kw) for g in range(1, sub_batches)]
         if not (first.autoreset and first._fused_autoreset):
             raise ValueError("PipelinedVecEnv steps with the in-launch autoreset (StateInit Default / Fall, autoreset=True)")
         self.device, self.nu, self.obs_size = first.device, first.nu, first.obs_size
@@ -49,7 +62,7 @@ class PipelinedVecEnv:
         self.streams = [_make_stream(self.device) for _ in range(sub_batches)]
         self.gen = torch.Generator(device=self.device)          # the single batch's generator: same seed, same draws, same order
         self.gen.manual_seed(int(seed))
-        self._draws = None
+        self._draws, self._consumed = None, set()
 
     def rows(self, g):
         return slice(g * self.n, (g + 1) * self.n)
@@ -80,7 +93,11 @@ class PipelinedVecEnv:
         tr2, fa = self._rand4(), None
         if self.envs[0]._fall_buf is not None:
             fa = torch.empty(self.num_envs, 3, self.nu, device=self.device).uniform_(0.0, 1.0, generator=self.gen)
-        self._draws = (tr, tr2, fa, _record_event(self.device))
+        if self._draws is not None:
+            missing = sorted(set(range(self.sub_batches)) - self._consumed)
+            raise RuntimeError(f"draw_step_inputs: sub-batches {missing} have not stepped on the previous draws (every sub-batch steps once per "
+                               "control step; a new draw now would desynchronise the generator from the single batch's sequence)")
+        self._draws, self._consumed = (tr, tr2, fa, _record_event(self.device)), set()
 
     def step_async(self, g, actions, wait=None):
         """Enqueue one control step of sub-batch g on its stream (after `wait`, an event on another stream, if given); returns the
@@ -88,6 +105,9 @@ class PipelinedVecEnv:
         `stream(g)` are ordered after it)."""
         if self._draws is None:
             self.draw_step_inputs()
+        if g in self._consumed:
+            raise RuntimeError(f"step_async: sub-batch {g} stepped twice on one control step's draws (the others have not: "
+                               f"{sorted(set(range(self.sub_batches)) - self._consumed)})")
         tr, tr2, fa, ev = self._draws
         r, env, s = self.rows(g), self.envs[g], self.streams[g]
         with _stream_ctx(s):
@@ -100,8 +120,9 @@ class PipelinedVecEnv:
             if fa is not None:
                 env._fall_buf.copy_(fa[r])
             out = env.step(actions, None if tr is None else tr[r], task_rand2=None if tr2 is None else tr2[r], _fall_drawn=fa is not None)
-        if g == self.sub_batches - 1:
-            self._draws = None
+        self._consumed.add(g)                                     # any order: the draws go when every sub-batch has used its rows
+        if len(self._consumed) == self.sub_batches:
+            self._draws, self._consumed = None, set()
         return out
 
     def stream(self, g):

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# Some tests load modules from the read-only reference checkout (/root/reference): never leave __pycache__/*.pyc in it.  Set before
+# any such import and inherited by the forked sampler workers of tests/test_reference_agent.py.
+sys.dont_write_bytecode = True
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -20,6 +20,7 @@ from helpers import oracle_model
 from oracle import oracle as O
 
 TOL_QPOS, TOL_QVEL, TOL_OBS = 1e-5, 2e-3, 2e-3
+RESET_SCALE = 1e4                                          # |qvel|_max from which "on its way to MuJoCo's bad-state reset" is an accepted cause
 MAX_OUTSIDE = {"one_action": 3, "fresh_actions": 6}        # of 120 steps; measured 1 / 1-3 (profiles/r05_parity_measured.json)
 
 
@@ -83,7 +84,13 @@ def run(env, mode, steps=120, to_np=lambda t: np.asarray(t)):
         if not rec["contact_sets_equal"]:
             rec["cause"] += "; the body-body contact lists of the step's last forward pass differ (kernel %d, oracle %d: a pair within float32 rounding of the margin)" % (len(mine), len(theirs))
         if t["reset"][0]:
-            rec["cause"] = "a float64 replay takes MuJoCo's bad-state reset inside the step (state blowing up)"
+            # excused as a reset only when the state really is at the reset threshold for everybody: the float64 kernel replay resets
+            # (t["reset"]) while kernel and oracle agreed on NOT resetting (asserted above) is a state within rounding of the check —
+            # accept it only next to a velocity scale that says so, otherwise the step stays what the checks above made of it
+            if scale > RESET_SCALE:
+                rec["cause"] = ("a float64 replay takes MuJoCo's bad-state reset inside the step (state blowing up: velocity scale %.1e); was: " % scale) + rec["cause"]
+            else:
+                rec["cause"] = "UNEXPLAINED: a float64 replay resets at velocity scale %.1e while kernel and oracle do not; " % scale + rec["cause"]
         outside.append(rec)
         print("outside tolerance:", rec)
     return dict(steps=steps, qpos=worst[0], qvel=worst[1], obs=worst[2], steps_with_body_body_contact=int(with_self), bad_state_resets=resets,

@@ -292,6 +292,57 @@ def test_pipelined_sub_batches_are_the_single_batch_bit_for_bit(emu_backend, hos
     one.close(); pipe.close()
 
 
+def test_pipelined_sub_batches_keep_the_jobs_body_shapes(emu_backend, host_streams):
+    """A multi-shape model: env i of the job has shape i % num_shapes in BOTH forms (the sub-batches used to restart the
+    default table at 0, so with n % num_shapes != 0 env i got shape (i - g n) % num_shapes); an explicit job-wide shape_id is sliced."""
+    from smplsim_amd.batch import ShardModel, SMPLSimVecEnv
+    from smplsim_amd.mjcf_writer import scaled_xml_str
+    from smplsim_amd.pipeline import PipelinedVecEnv
+    xmls = [scaled_xml_str("smpl_humanoid", 1.0), scaled_xml_str("smpl_humanoid", 0.9, {"L_Knee": 1.1})]
+    N, G = 6, 2                                                  # n = 3 per sub-batch, 2 shapes: 3 % 2 != 0
+    kw = dict(task="HumanoidSpeed", episode_length=3, seed=5)
+    model = ShardModel(xmls=xmls, device=0)
+    one, pipe = SMPLSimVecEnv(N, model=model, **kw), PipelinedVecEnv(N, sub_batches=G, model=model, **kw)
+    assert torch.cat([e.shape_id for e in pipe.envs]).tolist() == one.shape_id.tolist() == [0, 1, 0, 1, 0, 1]
+    assert torch.equal(one.reset()[0], torch.cat(pipe.reset()))
+    g = torch.Generator(); g.manual_seed(2)
+    for t in range(5):
+        a = torch.rand(N, one.nu, generator=g) * 2 - 1
+        o1 = one.step(a)[0]
+        outs = [pipe.step_async(k, a[pipe.rows(k)].contiguous()) for k in range(G)]
+        assert torch.equal(o1, torch.cat([o[0] for o in outs])) and torch.equal(one.qpos, torch.cat([e.qpos for e in pipe.envs]))
+    sid = [1, 1, 0, 0, 0, 1]
+    pipe2 = PipelinedVecEnv(N, sub_batches=G, model=model, shape_id=sid, **kw)
+    assert torch.cat([e.shape_id for e in pipe2.envs]).tolist() == sid
+    with pytest.raises(ValueError, match="shape_id"):
+        PipelinedVecEnv(N, sub_batches=G, model=model, shape_id=[0, 1, 0], **kw)
+    one.close(); pipe.close(); pipe2.close()
+
+
+def test_pipelined_draws_are_consumed_once_per_sub_batch_in_any_order(emu_backend, host_streams):
+    """One control step's draws serve every sub-batch exactly once, in whatever order the caller steps them; stepping one twice, or
+    drawing again before all have stepped, raises instead of silently leaving the single batch's random sequence."""
+    from smplsim_amd.batch import SMPLSimVecEnv
+    from smplsim_amd.pipeline import PipelinedVecEnv
+    N, G = 6, 3
+    kw = dict(task="HumanoidSpeed", episode_length=3, seed=5)
+    one, pipe = SMPLSimVecEnv(N, **kw), PipelinedVecEnv(N, sub_batches=G, **kw)
+    one.reset(); pipe.reset()
+    g = torch.Generator(); g.manual_seed(1)
+    for order in ([2, 0, 1], [1, 2, 0], [0, 1, 2], [2, 1, 0]):
+        a = torch.rand(N, one.nu, generator=g) * 2 - 1
+        o1 = one.step(a)[0]
+        outs = {k: pipe.step_async(k, a[pipe.rows(k)].contiguous()) for k in order}
+        assert torch.equal(o1, torch.cat([outs[k][0] for k in range(G)]))
+    a = torch.rand(N, one.nu, generator=g) * 2 - 1
+    pipe.step_async(1, a[pipe.rows(1)].contiguous())
+    with pytest.raises(RuntimeError, match="stepped twice"):
+        pipe.step_async(1, a[pipe.rows(1)].contiguous())
+    with pytest.raises(RuntimeError, match="have not stepped"):
+        pipe.draw_step_inputs()
+    one.close(); pipe.close()
+
+
 def test_pipelined_sampler_equals_the_serial_sampler(emu_backend, host_streams):
     """AgentPPO.sample_pipelined over G sub-batches returns the rollout of AgentPPO.sample over the single batch: same policy draws
     (the step's noise is drawn for all N envs and sliced), same env inputs (master generator), same tensors."""

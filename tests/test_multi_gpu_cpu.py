@@ -69,6 +69,7 @@ class Ev:
 class HostGpu:                                          # bench.Gpu with host stand-ins (gloo instead of RCCL)
     backend = "gloo"
     device = staticmethod(lambda index: torch.device("cpu"))
+    device_count = staticmethod(lambda: int(os.environ.get("SS_TEST_HOST_DEVICES", "2")))
     sync = staticmethod(lambda: None)
     event = staticmethod(lambda: Ev())
     stream_ptr = staticmethod(lambda dev: None)
@@ -119,6 +120,44 @@ def test_bench_main_strong_scaling_switch(tmp_path):
     assert res["scaling"] == "strong" and res["config"]["envs_per_gpu"] == 3 and res["config"]["envs_total"] == 6
     assert abs(res["value"] - 6 * 2 / (res["ms_per_step"] * 1e-3 * 2)) < 1e-6 * res["value"]
     assert "1.25x" in res["config"]["scaling_note"] and "--envs-total" in res["config"]["scaling_note"]
+
+
+def _run_plain(tmp_path, args, extra_env=None, timeout=900):
+    """`python worker.py --gpus N ...` with NO rank variables in the environment and no process fan-out on the test's side: the ranks
+    are whatever bench.main starts by itself."""
+    path = tmp_path / "worker.py"
+    path.write_text(_BENCH % ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(OMP_NUM_THREADS="2", **(extra_env or {}))
+    return subprocess.run([sys.executable, str(path), *args], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+
+
+def test_plain_gpus_flag_spawns_ranks(tmp_path):
+    """`bench.py --gpus 2` as the driver calls it (no torchrun around it): main() starts the two ranks itself (spawn_ranks ->
+    torch.distributed.run on 127.0.0.1), each pins its slice of the host cores, rank 0 prints ONE line with n_gpus = 2 and the
+    whole-job value.  The reference's fan-out is one call as well (examples/benchmark.py:78-81)."""
+    n, steps = 3, 2
+    pr = _run_plain(tmp_path, ["--gpus", "2", "--envs-per-gpu", str(n), "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline",
+                               "--no-reference-contact-set"])
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    lines = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, pr.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["envs_total"] == 2 * n and res["scaling"] == "weak"
+    assert abs(res["value"] - 2 * n * steps / (res["ms_per_step"] * 1e-3 * steps)) < 1e-6 * res["value"]
+    if len(os.sched_getaffinity(0)) >= 2:
+        assert res["config"]["host_cores_pinned_per_rank"] == len(os.sched_getaffinity(0)) // 2
+
+
+def test_plain_gpus_flag_refuses_more_ranks_than_devices(tmp_path):
+    """Fewer devices than --gpus: exit status != 0 and no result line (never a line that says n_gpus 1 for a --gpus 8 command);
+    likewise a launcher whose WORLD_SIZE is not the --gpus asked for."""
+    pr = _run_plain(tmp_path, ["--gpus", "4", "--envs-per-gpu", "3", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                    {"SS_TEST_HOST_DEVICES": "2"}, timeout=120)
+    assert pr.returncode != 0 and "only 2 device(s) visible" in pr.stderr and not any(l.startswith("{") for l in pr.stdout.splitlines())
+    pr = _run_plain(tmp_path, ["--gpus", "4", "--envs-per-gpu", "3", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                    {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"}, timeout=120)
+    assert pr.returncode != 0 and "WORLD_SIZE=1" in pr.stderr and not any(l.startswith("{") for l in pr.stdout.splitlines())
 
 
 def test_ranks_pin_disjoint_slices_of_the_host_cores():

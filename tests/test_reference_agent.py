@@ -32,6 +32,7 @@ pytestmark = pytest.mark.skipif(not os.path.exists(RUN_PY), reason="the referenc
 @pytest.fixture()
 def reference_on_path(emu_backend, monkeypatch, tmp_path):
     """This repository first (the shim), the reference checkout behind it, stand-ins for the absent third-party modules last."""
+    sys.dont_write_bytecode = True                              # the checkout is read-only: no __pycache__ in it
     import smpl_sim                                             # the shim: extends its __path__ over the checkout behind it
     for name in ("wandb", "hydra", "omegaconf", "gymnasium"):
         if importlib.util.find_spec(name) is None and STUBS not in sys.path:

@@ -17,6 +17,7 @@ STUBS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "refstubs")
 
 
 def _load_harness():
+    sys.dont_write_bytecode = True                              # the checkout is read-only: no __pycache__ in it
     added = []
     for name in ("gymnasium", "omegaconf", "mujoco"):
         if importlib.util.find_spec(name) is None and STUBS not in sys.path:
