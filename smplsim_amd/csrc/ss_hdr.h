@@ -145,13 +145,15 @@ constexpr int kGeomC = 16;                       // floats per body in the geom 
 constexpr int kDenseMaxRows = 64;                // block rows of the dense system at most (one block row per lane in its back substitution)
 struct HdrSC {
   int npair;                                     // candidate body pairs of the model (b1 | b2 << 8 each)
-  int l_H, l_g, l_list, l_Wst2, nloc, o_sctab, l_gc, l_tab, nmax, l_cand, l_zb;   // float offsets in the env slice (o_sctab: ints from k->pairs)
-  //   l_H     dense system, lower triangle of 3x3 blocks by (row, column) rank: the base layout's Aown, IA and (W, y) regions (all dead
-  //           between the sweep towards the root and the one away from it), which hold nloc block rows.  A coupled set larger than
-  //           that (SMPL: more than 16 bodies; rare) takes the workgroup's ONE shared block of nmax rows behind the env slices instead
-  //           (ss_pool_floats; a lock word in front of it) — sizing every env for the worst case would cost a resident env per CU
-  //   l_g     right-hand side / solution by rank, 3 (nmax) floats
-  //   l_list  node list of the contact being assembled; pair list of the broad phase (64 words)
+  int l_H, l_g, l_list, l_Wst2, hloc, o_sctab, l_gc, l_tab, nmax, l_cand, l_zb;   // float offsets in the env slice (o_sctab: ints from k->pairs)
+  //   l_H     dense system (round 6): the lower triangle by TILE ROWS of 16 matrix rows (the M and N of the matrix instruction), tile row ti =
+  //           16 rows of 16 (ti + 1) reals, row-major, at 256 ti (ti + 1) / 2; over the scalar unknowns 3 rank(body) + axis, the root body's six
+  //           behind them and the right-hand side as one more ROW (index N = 3 nc + 6), the last tile row cut behind it (dense_floats).  It lies
+  //           over the base layout's An, Aown, IA and (W, y) regions (all dead between the sweep towards the root and the one away from it) + kDenseExtra: hloc
+  //           reals.  A coupled set that needs more (SMPL: more than 12 bodies; rare) takes the workgroup's ONE shared block behind the env
+  //           slices instead (ss_pool_floats; a lock word in front of it) — sizing every env for the worst case would cost a resident env per CU
+  //   l_g     pivots d of the factorization, then the solution, by unknown: 16 floats per tile row of the largest system
+  //   l_list  coupled bodies by rank (body | joint node << 8); pair list of the broad phase (64 words)
   //   l_Wst2  (W, y) per body of the articulated-body sweeps: the base layout's slot is part of H.  Outside the solves the slot holds
   //           the narrow phase's candidates (l_cand) and the wrenches of the active contacts on their way into the per-body forces
   //   l_tab   per body: neighbour towards the root | joint node << 8 | S negated << 16 ; path mask (bodies from it up to, not including, the root), 2 words
@@ -159,25 +161,31 @@ struct HdrSC {
   //   nmax    block rows of the largest dense system (bodies + 1: all joints coupled, + 2 for the root body's six unknowns)
   int env_floats;                                // slice size of a SELFCOL env
 };
-constexpr int dense_floats(int n) { return 9 * (n * (n + 1) / 2); }
-constexpr HdrSC make_layout_sc(int nb, int base_floats, int l_Aown) {
+constexpr int kDenseTile = 16;                   // the tile edge = the M and N of v_mfma_f32_16x16x4_f32
+constexpr int dense_tile_rows(int nblock) { return (3 * nblock + 1 + kDenseTile - 1) / kDenseTile; }   // tile rows of a system of nblock 3x3 block rows (+ the right-hand-side row)
+constexpr int dense_floats(int np) {                // reals of a system of np matrix rows (right-hand side included): whole tile rows + the cut one
+  const int t = (np - 1) / kDenseTile;
+  return kDenseTile * kDenseTile * (t * (t + 1) / 2) + kDenseTile * (t + 1) * (np - kDenseTile * t);
+}
+constexpr int kDenseExtra = 256;                 // reals appended to the dead stretch for the dense system (what 8 resident SMPL envs leave of the CU's 160 KiB)
+constexpr HdrSC make_layout_sc(int nb, int base_floats, int l_An) {
   HdrSC y{};
   int o = base_floats;
   auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
   y.nmax = nb + 1 < kDenseMaxRows ? nb + 1 : kDenseMaxRows;
-  y.l_H = l_Aown;
-  int nl = 0;
-  while (nl < y.nmax && dense_floats(nl + 1) <= base_floats - l_Aown) nl++;
-  y.nloc = nl;
-  y.l_g = take(3 * y.nmax); y.l_list = take(64);
+  // An (the solve's output, written when the dense system is done) | Aown | IA | (W, y) of the base layout, and kDenseExtra reals behind them
+  y.l_H = l_An;
+  take(kDenseExtra);
+  y.hloc = o - y.l_H;
+  y.l_g = take(kDenseTile * dense_tile_rows(y.nmax)); y.l_list = take(64);
   const int w2 = 24 * (nb + 1) > kCandRec * kSelfCand ? 24 * (nb + 1) : kCandRec * kSelfCand;
   y.l_Wst2 = take(w2); y.l_cand = y.l_Wst2;
-  y.l_gc = take(3 * nb); y.l_zb = take(3 * nb); y.l_tab = take(3 * nb);   // (gc + zb: also the per-contact projections of the dense assembly, 12 reals per joint between the two bodies)
+  y.l_gc = take(3 * nb); y.l_zb = take(3 * nb); y.l_tab = take(3 * nb);
   y.env_floats = o;
   return y;
 }
 // reals of the workgroup's shared dense block behind the env slices (0: every coupled set fits the envs' own regions); [0] is the lock word
-constexpr int ss_pool_floats(const HdrSC &y) { return y.nmax > y.nloc ? 4 + dense_floats(y.nmax) : 0; }
+constexpr int ss_pool_floats(const HdrSC &y) { return dense_floats(3 * y.nmax + 1) > y.hloc ? 4 + ((dense_floats(3 * y.nmax + 1) + 3) & ~3) : 0; }
 
 // Elimination tree of the articulated-body solves: the body tree re-rooted at its CENTRE.  H x = b is a free-floating tree's system,
 // any body can carry the six free unknowns; eliminating towards the centre instead of towards the pelvis makes the sweeps as deep as

@@ -55,13 +55,16 @@ namespace ss {
 enum { PF_FWD = 0, PF_CONS, PF_NBEGIN, PF_NPREP, PF_ASM, PF_FACTOR, PF_SOLVE, PF_NFIN, PF_SPDPREP, PF_SPDFIN, PF_INTEG, PF_MISC,
        PF_F_P13, PF_F_SYNC1, PF_F_P2, PF_F_BSOL, PF_K_CHAIN,
        PF_K_PRO, PF_K_LEV, PF_K_INERTIA, PF_K_SUMS, PF_K_VPROD, PF_P_CONTACT, PF_P_SUMS, PF_P_GRAD,
-       PF_SC_NARROW, PF_SC_BASE, PF_SC_COLS, PF_SC_DENSE, PF_SC_FINAL, PF_COUNT };
+       PF_SC_NARROW, PF_SC_BASE, PF_SC_COLS, PF_SC_DENSE, PF_SC_FINAL,
+       PF_N_DENSE, PF_N_POOLED, PF_N_T1, PF_N_T2, PF_N_T3, PF_N_T4, PF_N_T5, PF_N_CONTACTS, PF_N_UNKNOWNS, PF_SC_LOCK, PF_COUNT };   // (PF_N_*: counts, not ticks)
 #ifdef SS_PROFILE
 #define SS_FT0() unsigned long long ft__ = w->clock()
 #define SS_FTICK(id) do { unsigned long long n__ = w->clock(); prof[id] += n__ - ft__; ft__ = n__; } while (0)
+#define SS_FCOUNT(id, v) do { prof[id] += (unsigned long long)(v); } while (0)
 #else
 #define SS_FT0() do {} while (0)
 #define SS_FTICK(id) do {} while (0)
+#define SS_FCOUNT(id, v) do {} while (0)
 #endif
 
 struct alignas(16) float4_t { real x, y, z, w; };   // 4 reals: one 16-byte LDS access in the product (float) build
@@ -790,7 +793,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL>, LeanState<HT::maybe_lea
             const unsigned long long bbm = w->ballot(pending && kind == 2), below = (1ull << lane) - 1ull;
             const int off = sc::kBoxBoxWork * __builtin_popcountll(bbm & below) + sc::kPairOut * __builtin_popcountll(pm & ~bbm & below);
             const bool go = pending && off + (kind == 2 ? sc::kBoxBoxWork : sc::kPairOut) <= room;
-            real *out = this->H + off;
+            real *out = Aown + off;
             int n = 0;
 #ifndef SS_STUB_PAIRFN
             if (go) {
@@ -1361,19 +1364,19 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL>, LeanState<HT::maybe_lea
   // towards the root left U_b and the composite bias force in b's (W, y) slot):
   //     H(i, i) = S_i^T U_i + diag_i,   H(i, k) = U_i^T S_k  (k between i and the root),   H(root, i) = U_i,   H(root, root) = IC_root,
   //     g_i = sgn_i b_i - S_i^T pC_i,   g_root = -pC_root,
-  // plus, per contact c with an active row, between bodies b1 -> b2:  sigma_i sigma_k S_i^T K_c S_k  for the joints i, k on the way from
-  // b1 to b2 through the tree (the joints above their meeting point move both bodies alike and drop out — no cancellation of
-  // large terms), sigma = +1 on b2's side and -1 on b1's,  K_c = sum_{active rows} D u u^T,  u = (p x d ; d).
-  // Block rows are ordered by body index (rank within the coupled mask), the root's angular and linear parts last.  Factorization
-  // L D L^T by 3x3 blocks, right-looking, one hand-off per pivot: the lane of block (i, j) forms W_i = U_i D_k^-1 itself (D_k
-  // by substitution: Ldl3), the right-hand side rides along as one more block row; the back substitution runs with one block row
-  // per lane and the pivot's solution passed by readlane.
-  SS_DEV static int tri_row(int idx) {                       // largest i with i (i + 1) / 2 <= idx
-    int i = (int)((SS_M(sqrt)((real)(8 * idx + 1)) - real(1)) * real(0.5));
-    while ((i + 1) * (i + 2) / 2 <= idx) i++;
-    while (i * (i + 1) / 2 > idx) i--;
-    return i;
-  }
+  // plus, per contact c with an active row, between bodies b1 -> b2:  sum_rows w w^T  with  w_i = sigma_i S_i^T u  over the joints i on the
+  // way from b1 to b2 through the tree (the joints above their meeting point move both bodies alike and drop out — no cancellation of
+  // large terms), sigma = +1 on b2's side and -1 on b1's,  u = sqrt(D) (p x d ; d) for an active pyramid row d.
+  //
+  // Round 6: the system is SCALAR and TILED for the matrix core (v_mfma_f32_16x16x4_f32: exact float32, an fma chain).  Unknown
+  // 3 rank(b) + axis for the coupled bodies by body index, the root's angular and linear parts behind them (N = 3 nc + 6), the right-hand
+  // side as row N; the lower triangle of 16 x 16 tiles, row-major inside a tile (ss_hdr.h).  One contact = 4 pyramid rows = the K of ONE
+  // matrix instruction per tile: lane l evaluates w for (row l >> 4, unknown 16 t + (l & 15)), tile (ti, tj) += W_ti^T W_tj.  Factorization
+  // L D L^T by panels of 16 columns: lane = matrix row, the row's 16 panel entries in registers, pivot values passed by v_readlane (no LDS
+  // round trip inside a panel, one hand-off per panel instead of one per 3 x 3 pivot block), the trailing tiles updated by 4 matrix
+  // instructions each.  Back substitution with one column per lane.  Rounds 4-5 (3 x 3 blocks, per-contact projection + block passes
+  // through LDS, one hand-off per block pivot) spent 31.6 k ticks per solve here; profiles/r06_selfcol_*.
+  SS_DEV static int drow(int i) { const int t = i >> 4; return 16 * ((t + 1) * (8 * t + (i & 15))); }   // element (i, j <= i) = H[drow(i) + j]  (ss_hdr.h dense_floats)
 #if defined(SS_DENSE_NOINLINE) && defined(__HIPCC__)
   __device__ __attribute__((noinline)) void dense_solve(const unsigned long long cmask, real *x, const real *rw, real pv) {
 #else
@@ -1387,21 +1390,26 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL>, LeanState<HT::maybe_lea
       real *H = this->H, *g = this->g;
       const int32_t *tab = this->tab;
       int32_t *list = this->list;
-      const int nc = __builtin_popcountll(cmask), n = nc + 2;
+      const int nc = __builtin_popcountll(cmask), N = 3 * nc + 6, Np = N + 1, Nt = (Np + 15) >> 4;
       // a system larger than the env's own region takes the workgroup's shared block (ss_hdr.h) for the duration of this solve
-      const bool pooled = n > k->sc.nloc;
-      if (pooled) { w->lock_acquire(reinterpret_cast<int *>(this->pool)); H = this->pool + 4; }
-      auto blk = [&](int i, int j) { return H + 9 * (i * (i + 1) / 2 + j); };
+      const int hf = dense_floats(Np);
+      const bool pooled = hf > k->sc.hloc;
+      if (pooled) { w->lock_acquire(reinterpret_cast<int *>(this->pool)); H = this->pool + 4; SS_FTICK(PF_SC_LOCK); }
+      SS_FCOUNT(PF_N_DENSE, 1); SS_FCOUNT(PF_N_POOLED, pooled); SS_FCOUNT(PF_N_T1, Nt == 1); SS_FCOUNT(PF_N_T2, Nt == 2); SS_FCOUNT(PF_N_T3, Nt == 3); SS_FCOUNT(PF_N_T4, Nt == 4); SS_FCOUNT(PF_N_T5, Nt >= 5);
+      SS_FCOUNT(PF_N_CONTACTS, __builtin_popcountll(this->amask)); SS_FCOUNT(PF_N_UNKNOWNS, N);
       auto rank = [&](int b) { return (int)__builtin_popcountll(cmask & ((1ull << b) - 1ull)); };
       const real mu = h.mu;
-      // ---- zero the block triangle (the level buffer and Aown it lies over are dead: the sweep towards the root is done)
-      const int hf = 9 * (n * (n + 1) / 2);
+      const int l15 = lane & 15, q4 = lane >> 4;              // this lane's place in a tile as the matrix instruction sees it: row l15, columns 4 q4 .. + 3
+      auto tq = [&](int ti, int tj) { return 256 * ((ti * (ti + 1)) >> 1) + 16 * (ti + 1) * l15 + 16 * tj + 4 * q4; };
+      auto trow_ok = [&](int ti) { return 16 * ti + l15 < Np; };   // (the last tile row ends with row N: what lies behind it is not ours to write)
+      // ---- zero the tiles (the level buffer and Aown they lie over are dead: the sweep towards the root is done)
       w->sync();                                              // (the root's lanes have read level 1's rows, which lie in this region)
-      for (int i = lane; i < hf; i += 64) H[i] = 0;
+      for (int i = 4 * lane; i < hf; i += 256) st4w(H + i, 0, 0, 0, 0);
       w->sync();
       // ---- tree part: lane = coupled body; with at most 32 bodies the two halves of the wave share a body's joints towards the root
       // (the chain walk is the long pole of this phase: 5 blocks for a hand or a toe)
       const int halves = h.nb <= 32 ? 2 : 1, half = halves == 2 ? lane >> 5 : 0, bl = halves == 2 ? lane & 31 : lane;
+      const int rowN = drow(N);
       if (bl < h.nb && ((cmask >> bl) & 1ull)) {
         const int b = bl, ri = rank(b), t0 = tab[3 * b], jn = (t0 >> 8) & 255;
         const real sgn = (t0 >> 16) & 1 ? real(-1) : real(1);
@@ -1411,35 +1419,33 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL>, LeanState<HT::maybe_lea
         const real *sn = S + 18 * jn;
 #pragma unroll
         for (int t = 0; t < 18; t++) sv[t] = sn[t];
+        int dro[3];
+#pragma unroll
+        for (int a_ = 0; a_ < 3; a_++) dro[a_] = drow(3 * ri + a_);
         if (half == 0) {
-          real *d = blk(ri, ri);
+          list[ri] = b | (jn << 8);                           // unknown -> body / joint node (the contact rows' lanes look their columns up here)
 #pragma unroll
           for (int a_ = 0; a_ < 3; a_++) {
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
+            for (int c = 0; c <= a_; c++) {
               real acc = a_ == c ? diag[3 * jn + a_] : real(0);
 #pragma unroll
               for (int r_ = 0; r_ < 6; r_++) acc += sv[6 * a_ + r_] * U[r_][c];
-              d[3 * a_ + c] = acc;
+              H[dro[a_] + 3 * ri + c] = acc;
             }
             real gg = sgn * x[3 * jn + a_];
 #pragma unroll
             for (int r_ = 0; r_ < 6; r_++) gg -= sv[6 * a_ + r_] * pa[r_];
-            g[3 * ri + a_] = gg;
+            H[rowN + 3 * ri + a_] = gg;
           }
-        } else {
-          real *ra = blk(nc, ri), *rl = blk(nc + 1, ri);
-#pragma unroll
-          for (int r_ = 0; r_ < 3; r_++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) { ra[3 * r_ + c] = U[r_][c]; rl[3 * r_ + c] = U[3 + r_][c]; }
         }
-        if (halves == 1) {
-          real *ra = blk(nc, ri), *rl = blk(nc + 1, ri);
+        if (half == 1 || halves == 1) {                       // the root body's rows
 #pragma unroll
-          for (int r_ = 0; r_ < 3; r_++)
+          for (int r_ = 0; r_ < 6; r_++) {
+            const int rr = drow(3 * nc + r_);
 #pragma unroll
-            for (int c = 0; c < 3; c++) { ra[3 * r_ + c] = U[r_][c]; rl[3 * r_ + c] = U[3 + r_][c]; }
+            for (int c = 0; c < 3; c++) H[rr + 3 * ri + c] = U[r_][c];
+          }
         }
         for (int kb = t0 & 255; kb != hc.root;) {             // the coupled joints between this body and the root: two per trip, one per half
           const int t1 = tab[3 * kb], k2 = t1 & 255;
@@ -1447,35 +1453,34 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL>, LeanState<HT::maybe_lea
           if (tgt != hc.root) {
             const int jk = (tab[3 * tgt] >> 8) & 255, rk = rank(tgt);
             const real *sk = S + 18 * jk;
-            real *o = ri > rk ? blk(ri, rk) : blk(rk, ri);
 #pragma unroll
-            for (int a_ = 0; a_ < 3; a_++)
+            for (int c = 0; c < 3; c++) {
+              const int rt = drow(3 * rk + c), ct = 3 * rk + c;
 #pragma unroll
-              for (int c = 0; c < 3; c++) {
+              for (int a_ = 0; a_ < 3; a_++) {
                 real acc = 0;
 #pragma unroll
                 for (int r_ = 0; r_ < 6; r_++) acc += U[r_][a_] * sk[6 * c + r_];
-                o[ri > rk ? 3 * a_ + c : 3 * c + a_] = acc;
+                H[ri > rk ? dro[a_] + ct : rt + 3 * ri + a_] = acc;
               }
+            }
           }
           kb = halves == 2 ? (k2 == hc.root ? k2 : (tab[3 * k2] & 255)) : k2;
         }
       }
-      if (lane < 6) {                                         // the root body's composite rows
-        if (lane < 3) { real *o = blk(nc, nc) + 3 * lane; o[0] = rw[0]; o[1] = rw[1]; o[2] = rw[2]; }
-        else {
-          real *o = blk(nc + 1, nc) + 3 * (lane - 3), *o2 = blk(nc + 1, nc + 1) + 3 * (lane - 3);
-          o[0] = rw[0]; o[1] = rw[1]; o[2] = rw[2]; o2[0] = rw[3]; o2[1] = rw[4]; o2[2] = rw[5];
-        }
-        g[3 * nc + lane] = -pv;
+      if (lane < 6) {                                         // the root body's composite rows (lower triangle) and right-hand side
+        const int rr = drow(3 * nc + lane);
+        for (int c = 0; c <= lane; c++) H[rr + 3 * nc + c] = rw[c];
+        H[rowN + 3 * nc + lane] = -pv;
       }
       w->sync();
       SS_FTICK(PF_SC_BASE);
       // ---- this lane's contact: its pyramid rows as spatial vectors u = (p x d ; d), scaled by sqrt(D) — zero for an inactive row
       // (branch-free: with `if (jar < 0)` around per-row updates the compiler computed all four rows' products up front and parked
-      // them in scratch: 84 serialized scratch reloads per solve, 1.2 GB of scratch traffic per launch).  The contact's share of the
-      // Hessian is  sum_rows (S_i^T u)(u^T S_k)  over the joints i, k between its two bodies
+      // them in scratch: 84 serialized scratch reloads per solve, 1.2 GB of scratch traffic per launch) — and the two sides of its
+      // path through the tree as body masks
       real urow[4][6];
+      unsigned pm[4] = {0u, 0u, 0u, 0u};                      // bodies on b1's side (lo, hi), on b2's side (lo, hi)
       {
         const SelfCon &c = this->sc;
         const bool mine = (this->amask >> lane) & 1ull;
@@ -1488,111 +1493,193 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL>, LeanState<HT::maybe_lea
           urow[i][0] = wgt * (c.py * d[2] - c.pz * d[1]); urow[i][1] = wgt * (c.pz * d[0] - c.px * d[2]); urow[i][2] = wgt * (c.px * d[1] - c.py * d[0]);
           urow[i][3] = wgt * d[0]; urow[i][4] = wgt * d[1]; urow[i][5] = wgt * d[2];
         }
-      }
-      // ---- the two-body rows, contact by contact (blocks of different contacts overlap).  Two phases per contact: (joint, row) lanes
-      // project the contact's rows onto the joints between its bodies — w = sigma S_i^T u, sigma = +1 on b2's side and -1 on b1's —
-      // into LDS, then (joint, joint) lanes add sum_rows w_i w_k^T to their block: 18 + 36 multiply-adds per lane instead of the 162 of
-      // S_i^T K S_k with the 6 x 6 stiffness
-      real *wbuf = this->gc;                                  // [joint][row][3] (+ pad): the geom centres of the broad phase are dead here
-      for (unsigned long long m_ = this->amask; m_; m_ &= m_ - 1ull) {
-        const int c = __builtin_ctzll(m_);
-        real uc[4][6];
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-          for (int t = 0; t < 6; t++) uc[i][t] = w->bcast(urow[i][t], c);
-        const int b1 = w->bcast_i(this->sc.b1, c), b2 = w->bcast_i(this->sc.b2, c);
-        const unsigned long long p2 = path_mask(b2), X = path_mask(b1) ^ p2;
-        const int mc = __builtin_popcountll(X);
-        if (lane < h.nb && ((X >> lane) & 1ull)) list[__builtin_popcountll(X & ((1ull << lane) - 1ull))] = lane | (int)(((p2 >> lane) & 1ull) << 8);
-        w->sync();
-        if (lane < 4 * mc) {
-          const int ii = lane >> 2, r_ = lane & 3, ei = list[ii];
-          const real *si = S + 18 * ((tab[3 * (ei & 255)] >> 8) & 255);
-          const real sg = (ei >> 8) & 1 ? real(1) : real(-1);
-          const real u0 = r_ == 0 ? uc[0][0] : r_ == 1 ? uc[1][0] : r_ == 2 ? uc[2][0] : uc[3][0], u1 = r_ == 0 ? uc[0][1] : r_ == 1 ? uc[1][1] : r_ == 2 ? uc[2][1] : uc[3][1],
-                     u2 = r_ == 0 ? uc[0][2] : r_ == 1 ? uc[1][2] : r_ == 2 ? uc[2][2] : uc[3][2], u3 = r_ == 0 ? uc[0][3] : r_ == 1 ? uc[1][3] : r_ == 2 ? uc[2][3] : uc[3][3],
-                     u4 = r_ == 0 ? uc[0][4] : r_ == 1 ? uc[1][4] : r_ == 2 ? uc[2][4] : uc[3][4], u5 = r_ == 0 ? uc[0][5] : r_ == 1 ? uc[1][5] : r_ == 2 ? uc[2][5] : uc[3][5];
-          real *o = wbuf + 12 * ii + 3 * r_;
-#pragma unroll
-          for (int a_ = 0; a_ < 3; a_++) o[a_] = sg * (si[6 * a_] * u0 + si[6 * a_ + 1] * u1 + si[6 * a_ + 2] * u2 + si[6 * a_ + 3] * u3 + si[6 * a_ + 4] * u4 + si[6 * a_ + 5] * u5);
+        if (mine) {
+          const unsigned long long p1 = path_mask(c.b1), p2 = path_mask(c.b2), s1 = p1 & ~p2, s2 = p2 & ~p1;
+          pm[0] = (unsigned)s1; pm[1] = (unsigned)(s1 >> 32); pm[2] = (unsigned)s2; pm[3] = (unsigned)(s2 >> 32);
         }
-        w->sync();
-        for (int idx = lane; idx < mc * (mc + 1) / 2; idx += 64) {
-          const int ii = tri_row(idx), kk = idx - ii * (ii + 1) / 2;
-          const int bi = list[ii] & 255, bk = list[kk] & 255;
-          const float4_t i0 = ld4(wbuf + 12 * ii), i1 = ld4(wbuf + 12 * ii + 4), i2 = ld4(wbuf + 12 * ii + 8);
-          const float4_t k0 = ld4(wbuf + 12 * kk), k1 = ld4(wbuf + 12 * kk + 4), k2 = ld4(wbuf + 12 * kk + 8);
-          const real wi[12] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w};   // [row][3]
-          const real wk[12] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w, k2.x, k2.y, k2.z, k2.w};
-          real *o = blk(rank(bi), rank(bk));                  // bi >= bk: the list is in body order, and so are the ranks
-#pragma unroll
-          for (int a_ = 0; a_ < 3; a_++)
-#pragma unroll
-            for (int cc_ = 0; cc_ < 3; cc_++)
-              o[3 * a_ + cc_] += wi[a_] * wk[cc_] + wi[3 + a_] * wk[3 + cc_] + wi[6 + a_] * wk[6 + cc_] + wi[9 + a_] * wk[9 + cc_];
-        }
-        w->sync();
       }
-      SS_FTICK(PF_SC_COLS);
-      // ---- L D L^T by blocks, the right-hand side as one more block row
-      const int ti0 = tri_row(lane), tj0 = lane - ti0 * (ti0 + 1) / 2, ti1 = tri_row(lane + 64), tj1 = lane + 64 - ti1 * (ti1 + 1) / 2;   // (the same for every pivot)
-      for (int kq = 0; kq < n; kq++) {
-        const real *dk = blk(kq, kq);
-        Ldl3 Dk;
-        Dk.factor(dk[0], dk[3], dk[4], dk[6], dk[7], dk[8]);
-        real y0, y1, y2;
-        Dk.solve(g[3 * kq], g[3 * kq + 1], g[3 * kq + 2], y0, y1, y2);
-        const int mr = n - 1 - kq, t1 = mr * (mr + 1) / 2;
-        for (int idx = lane; idx < t1 + mr; idx += 64) {
-          if (idx < t1) {
-            int ii, jj;
-            if (idx < 64) { ii = ti0; jj = tj0; } else if (idx < 128) { ii = ti1; jj = tj1; } else { ii = tri_row(idx); jj = idx - ii * (ii + 1) / 2; }
-            const int i = kq + 1 + ii, j = kq + 1 + jj;
-            const real *ui = blk(i, kq), *uj = blk(j, kq);
-            real *o = blk(i, j);
-            real uj_[9];
+      // ---- the two-body rows on the matrix core.  Lane l holds, per tile column t, the motion-vector column of unknown 16 t + (l & 15)
+      // and its body as a bit; per contact it takes pyramid row l >> 4 (24 v_readlane + selects) and forms
+      // w = sigma S_col^T u; tile (ti, tj) += W_ti^T W_tj is one instruction (A = w of tj, B = w of ti: the instruction's D is the
+      // transpose of the row-major tile, so that a lane's four results are one 16-byte row segment)
+      struct Col { real s[6]; unsigned lo, hi; };
+      auto colinfo = [&](int t, Col &c) {
+        const int u = 16 * t + l15;
+        c.lo = c.hi = 0u;
 #pragma unroll
-            for (int t = 0; t < 9; t++) uj_[t] = uj[t];
+        for (int i = 0; i < 6; i++) c.s[i] = 0;
+        if (u < 3 * nc) {
+          const int e = list[u / 3], b = e & 255;
+          const real *sn = S + 18 * (e >> 8) + 6 * (u % 3);
 #pragma unroll
-            for (int a_ = 0; a_ < 3; a_++) {
-              real w0, w1, w2;
-              Dk.solve(ui[3 * a_], ui[3 * a_ + 1], ui[3 * a_ + 2], w0, w1, w2);
+          for (int i = 0; i < 6; i++) c.s[i] = sn[i];
+          if (b < 32) c.lo = 1u << b; else c.hi = 1u << (b - 32);
+        }
+      };
+      struct Row { real u[6]; unsigned m[4]; };
+      const real mq[4] = {q4 == 0 ? real(1) : real(0), q4 == 1 ? real(1) : real(0), q4 == 2 ? real(1) : real(0), q4 == 3 ? real(1) : real(0)};
+      auto contact_row = [&](int c) {                         // contact c's pyramid row l >> 4 and its side masks, in every lane
+        Row r;
 #pragma unroll
-              for (int c = 0; c < 3; c++) o[3 * a_ + c] -= w0 * uj_[3 * c] + w1 * uj_[3 * c + 1] + w2 * uj_[3 * c + 2];
+        for (int t = 0; t < 6; t++) {
+          // (0 / 1 weights instead of selects: the compiler turned a chain of `q4 == i ?` into three divergent branches per component)
+          r.u[t] = mq[0] * w->bcast(urow[0][t], c) + mq[1] * w->bcast(urow[1][t], c) + mq[2] * w->bcast(urow[2][t], c) + mq[3] * w->bcast(urow[3][t], c);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) r.m[t] = (unsigned)w->bcast_i((int)pm[t], c);
+        return r;
+      };
+      auto weval = [&](const Col &c, const Row &r) -> real {
+        const real d = c.s[0] * r.u[0] + c.s[1] * r.u[1] + c.s[2] * r.u[2] + c.s[3] * r.u[3] + c.s[4] * r.u[4] + c.s[5] * r.u[5];
+        const bool on1 = ((r.m[0] & c.lo) | (r.m[1] & c.hi)) != 0u, on2 = ((r.m[2] & c.lo) | (r.m[3] & c.hi)) != 0u;
+        return on2 ? d : (on1 ? -d : real(0));
+      };
+      auto tile_add = [&](int ti, int tj, const real *acc) {
+        if (trow_ok(ti)) {
+          real *o = H + tq(ti, tj);
+          const float4_t v = ld4(o);
+          st4w(o, v.x + acc[0], v.y + acc[1], v.z + acc[2], v.w + acc[3]);
+        }
+      };
+      const int Ntc = (3 * nc + 15) >> 4;                     // tile columns that hold joint unknowns
+      if (this->amask) {
+        if (Ntc <= 4) {                                       // (all but coupled sets of 22 and 23 bodies) every tile stays in registers over the contacts
+          Col c0, c1, c2, c3;
+          colinfo(0, c0); colinfo(1, c1); colinfo(2, c2); colinfo(3, c3);
+          real a00[4] = {0, 0, 0, 0}, a10[4] = {0, 0, 0, 0}, a11[4] = {0, 0, 0, 0}, a20[4] = {0, 0, 0, 0}, a21[4] = {0, 0, 0, 0}, a22[4] = {0, 0, 0, 0},
+               a30[4] = {0, 0, 0, 0}, a31[4] = {0, 0, 0, 0}, a32[4] = {0, 0, 0, 0}, a33[4] = {0, 0, 0, 0};
+          for (unsigned long long m_ = this->amask; m_; m_ &= m_ - 1ull) {
+            const Row r = contact_row(__builtin_ctzll(m_));
+            const real w0 = weval(c0, r);
+            w->mfma16(w0, w0, a00);
+            if (Ntc >= 2) {
+              const real w1 = weval(c1, r);
+              w->mfma16(w0, w1, a10); w->mfma16(w1, w1, a11);
+              if (Ntc >= 3) {
+                const real w2 = weval(c2, r);
+                w->mfma16(w0, w2, a20); w->mfma16(w1, w2, a21); w->mfma16(w2, w2, a22);
+                if (Ntc >= 4) {
+                  const real w3 = weval(c3, r);
+                  w->mfma16(w0, w3, a30); w->mfma16(w1, w3, a31); w->mfma16(w2, w3, a32); w->mfma16(w3, w3, a33);
+                }
+              }
             }
-          } else {
-            const int j = kq + 1 + (idx - t1);
-            const real *uj = blk(j, kq);
-#pragma unroll
-            for (int c = 0; c < 3; c++) g[3 * j + c] -= uj[3 * c] * y0 + uj[3 * c + 1] * y1 + uj[3 * c + 2] * y2;
+          }
+          tile_add(0, 0, a00);
+          if (Ntc >= 2) { tile_add(1, 0, a10); tile_add(1, 1, a11); }
+          if (Ntc >= 3) { tile_add(2, 0, a20); tile_add(2, 1, a21); tile_add(2, 2, a22); }
+          if (Ntc >= 4) { tile_add(3, 0, a30); tile_add(3, 1, a31); tile_add(3, 2, a32); tile_add(3, 3, a33); }
+        } else {                                              // any size: tile by tile, the rows re-evaluated per tile
+          for (int ti = 0; ti < Ntc; ti++) {
+            Col ci;
+            colinfo(ti, ci);
+            for (int tj = 0; tj <= ti; tj++) {
+              Col cj;
+              colinfo(tj, cj);
+              real acc[4] = {0, 0, 0, 0};
+              for (unsigned long long m_ = this->amask; m_; m_ &= m_ - 1ull) {
+                const Row r = contact_row(__builtin_ctzll(m_));
+                w->mfma16(weval(cj, r), weval(ci, r), acc);
+              }
+              tile_add(ti, tj, acc);
+            }
           }
         }
+      }
+      w->sync();
+      SS_FTICK(PF_SC_COLS);
+      // ---- L D L^T by panels of 16 columns.  Lane = matrix row (64 rs + lane for row set rs), a[] = the row's entries in the panel's
+      // columns.  Pivot k: d = a_k[k] and the column below it, a_j[k], come by v_readlane from the pivot rows' lanes; every row
+      // below does  l = a[k] / d,  a[j] -= l a_j[k]  (rows at or above the pivot run the same instructions on the unused upper triangle
+      // of the diagonal tile).  Row N, the right-hand side, rides along: it ends as D^-1 L^-1 g.
+      for (int p = 0; 16 * p < N; p++) {
+        const int rs = p >> 2, lb = 16 * (p & 3), npiv = N - 16 * p < 16 ? N - 16 * p : 16;
+        {
+          const int row = 64 * rs + lane;
+          const bool have = row >= 16 * p && row < Np;
+          real *tr = H + drow(have ? row : 16 * p) + 16 * p;
+          real a[16];
+          {
+            float4_t v0{}, v1{}, v2{}, v3{};
+            if (have) { v0 = ld4(tr); v1 = ld4(tr + 4); v2 = ld4(tr + 8); v3 = ld4(tr + 12); }
+            a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w; a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
+            a[8] = v2.x; a[9] = v2.y; a[10] = v2.z; a[11] = v2.w; a[12] = v3.x; a[13] = v3.y; a[14] = v3.z; a[15] = v3.w;
+          }
+          real dsel = 0;
+#pragma unroll
+          for (int kk = 0; kk < 16; kk++) {                 // (all 16 steps, a dummy pivot of 1 behind the last unknown: with an early exit the compiler
+            const real dkk = w->bcast(a[kk], lb + kk);       //  kept the loops rolled and indexed a[] through M0, 12 instructions per update)
+            const real dk = kk < npiv ? dkk : real(1);       // (what the steps behind the last unknown touch are the unused columns N .. of the tile)
+            dsel = l15 == kk ? dk : dsel;
+            const real tl = a[kk] * rcp_nr(dk);
+#pragma unroll
+            for (int j = kk + 1; j < 16; j++) a[j] -= tl * w->bcast(a[kk], lb + j);
+            a[kk] = tl;
+          }
+          if (have) { st4w(tr, a[0], a[1], a[2], a[3]); st4w(tr + 4, a[4], a[5], a[6], a[7]); st4w(tr + 8, a[8], a[9], a[10], a[11]); st4w(tr + 12, a[12], a[13], a[14], a[15]); }
+          if (lane < npiv) g[16 * p + lane] = dsel;
+        }
         w->sync();
+        if (64 * (rs + 1) < Np) {                             // (models beyond 64 rows) the rows of the later row sets: in place, from the stored panel
+          for (int rs2 = rs + 1; 64 * rs2 < Np; rs2++) {
+            const int row = 64 * rs2 + lane;
+            if (row < Np) {
+              real *tr = H + drow(row) + 16 * p;
+              for (int kk = 0; kk < npiv; kk++) {
+                const real tl = tr[kk];
+                for (int j = kk + 1; j < npiv; j++) tr[j] -= tl * H[drow(16 * p + j) + 16 * p + kk];
+                tr[kk] = tl * rcp_nr(g[16 * p + kk]);
+              }
+            }
+          }
+          w->sync();
+        }
+        // the trailing tiles:  T(ti, tj) -= L(ti, p) D L(tj, p)^T, four instructions of K = 4 each
+        if (p + 1 < Nt) {
+          const float4_t dq = ld4(g + 16 * p + 4 * q4);
+          for (int ti = p + 1; ti < Nt; ti++) {
+            const float4_t bv = ld4(H + tq(ti, p));
+            const bool okr = trow_ok(ti);
+            for (int tj = p + 1; tj <= ti; tj++) {
+              const float4_t av = ld4(H + tq(tj, p));
+              real *o = H + tq(ti, tj);
+              const float4_t cv = ld4(o);
+              real acc[4] = {cv.x, cv.y, cv.z, cv.w};
+              w->mfma16(-(av.x * dq.x), bv.x, acc); w->mfma16(-(av.y * dq.y), bv.y, acc);
+              w->mfma16(-(av.z * dq.z), bv.z, acc); w->mfma16(-(av.w * dq.w), bv.w, acc);
+              if (okr) st4w(o, acc[0], acc[1], acc[2], acc[3]);
+            }
+          }
+          w->sync();
+        }
       }
       SS_FTICK(PF_SC_DENSE);
-      // ---- back substitution  z_k = D_k^-1 (g_k - sum_{i > k} U_ik^T z_i): lane = block row, the finished z_i passed by readlane
-      {
-        real tt0 = 0, tt1 = 0, tt2 = 0, g0 = 0, g1 = 0, g2 = 0, z0 = 0, z1 = 0, z2 = 0;
-        Ldl3 Dm{};
-        if (lane < n) {
-          const real *dk = blk(lane, lane);
-          Dm.factor(dk[0], dk[3], dk[4], dk[6], dk[7], dk[8]);
-          g0 = g[3 * lane]; g1 = g[3 * lane + 1]; g2 = g[3 * lane + 2];
+      // ---- back substitution  L^T z = (row N):  z_i is final once the rows behind it are in; lane = column, the finished z_i passed by
+      // v_readlane, the next row's entries requested one step ahead
+      if (N <= 64) {
+        real tacc = 0, zmine = 0;
+        const int cl = lane;
+        const real zp = lane < N ? H[rowN + cl] : real(0);
+        real lnext = lane < N - 1 ? H[drow(N - 1) + cl] : real(0);
+        for (int i = N - 1; i >= 0; i--) {
+          const real lcur = lnext;
+          if (i > 0) lnext = lane < i - 1 ? H[drow(i - 1) + cl] : real(0);
+          const real zi = w->bcast(zp - tacc, i);
+          zmine = lane == i ? zi : zmine;
+          tacc += lcur * zi;
         }
-        for (int i = n - 1; i >= 0; i--) {
-          real c0 = 0, c1 = 0, c2 = 0;
-          if (lane == i) { Dm.solve(g0 - tt0, g1 - tt1, g2 - tt2, c0, c1, c2); z0 = c0; z1 = c1; z2 = c2; }
-          const real zi0 = w->bcast(c0, i), zi1 = w->bcast(c1, i), zi2 = w->bcast(c2, i);
-          if (lane < i) {
-            const real *u = blk(i, lane);
-            tt0 += u[0] * zi0 + u[3] * zi1 + u[6] * zi2; tt1 += u[1] * zi0 + u[4] * zi1 + u[7] * zi2; tt2 += u[2] * zi0 + u[5] * zi1 + u[8] * zi2;
-          }
-        }
-        w->sync();                                            // (everyone has read its g)
-        if (lane < n) { g[3 * lane] = z0; g[3 * lane + 1] = z1; g[3 * lane + 2] = z2; }
         w->sync();
+        if (lane < N) g[lane] = zmine;
+      } else {
+        for (int i = N - 1; i >= 0; i--) {
+          const real zi = H[rowN + i];
+          const int ri_ = drow(i);
+          for (int k2 = lane; k2 < i; k2 += 64) H[rowN + k2] -= H[ri_ + k2] * zi;
+          w->sync();
+        }
+        for (int k2 = lane; k2 < N; k2 += 64) g[k2] = H[rowN + k2];
       }
+      w->sync();
       // ---- hand the solution to the sweep away from the root: z by body, the root body's acceleration, the free joint if the root carries it
       if (lane < h.nb && ((cmask >> lane) & 1ull)) {
         const int ri = rank(lane);

@@ -432,7 +432,7 @@ inline bool build_host_model(const ss_model_desc &d, HostModel &out) {
   }
   {
     const Layout yp = make_layout(nb, maxlev, false);
-    out.sc = make_layout_sc(nb, yp.env_floats, yp.l_Aown);
+    out.sc = make_layout_sc(nb, yp.env_floats, yp.l_An);
   }
   out.sc.npair = (int)out.pairs.size() / 2;
   // per body of the elimination tree (SELFCOL kernels copy this into the env's LDS slice): neighbour towards the root (255: it is the

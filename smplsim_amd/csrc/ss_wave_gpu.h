@@ -56,6 +56,14 @@ struct WaveGpu {
   // value of lane `src` (wave-uniform index) in every lane
   __device__ __forceinline__ float bcast(float v, int src) const { return rl(v, src); }
   __device__ __forceinline__ int bcast_i(int v, int src) const { return __builtin_amdgcn_readlane(v, src); }
+  // D = A B + C on the matrix core, exact float32 (v_mfma_f32_16x16x4_f32: an fmaf chain over k = 0..3): lane l supplies A[l & 15][l >> 4]
+  // and B[l >> 4][l & 15] and holds C/D[4 (l >> 4) + r][l & 15] in c[r]
+  __device__ __forceinline__ void mfma16(float a, float b, float *c) const {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 v = {c[0], c[1], c[2], c[3]};
+    v = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, v, 0, 0, 0);
+    c[0] = v[0]; c[1] = v[1]; c[2] = v[2]; c[3] = v[3];
+  }
   __device__ __forceinline__ float quad_xor1(float v) const { return dpp_f<0xB1>(v); }
   __device__ __forceinline__ float quad_xor2(float v) const { return dpp_f<0x4E>(v); }
   __device__ __forceinline__ int quad_xor1_i(int v) const { return dpp_i<0xB1>(v); }

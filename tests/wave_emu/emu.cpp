@@ -58,7 +58,7 @@ struct Machine {
   int cur = -1;
   int done[kLanes];
   // collective scratch (double holds both builds' values exactly)
-  double fx[kLanes];
+  double fx[kLanes], fy[kLanes];
   unsigned long long ux[kLanes];
   int siteh[4][kLanes];
   unsigned narr[kLanes];
@@ -196,6 +196,18 @@ struct WaveEmu {
     int r = (int)(unsigned)m->ux[src];
     arrive(17);
     return r;
+  }
+  // the 16x16x4 matrix instruction of the GPU build (ss_wave_gpu.h::mfma16), same operand layout, an fma chain over k
+  void mfma16(real a, real b, real *c) {
+    m->fx[ln] = a; m->fy[ln] = b;
+    arrive(18);
+    const int col = ln & 15, q = ln >> 4;
+    for (int r = 0; r < 4; r++) {
+      real acc = c[r];
+      for (int kk = 0; kk < 4; kk++) acc = std::fma((real)m->fx[(4 * q + r) + 16 * kk], (real)m->fy[col + 16 * kk], acc);
+      c[r] = acc;
+    }
+    arrive(19);
   }
   real quad_xor1(real v) { return shfl_xor(v, 1); }
   real quad_xor2(real v) { return shfl_xor(v, 2); }

@@ -30,13 +30,12 @@ env.reset()
 for _ in range(steps):
     env.step(torch.rand(N, 69, generator=g, device=env.device) * 2 - 1)
 torch.cuda.synchronize()
+out = (C.c_ulonglong * 64)()
+rc = _lib.lib().ss_debug_prof(env.handle, out, 40)
 names = ["fwd_kin", "constraints", "newton_begin", "newton_prepare", "sc:broad phase", "aba_solve", "sc:pair function calls", "newton_finish",
          "spd_prepare", "spd_finish", "integrate", "misc", "aba:up_phase1", "aba:up_last_sync", "aba:up_phase2", "aba:down", "fk:chain sums (V, Ab)",
          "fk:prologue", "fk:level_sweep", "fk:body inertia + bias force", "fk:subtree_C", "fk:velocity products + chain sum", "prep:contactK", "prep:subtree", "prep:grad",
-         "selfcol:pair functions", "selfcol:tree part", "selfcol:contact rows", "selfcol:factorization", "selfcol:back substitution",
-         "n:dense solves", "n:pooled", "n:1 tile row", "n:2 tile rows", "n:3 tile rows", "n:4 tile rows", "n:5+ tile rows", "n:active contacts", "n:unknowns", "selfcol:lock wait"]
-out = (C.c_ulonglong * 64)()
-rc = _lib.lib().ss_debug_prof(env.handle, out, len(names))
+         "selfcol:pair functions", "selfcol:factor+base solve", "selfcol:Delassus columns", "selfcol:dense solve", "selfcol:final re-solve"]
 tot = sum(out[i] for i in range(12))
 iters = float(env.solver_iters.float().mean().item())
 res = {"rc": rc, "total_ticks": tot, "mean_newton_iters": iters, "stages": {}}
