@@ -159,7 +159,7 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL>, LeanState<HT::maybe_lea
   int iters, nwarn_add, pid_on;
   int slot_body[SLOTP];    // body of this lane's contact slot(s): constant for the launch, read once from HBM
 #ifdef SS_PROFILE
-  unsigned long long prof[PF_COUNT];
+  unsigned long long prof[PF_COUNT], rt0;
 #endif
   unsigned long long touchmask;
 
@@ -231,6 +231,9 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL>, LeanState<HT::maybe_lea
     pid_on = (k->cfg.control_mode == SS_CTRL_SIMPLE_PID && k->st.pid_started) ? k->st.pid_started[env] : 0;
 #ifdef SS_PROFILE
     for (int i = 0; i < PF_COUNT; i++) prof[i] = 0ull;
+#if defined(SS_PROF_REALTIME) && defined(__HIPCC__)
+    rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
 #endif
   }
 
@@ -1475,31 +1478,39 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL>, LeanState<HT::maybe_lea
       }
       w->sync();
       SS_FTICK(PF_SC_BASE);
-      // ---- this lane's contact: its pyramid rows as spatial vectors u = (p x d ; d), scaled by sqrt(D) — zero for an inactive row
+      // ---- the contacts with an active row write their pyramid rows as spatial vectors u = sqrt(D) (p x d ; d) — zero for an inactive row
       // (branch-free: with `if (jar < 0)` around per-row updates the compiler computed all four rows' products up front and parked
-      // them in scratch: 84 serialized scratch reloads per solve, 1.2 GB of scratch traffic per launch) — and the two sides of its
-      // path through the tree as body masks
-      real urow[4][6];
-      unsigned pm[4] = {0u, 0u, 0u, 0u};                      // bodies on b1's side (lo, hi), on b2's side (lo, hi)
-      {
-        const SelfCon &c = this->sc;
-        const bool mine = (this->amask >> lane) & 1ull;
-        const real sd = mine ? SS_M(sqrt)(c.D) : real(0);
+      // them in scratch) — and the two sides of their path through the tree as body masks into a staging area, kRec reals per contact:
+      // [row][8] (6 used) | side masks (4 words).  The area is what the system leaves of the env's region (all of it when the system
+      // is in the shared block), or the geom-centre / solution-by-body arrays (dead here) when that is less than four records;
+      // more active contacts than records go in rounds.  (Round 6, first version: 24 v_readlane + 24 selects per contact.)
+      constexpr int kRec = 36;
+      real *stg = this->gc;
+      int cap = (6 * h.nb) / kRec;
+      { const int free_ = pooled ? k->sc.hloc : k->sc.hloc - hf;
+        if (free_ >= 4 * kRec) { stg = this->H + (pooled ? 0 : hf); cap = free_ / kRec; } }
+      auto stage = [&](unsigned long long rem) {               // the first `cap` contacts of rem, by rank
+        const bool mine = (rem >> lane) & 1ull;
+        const int slot = __builtin_popcountll(rem & ((1ull << lane) - 1ull));
+        if (mine && slot < cap) {
+          const SelfCon &c = this->sc;
+          real *o = stg + kRec * slot;
+          const real sd = SS_M(sqrt)(c.D);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const real wgt = (mine && c.jar[i] < 0) ? sd : real(0);
-          real d[3];
-          self_row_dir(i, mu, d);
-          urow[i][0] = wgt * (c.py * d[2] - c.pz * d[1]); urow[i][1] = wgt * (c.pz * d[0] - c.px * d[2]); urow[i][2] = wgt * (c.px * d[1] - c.py * d[0]);
-          urow[i][3] = wgt * d[0]; urow[i][4] = wgt * d[1]; urow[i][5] = wgt * d[2];
-        }
-        if (mine) {
+          for (int i = 0; i < 4; i++) {
+            const real wgt = c.jar[i] < 0 ? sd : real(0);
+            real d[3];
+            self_row_dir(i, mu, d);
+            st4w(o + 8 * i, wgt * (c.py * d[2] - c.pz * d[1]), wgt * (c.pz * d[0] - c.px * d[2]), wgt * (c.px * d[1] - c.py * d[0]), wgt * d[0]);
+            o[8 * i + 4] = wgt * d[1]; o[8 * i + 5] = wgt * d[2];
+          }
           const unsigned long long p1 = path_mask(c.b1), p2 = path_mask(c.b2), s1 = p1 & ~p2, s2 = p2 & ~p1;
-          pm[0] = (unsigned)s1; pm[1] = (unsigned)(s1 >> 32); pm[2] = (unsigned)s2; pm[3] = (unsigned)(s2 >> 32);
+          int32_t *om = reinterpret_cast<int32_t *>(o + 32);
+          om[0] = (int32_t)(unsigned)s1; om[1] = (int32_t)(unsigned)(s1 >> 32); om[2] = (int32_t)(unsigned)s2; om[3] = (int32_t)(unsigned)(s2 >> 32);
         }
-      }
+      };
       // ---- the two-body rows on the matrix core.  Lane l holds, per tile column t, the motion-vector column of unknown 16 t + (l & 15)
-      // and its body as a bit; per contact it takes pyramid row l >> 4 (24 v_readlane + selects) and forms
+      // and its body as a bit; per contact it reads pyramid row l >> 4 of the staged record and forms
       // w = sigma S_col^T u; tile (ti, tj) += W_ti^T W_tj is one instruction (A = w of tj, B = w of ti: the instruction's D is the
       // transpose of the row-major tile, so that a lane's four results are one 16-byte row segment)
       struct Col { real s[6]; unsigned lo, hi; };
@@ -1517,16 +1528,14 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL>, LeanState<HT::maybe_lea
         }
       };
       struct Row { real u[6]; unsigned m[4]; };
-      const real mq[4] = {q4 == 0 ? real(1) : real(0), q4 == 1 ? real(1) : real(0), q4 == 2 ? real(1) : real(0), q4 == 3 ? real(1) : real(0)};
-      auto contact_row = [&](int c) {                         // contact c's pyramid row l >> 4 and its side masks, in every lane
+      auto contact_row = [&](int slot) {                      // staged contact `slot`: pyramid row l >> 4 and the side masks
         Row r;
+        const real *o = stg + kRec * slot;
+        const float4_t v = ld4(o + 8 * q4);
+        r.u[0] = v.x; r.u[1] = v.y; r.u[2] = v.z; r.u[3] = v.w; r.u[4] = o[8 * q4 + 4]; r.u[5] = o[8 * q4 + 5];
+        const int32_t *om = reinterpret_cast<const int32_t *>(o + 32);
 #pragma unroll
-        for (int t = 0; t < 6; t++) {
-          // (0 / 1 weights instead of selects: the compiler turned a chain of `q4 == i ?` into three divergent branches per component)
-          r.u[t] = mq[0] * w->bcast(urow[0][t], c) + mq[1] * w->bcast(urow[1][t], c) + mq[2] * w->bcast(urow[2][t], c) + mq[3] * w->bcast(urow[3][t], c);
-        }
-#pragma unroll
-        for (int t = 0; t < 4; t++) r.m[t] = (unsigned)w->bcast_i((int)pm[t], c);
+        for (int t = 0; t < 4; t++) r.m[t] = (unsigned)om[t];
         return r;
       };
       auto weval = [&](const Col &c, const Row &r) -> real {
@@ -1548,8 +1557,17 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL>, LeanState<HT::maybe_lea
           colinfo(0, c0); colinfo(1, c1); colinfo(2, c2); colinfo(3, c3);
           real a00[4] = {0, 0, 0, 0}, a10[4] = {0, 0, 0, 0}, a11[4] = {0, 0, 0, 0}, a20[4] = {0, 0, 0, 0}, a21[4] = {0, 0, 0, 0}, a22[4] = {0, 0, 0, 0},
                a30[4] = {0, 0, 0, 0}, a31[4] = {0, 0, 0, 0}, a32[4] = {0, 0, 0, 0}, a33[4] = {0, 0, 0, 0};
-          for (unsigned long long m_ = this->amask; m_; m_ &= m_ - 1ull) {
-            const Row r = contact_row(__builtin_ctzll(m_));
+          for (unsigned long long rem = this->amask; rem;) {
+          int cnt = __builtin_popcountll(rem);
+          if (cnt > cap) cnt = cap;
+          w->sync();                                          // (the records of the round before are read)
+          stage(rem);
+          w->sync();
+          for (int i = 0; i < cnt; i++) rem &= rem - 1ull;
+          Row rn = contact_row(0);
+          for (int sl = 0; sl < cnt; sl++) {
+            const Row r = rn;
+            rn = contact_row(sl + 1 < cnt ? sl + 1 : sl);     // the next record is on its way while this one is used
             const real w0 = weval(c0, r);
             w->mfma16(w0, w0, a00);
             if (Ntc >= 2) {
@@ -1565,24 +1583,42 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL>, LeanState<HT::maybe_lea
               }
             }
           }
+          }
           tile_add(0, 0, a00);
           if (Ntc >= 2) { tile_add(1, 0, a10); tile_add(1, 1, a11); }
           if (Ntc >= 3) { tile_add(2, 0, a20); tile_add(2, 1, a21); tile_add(2, 2, a22); }
           if (Ntc >= 4) { tile_add(3, 0, a30); tile_add(3, 1, a31); tile_add(3, 2, a32); tile_add(3, 3, a33); }
-        } else {                                              // any size: tile by tile, the rows re-evaluated per tile
-          for (int ti = 0; ti < Ntc; ti++) {
-            Col ci;
+        } else {                                              // any size: tile row by tile row, the row's tiles in registers (5 tile columns = the 22 / 23-body sets)
+          for (int tb = 0; tb < Ntc; tb += 5) {
+          for (int ti = tb; ti < Ntc; ti++) {
+            Col ci, cj[5];
             colinfo(ti, ci);
-            for (int tj = 0; tj <= ti; tj++) {
-              Col cj;
-              colinfo(tj, cj);
-              real acc[4] = {0, 0, 0, 0};
-              for (unsigned long long m_ = this->amask; m_; m_ &= m_ - 1ull) {
-                const Row r = contact_row(__builtin_ctzll(m_));
-                w->mfma16(weval(cj, r), weval(ci, r), acc);
+#pragma unroll
+            for (int j = 0; j < 5; j++) colinfo(tb + j, cj[j]);
+            real acc[5][4];
+#pragma unroll
+            for (int j = 0; j < 5; j++)
+#pragma unroll
+              for (int r_ = 0; r_ < 4; r_++) acc[j][r_] = 0;
+            for (unsigned long long rem = this->amask; rem;) {
+              int cnt = __builtin_popcountll(rem);
+              if (cnt > cap) cnt = cap;
+              w->sync();
+              stage(rem);
+              w->sync();
+              for (int i = 0; i < cnt; i++) rem &= rem - 1ull;
+              for (int sl = 0; sl < cnt; sl++) {
+                const Row r = contact_row(sl);
+                const real wi = weval(ci, r);
+#pragma unroll
+                for (int j = 0; j < 5; j++)
+                  if (tb + j <= ti) w->mfma16(weval(cj[j], r), wi, acc[j]);
               }
-              tile_add(ti, tj, acc);
             }
+#pragma unroll
+            for (int j = 0; j < 5; j++)
+              if (tb + j <= ti) tile_add(ti, tb + j, acc[j]);
+          }
           }
         }
       }
@@ -1620,17 +1656,28 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL>, LeanState<HT::maybe_lea
           if (lane < npiv) g[16 * p + lane] = dsel;
         }
         w->sync();
-        if (64 * (rs + 1) < Np) {                             // (models beyond 64 rows) the rows of the later row sets: in place, from the stored panel
+        if (64 * (rs + 1) < Np) {                             // (more than 64 rows) the rows of the later row sets: the same elimination, the pivot rows'
+          const int st_ = 16 * (p + 1);                       // entries read from the stored diagonal tile (uniform addresses) instead of the pivot lanes
+          const real *Ld = H + drow(16 * p) + 16 * p;
           for (int rs2 = rs + 1; 64 * rs2 < Np; rs2++) {
             const int row = 64 * rs2 + lane;
-            if (row < Np) {
-              real *tr = H + drow(row) + 16 * p;
-              for (int kk = 0; kk < npiv; kk++) {
-                const real tl = tr[kk];
-                for (int j = kk + 1; j < npiv; j++) tr[j] -= tl * H[drow(16 * p + j) + 16 * p + kk];
-                tr[kk] = tl * rcp_nr(g[16 * p + kk]);
-              }
+            const bool have2 = row < Np;
+            real *tr = H + drow(have2 ? row : 16 * p) + 16 * p;
+            real a[16];
+            {
+              float4_t v0{}, v1{}, v2{}, v3{};
+              if (have2) { v0 = ld4(tr); v1 = ld4(tr + 4); v2 = ld4(tr + 8); v3 = ld4(tr + 12); }
+              a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w; a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
+              a[8] = v2.x; a[9] = v2.y; a[10] = v2.z; a[11] = v2.w; a[12] = v3.x; a[13] = v3.y; a[14] = v3.z; a[15] = v3.w;
             }
+#pragma unroll
+            for (int kk = 0; kk < 16; kk++) {                 // (a later row set behind a panel means the panel is full: 16 pivots)
+              const real tl = a[kk];
+#pragma unroll
+              for (int j = kk + 1; j < 16; j++) a[j] -= tl * Ld[st_ * j + kk];
+              a[kk] = tl * rcp_nr(g[16 * p + kk]);
+            }
+            if (have2) { st4w(tr, a[0], a[1], a[2], a[3]); st4w(tr + 4, a[4], a[5], a[6], a[7]); st4w(tr + 8, a[8], a[9], a[10], a[11]); st4w(tr + 12, a[12], a[13], a[14], a[15]); }
           }
           w->sync();
         }
@@ -1654,32 +1701,64 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL>, LeanState<HT::maybe_lea
         }
       }
       SS_FTICK(PF_SC_DENSE);
-      // ---- back substitution  L^T z = (row N):  z_i is final once the rows behind it are in; lane = column, the finished z_i passed by
-      // v_readlane, the next row's entries requested one step ahead
+      // ---- back substitution  L^T z = (row N).  Up to 64 unknowns: lane = column, rows from the last; z_i = (row N)_i - t_i is final when the
+      // rows behind it are in, passed on by v_readlane; the row's entries are requested one step ahead, the address walks down the rows
+      // (8 vector instructions per row; a first version re-derived the address and branched around the read: 30)
       if (N <= 64) {
-        real tacc = 0, zmine = 0;
-        const int cl = lane;
-        const real zp = lane < N ? H[rowN + cl] : real(0);
-        real lnext = lane < N - 1 ? H[drow(N - 1) + cl] : real(0);
-        for (int i = N - 1; i >= 0; i--) {
-          const real lcur = lnext;
-          if (i > 0) lnext = lane < i - 1 ? H[drow(i - 1) + cl] : real(0);
+        const real zp = H[rowN + (lane < N ? lane : 0)];
+        real tacc = 0;
+        int ti_ = (N - 1) >> 4, ri_ = (N - 1) & 15;
+        int st_ = 16 * (ti_ + 1);
+        const real *rp = H + drow(N - 1) + lane;             // (a lane beyond the row's end reads the rows behind it: inside the system, masked below)
+        real lnext = *rp;
+        for (int i = N - 1; i > 0; i--) {
+          const real lcur = lane < i ? lnext : real(0);
+          if (ri_ == 0) { ti_--; ri_ = 15; st_ -= 16; rp -= st_; } else { ri_--; rp -= st_; }
+          lnext = *rp;
           const real zi = w->bcast(zp - tacc, i);
-          zmine = lane == i ? zi : zmine;
           tacc += lcur * zi;
         }
         w->sync();
-        if (lane < N) g[lane] = zmine;
+        if (lane < N) g[lane] = zp - tacc;
+        w->sync();
       } else {
-        for (int i = N - 1; i >= 0; i--) {
-          const real zi = H[rowN + i];
-          const int ri_ = drow(i);
-          for (int k2 = lane; k2 < i; k2 += 64) H[rowN + k2] -= H[ri_ + k2] * zi;
-          w->sync();
+      // more than 64 unknowns: panel by panel from the last: what the rows behind a panel contribute is
+      // t_c = sum_r z_r L[r][c], four matrix instructions per tile (A = z of four rows, the same for every i; B = the rows' entries in the
+      // panel's columns: every lane ends with t of column l & 15); inside the panel lane = column with its column of the diagonal tile in
+      // registers, 16 steps of v_readlane.  z goes to g[] (over the pivots, which are done).  (First version: one column per lane over
+      // all N rows, an LDS read and 30 instructions per row.)
+      for (int p = (N - 1) >> 4; p >= 0; p--) {
+        real tacc[4] = {0, 0, 0, 0};
+        for (int qt = p + 1; 16 * qt < N; qt++) {
+          const int r0 = 16 * qt + 4 * q4, st_ = 16 * (qt + 1);
+          const float4_t zq = ld4(g + r0);
+          // (rows N .. of the last tile row: z is zero there; the address is held inside the system, row N - 1, so that 0 x garbage cannot make a NaN)
+          const real *lq = H + drow(16 * qt) + 16 * p + l15;
+          const int rl = 4 * q4, rmax = N - 1 - 16 * qt;
+          const real b0 = lq[st_ * (rl < rmax ? rl : rmax)], b1 = lq[st_ * (rl + 1 < rmax ? rl + 1 : rmax)], b2 = lq[st_ * (rl + 2 < rmax ? rl + 2 : rmax)], b3 = lq[st_ * (rl + 3 < rmax ? rl + 3 : rmax)];
+          w->mfma16(zq.x, b0, tacc); w->mfma16(zq.y, b1, tacc); w->mfma16(zq.z, b2, tacc); w->mfma16(zq.w, b3, tacc);
         }
-        for (int k2 = lane; k2 < N; k2 += 64) g[k2] = H[rowN + k2];
+        const int c0_ = 16 * p, kc = c0_ + l15;
+        real cl[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {                          // (unconditional reads of rows inside the system, then selects: no divergent branch per entry)
+          const real lv = H[drow(c0_ + i < N ? c0_ + i : c0_) + kc];
+          cl[i] = (i > l15 && c0_ + i < N) ? lv : real(0);
+        }
+        const real yv = H[rowN + kc];
+        const real v = (kc < N ? yv : real(0)) - tacc[0];
+        real acc = 0, z = 0;
+#pragma unroll
+        for (int i = 15; i >= 0; i--) {
+          const real zi = w->bcast(v - acc, i);
+          z = l15 == i ? zi : z;
+          acc += cl[i] * zi;
+        }
+        w->sync();
+        if (lane < 16) g[c0_ + lane] = kc < N ? z : real(0);
+        w->sync();
       }
-      w->sync();
+      }
       // ---- hand the solution to the sweep away from the root: z by body, the root body's acceleration, the free joint if the root carries it
       if (lane < h.nb && ((cmask >> lane) & 1ull)) {
         const int ri = rank(lane);
@@ -2477,6 +2556,17 @@ SS_DEV bool run_env(W *w, const KArgs *k, const uint32_t *T, real *L, int env, i
 
 #ifdef SS_PROFILE
   if (lane == 0 && k->prof) for (int i = 0; i < PF_COUNT; i++) w->atomic_add_u64(k->prof + i, sim.prof[i]);
+#ifdef SS_PROF_ENV
+  // per-env record of the control step (profile studies): total ticks >> 10 | dense-part ticks >> 10 << 16, in the truncation counter's array
+  if constexpr (SELFCOL) if (lane == 0 && k->self_trunc && mode == MODE_STEP) {
+    unsigned long long tt = 0, td = sim.prof[PF_SC_BASE] + sim.prof[PF_SC_COLS] + sim.prof[PF_SC_DENSE] + sim.prof[PF_SC_FINAL];
+    for (int i = 0; i < 12; i++) tt += sim.prof[i];
+#ifdef SS_PROF_REALTIME
+    td = (__builtin_amdgcn_s_memrealtime() - sim.rt0) << 6;   // 100 MHz wall clock of the control step, in units of 160 ns
+#endif
+    k->self_trunc[env] = (int)((tt >> 10) & 0xFFFF) | (int)(((td >> 10) & 0x7FFF) << 16);
+  }
+#endif
 #endif
   // body frames of the last forward: mj_kinematics readback, and (ss_set_body_outputs) a by-product of every step / reset
   if ((mode == MODE_KINEMATICS || (BODYOUT && k->out0 && !is_debug && mode != MODE_SUBSTEP)) && lane < h.nb) {

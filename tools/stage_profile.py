@@ -27,6 +27,12 @@ SELF = bool(int(os.environ.get("SELFCOL", "0")))
 env = SMPLSimVecEnv(N, autoreset=True, seed=1234, self_collision=SELF)
 g = torch.Generator(device=env.device); g.manual_seed(1234)
 env.reset()
+WARM = int(os.environ.get("WARMUP", "0"))                   # control steps before the counted ones (the counters of the warm-up are subtracted)
+for _ in range(WARM):
+    env.step(torch.rand(N, 69, generator=g, device=env.device) * 2 - 1)
+torch.cuda.synchronize()
+out0 = (C.c_ulonglong * 64)()
+_lib.lib().ss_debug_prof(env.handle, out0, 40)
 for _ in range(steps):
     env.step(torch.rand(N, 69, generator=g, device=env.device) * 2 - 1)
 torch.cuda.synchronize()
@@ -37,6 +43,7 @@ names = ["fwd_kin", "constraints", "newton_begin", "newton_prepare", "sc:broad p
          "n:dense solves", "n:pooled", "n:1 tile row", "n:2 tile rows", "n:3 tile rows", "n:4 tile rows", "n:5+ tile rows", "n:active contacts", "n:unknowns", "selfcol:lock wait"]
 out = (C.c_ulonglong * 64)()
 rc = _lib.lib().ss_debug_prof(env.handle, out, len(names))
+for i in range(64): out[i] -= out0[i]
 tot = sum(out[i] for i in range(12))
 iters = float(env.solver_iters.float().mean().item())
 res = {"rc": rc, "total_ticks": tot, "mean_newton_iters": iters, "stages": {}}

@@ -27,11 +27,18 @@ SELF = bool(int(os.environ.get("SELFCOL", "0")))
 env = SMPLSimVecEnv(N, autoreset=True, seed=1234, self_collision=SELF)
 g = torch.Generator(device=env.device); g.manual_seed(1234)
 env.reset()
+WARM = int(os.environ.get("WARMUP", "0"))                   # control steps before the counted ones (the counters of the warm-up are subtracted)
+for _ in range(WARM):
+    env.step(torch.rand(N, 69, generator=g, device=env.device) * 2 - 1)
+torch.cuda.synchronize()
+out0 = (C.c_ulonglong * 64)()
+_lib.lib().ss_debug_prof(env.handle, out0, 40)
 for _ in range(steps):
     env.step(torch.rand(N, 69, generator=g, device=env.device) * 2 - 1)
 torch.cuda.synchronize()
 out = (C.c_ulonglong * 64)()
 rc = _lib.lib().ss_debug_prof(env.handle, out, 40)
+for i in range(64): out[i] -= out0[i]
 names = ["fwd_kin", "constraints", "newton_begin", "newton_prepare", "sc:broad phase", "aba_solve", "sc:pair function calls", "newton_finish",
          "spd_prepare", "spd_finish", "integrate", "misc", "aba:up_phase1", "aba:up_last_sync", "aba:up_phase2", "aba:down", "fk:chain sums (V, Ab)",
          "fk:prologue", "fk:level_sweep", "fk:body inertia + bias force", "fk:subtree_C", "fk:velocity products + chain sum", "prep:contactK", "prep:subtree", "prep:grad",
