@@ -25,8 +25,9 @@ _LIB = None
 # -Os, so that translation unit keeps -O3 (MOTION_OPT).
 DEFAULT_OPT = "-Os -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-ilp"
 # the body-body-contact instantiations (smplsim_hip_sc.hip; round 4: dense block solve over the coupled set) are the other way round:
-# -O3 / -O2 5.90 ms per 4096-env step, -Os 6.39 ms (same-box A/B, profiles/r04_selfcol_ab.txt); scratch 912 vs 1104 bytes per lane
-SC_OPT = "-O3 -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-ilp"
+# -O3 / -O2 5.90 ms per 4096-env step, -Os 6.39 ms (same-box A/B, profiles/r04_selfcol_ab.txt); scratch 912 vs 1104 bytes per lane.
+# Round 6 (dense solve on the matrix core): -O2 4.32 ms, -O3 4.40, -Os 4.41, -O3 with the default scheduler 4.62 (profiles/r06_selfcol_ab.txt)
+SC_OPT = "-O2 -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-ilp"
 MOTION_OPT = "-O3"
 # the SMPL-X/H size class (smplsim_hip_x.hip, round 5; 256 VGPRs; A/B taken at 6 envs per CU, 7 since the lean tables): -O2 2.93 ms per 4096-env step, -O3 2.95, -Os 2.97
 X_OPT = "-O2 -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-ilp"

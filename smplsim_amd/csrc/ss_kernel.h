@@ -1403,8 +1403,9 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL>, LeanState<HT::maybe_lea
       auto rank = [&](int b) { return (int)__builtin_popcountll(cmask & ((1ull << b) - 1ull)); };
       const real mu = h.mu;
       const int l15 = lane & 15, q4 = lane >> 4;              // this lane's place in a tile as the matrix instruction sees it: row l15, columns 4 q4 .. + 3
-      auto tq = [&](int ti, int tj) { return 256 * ((ti * (ti + 1)) >> 1) + 16 * (ti + 1) * l15 + 16 * tj + 4 * q4; };
-      auto trow_ok = [&](int ti) { return 16 * ti + l15 < Np; };   // (the last tile row ends with row N: what lies behind it is not ours to write)
+      auto trow_ok = [&](int ti) { return 16 * ti + l15 < Np; };   // (the last tile row ends with row N: what lies behind it is not ours to write,
+      // and a lane whose row is behind it reads the tile row's first row instead — its results are not stored, its operands must be finite and in range)
+      auto tq = [&](int ti, int tj) { return 256 * ((ti * (ti + 1)) >> 1) + 16 * (ti + 1) * (trow_ok(ti) ? l15 : 0) + 16 * tj + 4 * q4; };
       // ---- zero the tiles (the level buffer and Aown they lie over are dead: the sweep towards the root is done)
       w->sync();                                              // (the root's lanes have read level 1's rows, which lie in this region)
       for (int i = 4 * lane; i < hf; i += 256) st4w(H + i, 0, 0, 0, 0);
@@ -2409,6 +2410,9 @@ SS_DEV bool run_env(W *w, const KArgs *k, const uint32_t *T, real *L, int env, i
   real *obs_also = (!fused_pass && k->fused_reset && k->obs2) ? k->obs2 + (size_t)env * ostride : nullptr;
   const int maxit = cf.newton_iters > 0 ? cf.newton_iters : 100;   // mjOption.iterations
 
+#if defined(SS_COST_KEY) && defined(__HIPCC__)
+  const unsigned long long cost_t0 = __builtin_readcyclecounter();   // study build: the env's own cycles of this pass go to the truncation counter's array
+#endif
   int cur_t = st.cur_t[env];
   // task scalars: speed/getup [target, change_steps, recovery, -] ; reach [tx, ty, tz, change_steps]
   const bool is_reach = cf.task == SS_TASK_REACH;
@@ -2575,6 +2579,9 @@ SS_DEV bool run_env(W *w, const KArgs *k, const uint32_t *T, real *L, int env, i
   }
   if (mode == MODE_KINEMATICS) return false;
   const unsigned long long touch = sim.touchmask;
+#if defined(SS_COST_KEY) && defined(__HIPCC__)
+  if (lane == 0 && k->self_trunc && mode == MODE_STEP) k->self_trunc[env] = (int)((__builtin_readcyclecounter() - cost_t0) >> 10);
+#endif
   if (lane == 0) {
     st.touch[2 * env] = (int)(touch & 0xFFFFFFFFull); st.touch[2 * env + 1] = (int)(touch >> 32);
     if (!fused_pass) st.solver_iters[env] = sim.iters;      // the scheduling hint is the step's count, not the reset's

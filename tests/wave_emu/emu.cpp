@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <algorithm>
 #include <vector>
 
@@ -333,7 +334,10 @@ struct EmuBackend {
     (void)envs_per_wg; (void)lds_bytes;
     static thread_local Machine *m = new Machine();
     std::vector<ss::real> L(ss::env_slice_floats(k));
-    std::vector<ss::real> pool(k.cfg.self_collision ? ss::ss_pool_floats(k.sc) + 4 : 4, ss::real(0));   // the workgroup's shared dense block (lock word first)
+    // the workgroup's shared dense block (lock word first); NaNs behind it: a read past the block's end shows up in the results instead of going unnoticed
+    const size_t pool_n = k.cfg.self_collision ? (size_t)ss::ss_pool_floats(k.sc) + 4 : 4;
+    std::vector<ss::real> pool(pool_n + 2048, std::numeric_limits<ss::real>::quiet_NaN());
+    std::fill(pool.begin(), pool.begin() + pool_n, ss::real(0));
     if (*k.work_counter != 0) return "work counter not zero at launch";
     *k.work_counter_next = 0;
     for (int env = 0; env < nenv; env++) {

@@ -7,7 +7,7 @@ NAME=$1; shift
 OPT=${SS_HIPCC_OPT:--Os -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-ilp}
 mkdir -p build/variants
 /opt/rocm/bin/hipcc --offload-arch=gfx950 $OPT "$@" -std=c++17 -fPIC -c smplsim_amd/csrc/smplsim_hip.hip -o build/variants/hip_$NAME.o &
-SCOPT=${SS_HIPCC_SC_OPT:--O3 -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-ilp}
+SCOPT=${SS_HIPCC_SC_OPT:--O2 -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-ilp}
 /opt/rocm/bin/hipcc --offload-arch=gfx950 $SCOPT "$@" -std=c++17 -fPIC -c smplsim_amd/csrc/smplsim_hip_sc.hip -o build/variants/hip_sc_$NAME.o &
 # (the imitation unit keeps the shipped flags unless SS_HIPCC_IM_OPT says otherwise: clang 22 crashes in its register allocator on that unit at -O2 / -O3)
 IMOPT=${SS_HIPCC_IM_OPT:--Os -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-ilp}

@@ -2,6 +2,7 @@
 SS_PROF_LIB = the library; prints the heaviest envs of a few steps: Newton iterations, contacts, total and dense-part kiloticks."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
 import torch
 from smplsim_amd import _cabi, _lib
 _lib._LIB = _cabi.bind_mlp(_cabi.bind(C.CDLL(os.environ["SS_PROF_LIB"])))
@@ -22,6 +23,12 @@ for s in range(int(os.environ.get("STEPS", "12"))):
     torch.cuda.synchronize()
     kms = e0.elapsed_time(e1)
     r = rec.cpu().numpy(); tot = r & 0xFFFF; den = (r >> 16) & 0x7FFF
+    if os.environ.get("DENSE_PARTS"):                       # -DSS_PROF_ENV_DENSE build: tree part | contact rows | factorization | back substitution, 32 k ticks each
+        parts = np.stack([r & 255, (r >> 8) & 255, (r >> 16) & 255, (r >> 24) & 127], 1) * 32.768
+        top = parts.sum(1).argsort()[::-1][:4]
+        it = env.solver_iters.cpu().numpy()
+        print(os.environ.get("TAG", ""), "step", s, "largest dense solves (iters | tree, rows, factorization, back substitution kticks):", [(int(it[i]), parts[i].round().tolist()) for i in top], "mean parts", parts.mean(0).round(1).tolist())
+        continue
     it = env.solver_iters.cpu().numpy(); nc = env.self_contacts.cpu().numpy()
     tot_all.append(tot.copy()); den_all.append(den.copy()); it_all.append(it.copy())
     top = tot.argsort()[::-1][:3]
