@@ -4,7 +4,9 @@ R=$GRAFT_REPO_ROOT
 OUT=/tmp/prof_raw
 rm -rf $OUT; mkdir -p $OUT $R/gpurun_out
 cd $R
-CMD="python bench.py --steps ${STEPS:-20} --warmup 3 --no-cpu-baseline ${BENCH_ARGS:-}"
+# WARMUP control steps are stepped but not counted (PROF_SKIP_STEPS of prof_summarize.py): the profiled launches are the workload as bench.py times it
+export PROF_SKIP_STEPS=${WARMUP:-3}
+CMD="python bench.py --steps ${STEPS:-20} --warmup ${WARMUP:-3} --no-cpu-baseline ${BENCH_ARGS:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1; echo "trace rc=$?"
 for grp in "fetch:FETCH_SIZE" "write:WRITE_SIZE" \
            "sq1:SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU" \

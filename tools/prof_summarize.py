@@ -10,6 +10,9 @@ from collections import defaultdict
 
 prof, out = sys.argv[1], sys.argv[2]
 summary = {}
+# PROF_SKIP_STEPS: step launches after the initial reset that are warm-up and do not count (getup / imitation: the profiled launches
+# must be the TIMED workload — Fall resets and re-initialisations running inside them — not the first launches after a fresh reset)
+SKIP = int(os.environ.get("PROF_SKIP_STEPS", "0"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from smplsim_amd._lib import source_hash   # noqa: E402  (the tree the counters were taken on: bench.py refuses a summary of another tree)
 SRC_HASH = source_hash()
@@ -33,6 +36,9 @@ for f in glob.glob(os.path.join(prof, "trace", "**", "*kernel_trace.csv"), recur
             st, rs = dur[1::2], dur[2::2]
             if rs and sum(rs) / len(rs) > 0.3 * sum(st) / len(st):   # fused autoreset: every launch after the first is a step
                 st, rs = dur[1:], []
+            if SKIP and not rs and len(st) > SKIP:
+                st = st[SKIP:]
+            summary["skipped_warmup_step_launches"] = SKIP
             summary["launches_alternate_step_reset"] = bool(rs)
             summary["step_launches"] = {"n": len(st), "avg_us": sum(st) / len(st), "min_us": min(st), "max_us": max(st)}
             if rs:
@@ -53,7 +59,7 @@ for d in sorted(glob.glob(os.path.join(prof, "pmc_*"))):
         rows = [r for r in csv.DictReader(open(f)) if "ss_env_kernel" in r["Kernel_Name"]]
         ids = sorted({int(r["Dispatch_Id"]) for r in rows})
         alt = summary.get("launches_alternate_step_reset", True)
-        kind = {d: ("initial_reset" if i == 0 else ("step" if (i % 2 == 1 or not alt) else "autoreset")) for i, d in enumerate(ids)}
+        kind = {d: ("initial_reset" if i == 0 else ("warmup" if (not alt and i <= SKIP) else ("step" if (i % 2 == 1 or not alt) else "autoreset"))) for i, d in enumerate(ids)}
         for r in rows:
             a = agg[kind[int(r["Dispatch_Id"])] + " launches of " + r["Kernel_Name"][:40]][r["Counter_Name"]]
             a[0] += 1; a[1] += float(r["Counter_Value"])
