@@ -26,6 +26,18 @@ enum { SS_ACT_NONE = 0, SS_ACT_SILU = 1, SS_ACT_TANH = 2, SS_ACT_RELU = 3 };   /
 int ss_linear_bf16(const void *x, const void *w, const float *bias, void *y, int32_t M, int32_t N, int32_t K, int32_t ldy,
                    int32_t activation, int32_t y_is_f32, void *stream);
 
+/* The product of the PPO update's forward and backward passes (round 6; the reference's update, agents/agent_ppo.py:20-83, runs them through
+ * autograd): the same K-contiguous y = x W^T on the matrix cores, K a multiple of 64, with what a training step needs of it
+ *   bf16 form (y_is_f32_accumulate = 0):  v = x W^T + bias;  v *= mul (if given: [M, ldy] bf16, the stored activation derivative of the layer
+ *       below: dZ = (dZ' W) * act'(z));  y [M, ldy] = act(v);  yt [N, ldyt] = y^T (every product of the backward pass contracts over what is a row
+ *       here: written transposed, dW = dZ^T h and dX = dZ W are this same kernel again);  dact [M, ldy] = act'(v).  Any of y / yt / dact may be
+ *       NULL (mul and dact need y).
+ *   accumulating fp32 form (y_is_f32_accumulate = 1):  y [M, ldy] fp32 += x W^T (+ bias), the contraction split over several workgroups whose
+ *       partial sums meet in y by hardware atomics — for products with few outputs and a deep K (the weight gradients: K = the batch).
+ *       The caller zeroes y. */
+int ss_linear_bf16_train(const void *x, const void *w, const float *bias, const void *mul, void *y, void *yt, void *dact, int32_t M, int32_t N,
+                         int32_t K, int32_t ldy, int32_t ldyt, int32_t activation, int32_t y_is_f32_accumulate, void *stream);
+
 /* Observation -> first layer input: y = clamp(obs, clip_lo, clip_hi) (AgentPPO's clip_obs), then, when *norm_n > 0,
  * clamp((y - mean) / (std + 1e-8), -norm_clip, norm_clip) (RunningNorm.forward in eval mode), rounded to bf16 into
  * out [M, kpad] with the columns >= dim zeroed.  norm_* may be NULL (no normalisation). */

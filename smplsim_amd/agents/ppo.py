@@ -46,6 +46,7 @@ class PPOConfig:
     bootstrap: bool = True
     amp_bf16: bool = False      # run the update's network passes under bf16 autocast (MFMA rate); off = the reference's fp32
     mfma_inference: bool = False   # sampler: policy forward by the library's fused bf16 MFMA kernels (learning/fast_policy.py)
+    mfma_update: bool = False      # update: the networks' forward AND backward passes on the library's own GEMM (learning/fused_train.py), bf16 operands
     extra: dict = field(default_factory=dict)
 
 
@@ -69,6 +70,11 @@ class AgentPPO:
         if c.mfma_inference:
             from ..learning.fast_policy import FusedPolicyInference
             self.fast_policy = FusedPolicyInference(self.policy_net, c.clip_obs_range if c.clip_obs else None)
+        self.fused_policy = self.fused_value = None
+        if c.mfma_update:
+            from ..learning.fused_train import FusedMLPTrain
+            self.fused_policy = FusedMLPTrain(self.policy_net.net.affine_layers, self.policy_net.action_mean, c.activation)
+            self.fused_value = FusedMLPTrain(self.value_net.net.affine_layers, self.value_net.value_head, c.activation)
 
     # ------------------------------------------------------------------ sampling
     def _prep_obs(self, obs):
@@ -194,17 +200,32 @@ class AgentPPO:
     def _f32(self, x):
         return x.float() if x.dtype == torch.bfloat16 else x
 
+    def _policy_log_prob(self, states, actions):
+        """PolicyGaussian.get_log_prob with the network passes on the library's GEMM (mfma_update): RunningNorm (train mode: its statistics
+        follow the passes as in the torch path), mean = head(MLP(.)), the log-density in fp32 torch."""
+        p = self.policy_net
+        mean = self.fused_policy(p.norm(states))
+        log_std = p.action_log_std.expand_as(mean)
+        z = (actions - mean) * torch.exp(-log_std)
+        return (-0.5 * z * z - log_std - 0.5 * math.log(2.0 * math.pi)).sum(dim=1, keepdim=True)
+
     def ppo_loss(self, states, actions, advantages, fixed_log_probs):
-        with self._autocast():
-            log_probs = self._f32(self.policy_net.get_log_prob(states, actions))
+        if getattr(self, "fused_policy", None) is not None:
+            log_probs = self._policy_log_prob(states, actions)
+        else:
+            with self._autocast():
+                log_probs = self._f32(self.policy_net.get_log_prob(states, actions))
         ratio = torch.exp(log_probs - fixed_log_probs)
         clipped = ratio.clamp(1.0 - self.cfg.clip_epsilon, 1.0 + self.cfg.clip_epsilon)
         return -torch.minimum(ratio * advantages, clipped * advantages).mean()
 
     def update_value(self, critic_states, returns):
         for _ in range(self.cfg.value_opt_niter):
-            with self._autocast():
-                pred = self._f32(self.value_net(critic_states))
+            if getattr(self, "fused_value", None) is not None:
+                pred = self.fused_value(critic_states)
+            else:
+                with self._autocast():
+                    pred = self._f32(self.value_net(critic_states))
             loss = (pred - returns).pow(2).mean()
             self.optimizer_value.zero_grad(set_to_none=True)
             loss.backward()
@@ -217,8 +238,9 @@ class AgentPPO:
         states = batch["states"].reshape(T * N, -1)
         self.policy_net.eval(); self.value_net.eval()
         with torch.no_grad():
-            values = self.value_net(states).reshape(T, N)
-            boot = self.value_net(batch["last_state"]).reshape(N) if c.bootstrap else None
+            vf = self.fused_value if getattr(self, "fused_value", None) is not None else self.value_net   # (mfma_update: the critic's passes for GAE on the library's GEMM too)
+            values = vf(states).reshape(T, N)
+            boot = vf(batch["last_state"]).reshape(N) if c.bootstrap else None
         adv, ret = estimate_advantages_columns(batch["rewards"], batch["not_done"], batch["not_dead"], values, c.gamma, c.tau, boot)
         adv = normalize_advantages(adv).reshape(T * N, 1)
         ret = ret.reshape(T * N, 1)

@@ -353,6 +353,196 @@ __global__ void __launch_bounds__(512) ss_linear_glds_kernel(const __bf16 *__res
   }
 }
 
+// ---- round 6: the GEMM of the PPO update (reference agent_ppo.py:20-83 runs the same three products per layer through
+// autograd).  The asynchronous-copy K loop of ss_linear_glds_kernel with (a) a K split over blockIdx.z for products whose output is small and whose
+// contraction is the batch (dW = dZ^T h: 2048 x 1536 outputs over K = 53248 rows), partial sums added to the fp32 output by hardware atomics;
+// (b) an epilogue that multiplies by a second operand (the stored activation derivative: dZ = (dZ' W) * act'(z)) and / or applies the activation;
+// (c) up to three bf16 outputs of the same tile staged through LDS at once: the result, its TRANSPOSE (every product of the backward pass
+// contracts over what the forward pass has as rows: with h^T and dZ^T written here, all three products of a layer are the one K-contiguous
+// "x W^T" kernel — no transposing loads, no separate transpose launches), and the activation's derivative at the pre-activation.
+struct LinearTrainArgs {
+  const __bf16 *X, *W;          // [M, K], [N, K] row-major, K a multiple of 64
+  const float *bias;            // [N] or null
+  const __bf16 *mul;            // [M, ldy] or null: the result is multiplied by it before the activation
+  void *Y;                      // [M, ldy] bf16 (or fp32 when f32_atomic: += partial sums; the caller zeroes it) or null
+  __bf16 *Yt;                   // [N, ldyt] transposed copy or null
+  __bf16 *Dact;                 // [M, ldy] act'(pre-activation) or null
+  int M, N, K, ldy, ldyt, act, xcd_remap, ksplit;
+};
+
+template <int BN, bool F32ATOMIC>
+__global__ void __launch_bounds__(512) ss_linear_train_kernel(const LinearTrainArgs a) {
+  constexpr int BK = 64, WM = 4, WN = 2, NST = 3;
+  constexpr int TN = BN / (32 * WN);
+  constexpr int STAGE = (BM + BN) * BK;
+  constexpr int NI = (BM + BN) / 64;
+  extern __shared__ __attribute__((aligned(16))) __bf16 lds_g[];
+  const __bf16 *__restrict__ X = a.X, *__restrict__ W = a.W;
+  const int M = a.M, N = a.N, K = a.K;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave / WN, wn = wave % WN;
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int gx = gridDim.x, gy = gridDim.y;
+    if (a.xcd_remap && gy % 8 == 0) {
+      const int id = by * gx + bx, xcd = id & 7, idx = id >> 3, rows_per = gy >> 3;
+      by = xcd * rows_per + idx % rows_per;
+      bx = idx / rows_per;
+    }
+  }
+  const int m0 = by * BM, n0 = bx * BN;
+  f32x16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; j++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+  const __bf16 *src[NI];
+  int dst[NI];
+#pragma unroll
+  for (int i = 0; i < NI; i++) {
+    const int blk = wave + 8 * i, row = 8 * blk + (lane >> 3), chunk = (lane & 7) ^ ((row >> 1) & 7);
+    if (row < BM) { const int g = m0 + row; src[i] = X + (size_t)(g < M ? g : M - 1) * K + chunk * 8; }
+    else { const int g = n0 + row - BM; src[i] = W + (size_t)(g < N ? g : N - 1) * K + chunk * 8; }
+    dst[i] = 8 * blk * BK;
+  }
+  // this workgroup's share of the K tiles
+  const int nkt_all = K / BK, per = (nkt_all + a.ksplit - 1) / a.ksplit, kt0 = (int)blockIdx.z * per, kt1 = kt0 + per < nkt_all ? kt0 + per : nkt_all;
+  const int nkt = kt1 - kt0;
+  if (nkt <= 0) return;
+  auto request = [&](int t) {
+    __bf16 *stage = lds_g + (t % NST) * STAGE;
+#pragma unroll
+    for (int i = 0; i < NI; i++) __builtin_amdgcn_global_load_lds((ss_gvoid *)(src[i] + (size_t)(kt0 + t) * BK), (ss_lvoid *)(stage + dst[i]), 16, 0, 0);
+  };
+  request(0);
+  if (nkt > 1) request(1);
+  const int arow = wm * 32 + (lane & 31), ax = (arow >> 1) & 7, half = lane >> 5;
+  for (int kt = 0; kt < nkt; kt++) {
+    if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nkt) request(kt + 2);
+    const __bf16 *As = lds_g + (kt % NST) * STAGE, *Bs = As + BM * BK;
+    bf16x8 fa[2], fb[2][TN];
+    auto frags = [&](int ks, int set) {
+      const int c = 2 * ks + half;
+      fa[set] = *reinterpret_cast<const bf16x8 *>(As + arow * BK + ((c ^ ax) << 3));
+#pragma unroll
+      for (int tn = 0; tn < TN; tn++) {
+        const int brow = wn * (BN / WN) + tn * 32 + (lane & 31);
+        fb[set][tn] = *reinterpret_cast<const bf16x8 *>(Bs + brow * BK + ((c ^ ((brow >> 1) & 7)) << 3));
+      }
+    };
+    frags(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      if (ks < 3) frags(ks + 1, (ks + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tn = 0; tn < TN; tn++) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1], fb[ks & 1][tn], acc[tn], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if constexpr (F32ATOMIC) {
+    // partial sums of this K share: hardware fp32 atomics, 32 adjacent columns per wave instruction (the bias, if any, is added by share 0)
+    float *Yf = reinterpret_cast<float *>(a.Y);
+#pragma unroll
+    for (int tn = 0; tn < TN; tn++) {
+      const int col = n0 + wn * (BN / WN) + tn * 32 + (lane & 31);
+      const float bv = (a.bias && col < N && blockIdx.z == 0) ? a.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < M && col < N) unsafeAtomicAdd(Yf + (size_t)row * a.ldy + col, acc[tn][r] + bv);
+      }
+    }
+  } else {
+    // up to three bf16 images of the tile, one after the other through the same LDS (rows | derivative rows | transposed): each pass
+    // re-evaluates the epilogue arithmetic from the accumulators (~10 instructions per element against a K loop of thousands of cycles)
+    constexpr int CS = BN + 8, CST = BM + 8;
+    __bf16 *Cs = lds_g;
+    const bool want_d = a.Dact != nullptr, want_t = a.Yt != nullptr;
+    constexpr int CPR = BN / 8;
+    auto value = [&](int tn, int r, float &v) {              // bias, multiplying operand; returns through v the pre-activation
+      const int cl = wn * (BN / WN) + tn * 32 + (lane & 31), col = n0 + cl;
+      const int rl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), row = m0 + rl;
+      v = acc[tn][r] + ((a.bias && col < N) ? a.bias[col] : 0.f);
+      if (a.mul) v *= (row < M && col < N) ? (float)a.mul[(size_t)row * a.ldy + col] : 0.f;
+    };
+    auto rows_out = [&](__bf16 *Yb) {
+      const bool vec_ok = (a.ldy & 7) == 0 && (reinterpret_cast<size_t>(Yb) & 15) == 0;
+#pragma unroll
+      for (int i = 0; i < BM * CPR / 512; i++) {
+        const int id = tid + 512 * i, rl = id / CPR, cc = (id % CPR) * 8, row = m0 + rl, col = n0 + cc;
+        if (row >= M || col >= N) continue;
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(Cs + rl * CS + cc);
+        if (vec_ok && col + 8 <= N) *reinterpret_cast<u32x4 *>(Yb + (size_t)row * a.ldy + col) = v;
+        else {
+          const __bf16 *e = reinterpret_cast<const __bf16 *>(&v);
+          for (int j = 0; j < 8 && col + j < N; j++) Yb[(size_t)row * a.ldy + col + j] = e[j];
+        }
+      }
+    };
+    // the multiplying operand is read once: fold it (and the bias) into the accumulators
+#pragma unroll
+    for (int tn = 0; tn < TN; tn++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) { float v; value(tn, r, v); acc[tn][r] = v; }
+    if (a.Y) {
+      __builtin_amdgcn_s_barrier();
+      with_activation(a.act, [&](auto fn) {
+#pragma unroll
+        for (int tn = 0; tn < TN; tn++)
+#pragma unroll
+          for (int r = 0; r < 16; r++)
+            Cs[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CS + wn * (BN / WN) + tn * 32 + (lane & 31)] = (__bf16)fn(acc[tn][r]);
+      });
+      __syncthreads();
+      rows_out(reinterpret_cast<__bf16 *>(a.Y));
+    }
+    if (want_d) {
+      __syncthreads();
+#pragma unroll
+      for (int tn = 0; tn < TN; tn++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const float v = acc[tn][r];
+          float d = 1.f;
+          if (a.act == SS_ACT_SILU) { const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-v)); d = sg * (1.f + v * (1.f - sg)); }
+          else if (a.act == SS_ACT_TANH) { const float e = __expf(-2.f * fabsf(v)); const float t = (1.f - e) * __builtin_amdgcn_rcpf(1.f + e); d = 1.f - t * t; }
+          else if (a.act == SS_ACT_RELU) d = v > 0.f ? 1.f : 0.f;
+          Cs[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CS + wn * (BN / WN) + tn * 32 + (lane & 31)] = (__bf16)d;
+        }
+      __syncthreads();
+      rows_out(a.Dact);
+    }
+    if (want_t) {
+      __bf16 *Ct = lds_g;
+      __syncthreads();
+      with_activation(a.act, [&](auto fn) {
+#pragma unroll
+        for (int tn = 0; tn < TN; tn++)
+#pragma unroll
+          for (int r = 0; r < 16; r++)
+            Ct[(wn * (BN / WN) + tn * 32 + (lane & 31)) * CST + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] = (__bf16)fn(acc[tn][r]);
+      });
+      __syncthreads();
+      constexpr int RPC = BM / 8;                             // 16-byte chunks per transposed tile row (a column of the result: 128 rows)
+      const bool vec_ok = (a.ldyt & 7) == 0 && (reinterpret_cast<size_t>(a.Yt) & 15) == 0;
+#pragma unroll
+      for (int i = 0; i < BN * RPC / 512; i++) {
+        const int id = tid + 512 * i, cl = id / RPC, rc = (id % RPC) * 8, col = n0 + cl, row = m0 + rc;
+        if (col >= N || row >= M) continue;
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(Ct + cl * CST + rc);
+        if (vec_ok && row + 8 <= M) *reinterpret_cast<u32x4 *>(a.Yt + (size_t)col * a.ldyt + row) = v;
+        else {
+          const __bf16 *e = reinterpret_cast<const __bf16 *>(&v);
+          for (int j = 0; j < 8 && row + j < M; j++) a.Yt[(size_t)col * a.ldyt + row + j] = e[j];
+        }
+      }
+    }
+  }
+}
+
 // torch.clamp semantics: a NaN stays a NaN (fminf / fmaxf would return the bound and hide a diverged policy or observation from the env)
 __device__ __forceinline__ float clamp_keep_nan(float v, float lo, float hi) { return v != v ? v : fminf(fmaxf(v, lo), hi); }
 
@@ -463,6 +653,72 @@ int ss_linear_bf16(const void *x, const void *w, const float *bias, void *y, int
   else SS_PICK(64);
 #undef SS_PICK
 #undef SS_LAUNCH
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SS_OK : fail(SS_ERR_HIP, hipGetErrorString(e));
+}
+
+int ss_linear_bf16_train(const void *x, const void *w, const float *bias, const void *mul, void *y, void *yt, void *dact, int32_t M, int32_t N, int32_t K,
+                         int32_t ldy, int32_t ldyt, int32_t act, int32_t y_is_f32_accumulate, void *stream) {
+  if (!x || !w || (!y && !yt)) return fail(SS_ERR_INVALID, "null argument");
+  if (M < 1 || N < 1 || K < 64 || K % 64 || (y && ldy < N) || (yt && ldyt < M)) return fail(SS_ERR_INVALID, "ss_linear_bf16_train: K must be a positive multiple of 64, ldy >= N, ldyt >= M");
+  if (act < SS_ACT_NONE || act > SS_ACT_RELU) return fail(SS_ERR_INVALID, "unknown activation");
+  if (y_is_f32_accumulate && (yt || dact || mul || act != SS_ACT_NONE || !y)) return fail(SS_ERR_INVALID, "ss_linear_bf16_train: the accumulating fp32 form has no other outputs, operand or activation");
+  if ((mul || dact) && !y) return fail(SS_ERR_INVALID, "ss_linear_bf16_train: mul / dact share y's row stride: y must be given");
+  hipStream_t st = (hipStream_t)stream;
+  const int gm = (M + BM - 1) / BM;
+  static const int remap = getenv("SS_MLP_NOREMAP") ? 0 : 1;
+  // tile width as in ss_linear_bf16 (whole rounds of the 256 CUs), then the K split: products whose output has fewer tiles than CUs and a deep
+  // contraction (the weight gradients: K = the batch) are cut along K into as many shares as fill about two rounds
+  int bn = 64;
+  {
+    double best = -1;
+    const int cand[4] = {256, 192, 128, 64};
+    for (int c = 0; c < 4; c++) {
+      if (cand[c] > 64 && N < cand[c]) continue;
+      if (cand[c] > 128 && K < 512) continue;
+      const long long tiles = (long long)((N + cand[c] - 1) / cand[c]) * gm, rounds = (tiles + 255) / 256;
+      // (the accumulating form fills the chip with its K split: only the columns wasted by the last tile count)
+      // ... and so does a batch of thousands of rows: there the widest tile wins on every product measured (profiles/r06_train_gemm_sweep.txt)
+      const double fill = ((y_is_f32_accumulate || gm >= 64) ? 1.0 : (double)tiles / (double)(rounds * 256)) * ((double)N / (double)(((N + cand[c] - 1) / cand[c]) * cand[c]));
+      if (fill > best + 1e-9) { best = fill; bn = cand[c]; }
+    }
+    static const char *force_bn = getenv("SS_MLP_TRAIN_BN");
+    if (force_bn && atoi(force_bn) > 0) bn = atoi(force_bn);
+    { const char *live = getenv("SS_MLP_TRAIN_BN_LIVE"); if (live && atoi(live) > 0) bn = atoi(live); }   // (tools/gpu_train_gemm_sweep.py: re-read per call)
+  }
+  int ksplit = 1;
+  if (y_is_f32_accumulate) {
+    const long long tiles = (long long)((N + bn - 1) / bn) * gm;
+    const int nkt = K / 64;
+    ksplit = (int)((512 + tiles - 1) / tiles);
+    if (ksplit > nkt / 8) ksplit = nkt / 8 > 0 ? nkt / 8 : 1;   // at least 8 K tiles per share
+    if (ksplit < 1) ksplit = 1;
+    static const char *force_ks = getenv("SS_MLP_TRAIN_KSPLIT");
+    if (force_ks && atoi(force_ks) > 0) ksplit = atoi(force_ks);
+  }
+  LinearTrainArgs a{static_cast<const __bf16 *>(x), static_cast<const __bf16 *>(w), bias, static_cast<const __bf16 *>(mul), y, static_cast<__bf16 *>(yt),
+                    static_cast<__bf16 *>(dact), M, N, K, ldy, ldyt, act, remap, ksplit};
+#define SS_TRAIN(BN_)                                                                                                          \
+  do {                                                                                                                         \
+    dim3 grid((N + BN_ - 1) / BN_, gm, ksplit);                                                                                \
+    const size_t loop_ = (size_t)3 * (BM + BN_) * 64 * sizeof(__bf16);                                                         \
+    const size_t epi_ = ((size_t)BM * (BN_ + 8) > (size_t)BN_ * (BM + 8) ? (size_t)BM * (BN_ + 8) : (size_t)BN_ * (BM + 8)) * sizeof(__bf16); \
+    const size_t lds_ = loop_ > epi_ ? loop_ : epi_;                                                                           \
+    if (y_is_f32_accumulate) {                                                                                                 \
+      auto kern_ = ss_linear_train_kernel<BN_, true>;                                                                          \
+      if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, (int)loop_) != hipSuccess) return fail(SS_ERR_HIP, "cannot size the GEMM's LDS"); \
+      hipLaunchKernelGGL(kern_, grid, dim3(512), loop_, st, a);                                                                \
+    } else {                                                                                                                   \
+      auto kern_ = ss_linear_train_kernel<BN_, false>;                                                                         \
+      if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_) != hipSuccess) return fail(SS_ERR_HIP, "cannot size the GEMM's LDS"); \
+      hipLaunchKernelGGL(kern_, grid, dim3(512), lds_, st, a);                                                                 \
+    }                                                                                                                          \
+  } while (0)
+  if (bn == 256) SS_TRAIN(256);
+  else if (bn == 192) SS_TRAIN(192);
+  else if (bn == 128) SS_TRAIN(128);
+  else SS_TRAIN(64);
+#undef SS_TRAIN
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SS_OK : fail(SS_ERR_HIP, hipGetErrorString(e));
 }

@@ -1040,6 +1040,112 @@ def test_linear_bf16_mfma_kernel(M, N, K, act):
     assert lib().ss_linear_bf16(ptr(x), ptr(w), ptr(b), ptr(y16), M, N, K - 1, N, 0, 0, st) == -1     # K must be a multiple of 32
 
 
+@pytest.mark.parametrize("M,N,K,act", [(1024, 1536, 2048, "silu"), (300, 192, 128, "tanh"), (2048, 64, 512, "none"), (1000, 1000, 64, "relu")])
+def test_linear_bf16_train_kernel_outputs(M, N, K, act):
+    """ss_linear_bf16_train, bf16 form: result, TRANSPOSED result and activation derivative of one launch against torch on the same bf16
+    operands (asymmetric: a row / column swap cannot pass), with and without the multiplying operand, ragged M and N."""
+    import ctypes as C
+    from smplsim_amd import _cabi
+    from smplsim_amd._lib import lib
+    g = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=g) * 0.5 + torch.linspace(-1, 1, K)[None, :] * 0.3).to(torch.bfloat16).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5 + torch.linspace(-1, 1, N)[:, None] * 0.02).to(torch.bfloat16).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    mul = (torch.rand(M, N, generator=g) + 0.5).to(torch.bfloat16).cuda()
+    ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    fn = {"silu": torch.nn.functional.silu, "tanh": torch.tanh, "relu": torch.relu, "none": lambda t: t}[act]
+    for use_mul in (False, True):
+        z = x.float() @ w.float().T + b
+        if use_mul:
+            z = z * mul.float()
+        zz = z.clone().requires_grad_(True)
+        ref = fn(zz)
+        dref, = torch.autograd.grad(ref.sum(), zz)
+        ldt = (M + 7) // 8 * 8
+        y = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda"); yt = torch.zeros(N, ldt, dtype=torch.bfloat16, device="cuda")
+        d = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        assert lib().ss_linear_bf16_train(ptr(x), ptr(w), ptr(b), ptr(mul if use_mul else None), ptr(y), ptr(yt), ptr(d), M, N, K, N, ldt,
+                                          _cabi.ACTIVATIONS[act], 0, st) == 0
+        torch.cuda.synchronize()
+        tol = 1e-2 * max(1.0, ref.abs().max().item())
+        assert (y.float() - ref.detach()).abs().max().item() < tol
+        assert torch.equal(yt[:, :M], y.t())                            # the transposed copy is the same rounding of the same numbers
+        assert (d.float() - dref).abs().max().item() < 2e-2
+    assert lib().ss_linear_bf16_train(ptr(x), ptr(w), ptr(b), None, ptr(y), None, None, M, N, K - 32, N, 0, 0, 0, st) == -1   # K: multiples of 64
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 1536, 53248), (69, 512, 4096 * 3), (1024, 320, 8192)])
+def test_linear_bf16_train_kernel_split_k_accumulates(M, N, K):
+    """The accumulating fp32 form (weight gradients: few outputs, the batch as K): the K split's partial sums meet in the output by
+    atomics; against the fp32 product of the same bf16 operands.  Accumulates: a second call doubles the result."""
+    import ctypes as C
+    from smplsim_amd._lib import lib
+    g = torch.Generator().manual_seed(M + N)
+    x = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.5 + torch.linspace(-1, 1, N)[:, None] * 0.1).to(torch.bfloat16).cuda()
+    ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    y = torch.zeros(M, N + 5, device="cuda")
+    assert lib().ss_linear_bf16_train(ptr(x), ptr(w), None, None, ptr(y), None, None, M, N, K, N + 5, 0, 0, 1, st) == 0
+    torch.cuda.synchronize()
+    ref = x.float() @ w.float().T
+    assert (y[:, N:] == 0).all()
+    assert (y[:, :N] - ref).abs().max().item() < 2e-3 * ref.abs().max().item()
+    assert lib().ss_linear_bf16_train(ptr(x), ptr(w), None, None, ptr(y), None, None, M, N, K, N + 5, 0, 0, 1, st) == 0
+    torch.cuda.synchronize()
+    assert (y[:, :N] - 2 * ref).abs().max().item() < 4e-3 * ref.abs().max().item()
+
+
+def test_fused_mlp_train_gradients_match_autograd():
+    """learning.fused_train.FusedMLPTrain (forward + backward on ss_linear_bf16_train) against torch autograd over the same layers in
+    fp32: outputs and every parameter gradient agree to bf16 round-off through the stack (relative to the gradient's own scale), on the
+    PPO losses' shapes: the policy's 69-wide head and the value's 1-wide head, a batch that is not a multiple of 64."""
+    from smplsim_amd.learning.fused_train import FusedMLPTrain
+    from smplsim_amd.learning.networks import MLP
+    torch.manual_seed(0)
+    for out_dim in (69, 1):
+        net = MLP(292, (512, 256, 256), "silu").cuda()
+        head = torch.nn.Linear(256, out_dim).cuda()
+        x = torch.randn(1000, 292, device="cuda")
+        target = torch.randn(1000, out_dim, device="cuda")
+        fused = FusedMLPTrain(net.affine_layers, head, "silu")
+        params = [p for l in list(net.affine_layers) + [head] for p in (l.weight, l.bias)]
+        y_ref = head(net(x))
+        g_ref = torch.autograd.grad((y_ref - target).pow(2).mean(), params)
+        y = fused(x)
+        g = torch.autograd.grad((y - target).pow(2).mean(), params)
+        assert (y - y_ref).abs().max().item() < 3e-2 * max(1.0, y_ref.abs().max().item())
+        for a, b_, p in zip(g, g_ref, params):
+            assert a.shape == p.shape
+            rel = (a - b_).norm().item() / max(b_.norm().item(), 1e-12)
+            assert rel < 3e-2, (out_dim, tuple(p.shape), rel)
+
+
+def test_ppo_update_on_the_librarys_gemm_follows_the_torch_update():
+    """AgentPPO(mfma_update=True): one update_params on the same rollout as the fp32 torch update — the losses agree to bf16 round-off
+    and the parameters move the same way (cosine of the two parameter steps > 0.98 for both networks)."""
+    from smplsim_amd.agents.ppo import AgentPPO, PPOConfig
+    from smplsim_amd.batch import SMPLSimVecEnv
+    kw = dict(hidden=(256, 128, 128), min_batch_size=256 * 8, opt_num_epochs=2)
+    env = SMPLSimVecEnv(256, task="HumanoidSpeed", autoreset=True, seed=3)
+    a0 = AgentPPO(env, PPOConfig(**kw), seed=1)
+    a1 = AgentPPO(env, PPOConfig(mfma_update=True, **kw), seed=1)
+    a1.policy_net.load_state_dict(a0.policy_net.state_dict()); a1.value_net.load_state_dict(a0.value_net.state_dict())
+    batch = a0.sample()
+    before = [p.detach().clone() for p in list(a0.policy_net.parameters()) + list(a0.value_net.parameters())]
+    i0 = a0.update_params({k: v.clone() for k, v in batch.items()})
+    i1 = a1.update_params({k: v.clone() for k, v in batch.items()})
+    assert abs(float(i0["value_loss"]) - float(i1["value_loss"])) < 3e-2 * max(1.0, abs(float(i0["value_loss"])))
+    assert abs(float(i0["surr_loss"]) - float(i1["surr_loss"])) < 3e-2
+    p0 = list(a0.policy_net.parameters()) + list(a0.value_net.parameters()); p1 = list(a1.policy_net.parameters()) + list(a1.value_net.parameters())
+    d0 = torch.cat([(p - b).flatten() for p, b in zip(p0, before) if p.requires_grad])
+    d1 = torch.cat([(p - b).flatten() for p, b in zip(p1, before) if p.requires_grad])
+    cos = float((d0 * d1).sum() / (d0.norm() * d1.norm()))
+    assert cos > 0.9, cos                                               # (Adam's first steps are sign-like: small gradient entries may flip)
+    env.close()
+
+
 def test_fused_policy_inference_matches_the_torch_policy():
     """FusedPolicyInference (obs clamp + RunningNorm + 7 fused bf16 layers) against PolicyGaussian in fp32: the action means agree
     to bf16 round-off through the 7 layers, with the normalisation on (n > 0) and off (n = 0), on a strided observation tensor."""

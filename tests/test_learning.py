@@ -134,3 +134,16 @@ def test_ppo_agent_runs_on_device_and_checkpoints_round_trip(tmp_path):
     with torch.no_grad():
         assert torch.equal(other.policy_net.select_action(x, True), agent.policy_net.select_action(x, True))
     assert set(torch.load(path, map_location="cpu")) == {"policy", "value", "epoch", "optimizer_policy", "optimizer_value", "frame"}
+
+
+def test_fused_train_has_no_cpu_path():
+    """learning.fused_train (the update's passes on the library's GEMM) refuses layers that are not on a GPU: like the rest of the package
+    it has no CPU fallback (the oracle and torch are the checkers, tests/test_gpu_parity.py::test_fused_mlp_train_gradients_match_autograd)."""
+    import pytest
+    from smplsim_amd.learning.fused_train import FusedMLPTrain
+    from smplsim_amd.learning.networks import MLP
+    net = MLP(10, (64, 64), "silu")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        FusedMLPTrain(net.affine_layers, torch.nn.Linear(64, 3), "silu")
+    with pytest.raises(ValueError, match="fused epilogue"):
+        FusedMLPTrain(net.affine_layers, torch.nn.Linear(64, 3), "gelu")

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--opt-epochs", type=int, default=10)
     ap.add_argument("--amp-bf16", action="store_true", help="bf16 autocast for the update passes (not the reference numerics)")
     ap.add_argument("--mfma-inference", action="store_true", help="sampler: policy forward by the library's fused bf16 MFMA kernels")
+    ap.add_argument("--mfma-update", action="store_true", help="update: forward and backward passes of both networks on the library's own GEMM (learning/fused_train.py)")
     ap.add_argument("--save", default="")
     ap.add_argument("--log-every", type=int, default=1)
     ap.add_argument("--motion-file", default="", help="HumanoidIm: AMASS-style pickle ({key: {pose_aa, trans, fps}}); default = synthetic clips")
@@ -49,7 +50,7 @@ def main():
         env = SMPLSimImitationVecEnv(args.envs, ml, model=model, seed=0)
     else:
         env = SMPLSimVecEnv(args.envs, task=args.task, autoreset=True, seed=0)
-    cfg = PPOConfig(hidden=tuple(int(x) for x in args.hidden.split(",")), min_batch_size=args.min_batch_size, opt_num_epochs=args.opt_epochs, amp_bf16=args.amp_bf16, mfma_inference=args.mfma_inference)
+    cfg = PPOConfig(hidden=tuple(int(x) for x in args.hidden.split(",")), min_batch_size=args.min_batch_size, opt_num_epochs=args.opt_epochs, amp_bf16=args.amp_bf16, mfma_inference=args.mfma_inference, mfma_update=args.mfma_update)
     agent = AgentPPO(env, cfg, seed=0)
     ts, tu, n = 0.0, 0.0, 0
     for ep in range(args.epochs):
