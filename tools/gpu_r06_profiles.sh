@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 WARMUP=20 TAG=r06_smpl WORKLOAD=smpl ENVS_PER_GPU=4096 BENCH_ARGS="--no-reference-contact-set" bash tools/gpu_prof.sh > gpurun_out/prof_smpl.log 2>&1; echo "prof smpl rc=$?"
 WARMUP=60 TAG=r06_smpl_selfcollision WORKLOAD=smpl_selfcollision ENVS_PER_GPU=4096 BENCH_ARGS="--self-collision" bash tools/gpu_prof.sh > gpurun_out/prof_selfcol.log 2>&1; echo "prof selfcol rc=$?"
 WARMUP=20 TAG=r06_smplx WORKLOAD=smplx ENVS_PER_GPU=4096 BENCH_ARGS="--workload smplx --no-reference-contact-set" bash tools/gpu_prof.sh > gpurun_out/prof_smplx.log 2>&1; echo "prof smplx rc=$?"
-WARMUP=60 TAG=r06_getup WORKLOAD=getup ENVS_PER_GPU=4096 BENCH_ARGS="--workload getup --no-reference-contact-set" bash tools/gpu_prof.sh > gpurun_out/prof_getup.log 2>&1; echo "prof getup rc=$?"
+WARMUP=150 STEPS=60 TAG=r06_getup WORKLOAD=getup ENVS_PER_GPU=4096 BENCH_ARGS="--workload getup --no-reference-contact-set" bash tools/gpu_prof.sh > gpurun_out/prof_getup.log 2>&1; echo "prof getup rc=$?"
 WARMUP=60 TAG=r06_imitation WORKLOAD=imitation ENVS_PER_GPU=1024 BENCH_ARGS="--workload imitation" bash tools/gpu_prof.sh > gpurun_out/prof_imitation.log 2>&1; echo "prof imitation rc=$?"
 # the summaries go where bench.py looks for them BEFORE the bench lines are taken
 for w in smpl smpl_selfcollision smplx getup imitation; do cp gpurun_out/r06_${w}_summary_pmc_summary.json profiles/pmc_summary_${w}.json 2>/dev/null; done
