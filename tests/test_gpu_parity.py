@@ -435,6 +435,12 @@ def test_per_sample_parity_on_the_benchmark_distribution(vec, which):
     outside = [(int(i), r["f32_vs_oracle"][i].tolist(), r["cond"][i].tolist()) for i in np.flatnonzero(ok & ~f32_ok)]
     print(f"solver rule within {P.TOL_STEP}: {rule_ok[ok].mean():.4f}; outside {r['solver_rule'][ok & ~rule_ok].tolist()}")
     print(f"GPU float32 vs oracle at MuJoCo's settings within {P.TOL_STEP}: {f32_ok[ok].mean():.4f}; outside (sample, error, cond): {outside}")
+    try:                                                         # per-sample record for choosing / checking the gate (tests/test_parity_f64.py COND_REF)
+        out_ = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out_, exist_ok=True)
+        np.savez_compressed(os.path.join(out_, f"parity_samples_{which}.npz"), precision=r["precision"], cond=r["cond"], ok=ok, f32_vs_oracle=r["f32_vs_oracle"])
+    except OSError:
+        pass
     _record("benchmark_distribution_" + which, samples=len(ok), resets=int((~ok).sum()), max_newton_iters=int(post["iters"].max()),
             mean_newton_iters=float(post["iters"].mean()), mean_newton_iters_f64_kernel=float(r["iters"].mean()),
             formulation_max=r["formulation"][ok].max(axis=0), solver_rule_max=r["solver_rule"][ok].max(axis=0),

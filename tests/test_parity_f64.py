@@ -24,11 +24,12 @@ COND_FLOOR = np.array([1.0, 50.0])       # qpos, qvel: the conditioning of a qui
 # float32 kernel vs float64 kernel, per sample: the stated per-step tolerance P.TOL_STEP holds for every sample whose measured
 # conditioning is at most COND_REF (about the median of the benchmark's states) and grows in proportion to the conditioning
 # beyond it:  error <= TOL_STEP * max(1, cond / COND_REF).  Round 6: COND_REF was (1, 80), 15-40 x looser than anything
-# measured (worst precision / bound over the six configurations on the MI355X: 0.066 / 0.025); at (4.5, 1000) the bound is 37 / 34
-# rounding units x conditioning and the worst measured sample sits at 0.3 of it (profiles/r06_parity_measured.json): a regression that
-# makes the float32 error 4 x worse on ill-conditioned samples now fails.  Samples whose conditioning is below COND_REF are held to
-# TOL_STEP itself, as before.
-COND_REF = np.array([4.5, 1000.0])
+# measured (worst precision / bound over the six configurations on the MI355X: 0.066 / 0.025).  From the per-sample records of the GPU
+# run (gpurun_out/parity_samples_*.npz: precision and conditioning of every sample) the bound was moved to where the worst sample sits at
+# 0.30 / 0.27 of it on the MI355X (getup, a sample of conditioning < 20 at 0.3 of TOL_STEP itself: the flat part cannot go lower without
+# changing the stated tolerance; smpl for qvel) and at 0.38 / 0.89 on the emulator's samples: a float32 error 1.1 x (emulator) / 3 x (GPU)
+# worse on the worst sample now fails.  profiles/r06_parity_measured.json.
+COND_REF = np.array([20.0, 10000.0])
 
 
 def f32_bound(cond):
