@@ -8,7 +8,7 @@ from smplsim_amd import _cabi, _lib
 _lib._LIB = _cabi.bind_mlp(_cabi.bind(C.CDLL(os.environ["SS_PROF_LIB"])))
 from smplsim_amd.batch import SMPLSimVecEnv, _check, _ptr
 N = int(os.environ.get("NENV", "256"))
-env = SMPLSimVecEnv(N, autoreset=True, seed=1234, self_collision=True)
+env = SMPLSimVecEnv(N, autoreset=True, seed=1234, self_collision=os.environ.get("SELFCOL", "1") == "1")
 g = torch.Generator(device=env.device); g.manual_seed(1234)
 env.reset()
 rec = torch.zeros(N, dtype=torch.int32, device=env.device)
