@@ -4,7 +4,7 @@ import ctypes as C, os, subprocess, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from smplsim_amd._lib import lib
-M = 53248
+M = int(os.environ.get("ROWS", "53248"))
 dims = [320, 2048, 1536, 1024, 1024, 512, 512]
 ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
