@@ -237,10 +237,12 @@ class AgentPPO:
         T, N = batch["rewards"].shape
         states = batch["states"].reshape(T * N, -1)
         self.policy_net.eval(); self.value_net.eval()
-        with torch.no_grad():
-            vf = self.fused_value if getattr(self, "fused_value", None) is not None else self.value_net   # (mfma_update: the critic's passes for GAE on the library's GEMM too)
-            values = vf(states).reshape(T, N)
-            boot = vf(batch["last_state"]).reshape(N) if c.bootstrap else None
+        with torch.no_grad(), self._autocast():
+            # the critic's passes for GAE: on the library's GEMM with mfma_update, under the update's bf16 autocast with amp_bf16 (round 6: they ran
+            # in fp32 whatever the update's precision was: 0.8 TFLOP at the fp32 rate, 8 ms of a 116 ms update), fp32 otherwise (the reference)
+            vf = self.fused_value if getattr(self, "fused_value", None) is not None else self.value_net
+            values = self._f32(vf(states)).reshape(T, N)
+            boot = self._f32(vf(batch["last_state"])).reshape(N) if c.bootstrap else None
         adv, ret = estimate_advantages_columns(batch["rewards"], batch["not_done"], batch["not_dead"], values, c.gamma, c.tau, boot)
         adv = normalize_advantages(adv).reshape(T * N, 1)
         ret = ret.reshape(T * N, 1)
