@@ -1987,11 +1987,21 @@ struct Sim : ShapeTables<SHAPED>, SelfColState<SELFCOL>, LeanState<HT::maybe_lea
             o[6] = (real)c.b1; o[7] = (real)c.b2;
           }
           w->sync();
-          if (lane < 6)
+          // lane = body: every lane walks the staged wrenches (uniform addresses) and keeps the sum of those on its own body in registers,
+          // one read-modify-write of Pb per body at the end.  (Rounds 2-5: six lanes, one per component, with two LDS read-modify-writes per
+          // contact one after the other — a serial chain of ~250 cycles per contact in every Newton iteration, 7 k cycles with 30 contacts.)
+          if (lane < h.nb) {
+            real f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0, f5 = 0;
+            const real me = (real)lane;
             for (unsigned long long m_ = am; m_; m_ &= m_ - 1ull) {
               const real *o = this->stage + 8 * __builtin_ctzll(m_);
-              Pb[6 * (int)o[7] + lane] -= o[lane]; Pb[6 * (int)o[6] + lane] += o[lane];
+              const float4_t v0 = ld4(o), v1 = ld4(o + 4);
+              const real sg = v1.z == me ? real(1) : (v1.w == me ? real(-1) : real(0));   // + on body 1, - on body 2
+              f0 += sg * v0.x; f1 += sg * v0.y; f2 += sg * v0.z; f3 += sg * v0.w; f4 += sg * v1.x; f5 += sg * v1.y;
             }
+            real *pb = Pb + 6 * lane;
+            pb[0] += f0; pb[1] += f1; pb[2] += f2; pb[3] += f3; pb[4] += f4; pb[5] += f5;
+          }
           w->sync();
         }
       }
