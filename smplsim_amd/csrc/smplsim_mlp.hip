@@ -24,6 +24,7 @@
 #include "../../include/smplsim_hip.h"
 #include "../../include/smplsim_mlp.h"
 #include "ss_api.h"
+#include "ss_gemm256.h"
 
 namespace {
 
@@ -543,6 +544,214 @@ __global__ void __launch_bounds__(512) ss_linear_train_kernel(const LinearTrainA
   }
 }
 
+// ---- round 6, second GEMM of the update: 256 x 256 macro-tiles, the two wave rows one barrier apart (ss_gemm256.h has the K loop and the
+// ordering argument).  Arguments as ss_linear_train_kernel; the set of outputs is a template parameter:
+//     G256_ACCUM   fp32 partial sums of a K share added to Y by atomics (weight gradients)
+//     G256_PLAIN   Y = act(x W^T + b)
+//     G256_FWD     Y, Y^T and act'(pre-activation)                  (a hidden layer's forward pass)
+//     G256_DX      Y = (x W^T) * mul and Y^T                        (dZ of the layer below)
+// Why compile-time: the K loop alone runs the 53 248 x 1536 x 2048 product in 256 us = 1.31 PFLOP/s; the first epilogue (run-time `if (Y)`, `if (Dact)` per
+// element, one dependent exp -> rcp chain after the other between the branches, every 16-byte chunk of the output parked in scratch because its edge
+// path indexed it dynamically) cost 90 us for ONE image and 200 us for three (profiles/r06_gemm256.txt).
+enum { G256_ACCUM = 0, G256_PLAIN = 1, G256_FWD = 2, G256_DX = 3 };
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  union { __bf16 h[2]; unsigned u; } c;
+  c.h[0] = (__bf16)lo; c.h[1] = (__bf16)hi;
+  return c.u;
+}
+// the first n (< 8) elements of a 16-byte chunk, 2 bytes at a time (static indices: a dynamically indexed chunk lives in scratch)
+__device__ __forceinline__ void store_chunk_edge(__bf16 *dst, const u32x4 &v, int n) {
+#pragma unroll
+  for (int j = 0; j < 8; j++)
+    if (j < n) reinterpret_cast<unsigned short *>(dst)[j] = (unsigned short)((j & 1) ? (v[j >> 1] >> 16) : (v[j >> 1] & 0xffffu));
+}
+__device__ __forceinline__ u32x4 load_chunk_edge(const __bf16 *src, int n) {
+  u32x4 v = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int j = 0; j < 8; j++)
+    if (j < n) v[j >> 1] |= (unsigned)reinterpret_cast<const unsigned short *>(src)[j] << (16 * (j & 1));
+  return v;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(512) ss_gemm256_kernel(const LinearTrainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 lds_g[];
+  constexpr int T = gemm256::TILE;
+  const int M = a.M, N = a.N, K = a.K;
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int gx = gridDim.x, gy = gridDim.y;
+    if ((a.xcd_remap & 1) && gy % 8 == 0) {
+      const int id = by * gx + bx, xcd = id & 7, idx = id >> 3, rows_per = gy >> 3;
+      by = xcd * rows_per + idx % rows_per;
+      bx = idx / rows_per;
+    }
+  }
+  const int m0 = by * T, n0 = bx * T;
+  const int nkt_all = K / 64, per = (nkt_all + a.ksplit - 1) / a.ksplit, kt0 = (int)blockIdx.z * per, kt1 = kt0 + per < nkt_all ? kt0 + per : nkt_all;
+  const int nkt = kt1 - kt0;
+  if (nkt < 2 || (nkt & 1)) return;                           // (the host cuts K into shares of an even number of tiles)
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  gemm256::Loop L;
+  L.init(a.X, a.W, M, N, K, m0, n0, kt0, reinterpret_cast<char *>(lds_g));
+  L.run(acc, nkt);
+#ifdef SS_GEMM256_ABLATE
+  if (a.xcd_remap & 2) {                                      // K loop only: one store per lane keeps the accumulators alive
+    float sacc = 0.f;
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 2; j++) for (int r = 0; r < 16; r++) sacc += acc[i][j][r];
+    if (sacc == 12345.f) reinterpret_cast<__bf16 *>(a.Y)[threadIdx.x] = (__bf16)sacc;
+    return;
+  }
+#endif
+  const int tid = threadIdx.x, lane = L.lane, wr = L.wr, wc = L.wc;
+  const int col_l = wc * 64 + (lane & 31), row_l = wr * 128 + 4 * (lane >> 5);   // + tn * 32 resp. + tm * 32 + (r & 3) + 8 * (r >> 2)
+  if constexpr (MODE == G256_ACCUM) {
+    float *Yf = reinterpret_cast<float *>(a.Y);
+#pragma unroll
+    for (int tn = 0; tn < 2; tn++) {
+      const int col = n0 + col_l + tn * 32;
+      const float bv = (a.bias && col < N && blockIdx.z == 0) ? a.bias[col] : 0.f;
+#pragma unroll
+      for (int tm = 0; tm < 4; tm++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int row = m0 + row_l + tm * 32 + (r & 3) + 8 * (r >> 2);
+          if (row < M && col < N) unsafeAtomicAdd(Yf + (size_t)row * a.ldy + col, acc[tm][tn][r] + bv);
+        }
+    }
+  } else {
+    constexpr bool HAS_MUL = MODE == G256_DX, HAS_D = MODE == G256_FWD, HAS_T = MODE != G256_PLAIN;
+    constexpr int CS = T + 8, CPR = T / 8;
+    constexpr int HALF_IMG = 128 * CS;                        // elements of one half image (128 rows)
+    __bf16 *Cs = lds_g;
+    __bf16 *Yb = reinterpret_cast<__bf16 *>(a.Y);
+    const bool rows_vec = (a.ldy & 7) == 0 && (reinterpret_cast<size_t>(Yb) & 15) == 0 && (!HAS_D || (reinterpret_cast<size_t>(a.Dact) & 15) == 0) &&
+                          (!HAS_MUL || (reinterpret_cast<size_t>(a.mul) & 15) == 0);
+    // ---- the multiplying operand: the tile by 16-byte row loads into LDS, from there into the accumulators
+    if constexpr (HAS_MUL) {
+#pragma unroll
+      for (int i0 = 0; i0 < T * CPR / 512; i0 += 8) {
+        u32x4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const int id = tid + 512 * (i0 + i), rl = id / CPR, cc = (id % CPR) * 8, row = m0 + rl, col = n0 + cc;
+          v[i] = u32x4{0u, 0u, 0u, 0u};
+          if (row < M && col < N) {
+            const __bf16 *src = a.mul + (size_t)row * a.ldy + col;
+            if (rows_vec && col + 8 <= N) v[i] = *reinterpret_cast<const u32x4 *>(src);
+            else v[i] = load_chunk_edge(src, N - col);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const int id = tid + 512 * (i0 + i), rl = id / CPR, cc = (id % CPR) * 8;
+          *reinterpret_cast<u32x4 *>(Cs + rl * CS + cc) = v[i];
+        }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int tn = 0; tn < 2; tn++) {
+      const int col = n0 + col_l + tn * 32;
+      const float bv = (a.bias && col < N) ? a.bias[col] : 0.f;
+#pragma unroll
+      for (int tm = 0; tm < 4; tm++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          float v = acc[tm][tn][r] + bv;
+          if constexpr (HAS_MUL) v *= (float)Cs[(row_l + tm * 32 + (r & 3) + 8 * (r >> 2)) * CS + col_l + tn * 32];
+          acc[tm][tn][r] = v;
+        }
+    }
+    if constexpr (HAS_MUL) __syncthreads();
+    // ---- result (and derivative) in two halves of the tile — each wave's upper 64 rows, then its lower 64 — so that a half's two images sit in
+    // LDS side by side and the exponential is evaluated ONCE per element; the accumulators keep the activated values for the transposed image
+    auto half_rows = [&](__bf16 *dst, const __bf16 *img, int half) {
+      u32x4 v[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const int id = tid + 512 * i, lr = id / CPR, cc = (id % CPR) * 8;
+        v[i] = *reinterpret_cast<const u32x4 *>(img + lr * CS + cc);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const int id = tid + 512 * i, lr = id / CPR, cc = (id % CPR) * 8, row = m0 + (lr >> 6) * 128 + half * 64 + (lr & 63), col = n0 + cc;
+        if (row >= M || col >= N) continue;
+#ifdef SS_GEMM256_ABLATE
+        if ((a.xcd_remap & 4) && v[i][0] != 0x12345678u) continue;
+#endif
+        if (rows_vec && col + 8 <= N) *reinterpret_cast<u32x4 *>(dst + (size_t)row * a.ldy + col) = v[i];
+        else store_chunk_edge(dst + (size_t)row * a.ldy + col, v[i], N - col);
+      }
+    };
+    auto halves = [&](auto fn2) {
+#pragma unroll
+      for (int half = 0; half < 2; half++) {
+#pragma unroll
+        for (int tml = 0; tml < 2; tml++)
+#pragma unroll
+          for (int tn = 0; tn < 2; tn++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+              float h, d;
+              fn2(acc[2 * half + tml][tn][r], h, d);
+              acc[2 * half + tml][tn][r] = h;
+              const int at = (wr * 64 + tml * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CS + col_l + tn * 32;
+              Cs[at] = (__bf16)h;
+              if constexpr (HAS_D) Cs[HALF_IMG + at] = (__bf16)d;
+            }
+        __syncthreads();
+        half_rows(Yb, Cs, half);
+        if constexpr (HAS_D) half_rows(a.Dact, Cs + HALF_IMG, half);
+        __syncthreads();
+      }
+    };
+    if (a.act == SS_ACT_SILU) halves([](float v, float &h, float &d) { const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-v)); h = v * sg; d = sg * (1.f + v * (1.f - sg)); });
+    else if (a.act == SS_ACT_TANH) halves([](float v, float &h, float &d) { const float e = __expf(-2.f * fabsf(v)); const float t = (1.f - e) * __builtin_amdgcn_rcpf(1.f + e); h = v < 0.f ? -t : t; d = 1.f - t * t; });
+    else if (a.act == SS_ACT_RELU) halves([](float v, float &h, float &d) { h = v > 0.f ? v : 0.f; d = v > 0.f ? 1.f : 0.f; });
+    else halves([](float v, float &h, float &d) { h = v; d = 1.f; });
+    // ---- transposed image: an accumulator's registers r .. r + 3 are four consecutive rows of one column = 8 contiguous bytes of it
+    if constexpr (HAS_T) {
+      typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+#pragma unroll
+      for (int tm = 0; tm < 4; tm++)
+#pragma unroll
+        for (int tn = 0; tn < 2; tn++)
+#pragma unroll
+          for (int r = 0; r < 16; r += 4) {
+            u32x2 v;
+            v[0] = pack_bf16x2(acc[tm][tn][r], acc[tm][tn][r + 1]); v[1] = pack_bf16x2(acc[tm][tn][r + 2], acc[tm][tn][r + 3]);
+            *reinterpret_cast<u32x2 *>(Cs + (col_l + tn * 32) * CS + row_l + tm * 32 + 8 * (r >> 2)) = v;
+          }
+      __syncthreads();
+      const bool cols_vec = (a.ldyt & 7) == 0 && (reinterpret_cast<size_t>(a.Yt) & 15) == 0;
+#pragma unroll
+      for (int i0 = 0; i0 < T * CPR / 512; i0 += 8) {
+        u32x4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const int id = tid + 512 * (i0 + i), cl = id / CPR, rc = (id % CPR) * 8;
+          v[i] = *reinterpret_cast<const u32x4 *>(Cs + cl * CS + rc);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const int id = tid + 512 * (i0 + i), cl = id / CPR, rc = (id % CPR) * 8, col = n0 + cl, row = m0 + rc;
+          if (col >= N || row >= M) continue;
+          if (cols_vec && row + 8 <= M) *reinterpret_cast<u32x4 *>(a.Yt + (size_t)col * a.ldyt + row) = v[i];
+          else store_chunk_edge(a.Yt + (size_t)col * a.ldyt + row, v[i], M - row);
+        }
+      }
+    }
+  }
+}
+
 // torch.clamp semantics: a NaN stays a NaN (fminf / fmaxf would return the bound and hide a diverged policy or observation from the env)
 __device__ __forceinline__ float clamp_keep_nan(float v, float lo, float hi) { return v != v ? v : fminf(fmaxf(v, lo), hi); }
 
@@ -592,6 +801,21 @@ int ss_linear_bf16(const void *x, const void *w, const float *bias, void *y, int
   if (act < SS_ACT_NONE || act > SS_ACT_RELU) return fail(SS_ERR_INVALID, "unknown activation");
   const __bf16 *X = static_cast<const __bf16 *>(x), *Wt = static_cast<const __bf16 *>(w);
   hipStream_t st = (hipStream_t)stream;
+  // thousands of rows (the update's and GAE's passes over the whole rollout): the 256 x 256 kernel (ss_gemm256.h), 1.19 PFLOP/s on 53 248 x 1536 x 2048
+  // against 0.60 for the 128-row tiles below; at the sampler's 4096 rows it has at most 128 tiles for 256 CUs and stays out
+  {
+    static const bool no256 = getenv("SS_MLP_NO256") != nullptr;
+    const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256);
+    if (!no256 && !y_is_f32 && tiles >= 230 && N % 256 == 0 && K >= 256 && K % 128 == 0 && (long long)M * K < (1ll << 32) && (long long)N * K < (1ll << 32)) {
+      LinearTrainArgs a{X, Wt, bias, nullptr, y, nullptr, nullptr, M, N, K, ldy, 0, act, 1, 1};
+      auto kern_ = ss_gemm256_kernel<G256_PLAIN>;
+      const size_t epi_ = (size_t)gemm256::TILE * (gemm256::TILE + 8) * sizeof(__bf16);
+      if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, (int)epi_) != hipSuccess) return fail(SS_ERR_HIP, "cannot size the GEMM's LDS");
+      hipLaunchKernelGGL(kern_, dim3((N + 255) / 256, (M + 255) / 256, 1), dim3(512), epi_, st, a);
+      hipError_t e = hipGetLastError();
+      return e == hipSuccess ? SS_OK : fail(SS_ERR_HIP, hipGetErrorString(e));
+    }
+  }
   const int gm = (M + BM - 1) / BM;
   // Tile width: the one whose tile count fills the chip's 256 CUs in whole rounds (4096 x 2048 -> 256 columns, x 1536 -> 192, x 1024 ->
   // 128, x 512 -> 64: exactly one 128-row tile per CU each; round 3 used 128 x 128 for the two widest layers = 1.5 rounds of
@@ -698,6 +922,47 @@ int ss_linear_bf16_train(const void *x, const void *w, const float *bias, const 
   }
   LinearTrainArgs a{static_cast<const __bf16 *>(x), static_cast<const __bf16 *>(w), bias, static_cast<const __bf16 *>(mul), y, static_cast<__bf16 *>(yt),
                     static_cast<__bf16 *>(dact), M, N, K, ldy, ldyt, act, remap, ksplit};
+  // the 256 x 256 kernel (ss_gemm256.h): products with thousands of rows or a K split to fill the chip with; its source offsets are 32-bit
+  // (measured, profiles/r06_gemm256.txt: thousands of rows -> 1.5-2 x the 128-row kernel; of the weight gradients only the one with 50+ tiles gains)
+  // the set of outputs it is built for (the other combinations keep the 128-row kernel)
+  const int mode256 = y_is_f32_accumulate ? G256_ACCUM : (y && !mul && !yt && !dact) ? G256_PLAIN : (y && !mul && yt && dact) ? G256_FWD : (y && mul && yt && !dact) ? G256_DX : -1;
+  bool big = mode256 >= 0 && N >= 256 && M >= 256 && K >= 128 && K % 128 == 0 && (long long)M * K < (1ll << 32) && (long long)N * K < (1ll << 32) &&
+             (y_is_f32_accumulate ? (long long)((N + 255) / 256) * ((M + 255) / 256) >= 48 : M >= 2048);
+  { const char *live = getenv("SS_MLP_TRAIN_256"); if (live) big = atoi(live) != 0 && mode256 >= 0 && K >= 128 && K % 128 == 0 && (long long)M * K < (1ll << 32) && (long long)N * K < (1ll << 32); }
+  if (big) {
+    constexpr int T = gemm256::TILE;
+    const int gx = (N + T - 1) / T, gy = (M + T - 1) / T, nkt = K / 64;
+    int ks = 1;
+    if (y_is_f32_accumulate) {
+      ks = (int)((512 + (long long)gx * gy - 1) / ((long long)gx * gy));
+      if (ks > nkt / 8) ks = nkt / 8 > 0 ? nkt / 8 : 1;
+      static const char *force_ks = getenv("SS_MLP_TRAIN_KSPLIT");
+      if (force_ks && atoi(force_ks) > 0) ks = atoi(force_ks);
+      if (ks > nkt / 2) ks = nkt / 2;
+      int per = (nkt + ks - 1) / ks;
+      per += per & 1;                                         // shares of an even number of K tiles (nkt is even: the last share too)
+      ks = (nkt + per - 1) / per;
+    }
+    a.ksplit = ks;
+#ifdef SS_GEMM256_ABLATE
+    { const char *ab = getenv("SS_GEMM256_KLOOP_ONLY"); if (ab && atoi(ab)) a.xcd_remap |= 2 * atoi(ab); }
+#endif
+    dim3 grid(gx, gy, ks);
+    const size_t loop_ = gemm256::LOOP_LDS_BYTES, epi_ = (size_t)T * (T + 8) * sizeof(__bf16);
+#define SS_G256(MODE_, LDS_)                                                                                                   \
+    do {                                                                                                                       \
+      auto kern_ = ss_gemm256_kernel<MODE_>;                                                                                   \
+      if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_)) != hipSuccess) return fail(SS_ERR_HIP, "cannot size the GEMM's LDS"); \
+      hipLaunchKernelGGL(kern_, grid, dim3(512), LDS_, st, a);                                                                 \
+    } while (0)
+    if (y_is_f32_accumulate) SS_G256(G256_ACCUM, loop_);
+    else if (mode256 == G256_PLAIN) SS_G256(G256_PLAIN, epi_);
+    else if (mode256 == G256_FWD) SS_G256(G256_FWD, epi_);
+    else SS_G256(G256_DX, epi_);
+#undef SS_G256
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SS_OK : fail(SS_ERR_HIP, hipGetErrorString(e));
+  }
 #define SS_TRAIN(BN_)                                                                                                          \
   do {                                                                                                                         \
     dim3 grid((N + BN_ - 1) / BN_, gm, ksplit);                                                                                \

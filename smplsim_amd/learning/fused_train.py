@@ -32,41 +32,73 @@ def _linear_train(x, w, bias, mul, y, yt, dact, M, N, K, ldy, ldyt, act, accumul
     _check(lib().ss_linear_bf16_train(_ptr(x), _ptr(w), _ptr(bias), _ptr(mul), _ptr(y), _ptr(yt), _ptr(dact), M, N, K, ldy, ldyt, act, int(accumulate), stream))
 
 
+class _Buffers:
+    """Work tensors of one FusedMLPTrain, kept between calls (a pass allocated and zero-filled ~1 GB of activations and transposes: allocator
+    round trips and memsets of tensors the kernels overwrite completely).  A forward pass that starts while the previous pass's backward has not run
+    (two graphs alive) gets fresh tensors instead."""
+
+    def __init__(self):
+        self.t = {}
+        self.busy = False
+
+    def get(self, key, shape, dtype, device, fresh, init=None):
+        if fresh:
+            t = torch.zeros(shape, dtype=dtype, device=device)
+            if init is not None:
+                init(t)
+            return t
+        k = (key, tuple(shape), dtype)
+        t = self.t.get(k)
+        if t is None:
+            t = self.t[k] = torch.zeros(shape, dtype=dtype, device=device)
+            if init is not None:
+                init(t)
+        return t
+
+
 class _FusedMLP(torch.autograd.Function):
     """y = Linear_{L+1}(act(Linear_L(... act(Linear_1(x))))) with x [M, D] fp32; params = W_1, b_1, ..., W_{L+1}, b_{L+1} (fp32, torch.nn.Linear layout)."""
 
     @staticmethod
-    def forward(ctx, x, act, *params):
+    def forward(ctx, x, act, bufs, track, *params):
         dev, st = x.device, _launch_stream(x.device)
         ws, bs = params[0::2], params[1::2]
         nl = len(ws)
         M, D = x.shape
-        Mp = _pad(M, 64)                                           # the batch is the K of the weight-gradient products
-        kpad = [_pad(w.shape[1], 64) for w in ws]                 # a layer's input width as a K
-        bf = dict(dtype=torch.bfloat16, device=dev)
-        h = torch.zeros(Mp, kpad[0], **bf)
+        Mp = _pad(M, 128)                                          # the batch is the K of the weight-gradient products; its pad rows are zero in every
+                                                                   # dZ (zero rows of the head's gradient stay zero through (dZ W) * g), so what the
+                                                                   # forward pass leaves in the pad rows of h (act(bias)) never reaches a gradient
+        kpad = [_pad(w.shape[1], 128) if i == 0 else _pad(w.shape[1], 64) for i, w in enumerate(ws)]   # a layer's input width as a K (the first: a whole number of K-tile pairs for the 256-tile kernel)
+        fresh = track and bufs.busy                                # (track: a backward pass will follow and release the tensors)
+        if track and not fresh:
+            bufs.busy = True
+        ctx.bufs = bufs if track and not fresh else None
+        bf = torch.bfloat16
+
+        def ones_row(n):                                           # a layer's transposed input + 64 rows, the first of them ones: as the "W" of the
+            def init(t):                                           # weight-gradient product its extra output column is the bias gradient
+                t[n, :M] = 1.0                                     # (sum of dZ over the batch: no separate reduction launches)
+            return init
+
+        h = bufs.get("x", (Mp, kpad[0]), bf, dev, fresh)           # (pad rows and columns stay zero: only [:M, :D] is ever written)
         h[:M, :D] = x
-
-        def with_ones(n):                                          # a layer's transposed input + 64 rows, the first of them ones: as the "W" of the
-            t = torch.zeros(n + 64, Mp, **bf)                      # weight-gradient product its extra output column is the bias gradient
-            t[n, :M] = 1.0                                         # (sum of dZ over the batch: no separate reduction launches)
-            return t
-
-        t0 = with_ones(kpad[0])
-        t0[:kpad[0]] = h.t()
+        t0 = bufs.get("xt", (kpad[0] + 64, Mp), bf, dev, fresh, ones_row(kpad[0]))
+        t0[:D, :M] = x.t()
         hts, gs, wbs = [t0], [], []
         for i in range(nl - 1):
             w = ws[i]
             N = w.shape[0]
             assert N % 64 == 0 and kpad[i + 1] == N, "hidden widths must be multiples of 64"
-            wb = torch.zeros(N, kpad[i], **bf)
+            wb = bufs.get(("w", i), (N, kpad[i]), bf, dev, fresh)
             wb[:, :w.shape[1]] = w
-            y, yt, g = torch.empty(Mp, N, **bf), with_ones(N), torch.empty(Mp, N, **bf)
+            y = bufs.get(("h", i), (Mp, N), bf, dev, fresh)
+            yt = bufs.get(("ht", i), (N + 64, Mp), bf, dev, fresh, ones_row(N))
+            g = bufs.get(("g", i), (Mp, N), bf, dev, fresh)
             _linear_train(h, wb, bs[i].detach().float().contiguous(), None, y, yt, g, Mp, N, kpad[i], N, Mp, act, False, st)
             wbs.append(wb); hts.append(yt); gs.append(g)
             h = y
         w = ws[-1]
-        wb = torch.zeros(w.shape[0], kpad[-1], **bf)
+        wb = bufs.get(("w", nl - 1), (w.shape[0], kpad[-1]), bf, dev, fresh)
         wb[:, :w.shape[1]] = w
         wbs.append(wb)
         out = torch.empty(Mp, w.shape[0], dtype=torch.float32, device=dev)
@@ -81,14 +113,17 @@ class _FusedMLP(torch.autograd.Function):
         dev, st = grad_out.device, _launch_stream(grad_out.device)
         M, Mp, kpad, dims = ctx.M, ctx.Mp, ctx.kpad, ctx.dims
         nl = len(dims)
-        bf = dict(dtype=torch.bfloat16, device=dev)
+        bufs = ctx.bufs if ctx.bufs is not None else _Buffers()
+        fresh = ctx.bufs is None
+        bf = torch.bfloat16
         none = _cabi.ACTIVATIONS["none"]
         # the head's dZ: the caller's gradient, rounded to bf16, its width padded to a K
         nh = dims[-1][0]
-        nhp = _pad(nh, 64)
-        dz = torch.zeros(Mp, nhp, **bf)
+        nhp = _pad(nh, 128)
+        dz = bufs.get("dz_head", (Mp, nhp), bf, dev, fresh)
         dz[:M, :nh] = grad_out
-        dzt = dz.t().contiguous()
+        dzt = bufs.get("dzt_head", (nhp, Mp), bf, dev, fresh)
+        dzt[:nh, :M] = grad_out.t()
         grads = [None] * (2 * nl)
         for i in range(nl - 1, -1, -1):
             n_out, n_in = dims[i]
@@ -100,14 +135,17 @@ class _FusedMLP(torch.autograd.Function):
             grads[2 * i + 1] = dw[:, kpad[i]]                      # the ones row's column: sum of dZ over the batch
             if i > 0:
                 # dZ_below = (dZ W) * act'(z_below): W^T [kpad_i, n_outp] as the kernel's "W", contraction over this layer's outputs
-                wt = torch.zeros(kpad[i], n_outp, **bf)
+                wt = bufs.get(("wt", i), (kpad[i], n_outp), bf, dev, fresh)
                 wt[:, :n_out] = ctx.wbs[i].t()
                 nb = kpad[i]
-                dzb, dzbt = torch.empty(Mp, nb, **bf), torch.empty(nb, Mp, **bf)
+                dzb = bufs.get(("dz", i), (Mp, nb), bf, dev, fresh)
+                dzbt = bufs.get(("dzt", i), (nb, Mp), bf, dev, fresh)
                 _linear_train(dz, wt, None, ctx.gs[i - 1], dzb, dzbt, None, Mp, nb, n_outp, nb, Mp, none, False, st)
                 dz, dzt = dzb, dzbt
         ctx.hts = ctx.gs = ctx.wbs = None
-        return (None, None, *grads)
+        if ctx.bufs is not None:
+            ctx.bufs.busy = False
+        return (None, None, None, None, *grads)
 
 
 class FusedMLPTrain:
@@ -122,9 +160,11 @@ class FusedMLPTrain:
         dev = self.layers[0].weight.device
         if dev.type != "cuda":
             raise RuntimeError("FusedMLPTrain needs the networks on a GPU (there is no CPU path)")
+        self.bufs, self.bufs_nograd = _Buffers(), _Buffers()
 
     def __call__(self, x):
         params = []
         for l in self.layers:
             params += [l.weight, l.bias]
-        return _FusedMLP.apply(x.detach().float(), self.act, *params)
+        track = torch.is_grad_enabled()                           # (inside Function.forward the grad mode is always off)
+        return _FusedMLP.apply(x.detach().float(), self.act, self.bufs if track else self.bufs_nograd, track, *params)

@@ -1018,7 +1018,8 @@ def test_external_init_refuses_autoreset(vec):
 
 
 # ---------------------------------------------------------------------------------------------- policy inference on the matrix cores
-@pytest.mark.parametrize("M,N,K,act", [(4096, 2048, 320, "silu"), (1000, 512, 1024, "tanh"), (37, 69, 512, "none"), (256, 1536, 2048, "relu")])
+@pytest.mark.parametrize("M,N,K,act", [(4096, 2048, 320, "silu"), (1000, 512, 1024, "tanh"), (37, 69, 512, "none"), (256, 1536, 2048, "relu"),
+                                       (16000, 1024, 512, "silu")])       # (the last: 252 tiles of 256 x 256 -> the big-batch kernel, ragged M)
 def test_linear_bf16_mfma_kernel(M, N, K, act):
     """ss_linear_bf16 against torch on the same bf16-rounded operands with fp32 accumulation: asymmetric operands (a row / column
     swap or a wrong fragment layout cannot pass), ragged M and N, both tile widths, every epilogue."""
@@ -1079,6 +1080,55 @@ def test_linear_bf16_train_kernel_outputs(M, N, K, act):
         assert torch.equal(yt[:, :M], y.t())                            # the transposed copy is the same rounding of the same numbers
         assert (d.float() - dref).abs().max().item() < 2e-2
     assert lib().ss_linear_bf16_train(ptr(x), ptr(w), ptr(b), None, ptr(y), None, None, M, N, K - 32, N, 0, 0, 0, st) == -1   # K: multiples of 64
+
+
+@pytest.mark.parametrize("M,N,K,act", [(2048, 1536, 2048, "silu"), (300, 260, 128, "tanh"), (4096, 512, 1024, "none"), (1000, 1000, 384, "relu")])
+def test_gemm256_kernel_outputs(M, N, K, act, monkeypatch):
+    """The 256 x 256 macro-tile kernel behind ss_linear_bf16_train (csrc/ss_gemm256.h: staggered wave rows, copies in flight across barriers):
+    the same three outputs against torch on asymmetric bf16 operands, ragged M and N, the shortest K loop it takes (two K tiles), and the same
+    bits from every one of 20 launches (a copy that lands after its reader shows up as a launch that differs)."""
+    import ctypes as C
+    from smplsim_amd import _cabi
+    from smplsim_amd._lib import lib
+    monkeypatch.setenv("SS_MLP_TRAIN_256", "1")
+    g = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=g) * 0.5 + torch.linspace(-1, 1, K)[None, :] * 0.3).to(torch.bfloat16).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5 + torch.linspace(-1, 1, N)[:, None] * 0.02).to(torch.bfloat16).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    mul = (torch.rand(M, N, generator=g) + 0.5).to(torch.bfloat16).cuda()
+    ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    fn = {"silu": torch.nn.functional.silu, "tanh": torch.tanh, "relu": torch.relu, "none": lambda t: t}[act]
+    ldt = (M + 7) // 8 * 8
+    for use_mul in (False, True):
+        z = x.float() @ w.float().T + b
+        if use_mul:
+            z = z * mul.float()
+        zz = z.clone().requires_grad_(True)
+        ref = fn(zz)
+        dref, = torch.autograd.grad(ref.sum(), zz)
+        first = None
+        for rep in range(20):
+            y = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda"); yt = torch.zeros(N, ldt, dtype=torch.bfloat16, device="cuda")
+            d = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+            assert lib().ss_linear_bf16_train(ptr(x), ptr(w), ptr(b), ptr(mul if use_mul else None), ptr(y), ptr(yt), ptr(d), M, N, K, N, ldt,
+                                              _cabi.ACTIVATIONS[act], 0, st) == 0
+            torch.cuda.synchronize()
+            if first is None:
+                first = (y.clone(), yt.clone(), d.clone())
+                tol = 1e-2 * max(1.0, ref.abs().max().item())
+                assert (y.float() - ref.detach()).abs().max().item() < tol
+                assert torch.equal(yt[:, :M], y.t())
+                assert (d.float() - dref).abs().max().item() < 2e-2
+            else:
+                assert torch.equal(y, first[0]) and torch.equal(yt, first[1]) and torch.equal(d, first[2]), rep
+    # the accumulating form: K split into shares of an even number of tiles, against the fp32 product
+    yf = torch.zeros(M, N + 3, device="cuda")
+    assert lib().ss_linear_bf16_train(ptr(x), ptr(w), None, None, ptr(yf), None, None, M, N, K, N + 3, 0, 0, 1, st) == 0
+    torch.cuda.synchronize()
+    ref = x.float() @ w.float().T
+    assert (yf[:, N:] == 0).all()
+    assert (yf[:, :N] - ref).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())
 
 
 @pytest.mark.parametrize("M,N,K", [(2048, 1536, 53248), (69, 512, 4096 * 3), (1024, 320, 8192)])
