@@ -1,5 +1,7 @@
-"""The 256 x 256 kernel of ss_linear_bf16_train (SS_MLP_TRAIN_256=1) against the 128-row kernel at its best tile width and torch.matmul (hipBLASLt),
-on every product of one PPO update pass (ROWS rows, the reference MLP), uniform random [-1, 1) operands.  Interleaved rounds, median."""
+"""The 256 x 256 kernel of ss_linear_bf16_train (SS_MLP_TRAIN_256=1) against the 128-row kernel (=0) and torch.matmul (hipBLASLt) on every product of one
+PPO update pass (ROWS rows, the reference MLP), uniform random [-1, 1) operands.  Interleaved rounds, median.  Columns: g256 / k128 = the product with
+the outputs the pass needs (forward: result + transposed result + derivative; dX: multiplying operand, result + transposed; dW: fp32 accumulate),
+*_plain = one bf16 output only (what torch.matmul computes)."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -32,23 +34,15 @@ for name, kind, m, n, k in shapes:
             f = lambda: lib().ss_linear_bf16_train(ptr(x), ptr(w), None, None, ptr(y), ptr(yt), ptr(g), m, n, k, n, m, 1, 0, st)
         else:
             f = lambda: lib().ss_linear_bf16_train(ptr(x), ptr(w), None, ptr(g), ptr(y), ptr(yt), None, m, n, k, n, m, 0, 0, st)
-    if kind == "fwd":
-        part1 = lambda: lib().ss_linear_bf16_train(ptr(x), ptr(w), None, None, ptr(y), None, ptr(g), m, n, k, n, m, 1, 0, st)     # result + derivative
-        part2 = lambda: lib().ss_linear_bf16_train(ptr(x), ptr(w), None, None, ptr(y), ptr(yt), None, m, n, k, n, m, 1, 0, st)    # result + transposed
-    elif kind == "dx":
-        part1 = lambda: lib().ss_linear_bf16_train(ptr(x), ptr(w), None, ptr(g), ptr(y), None, None, m, n, k, n, m, 0, 0, st)     # operand + result
-        part2 = lambda: lib().ss_linear_bf16_train(ptr(x), ptr(w), None, None, ptr(y), ptr(yt), None, m, n, k, n, m, 0, 0, st)    # result + transposed
-    else:
-        part1 = part2 = f
     plain = lambda: lib().ss_linear_bf16_train(ptr(x), ptr(w), None, None, ptr(y), None, None, m, n, k, n, 0, 0, 1 if kind == "dw" else 0, st)
     def run(which, fn):
         if which == "torch": return once(lambda: torch.matmul(x, w.t()))
         os.environ["SS_MLP_TRAIN_256"] = "1" if which.startswith("g256") else "0"
         return once(fn)
     ok256 = k % 128 == 0
-    variants = (["g256", "g256_p1", "g256_p2", "g256_plain"] if ok256 else []) + ["k128", "torch"]
+    variants = (["g256", "g256_plain"] if ok256 else []) + ["k128", "k128_plain", "torch"]
     t = {v: [] for v in variants}
-    pick = lambda v: plain if v.endswith("plain") else part1 if v.endswith("p1") else part2 if v.endswith("p2") else f
+    pick = lambda v: plain if v.endswith("plain") else f
     for v in variants: run(v, pick(v))   # warm-up
     for rnd in range(5):
         for v in variants: t[v].append(run(v, pick(v)))
@@ -57,4 +51,4 @@ for name, kind, m, n, k in shapes:
     flops += gf
     tot["g256"] += med.get("g256", med["k128"]); tot["k128"] += med["k128"]; tot["torch"] += med["torch"]
     print(f"{name:5s} [{m} x {n}, K {k}] {gf:6.0f} GFLOP  " + "  ".join(f"{v}: {med[v]:7.1f} us {gf / med[v] * 1e3:5.0f} TF/s" for v in variants), flush=True)
-print(f"one pass: {flops / 1e3:.2f} TFLOP; 256-tile kernel {tot['g256'] / 1e3:.2f} ms = {flops / tot['g256']:.0f} TF/s; 128-row kernel {tot['k128'] / 1e3:.2f} ms = {flops / tot['k128']:.0f}; torch.matmul alone {tot['torch'] / 1e3:.2f} ms = {flops / tot['torch']:.0f}")
+print(f"one pass: {flops / 1e3:.2f} TFLOP; 256-tile kernel {tot['g256'] / 1e3:.2f} ms = {flops / tot['g256'] * 1e3:.0f} TF/s; 128-row kernel {tot['k128'] / 1e3:.2f} ms = {flops / tot['k128'] * 1e3:.0f}; torch.matmul alone {tot['torch'] / 1e3:.2f} ms = {flops / tot['torch'] * 1e3:.0f}")
