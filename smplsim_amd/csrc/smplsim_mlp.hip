@@ -369,6 +369,7 @@ struct LinearTrainArgs {
   __bf16 *Yt;                   // [N, ldyt] transposed copy or null
   __bf16 *Dact;                 // [M, ldy] act'(pre-activation) or null
   int M, N, K, ldy, ldyt, act, xcd_remap, ksplit;
+  int kper = 0;                 // ss_gemm256_kernel: K tiles per share (even; the host's number, not re-derived from ksplit)
 };
 
 template <int BN, bool F32ATOMIC>
@@ -589,7 +590,7 @@ __global__ void __launch_bounds__(512) ss_gemm256_kernel(const LinearTrainArgs a
     }
   }
   const int m0 = by * T, n0 = bx * T;
-  const int nkt_all = K / 64, per = (nkt_all + a.ksplit - 1) / a.ksplit, kt0 = (int)blockIdx.z * per, kt1 = kt0 + per < nkt_all ? kt0 + per : nkt_all;
+  const int nkt_all = K / 64, per = a.kper > 0 ? a.kper : nkt_all, kt0 = (int)blockIdx.z * per, kt1 = kt0 + per < nkt_all ? kt0 + per : nkt_all;
   const int nkt = kt1 - kt0;
   if (nkt < 2 || (nkt & 1)) return;                           // (the host cuts K into shares of an even number of tiles)
   f32x16 acc[4][2];
@@ -923,18 +924,22 @@ int ss_linear_bf16_train(const void *x, const void *w, const float *bias, const 
   LinearTrainArgs a{static_cast<const __bf16 *>(x), static_cast<const __bf16 *>(w), bias, static_cast<const __bf16 *>(mul), y, static_cast<__bf16 *>(yt),
                     static_cast<__bf16 *>(dact), M, N, K, ldy, ldyt, act, remap, ksplit};
   // the 256 x 256 kernel (ss_gemm256.h): products with thousands of rows or a K split to fill the chip with; its source offsets are 32-bit
-  // (measured, profiles/r06_gemm256.txt: thousands of rows -> 1.5-2 x the 128-row kernel; of the weight gradients only the one with 50+ tiles gains)
+  // (measured, profiles/r06_gemm256.txt: thousands of rows -> 1.5-2 x the 128-row kernel; weight gradients with the batch as K -> 1.05-2.2 x once the K split fills ONE round)
   // the set of outputs it is built for (the other combinations keep the 128-row kernel)
   const int mode256 = y_is_f32_accumulate ? G256_ACCUM : (y && !mul && !yt && !dact) ? G256_PLAIN : (y && !mul && yt && dact) ? G256_FWD : (y && mul && yt && !dact) ? G256_DX : -1;
   bool big = mode256 >= 0 && N >= 256 && M >= 256 && K >= 128 && K % 128 == 0 && (long long)M * K < (1ll << 32) && (long long)N * K < (1ll << 32) &&
-             (y_is_f32_accumulate ? (long long)((N + 255) / 256) * ((M + 255) / 256) >= 48 : M >= 2048);
+             (y_is_f32_accumulate ? K >= 8192 : M >= 2048);
   { const char *live = getenv("SS_MLP_TRAIN_256"); if (live) big = atoi(live) != 0 && mode256 >= 0 && K >= 128 && K % 128 == 0 && (long long)M * K < (1ll << 32) && (long long)N * K < (1ll << 32); }
   if (big) {
     constexpr int T = gemm256::TILE;
     const int gx = (N + T - 1) / T, gy = (M + T - 1) / T, nkt = K / 64;
     int ks = 1;
     if (y_is_f32_accumulate) {
-      ks = (int)((512 + (long long)gx * gy - 1) / ((long long)gx * gy));
+      // whole rounds of the 256 CUs (one workgroup per CU): as many shares as fill ONE round — 28 tiles x 19 shares = 532 workgroups ran as three rounds
+      int rounds = 1;
+      { const char *rd = getenv("SS_MLP_TRAIN_ROUNDS"); if (rd && atoi(rd) > 0) rounds = atoi(rd); }
+      ks = (int)(((long long)256 * rounds) / ((long long)gx * gy));
+      if (ks < 1) ks = 1;
       if (ks > nkt / 8) ks = nkt / 8 > 0 ? nkt / 8 : 1;
       static const char *force_ks = getenv("SS_MLP_TRAIN_KSPLIT");
       if (force_ks && atoi(force_ks) > 0) ks = atoi(force_ks);
@@ -942,6 +947,7 @@ int ss_linear_bf16_train(const void *x, const void *w, const float *bias, const 
       int per = (nkt + ks - 1) / ks;
       per += per & 1;                                         // shares of an even number of K tiles (nkt is even: the last share too)
       ks = (nkt + per - 1) / per;
+      a.kper = per;
     }
     a.ksplit = ks;
 #ifdef SS_GEMM256_ABLATE

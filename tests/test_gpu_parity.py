@@ -1131,7 +1131,7 @@ def test_gemm256_kernel_outputs(M, N, K, act, monkeypatch):
     assert (yf[:, :N] - ref).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("M,N,K", [(2048, 1536, 53248), (69, 512, 4096 * 3), (1024, 320, 8192)])
+@pytest.mark.parametrize("M,N,K", [(2048, 1536, 53248), (69, 512, 4096 * 3), (1024, 320, 8192), (1024, 1600, 53248), (512, 576, 53248 + 128)])   # (the last two: 256-tile kernel, K shares rounded to even tile counts)
 def test_linear_bf16_train_kernel_split_k_accumulates(M, N, K):
     """The accumulating fp32 form (weight gradients: few outputs, the batch as K): the K split's partial sums meet in the output by
     atomics; against the fp32 product of the same bf16 operands.  Accumulates: a second call doubles the result."""

@@ -47,8 +47,17 @@ for name, kind, m, n, k in shapes:
     for rnd in range(5):
         for v in variants: t[v].append(run(v, pick(v)))
     med = {v: float(np.median(t[v])) for v in variants}
+    err = ""
+    if ok256:                                                      # the 256-tile kernel's result of this product against fp32 on the same operands
+        os.environ["SS_MLP_TRAIN_256"] = "1"
+        ref = x[:2048].float() @ w.float().t()
+        if kind == "dw":
+            y.zero_(); f(); torch.cuda.synchronize(); got = y[:2048]
+        else:
+            plain(); torch.cuda.synchronize(); got = y[:2048].float()
+        err = f"  max err / max |ref| {float((got - ref).abs().max() / ref.abs().max()):.1e}"
     gf = 2.0 * m * n * k / 1e9
     flops += gf
     tot["g256"] += med.get("g256", med["k128"]); tot["k128"] += med["k128"]; tot["torch"] += med["torch"]
-    print(f"{name:5s} [{m} x {n}, K {k}] {gf:6.0f} GFLOP  " + "  ".join(f"{v}: {med[v]:7.1f} us {gf / med[v] * 1e3:5.0f} TF/s" for v in variants), flush=True)
+    print(f"{name:5s} [{m} x {n}, K {k}] {gf:6.0f} GFLOP  " + "  ".join(f"{v}: {med[v]:7.1f} us {gf / med[v] * 1e3:5.0f} TF/s" for v in variants) + err, flush=True)
 print(f"one pass: {flops / 1e3:.2f} TFLOP; 256-tile kernel {tot['g256'] / 1e3:.2f} ms = {flops / tot['g256'] * 1e3:.0f} TF/s; 128-row kernel {tot['k128'] / 1e3:.2f} ms = {flops / tot['k128'] * 1e3:.0f}; torch.matmul alone {tot['torch'] / 1e3:.2f} ms = {flops / tot['torch'] * 1e3:.0f}")
