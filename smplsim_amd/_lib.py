@@ -40,7 +40,7 @@ class ExtensionMissing(RuntimeError):
 def build(verbose=False, force=False):
     """hipcc --offload-arch=gfx950 build of the kernels + C ABI (cross-compiles without a GPU)."""
     srcs = [os.path.join(SRC_DIR, f) for f in ("smplsim_hip.hip", "smplsim_hip_sc.hip", "smplsim_hip_im.hip", "smplsim_motion.hip", "smplsim_mlp.hip", "smplsim_hip_x.hip", "ss_env_kernel.h", "ss_kernel.h", "ss_selfcol.h", "ss_api.h", "ss_tables.h", "ss_hdr.h",
-                                                  "ss_motion.h", "ss_motion_api.h", "ss_wave_gpu.h", "ss_imfused.h", "ss_mjcf.h")]
+                                                  "ss_motion.h", "ss_motion_api.h", "ss_wave_gpu.h", "ss_imfused.h", "ss_mjcf.h", "ss_gemm256.h")]
     srcs += [os.path.join(os.path.dirname(_PKG), "include", h) for h in ("smplsim_hip.h", "smplsim_motion.h", "smplsim_mlp.h")]
     opt = os.environ.get("SS_HIPCC_OPT", DEFAULT_OPT).split()
     scopt = os.environ.get("SS_HIPCC_SC_OPT", SC_OPT).split()
