@@ -147,3 +147,24 @@ def test_fused_train_has_no_cpu_path():
         FusedMLPTrain(net.affine_layers, torch.nn.Linear(64, 3), "silu")
     with pytest.raises(ValueError, match="fused epilogue"):
         FusedMLPTrain(net.affine_layers, torch.nn.Linear(64, 3), "gelu")
+
+
+def test_fused_train_work_tensors_are_reused_only_between_finished_passes():
+    """learning.fused_train._Buffers (host logic, no kernel): a pass's work tensors are kept between calls, initialised once (the ones row behind a
+    transposed activation), keyed by shape; a pass that starts while the previous one's backward has not run gets fresh tensors."""
+    from smplsim_amd.learning.fused_train import _Buffers
+    b = _Buffers()
+    calls = []
+
+    def init(t):
+        calls.append(1)
+        t[2, :3] = 1.0
+    t1 = b.get("ht", (4, 8), torch.float32, "cpu", False, init)
+    t1[0, 0] = 5.0
+    t2 = b.get("ht", (4, 8), torch.float32, "cpu", False, init)
+    assert t2 is t1 and len(calls) == 1 and float(t2[2, :3].sum()) == 3.0 and float(t2[0, 0]) == 5.0     # kept, initialised once
+    t3 = b.get("ht", (4, 16), torch.float32, "cpu", False, init)
+    assert t3 is not t1 and tuple(t3.shape) == (4, 16) and len(calls) == 2                                 # another shape: another tensor
+    f = b.get("ht", (4, 8), torch.float32, "cpu", True, init)
+    assert f is not t1 and float(f[0, 0]) == 0.0 and float(f[2, :3].sum()) == 3.0 and len(calls) == 3       # fresh: zeroed and initialised
+    assert b.busy is False
