@@ -82,8 +82,10 @@ class _FusedMLP(torch.autograd.Function):
 
         h = bufs.get("x", (Mp, kpad[0]), bf, dev, fresh)           # (pad rows and columns stay zero: only [:M, :D] is ever written)
         h[:M, :D] = x
-        t0 = bufs.get("xt", (kpad[0] + 64, Mp), bf, dev, fresh, ones_row(kpad[0]))
-        t0[:D, :M] = x.t()
+        t0 = None
+        if track:
+            t0 = bufs.get("xt", (kpad[0] + 64, Mp), bf, dev, fresh, ones_row(kpad[0]))
+            t0[:D, :M] = x.t()
         hts, gs, wbs = [t0], [], []
         for i in range(nl - 1):
             w = ws[i]
@@ -92,8 +94,11 @@ class _FusedMLP(torch.autograd.Function):
             wb = bufs.get(("w", i), (N, kpad[i]), bf, dev, fresh)
             wb[:, :w.shape[1]] = w
             y = bufs.get(("h", i), (Mp, N), bf, dev, fresh)
-            yt = bufs.get(("ht", i), (N + 64, Mp), bf, dev, fresh, ones_row(N))
-            g = bufs.get(("g", i), (Mp, N), bf, dev, fresh)
+            if track:
+                yt = bufs.get(("ht", i), (N + 64, Mp), bf, dev, fresh, ones_row(N))
+                g = bufs.get(("g", i), (Mp, N), bf, dev, fresh)
+            else:
+                yt = g = None                                      # no backward pass will follow (GAE's value pass): the result alone, a third of the bytes
             _linear_train(h, wb, bs[i].detach().float().contiguous(), None, y, yt, g, Mp, N, kpad[i], N, Mp, act, False, st)
             wbs.append(wb); hts.append(yt); gs.append(g)
             h = y
