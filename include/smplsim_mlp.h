@@ -44,6 +44,13 @@ int ss_linear_bf16_train(const void *x, const void *w, const float *bias, const 
 int ss_obs_to_bf16(const float *obs, int32_t M, int32_t dim, int32_t obs_stride, const float *norm_mean, const float *norm_std,
                    const int64_t *norm_n, float clip_lo, float clip_hi, float norm_clip, void *out, int32_t kpad, void *stream);
 
+/* Weight gradient of a linear layer from the two tensors as autograd holds them (replaces `grad_W = dZ^T @ h` of torch.nn.Linear's backward inside the
+ * reference's update_policy / update_value, agents/agent_ppo.py:20-83):
+ *   dw[i, j] += sum_m dz[m, i] * h[m, j]      dz [Mb, ldz] bf16 (columns 0 .. n_out - 1 used), h [Mb, ldh] bf16 (columns 0 .. n_in - 1), dw [n_out, ldw] fp32
+ * Both operands are read untransposed (contraction over their ROWS); the caller zeroes dw; partial sums of a K split meet by fp32 atomics.
+ * Mb a multiple of 128 (pad rows zero), n_out, n_in, ldz, ldh multiples of 8, dz and h 16-byte aligned, ldw >= n_in. */
+int ss_wgrad_bf16(const void *dz, const void *h, float *dw, int32_t Mb, int32_t n_out, int32_t n_in, int32_t ldz, int32_t ldh, int32_t ldw, void *stream);
+
 /* The Gaussian head of the sampler in one launch (PolicyGaussian.select_action, policy_gaussian.py:25-41 -> DiagGaussian.sample;
  * Agent.preprocess_actions with clip_actions, agents/agent.py:153-161; normal_log_density of get_log_prob): per row
  *   action = mean + exp(log_std) * noise          [M, dim], row stride lda (the rollout's action row: the UNCLIPPED draw is what is stored)

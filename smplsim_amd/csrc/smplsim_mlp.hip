@@ -551,10 +551,11 @@ __global__ void __launch_bounds__(512) ss_linear_train_kernel(const LinearTrainA
 //     G256_PLAIN   Y = act(x W^T + b)
 //     G256_FWD     Y, Y^T and act'(pre-activation)                  (a hidden layer's forward pass)
 //     G256_DX      Y = (x W^T) * mul and Y^T                        (dZ of the layer below)
+//     G256_FWDN / G256_DXN   the same two without Y^T: since ss_wgrad_bf16 contracts over the ROWS of dZ and h, nothing needs a transposed copy
 // Why compile-time: the K loop alone runs the 53 248 x 1536 x 2048 product in 256 us = 1.31 PFLOP/s; the first epilogue (run-time `if (Y)`, `if (Dact)` per
 // element, one dependent exp -> rcp chain after the other between the branches, every 16-byte chunk of the output parked in scratch because its edge
 // path indexed it dynamically) cost 90 us for ONE image and 200 us for three (profiles/r06_gemm256.txt).
-enum { G256_ACCUM = 0, G256_PLAIN = 1, G256_FWD = 2, G256_DX = 3 };
+enum { G256_ACCUM = 0, G256_PLAIN = 1, G256_FWD = 2, G256_DX = 3, G256_FWDN = 4, G256_DXN = 5 };   // ..N: without the transposed image (ss_wgrad_bf16 reads the operands as they lie)
 
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   union { __bf16 h[2]; unsigned u; } c;
@@ -628,7 +629,7 @@ __global__ void __launch_bounds__(512) ss_gemm256_kernel(const LinearTrainArgs a
         }
     }
   } else {
-    constexpr bool HAS_MUL = MODE == G256_DX, HAS_D = MODE == G256_FWD, HAS_T = MODE != G256_PLAIN;
+    constexpr bool HAS_MUL = MODE == G256_DX || MODE == G256_DXN, HAS_D = MODE == G256_FWD || MODE == G256_FWDN, HAS_T = MODE == G256_FWD || MODE == G256_DX;
     constexpr int CS = T + 8, CPR = T / 8;
     constexpr int HALF_IMG = 128 * CS;                        // elements of one half image (128 rows)
     __bf16 *Cs = lds_g;
@@ -750,6 +751,44 @@ __global__ void __launch_bounds__(512) ss_gemm256_kernel(const LinearTrainArgs a
         }
       }
     }
+  }
+}
+
+// ---- round 6: the weight gradient from dZ and the layer's input AS THEY LIE (both [batch, features] row-major): dW[i][j] += sum_m dZ[m][i] h[m][j].  The forward and dX
+// products of the update are bound by what they WRITE (profiles/r06_gemm256.txt); with this kernel they need not write transposed copies any more.  K loop:
+// gemm256::LoopTN (fragments by ds_read_b64_tr_b16); K split over one round of the CUs, fp32 atomics, as ss_gemm256_kernel<G256_ACCUM>.
+struct WgradArgs {
+  const __bf16 *Z, *H;          // [Mb, ldz], [Mb, ldh]
+  float *dW;                    // [NI, ldw] += ; NI = columns of Z used, NJ = columns of H used
+  int NI, NJ, ldz, ldh, ldw, nkt, kper;
+};
+
+__global__ void __launch_bounds__(512) ss_wgrad_tn_kernel(const WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 lds_g[];
+  const int i0 = blockIdx.y * 256, j0 = blockIdx.x * 256;
+  const int kt0 = (int)blockIdx.z * a.kper, kt1 = kt0 + a.kper < a.nkt ? kt0 + a.kper : a.nkt, nkt = kt1 - kt0;
+  if (nkt < 2 || (nkt & 1)) return;
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  gemm256::LoopTN L;
+  L.init(a.Z, a.H, a.ldz, a.ldh, a.NI, a.NJ, i0, j0, kt0, reinterpret_cast<char *>(lds_g));
+  L.run(acc, nkt);
+  const int lane = L.lane;
+#pragma unroll
+  for (int tn = 0; tn < 2; tn++) {
+    const int col = j0 + L.wc * 64 + tn * 32 + (lane & 31);
+#pragma unroll
+    for (int tm = 0; tm < 4; tm++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = i0 + L.wr * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < a.NI && col < a.NJ) unsafeAtomicAdd(a.dW + (size_t)row * a.ldw + col, acc[tm][tn][r]);
+      }
   }
 }
 
@@ -926,7 +965,8 @@ int ss_linear_bf16_train(const void *x, const void *w, const float *bias, const 
   // the 256 x 256 kernel (ss_gemm256.h): products with thousands of rows or a K split to fill the chip with; its source offsets are 32-bit
   // (measured, profiles/r06_gemm256.txt: thousands of rows -> 1.5-2 x the 128-row kernel; weight gradients with the batch as K -> 1.05-2.2 x once the K split fills ONE round)
   // the set of outputs it is built for (the other combinations keep the 128-row kernel)
-  const int mode256 = y_is_f32_accumulate ? G256_ACCUM : (y && !mul && !yt && !dact) ? G256_PLAIN : (y && !mul && yt && dact) ? G256_FWD : (y && mul && yt && !dact) ? G256_DX : -1;
+  const int mode256 = y_is_f32_accumulate ? G256_ACCUM : (y && !mul && !yt && !dact) ? G256_PLAIN : (y && !mul && yt && dact) ? G256_FWD : (y && mul && yt && !dact) ? G256_DX :
+                      (y && !mul && !yt && dact) ? G256_FWDN : (y && mul && !yt && !dact) ? G256_DXN : -1;
   bool big = mode256 >= 0 && N >= 256 && M >= 256 && K >= 128 && K % 128 == 0 && (long long)M * K < (1ll << 32) && (long long)N * K < (1ll << 32) &&
              (y_is_f32_accumulate ? K >= 8192 : M >= 2048);
   { const char *live = getenv("SS_MLP_TRAIN_256"); if (live) big = atoi(live) != 0 && mode256 >= 0 && K >= 128 && K % 128 == 0 && (long long)M * K < (1ll << 32) && (long long)N * K < (1ll << 32); }
@@ -964,7 +1004,9 @@ int ss_linear_bf16_train(const void *x, const void *w, const float *bias, const 
     if (y_is_f32_accumulate) SS_G256(G256_ACCUM, loop_);
     else if (mode256 == G256_PLAIN) SS_G256(G256_PLAIN, epi_);
     else if (mode256 == G256_FWD) SS_G256(G256_FWD, epi_);
-    else SS_G256(G256_DX, epi_);
+    else if (mode256 == G256_DX) SS_G256(G256_DX, epi_);
+    else if (mode256 == G256_FWDN) SS_G256(G256_FWDN, epi_);
+    else SS_G256(G256_DXN, epi_);
 #undef SS_G256
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? SS_OK : fail(SS_ERR_HIP, hipGetErrorString(e));
@@ -990,6 +1032,27 @@ int ss_linear_bf16_train(const void *x, const void *w, const float *bias, const 
   else if (bn == 128) SS_TRAIN(128);
   else SS_TRAIN(64);
 #undef SS_TRAIN
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SS_OK : fail(SS_ERR_HIP, hipGetErrorString(e));
+}
+
+int ss_wgrad_bf16(const void *dz, const void *h, float *dw, int32_t Mb, int32_t n_out, int32_t n_in, int32_t ldz, int32_t ldh, int32_t ldw, void *stream) {
+  if (!dz || !h || !dw) return fail(SS_ERR_INVALID, "null argument");
+  if (Mb < 128 || Mb % 128 || n_out < 1 || n_in < 1 || ldz < n_out || ldh < n_in || ldw < n_in || (ldz & 7) || (ldh & 7) || (n_out & 7) || (n_in & 7) ||
+      (reinterpret_cast<size_t>(dz) & 15) || (reinterpret_cast<size_t>(h) & 15))
+    return fail(SS_ERR_INVALID, "ss_wgrad_bf16: the batch a multiple of 128 rows; n_out, n_in, ldz, ldh multiples of 8; 16-byte aligned operands; ldw >= n_in");
+  if ((long long)Mb * ldz >= (1ll << 32) || (long long)Mb * ldh >= (1ll << 32)) return fail(SS_ERR_INVALID, "ss_wgrad_bf16: operands beyond 2^32 elements");
+  const int gx = (n_in + 255) / 256, gy = (n_out + 255) / 256, nkt = Mb / 64;
+  int ks = (int)(256ll / ((long long)gx * gy));               // K shares that fill one round of the CUs (one workgroup per CU)
+  if (ks < 1) ks = 1;
+  if (ks > nkt / 8) ks = nkt / 8 > 0 ? nkt / 8 : 1;
+  int per = (nkt + ks - 1) / ks;
+  per += per & 1;                                             // shares of an even number of K tiles (nkt is even)
+  ks = (nkt + per - 1) / per;
+  WgradArgs a{static_cast<const __bf16 *>(dz), static_cast<const __bf16 *>(h), dw, n_out, n_in, ldz, ldh, ldw, nkt, per};
+  const size_t lds = gemm256::LoopTN::LDS_BYTES;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(ss_wgrad_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return fail(SS_ERR_HIP, "cannot size the GEMM's LDS");
+  hipLaunchKernelGGL(ss_wgrad_tn_kernel, dim3(gx, gy, ks), dim3(512), lds, (hipStream_t)stream, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SS_OK : fail(SS_ERR_HIP, hipGetErrorString(e));
 }

@@ -157,4 +157,113 @@ struct Loop {
   }
 };
 
+// ---- the same loop for a product that contracts over the ROWS of both operands: dW[i][j] = sum_m Z[m][i] H[m][j], Z [Mb, ldz] and H [Mb, ldh] row-major
+// (the weight gradient of a layer from dZ and the layer's input as they lie in memory: no transposed copies).  What changes against Loop:
+//   * a half-tile is 32 m x 256 columns of one operand, stored as 16 subtiles [32 m][16 columns] of 1 KB (one copy instruction each: lane -> row lane / 2, 16-byte
+//     half lane % 2), 1152 bytes apart so that the even and odd subtiles of a fragment read fall into different halves of the 256-byte bank row;
+//   * a fragment (lane = column, 8 consecutive m) is two ds_read_b64_tr_b16: per 16-lane group lane p passes the address of row p / 4, column quad p % 4 of a
+//     [4 m][16 columns] block and receives column p of it (profiles/r06_tr_read_probe.txt);
+//   * a phase is one k16 step of the whole 128 x 64 wave tile (12 reads, 8 matrix instructions); phases 0, 1 read the m-low half-tiles, 2, 3 the m-high ones;
+//     request order per K tile Z-low, H-low, Z-high, H-high, half-tile s requested in phase s - 5 (its region's last reader is phase s - 7 at the latest: two
+//     phases before), `s_waitcnt vmcnt(6)` = three half-tiles in flight.
+struct LoopTN {
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+  static constexpr int SUB = 1152, HALF = 16 * SUB, BUF = 4 * HALF;   // bytes: subtile stride, half-tile, one K tile's four half-tiles
+  static constexpr int LDS_BYTES = 2 * BUF;                            // 147 456
+  unsigned zoff[2], hoff[2];                                  // per lane: element offsets (K tile 0, m-low) of its two copies of a Z resp. H half-tile
+  const __bf16 *Z, *H;
+  unsigned ldz, ldh;
+  unsigned lds;                                               // LDS byte address of the workgroup's block
+  int wave, lane, wr, wc, kt0;
+  unsigned fa_addr, fb_addr;                                  // this lane's fragment-read byte offsets inside a Z resp. H half-tile (row tile 0, k16 step 0, read 0)
+  bf16x8 fa[4], fb[2];
+
+  __device__ __forceinline__ void init(const __bf16 *Z_, const __bf16 *H_, int ldz_, int ldh_, int NI, int NJ, int i0, int j0, int kt0_, char *lds_) {
+    Z = Z_; H = H_; ldz = (unsigned)ldz_; ldh = (unsigned)ldh_; kt0 = kt0_;
+    lds = (unsigned)(size_t)lds_;
+    const int tid = threadIdx.x;
+    lane = tid & 63;
+    wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    wr = wave >> 2; wc = wave & 3;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int nblk = wave + 8 * i, ml = lane >> 1, hh = lane & 1;
+      int ci = i0 + 16 * nblk + 8 * hh, cj = j0 + 16 * nblk + 8 * hh;
+      ci = ci + 8 <= NI ? ci : 0;                             // (columns beyond the matrix: any readable chunk, their results are never stored)
+      cj = cj + 8 <= NJ ? cj : 0;
+      zoff[i] = (unsigned)ml * ldz + (unsigned)ci;
+      hoff[i] = (unsigned)ml * ldh + (unsigned)cj;
+    }
+    const int g = lane >> 4, p = lane & 15;
+    const unsigned inner = (unsigned)((8 * (g >> 1) + (p >> 2)) * 32 + (p & 3) * 8);
+    fa_addr = (unsigned)((2 * (wr * 4) + (g & 1)) * SUB) + inner;     // row tile tm: + 2 tm SUB; k16 step ks: half-tile ks / 2, + 512 (ks % 2); second read: + 128
+    fb_addr = (unsigned)((2 * (wc * 2) + (g & 1)) * SUB) + inner;
+  }
+
+  template <int KIND, int BUFI> __device__ __forceinline__ void request(int tile) {   // KIND 0 Z-low, 1 H-low, 2 Z-high, 3 H-high
+    constexpr bool isz = (KIND & 1) == 0;
+    const __bf16 *base = isz ? Z : H;
+    const size_t m = (size_t)(kt0 + tile) * 64 + (KIND >> 1) * 32;
+    const size_t adv = m * (isz ? ldz : ldh);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const unsigned dst = lds + BUFI * BUF + KIND * HALF + (wave + 8 * i) * SUB;
+      __builtin_amdgcn_global_load_lds((gvoid *)(base + (isz ? zoff[i] : hoff[i]) + adv), (lvoid *)(size_t)dst, 16, 0, 0);
+    }
+  }
+
+  template <int OFF> __device__ __forceinline__ bf16x8 frag(unsigned addr) {
+    u32x2 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"(OFF));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(OFF + 128));
+    union { struct { u32x2 a, b; } s; bf16x8 v; } c;
+    c.s.a = lo; c.s.b = hi;
+    return c.v;
+  }
+
+  // one phase = k16 step J of K tile (buffer BUFI): fragment reads, request of half-tile (phase + 5), counted wait | barrier | 8 matrix instructions | barrier
+  template <int J, int BUFI> __device__ __forceinline__ void phase(f32x16 (&acc)[4][2], int rt) {
+    constexpr int zh = (J >> 1) ? 2 : 0, hh = (J >> 1) ? 3 : 1;                  // the half-tiles this step reads
+    constexpr int ko = 512 * (J & 1);
+    const unsigned ab = lds + BUFI * BUF + zh * HALF + fa_addr, bb = lds + BUFI * BUF + hh * HALF + fb_addr;
+    fa[0] = frag<ko>(ab); fa[1] = frag<ko + 2 * SUB>(ab); fa[2] = frag<ko + 4 * SUB>(ab); fa[3] = frag<ko + 6 * SUB>(ab);
+    fb[0] = frag<ko>(bb); fb[1] = frag<ko + 2 * SUB>(bb);
+    // phase g requests half-tile g + 5: H-low, Z-high, H-high of the next tile (other buffer) in steps 0, 1, 2; Z-low of the tile after it (this buffer) in step 3
+    if constexpr (J == 0) request<1, BUFI ^ 1>(rt);
+    if constexpr (J == 1) request<2, BUFI ^ 1>(rt);
+    if constexpr (J == 2) request<3, BUFI ^ 1>(rt);
+    if constexpr (J == 3) request<0, BUFI>(rt);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int tn = 0; tn < 2; tn++)
+#pragma unroll
+      for (int tm = 0; tm < 4; tm++) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm], fb[tn], acc[tm][tn], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  }
+
+  template <int BUFI> __device__ __forceinline__ void tile(f32x16 (&acc)[4][2], int t, int last) {
+    const int t1 = t + 1 < last ? t + 1 : last, t2 = t + 2 < last ? t + 2 : last;
+    phase<0, BUFI>(acc, t1); phase<1, BUFI>(acc, t1); phase<2, BUFI>(acc, t1); phase<3, BUFI>(acc, t2);
+  }
+
+  // an EVEN number nkt >= 2 of K tiles (64 rows of Z and H each)
+  __device__ __forceinline__ void run(f32x16 (&acc)[4][2], int nkt) {
+    request<0, 0>(0); request<1, 0>(0); request<2, 0>(0); request<3, 0>(0);   // half-tiles 0..4: tile 0 whole, Z-low of tile 1
+    request<0, 1>(1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          // half-tiles 0, 1 landed (this wave's share)
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < nkt; t += 2) { tile<0>(acc, t, nkt - 1); tile<1>(acc, t + 1, nkt - 1); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
+  }
+};
+
 }  // namespace gemm256

@@ -1,21 +1,20 @@
-"""The PPO update's network passes on this library's own matrix-core GEMM (include/smplsim_mlp.h: ss_linear_bf16_train).
+"""The PPO update's network passes on this library's own matrix-core GEMMs (include/smplsim_mlp.h: ss_linear_bf16_train, ss_wgrad_bf16).
 
 What it replaces: autograd over torch.nn.Linear + activation under bf16 autocast (hipBLASLt GEMMs plus separate bias, activation,
 cast and transpose launches) in the reference's update_policy / update_value (agents/agent_ppo.py:20-83).  The loss, the optimiser,
 the gradient clipping and the RunningNorm stay torch code and untouched; only `y = head(MLP(x))` and its backward are here:
 
-  forward, per hidden layer   h, h^T, g = act(z), act(z)^T, act'(z)   with z = h_below W^T + b     ONE launch: the result, its transpose and
-                                                                                                   the activation's derivative from one tile
+  forward, per hidden layer   h = act(z), g = act'(z)   with z = h_below W^T + b     ONE launch: the result and the activation's derivative from one tile
   head                        y = h W^T + b in fp32 (the inference kernel: the action mean must not be rounded to bf16)
-  backward, per layer         dW = dZ^T h_below     -> the same kernel on (dZ^T, h_below^T), contraction over the batch, split along K,
-                                                      fp32 partial sums by hardware atomics
-                              db = one more output column of the same product (a row of ones behind h_below^T)
-                              dZ_below = (dZ W) * g_below   -> the same kernel on (dZ, W^T) with the multiply in its epilogue; writes dZ_below
-                                                               and dZ_below^T
+  backward, per layer         dW = dZ^T h_below     -> ss_wgrad_bf16: both operands as they lie ([batch, features] row-major), contraction over their ROWS
+                                                      (fragments by ds_read_b64_tr_b16), split along the batch, fp32 partial sums by hardware atomics
+                              db = column sums of dZ (one torch reduction)
+                              dZ_below = (dZ W) * g_below   -> ss_linear_bf16_train on (dZ, W^T) with the multiply in its epilogue
 
-Every product is the K-contiguous `x W^T` form because each tensor that a later product contracts over its rows was written transposed by
-the launch that produced it.  bf16 operands, fp32 accumulation: the precision class of the autocast path it replaces (weights, activations and
-gradients of activations rounded to bf16; weight gradients and the head's output fp32).  No CPU path: the package has none.
+No transposed copies of activations or gradients exist: the forward and dX products are bound by the bytes they WRITE (profiles/r06_gemm256.txt: 2.1 TB/s), and
+the first version of this file wrote h^T and dZ^T next to h and dZ so that the weight gradient could be the K-contiguous `x W^T` kernel — 1.35 of the 3.4 GB a
+pass wrote.  bf16 operands, fp32 accumulation: the precision class of the autocast path it replaces (weights, activations and gradients of activations rounded
+to bf16; weight gradients and the head's output fp32).  No CPU path: the package has none.
 """
 import torch
 
@@ -74,19 +73,9 @@ class _FusedMLP(torch.autograd.Function):
             bufs.busy = True
         ctx.bufs = bufs if track and not fresh else None
         bf = torch.bfloat16
-
-        def ones_row(n):                                           # a layer's transposed input + 64 rows, the first of them ones: as the "W" of the
-            def init(t):                                           # weight-gradient product its extra output column is the bias gradient
-                t[n, :M] = 1.0                                     # (sum of dZ over the batch: no separate reduction launches)
-            return init
-
         h = bufs.get("x", (Mp, kpad[0]), bf, dev, fresh)           # (pad rows and columns stay zero: only [:M, :D] is ever written)
         h[:M, :D] = x
-        t0 = None
-        if track:
-            t0 = bufs.get("xt", (kpad[0] + 64, Mp), bf, dev, fresh, ones_row(kpad[0]))
-            t0[:D, :M] = x.t()
-        hts, gs, wbs = [t0], [], []
+        hs, gs, wbs = [h], [], []
         for i in range(nl - 1):
             w = ws[i]
             N = w.shape[0]
@@ -94,13 +83,9 @@ class _FusedMLP(torch.autograd.Function):
             wb = bufs.get(("w", i), (N, kpad[i]), bf, dev, fresh)
             wb[:, :w.shape[1]] = w
             y = bufs.get(("h", i), (Mp, N), bf, dev, fresh)
-            if track:
-                yt = bufs.get(("ht", i), (N + 64, Mp), bf, dev, fresh, ones_row(N))
-                g = bufs.get(("g", i), (Mp, N), bf, dev, fresh)
-            else:
-                yt = g = None                                      # no backward pass will follow (GAE's value pass): the result alone, a third of the bytes
-            _linear_train(h, wb, bs[i].detach().float().contiguous(), None, y, yt, g, Mp, N, kpad[i], N, Mp, act, False, st)
-            wbs.append(wb); hts.append(yt); gs.append(g)
+            g = bufs.get(("g", i), (Mp, N), bf, dev, fresh) if track else None   # no backward pass will follow (GAE's value pass): the result alone
+            _linear_train(h, wb, bs[i].detach().float().contiguous(), None, y, None, g, Mp, N, kpad[i], N, 0, act, False, st)
+            wbs.append(wb); hs.append(y); gs.append(g)
             h = y
         w = ws[-1]
         wb = bufs.get(("w", nl - 1), (w.shape[0], kpad[-1]), bf, dev, fresh)
@@ -110,7 +95,7 @@ class _FusedMLP(torch.autograd.Function):
         _check(lib().ss_linear_bf16(_ptr(h), _ptr(wb), _ptr(bs[-1].detach().float().contiguous()), _ptr(out), Mp, w.shape[0], kpad[-1], w.shape[0],
                                     _cabi.ACTIVATIONS["none"], 1, st))
         ctx.act, ctx.M, ctx.Mp, ctx.kpad, ctx.dims = act, M, Mp, kpad, [(w_.shape[0], w_.shape[1]) for w_ in ws]
-        ctx.hts, ctx.gs, ctx.wbs = hts, gs, wbs
+        ctx.hs, ctx.gs, ctx.wbs = hs, gs, wbs
         return out[:M]
 
     @staticmethod
@@ -127,27 +112,25 @@ class _FusedMLP(torch.autograd.Function):
         nhp = _pad(nh, 128)
         dz = bufs.get("dz_head", (Mp, nhp), bf, dev, fresh)
         dz[:M, :nh] = grad_out
-        dzt = bufs.get("dzt_head", (nhp, Mp), bf, dev, fresh)
-        dzt[:nh, :M] = grad_out.t()
         grads = [None] * (2 * nl)
         for i in range(nl - 1, -1, -1):
             n_out, n_in = dims[i]
             n_outp = dz.shape[1]
-            # dW [n_out, kpad_i] = dZ^T h_below: rows of dZ^T are output features, the contraction is the batch
-            dw = torch.zeros(n_out, kpad[i] + 64, dtype=torch.float32, device=dev)
-            _linear_train(dzt, ctx.hts[i], None, None, dw, None, None, n_out, kpad[i] + 64, Mp, kpad[i] + 64, 0, none, True, st)
-            grads[2 * i] = dw[:, :n_in]
-            grads[2 * i + 1] = dw[:, kpad[i]]                      # the ones row's column: sum of dZ over the batch
+            # dW [n_out, kpad_i] = dZ^T h_below with both operands as they lie (ss_wgrad_bf16 contracts over their rows); db = the column sums of dZ
+            no8 = _pad(n_out, 8)
+            dw = torch.zeros(no8, kpad[i], dtype=torch.float32, device=dev)
+            _check(lib().ss_wgrad_bf16(_ptr(dz), _ptr(ctx.hs[i]), _ptr(dw), Mp, no8, kpad[i], n_outp, kpad[i], kpad[i], st))
+            grads[2 * i] = dw[:n_out, :n_in]
+            grads[2 * i + 1] = dz[:, :n_out].sum(0, dtype=torch.float32)
             if i > 0:
                 # dZ_below = (dZ W) * act'(z_below): W^T [kpad_i, n_outp] as the kernel's "W", contraction over this layer's outputs
                 wt = bufs.get(("wt", i), (kpad[i], n_outp), bf, dev, fresh)
                 wt[:, :n_out] = ctx.wbs[i].t()
                 nb = kpad[i]
                 dzb = bufs.get(("dz", i), (Mp, nb), bf, dev, fresh)
-                dzbt = bufs.get(("dzt", i), (nb, Mp), bf, dev, fresh)
-                _linear_train(dz, wt, None, ctx.gs[i - 1], dzb, dzbt, None, Mp, nb, n_outp, nb, Mp, none, False, st)
-                dz, dzt = dzb, dzbt
-        ctx.hts = ctx.gs = ctx.wbs = None
+                _linear_train(dz, wt, None, ctx.gs[i - 1], dzb, None, None, Mp, nb, n_outp, nb, 0, none, False, st)
+                dz = dzb
+        ctx.hs = ctx.gs = ctx.wbs = None
         if ctx.bufs is not None:
             ctx.bufs.busy = False
         return (None, None, None, None, *grads)

@@ -1159,6 +1159,30 @@ def test_linear_bf16_train_kernel_split_k_accumulates(M, N, K):
     assert (y[:, :N] - 2 * ref).abs().max().item() < 4e-3 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("Mb,n_out,n_in,ldz,ldh", [(53248, 1536, 2048, 1536, 2048), (1024, 72, 520, 128, 576), (4096, 1000, 264, 1024, 320), (256, 8, 8, 8, 8)])
+def test_wgrad_bf16_reads_both_operands_untransposed(Mb, n_out, n_in, ldz, ldh):
+    """ss_wgrad_bf16: dW += dZ^T h with dZ [Mb, ldz] and h [Mb, ldh] as they lie (contraction over their rows, fragments by the LDS transpose read) against
+    the fp32 product of the same bf16 operands; asymmetric operands (a swap of the two cannot pass), widths that are not multiples of the 256-wide tile, row strides
+    wider than the used columns (what lies beyond them must not leak in), the K split's shares rounded to even tile counts, accumulation into dW."""
+    import ctypes as C
+    from smplsim_amd._lib import lib
+    g = torch.Generator().manual_seed(Mb + n_out + n_in)
+    dz = (torch.randn(Mb, ldz, generator=g) * 0.5 + torch.linspace(-1, 1, ldz)[None, :] * 0.2).to(torch.bfloat16).cuda()
+    h = (torch.randn(Mb, ldh, generator=g) * 0.5 + torch.linspace(1, -1, Mb)[:, None] * 0.2).to(torch.bfloat16).cuda()
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dw = torch.zeros(n_out, n_in + 3, device="cuda")
+    assert lib().ss_wgrad_bf16(ptr(dz), ptr(h), ptr(dw), Mb, n_out, n_in, ldz, ldh, n_in + 3, st) == 0
+    torch.cuda.synchronize()
+    ref = dz[:, :n_out].float().t() @ h[:, :n_in].float()
+    assert (dw[:, n_in:] == 0).all()
+    assert (dw[:, :n_in] - ref).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())
+    assert lib().ss_wgrad_bf16(ptr(dz), ptr(h), ptr(dw), Mb, n_out, n_in, ldz, ldh, n_in + 3, st) == 0
+    torch.cuda.synchronize()
+    assert (dw[:, :n_in] - 2 * ref).abs().max().item() < 4e-3 * max(1.0, ref.abs().max().item())
+    assert lib().ss_wgrad_bf16(ptr(dz), ptr(h), ptr(dw), Mb - 64, n_out, n_in, ldz, ldh, n_in + 3, st) == -1      # the batch: multiples of 128 rows
+
+
 def test_fused_mlp_train_gradients_match_autograd():
     """learning.fused_train.FusedMLPTrain (forward + backward on ss_linear_bf16_train) against torch autograd over the same layers in
     fp32: outputs and every parameter gradient agree to bf16 round-off through the stack (relative to the gradient's own scale), on the
