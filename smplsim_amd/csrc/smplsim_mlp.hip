@@ -638,23 +638,32 @@ __global__ void __launch_bounds__(512) ss_gemm256_kernel(const LinearTrainArgs a
                           (!HAS_MUL || (reinterpret_cast<size_t>(a.mul) & 15) == 0);
     // ---- the multiplying operand: the tile by 16-byte row loads into LDS, from there into the accumulators
     if constexpr (HAS_MUL) {
+      if (m0 + T <= M && n0 + T <= N && rows_vec) {
+        // a tile inside the matrix: eight loads in flight, NO control flow between them.  With the bounds tests around every load the compiler put each load in
+        // its own branch region and waited (vmcnt(0)) before entering the next: 16 HBM round trips one after the other, 30 us per tile, +110 us on a 53 248 x 1024
+        // product (profiles/r06_gemm256.txt)
+        const __bf16 *src = a.mul + (size_t)(m0 + tid / CPR) * a.ldy + n0 + (tid % CPR) * 8;
+        __bf16 *dst = Cs + (tid / CPR) * CS + (tid % CPR) * 8;
+        const size_t rstep = (size_t)(512 / CPR) * a.ldy;     // 512 threads cover 16 rows per step
 #pragma unroll
-      for (int i0 = 0; i0 < T * CPR / 512; i0 += 8) {
-        u32x4 v[8];
+        for (int i0 = 0; i0 < T * CPR / 512; i0 += 8) {
+          u32x4 v[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-          const int id = tid + 512 * (i0 + i), rl = id / CPR, cc = (id % CPR) * 8, row = m0 + rl, col = n0 + cc;
-          v[i] = u32x4{0u, 0u, 0u, 0u};
+          for (int i = 0; i < 8; i++) v[i] = *reinterpret_cast<const u32x4 *>(src + (size_t)(i0 + i) * rstep);
+#pragma unroll
+          for (int i = 0; i < 8; i++) *reinterpret_cast<u32x4 *>(dst + (i0 + i) * (512 / CPR) * CS) = v[i];
+        }
+      } else {
+#pragma unroll 1
+        for (int i = 0; i < T * CPR / 512; i++) {
+          const int id = tid + 512 * i, rl = id / CPR, cc = (id % CPR) * 8, row = m0 + rl, col = n0 + cc;
+          u32x4 v = {0u, 0u, 0u, 0u};
           if (row < M && col < N) {
             const __bf16 *src = a.mul + (size_t)row * a.ldy + col;
-            if (rows_vec && col + 8 <= N) v[i] = *reinterpret_cast<const u32x4 *>(src);
-            else v[i] = load_chunk_edge(src, N - col);
+            if (rows_vec && col + 8 <= N) v = *reinterpret_cast<const u32x4 *>(src);
+            else v = load_chunk_edge(src, N - col);
           }
-        }
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-          const int id = tid + 512 * (i0 + i), rl = id / CPR, cc = (id % CPR) * 8;
-          *reinterpret_cast<u32x4 *>(Cs + rl * CS + cc) = v[i];
+          *reinterpret_cast<u32x4 *>(Cs + rl * CS + cc) = v;
         }
       }
       __syncthreads();
