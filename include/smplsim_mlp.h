@@ -44,6 +44,12 @@ int ss_linear_bf16_train(const void *x, const void *w, const float *bias, const 
 int ss_obs_to_bf16(const float *obs, int32_t M, int32_t dim, int32_t obs_stride, const float *norm_mean, const float *norm_std,
                    const int64_t *norm_n, float clip_lo, float clip_hi, float norm_clip, void *out, int32_t kpad, void *stream);
 
+/* dZ of the layer below in one launch (the `grad_input = dZ @ W` of torch.nn.Linear's backward followed by the activation's backward, agents/agent_ppo.py:20-83):
+ *   y = (x W^T) * mul   [M, ldy] bf16        x = dZ [M, K], w = W^T [N, K] (both K-contiguous), mul = act'(z_below) [M, ldy] bf16
+ *   colsum[j] += sum_m of the fp32 result    [N] fp32: the bias gradient of the layer below (the caller zeroes it; partial sums by fp32 atomics)
+ * Served by the 256 x 256 kernel only: M >= 2048, N >= 256, K a multiple of 128 (SS_ERR_INVALID otherwise: use ss_linear_bf16_train and sum the columns yourself). */
+int ss_linear_bf16_dx(const void *x, const void *w, const void *mul, void *y, float *colsum, int32_t M, int32_t N, int32_t K, int32_t ldy, void *stream);
+
 /* Weight gradient of a linear layer from the two tensors as autograd holds them (replaces `grad_W = dZ^T @ h` of torch.nn.Linear's backward inside the
  * reference's update_policy / update_value, agents/agent_ppo.py:20-83):
  *   dw[i, j] += sum_m dz[m, i] * h[m, j]      dz [Mb, ldz] bf16 (columns 0 .. n_out - 1 used), h [Mb, ldh] bf16 (columns 0 .. n_in - 1), dw [n_out, ldw] fp32

@@ -142,13 +142,14 @@ def bind(lib):
 
 FIELDS = {"qpos": 0, "qvel": 1, "xpos": 2, "xmat": 3, "body_vel": 4, "touch": 5, "qacc_warm": 6, "cur_t": 7}   # SS_FIELD_*
 ACTIVATIONS = {"none": 0, "silu": 1, "tanh": 2, "relu": 3}
-MLP_EXPORTS = ["ss_linear_bf16", "ss_linear_bf16_train", "ss_wgrad_bf16", "ss_obs_to_bf16", "ss_gaussian_sample"]            # include/smplsim_mlp.h (product library only: the matrix-core kernels)
+MLP_EXPORTS = ["ss_linear_bf16", "ss_linear_bf16_train", "ss_linear_bf16_dx", "ss_wgrad_bf16", "ss_obs_to_bf16", "ss_gaussian_sample"]            # include/smplsim_mlp.h (product library only: the matrix-core kernels)
 
 
 def bind_mlp(lib):
     vp = C.c_void_p
     lib.ss_linear_bf16.argtypes = [vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]
     lib.ss_linear_bf16_train.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]
+    lib.ss_linear_bf16_dx.argtypes = [vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]
     lib.ss_wgrad_bf16.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]
     lib.ss_obs_to_bf16.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, C.c_float, C.c_float, C.c_float, vp, C.c_int32, vp]
     lib.ss_gaussian_sample.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, vp, C.c_int32, vp, C.c_int32, C.c_float, C.c_float, vp, vp]

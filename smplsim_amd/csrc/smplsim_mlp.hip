@@ -370,6 +370,7 @@ struct LinearTrainArgs {
   __bf16 *Dact;                 // [M, ldy] act'(pre-activation) or null
   int M, N, K, ldy, ldyt, act, xcd_remap, ksplit;
   int kper = 0;                 // ss_gemm256_kernel: K tiles per share (even; the host's number, not re-derived from ksplit)
+  float *colsum = nullptr;      // ss_gemm256_kernel with `mul`: [N] += column sums of the fp32 result (the bias gradient of the layer below)
 };
 
 template <int BN, bool F32ATOMIC>
@@ -681,7 +682,27 @@ __global__ void __launch_bounds__(512) ss_gemm256_kernel(const LinearTrainArgs a
           acc[tm][tn][r] = v;
         }
     }
-    if constexpr (HAS_MUL) __syncthreads();
+    if constexpr (HAS_MUL) {
+      if (a.colsum) {
+        // bias gradient of the layer below: the column sums of dZ, from the fp32 values in the accumulators (a lane holds 64 rows of each of its two columns;
+        // its partner 32 lanes on holds the other 64 of this wave's 128), one atomic per column and wave
+#pragma unroll
+        for (int tn = 0; tn < 2; tn++) {
+          float sum = 0.f;
+#pragma unroll
+          for (int tm = 0; tm < 4; tm++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+              const int row = m0 + row_l + tm * 32 + (r & 3) + 8 * (r >> 2);
+              sum += row < M ? acc[tm][tn][r] : 0.f;
+            }
+          sum += __shfl_xor(sum, 32, 64);
+          const int col = n0 + col_l + tn * 32;
+          if (lane < 32 && col < N) unsafeAtomicAdd(a.colsum + col, sum);
+        }
+      }
+      __syncthreads();
+    }
     // ---- result (and derivative) in two halves of the tile — each wave's upper 64 rows, then its lower 64 — so that a half's two images sit in
     // LDS side by side and the exponential is evaluated ONCE per element; the accumulators keep the activated values for the transposed image
     auto half_rows = [&](__bf16 *dst, const __bf16 *img, int half) {
@@ -930,8 +951,8 @@ int ss_linear_bf16(const void *x, const void *w, const float *bias, void *y, int
   return e == hipSuccess ? SS_OK : fail(SS_ERR_HIP, hipGetErrorString(e));
 }
 
-int ss_linear_bf16_train(const void *x, const void *w, const float *bias, const void *mul, void *y, void *yt, void *dact, int32_t M, int32_t N, int32_t K,
-                         int32_t ldy, int32_t ldyt, int32_t act, int32_t y_is_f32_accumulate, void *stream) {
+static int linear_train_impl(const void *x, const void *w, const float *bias, const void *mul, void *y, void *yt, void *dact, int32_t M, int32_t N, int32_t K,
+                             int32_t ldy, int32_t ldyt, int32_t act, int32_t y_is_f32_accumulate, float *colsum, void *stream) {
   if (!x || !w || (!y && !yt)) return fail(SS_ERR_INVALID, "null argument");
   if (M < 1 || N < 1 || K < 64 || K % 64 || (y && ldy < N) || (yt && ldyt < M)) return fail(SS_ERR_INVALID, "ss_linear_bf16_train: K must be a positive multiple of 64, ldy >= N, ldyt >= M");
   if (act < SS_ACT_NONE || act > SS_ACT_RELU) return fail(SS_ERR_INVALID, "unknown activation");
@@ -979,7 +1000,10 @@ int ss_linear_bf16_train(const void *x, const void *w, const float *bias, const 
   bool big = mode256 >= 0 && N >= 256 && M >= 256 && K >= 128 && K % 128 == 0 && (long long)M * K < (1ll << 32) && (long long)N * K < (1ll << 32) &&
              (y_is_f32_accumulate ? K >= 8192 : M >= 2048);
   { const char *live = getenv("SS_MLP_TRAIN_256"); if (live) big = atoi(live) != 0 && mode256 >= 0 && K >= 128 && K % 128 == 0 && (long long)M * K < (1ll << 32) && (long long)N * K < (1ll << 32); }
+  if (colsum && !(big && (mode256 == G256_DX || mode256 == G256_DXN)))
+    return fail(SS_ERR_INVALID, "ss_linear_bf16_dx: column sums come from the 256 x 256 kernel only (M >= 2048, N >= 256, K a multiple of 128, mul and y given)");
   if (big) {
+    a.colsum = colsum;
     constexpr int T = gemm256::TILE;
     const int gx = (N + T - 1) / T, gy = (M + T - 1) / T, nkt = K / 64;
     int ks = 1;
@@ -1043,6 +1067,16 @@ int ss_linear_bf16_train(const void *x, const void *w, const float *bias, const 
 #undef SS_TRAIN
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SS_OK : fail(SS_ERR_HIP, hipGetErrorString(e));
+}
+
+int ss_linear_bf16_train(const void *x, const void *w, const float *bias, const void *mul, void *y, void *yt, void *dact, int32_t M, int32_t N, int32_t K,
+                         int32_t ldy, int32_t ldyt, int32_t act, int32_t y_is_f32_accumulate, void *stream) {
+  return linear_train_impl(x, w, bias, mul, y, yt, dact, M, N, K, ldy, ldyt, act, y_is_f32_accumulate, nullptr, stream);
+}
+
+int ss_linear_bf16_dx(const void *x, const void *w, const void *mul, void *y, float *colsum, int32_t M, int32_t N, int32_t K, int32_t ldy, void *stream) {
+  if (!mul || !y || !colsum) return fail(SS_ERR_INVALID, "null argument");
+  return linear_train_impl(x, w, nullptr, mul, y, nullptr, nullptr, M, N, K, ldy, 0, SS_ACT_NONE, 0, colsum, stream);
 }
 
 int ss_wgrad_bf16(const void *dz, const void *h, float *dw, int32_t Mb, int32_t n_out, int32_t n_in, int32_t ldz, int32_t ldh, int32_t ldw, void *stream) {

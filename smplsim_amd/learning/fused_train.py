@@ -8,8 +8,8 @@ the gradient clipping and the RunningNorm stay torch code and untouched; only `y
   head                        y = h W^T + b in fp32 (the inference kernel: the action mean must not be rounded to bf16)
   backward, per layer         dW = dZ^T h_below     -> ss_wgrad_bf16: both operands as they lie ([batch, features] row-major), contraction over their ROWS
                                                       (fragments by ds_read_b64_tr_b16), split along the batch, fp32 partial sums by hardware atomics
-                              db = column sums of dZ (one torch reduction)
-                              dZ_below = (dZ W) * g_below   -> ss_linear_bf16_train on (dZ, W^T) with the multiply in its epilogue
+                              dZ_below = (dZ W) * g_below   -> ss_linear_bf16_dx on (dZ, W^T): the multiply in its epilogue, and the column sums of
+                                                               the fp32 result = db of the layer below from the same launch
 
 No transposed copies of activations or gradients exist: the forward and dX products are bound by the bytes they WRITE (profiles/r06_gemm256.txt: 2.1 TB/s), and
 the first version of this file wrote h^T and dZ^T next to h and dZ so that the weight gradient could be the K-contiguous `x W^T` kernel — 1.35 of the 3.4 GB a
@@ -113,6 +113,7 @@ class _FusedMLP(torch.autograd.Function):
         dz = bufs.get("dz_head", (Mp, nhp), bf, dev, fresh)
         dz[:M, :nh] = grad_out
         grads = [None] * (2 * nl)
+        db = grad_out.sum(0)                                       # the head's bias gradient (its dZ is the caller's tensor)
         for i in range(nl - 1, -1, -1):
             n_out, n_in = dims[i]
             n_outp = dz.shape[1]
@@ -121,14 +122,20 @@ class _FusedMLP(torch.autograd.Function):
             dw = torch.zeros(no8, kpad[i], dtype=torch.float32, device=dev)
             _check(lib().ss_wgrad_bf16(_ptr(dz), _ptr(ctx.hs[i]), _ptr(dw), Mp, no8, kpad[i], n_outp, kpad[i], kpad[i], st))
             grads[2 * i] = dw[:n_out, :n_in]
-            grads[2 * i + 1] = dz[:, :n_out].sum(0, dtype=torch.float32)
+            grads[2 * i + 1] = db if db is not None else dz[:, :n_out].sum(0, dtype=torch.float32)
             if i > 0:
-                # dZ_below = (dZ W) * act'(z_below): W^T [kpad_i, n_outp] as the kernel's "W", contraction over this layer's outputs
+                # dZ_below = (dZ W) * act'(z_below): W^T [kpad_i, n_outp] as the kernel's "W", contraction over this layer's outputs; the column sums of
+                # the fp32 result (the bias gradient of the layer below) come out of the same launch where the 256 x 256 kernel serves the product
                 wt = bufs.get(("wt", i), (kpad[i], n_outp), bf, dev, fresh)
                 wt[:, :n_out] = ctx.wbs[i].t()
                 nb = kpad[i]
                 dzb = bufs.get(("dz", i), (Mp, nb), bf, dev, fresh)
-                _linear_train(dz, wt, None, ctx.gs[i - 1], dzb, None, None, Mp, nb, n_outp, nb, 0, none, False, st)
+                if Mp >= 2048 and nb >= 256 and n_outp % 128 == 0:
+                    db = torch.zeros(nb, dtype=torch.float32, device=dev)
+                    _check(lib().ss_linear_bf16_dx(_ptr(dz), _ptr(wt), _ptr(ctx.gs[i - 1]), _ptr(dzb), _ptr(db), Mp, nb, n_outp, nb, st))
+                else:
+                    db = None
+                    _linear_train(dz, wt, None, ctx.gs[i - 1], dzb, None, None, Mp, nb, n_outp, nb, 0, none, False, st)
                 dz = dzb
         ctx.hs = ctx.gs = ctx.wbs = None
         if ctx.bufs is not None:

@@ -1183,6 +1183,27 @@ def test_wgrad_bf16_reads_both_operands_untransposed(Mb, n_out, n_in, ldz, ldh):
     assert lib().ss_wgrad_bf16(ptr(dz), ptr(h), ptr(dw), Mb - 64, n_out, n_in, ldz, ldh, n_in + 3, st) == -1      # the batch: multiples of 128 rows
 
 
+def test_linear_bf16_dx_result_and_column_sums():
+    """ss_linear_bf16_dx: y = (x W^T) * mul in bf16 and the column sums of the fp32 result from the same launch (the bias gradient of the layer below), against torch;
+    ragged M; refused (not silently computed without the sums) on shapes the 256 x 256 kernel does not serve."""
+    import ctypes as C
+    from smplsim_amd._lib import lib
+    M, N, K = 5000, 768, 384
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5 + torch.linspace(-1, 1, N)[:, None] * 0.02).to(torch.bfloat16).cuda()
+    mul = (torch.rand(M, N, generator=g) + 0.5).to(torch.bfloat16).cuda()
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    y = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda"); cs = torch.zeros(N, device="cuda")
+    assert lib().ss_linear_bf16_dx(ptr(x), ptr(w), ptr(mul), ptr(y), ptr(cs), M, N, K, N, st) == 0
+    torch.cuda.synchronize()
+    ref = (x.float() @ w.float().T) * mul.float()
+    assert (y.float() - ref).abs().max().item() < 1e-2 * max(1.0, ref.abs().max().item())
+    assert (cs - ref.sum(0)).abs().max().item() < 2e-3 * max(1.0, ref.sum(0).abs().max().item())
+    assert lib().ss_linear_bf16_dx(ptr(x), ptr(w), ptr(mul), ptr(y), ptr(cs), 1000, N, K, N, st) == -1
+
+
 def test_fused_mlp_train_gradients_match_autograd():
     """learning.fused_train.FusedMLPTrain (forward + backward on ss_linear_bf16_train) against torch autograd over the same layers in
     fp32: outputs and every parameter gradient agree to bf16 round-off through the stack (relative to the gradient's own scale), on the
