@@ -113,13 +113,23 @@ class _FusedMLP(torch.autograd.Function):
         dz = bufs.get("dz_head", (Mp, nhp), bf, dev, fresh)
         dz[:M, :nh] = grad_out
         grads = [None] * (2 * nl)
-        db = grad_out.sum(0)                                       # the head's bias gradient (its dZ is the caller's tensor)
+        # the head's bias gradient (its dZ is the caller's tensor): a matrix-vector product (torch's column reduction of a [53 248, 69] tensor took 180 us)
+        ones = bufs.get("ones", (1, M), torch.float32, dev, fresh, lambda t: t.fill_(1.0))
+        db = torch.matmul(ones, grad_out.float()).reshape(-1)
+        # every weight and bias gradient of the pass in ONE zero-filled tensor (the kernels accumulate into them: 13 memsets otherwise).  Not kept between
+        # passes: the optimiser holds the views as .grad until the next backward
+        no8s = [_pad(d[0], 8) for d in dims]
+        sizes = [no8s[i] * kpad[i] for i in range(nl)] + [kpad[i] for i in range(1, nl)]
+        offs = [0]
+        for z in sizes:
+            offs.append(offs[-1] + _pad(z, 64))
+        flat = torch.zeros(offs[-1], dtype=torch.float32, device=dev)
         for i in range(nl - 1, -1, -1):
             n_out, n_in = dims[i]
             n_outp = dz.shape[1]
             # dW [n_out, kpad_i] = dZ^T h_below with both operands as they lie (ss_wgrad_bf16 contracts over their rows); db = the column sums of dZ
-            no8 = _pad(n_out, 8)
-            dw = torch.zeros(no8, kpad[i], dtype=torch.float32, device=dev)
+            no8 = no8s[i]
+            dw = flat[offs[i]:offs[i] + no8 * kpad[i]].view(no8, kpad[i])
             _check(lib().ss_wgrad_bf16(_ptr(dz), _ptr(ctx.hs[i]), _ptr(dw), Mp, no8, kpad[i], n_outp, kpad[i], kpad[i], st))
             grads[2 * i] = dw[:n_out, :n_in]
             grads[2 * i + 1] = db if db is not None else dz[:, :n_out].sum(0, dtype=torch.float32)
@@ -131,7 +141,7 @@ class _FusedMLP(torch.autograd.Function):
                 nb = kpad[i]
                 dzb = bufs.get(("dz", i), (Mp, nb), bf, dev, fresh)
                 if Mp >= 2048 and nb >= 256 and n_outp % 128 == 0:
-                    db = torch.zeros(nb, dtype=torch.float32, device=dev)
+                    db = flat[offs[nl + i - 1]:offs[nl + i - 1] + nb]
                     _check(lib().ss_linear_bf16_dx(_ptr(dz), _ptr(wt), _ptr(ctx.gs[i - 1]), _ptr(dzb), _ptr(db), Mp, nb, n_outp, nb, st))
                 else:
                     db = None
