@@ -61,8 +61,10 @@ class AgentPPO:
         self.state_dim, self.action_dim = env.obs_size, env.nu
         self.policy_net = PolicyGaussian(self.state_dim, self.action_dim, c.hidden, c.activation, c.log_std, c.fix_std).to(self.device)
         self.value_net = Value(MLP(self.state_dim, c.hidden, c.activation)).to(self.device)
-        self.optimizer_policy = torch.optim.Adam(self.policy_net.parameters(), lr=c.policy_lr, eps=1e-8, weight_decay=c.policy_weightdecay)
-        self.optimizer_value = torch.optim.Adam(self.value_net.parameters(), lr=c.value_lr, eps=1e-8, weight_decay=c.value_weightdecay)
+        # (with mfma_update: torch's single-kernel Adam — the same update rule; the default multi-tensor form is 8 launches per step, 3 ms of an 80 ms update)
+        fused = dict(fused=True) if c.mfma_update and self.device.type == "cuda" else {}
+        self.optimizer_policy = torch.optim.Adam(self.policy_net.parameters(), lr=c.policy_lr, eps=1e-8, weight_decay=c.policy_weightdecay, **fused)
+        self.optimizer_value = torch.optim.Adam(self.value_net.parameters(), lr=c.value_lr, eps=1e-8, weight_decay=c.value_weightdecay, **fused)
         self.epoch, self.num_steps = 0, 0
         self.horizon = max(1, -(-c.min_batch_size // env.num_envs))
         self._obs = None
