@@ -113,9 +113,12 @@ class _FusedMLP(torch.autograd.Function):
         dz = bufs.get("dz_head", (Mp, nhp), bf, dev, fresh)
         dz[:M, :nh] = grad_out
         grads = [None] * (2 * nl)
-        # the head's bias gradient (its dZ is the caller's tensor): a matrix-vector product (torch's column reduction of a [53 248, 69] tensor took 180 us)
-        ones = bufs.get("ones", (1, M), torch.float32, dev, fresh, lambda t: t.fill_(1.0))
-        db = torch.matmul(ones, grad_out.float()).reshape(-1)
+        # the head's bias gradient (its dZ is the caller's tensor): dZ^T 1 by the weight-gradient kernel against a column of ones (torch's column reduction of a
+        # [53 248, 69] tensor took 180 us, a matrix-vector product through rocBLAS 175)
+        ones = bufs.get("ones", (Mp, 8), bf, dev, fresh, lambda t: t[:, 0].fill_(1.0))
+        dbh = torch.zeros(_pad(nh, 8), 8, dtype=torch.float32, device=dev)
+        _check(lib().ss_wgrad_bf16(_ptr(dz), _ptr(ones), _ptr(dbh), Mp, _pad(nh, 8), 8, nhp, 8, 8, st))
+        db = dbh[:nh, 0]
         # every weight and bias gradient of the pass in ONE zero-filled tensor (the kernels accumulate into them: 13 memsets otherwise).  Not kept between
         # passes: the optimiser holds the views as .grad until the next backward
         no8s = [_pad(d[0], 8) for d in dims]
