@@ -119,3 +119,14 @@ def test_mlp_entry_points_validate_their_arguments():
     assert lib.ss_linear_bf16(one, one, None, one, 4, 4, 32, 4, 9, 0, None) == -1 and b"activation" in lib.ss_last_error()
     assert lib.ss_obs_to_bf16(one, 4, 289, 289, None, None, None, -5.0, 5.0, 5.0, one, 300, None) == -1      # kpad not a multiple of 32
     assert lib.ss_obs_to_bf16(one, 4, 289, 100, None, None, None, -5.0, 5.0, 5.0, one, 320, None) == -1      # row stride < dim
+    # the update's entry points (round 6)
+    assert lib.ss_linear_bf16_train(one, one, None, None, None, None, None, 64, 64, 64, 64, 0, 0, 0, None) == -1 and b"null" in lib.ss_last_error()
+    assert lib.ss_linear_bf16_train(one, one, None, None, one, None, None, 64, 64, 96, 64, 0, 0, 0, None) == -1 and b"multiple of 64" in lib.ss_last_error()
+    assert lib.ss_linear_bf16_train(one, one, None, one, one, None, None, 64, 64, 64, 64, 0, 0, 1, None) == -1 and b"accumulating" in lib.ss_last_error()
+    assert lib.ss_linear_bf16_dx(one, one, None, one, one, 4096, 512, 256, 512, None) == -1 and b"null" in lib.ss_last_error()
+    assert lib.ss_linear_bf16_dx(one, one, one, one, one, 1000, 512, 256, 512, None) == -1 and b"256 x 256 kernel only" in lib.ss_last_error()   # too few rows
+    assert lib.ss_linear_bf16_dx(one, one, one, one, one, 4096, 512, 192, 512, None) == -1                                                      # K not a multiple of 128
+    assert lib.ss_wgrad_bf16(one, None, one, 1024, 64, 64, 64, 64, 64, None) == -1 and b"null" in lib.ss_last_error()
+    assert lib.ss_wgrad_bf16(one, one, one, 1000, 64, 64, 64, 64, 64, None) == -1 and b"multiple of 128" in lib.ss_last_error()
+    assert lib.ss_wgrad_bf16(one, one, one, 1024, 60, 64, 64, 64, 64, None) == -1                                # n_out not a multiple of 8
+    assert lib.ss_wgrad_bf16(one, one, one, 1024, 64, 64, 32, 64, 64, None) == -1                                # ldz < n_out
