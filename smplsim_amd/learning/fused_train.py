@@ -76,20 +76,21 @@ class _FusedMLP(torch.autograd.Function):
         h = bufs.get("x", (Mp, kpad[0]), bf, dev, fresh)           # (pad rows and columns stay zero: only [:M, :D] is ever written)
         h[:M, :D] = x
         hs, gs, wbs = [h], [], []
+        # the layers' weights in bf16, all by one multi-tensor copy (they change with every optimiser step; 7 launches a pass otherwise)
+        wb_all = [bufs.get(("w", i), (ws[i].shape[0], kpad[i]), bf, dev, fresh) for i in range(nl)]
+        torch._foreach_copy_([wb_all[i][:, :ws[i].shape[1]] for i in range(nl)], [w_.detach() for w_ in ws])
         for i in range(nl - 1):
             w = ws[i]
             N = w.shape[0]
             assert N % 64 == 0 and kpad[i + 1] == N, "hidden widths must be multiples of 64"
-            wb = bufs.get(("w", i), (N, kpad[i]), bf, dev, fresh)
-            wb[:, :w.shape[1]] = w
+            wb = wb_all[i]
             y = bufs.get(("h", i), (Mp, N), bf, dev, fresh)
             g = bufs.get(("g", i), (Mp, N), bf, dev, fresh) if track else None   # no backward pass will follow (GAE's value pass): the result alone
             _linear_train(h, wb, bs[i].detach().float().contiguous(), None, y, None, g, Mp, N, kpad[i], N, 0, act, False, st)
             wbs.append(wb); hs.append(y); gs.append(g)
             h = y
         w = ws[-1]
-        wb = bufs.get(("w", nl - 1), (w.shape[0], kpad[-1]), bf, dev, fresh)
-        wb[:, :w.shape[1]] = w
+        wb = wb_all[-1]
         wbs.append(wb)
         out = torch.empty(Mp, w.shape[0], dtype=torch.float32, device=dev)
         _check(lib().ss_linear_bf16(_ptr(h), _ptr(wb), _ptr(bs[-1].detach().float().contiguous()), _ptr(out), Mp, w.shape[0], kpad[-1], w.shape[0],
