@@ -128,6 +128,9 @@ class _FusedMLP(torch.autograd.Function):
         for z in sizes:
             offs.append(offs[-1] + _pad(z, 64))
         flat = torch.zeros(offs[-1], dtype=torch.float32, device=dev)
+        # W^T of every layer but the first (the "W" operand of the dX products), all by one multi-tensor copy
+        wts = {i: bufs.get(("wt", i), (kpad[i], nhp if i == nl - 1 else dims[i][0]), bf, dev, fresh) for i in range(1, nl)}
+        torch._foreach_copy_([wts[i][:, :dims[i][0]] for i in range(1, nl)], [ctx.wbs[i].t() for i in range(1, nl)])
         for i in range(nl - 1, -1, -1):
             n_out, n_in = dims[i]
             n_outp = dz.shape[1]
@@ -140,8 +143,7 @@ class _FusedMLP(torch.autograd.Function):
             if i > 0:
                 # dZ_below = (dZ W) * act'(z_below): W^T [kpad_i, n_outp] as the kernel's "W", contraction over this layer's outputs; the column sums of
                 # the fp32 result (the bias gradient of the layer below) come out of the same launch where the 256 x 256 kernel serves the product
-                wt = bufs.get(("wt", i), (kpad[i], n_outp), bf, dev, fresh)
-                wt[:, :n_out] = ctx.wbs[i].t()
+                wt = wts[i]
                 nb = kpad[i]
                 dzb = bufs.get(("dz", i), (Mp, nb), bf, dev, fresh)
                 if Mp >= 2048 and nb >= 256 and n_outp % 128 == 0:
